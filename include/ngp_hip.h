@@ -1,0 +1,301 @@
+/*
+ * ngp_hip.h -- C ABI of libngp_hip.so, the MI355X (gfx950) native Instant-NGP hot path.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one
+ * function of the reference's two native dependencies for this path:
+ *   - the `vren` pybind module        (/root/reference/models/csrc/binding.cpp:234-250), and
+ *   - the `tinycudann` torch modules  (call sites /root/reference/models/networks.py:36-92),
+ * plus apex FusedAdam (train.py:131).  The reference ABI is torch::Tensor based; this one is
+ * plain C: raw DEVICE pointers, explicit sizes, caller-allocated outputs, a hipStream_t passed
+ * as void*.  No torch types.  Return value: 0 on success, a positive hipError_t if a launch
+ * failed, a negative NGP_E* code for bad arguments.  Nothing here allocates or synchronises
+ * unless the comment says so; all work is enqueued on `stream`.
+ *
+ * Tensors are contiguous, row-major.  f32 = float, f16 = IEEE half (uint16_t in this header),
+ * i64 = int64_t.  "R" = rays, "S" = packed samples.
+ */
+#ifndef NGP_HIP_H
+#define NGP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ngp_stream_t;   /* hipStream_t */
+typedef uint16_t ngp_half;    /* IEEE binary16 bits */
+
+#define NGP_EINVAL   (-1)  /* bad argument (null pointer, size out of range) */
+#define NGP_EUNSUP   (-2)  /* configuration not supported by the native kernels */
+
+#define NGP_MAX_LEVELS 16
+
+/* ABI version; bumped when a signature changes. */
+int ngp_abi_version(void);
+/* Name of the GPU arch the library was built for ("gfx950"). */
+const char* ngp_build_arch(void);
+
+/* ------------------------------------------------------------------------------------------
+ * vren: intersection            (reference: models/csrc/intersection.cu)
+ * ------------------------------------------------------------------------------------------ */
+
+/* vren.ray_aabb_intersect (binding.cpp:4-16, intersection.cu:5-100).
+ * rays_o,rays_d (R,3) f32; centers,half_sizes (V,3) f32.
+ * out: hit_cnt (R) i32, hits_t (R,max_hits,2) f32, hits_voxel_idx (R,max_hits) i64.
+ * Rows are sorted ascending by t1 with unfilled (-1) slots first, as torch::sort leaves them
+ * (intersection.cu:95-97). */
+int ngp_ray_aabb_intersect(const float* rays_o, const float* rays_d,
+                           const float* centers, const float* half_sizes,
+                           int n_rays, int n_voxels, int max_hits,
+                           int32_t* hit_cnt, float* hits_t, int64_t* hits_voxel_idx,
+                           ngp_stream_t stream);
+
+/* vren.ray_sphere_intersect (binding.cpp:19-31, intersection.cu:103-197). radii (V) f32. */
+int ngp_ray_sphere_intersect(const float* rays_o, const float* rays_d,
+                             const float* centers, const float* radii,
+                             int n_rays, int n_spheres, int max_hits,
+                             int32_t* hit_cnt, float* hits_t, int64_t* hits_sphere_idx,
+                             ngp_stream_t stream);
+
+/* Hot-path specialisation of render()'s prologue (rendering.py:27-29): one box, max_hits=1,
+ * and the near-plane clamp hits_t[0] in [0,near) -> near fused in.  hits_t (R,2). */
+int ngp_ray_aabb_near(const float* rays_o, const float* rays_d,
+                      const float* center, const float* half_size, float near_distance,
+                      int n_rays, float* hits_t, ngp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * vren: occupancy grid helpers  (reference: models/csrc/raymarching.cu:35-161)
+ * ------------------------------------------------------------------------------------------ */
+
+/* vren.morton3D (binding.cpp:46-50): coords (N,3) i32 -> indices (N) i32. */
+int ngp_morton3D(const int32_t* coords, int n, int32_t* indices, ngp_stream_t stream);
+/* vren.morton3D_invert (binding.cpp:53-57): indices (N) i32 -> coords (N,3) i32. */
+int ngp_morton3D_invert(const int32_t* indices, int n, int32_t* coords, ngp_stream_t stream);
+/* vren.packbits (binding.cpp:34-43): bit i of byte n = grid[8n+i] > threshold.
+ * grid_is_half: 0 -> f32 grid, 1 -> f16 grid.  n_bytes = C*G^3/8. */
+int ngp_packbits(const void* density_grid, int grid_is_half, int n_bytes,
+                 float density_threshold, uint8_t* density_bitfield, ngp_stream_t stream);
+
+/* Fused occupancy-grid maintenance (networks.py:248-268), device side only:
+ *   grid = (grid<0) ? grid : max(grid*decay, tmp)       [decay scalar, or per cell if decay_grid]
+ * and the masked sum/count of grid>0 into stats[0] (f32 sum) / stats[1] (f32 count).
+ * stats must be zeroed by the caller. */
+int ngp_density_grid_update(float* density_grid, const float* density_grid_tmp,
+                            const float* decay_grid /* may be NULL */, float decay,
+                            int n_cells, float* stats, ngp_stream_t stream);
+/* packbits with the threshold min(stats[0]/stats[1], density_threshold) read on device
+ * (networks.py:266-268 without the .item() host sync). */
+int ngp_packbits_auto(const float* density_grid, int n_bytes, const float* stats,
+                      float density_threshold, uint8_t* density_bitfield, ngp_stream_t stream);
+/* Jittered cell-centre sample points (networks.py:251-255): coords (N,3) i32, noise (N,3) f32
+ * in [0,1) -> xyzs_w (N,3) f32 for cascade with half-extent s. */
+int ngp_cells_to_xyz(const int32_t* coords, const float* noise, int n, int grid_size, float s,
+                     float* xyzs_w, ngp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * vren: ray marching            (reference: models/csrc/raymarching.cu:163-454)
+ * ------------------------------------------------------------------------------------------ */
+
+/* vren.raymarching_train (binding.cpp:60-81, raymarching.cu:166-332) as a two-call pattern
+ * that packs samples in RAY ORDER (deterministic; the reference order comes from atomics):
+ *
+ *  1. ngp_raymarching_train_count: one march per ray.  Writes rays_a (R,3) i64 =
+ *     [ray_idx, start_idx, N_samples] with start_idx the exclusive prefix sum of N_samples in
+ *     ray order, counter[0] = S, counter[1] = R (i32), and each ray's sample t values into
+ *     t_scratch[r*max_samples + k] (caller provides R*max_samples floats; not zero-filled).
+ *  2. the caller reads counter[0] (the only host sync) and allocates S-sized outputs;
+ *  3. ngp_raymarching_train_write expands the scratch into xyzs,dirs (S,3), deltas,ts (S).
+ *
+ * hits_t (R,2) f32, noise (R) f32 in [0,1), density_bitfield (cascades*G^3/8) u8. */
+int ngp_raymarching_train_count(const float* rays_o, const float* rays_d, const float* hits_t,
+                                const uint8_t* density_bitfield, int cascades, float scale,
+                                float exp_step_factor, const float* noise, int grid_size,
+                                int max_samples, int n_rays,
+                                int64_t* rays_a, int32_t* counter, float* t_scratch,
+                                ngp_stream_t stream);
+int ngp_raymarching_train_write(const float* rays_o, const float* rays_d, const int64_t* rays_a,
+                                const float* t_scratch, float scale, float exp_step_factor,
+                                int grid_size, int max_samples, int n_rays,
+                                float* xyzs, float* dirs, float* deltas, float* ts,
+                                ngp_stream_t stream);
+
+/* vren.raymarching_test (binding.cpp:84-106, raymarching.cu:335-454).  hits_t (R_total,2) is
+ * advanced in place; alive_indices (N_alive) i64; outputs are dense (N_alive,N_samples,.) and
+ * fully written (unused slots zero), N_eff_samples (N_alive) i32.  Keeps the reference's
+ * calc_dt(..., cascades) quirk (raymarching.cu:370,399). */
+int ngp_raymarching_test(const float* rays_o, const float* rays_d, float* hits_t,
+                         const int64_t* alive_indices, const uint8_t* density_bitfield,
+                         int cascades, float scale, float exp_step_factor, int grid_size,
+                         int max_samples, int n_samples, int n_alive,
+                         float* xyzs, float* dirs, float* deltas, float* ts,
+                         int32_t* n_eff_samples, ngp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * vren: volume rendering        (reference: models/csrc/volumerendering.cu)
+ * ------------------------------------------------------------------------------------------ */
+
+/* vren.composite_train_fw (binding.cpp:109-126, volumerendering.cu:6-84).
+ * sigmas,deltas,ts (S) f32; rgbs (S,3) f32; rays_a (R,3) i64.
+ * out (all fully written): total_samples (R) i64, opacity,depth (R), rgb (R,3), ws (S). */
+int ngp_composite_train_fw(const float* sigmas, const float* rgbs, const float* deltas,
+                           const float* ts, const int64_t* rays_a, float T_threshold,
+                           int n_rays, int n_samples,
+                           int64_t* total_samples, float* opacity, float* depth, float* rgb,
+                           float* ws, ngp_stream_t stream);
+
+/* vren.composite_train_bw (binding.cpp:129-163, volumerendering.cu:87-202).
+ * dL_dws may be NULL (treated as zeros).  out: dL_dsigmas (S), dL_drgbs (S,3), fully written. */
+int ngp_composite_train_bw(const float* dL_dopacity, const float* dL_ddepth, const float* dL_drgb,
+                           const float* dL_dws, const float* sigmas, const float* rgbs,
+                           const float* ws, const float* deltas, const float* ts,
+                           const int64_t* rays_a, const float* opacity, const float* depth,
+                           const float* rgb, float T_threshold, int n_rays, int n_samples,
+                           float* dL_dsigmas, float* dL_drgbs, ngp_stream_t stream);
+
+/* vren.composite_test_fw (binding.cpp:166-194, volumerendering.cu:205-285).
+ * sigmas,deltas,ts (N_alive,N_samples); rgbs (N_alive,N_samples,3); alive_indices, opacity,
+ * depth, rgb are updated in place. */
+int ngp_composite_test_fw(const float* sigmas, const float* rgbs, const float* deltas,
+                          const float* ts, int64_t* alive_indices, float T_threshold,
+                          const int32_t* n_eff_samples, int n_alive, int n_samples,
+                          float* opacity, float* depth, float* rgb, ngp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * vren: distortion loss         (reference: models/csrc/losses.cu)
+ * ------------------------------------------------------------------------------------------ */
+
+/* vren.distortion_loss_fw (binding.cpp:197-209, losses.cu:9-109).
+ * out: loss (R) [indexed by ray_idx], ws_inclusive_scan, wts_inclusive_scan (S). */
+int ngp_distortion_loss_fw(const float* ws, const float* deltas, const float* ts,
+                           const int64_t* rays_a, int n_rays, int n_samples,
+                           float* loss, float* ws_inclusive_scan, float* wts_inclusive_scan,
+                           ngp_stream_t stream);
+/* vren.distortion_loss_bw (binding.cpp:212-231, losses.cu:112-175). out: dL_dws (S). */
+int ngp_distortion_loss_bw(const float* dL_dloss, const float* ws_inclusive_scan,
+                           const float* wts_inclusive_scan, const float* ws, const float* deltas,
+                           const float* ts, const int64_t* rays_a, int n_rays, int n_samples,
+                           float* dL_dws, ngp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * tinycudann: multiresolution hash grid   (call site networks.py:36-48; algorithm:
+ * NVlabs/tiny-cuda-nn include/tiny-cuda-nn/encodings/grid.h, version unpinned by the reference)
+ * ------------------------------------------------------------------------------------------ */
+
+typedef struct ngp_grid_meta {
+    int32_t  n_levels;                       /* L (<= NGP_MAX_LEVELS) */
+    int32_t  n_features;                     /* F, must be 2 */
+    uint32_t offset[NGP_MAX_LEVELS + 1];     /* entry offset of each level; offset[L] = total */
+    uint32_t resolution[NGP_MAX_LEVELS];     /* ceil(scale)+1 */
+    float    scale[NGP_MAX_LEVELS];          /* exp2(l*log2(b))*N_min - 1 */
+} ngp_grid_meta;
+
+/* Fill meta exactly as tiny-cuda-nn does (grid.h GridEncodingTemplated ctor): host side. */
+int ngp_grid_meta_init(ngp_grid_meta* meta, int n_levels, int n_features, int log2_hashmap_size,
+                       int base_resolution, float per_level_scale);
+
+/* Encode forward.  x (S,3) f32 world positions; x01 = (x - xyz_min)/(xyz_max - xyz_min) is
+ * applied in-kernel (networks.py:103; pass min 0 / max 1 for already normalised input).
+ * table: (total_entries, 2) f16.  feats: LEVEL-MAJOR [L][S] half2. */
+int ngp_hashgrid_fwd(const float* x, const float* xyz_min, const float* xyz_max,
+                     const ngp_half* table, const ngp_grid_meta* meta, int n_samples,
+                     ngp_half* feats, ngp_stream_t stream);
+/* Encode backward w.r.t. the table: scatter-add of w*dL/dfeat into grad_table (total,2) f16
+ * (packed f16 atomics, as tiny-cuda-nn) or f32 when grad_is_f32.  Accumulates (caller zeroes). */
+int ngp_hashgrid_bwd(const float* x, const float* xyz_min, const float* xyz_max,
+                     const ngp_half* dfeats /* [L][S] half2 */, const ngp_grid_meta* meta,
+                     int n_samples, void* grad_table, int grad_is_f32, ngp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * tinycudann: FullyFusedMLP + SphericalHarmonics  (call sites networks.py:49-77)
+ * ------------------------------------------------------------------------------------------ */
+
+/* Weight blob layout (f16, tiny-cuda-nn order: layers in order, each (out,in) row-major,
+ * output layer padded to 16 rows):
+ *   density net: W0 (64,32) | W1 (16,64)                       = 3072
+ *   rgb net:     W0 (64,32) | W1 (64,64) | W2 (16,64)          = 7168
+ */
+#define NGP_DENSITY_NET_PARAMS 3072
+#define NGP_RGB_NET_PARAMS     7168
+
+/* Fused field forward (NGP.forward, networks.py:132-153, rgb_act == "Sigmoid"):
+ *   h = density_net(feats) [f16], sigma = exp(h[0]), sh = SH4(d/|d|), rgb = sigmoid(rgb_net([sh,h]))
+ * feats [L=16][S] half2; dirs (S,3) f32 un-normalised (may be NULL with rgbs NULL: density only).
+ * out: sigmas (S) f32; rgbs (S,3) f32 (values rounded through f16 as tiny-cuda-nn emits them);
+ *      h_out (S,16) f16 optional (NULL to skip). */
+int ngp_field_fwd(const ngp_half* feats, const float* dirs,
+                  const ngp_half* density_w, const ngp_half* rgb_w, int n_samples,
+                  float* sigmas, float* rgbs, ngp_half* h_out, ngp_stream_t stream);
+
+/* Fused field backward.  Recomputes the forward, then dgrad through the rgb net, TruncExp
+ * (custom_functions.py:168-173) and the density net, writing dfeats [L][S] half2 (scaled by
+ * loss_scale) and per-workgroup partial weight gradients (scaled by loss_scale):
+ *   wgrad_partial = [ n_partials x 3072 density | n_partials x 7168 rgb ] f32,
+ * n_partials = ngp_field_bwd_partials(n_samples); sum them with ngp_reduce_partials.
+ * h (S,16) f16 is the forward's h_out; dh_scratch (S,16) f16 is workspace.
+ * dL_drgbs NULL -> density-only backward (dirs, h, rgb_w, dh_scratch unused). */
+int ngp_field_bwd_partials(int n_samples);
+int ngp_field_bwd(const ngp_half* feats, const float* dirs, const ngp_half* h,
+                  const ngp_half* density_w, const ngp_half* rgb_w,
+                  const float* dL_dsigmas, const float* dL_drgbs, float loss_scale,
+                  int n_samples, ngp_half* dh_scratch, ngp_half* dfeats, float* wgrad_partial,
+                  ngp_stream_t stream);
+
+/* Generic tcnn.Network / the MLP half of NetworkWithInputEncoding:
+ * n_in in {16,32,64} (multiple of 16), 64 neurons, n_hidden in {1,2}, n_out <= 16,
+ * out_act 0 None / 1 Sigmoid.  in (S,n_in) f16 row-major, out (S,n_out) f16. */
+int ngp_mlp_fwd(const ngp_half* in, const ngp_half* weights, int n_in, int n_hidden, int n_out,
+                int out_act, int n_samples, ngp_half* out, ngp_stream_t stream);
+int ngp_mlp_bwd_partials(int n_samples);
+int ngp_mlp_bwd(const ngp_half* in, const ngp_half* weights, const ngp_half* dL_dout,
+                int n_in, int n_hidden, int n_out, int out_act, int n_samples,
+                ngp_half* dL_din /* may be NULL */, float* wgrad_partial, ngp_stream_t stream);
+
+/* tcnn.Encoding SphericalHarmonics degree 4 (networks.py:58-65): in (S,3) f32 in [0,1]
+ * (the module maps it back to [-1,1]), out (S,16) f16. */
+int ngp_sh4_fwd(const float* dirs01, int n_samples, ngp_half* out, ngp_stream_t stream);
+
+/* Layout converters between the level-major feature layout and tcnn's (S,32) row-major one. */
+int ngp_feats_to_rowmajor(const ngp_half* feats, int n_levels, int n_samples, ngp_half* out,
+                          ngp_stream_t stream);
+int ngp_feats_from_rowmajor(const ngp_half* in, int n_levels, int n_samples, ngp_half* feats,
+                            ngp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * optimizer: apex FusedAdam equivalent (train.py:131, eps 1e-15) fused with AMP plumbing
+ * ------------------------------------------------------------------------------------------ */
+
+/* One dense pass over n params:  g = grad/grad_scale (grad f16 or f32), Adam update of the f32
+ * master `param` with moments m,v, write the f16 working copy `param_h` (may be NULL), and zero
+ * the gradient.  step is 1-based.  If found_inf (device i32, may be NULL) is non-zero the update
+ * is skipped but gradients are still zeroed (GradScaler semantics). */
+int ngp_adam_step(float* param, ngp_half* param_h, void* grad, int grad_is_f32,
+                  float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int step, float grad_scale, const int32_t* found_inf,
+                  ngp_stream_t stream);
+/* Sum n_partials rows of (n) f32 into out (n) f32 (out = sum, not accumulated). */
+int ngp_reduce_partials(const float* partials, int n_partials, int n, float* out,
+                        ngp_stream_t stream);
+/* f32 -> f16 cast (tiny-cuda-nn casts the master params every forward). */
+int ngp_cast_f32_to_f16(const float* in, int64_t n, ngp_half* out, ngp_stream_t stream);
+int ngp_cast_f16_to_f32(const ngp_half* in, int64_t n, float scale, float* out,
+                        ngp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * loss seeds (losses.py:47-60 + the mean reduction of train.py:173)
+ * ------------------------------------------------------------------------------------------ */
+
+/* With rgb_f = rgb + bg*(1-opacity) (bg (3) f32 or NULL = black; rendering.py:153-161):
+ *   loss[0] += mean((rgb_f-gt)^2) + mean(lambda_o * -(o+1e-10) log(o+1e-10))
+ * and the backward seeds dL_drgb (R,3), dL_dopacity (R) w.r.t. the COMPOSITED rgb/opacity, both
+ * multiplied by grad_scale.  loss (1) f32 accumulates (caller zeroes); sq_err (1) f32 (may be
+ * NULL) accumulates sum((rgb_f-gt)^2) for PSNR. */
+int ngp_nerf_loss(const float* rgb, const float* opacity, const float* gt_rgb, const float* bg,
+                  float lambda_opacity, float grad_scale, int n_rays,
+                  float* loss, float* sq_err, float* dL_drgb, float* dL_dopacity,
+                  ngp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NGP_HIP_H */

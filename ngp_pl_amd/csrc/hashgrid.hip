@@ -1,0 +1,271 @@
+// Multiresolution hash-grid encoding, forward and backward, for gfx950.
+//
+// Algorithm: tiny-cuda-nn's GridEncoding (NVlabs/tiny-cuda-nn, include/tiny-cuda-nn/encodings/
+// grid.h: grid_scale / grid_resolution / pos_fract / grid_index / coherent prime hash), as
+// configured by the reference at /root/reference/models/networks.py:36-48 (L=16, F=2, T=2^19,
+// N_min=16, linear interpolation).  tiny-cuda-nn is NOT vendored by the reference and its
+// version is unpinned; the restatement here and in oracle/tcnn_oracle.py is from its published
+// source.
+//
+// MI355X mapping (DESIGN.md "hash grid"):
+//   * work item = (sample, level); one thread gathers the 8 corners of one level (8 x 4 B
+//     half2 loads in flight per lane), so a workgroup only ever touches ONE level's table;
+//   * workgroups are mapped level-major and XCD-aware: workgroup b runs (observed, speed
+//     only) on XCD b%8, and each XCD is handed two whole levels {x, 15-x}, so the 2 MiB
+//     hashed table it is gathering from stays resident in that XCD's private 4 MiB L2
+//     instead of all 22.8 MB competing for every L2;
+//   * features are stored LEVEL-MAJOR [L][S] half2: every store/load of the stream is a
+//     contiguous 256 B per wave (the row-major (S,32) layout would be 4-byte writes at a
+//     64-byte stride);
+//   * the per-sample position/feature streams use non-temporal accesses so they do not evict
+//     the table from L2.
+#include "ngp_common.h"
+#include <hip/hip_fp16.h>
+
+namespace {
+
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+struct GridMeta {
+    int32_t n_levels;
+    uint32_t offset[NGP_MAX_LEVELS + 1];
+    uint32_t resolution[NGP_MAX_LEVELS];
+    float scale[NGP_MAX_LEVELS];
+};
+
+// workgroup -> (level, chunk).  n_chunks = ceil(S/256).
+__device__ __forceinline__ bool map_block(int n_levels, int n_chunks, int& level, int& chunk) {
+    const int b = blockIdx.x;
+    const int xcd = b & 7, q = b >> 3;
+    const int slot = q / n_chunks;
+    chunk = q - slot * n_chunks;
+    if (n_levels == 16) level = (slot == 0) ? xcd : 15 - xcd;   // pair a small dense level with a hashed one
+    else level = xcd + 8 * slot;
+    return level < n_levels;
+}
+
+struct Corner {
+    uint32_t base;       // index of corner (0,0,0) ingredients
+    uint32_t px, py, pz; // integer cell coordinates
+    float fx, fy, fz;    // fractional position
+};
+
+__device__ __forceinline__ void cell_of(const float* __restrict__ x, const float* __restrict__ xyz_min,
+                                        const float* __restrict__ xyz_max, int i, float scale,
+                                        uint32_t& px, uint32_t& py, uint32_t& pz, float& fx, float& fy, float& fz) {
+    const float mnx = xyz_min[0], mny = xyz_min[1], mnz = xyz_min[2];
+    const float x0 = (__builtin_nontemporal_load(x + 3 * (size_t)i) - mnx) / (xyz_max[0] - mnx);
+    const float x1 = (__builtin_nontemporal_load(x + 3 * (size_t)i + 1) - mny) / (xyz_max[1] - mny);
+    const float x2 = (__builtin_nontemporal_load(x + 3 * (size_t)i + 2) - mnz) / (xyz_max[2] - mnz);
+    // pos_fract: pos = x*scale + 0.5; cell = floor(pos); frac = pos - cell
+    const float p0 = fmaf(x0, scale, 0.5f), p1 = fmaf(x1, scale, 0.5f), p2 = fmaf(x2, scale, 0.5f);
+    const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
+    px = (uint32_t)(int)f0; py = (uint32_t)(int)f1; pz = (uint32_t)(int)f2;
+    fx = p0 - f0; fy = p1 - f1; fz = p2 - f2;
+}
+
+template <bool HASHED>
+__device__ __forceinline__ uint32_t grid_index(uint32_t x, uint32_t y, uint32_t z, uint32_t res, uint32_t size) {
+    uint32_t idx;
+    if (HASHED) idx = x ^ (y * 2654435761u) ^ (z * 805459861u);
+    else idx = x + y * res + z * res * res;
+    return idx % size;
+}
+
+// tiny-cuda-nn grid_index(): the dense stride walk uses the hash iff res^3 overflows the level
+__device__ __forceinline__ bool level_is_hashed(uint32_t res, uint32_t size) {
+    uint32_t stride = 1;
+    for (int d = 0; d < 3 && stride <= size; ++d) stride *= res;
+    return size < stride;
+}
+
+template <bool HASHED>
+__device__ __forceinline__ void encode_one(const half2_t* __restrict__ tab, uint32_t res, uint32_t size,
+                                           uint32_t px, uint32_t py, uint32_t pz, float fx, float fy, float fz,
+                                           float& o0, float& o1) {
+    half2_t v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const uint32_t idx = grid_index<HASHED>(px + (c & 1), py + ((c >> 1) & 1), pz + (c >> 2), res, size);
+        v[c] = tab[idx];
+    }
+    o0 = 0.f; o1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float w = ((c & 1) ? fx : 1.f - fx) * (((c >> 1) & 1) ? fy : 1.f - fy) * ((c >> 2) ? fz : 1.f - fz);
+        o0 = fmaf(w, (float)v[c][0], o0);
+        o1 = fmaf(w, (float)v[c][1], o1);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+hashgrid_fwd_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const float* __restrict__ xyz_max,
+                    const half2_t* __restrict__ table, GridMeta meta, int n_samples, int n_chunks,
+                    half2_t* __restrict__ feats) {
+    int level, chunk;
+    if (!map_block(meta.n_levels, n_chunks, level, chunk)) return;
+    const int i = chunk * 256 + threadIdx.x;
+    if (i >= n_samples) return;
+    const uint32_t res = meta.resolution[level];
+    const uint32_t size = meta.offset[level + 1] - meta.offset[level];
+    const half2_t* __restrict__ tab = table + meta.offset[level];
+    uint32_t px, py, pz; float fx, fy, fz;
+    cell_of(x, xyz_min, xyz_max, i, meta.scale[level], px, py, pz, fx, fy, fz);
+    float o0, o1;
+    if (level_is_hashed(res, size)) encode_one<true>(tab, res, size, px, py, pz, fx, fy, fz, o0, o1);
+    else encode_one<false>(tab, res, size, px, py, pz, fx, fy, fz, o0, o1);
+    half2_t out; out[0] = (_Float16)o0; out[1] = (_Float16)o1;
+    __builtin_nontemporal_store(out, feats + (size_t)level * n_samples + i);
+}
+
+template <bool HASHED, bool F32>
+__device__ __forceinline__ void scatter_one(void* __restrict__ grad_level, uint32_t res, uint32_t size,
+                                            uint32_t px, uint32_t py, uint32_t pz, float fx, float fy, float fz,
+                                            float g0, float g1) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const uint32_t idx = grid_index<HASHED>(px + (c & 1), py + ((c >> 1) & 1), pz + (c >> 2), res, size);
+        const float w = ((c & 1) ? fx : 1.f - fx) * (((c >> 1) & 1) ? fy : 1.f - fy) * ((c >> 2) ? fz : 1.f - fz);
+        if (F32) {
+            float* g = reinterpret_cast<float*>(grad_level) + 2 * (size_t)idx;
+            unsafeAtomicAdd(g, w * g0);
+            unsafeAtomicAdd(g + 1, w * g1);
+        } else {
+            __half2* g = reinterpret_cast<__half2*>(grad_level) + idx;
+            unsafeAtomicAdd(g, __floats2half2_rn(w * g0, w * g1));   // global_atomic_pk_add_f16
+        }
+    }
+}
+
+template <bool F32>
+__global__ void __launch_bounds__(256)
+hashgrid_bwd_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const float* __restrict__ xyz_max,
+                    const half2_t* __restrict__ dfeats, GridMeta meta, int n_samples, int n_chunks,
+                    void* __restrict__ grad_table) {
+    int level, chunk;
+    if (!map_block(meta.n_levels, n_chunks, level, chunk)) return;
+    const int i = chunk * 256 + threadIdx.x;
+    if (i >= n_samples) return;
+    const half2_t g = __builtin_nontemporal_load(dfeats + (size_t)level * n_samples + i);
+    const float g0 = (float)g[0], g1 = (float)g[1];
+    if (g0 == 0.f && g1 == 0.f) return;   // samples past a ray's early stop carry exact zeros
+    const uint32_t res = meta.resolution[level];
+    const uint32_t size = meta.offset[level + 1] - meta.offset[level];
+    void* grad_level = F32 ? (void*)(reinterpret_cast<float*>(grad_table) + 2 * (size_t)meta.offset[level])
+                           : (void*)(reinterpret_cast<__half2*>(grad_table) + meta.offset[level]);
+    uint32_t px, py, pz; float fx, fy, fz;
+    cell_of(x, xyz_min, xyz_max, i, meta.scale[level], px, py, pz, fx, fy, fz);
+    if (level_is_hashed(res, size)) scatter_one<true, F32>(grad_level, res, size, px, py, pz, fx, fy, fz, g0, g1);
+    else scatter_one<false, F32>(grad_level, res, size, px, py, pz, fx, fy, fz, g0, g1);
+}
+
+__global__ void __launch_bounds__(256)
+feats_to_rowmajor_kernel(const half2_t* __restrict__ feats, int n_levels, int n_samples, half2_t* __restrict__ out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over (sample, level), level fastest
+    if (t >= (long long)n_samples * n_levels) return;
+    const int l = (int)(t % n_levels); const long long s = t / n_levels;
+    out[t] = feats[(size_t)l * n_samples + s];
+}
+
+__global__ void __launch_bounds__(256)
+feats_from_rowmajor_kernel(const half2_t* __restrict__ in, int n_levels, int n_samples, half2_t* __restrict__ feats) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over (level, sample), sample fastest
+    if (t >= (long long)n_samples * n_levels) return;
+    const int l = (int)(t / n_samples); const long long s = t - (long long)l * n_samples;
+    feats[t] = in[(size_t)s * n_levels + l];
+}
+
+GridMeta to_dev_meta(const ngp_grid_meta* m) {
+    GridMeta d;
+    d.n_levels = m->n_levels;
+    for (int l = 0; l < NGP_MAX_LEVELS; ++l) {
+        d.offset[l] = m->offset[l]; d.resolution[l] = m->resolution[l]; d.scale[l] = m->scale[l];
+    }
+    d.offset[NGP_MAX_LEVELS] = m->offset[NGP_MAX_LEVELS];
+    return d;
+}
+
+int n_blocks_for(int n_levels, int n_chunks) {
+    const int slots = (n_levels == 16) ? 2 : (n_levels + 7) / 8;
+    return 8 * slots * n_chunks;
+}
+
+}  // namespace
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+// tiny-cuda-nn grid.h, GridEncodingTemplated constructor: per level
+//   scale = exp2(l * log2(per_level_scale)) * base_resolution - 1
+//   res   = ceil(scale) + 1
+//   n     = min(next_multiple(res^3, 8), 2^log2_hashmap_size)      (hash grid type)
+int ngp_grid_meta_init(ngp_grid_meta* meta, int n_levels, int n_features, int log2_hashmap_size,
+                       int base_resolution, float per_level_scale) {
+    if (!meta || n_levels < 1 || n_levels > NGP_MAX_LEVELS || n_features != 2 ||
+        log2_hashmap_size < 1 || log2_hashmap_size > 28 || base_resolution < 1) return NGP_EINVAL;
+    meta->n_levels = n_levels; meta->n_features = n_features;
+    const float log2_pls = log2f(per_level_scale);
+    uint32_t off = 0;
+    for (int l = 0; l < NGP_MAX_LEVELS; ++l) { meta->offset[l] = 0; meta->resolution[l] = 0; meta->scale[l] = 0.f; }
+    for (int l = 0; l < n_levels; ++l) {
+        const float scale = exp2f(l * log2_pls) * base_resolution - 1.0f;
+        const uint32_t res = (uint32_t)ceilf(scale) + 1;
+        const uint32_t max_params = 0xFFFFFFFFu / 2;
+        uint32_t n = (powf((float)res, 3.f) > (float)max_params) ? max_params : res * res * res;
+        n = (n + 7u) / 8u * 8u;
+        const uint32_t cap = 1u << log2_hashmap_size;
+        if (n > cap) n = cap;
+        meta->offset[l] = off; meta->resolution[l] = res; meta->scale[l] = scale;
+        off += n;
+    }
+    for (int l = n_levels; l <= NGP_MAX_LEVELS; ++l) meta->offset[l] = off;
+    return 0;
+}
+
+int ngp_hashgrid_fwd(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* table,
+                     const ngp_grid_meta* meta, int n_samples, ngp_half* feats, ngp_stream_t stream) {
+    if (n_samples < 0 || !meta || meta->n_features != 2) return NGP_EINVAL;
+    if (n_samples == 0) return 0;
+    NGP_CHECK_PTR(x); NGP_CHECK_PTR(xyz_min); NGP_CHECK_PTR(xyz_max); NGP_CHECK_PTR(table); NGP_CHECK_PTR(feats);
+    const int n_chunks = ngp_div_up(n_samples, 256);
+    hipLaunchKernelGGL(hashgrid_fwd_kernel, dim3(n_blocks_for(meta->n_levels, n_chunks)), dim3(256), 0, ngp_stream(stream),
+                       x, xyz_min, xyz_max, (const half2_t*)table, to_dev_meta(meta), n_samples, n_chunks, (half2_t*)feats);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_hashgrid_bwd(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* dfeats,
+                     const ngp_grid_meta* meta, int n_samples, void* grad_table, int grad_is_f32,
+                     ngp_stream_t stream) {
+    if (n_samples < 0 || !meta || meta->n_features != 2) return NGP_EINVAL;
+    if (n_samples == 0) return 0;
+    NGP_CHECK_PTR(x); NGP_CHECK_PTR(xyz_min); NGP_CHECK_PTR(xyz_max); NGP_CHECK_PTR(dfeats); NGP_CHECK_PTR(grad_table);
+    const int n_chunks = ngp_div_up(n_samples, 256);
+    const dim3 grid(n_blocks_for(meta->n_levels, n_chunks)), block(256);
+    if (grad_is_f32)
+        hipLaunchKernelGGL(hashgrid_bwd_kernel<true>, grid, block, 0, ngp_stream(stream),
+                           x, xyz_min, xyz_max, (const half2_t*)dfeats, to_dev_meta(meta), n_samples, n_chunks, grad_table);
+    else
+        hipLaunchKernelGGL(hashgrid_bwd_kernel<false>, grid, block, 0, ngp_stream(stream),
+                           x, xyz_min, xyz_max, (const half2_t*)dfeats, to_dev_meta(meta), n_samples, n_chunks, grad_table);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_feats_to_rowmajor(const ngp_half* feats, int n_levels, int n_samples, ngp_half* out, ngp_stream_t stream) {
+    if (n_samples < 0 || n_levels < 1) return NGP_EINVAL;
+    if (n_samples == 0) return 0;
+    NGP_CHECK_PTR(feats); NGP_CHECK_PTR(out);
+    hipLaunchKernelGGL(feats_to_rowmajor_kernel, dim3(ngp_div_up((long long)n_samples * n_levels, 256)), dim3(256), 0,
+                       ngp_stream(stream), (const half2_t*)feats, n_levels, n_samples, (half2_t*)out);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_feats_from_rowmajor(const ngp_half* in, int n_levels, int n_samples, ngp_half* feats, ngp_stream_t stream) {
+    if (n_samples < 0 || n_levels < 1) return NGP_EINVAL;
+    if (n_samples == 0) return 0;
+    NGP_CHECK_PTR(feats); NGP_CHECK_PTR(in);
+    hipLaunchKernelGGL(feats_from_rowmajor_kernel, dim3(ngp_div_up((long long)n_samples * n_levels, 256)), dim3(256), 0,
+                       ngp_stream(stream), (const half2_t*)in, n_levels, n_samples, (half2_t*)feats);
+    return NGP_LAUNCH_RESULT();
+}
+
+}  // extern "C"

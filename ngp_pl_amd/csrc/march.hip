@@ -1,0 +1,553 @@
+// Occupancy-grid ray marching, intersection and grid helpers for gfx950.
+//
+// Semantics follow /root/reference/models/csrc/{intersection,raymarching}.cu (cited per kernel);
+// the decomposition does not: train marching is ONE march per ray that records the sample
+// parameters t into a scratch row, a single-block scan that fixes the ray-ordered packing,
+// and a sample-parallel coalesced expansion (the reference marches every ray twice and packs
+// in atomicAdd order).
+//
+// Floating-point contract: the compiler may not contract (pragma below); the two places where
+// nvcc's default -fmad contracts AND the result can differ are written as explicit fmaf:
+//   x = fmaf(t, d, o)            (raymarching.cu:205,246,357)
+//   t1 = fmaf(dt, noise, t1)     (raymarching.cu:198)
+// All other mul+add pairs in the marching maths have an exact product (power-of-two factor),
+// so contraction cannot change them.  The CPU oracle makes the same choice (oracle/ngp_oracle.c).
+#pragma clang fp contract(off)
+
+#include "ngp_common.h"
+
+#define NGP_SQRT3 1.73205080757f
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// intersection (intersection.cu:5-22, 103-121)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 aabb_hit(float ox, float oy, float oz, float ix, float iy, float iz,
+                                           float cx, float cy, float cz, float hx, float hy, float hz) {
+    const float tminx = (cx - hx - ox) * ix, tmaxx = (cx + hx - ox) * ix;
+    const float tminy = (cy - hy - oy) * iy, tmaxy = (cy + hy - oy) * iy;
+    const float tminz = (cz - hz - oz) * iz, tmaxz = (cz + hz - oz) * iz;
+    const float t1 = fmaxf(fmaxf(fminf(tminx, tmaxx), fminf(tminy, tmaxy)), fminf(tminz, tmaxz));
+    const float t2 = fminf(fminf(fmaxf(tminx, tmaxx), fmaxf(tminy, tmaxy)), fmaxf(tminz, tmaxz));
+    if (t1 > t2) return make_float2(-1.0f, -1.0f);
+    return make_float2(t1, t2);
+}
+
+__device__ __forceinline__ float2 sphere_hit(float ox, float oy, float oz, float dx, float dy, float dz,
+                                             float cx, float cy, float cz, float radius) {
+    const float cox = ox - cx, coy = oy - cy, coz = oz - cz;
+    // dot() of helper_math.h: a.x*b.x + a.y*b.y + a.z*b.z, left to right
+    const float a = dx * dx + dy * dy + dz * dz;
+    const float half_b = dx * cox + dy * coy + dz * coz;
+    const float c = (cox * cox + coy * coy + coz * coz) - radius * radius;
+    const float disc = half_b * half_b - a * c;
+    if (disc < 0) return make_float2(-1.0f, -1.0f);
+    const float s = sqrtf(disc);
+    return make_float2((-half_b - s) / a, (-half_b + s) / a);
+}
+
+// One thread per ray walks all primitives in index order, keeps the first max_hits hits, then
+// orders the row ascending by t1 with the unfilled (-1) slots first -- what torch::sort over
+// the -1-initialised buffer produces (intersection.cu:69,95-97).
+template <bool SPHERE>
+__global__ void __launch_bounds__(256)
+ray_prim_intersect_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                          const float* __restrict__ centers, const float* __restrict__ extents,
+                          int n_rays, int n_prims, int max_hits,
+                          int32_t* __restrict__ hit_cnt, float* __restrict__ hits_t,
+                          int64_t* __restrict__ hits_idx) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const float ox = rays_o[3 * r], oy = rays_o[3 * r + 1], oz = rays_o[3 * r + 2];
+    const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz = rays_d[3 * r + 2];
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    float* row_t = hits_t + (size_t)r * max_hits * 2;
+    int64_t* row_i = hits_idx + (size_t)r * max_hits;
+    for (int k = 0; k < max_hits; ++k) { row_t[2 * k] = -1.0f; row_t[2 * k + 1] = -1.0f; row_i[k] = -1; }
+    int cnt = 0;
+    for (int v = 0; v < n_prims; ++v) {
+        float2 t;
+        if (SPHERE) t = sphere_hit(ox, oy, oz, dx, dy, dz, centers[3 * v], centers[3 * v + 1], centers[3 * v + 2], extents[v]);
+        else t = aabb_hit(ox, oy, oz, ix, iy, iz, centers[3 * v], centers[3 * v + 1], centers[3 * v + 2],
+                          extents[3 * v], extents[3 * v + 1], extents[3 * v + 2]);
+        if (t.y > 0) {
+            if (cnt < max_hits) {
+                row_t[2 * cnt] = fmaxf(t.x, 0.0f);
+                row_t[2 * cnt + 1] = t.y;
+                row_i[cnt] = v;
+            }
+            ++cnt;
+        }
+    }
+    hit_cnt[r] = cnt;
+    if (max_hits > 1) {  // stable insertion sort by t1 (the -1 rows float to the front)
+        for (int i = 1; i < max_hits; ++i) {
+            const float k0 = row_t[2 * i], k1 = row_t[2 * i + 1];
+            const int64_t ki = row_i[i];
+            int j = i - 1;
+            while (j >= 0 && row_t[2 * j] > k0) {
+                row_t[2 * j + 2] = row_t[2 * j]; row_t[2 * j + 3] = row_t[2 * j + 1]; row_i[j + 1] = row_i[j];
+                --j;
+            }
+            row_t[2 * j + 2] = k0; row_t[2 * j + 3] = k1; row_i[j + 1] = ki;
+        }
+    }
+}
+
+// Hot path: one box, one hit, near clamp fused (rendering.py:27-29).
+__global__ void __launch_bounds__(256)
+ray_aabb_near_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                     const float* __restrict__ center, const float* __restrict__ half_size,
+                     float near_distance, int n_rays, float* __restrict__ hits_t) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const float ox = rays_o[3 * r], oy = rays_o[3 * r + 1], oz = rays_o[3 * r + 2];
+    const float ix = 1.0f / rays_d[3 * r], iy = 1.0f / rays_d[3 * r + 1], iz = 1.0f / rays_d[3 * r + 2];
+    const float2 t = aabb_hit(ox, oy, oz, ix, iy, iz, center[0], center[1], center[2],
+                              half_size[0], half_size[1], half_size[2]);
+    float t1 = -1.0f, t2 = -1.0f;
+    if (t.y > 0) { t1 = fmaxf(t.x, 0.0f); t2 = t.y; }
+    if (t1 >= 0 && t1 < near_distance) t1 = near_distance;
+    reinterpret_cast<float2*>(hits_t)[r] = make_float2(t1, t2);
+}
+
+// ------------------------------------------------------------------------------------------
+// Morton / packbits (raymarching.cu:62-161)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+morton3D_kernel(const int32_t* __restrict__ coords, int n, int32_t* __restrict__ indices) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    indices[i] = (int32_t)ngp_morton3D((uint32_t)coords[3 * i], (uint32_t)coords[3 * i + 1], (uint32_t)coords[3 * i + 2]);
+}
+
+__global__ void __launch_bounds__(256)
+morton3D_invert_kernel(const int32_t* __restrict__ indices, int n, int32_t* __restrict__ coords) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t ind = indices[i];   // arithmetic shifts on int, as the reference (raymarching.cu:97-100)
+    coords[3 * i] = (int32_t)ngp_compact_bits((uint32_t)(ind >> 0));
+    coords[3 * i + 1] = (int32_t)ngp_compact_bits((uint32_t)(ind >> 1));
+    coords[3 * i + 2] = (int32_t)ngp_compact_bits((uint32_t)(ind >> 2));
+}
+
+// 8 floats -> 1 byte per thread; the 32-byte read per lane is two dwordx4 loads, coalesced
+// across the wave (2 KiB per wave-instruction pair).
+template <typename T>
+__global__ void __launch_bounds__(256)
+packbits_kernel(const T* __restrict__ grid, int n_bytes, float thr, const float* __restrict__ stats,
+                uint8_t* __restrict__ bitfield) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_bytes) return;
+    if (stats != nullptr) {  // threshold = min(mean of grid>0, thr)  (networks.py:266-268)
+        const float mean = stats[0] / stats[1];
+        thr = (thr < mean) ? thr : mean;   // python min(mean, thr): NaN mean (no cell > 0) stays NaN -> all bits 0
+    }
+    uint32_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bits |= ((float)grid[(size_t)8 * n + i] > thr) ? (1u << i) : 0u;
+    bitfield[n] = (uint8_t)bits;
+}
+
+__global__ void __launch_bounds__(256)
+density_grid_update_kernel(float* __restrict__ grid, const float* __restrict__ tmp,
+                           const float* __restrict__ decay_grid, float decay, int n,
+                           float* __restrict__ stats) {
+    float sum = 0.f, cnt = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float g = grid[i];
+        const float dk = decay_grid ? decay_grid[i] : decay;
+        const float v = (g < 0) ? g : fmaxf(g * dk, tmp[i]);
+        grid[i] = v;
+        if (v > 0) { sum += v; cnt += 1.f; }
+    }
+    sum = ngp_wave_sum(sum); cnt = ngp_wave_sum(cnt);
+    __shared__ float s_sum[4], s_cnt[4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_sum[w] = sum; s_cnt[w] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&stats[0], s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+        atomicAdd(&stats[1], s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+cells_to_xyz_kernel(const int32_t* __restrict__ coords, const float* __restrict__ noise, int n3,
+                    float gm1, float s_minus_hgs, float hgs, float* __restrict__ xyzs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n3) return;
+    // (coords/(G-1)*2-1)*(s-hgs) + (rand*2-1)*hgs   (networks.py:253-255), torch op order
+    const float c = ((float)coords[i] / gm1 * 2.0f - 1.0f) * s_minus_hgs;
+    xyzs[i] = c + (noise[i] * 2.0f - 1.0f) * hgs;
+}
+
+// ------------------------------------------------------------------------------------------
+// marching core (raymarching.cu:7-32, 204-234)
+// ------------------------------------------------------------------------------------------
+struct MarchParams {
+    const uint8_t* __restrict__ bitfield;
+    int cascades;
+    int grid_size;
+    float scale;        // scene scale: bound of the finest cascade is min(2^(mip-1), scale)
+    float esf;          // exp_step_factor
+    float dt_lo;        // SQRT3 / max_samples
+    float dt_hi;        // SQRT3 * 2 * scale_for_dt / grid_size
+};
+
+__device__ __forceinline__ float calc_dt(float t, const MarchParams& p) {
+    return fmaxf(p.dt_lo, fminf(t * p.esf, p.dt_hi));
+}
+
+struct Ray {
+    float ox, oy, oz, dx, dy, dz, ix, iy, iz;
+};
+
+// Evaluates the cell containing the sample at parameter t.  Returns whether it is occupied,
+// the sample position, dt, and (when empty) the next t on the step lattice past the cell.
+__device__ __forceinline__ bool march_probe(const Ray& ray, const MarchParams& p, float t,
+                                            float& x, float& y, float& z, float& dt, float& t_next) {
+    x = fmaf(t, ray.dx, ray.ox); y = fmaf(t, ray.dy, ray.oy); z = fmaf(t, ray.dz, ray.oz);
+    dt = calc_dt(t, p);
+    const float G = (float)p.grid_size;
+    int e_pos; frexpf(fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))), &e_pos);
+    int e_dt; frexpf(dt * G, &e_dt);
+    const int mip_pos = min(p.cascades - 1, max(0, e_pos + 1));
+    const int mip_dt = min(p.cascades - 1, max(0, e_dt));
+    const int mip = max(mip_pos, mip_dt);
+    const float mip_bound = fminf(scalbnf(1.0f, mip - 1), p.scale);
+    const float mip_bound_inv = 1 / mip_bound;
+    const float gm1 = G - 1.0f;
+    const int nx = (int)fmaxf(0.0f, fminf(0.5f * (x * mip_bound_inv + 1) * G, gm1));
+    const int ny = (int)fmaxf(0.0f, fminf(0.5f * (y * mip_bound_inv + 1) * G, gm1));
+    const int nz = (int)fmaxf(0.0f, fminf(0.5f * (z * mip_bound_inv + 1) * G, gm1));
+    const uint32_t g3 = (uint32_t)(p.grid_size * p.grid_size * p.grid_size);
+    const uint32_t idx = (uint32_t)mip * g3 + ngp_morton3D((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+    const bool occ = (p.bitfield[idx >> 3] >> (idx & 7)) & 1;
+    if (!occ) {
+        const float ginv = 1.0f / G;
+        const float tx = (((nx + 0.5f + 0.5f * copysignf(1.0f, ray.dx)) * ginv * 2 - 1) * mip_bound - x) * ray.ix;
+        const float ty = (((ny + 0.5f + 0.5f * copysignf(1.0f, ray.dy)) * ginv * 2 - 1) * mip_bound - y) * ray.iy;
+        const float tz = (((nz + 0.5f + 0.5f * copysignf(1.0f, ray.dz)) * ginv * 2 - 1) * mip_bound - z) * ray.iz;
+        const float t_target = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+        float tt = t;
+        do { tt += calc_dt(tt, p); } while (tt < t_target);
+        t_next = tt;
+    }
+    return occ;
+}
+
+__device__ __forceinline__ Ray load_ray(const float* __restrict__ rays_o, const float* __restrict__ rays_d, size_t r) {
+    Ray ray;
+    ray.ox = rays_o[3 * r]; ray.oy = rays_o[3 * r + 1]; ray.oz = rays_o[3 * r + 2];
+    ray.dx = rays_d[3 * r]; ray.dy = rays_d[3 * r + 1]; ray.dz = rays_d[3 * r + 2];
+    ray.ix = 1.0f / ray.dx; ray.iy = 1.0f / ray.dy; ray.iz = 1.0f / ray.dz;
+    return ray;
+}
+
+// Pass 1 of train marching (raymarching.cu:184-234): one march, t of every emitted sample goes
+// to the ray's scratch row.  64-thread blocks: 8192 rays -> 128 workgroups spread over the CUs
+// instead of the reference's 32 blocks of 256.
+__global__ void __launch_bounds__(64)
+march_train_count_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                         const float* __restrict__ hits_t, const float* __restrict__ noise,
+                         MarchParams p, int max_samples, int n_rays,
+                         int64_t* __restrict__ rays_a, float* __restrict__ t_scratch) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const Ray ray = load_ray(rays_o, rays_d, r);
+    float t1 = hits_t[2 * r];
+    const float t2 = hits_t[2 * r + 1];
+    if (t1 >= 0) t1 = fmaf(calc_dt(t1, p), noise[r], t1);
+    float* __restrict__ row = t_scratch + (size_t)r * max_samples;
+    float t = t1;
+    int n = 0;
+    while (0 <= t && t < t2 && n < max_samples) {
+        float x, y, z, dt, t_next;
+        if (march_probe(ray, p, t, x, y, z, dt, t_next)) {
+            row[n] = t;
+            t += dt; ++n;
+        } else {
+            t = t_next;
+        }
+    }
+    rays_a[3 * (size_t)r] = r;
+    rays_a[3 * (size_t)r + 2] = n;
+}
+
+// Exclusive scan of rays_a[:,2] into rays_a[:,1] in ray order; counter = {S, R}.
+// Single 1024-thread workgroup; each thread owns a contiguous run of rays.
+__global__ void __launch_bounds__(1024)
+march_train_scan_kernel(int64_t* __restrict__ rays_a, int n_rays, int32_t* __restrict__ counter) {
+    __shared__ int s_wave[16];
+    const int tid = threadIdx.x;
+    const int per = (n_rays + 1023) / 1024;
+    const int begin = min(tid * per, n_rays), end = min(begin + per, n_rays);
+    int local = 0;
+    for (int r = begin; r < end; ++r) local += (int)rays_a[3 * (size_t)r + 2];
+    // inclusive scan across the workgroup: wave shuffle scan + scan of wave totals
+    int incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if ((tid & 63) >= o) incl += v;
+    }
+    if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+    __syncthreads();
+    if (tid < 64) {
+        int w = (tid < 16) ? s_wave[tid] : 0;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const int v = __shfl_up(w, o, 64);
+            if (tid >= o) w += v;
+        }
+        if (tid < 16) s_wave[tid] = w;   // inclusive wave totals
+    }
+    __syncthreads();
+    const int wave_off = (tid >> 6) ? s_wave[(tid >> 6) - 1] : 0;
+    int run = wave_off + incl - local;   // exclusive offset of this thread's run
+    for (int r = begin; r < end; ++r) {
+        const int n = (int)rays_a[3 * (size_t)r + 2];
+        rays_a[3 * (size_t)r + 1] = run;
+        run += n;
+    }
+    if (tid == 1023) { counter[0] = run; counter[1] = n_rays; }
+}
+
+// Pass 2 of train marching: expand (ray, k) -> packed sample.  One wave per ray, lanes stride
+// the ray's samples: scratch reads and all four output streams are coalesced.
+__global__ void __launch_bounds__(256)
+march_train_write_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                         const int64_t* __restrict__ rays_a, const float* __restrict__ t_scratch,
+                         MarchParams p, int max_samples, int n_rays,
+                         float* __restrict__ xyzs, float* __restrict__ dirs,
+                         float* __restrict__ deltas, float* __restrict__ ts) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= n_rays) return;
+    const int64_t r = rays_a[3 * (size_t)wave];
+    const int64_t start = rays_a[3 * (size_t)wave + 1];
+    const int n = (int)rays_a[3 * (size_t)wave + 2];
+    const float ox = rays_o[3 * r], oy = rays_o[3 * r + 1], oz = rays_o[3 * r + 2];
+    const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz = rays_d[3 * r + 2];
+    const float* __restrict__ row = t_scratch + (size_t)r * max_samples;
+    for (int k = lane; k < n; k += 64) {
+        const float t = row[k];
+        const size_t s = (size_t)start + k;
+        xyzs[3 * s] = fmaf(t, dx, ox); xyzs[3 * s + 1] = fmaf(t, dy, oy); xyzs[3 * s + 2] = fmaf(t, dz, oz);
+        dirs[3 * s] = dx; dirs[3 * s + 1] = dy; dirs[3 * s + 2] = dz;
+        ts[s] = t;
+        deltas[s] = calc_dt(t, p);
+    }
+}
+
+// Test-time marching (raymarching.cu:353-403).  Dense (n_alive, n_samples) outputs are fully
+// written here (the reference zero-fills them on the host first).
+__global__ void __launch_bounds__(64)
+march_test_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                  float* __restrict__ hits_t, const int64_t* __restrict__ alive,
+                  MarchParams p, int n_samples, int n_alive,
+                  float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas,
+                  float* __restrict__ ts, int32_t* __restrict__ n_eff) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const size_t r = (size_t)alive[n];
+    const Ray ray = load_ray(rays_o, rays_d, r);
+    float t = hits_t[2 * r];
+    const float t2 = hits_t[2 * r + 1];
+    const size_t base = (size_t)n * n_samples;
+    int s = 0;
+    float t_resume = t;
+    while (t < t2 && s < n_samples) {
+        float x, y, z, dt, t_next;
+        if (march_probe(ray, p, t, x, y, z, dt, t_next)) {
+            const size_t o = base + s;
+            xyzs[3 * o] = x; xyzs[3 * o + 1] = y; xyzs[3 * o + 2] = z;
+            dirs[3 * o] = ray.dx; dirs[3 * o + 1] = ray.dy; dirs[3 * o + 2] = ray.dz;
+            ts[o] = t; deltas[o] = dt;
+            t += dt; ++s;
+            t_resume = t;           // raymarching.cu:390: stored after every emitted sample only
+        } else {
+            t = t_next;
+        }
+    }
+    if (s > 0) hits_t[2 * r] = t_resume;
+    n_eff[n] = s;
+    for (int k = s; k < n_samples; ++k) {
+        const size_t o = base + k;
+        xyzs[3 * o] = 0.f; xyzs[3 * o + 1] = 0.f; xyzs[3 * o + 2] = 0.f;
+        dirs[3 * o] = 0.f; dirs[3 * o + 1] = 0.f; dirs[3 * o + 2] = 0.f;
+        ts[o] = 0.f; deltas[o] = 0.f;
+    }
+}
+
+MarchParams make_march_params(const uint8_t* bitfield, int cascades, int grid_size, float scale,
+                              float scale_for_dt, float esf, int max_samples) {
+    MarchParams p;
+    p.bitfield = bitfield; p.cascades = cascades; p.grid_size = grid_size; p.scale = scale; p.esf = esf;
+    p.dt_lo = NGP_SQRT3 / max_samples;                 // raymarching.cu:12, float / int
+    p.dt_hi = NGP_SQRT3 * 2 * scale_for_dt / grid_size;
+    return p;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+#pragma GCC visibility push(default)
+
+int ngp_abi_version(void) { return 1; }
+const char* ngp_build_arch(void) { return "gfx950"; }
+
+int ngp_ray_aabb_intersect(const float* rays_o, const float* rays_d, const float* centers,
+                           const float* half_sizes, int n_rays, int n_voxels, int max_hits,
+                           int32_t* hit_cnt, float* hits_t, int64_t* hits_voxel_idx, ngp_stream_t stream) {
+    if (n_rays < 0 || n_voxels < 0 || max_hits < 1) return NGP_EINVAL;
+    if (n_rays == 0) return 0;
+    NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d); NGP_CHECK_PTR(hit_cnt); NGP_CHECK_PTR(hits_t); NGP_CHECK_PTR(hits_voxel_idx);
+    if (n_voxels > 0) { NGP_CHECK_PTR(centers); NGP_CHECK_PTR(half_sizes); }
+    hipLaunchKernelGGL(ray_prim_intersect_kernel<false>, dim3(ngp_div_up(n_rays, 256)), dim3(256), 0, ngp_stream(stream),
+                       rays_o, rays_d, centers, half_sizes, n_rays, n_voxels, max_hits, hit_cnt, hits_t, hits_voxel_idx);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_ray_sphere_intersect(const float* rays_o, const float* rays_d, const float* centers,
+                             const float* radii, int n_rays, int n_spheres, int max_hits,
+                             int32_t* hit_cnt, float* hits_t, int64_t* hits_sphere_idx, ngp_stream_t stream) {
+    if (n_rays < 0 || n_spheres < 0 || max_hits < 1) return NGP_EINVAL;
+    if (n_rays == 0) return 0;
+    NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d); NGP_CHECK_PTR(hit_cnt); NGP_CHECK_PTR(hits_t); NGP_CHECK_PTR(hits_sphere_idx);
+    if (n_spheres > 0) { NGP_CHECK_PTR(centers); NGP_CHECK_PTR(radii); }
+    hipLaunchKernelGGL(ray_prim_intersect_kernel<true>, dim3(ngp_div_up(n_rays, 256)), dim3(256), 0, ngp_stream(stream),
+                       rays_o, rays_d, centers, radii, n_rays, n_spheres, max_hits, hit_cnt, hits_t, hits_sphere_idx);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_ray_aabb_near(const float* rays_o, const float* rays_d, const float* center,
+                      const float* half_size, float near_distance, int n_rays, float* hits_t,
+                      ngp_stream_t stream) {
+    if (n_rays < 0) return NGP_EINVAL;
+    if (n_rays == 0) return 0;
+    NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d); NGP_CHECK_PTR(center); NGP_CHECK_PTR(half_size); NGP_CHECK_PTR(hits_t);
+    hipLaunchKernelGGL(ray_aabb_near_kernel, dim3(ngp_div_up(n_rays, 256)), dim3(256), 0, ngp_stream(stream),
+                       rays_o, rays_d, center, half_size, near_distance, n_rays, hits_t);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_morton3D(const int32_t* coords, int n, int32_t* indices, ngp_stream_t stream) {
+    if (n < 0) return NGP_EINVAL;
+    if (n == 0) return 0;
+    NGP_CHECK_PTR(coords); NGP_CHECK_PTR(indices);
+    hipLaunchKernelGGL(morton3D_kernel, dim3(ngp_div_up(n, 256)), dim3(256), 0, ngp_stream(stream), coords, n, indices);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_morton3D_invert(const int32_t* indices, int n, int32_t* coords, ngp_stream_t stream) {
+    if (n < 0) return NGP_EINVAL;
+    if (n == 0) return 0;
+    NGP_CHECK_PTR(coords); NGP_CHECK_PTR(indices);
+    hipLaunchKernelGGL(morton3D_invert_kernel, dim3(ngp_div_up(n, 256)), dim3(256), 0, ngp_stream(stream), indices, n, coords);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_packbits(const void* density_grid, int grid_is_half, int n_bytes, float density_threshold,
+                 uint8_t* density_bitfield, ngp_stream_t stream) {
+    if (n_bytes < 0) return NGP_EINVAL;
+    if (n_bytes == 0) return 0;
+    NGP_CHECK_PTR(density_grid); NGP_CHECK_PTR(density_bitfield);
+    const dim3 grid(ngp_div_up(n_bytes, 256)), block(256);
+    if (grid_is_half)
+        hipLaunchKernelGGL(packbits_kernel<_Float16>, grid, block, 0, ngp_stream(stream),
+                           (const _Float16*)density_grid, n_bytes, density_threshold, (const float*)nullptr, density_bitfield);
+    else
+        hipLaunchKernelGGL(packbits_kernel<float>, grid, block, 0, ngp_stream(stream),
+                           (const float*)density_grid, n_bytes, density_threshold, (const float*)nullptr, density_bitfield);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_packbits_auto(const float* density_grid, int n_bytes, const float* stats, float density_threshold,
+                      uint8_t* density_bitfield, ngp_stream_t stream) {
+    if (n_bytes < 0) return NGP_EINVAL;
+    if (n_bytes == 0) return 0;
+    NGP_CHECK_PTR(density_grid); NGP_CHECK_PTR(density_bitfield); NGP_CHECK_PTR(stats);
+    hipLaunchKernelGGL(packbits_kernel<float>, dim3(ngp_div_up(n_bytes, 256)), dim3(256), 0, ngp_stream(stream),
+                       density_grid, n_bytes, density_threshold, stats, density_bitfield);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_density_grid_update(float* density_grid, const float* density_grid_tmp, const float* decay_grid,
+                            float decay, int n_cells, float* stats, ngp_stream_t stream) {
+    if (n_cells < 0) return NGP_EINVAL;
+    if (n_cells == 0) return 0;
+    NGP_CHECK_PTR(density_grid); NGP_CHECK_PTR(density_grid_tmp); NGP_CHECK_PTR(stats);
+    const int blocks = min(ngp_div_up(n_cells, 256), 2048);
+    hipLaunchKernelGGL(density_grid_update_kernel, dim3(blocks), dim3(256), 0, ngp_stream(stream),
+                       density_grid, density_grid_tmp, decay_grid, decay, n_cells, stats);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_cells_to_xyz(const int32_t* coords, const float* noise, int n, int grid_size, float s,
+                     float* xyzs_w, ngp_stream_t stream) {
+    if (n < 0 || grid_size < 2) return NGP_EINVAL;
+    if (n == 0) return 0;
+    NGP_CHECK_PTR(coords); NGP_CHECK_PTR(noise); NGP_CHECK_PTR(xyzs_w);
+    const double sd = (double)s, hgs = sd / grid_size;   // python floats are doubles (networks.py:251-253)
+    hipLaunchKernelGGL(cells_to_xyz_kernel, dim3(ngp_div_up(3LL * n, 256)), dim3(256), 0, ngp_stream(stream),
+                       coords, noise, 3 * n, (float)(grid_size - 1), (float)(sd - hgs), (float)hgs, xyzs_w);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_raymarching_train_count(const float* rays_o, const float* rays_d, const float* hits_t,
+                                const uint8_t* density_bitfield, int cascades, float scale,
+                                float exp_step_factor, const float* noise, int grid_size,
+                                int max_samples, int n_rays, int64_t* rays_a, int32_t* counter,
+                                float* t_scratch, ngp_stream_t stream) {
+    if (n_rays < 0 || cascades < 1 || grid_size < 1 || grid_size > 1024 || max_samples < 1) return NGP_EINVAL;
+    NGP_CHECK_PTR(counter);
+    if (n_rays > 0) {
+        NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d); NGP_CHECK_PTR(hits_t); NGP_CHECK_PTR(density_bitfield);
+        NGP_CHECK_PTR(noise); NGP_CHECK_PTR(rays_a); NGP_CHECK_PTR(t_scratch);
+        const MarchParams p = make_march_params(density_bitfield, cascades, grid_size, scale, scale, exp_step_factor, max_samples);
+        hipLaunchKernelGGL(march_train_count_kernel, dim3(ngp_div_up(n_rays, 64)), dim3(64), 0, ngp_stream(stream),
+                           rays_o, rays_d, hits_t, noise, p, max_samples, n_rays, rays_a, t_scratch);
+    }
+    hipLaunchKernelGGL(march_train_scan_kernel, dim3(1), dim3(1024), 0, ngp_stream(stream), rays_a, n_rays, counter);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_raymarching_train_write(const float* rays_o, const float* rays_d, const int64_t* rays_a,
+                                const float* t_scratch, float scale, float exp_step_factor,
+                                int grid_size, int max_samples, int n_rays,
+                                float* xyzs, float* dirs, float* deltas, float* ts, ngp_stream_t stream) {
+    if (n_rays < 0 || grid_size < 1 || max_samples < 1) return NGP_EINVAL;
+    if (n_rays == 0) return 0;
+    NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d); NGP_CHECK_PTR(rays_a); NGP_CHECK_PTR(t_scratch);
+    // xyzs..ts may be null only when S == 0, which the kernel never dereferences
+    const MarchParams p = make_march_params(nullptr, 1, grid_size, scale, scale, exp_step_factor, max_samples);
+    hipLaunchKernelGGL(march_train_write_kernel, dim3(ngp_div_up((long long)n_rays * 64, 256)), dim3(256), 0, ngp_stream(stream),
+                       rays_o, rays_d, rays_a, t_scratch, p, max_samples, n_rays, xyzs, dirs, deltas, ts);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_raymarching_test(const float* rays_o, const float* rays_d, float* hits_t,
+                         const int64_t* alive_indices, const uint8_t* density_bitfield,
+                         int cascades, float scale, float exp_step_factor, int grid_size,
+                         int max_samples, int n_samples, int n_alive,
+                         float* xyzs, float* dirs, float* deltas, float* ts,
+                         int32_t* n_eff_samples, ngp_stream_t stream) {
+    if (n_alive < 0 || cascades < 1 || grid_size < 1 || grid_size > 1024 || max_samples < 1 || n_samples < 1) return NGP_EINVAL;
+    if (n_alive == 0) return 0;
+    NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d); NGP_CHECK_PTR(hits_t); NGP_CHECK_PTR(alive_indices);
+    NGP_CHECK_PTR(density_bitfield); NGP_CHECK_PTR(xyzs); NGP_CHECK_PTR(dirs); NGP_CHECK_PTR(deltas);
+    NGP_CHECK_PTR(ts); NGP_CHECK_PTR(n_eff_samples);
+    // the reference passes `cascades` where calc_dt expects `scale` (raymarching.cu:370,399)
+    const MarchParams p = make_march_params(density_bitfield, cascades, grid_size, scale, (float)cascades, exp_step_factor, max_samples);
+    hipLaunchKernelGGL(march_test_kernel, dim3(ngp_div_up(n_alive, 64)), dim3(64), 0, ngp_stream(stream),
+                       rays_o, rays_d, hits_t, alive_indices, p, n_samples, n_alive, xyzs, dirs, deltas, ts, n_eff_samples);
+    return NGP_LAUNCH_RESULT();
+}
+
+}  // extern "C"

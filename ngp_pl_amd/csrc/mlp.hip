@@ -1,0 +1,715 @@
+// 64-wide fully fused MLPs (+ SH degree-4 encoding, TruncExp) on gfx950 matrix cores.
+//
+// Replaces tiny-cuda-nn's FullyFusedMLP / SphericalHarmonics as the reference configures them
+// (/root/reference/models/networks.py:49-77): no biases, ReLU hidden activations, weights
+// (out,in) row-major, f16 storage, output layer padded to 16 rows, f16 activations between
+// layers.  tiny-cuda-nn is an un-vendored, unpinned dependency of the reference; semantics are
+// restated from its published source and checked against
+// oracle/tcnn_oracle.py.
+//
+// MI355X mapping.  One wave64 owns a tile of 32 samples and runs the whole network on
+// v_mfma_f32_32x32x16_f16 with the operands SWAPPED: it computes Y^T = W * X^T, so the MFMA
+// "N" index (lane & 31) is the SAMPLE and the "M" index is the output neuron.  The D fragment
+// of layer n (neuron rows spread over registers, one sample per lane) is then already a valid
+// B fragment for layer n+1 once the K slots are renamed -- and a K renaming is free, it only
+// changes which weight columns the A fragment loads.  Activations therefore never leave
+// registers in forward/dgrad; no LDS round trip, no barrier (tiny-cuda-nn goes through shared
+// memory between layers because wmma keeps samples on M).  Only the weight gradient needs the
+// sample on K, i.e. a transpose, which goes through a small wave-private LDS tile.
+//
+// K-slot renaming: MFMA element e (0..7) of lane-half hh (lane>>5) in K-chunk c is
+//   natural order : unit 16c + 8hh + e                      (operand loaded from memory)
+//   D order       : unit 16c + 4hh + (e&3) + 8(e>>2)        (operand is a previous D fragment;
+//                   D register r of lane-half hh holds row (r&3) + 8(r>>2) + 4hh)
+// Weights live in LDS (row pitch padded by 16 B -> conflict-free ds_read_b128/b64).
+#include "ngp_common.h"
+
+namespace {
+
+typedef _Float16 h1;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int HID = 64;          // neurons
+constexpr int PAD = 8;           // halves of row padding in LDS
+constexpr int WAVES = 4;         // waves per workgroup
+constexpr int TILE = 32;         // samples per wave tile
+
+__device__ __forceinline__ f32x16 mfma(half8_t a, half8_t b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 zero16() { f32x16 z; for (int i = 0; i < 16; ++i) z[i] = 0.f; return z; }
+
+// ---- A fragments from LDS weights (row-major, pitch ld halves) ----
+__device__ __forceinline__ half8_t ldsA_nat(const h1* W, int ld, int row, bool valid, int c, int hh) {
+    half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return valid ? *reinterpret_cast<const half8_t*>(W + row * ld + 16 * c + 8 * hh) : z;
+}
+__device__ __forceinline__ half8_t ldsA_dl(const h1* W, int ld, int row, bool valid, int c, int hh) {
+    half8_t r = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (valid) {
+        const half4_t lo = *reinterpret_cast<const half4_t*>(W + row * ld + 16 * c + 4 * hh);
+        const half4_t hi = *reinterpret_cast<const half4_t*>(W + row * ld + 16 * c + 4 * hh + 8);
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    }
+    return r;
+}
+
+// D fragment (f32) -> B fragment (f16) for chunk half c2 (registers 8*c2 .. 8*c2+7)
+template <bool RELU>
+__device__ __forceinline__ half8_t d_to_b(const f32x16& d, int c2) {
+    half8_t b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float v = d[8 * c2 + e];
+        if (RELU) v = fmaxf(v, 0.f);
+        b[e] = (h1)v;
+    }
+    return b;
+}
+
+// Stage a (rows, cols) row-major f16 matrix from global into LDS with padded pitch, optionally
+// transposed (LDS gets (cols, rows)).  Whole workgroup participates.
+__device__ __forceinline__ void stage_weights(const h1* __restrict__ g, h1* lds, int rows, int cols, bool transpose) {
+    const int n = rows * cols;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+        const int r = t / cols, c = t - r * cols;
+        if (transpose) lds[c * (rows + PAD) + r] = g[t];
+        else lds[r * (cols + PAD) + c] = g[t];
+    }
+}
+
+// ---- SH degree 4 (tiny-cuda-nn spherical_harmonics.h, constants as SURVEY.md section 8a) ----
+__device__ __forceinline__ void sh4(float x, float y, float z, float* o) {
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    o[0] = 0.28209479177387814f;
+    o[1] = -0.48860251190291987f * y;
+    o[2] = 0.48860251190291987f * z;
+    o[3] = -0.48860251190291987f * x;
+    o[4] = 1.0925484305920792f * xy;
+    o[5] = -1.0925484305920792f * yz;
+    o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    o[7] = -1.0925484305920792f * xz;
+    o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+    o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+    o[10] = 2.8906114426405538f * xy * z;
+    o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+    o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+    o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+    o[14] = 1.4453057213202769f * z * (x2 - y2);
+    o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+}
+
+enum InMode { IN_ROWMAJOR = 0, IN_LEVELMAJOR = 1, IN_SH_H = 2 };
+enum OutMode { OUT_PLAIN = 0, OUT_DENSITY = 1, OUT_RGB = 2 };
+
+struct MlpIO {
+    const h1* in;          // IN_ROWMAJOR: (S,N_IN); IN_LEVELMAJOR: [16][S] half2; IN_SH_H: h (S,16)
+    const float* dirs;     // IN_SH_H: (S,3) un-normalised
+    h1* out16;             // (S, out_ld) f16, may be null
+    int out_ld;            // row length of out16 (n_out for tcnn.Network, 16 for h)
+    int n_out;             // columns actually written
+    float* sigmas;         // OUT_DENSITY
+    float* rgbs;           // OUT_RGB (S,3)
+    int out_act;           // OUT_PLAIN: 0 none, 1 sigmoid
+};
+
+// Load the B fragments (natural K order) of the network input for this lane's sample.
+template <int N_IN, int IN_MODE>
+__device__ __forceinline__ void load_input(const MlpIO& io, long long s, bool valid, int n_samples, int hh,
+                                           half8_t (&b)[N_IN / 16]) {
+    const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < N_IN / 16; ++c) b[c] = z;
+    if (!valid) return;
+    if (IN_MODE == IN_ROWMAJOR) {
+#pragma unroll
+        for (int c = 0; c < N_IN / 16; ++c)
+            b[c] = *reinterpret_cast<const half8_t*>(io.in + s * N_IN + 16 * c + 8 * hh);
+    } else if (IN_MODE == IN_LEVELMAJOR) {
+        const half2_t* f = reinterpret_cast<const half2_t*>(io.in);
+#pragma unroll
+        for (int c = 0; c < N_IN / 16; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const half2_t v = __builtin_nontemporal_load(f + (size_t)(8 * c + 4 * hh + q) * n_samples + s);
+                b[c][2 * q] = v[0]; b[c][2 * q + 1] = v[1];
+            }
+    } else {  // IN_SH_H: chunk 0 = SH(d/|d|), chunk 1 = h
+        const float dx = io.dirs[3 * s], dy = io.dirs[3 * s + 1], dz = io.dirs[3 * s + 2];
+        const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+        float sh[16];
+        sh4(dx * inv, dy * inv, dz * inv, sh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b[0][e] = (h1)(hh ? sh[8 + e] : sh[e]);
+        b[1] = *reinterpret_cast<const half8_t*>(io.in + s * 16 + 8 * hh);
+    }
+}
+
+// Forward through the hidden stack.  LDS weights: W0 (64, N_IN), W1 (64,64) [if N_HIDDEN==2],
+// Wo (16,64); pitches padded.  Leaves hidden activations (post-ReLU, f16 B fragments) in hb*.
+template <int N_IN, int N_HIDDEN>
+struct LdsW {
+    static constexpr int LD0 = N_IN + PAD, LDH = HID + PAD;
+    static constexpr int OFF_W0 = 0;
+    static constexpr int OFF_W1 = OFF_W0 + HID * LD0;
+    static constexpr int OFF_WO = OFF_W1 + (N_HIDDEN == 2 ? HID * LDH : 0);
+    static constexpr int SIZE = OFF_WO + 16 * LDH;          // halves
+    // global blob offsets (tight)
+    static constexpr int G_W1 = HID * N_IN;
+    static constexpr int G_WO = G_W1 + (N_HIDDEN == 2 ? HID * HID : 0);
+    static constexpr int G_SIZE = G_WO + 16 * HID;
+};
+
+template <int N_IN, int N_HIDDEN>
+__device__ __forceinline__ void stage_fwd_weights(const h1* __restrict__ w, h1* lds) {
+    using L = LdsW<N_IN, N_HIDDEN>;
+    stage_weights(w, lds + L::OFF_W0, HID, N_IN, false);
+    if (N_HIDDEN == 2) stage_weights(w + L::G_W1, lds + L::OFF_W1, HID, HID, false);
+    stage_weights(w + L::G_WO, lds + L::OFF_WO, 16, HID, false);
+}
+
+// hidden layer from natural-order input fragments: out tiles m=0,1 (64 neurons)
+template <int N_IN>
+__device__ __forceinline__ void layer_in(const h1* W, const half8_t (&b)[N_IN / 16], int i, int hh, f32x16 (&acc)[2]) {
+    acc[0] = zero16(); acc[1] = zero16();
+#pragma unroll
+    for (int c = 0; c < N_IN / 16; ++c)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+            acc[m] = mfma(ldsA_nat(W, N_IN + PAD, 32 * m + i, true, c, hh), b[c], acc[m]);
+}
+// 64 -> (32*M_TILES rows, first n_rows valid) from D-order fragments hb[4]
+template <int M_TILES>
+__device__ __forceinline__ void layer_hid(const h1* W, int ld, int n_rows, const half8_t (&hb)[4], int i, int hh,
+                                          f32x16 (&acc)[M_TILES]) {
+#pragma unroll
+    for (int m = 0; m < M_TILES; ++m) acc[m] = zero16();
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int m = 0; m < M_TILES; ++m)
+            acc[m] = mfma(ldsA_dl(W, ld, 32 * m + i, (32 * m + i) < n_rows, c, hh), hb[c], acc[m]);
+}
+template <bool RELU>
+__device__ __forceinline__ void acc_to_frag(const f32x16 (&acc)[2], half8_t (&hb)[4]) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) hb[2 * m + c2] = d_to_b<RELU>(acc[m], c2);
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// ------------------------------------------------------------------------------------------
+// forward kernel
+// ------------------------------------------------------------------------------------------
+template <int N_IN, int N_HIDDEN, int IN_MODE, int OUT_MODE>
+__global__ void __launch_bounds__(64 * WAVES)
+mlp_fwd_kernel(MlpIO io, const h1* __restrict__ weights, int n_samples) {
+    using L = LdsW<N_IN, N_HIDDEN>;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    h1* lds = reinterpret_cast<h1*>(smem_raw);
+    stage_fwd_weights<N_IN, N_HIDDEN>(weights, lds);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, i = lane & 31, hh = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    const int n_tiles = (n_samples + TILE - 1) / TILE;
+    for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
+        const long long s = (long long)tile * TILE + i;
+        const bool valid = s < n_samples;
+        half8_t xb[N_IN / 16];
+        load_input<N_IN, IN_MODE>(io, s, valid, n_samples, hh, xb);
+        f32x16 acc[2];
+        half8_t hb[4];
+        layer_in<N_IN>(lds + L::OFF_W0, xb, i, hh, acc);
+        acc_to_frag<true>(acc, hb);
+        if (N_HIDDEN == 2) {
+            layer_hid<2>(lds + L::OFF_W1, L::LDH, 64, hb, i, hh, acc);
+            acc_to_frag<true>(acc, hb);
+        }
+        f32x16 o[1];
+        layer_hid<1>(lds + L::OFF_WO, L::LDH, 16, hb, i, hh, o);
+        if (!valid) continue;
+        // o[0][r], r<8: output unit 4hh + (r&3) + 8(r>>2)
+        if (OUT_MODE == OUT_DENSITY) {
+            half4_t lo, hi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lo[e] = (h1)o[0][e]; hi[e] = (h1)o[0][4 + e]; }
+            if (io.out16) {
+                *reinterpret_cast<half4_t*>(io.out16 + s * 16 + 4 * hh) = lo;
+                *reinterpret_cast<half4_t*>(io.out16 + s * 16 + 8 + 4 * hh) = hi;
+            }
+            if (hh == 0) io.sigmas[s] = __expf((float)lo[0]);   // TruncExp fwd on the f16 h[0] (networks.py:105)
+        } else if (OUT_MODE == OUT_RGB) {
+            if (hh == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) io.rgbs[3 * s + c] = (float)(h1)sigmoidf(o[0][c]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int u = 4 * hh + (r & 3) + 8 * (r >> 2);
+                if (u < io.n_out) {
+                    float v = o[0][r];
+                    if (io.out_act == 1) v = sigmoidf(v);
+                    io.out16[s * io.out_ld + u] = (h1)v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward kernel: recompute forward, dgrad in registers, wgrad through a wave-private LDS
+// transpose, per-workgroup partial weight gradients.
+// ------------------------------------------------------------------------------------------
+struct MlpBwdIO {
+    MlpIO fwd;               // inputs as in forward (outputs unused)
+    const h1* dL_dout16;     // OUT_PLAIN / OUT_DENSITY: (S, dout_ld) f16 (already loss-scaled), may be null
+    int dout_ld;
+    const float* dL_dsigmas; // OUT_DENSITY: (S) f32 unscaled, may be null
+    const float* dL_drgbs;   // OUT_RGB: (S,3) f32 unscaled
+    float loss_scale;
+    h1* dL_din;              // IN_ROWMAJOR: (S,N_IN); IN_LEVELMAJOR: [16][S] half2; IN_SH_H: dh (S,16); may be null
+    float* wgrad_partial;    // (gridDim.x, G_SIZE) f32
+};
+
+// wave-private transpose tile: [unit][sample], pitch 40 halves (80 B)
+constexpr int TP = TILE + PAD;
+
+// Lanes of one wave exchange data through LDS: DS operations of a wave execute in program
+// order, so only the COMPILER has to be kept from moving reads above other lanes' writes.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// write a natural-order B fragment set (units 16c+8hh+e) for N units
+template <int NCH>
+__device__ __forceinline__ void tr_write_nat(h1* t, const half8_t (&b)[NCH], int j, int hh) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[(16 * c + 8 * hh + e) * TP + j] = b[c][e];
+}
+// write D-order fragments hb[NCH] (units 16c + 4hh + (e&3) + 8(e>>2))
+template <int NCH>
+__device__ __forceinline__ void tr_write_dl(h1* t, const half8_t (&b)[NCH], int j, int hh) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[(16 * c + 4 * hh + (e & 3) + 8 * (e >> 2)) * TP + j] = b[c][e];
+}
+// fragment read for wgrad: rows = units, K = samples (natural order both operands)
+__device__ __forceinline__ half8_t tr_read(const h1* t, int unit, int c, int hh) {
+    return *reinterpret_cast<const half8_t*>(t + unit * TP + 16 * c + 8 * hh);
+}
+// dW(MT*32 x NT*32) += dY^T (rows) * X (cols) over the 32 samples of the tile
+template <int MT, int NT>
+__device__ __forceinline__ void wgrad_tile(const h1* tdy, const h1* tx, int i, int hh, f32x16 (&acc)[MT][NT]) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        half8_t a[MT], b[NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = tr_read(tdy, 32 * m + i, c, hh);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) b[n] = tr_read(tx, 32 * n + i, c, hh);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = mfma(a[m], b[n], acc[m][n]);
+    }
+}
+// add a wave's dW accumulators into the workgroup's f32 LDS partial (row-major (rows, ld))
+template <int MT, int NT>
+__device__ __forceinline__ void wgrad_flush(float* part, int ld, int n_rows, int n_cols, int j, int hh,
+                                            const f32x16 (&acc)[MT][NT]) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * hh, col = 32 * n + j;
+                if (row < n_rows && col < n_cols) atomicAdd(part + row * ld + col, acc[m][n][r]);
+            }
+}
+
+template <int N_IN, int N_HIDDEN, int IN_MODE, int OUT_MODE>
+__global__ void __launch_bounds__(64 * WAVES)
+mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
+    using L = LdsW<N_IN, N_HIDDEN>;
+    // LDS carve-up (halves unless noted):
+    //   forward weights (L::SIZE) | transposed weights W0^T (N_IN, 64) W1^T (64,64) Wo^T (64,16)
+    //   | per-wave transpose tiles 2 x (64 x TP) | f32 partial dW (G_SIZE floats)
+    constexpr int LDT0 = HID + PAD;                 // W0^T rows = in units, cols = 64 hidden
+    constexpr int OFF_T0 = L::SIZE;
+    constexpr int OFF_T1 = OFF_T0 + N_IN * LDT0;    // W1^T (64,64)
+    constexpr int OFF_TO = OFF_T1 + (N_HIDDEN == 2 ? HID * (HID + PAD) : 0);   // Wo^T (64,16)
+    constexpr int LDTO = 16 + PAD;
+    constexpr int OFF_TR = OFF_TO + HID * LDTO;
+    constexpr int TR_PER_WAVE = 2 * 64 * TP;
+    constexpr int OFF_PART_H = OFF_TR + WAVES * TR_PER_WAVE;   // halves; f32 partial follows (16B aligned)
+    static_assert(OFF_PART_H % 8 == 0, "partial must be 16-byte aligned");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    h1* lds = reinterpret_cast<h1*>(smem_raw);
+    float* part = reinterpret_cast<float*>(lds + OFF_PART_H);
+
+    stage_fwd_weights<N_IN, N_HIDDEN>(weights, lds);
+    stage_weights(weights, lds + OFF_T0, HID, N_IN, true);
+    if (N_HIDDEN == 2) stage_weights(weights + L::G_W1, lds + OFF_T1, HID, HID, true);
+    stage_weights(weights + L::G_WO, lds + OFF_TO, 16, HID, true);
+    for (int t = threadIdx.x; t < L::G_SIZE; t += blockDim.x) part[t] = 0.f;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, i = lane & 31, hh = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    h1* tx = lds + OFF_TR + wave * TR_PER_WAVE;
+    h1* tdy = tx + 64 * TP;
+    const int n_tiles = (n_samples + TILE - 1) / TILE;
+
+    f32x16 gW0[2][N_IN / 32 > 0 ? N_IN / 32 : 1];
+    f32x16 gW1[2][2];
+    f32x16 gWo[1][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int n = 0; n < (N_IN / 32 > 0 ? N_IN / 32 : 1); ++n) gW0[m][n] = zero16();
+        gW1[m][0] = zero16(); gW1[m][1] = zero16();
+    }
+    gWo[0][0] = zero16(); gWo[0][1] = zero16();
+
+    for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
+        const long long s = (long long)tile * TILE + i;
+        const bool valid = s < n_samples;
+        // ---- forward recompute ----
+        half8_t xb[N_IN / 16];
+        load_input<N_IN, IN_MODE>(io.fwd, s, valid, n_samples, hh, xb);
+        f32x16 acc[2];
+        half8_t h0b[4], h1b[4];
+        layer_in<N_IN>(lds + L::OFF_W0, xb, i, hh, acc);
+        acc_to_frag<true>(acc, h0b);
+        if (N_HIDDEN == 2) {
+            layer_hid<2>(lds + L::OFF_W1, L::LDH, 64, h0b, i, hh, acc);
+            acc_to_frag<true>(acc, h1b);
+        }
+        const half8_t (&hlast)[4] = (N_HIDDEN == 2) ? h1b : h0b;
+        // ---- output gradient (D order, rows = 16 output units, registers 0..7) ----
+        // The pre-activation output is recomputed where the output non-linearity needs it; the
+        // condition is wave-uniform so the MFMAs stay in uniform control flow.
+        const bool need_out = (OUT_MODE == OUT_RGB) || (OUT_MODE == OUT_DENSITY && io.dL_dsigmas != nullptr) ||
+                              (OUT_MODE == OUT_PLAIN && io.fwd.out_act == 1);
+        f32x16 o[1];
+        o[0] = zero16();
+        if (need_out) layer_hid<1>(lds + L::OFF_WO, L::LDH, 16, hlast, i, hh, o);
+        half8_t dyb[1];
+        {
+            const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+            dyb[0] = z;
+            if (valid) {
+                if (OUT_MODE == OUT_RGB) {
+                    if (hh == 0) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float sg = sigmoidf(o[0][c]);
+                            dyb[0][c] = (h1)(io.dL_drgbs[3 * s + c] * io.loss_scale * sg * (1.0f - sg));
+                        }
+                    }
+                } else {
+                    float g[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const int u = 4 * hh + (r & 3) + 8 * (r >> 2);
+                        g[r] = (io.dL_dout16 && u < io.fwd.n_out) ? (float)io.dL_dout16[s * io.dout_ld + u] : 0.f;
+                    }
+                    if (OUT_MODE == OUT_DENSITY) {
+                        if (hh == 0 && io.dL_dsigmas) {
+                            // TruncExp backward (custom_functions.py:168-173) on the f16 h[0]
+                            const float h0 = (float)(h1)o[0][0];
+                            g[0] += io.dL_dsigmas[s] * io.loss_scale * __expf(fminf(fmaxf(h0, -15.f), 15.f));
+                        }
+                    } else if (io.fwd.out_act == 1) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) { const float sg = sigmoidf(o[0][r]); g[r] *= sg * (1.0f - sg); }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) dyb[0][r] = (h1)g[r];
+                }
+            }
+        }
+        // ---- dgrad: output layer -> last hidden ----
+        half8_t dh1b[4], dh0b[4];
+        {
+            // dH^T (64 x samples) = Wo^T (64 x 16) * dY^T : one K chunk (16 output units, D order)
+            f32x16 d[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                d[m] = mfma(ldsA_dl(lds + OFF_TO, LDTO, 32 * m + i, true, 0, hh), dyb[0], zero16());
+            half8_t (&dst)[4] = (N_HIDDEN == 2) ? dh1b : dh0b;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    half8_t b = d_to_b<false>(d[m], c2);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (!(hlast[2 * m + c2][e] > (h1)0)) b[e] = (h1)0;   // ReLU'
+                    dst[2 * m + c2] = b;
+                }
+        }
+        if (N_HIDDEN == 2) {
+            f32x16 d[2];
+            d[0] = zero16(); d[1] = zero16();
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    d[m] = mfma(ldsA_dl(lds + OFF_T1, HID + PAD, 32 * m + i, true, c, hh), dh1b[c], d[m]);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    half8_t b = d_to_b<false>(d[m], c2);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (!(h0b[2 * m + c2][e] > (h1)0)) b[e] = (h1)0;
+                    dh0b[2 * m + c2] = b;
+                }
+        }
+        // ---- dgrad into the network input ----
+        if (io.dL_din) {
+            constexpr int MT_IN = (N_IN + 31) / 32;
+            f32x16 d[MT_IN];
+#pragma unroll
+            for (int m = 0; m < MT_IN; ++m) d[m] = zero16();
+            // IN_SH_H only needs input rows 16..31 (the h half); map them to tile rows 0..15
+            const int row_off = (IN_MODE == IN_SH_H) ? 16 : 0;
+            const int n_rows = (IN_MODE == IN_SH_H) ? 16 : N_IN;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int m = 0; m < MT_IN; ++m)
+                    d[m] = mfma(ldsA_dl(lds + OFF_T0, LDT0, row_off + 32 * m + i, (32 * m + i) < n_rows, c, hh), dh0b[c], d[m]);
+            if (valid) {
+                if (IN_MODE == IN_LEVELMAJOR) {
+                    // row (r&3)+8(r>>2)+4hh of tile 0 = feature index; pairs (r, r+1) are one level
+                    half2_t* df = reinterpret_cast<half2_t*>(io.dL_din);
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const int f = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        half2_t v; v[0] = (h1)d[0][r]; v[1] = (h1)d[0][r + 1];
+                        __builtin_nontemporal_store(v, df + (size_t)(f >> 1) * n_samples + s);
+                    }
+                } else if (IN_MODE == IN_SH_H) {
+                    half4_t lo, hi;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { lo[e] = (h1)d[0][e]; hi[e] = (h1)d[0][4 + e]; }
+                    *reinterpret_cast<half4_t*>(io.dL_din + s * 16 + 4 * hh) = lo;
+                    *reinterpret_cast<half4_t*>(io.dL_din + s * 16 + 8 + 4 * hh) = hi;
+                } else {
+#pragma unroll
+                    for (int m = 0; m < MT_IN; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int u = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                            if (u < N_IN) io.dL_din[s * N_IN + u] = (h1)d[m][r];
+                        }
+                }
+            }
+        }
+        // ---- wgrad (samples on K: transpose through the wave-private LDS tiles) ----
+        // layer 0: dW0 (64 x N_IN) = dH0^T * X
+        tr_write_nat<N_IN / 16>(tx, xb, i, hh);
+        if (N_IN < 32) {   // zero the unused rows of the 32-wide N tile
+            const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+            half8_t zz[1] = {z};
+            tr_write_nat<1>(tx + 16 * TP, zz, i, hh);
+        }
+        tr_write_dl<4>(tdy, dh0b, i, hh);
+        wave_lds_sync();
+        wgrad_tile<2, (N_IN / 32 > 0 ? N_IN / 32 : 1)>(tdy, tx, i, hh, gW0);
+        wave_lds_sync();
+        if (N_HIDDEN == 2) {   // layer 1: dW1 (64 x 64) = dH1^T * H0
+            tr_write_dl<4>(tx, h0b, i, hh);
+            tr_write_dl<4>(tdy, dh1b, i, hh);
+            wave_lds_sync();
+            wgrad_tile<2, 2>(tdy, tx, i, hh, gW1);
+            wave_lds_sync();
+        }
+        // output layer: dWo (16 x 64) = dY^T * Hlast   (dY rows 16..31 of the M tile are zero)
+        tr_write_dl<4>(tx, hlast, i, hh);
+        {
+            const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+            half8_t two[2] = {dyb[0], z};
+            tr_write_dl<2>(tdy, two, i, hh);
+        }
+        wave_lds_sync();
+        wgrad_tile<1, 2>(tdy, tx, i, hh, gWo);
+        wave_lds_sync();
+    }
+    // ---- reduce the 4 waves' dW into LDS, then one coalesced partial row per workgroup ----
+    wgrad_flush<2, (N_IN / 32 > 0 ? N_IN / 32 : 1)>(part, N_IN, HID, N_IN, i, hh, gW0);
+    if (N_HIDDEN == 2) wgrad_flush<2, 2>(part + L::G_W1, HID, HID, HID, i, hh, gW1);
+    wgrad_flush<1, 2>(part + L::G_WO, HID, 16, HID, i, hh, gWo);
+    __syncthreads();
+    float* out = io.wgrad_partial + (size_t)blockIdx.x * L::G_SIZE;
+    for (int t = threadIdx.x; t < L::G_SIZE; t += blockDim.x) out[t] = part[t];
+}
+
+template <int N_IN, int N_HIDDEN>
+constexpr int fwd_smem_bytes() { return LdsW<N_IN, N_HIDDEN>::SIZE * 2; }
+template <int N_IN, int N_HIDDEN>
+constexpr int bwd_smem_bytes() {
+    using L = LdsW<N_IN, N_HIDDEN>;
+    return (L::SIZE + N_IN * (HID + PAD) + (N_HIDDEN == 2 ? HID * (HID + PAD) : 0) + HID * (16 + PAD) +
+            WAVES * 2 * 64 * TP) * 2 + L::G_SIZE * 4;
+}
+
+int fwd_grid(int n_samples) {
+    const int n_tiles = (n_samples + TILE - 1) / TILE;
+    const int blocks = (n_tiles + WAVES - 1) / WAVES;
+    return blocks < 1024 ? (blocks < 1 ? 1 : blocks) : 1024;
+}
+int bwd_grid(int n_samples) {
+    const int n_tiles = (n_samples + TILE - 1) / TILE;
+    const int blocks = (n_tiles + WAVES - 1) / WAVES;
+    return blocks < 256 ? (blocks < 1 ? 1 : blocks) : 256;   // one workgroup per CU; bounds the partial buffer
+}
+
+template <int N_IN, int N_HIDDEN, int IN_MODE, int OUT_MODE>
+int launch_fwd(const MlpIO& io, const h1* w, int n_samples, hipStream_t st) {
+    constexpr int smem = fwd_smem_bytes<N_IN, N_HIDDEN>();
+    mlp_fwd_kernel<N_IN, N_HIDDEN, IN_MODE, OUT_MODE><<<dim3(fwd_grid(n_samples)), dim3(64 * WAVES), smem, st>>>(io, w, n_samples);
+    return NGP_LAUNCH_RESULT();
+}
+template <int N_IN, int N_HIDDEN, int IN_MODE, int OUT_MODE>
+int launch_bwd(const MlpBwdIO& io, const h1* w, int n_samples, hipStream_t st) {
+    constexpr int smem = bwd_smem_bytes<N_IN, N_HIDDEN>();
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    auto kern = mlp_bwd_kernel<N_IN, N_HIDDEN, IN_MODE, OUT_MODE>;
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    kern<<<dim3(bwd_grid(n_samples)), dim3(64 * WAVES), smem, st>>>(io, w, n_samples);
+    return NGP_LAUNCH_RESULT();
+}
+
+__global__ void __launch_bounds__(256)
+sh4_kernel(const float* __restrict__ d01, int n, h1* __restrict__ out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    // tcnn.Encoding receives (d+1)/2 and maps it back (networks.py:144; spherical_harmonics.h)
+    const float x = d01[3 * s] * 2.f - 1.f, y = d01[3 * s + 1] * 2.f - 1.f, z = d01[3 * s + 2] * 2.f - 1.f;
+    float sh[16];
+    sh4(x, y, z, sh);
+    half8_t a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = (h1)sh[e]; b[e] = (h1)sh[8 + e]; }
+    *reinterpret_cast<half8_t*>(out + (size_t)s * 16) = a;
+    *reinterpret_cast<half8_t*>(out + (size_t)s * 16 + 8) = b;
+}
+
+}  // namespace
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+int ngp_field_fwd(const ngp_half* feats, const float* dirs, const ngp_half* density_w, const ngp_half* rgb_w,
+                  int n_samples, float* sigmas, float* rgbs, ngp_half* h_out, ngp_stream_t stream) {
+    if (n_samples < 0) return NGP_EINVAL;
+    if (n_samples == 0) return 0;
+    NGP_CHECK_PTR(feats); NGP_CHECK_PTR(density_w); NGP_CHECK_PTR(sigmas);
+    const bool want_rgb = rgbs != nullptr;
+    if (want_rgb) { NGP_CHECK_PTR(dirs); NGP_CHECK_PTR(rgb_w); NGP_CHECK_PTR(h_out); }
+    MlpIO d = {};
+    d.in = (const h1*)feats; d.out16 = (h1*)h_out; d.out_ld = 16; d.n_out = 16; d.sigmas = sigmas;
+    int rc = launch_fwd<32, 1, IN_LEVELMAJOR, OUT_DENSITY>(d, (const h1*)density_w, n_samples, ngp_stream(stream));
+    if (rc || !want_rgb) return rc;
+    MlpIO r = {};
+    r.in = (const h1*)h_out; r.dirs = dirs; r.rgbs = rgbs; r.n_out = 3;
+    return launch_fwd<32, 2, IN_SH_H, OUT_RGB>(r, (const h1*)rgb_w, n_samples, ngp_stream(stream));
+}
+
+int ngp_field_bwd_partials(int n_samples) { return n_samples <= 0 ? 0 : bwd_grid(n_samples); }
+
+int ngp_field_bwd(const ngp_half* feats, const float* dirs, const ngp_half* h, const ngp_half* density_w,
+                  const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale,
+                  int n_samples, ngp_half* dh_scratch, ngp_half* dfeats, float* wgrad_partial, ngp_stream_t stream) {
+    if (n_samples < 0) return NGP_EINVAL;
+    if (n_samples == 0) return 0;
+    NGP_CHECK_PTR(feats); NGP_CHECK_PTR(density_w); NGP_CHECK_PTR(dfeats); NGP_CHECK_PTR(wgrad_partial);
+    const int n_part = bwd_grid(n_samples);
+    const bool have_rgb = dL_drgbs != nullptr;
+    float* part_density = wgrad_partial;
+    float* part_rgb = wgrad_partial + (size_t)n_part * NGP_DENSITY_NET_PARAMS;
+    if (have_rgb) {
+        NGP_CHECK_PTR(dirs); NGP_CHECK_PTR(h); NGP_CHECK_PTR(rgb_w); NGP_CHECK_PTR(dh_scratch);
+        MlpBwdIO r = {};
+        r.fwd.in = (const h1*)h; r.fwd.dirs = dirs; r.fwd.n_out = 3;
+        r.dL_drgbs = dL_drgbs; r.loss_scale = loss_scale; r.dL_din = (h1*)dh_scratch; r.wgrad_partial = part_rgb;
+        const int rc = launch_bwd<32, 2, IN_SH_H, OUT_RGB>(r, (const h1*)rgb_w, n_samples, ngp_stream(stream));
+        if (rc) return rc;
+    }
+    MlpBwdIO d = {};
+    d.fwd.in = (const h1*)feats; d.fwd.n_out = 16; d.fwd.out_ld = 16;
+    d.dL_dout16 = have_rgb ? (const h1*)dh_scratch : nullptr; d.dout_ld = 16;
+    d.dL_dsigmas = dL_dsigmas; d.loss_scale = loss_scale; d.dL_din = (h1*)dfeats; d.wgrad_partial = part_density;
+    return launch_bwd<32, 1, IN_LEVELMAJOR, OUT_DENSITY>(d, (const h1*)density_w, n_samples, ngp_stream(stream));
+}
+
+int ngp_mlp_fwd(const ngp_half* in, const ngp_half* weights, int n_in, int n_hidden, int n_out, int out_act,
+                int n_samples, ngp_half* out, ngp_stream_t stream) {
+    if (n_samples < 0) return NGP_EINVAL;
+    if (n_out < 1 || n_out > 16 || (out_act != 0 && out_act != 1)) return NGP_EUNSUP;
+    if (n_samples == 0) return 0;
+    NGP_CHECK_PTR(in); NGP_CHECK_PTR(weights); NGP_CHECK_PTR(out);
+    MlpIO io = {};
+    io.in = (const h1*)in; io.out16 = (h1*)out; io.out_ld = n_out; io.n_out = n_out; io.out_act = out_act;
+    hipStream_t st = ngp_stream(stream);
+    const h1* w = (const h1*)weights;
+    if (n_in == 16 && n_hidden == 1) return launch_fwd<16, 1, IN_ROWMAJOR, OUT_PLAIN>(io, w, n_samples, st);
+    if (n_in == 16 && n_hidden == 2) return launch_fwd<16, 2, IN_ROWMAJOR, OUT_PLAIN>(io, w, n_samples, st);
+    if (n_in == 32 && n_hidden == 1) return launch_fwd<32, 1, IN_ROWMAJOR, OUT_PLAIN>(io, w, n_samples, st);
+    if (n_in == 32 && n_hidden == 2) return launch_fwd<32, 2, IN_ROWMAJOR, OUT_PLAIN>(io, w, n_samples, st);
+    if (n_in == 64 && n_hidden == 1) return launch_fwd<64, 1, IN_ROWMAJOR, OUT_PLAIN>(io, w, n_samples, st);
+    if (n_in == 64 && n_hidden == 2) return launch_fwd<64, 2, IN_ROWMAJOR, OUT_PLAIN>(io, w, n_samples, st);
+    return NGP_EUNSUP;
+}
+
+int ngp_mlp_bwd_partials(int n_samples) { return n_samples <= 0 ? 0 : bwd_grid(n_samples); }
+
+int ngp_mlp_bwd(const ngp_half* in, const ngp_half* weights, const ngp_half* dL_dout, int n_in, int n_hidden,
+                int n_out, int out_act, int n_samples, ngp_half* dL_din, float* wgrad_partial, ngp_stream_t stream) {
+    if (n_samples < 0) return NGP_EINVAL;
+    if (n_out < 1 || n_out > 16 || (out_act != 0 && out_act != 1)) return NGP_EUNSUP;
+    if (n_samples == 0) return 0;
+    NGP_CHECK_PTR(in); NGP_CHECK_PTR(weights); NGP_CHECK_PTR(dL_dout); NGP_CHECK_PTR(wgrad_partial);
+    MlpBwdIO io = {};
+    io.fwd.in = (const h1*)in; io.fwd.n_out = n_out; io.fwd.out_act = out_act; io.fwd.out_ld = n_out;
+    io.dL_dout16 = (const h1*)dL_dout; io.dout_ld = n_out; io.loss_scale = 1.0f;
+    io.dL_din = (h1*)dL_din; io.wgrad_partial = wgrad_partial;
+    hipStream_t st = ngp_stream(stream);
+    const h1* w = (const h1*)weights;
+    if (n_in == 16 && n_hidden == 1) return launch_bwd<16, 1, IN_ROWMAJOR, OUT_PLAIN>(io, w, n_samples, st);
+    if (n_in == 16 && n_hidden == 2) return launch_bwd<16, 2, IN_ROWMAJOR, OUT_PLAIN>(io, w, n_samples, st);
+    if (n_in == 32 && n_hidden == 1) return launch_bwd<32, 1, IN_ROWMAJOR, OUT_PLAIN>(io, w, n_samples, st);
+    if (n_in == 32 && n_hidden == 2) return launch_bwd<32, 2, IN_ROWMAJOR, OUT_PLAIN>(io, w, n_samples, st);
+    if (n_in == 64 && n_hidden == 1) return launch_bwd<64, 1, IN_ROWMAJOR, OUT_PLAIN>(io, w, n_samples, st);
+    if (n_in == 64 && n_hidden == 2) return launch_bwd<64, 2, IN_ROWMAJOR, OUT_PLAIN>(io, w, n_samples, st);
+    return NGP_EUNSUP;
+}
+
+int ngp_sh4_fwd(const float* dirs01, int n_samples, ngp_half* out, ngp_stream_t stream) {
+    if (n_samples < 0) return NGP_EINVAL;
+    if (n_samples == 0) return 0;
+    NGP_CHECK_PTR(dirs01); NGP_CHECK_PTR(out);
+    hipLaunchKernelGGL(sh4_kernel, dim3(ngp_div_up(n_samples, 256)), dim3(256), 0, ngp_stream(stream), dirs01, n_samples, (h1*)out);
+    return NGP_LAUNCH_RESULT();
+}
+
+}  // extern "C"

@@ -1,0 +1,40 @@
+// Shared device helpers for the gfx950 Instant-NGP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ngp_hip.h"
+
+#define NGP_WAVE 64
+
+#define NGP_CHECK_PTR(p) do { if ((p) == nullptr) return NGP_EINVAL; } while (0)
+#define NGP_LAUNCH_RESULT() ((int)hipGetLastError())
+
+static inline hipStream_t ngp_stream(ngp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int ngp_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- Morton code (3 x 10 bit), semantics of raymarching.cu:35-60 ----
+__device__ __forceinline__ uint32_t ngp_expand_bits(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t ngp_morton3D(uint32_t x, uint32_t y, uint32_t z) {
+    return ngp_expand_bits(x) | (ngp_expand_bits(y) << 1) | (ngp_expand_bits(z) << 2);
+}
+__device__ __forceinline__ uint32_t ngp_compact_bits(uint32_t x) {
+    x &= 0x49249249u;
+    x = (x | (x >> 2)) & 0xC30C30C3u;
+    x = (x | (x >> 4)) & 0x0F00F00Fu;
+    x = (x | (x >> 8)) & 0xFF0000FFu;
+    x = (x | (x >> 16)) & 0x0000FFFFu;
+    return x;
+}
+
+// ---- wave64 helpers ----
+__device__ __forceinline__ float ngp_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
