@@ -1,0 +1,127 @@
+"""ctypes binding of libngp_hip.so (C ABI: include/ngp_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails this raises.
+torch is imported first so that the library binds to the HIP runtime torch already loaded
+(same SONAME libamdhip64.so.7) and torch's streams/pointers are valid inside it.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the CDLL below)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libngp_hip.so")
+
+P = C.c_void_p
+I = C.c_int
+F = C.c_float
+L = C.c_int64
+
+NGP_MAX_LEVELS = 16
+
+
+class GridMeta(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("n_features", C.c_int32),
+                ("offset", C.c_uint32 * (NGP_MAX_LEVELS + 1)),
+                ("resolution", C.c_uint32 * NGP_MAX_LEVELS),
+                ("scale", C.c_float * NGP_MAX_LEVELS)]
+
+
+# name -> argtypes (every function returns int, except the two queries noted below)
+_PROTOS = {
+    "ngp_ray_aabb_intersect": [P, P, P, P, I, I, I, P, P, P, P],
+    "ngp_ray_sphere_intersect": [P, P, P, P, I, I, I, P, P, P, P],
+    "ngp_ray_aabb_near": [P, P, P, P, F, I, P, P],
+    "ngp_morton3D": [P, I, P, P],
+    "ngp_morton3D_invert": [P, I, P, P],
+    "ngp_packbits": [P, I, I, F, P, P],
+    "ngp_density_grid_update": [P, P, P, F, I, P, P],
+    "ngp_packbits_auto": [P, I, P, F, P, P],
+    "ngp_cells_to_xyz": [P, P, I, I, F, P, P],
+    "ngp_raymarching_train_count": [P, P, P, P, I, F, F, P, I, I, I, P, P, P, P],
+    "ngp_raymarching_train_write": [P, P, P, P, F, F, I, I, I, P, P, P, P, P],
+    "ngp_raymarching_test": [P, P, P, P, P, I, F, F, I, I, I, I, P, P, P, P, P, P],
+    "ngp_composite_train_fw": [P, P, P, P, P, F, I, I, P, P, P, P, P, P],
+    "ngp_composite_train_bw": [P] * 13 + [F, I, I, P, P, P],
+    "ngp_composite_test_fw": [P, P, P, P, P, F, P, I, I, P, P, P, P],
+    "ngp_distortion_loss_fw": [P, P, P, P, I, I, P, P, P, P],
+    "ngp_distortion_loss_bw": [P, P, P, P, P, P, P, I, I, P, P],
+    "ngp_grid_meta_init": [C.POINTER(GridMeta), I, I, I, I, F],
+    "ngp_hashgrid_fwd": [P, P, P, P, C.POINTER(GridMeta), I, P, P],
+    "ngp_hashgrid_bwd": [P, P, P, P, C.POINTER(GridMeta), I, P, I, P],
+    "ngp_field_fwd": [P, P, P, P, I, P, P, P, P],
+    "ngp_field_bwd_partials": [I],
+    "ngp_field_bwd": [P, P, P, P, P, P, P, F, I, P, P, P, P],
+    "ngp_mlp_fwd": [P, P, I, I, I, I, I, P, P],
+    "ngp_mlp_bwd_partials": [I],
+    "ngp_mlp_bwd": [P, P, P, I, I, I, I, I, P, P, P],
+    "ngp_sh4_fwd": [P, I, P, P],
+    "ngp_feats_to_rowmajor": [P, I, I, P, P],
+    "ngp_feats_from_rowmajor": [P, I, I, P, P],
+    "ngp_adam_step": [P, P, P, I, P, P, L, F, F, F, F, F, I, F, P, P],
+    "ngp_reduce_partials": [P, I, I, P, P],
+    "ngp_cast_f32_to_f16": [P, L, P, P],
+    "ngp_cast_f16_to_f32": [P, L, F, P, P],
+    "ngp_nerf_loss": [P, P, P, P, F, F, I, P, P, P, P, P],
+    "ngp_abi_version": [],
+}
+_COUNT_QUERIES = ("ngp_field_bwd_partials", "ngp_mlp_bwd_partials", "ngp_abi_version")
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libngp_hip.so is missing (%s): run `python -m ngp_pl_amd.build` or "
+                               "__graft_entry__.build(); there is no CPU/eager fallback" % LIB_PATH)
+        h = C.CDLL(LIB_PATH)
+        for name, argtypes in _PROTOS.items():
+            f = getattr(h, name)
+            f.argtypes = argtypes
+            f.restype = I
+        h.ngp_build_arch.argtypes = []
+        h.ngp_build_arch.restype = C.c_char_p
+        _lib = h
+    return _lib
+
+
+def exported_symbols():
+    return list(_PROTOS) + ["ngp_build_arch"]
+
+
+class NgpError(RuntimeError):
+    pass
+
+
+def call(name, *args):
+    """Invoke a C-ABI entry point; non-zero status raises."""
+    rc = getattr(lib(), name)(*args)
+    if name in _COUNT_QUERIES:
+        return rc
+    if rc != 0:
+        kind = {-1: "NGP_EINVAL (bad argument)", -2: "NGP_EUNSUP (unsupported configuration)"}.get(rc, "hipError_t %d" % rc)
+        raise NgpError("%s failed: %s" % (name, kind))
+    return 0
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    """Mirrors CHECK_INPUT of the reference (include/utils.h:4-6): device + contiguity."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("tensor must be a CUDA (HIP) tensor")
+        if not t.is_contiguous():
+            raise RuntimeError("tensor must be contiguous")

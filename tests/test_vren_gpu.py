@@ -1,0 +1,207 @@
+"""GPU parity: ngp_pl_amd.vren (HIP, through the C ABI) against the CPU oracle on the same inputs.
+
+Bars (BASELINE.json north_star): packed sample indices / ray counts bit-exact; t, dt, xyz
+bit-exact (the oracle's fma mode states the contraction nvcc applies, the kernels use the same
+explicit fmaf); composited RGB / opacity / depth and their gradients within 1e-4 abs (we test
+1e-5; the only modelled difference is __expf vs expf).
+"""
+import numpy as np
+import pytest
+import torch
+
+from ngp_pl_amd import synthetic as syn
+from oracle.vren_oracle import Oracle
+from tests.helpers import aabb_hits, make_rays
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vren():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    import ngp_pl_amd.vren as v
+    return v
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return Oracle(fma=True)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def same_bits(t, a, what):
+    b = t.cpu().numpy()
+    assert b.shape == a.shape, "%s shape %s vs %s" % (what, b.shape, a.shape)
+    if a.dtype == np.float32:
+        a, b = a.view(np.uint32), b.view(np.uint32)
+    assert np.array_equal(a, b), "%s: %d of %d differ" % (what, (a != b).sum(), a.size)
+
+
+def test_morton_packbits(vren, oracle):
+    g = np.random.RandomState(0)
+    # known answers: one bit per axis, and the all-ones corner
+    kat = torch.tensor([[1, 0, 0], [0, 1, 0], [0, 0, 1], [127, 127, 127], [0, 0, 0]], dtype=torch.int32).cuda()
+    assert vren.morton3D(kat).cpu().tolist() == [1, 2, 4, 2097151, 0]
+    coords = g.randint(0, 128, (100000, 3)).astype(np.int32)
+    same_bits(vren.morton3D(dev(coords)), oracle.morton3D(coords), "morton3D")
+    allidx = torch.arange(128 ** 3, dtype=torch.int32).cuda()        # full round trip over the grid
+    assert torch.equal(vren.morton3D(vren.morton3D_invert(allidx)), allidx)
+    idx = g.randint(0, 128 ** 3, 100000).astype(np.int32)
+    same_bits(vren.morton3D_invert(dev(idx)), oracle.morton3D_invert(idx), "morton3D_invert")
+    grid = g.rand(2 * 128 ** 3).astype(np.float32); grid[::5] = -1
+    b0 = np.zeros(grid.size // 8, np.uint8); oracle.packbits(grid, 0.4, b0)
+    b1 = torch.zeros(grid.size // 8, dtype=torch.uint8).cuda()
+    vren.packbits(dev(grid), 0.4, b1)
+    same_bits(b1, b0, "packbits")
+    # empty input
+    assert vren.morton3D(torch.zeros(0, 3, dtype=torch.int32).cuda()).shape == (0,)
+
+
+def test_intersections(vren, oracle):
+    ro, rd = make_rays(20000, seed=1)
+    c = np.stack(np.meshgrid(*[np.array([-0.3, 0.0, 0.3])] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    h = np.full_like(c, 0.12)
+    for mh in (1, 8):
+        got = vren.ray_aabb_intersect(dev(ro), dev(rd), dev(c), dev(h), mh)
+        want = oracle.ray_aabb_intersect(ro, rd, c, h, mh)
+        for t, a, name in zip(got, want, ("hit_cnt", "hits_t", "hits_idx")):
+            same_bits(t, a, "aabb %s mh=%d" % (name, mh))
+    # the hot-path call: one box, one hit (rendering.py:27-28)
+    got = vren.ray_aabb_intersect(dev(ro), dev(rd), torch.zeros(1, 3).cuda(), torch.full((1, 3), 0.5).cuda(), 1)
+    want = oracle.ray_aabb_intersect(ro, rd, np.zeros((1, 3), np.float32), np.full((1, 3), 0.5, np.float32), 1)
+    for t, a, name in zip(got, want, ("hit_cnt", "hits_t", "hits_idx")):
+        same_bits(t, a, "scene box " + name)
+    assert (want[1][:, 0, 0] == -1).any() and (want[1][:, 0, 0] == 0).any()   # misses and inside-origin covered
+    radii = np.random.RandomState(2).uniform(0.05, 0.2, c.shape[0]).astype(np.float32)
+    got = vren.ray_sphere_intersect(dev(ro), dev(rd), dev(c), dev(radii), 8)
+    want = oracle.ray_sphere_intersect(ro, rd, c, radii, 8)
+    assert np.array_equal(got[0].cpu().numpy(), want[0])
+    np.testing.assert_allclose(got[1].cpu().numpy(), want[1], rtol=2e-3, atol=1e-6)   # cancellation in the discriminant
+
+
+CFGS = [
+    dict(cascades=1, scale=0.5, esf=0.0, fill=0.08, n=8192),
+    dict(cascades=1, scale=0.5, esf=0.0, fill=1.0, n=2048),
+    dict(cascades=3, scale=2.0, esf=1 / 256, fill=0.15, n=4096),
+    dict(cascades=1, scale=0.5, esf=0.0, fill=0.0, n=512),     # nothing occupied: S = 0
+]
+
+
+@pytest.mark.parametrize("cfg", CFGS, ids=["synthetic", "dense", "cascaded", "empty"])
+def test_raymarching_train(vren, oracle, cfg):
+    n = cfg["n"]
+    ro, rd = make_rays(n, seed=3)
+    if cfg["scale"] > 0.5:
+        ro = ro * 1.5
+    if cfg["fill"] >= 1.0:
+        bf = np.full(cfg["cascades"] * 128 ** 3 // 8, 255, np.uint8)
+    elif cfg["fill"] == 0.0:
+        bf = np.zeros(cfg["cascades"] * 128 ** 3 // 8, np.uint8)
+    else:
+        bf = syn.random_blob_bitfield(cfg["cascades"], 128, cfg["fill"], seed=4)
+    ht = aabb_hits(oracle, ro, rd, cfg["scale"])
+    noise = np.random.RandomState(5).rand(n).astype(np.float32)
+    want = oracle.raymarching_train(ro, rd, ht, bf, cfg["cascades"], cfg["scale"], cfg["esf"], noise, 128, 1024)
+    got = vren.raymarching_train(dev(ro), dev(rd), dev(ht), dev(bf), cfg["cascades"], cfg["scale"], cfg["esf"],
+                                 dev(noise), 128, 1024)
+    for t, a, name in zip(got, want, ("rays_a", "xyzs", "dirs", "deltas", "ts", "counter")):
+        same_bits(t, a, "train " + name)
+    if cfg["fill"] >= 1.0:
+        assert want[0][:, 2].max() > 400      # long rays exercised (cube crossing ~591 steps)
+
+
+@pytest.mark.parametrize("cfg", CFGS[:3], ids=["synthetic", "dense", "cascaded"])
+def test_raymarching_test(vren, oracle, cfg):
+    n = 4096
+    ro, rd = make_rays(n, seed=7)
+    if cfg["scale"] > 0.5:
+        ro = ro * 1.5
+    bf = (np.full(cfg["cascades"] * 128 ** 3 // 8, 255, np.uint8) if cfg["fill"] >= 1.0
+          else syn.random_blob_bitfield(cfg["cascades"], 128, cfg["fill"], seed=8))
+    ht = aabb_hits(oracle, ro, rd, cfg["scale"])
+    alive = np.arange(0, n, 2, dtype=np.int64)        # a non-trivial alive subset
+    h_cpu = ht.copy(); h_gpu = dev(ht)
+    for ns in (1, 3, 8):
+        want = oracle.raymarching_test(ro, rd, h_cpu, alive, bf, cfg["cascades"], cfg["scale"], cfg["esf"], 128, 1024, ns)
+        got = vren.raymarching_test(dev(ro), dev(rd), h_gpu, dev(alive), dev(bf), cfg["cascades"], cfg["scale"], cfg["esf"],
+                                    128, 1024, ns)
+        for t, a, name in zip(got, want, ("xyzs", "dirs", "deltas", "ts", "N_eff")):
+            same_bits(t, a, "test %s ns=%d" % (name, ns))
+        same_bits(h_gpu, h_cpu, "hits_t ns=%d" % ns)
+
+
+def _packed(oracle, n=8192, seed=6):
+    ro, rd = make_rays(n, seed=seed)
+    bf = syn.random_blob_bitfield(1, 128, 0.1, seed=seed)
+    ht = aabb_hits(oracle, ro, rd)
+    noise = np.random.RandomState(seed).rand(n).astype(np.float32)
+    rays_a, xyzs, dirs, deltas, ts, _ = oracle.raymarching_train(ro, rd, ht, bf, 1, 0.5, 0.0, noise, 128, 1024)
+    g = np.random.RandomState(seed + 1)
+    S = ts.shape[0]
+    sigmas = (g.rand(S).astype(np.float32) ** 3) * 400
+    rgbs = g.rand(S, 3).astype(np.float32)
+    return rays_a, sigmas, rgbs, deltas, ts
+
+
+def test_composite_train(vren, oracle):
+    rays_a, sigmas, rgbs, deltas, ts = _packed(oracle)
+    want = oracle.composite_train_fw(sigmas, rgbs, deltas, ts, rays_a, 1e-4)
+    got = vren.composite_train_fw(dev(sigmas), dev(rgbs), dev(deltas), dev(ts), dev(rays_a), 1e-4)
+    # closed form: constant sigma along a ray -> opacity = 1 - exp(-sigma * sum(delta)) is covered in test_properties
+    tol = dict(rtol=0, atol=1e-5)
+    mism = (got[0].cpu().numpy() != want[0]).mean()
+    assert mism < 1e-3, "total_samples mismatch fraction %g (threshold crossings only)" % mism
+    for t, a, name in zip(got[1:], want[1:], ("opacity", "depth", "rgb", "ws")):
+        np.testing.assert_allclose(t.cpu().numpy(), a, err_msg=name, **tol)
+    g = np.random.RandomState(9)
+    R, S = rays_a.shape[0], sigmas.shape[0]
+    dO, dD, dRGB, dW = (g.randn(R).astype(np.float32), g.randn(R).astype(np.float32),
+                        g.randn(R, 3).astype(np.float32), g.randn(S).astype(np.float32))
+    total, opacity, depth, rgb, ws = want
+    wb = oracle.composite_train_bw(dO, dD, dRGB, dW, sigmas, rgbs, ws, deltas, ts, rays_a, opacity, depth, rgb, 1e-4)
+    gb = vren.composite_train_bw(dev(dO), dev(dD), dev(dRGB), dev(dW), dev(sigmas), dev(rgbs), dev(ws), dev(deltas), dev(ts),
+                                 dev(rays_a), dev(opacity), dev(depth), dev(rgb), 1e-4)
+    # gradients w.r.t. sigma are O(delta * |seeds|): compare relative to their scale
+    scale = np.abs(wb[0]).max()
+    np.testing.assert_allclose(gb[0].cpu().numpy() / scale, wb[0] / scale, rtol=0, atol=1e-5, err_msg="dL_dsigmas")
+    np.testing.assert_allclose(gb[1].cpu().numpy(), wb[1], rtol=0, atol=1e-5, err_msg="dL_drgbs")
+    # distortion loss on the same packing
+    wl = oracle.distortion_loss_fw(ws, deltas, ts, rays_a)
+    gl = vren.distortion_loss_fw(dev(ws), dev(deltas), dev(ts), dev(rays_a))
+    for t, a, name in zip(gl, wl, ("loss", "ws_incl", "wts_incl")):
+        np.testing.assert_allclose(t.cpu().numpy(), a, rtol=1e-5, atol=1e-6, err_msg="distortion " + name)
+    dl = g.randn(R).astype(np.float32)
+    wdb = oracle.distortion_loss_bw(dl, wl[1], wl[2], ws, deltas, ts, rays_a)
+    gdb = vren.distortion_loss_bw(dev(dl), dev(wl[1]), dev(wl[2]), dev(ws), dev(deltas), dev(ts), dev(rays_a))
+    np.testing.assert_allclose(gdb.cpu().numpy(), wdb, rtol=1e-5, atol=1e-5, err_msg="distortion bw")
+
+
+def test_composite_test_fw(vren, oracle):
+    g = np.random.RandomState(11)
+    n_rays, na, ns = 5000, 3000, 4
+    alive0 = np.sort(g.choice(n_rays, na, replace=False)).astype(np.int64)
+    sig = (g.rand(na, ns).astype(np.float32) ** 2) * 3000
+    rgbs = g.rand(na, ns, 3).astype(np.float32)
+    deltas = np.full((na, ns), 1.7e-3, np.float32); ts = g.rand(na, ns).astype(np.float32)
+    n_eff = g.randint(0, ns + 1, na).astype(np.int32)
+    hits_t = np.zeros((n_rays, 2), np.float32)
+    o0 = g.rand(n_rays).astype(np.float32) * 0.5
+    a_c, o_c, d_c, c_c = alive0.copy(), o0.copy(), np.zeros(n_rays, np.float32), np.zeros((n_rays, 3), np.float32)
+    oracle.composite_test_fw(sig, rgbs, deltas, ts, hits_t, a_c, 1e-4, n_eff, o_c, d_c, c_c)
+    a_g, o_g, d_g, c_g = dev(alive0), dev(o0), torch.zeros(n_rays).cuda(), torch.zeros(n_rays, 3).cuda()
+    vren.composite_test_fw(dev(sig), dev(rgbs), dev(deltas), dev(ts), dev(hits_t), a_g, 1e-4, dev(n_eff), o_g, d_g, c_g)
+    assert (a_g.cpu().numpy() != a_c).mean() < 1e-3
+    for t, a, name in ((o_g, o_c, "opacity"), (d_g, d_c, "depth"), (c_g, c_c, "rgb")):
+        np.testing.assert_allclose(t.cpu().numpy(), a, rtol=0, atol=1e-5, err_msg=name)
+
+
+def test_rejects_cpu_and_noncontiguous(vren):
+    x = torch.zeros(4, 3)
+    with pytest.raises(RuntimeError):      # CHECK_CUDA of the reference (include/utils.h:4)
+        vren.morton3D(x.int())
+    y = torch.zeros(3, 4, dtype=torch.int32).cuda().t()
+    with pytest.raises(RuntimeError):      # CHECK_CONTIGUOUS (include/utils.h:5)
+        vren.morton3D(y)
