@@ -206,6 +206,14 @@ int ngp_hashgrid_bwd(const float* x, const float* xyz_min, const float* xyz_max,
                      const ngp_half* dfeats /* [L][S] half2 */, const ngp_grid_meta* meta,
                      int n_samples, void* grad_table, int grad_is_f32, ngp_stream_t stream);
 
+/* The same gradient without global atomics (the fast path; DESIGN.md "hash grid backward"):
+ * every workgroup owns a 32768-entry slice of the table in LDS, scans all samples of its level
+ * and keeps the updates that fall in its slice (ds_pk_add_f16), then stores the slice.
+ * grad_table (total,2) f16 is OVERWRITTEN entirely (no zero-fill needed, no accumulation). */
+int ngp_hashgrid_bwd_sliced(const float* x, const float* xyz_min, const float* xyz_max,
+                            const ngp_half* dfeats /* [L][S] half2 */, const ngp_grid_meta* meta,
+                            int n_samples, ngp_half* grad_table, ngp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * tinycudann: FullyFusedMLP + SphericalHarmonics  (call sites networks.py:49-77)
  * ------------------------------------------------------------------------------------------ */
@@ -218,23 +226,38 @@ int ngp_hashgrid_bwd(const float* x, const float* xyz_min, const float* xyz_max,
 #define NGP_DENSITY_NET_PARAMS 3072
 #define NGP_RGB_NET_PARAMS     7168
 
-/* Fused field forward (NGP.forward, networks.py:132-153, rgb_act == "Sigmoid"):
- *   h = density_net(feats) [f16], sigma = exp(h[0]), sh = SH4(d/|d|), rgb = sigmoid(rgb_net([sh,h]))
- * feats [L=16][S] half2; dirs (S,3) f32 un-normalised (may be NULL with rgbs NULL: density only).
- * out: sigmas (S) f32; rgbs (S,3) f32 (values rounded through f16 as tiny-cuda-nn emits them);
- *      h_out (S,16) f16 optional (NULL to skip). */
+/* The two halves of NGP.forward (networks.py:94-107,132-153, rgb_act == "Sigmoid"):
+ *   density: h = density_net(feats) [f16 (S,16)], sigma = exp(h[0])      (TruncExp forward)
+ *   rgb:     sh = SH4(d/|d|), rgb = sigmoid(rgb_net([sh, h]))
+ * feats [L=16][S] half2; dirs (S,3) f32 un-normalised.
+ * out: sigmas (S) f32; h_out (S,16) f16 (may be NULL for ngp_density_fwd);
+ *      rgbs (S,3) f32 (values rounded through f16 as tiny-cuda-nn emits them). */
+int ngp_density_fwd(const ngp_half* feats, const ngp_half* density_w, int n_samples,
+                    float* sigmas, ngp_half* h_out, ngp_stream_t stream);
+int ngp_rgb_fwd(const ngp_half* h, const float* dirs, const ngp_half* rgb_w, int n_samples,
+                float* rgbs, ngp_stream_t stream);
+/* both, back to back */
 int ngp_field_fwd(const ngp_half* feats, const float* dirs,
                   const ngp_half* density_w, const ngp_half* rgb_w, int n_samples,
                   float* sigmas, float* rgbs, ngp_half* h_out, ngp_stream_t stream);
 
-/* Fused field backward.  Recomputes the forward, then dgrad through the rgb net, TruncExp
- * (custom_functions.py:168-173) and the density net, writing dfeats [L][S] half2 (scaled by
- * loss_scale) and per-workgroup partial weight gradients (scaled by loss_scale):
- *   wgrad_partial = [ n_partials x 3072 density | n_partials x 7168 rgb ] f32,
- * n_partials = ngp_field_bwd_partials(n_samples); sum them with ngp_reduce_partials.
- * h (S,16) f16 is the forward's h_out; dh_scratch (S,16) f16 is workspace.
- * dL_drgbs NULL -> density-only backward (dirs, h, rgb_w, dh_scratch unused). */
+/* Backward of the two halves.  Each recomputes its forward, runs dgrad in registers and emits
+ * per-workgroup partial weight gradients (n_partials, n_params) f32, n_partials =
+ * ngp_field_bwd_partials(n_samples); sum them with ngp_reduce_partials.  All gradients carry
+ * the factor loss_scale (tiny-cuda-nn uses 128 for f16).
+ *   ngp_rgb_bwd:     dL_drgbs (S,3) f32 unscaled -> dL_dh (S,16) f16, partials (.,7168)
+ *   ngp_density_bwd: dL_dh (S,16) f16 already scaled (may be NULL) and dL_dsigmas (S) f32
+ *                    unscaled (may be NULL; TruncExp backward custom_functions.py:168-173 is
+ *                    applied here) -> dfeats [L][S] half2, partials (.,3072)
+ *   ngp_field_bwd:   both; wgrad_partial = [n_partials x 3072 | n_partials x 7168],
+ *                    h = forward's h_out, dh_scratch (S,16) f16 workspace. */
 int ngp_field_bwd_partials(int n_samples);
+int ngp_rgb_bwd(const ngp_half* h, const float* dirs, const ngp_half* rgb_w,
+                const float* dL_drgbs, float loss_scale, int n_samples,
+                ngp_half* dL_dh, float* wgrad_partial, ngp_stream_t stream);
+int ngp_density_bwd(const ngp_half* feats, const ngp_half* density_w, const ngp_half* dL_dh,
+                    const float* dL_dsigmas, float loss_scale, int n_samples,
+                    ngp_half* dfeats, float* wgrad_partial, ngp_stream_t stream);
 int ngp_field_bwd(const ngp_half* feats, const float* dirs, const ngp_half* h,
                   const ngp_half* density_w, const ngp_half* rgb_w,
                   const float* dL_dsigmas, const float* dL_drgbs, float loss_scale,

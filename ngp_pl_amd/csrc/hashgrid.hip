@@ -44,12 +44,6 @@ __device__ __forceinline__ bool map_block(int n_levels, int n_chunks, int& level
     return level < n_levels;
 }
 
-struct Corner {
-    uint32_t base;       // index of corner (0,0,0) ingredients
-    uint32_t px, py, pz; // integer cell coordinates
-    float fx, fy, fz;    // fractional position
-};
-
 __device__ __forceinline__ void cell_of(const float* __restrict__ x, const float* __restrict__ xyz_min,
                                         const float* __restrict__ xyz_max, int i, float scale,
                                         uint32_t& px, uint32_t& py, uint32_t& pz, float& fx, float& fy, float& fz) {
@@ -159,6 +153,75 @@ hashgrid_bwd_kernel(const float* __restrict__ x, const float* __restrict__ xyz_m
     else scatter_one<false, F32>(grad_level, res, size, px, py, pz, fx, fy, fz, g0, g1);
 }
 
+// ------------------------------------------------------------------------------------------
+// Backward without global atomics: LDS-privatised scatter.
+//
+// Measured on MI355X: device-scope f16x2 atomics retire at ~19 G/s whatever the address pattern
+// (they execute below the XCD-private L2s), i.e. 1.7 ms for the 33.5 M corner updates of a
+// 262 k-sample batch.  Instead the gradient table is cut into slices of SLICE entries (128 KiB
+// of packed-f16 accumulators); one workgroup owns one slice in its CU's LDS, scans ALL samples
+// of its level, recomputes the 8 corner indices (cheap VALU) and applies only the updates that
+// fall into its slice with ds_pk_add_f16.  The whole 22.9 MB gradient table lives in the
+// chip's 40 MB of LDS for the duration of the kernel and is written out once with plain
+// coalesced stores -- the output is OVERWRITTEN (no zero-fill, no accumulate).
+// ------------------------------------------------------------------------------------------
+constexpr int SLICE_LOG2 = 15;
+constexpr uint32_t SLICE = 1u << SLICE_LOG2;   // entries per workgroup: 32768 x 4 B = 128 KiB
+
+template <bool HASHED>
+__device__ __forceinline__ void scatter_lds(half2_t* lds, uint32_t lo, uint32_t res, uint32_t size,
+                                            uint32_t px, uint32_t py, uint32_t pz, float fx, float fy, float fz,
+                                            float g0, float g1) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const uint32_t idx = grid_index<HASHED>(px + (c & 1), py + ((c >> 1) & 1), pz + (c >> 2), res, size);
+        const uint32_t local = idx - lo;
+        if (local < SLICE) {
+            const float w = ((c & 1) ? fx : 1.f - fx) * (((c >> 1) & 1) ? fy : 1.f - fy) * ((c >> 2) ? fz : 1.f - fz);
+            half2_t v; v[0] = (_Float16)(w * g0); v[1] = (_Float16)(w * g1);
+            __builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) half2_t*)(lds + local), v);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+hashgrid_bwd_sliced_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const float* __restrict__ xyz_max,
+                           const half2_t* __restrict__ dfeats, GridMeta meta, int n_samples,
+                           half2_t* __restrict__ grad_table) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    half2_t* lds = reinterpret_cast<half2_t*>(smem_raw);
+    // workgroup -> (level, slice)
+    int level = 0, slice = (int)blockIdx.x;
+    for (; level < meta.n_levels; ++level) {
+        const int n_slices = (int)((meta.offset[level + 1] - meta.offset[level] + SLICE - 1) >> SLICE_LOG2);
+        if (slice < n_slices) break;
+        slice -= n_slices;
+    }
+    if (level >= meta.n_levels) return;
+    const uint32_t res = meta.resolution[level];
+    const uint32_t size = meta.offset[level + 1] - meta.offset[level];
+    const uint32_t lo = (uint32_t)slice << SLICE_LOG2;
+    const uint32_t n_here = min(SLICE, size - lo);
+    const half2_t z = {0, 0};
+    for (uint32_t k = threadIdx.x; k < n_here; k += blockDim.x) lds[k] = z;
+    __syncthreads();
+    const bool hashed = level_is_hashed(res, size);
+    const float scale = meta.scale[level];
+    const half2_t* __restrict__ g_level = dfeats + (size_t)level * n_samples;
+    for (int i = threadIdx.x; i < n_samples; i += blockDim.x) {
+        const half2_t g = g_level[i];
+        const float g0 = (float)g[0], g1 = (float)g[1];
+        if (g0 == 0.f && g1 == 0.f) continue;
+        uint32_t px, py, pz; float fx, fy, fz;
+        cell_of(x, xyz_min, xyz_max, i, scale, px, py, pz, fx, fy, fz);
+        if (hashed) scatter_lds<true>(lds, lo, res, size, px, py, pz, fx, fy, fz, g0, g1);
+        else scatter_lds<false>(lds, lo, res, size, px, py, pz, fx, fy, fz, g0, g1);
+    }
+    __syncthreads();
+    half2_t* __restrict__ out = grad_table + meta.offset[level] + lo;
+    for (uint32_t k = threadIdx.x; k < n_here; k += blockDim.x) out[k] = lds[k];
+}
+
 __global__ void __launch_bounds__(256)
 feats_to_rowmajor_kernel(const half2_t* __restrict__ feats, int n_levels, int n_samples, half2_t* __restrict__ out) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over (sample, level), level fastest
@@ -247,6 +310,26 @@ int ngp_hashgrid_bwd(const float* x, const float* xyz_min, const float* xyz_max,
     else
         hipLaunchKernelGGL(hashgrid_bwd_kernel<false>, grid, block, 0, ngp_stream(stream),
                            x, xyz_min, xyz_max, (const half2_t*)dfeats, to_dev_meta(meta), n_samples, n_chunks, grad_table);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_hashgrid_bwd_sliced(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* dfeats,
+                            const ngp_grid_meta* meta, int n_samples, ngp_half* grad_table, ngp_stream_t stream) {
+    if (n_samples < 0 || !meta || meta->n_features != 2) return NGP_EINVAL;
+    NGP_CHECK_PTR(grad_table);
+    if (n_samples > 0) { NGP_CHECK_PTR(x); NGP_CHECK_PTR(xyz_min); NGP_CHECK_PTR(xyz_max); NGP_CHECK_PTR(dfeats); }
+    int n_blocks = 0;
+    for (int l = 0; l < meta->n_levels; ++l) n_blocks += (int)((meta->offset[l + 1] - meta->offset[l] + SLICE - 1) >> SLICE_LOG2);
+    constexpr int smem = (int)(SLICE * sizeof(half2_t));
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hashgrid_bwd_sliced_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hashgrid_bwd_sliced_kernel<<<dim3(n_blocks), dim3(1024), smem, ngp_stream(stream)>>>(
+        x, xyz_min, xyz_max, (const half2_t*)dfeats, to_dev_meta(meta), n_samples, (half2_t*)grad_table);
     return NGP_LAUNCH_RESULT();
 }
 

@@ -619,47 +619,70 @@ sh4_kernel(const float* __restrict__ d01, int n, h1* __restrict__ out) {
 extern "C" {
 #pragma GCC visibility push(default)
 
-int ngp_field_fwd(const ngp_half* feats, const float* dirs, const ngp_half* density_w, const ngp_half* rgb_w,
-                  int n_samples, float* sigmas, float* rgbs, ngp_half* h_out, ngp_stream_t stream) {
+int ngp_density_fwd(const ngp_half* feats, const ngp_half* density_w, int n_samples, float* sigmas,
+                    ngp_half* h_out, ngp_stream_t stream) {
     if (n_samples < 0) return NGP_EINVAL;
     if (n_samples == 0) return 0;
     NGP_CHECK_PTR(feats); NGP_CHECK_PTR(density_w); NGP_CHECK_PTR(sigmas);
-    const bool want_rgb = rgbs != nullptr;
-    if (want_rgb) { NGP_CHECK_PTR(dirs); NGP_CHECK_PTR(rgb_w); NGP_CHECK_PTR(h_out); }
     MlpIO d = {};
     d.in = (const h1*)feats; d.out16 = (h1*)h_out; d.out_ld = 16; d.n_out = 16; d.sigmas = sigmas;
-    int rc = launch_fwd<32, 1, IN_LEVELMAJOR, OUT_DENSITY>(d, (const h1*)density_w, n_samples, ngp_stream(stream));
-    if (rc || !want_rgb) return rc;
+    return launch_fwd<32, 1, IN_LEVELMAJOR, OUT_DENSITY>(d, (const h1*)density_w, n_samples, ngp_stream(stream));
+}
+
+int ngp_rgb_fwd(const ngp_half* h, const float* dirs, const ngp_half* rgb_w, int n_samples, float* rgbs,
+                ngp_stream_t stream) {
+    if (n_samples < 0) return NGP_EINVAL;
+    if (n_samples == 0) return 0;
+    NGP_CHECK_PTR(h); NGP_CHECK_PTR(dirs); NGP_CHECK_PTR(rgb_w); NGP_CHECK_PTR(rgbs);
     MlpIO r = {};
-    r.in = (const h1*)h_out; r.dirs = dirs; r.rgbs = rgbs; r.n_out = 3;
+    r.in = (const h1*)h; r.dirs = dirs; r.rgbs = rgbs; r.n_out = 3;
     return launch_fwd<32, 2, IN_SH_H, OUT_RGB>(r, (const h1*)rgb_w, n_samples, ngp_stream(stream));
 }
 
+int ngp_field_fwd(const ngp_half* feats, const float* dirs, const ngp_half* density_w, const ngp_half* rgb_w,
+                  int n_samples, float* sigmas, float* rgbs, ngp_half* h_out, ngp_stream_t stream) {
+    NGP_CHECK_PTR(h_out);
+    const int rc = ngp_density_fwd(feats, density_w, n_samples, sigmas, h_out, stream);
+    if (rc) return rc;
+    return ngp_rgb_fwd(h_out, dirs, rgb_w, n_samples, rgbs, stream);
+}
+
 int ngp_field_bwd_partials(int n_samples) { return n_samples <= 0 ? 0 : bwd_grid(n_samples); }
+
+int ngp_rgb_bwd(const ngp_half* h, const float* dirs, const ngp_half* rgb_w, const float* dL_drgbs, float loss_scale,
+                int n_samples, ngp_half* dL_dh, float* wgrad_partial, ngp_stream_t stream) {
+    if (n_samples < 0) return NGP_EINVAL;
+    if (n_samples == 0) return 0;
+    NGP_CHECK_PTR(h); NGP_CHECK_PTR(dirs); NGP_CHECK_PTR(rgb_w); NGP_CHECK_PTR(dL_drgbs); NGP_CHECK_PTR(dL_dh); NGP_CHECK_PTR(wgrad_partial);
+    MlpBwdIO r = {};
+    r.fwd.in = (const h1*)h; r.fwd.dirs = dirs; r.fwd.n_out = 3;
+    r.dL_drgbs = dL_drgbs; r.loss_scale = loss_scale; r.dL_din = (h1*)dL_dh; r.wgrad_partial = wgrad_partial;
+    return launch_bwd<32, 2, IN_SH_H, OUT_RGB>(r, (const h1*)rgb_w, n_samples, ngp_stream(stream));
+}
+
+int ngp_density_bwd(const ngp_half* feats, const ngp_half* density_w, const ngp_half* dL_dh, const float* dL_dsigmas,
+                    float loss_scale, int n_samples, ngp_half* dfeats, float* wgrad_partial, ngp_stream_t stream) {
+    if (n_samples < 0) return NGP_EINVAL;
+    if (n_samples == 0) return 0;
+    NGP_CHECK_PTR(feats); NGP_CHECK_PTR(density_w); NGP_CHECK_PTR(dfeats); NGP_CHECK_PTR(wgrad_partial);
+    MlpBwdIO d = {};
+    d.fwd.in = (const h1*)feats; d.fwd.n_out = 16; d.fwd.out_ld = 16;
+    d.dL_dout16 = (const h1*)dL_dh; d.dout_ld = 16;
+    d.dL_dsigmas = dL_dsigmas; d.loss_scale = loss_scale; d.dL_din = (h1*)dfeats; d.wgrad_partial = wgrad_partial;
+    return launch_bwd<32, 1, IN_LEVELMAJOR, OUT_DENSITY>(d, (const h1*)density_w, n_samples, ngp_stream(stream));
+}
 
 int ngp_field_bwd(const ngp_half* feats, const float* dirs, const ngp_half* h, const ngp_half* density_w,
                   const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale,
                   int n_samples, ngp_half* dh_scratch, ngp_half* dfeats, float* wgrad_partial, ngp_stream_t stream) {
     if (n_samples < 0) return NGP_EINVAL;
     if (n_samples == 0) return 0;
-    NGP_CHECK_PTR(feats); NGP_CHECK_PTR(density_w); NGP_CHECK_PTR(dfeats); NGP_CHECK_PTR(wgrad_partial);
+    NGP_CHECK_PTR(wgrad_partial);
     const int n_part = bwd_grid(n_samples);
-    const bool have_rgb = dL_drgbs != nullptr;
-    float* part_density = wgrad_partial;
-    float* part_rgb = wgrad_partial + (size_t)n_part * NGP_DENSITY_NET_PARAMS;
-    if (have_rgb) {
-        NGP_CHECK_PTR(dirs); NGP_CHECK_PTR(h); NGP_CHECK_PTR(rgb_w); NGP_CHECK_PTR(dh_scratch);
-        MlpBwdIO r = {};
-        r.fwd.in = (const h1*)h; r.fwd.dirs = dirs; r.fwd.n_out = 3;
-        r.dL_drgbs = dL_drgbs; r.loss_scale = loss_scale; r.dL_din = (h1*)dh_scratch; r.wgrad_partial = part_rgb;
-        const int rc = launch_bwd<32, 2, IN_SH_H, OUT_RGB>(r, (const h1*)rgb_w, n_samples, ngp_stream(stream));
-        if (rc) return rc;
-    }
-    MlpBwdIO d = {};
-    d.fwd.in = (const h1*)feats; d.fwd.n_out = 16; d.fwd.out_ld = 16;
-    d.dL_dout16 = have_rgb ? (const h1*)dh_scratch : nullptr; d.dout_ld = 16;
-    d.dL_dsigmas = dL_dsigmas; d.loss_scale = loss_scale; d.dL_din = (h1*)dfeats; d.wgrad_partial = part_density;
-    return launch_bwd<32, 1, IN_LEVELMAJOR, OUT_DENSITY>(d, (const h1*)density_w, n_samples, ngp_stream(stream));
+    const int rc = ngp_rgb_bwd(h, dirs, rgb_w, dL_drgbs, loss_scale, n_samples, dh_scratch,
+                               wgrad_partial + (size_t)n_part * NGP_DENSITY_NET_PARAMS, stream);
+    if (rc) return rc;
+    return ngp_density_bwd(feats, density_w, dh_scratch, dL_dsigmas, loss_scale, n_samples, dfeats, wgrad_partial, stream);
 }
 
 int ngp_mlp_fwd(const ngp_half* in, const ngp_half* weights, int n_in, int n_hidden, int n_out, int out_act,

@@ -1,0 +1,98 @@
+"""`render()` of the reference (/root/reference/models/rendering.py:11-163): same signature, same
+kwargs (test_time, exp_step_factor, T_threshold, max_samples, random_bg, exposure,
+output_radiance, to_cpu, to_numpy), same result dictionary.
+"""
+import torch
+
+from . import vren
+from .custom_functions import RayAABBIntersector, RayMarcher, VolumeRenderer
+
+MAX_SAMPLES = 1024
+NEAR_DISTANCE = 0.01
+
+
+def _background(exp_step_factor, device, random_bg=False):
+    if exp_step_factor == 0:                 # synthetic scenes: white (rendering.py:111-112,153-154)
+        return torch.ones(3, device=device)
+    if random_bg:
+        return torch.rand(3, device=device)
+    return torch.zeros(3, device=device)
+
+
+@torch.autocast("cuda")
+def render(model, rays_o, rays_d, **kwargs):
+    """rays (R,3)/(R,3) -> dict with rgb (R,3), depth (R), opacity (R) and, in training, ws, deltas,
+    ts, rays_a, rm_samples, vr_samples; at test time total_samples (rendering.py:11-43)."""
+    rays_o = rays_o.contiguous(); rays_d = rays_d.contiguous()
+    _, hits_t, _ = RayAABBIntersector.apply(rays_o, rays_d, model.center, model.half_size, 1)
+    t1 = hits_t[:, 0, 0]
+    hits_t[(t1 >= 0) & (t1 < NEAR_DISTANCE), 0, 0] = NEAR_DISTANCE
+    fn = _render_test if kwargs.get("test_time", False) else _render_train
+    results = fn(model, rays_o, rays_d, hits_t, **kwargs)
+    if kwargs.get("to_cpu", False):
+        for k, v in results.items():
+            if torch.is_tensor(v):
+                v = v.cpu()
+                if kwargs.get("to_numpy", False):
+                    v = v.numpy()
+            results[k] = v
+    return results
+
+
+@torch.no_grad()
+def _render_test(model, rays_o, rays_d, hits_t, **kwargs):
+    """Iterative march / infer / composite with alive-ray compaction (rendering.py:46-118)."""
+    esf = kwargs.get("exp_step_factor", 0.)
+    n_rays, device = len(rays_o), rays_o.device
+    opacity = torch.zeros(n_rays, device=device)
+    depth = torch.zeros(n_rays, device=device)
+    rgb = torch.zeros(n_rays, 3, device=device)
+    hits = hits_t[:, 0].contiguous()          # (R,2), advanced in place by the marcher
+    alive = torch.arange(n_rays, device=device)
+    min_samples = 1 if esf == 0 else 4
+    samples = 0
+    total_samples = 0
+    max_samples = kwargs.get("max_samples", MAX_SAMPLES)
+    T_threshold = kwargs.get("T_threshold", 1e-4)
+    while samples < max_samples:
+        n_alive = len(alive)
+        if n_alive == 0:
+            break
+        n_step = max(min(n_rays // n_alive, 64), min_samples)
+        samples += n_step
+        xyzs, dirs, deltas, ts, n_eff = vren.raymarching_test(
+            rays_o, rays_d, hits, alive, model.density_bitfield, model.cascades, model.scale, esf,
+            model.grid_size, MAX_SAMPLES, n_step)
+        total_samples += n_eff.sum()
+        xyzs = xyzs.view(-1, 3); dirs = dirs.view(-1, 3)
+        valid = ~torch.all(dirs == 0, dim=1)
+        if valid.sum() == 0:
+            break
+        sigmas = torch.zeros(len(xyzs), device=device)
+        rgbs = torch.zeros(len(xyzs), 3, device=device)
+        s, c = model(xyzs[valid], dirs[valid], **kwargs)
+        sigmas[valid] = s.float(); rgbs[valid] = c.float()
+        vren.composite_test_fw(sigmas.view(-1, n_step), rgbs.view(-1, n_step, 3), deltas, ts, hits, alive,
+                               T_threshold, n_eff, opacity, depth, rgb)
+        alive = alive[alive >= 0]
+    bg = _background(esf, device)
+    return {"opacity": opacity, "depth": depth, "rgb": rgb + bg * (1 - opacity)[:, None], "total_samples": total_samples}
+
+
+def _render_train(model, rays_o, rays_d, hits_t, **kwargs):
+    """march -> field -> composite (rendering.py:121-163)."""
+    esf = kwargs.get("exp_step_factor", 0.)
+    results = {}
+    rays_a, xyzs, dirs, results["deltas"], results["ts"], results["rm_samples"] = RayMarcher.apply(
+        rays_o, rays_d, hits_t[:, 0], model.density_bitfield, model.cascades, model.scale, esf,
+        model.grid_size, MAX_SAMPLES)
+    for k, v in kwargs.items():              # per-ray tensors (e.g. exposure) repeated per sample
+        if isinstance(v, torch.Tensor):
+            kwargs[k] = torch.repeat_interleave(v[rays_a[:, 0]], rays_a[:, 2], 0)
+    sigmas, rgbs = model(xyzs, dirs, **kwargs)
+    (results["vr_samples"], results["opacity"], results["depth"], results["rgb"], results["ws"]) = VolumeRenderer.apply(
+        sigmas, rgbs.contiguous(), results["deltas"], results["ts"], rays_a, kwargs.get("T_threshold", 1e-4))
+    results["rays_a"] = rays_a
+    bg = _background(esf, rays_o.device, kwargs.get("random_bg", False))
+    results["rgb"] = results["rgb"] + bg * (1 - results["opacity"])[:, None]
+    return results

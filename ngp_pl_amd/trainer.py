@@ -1,0 +1,149 @@
+"""Lightning-free driver of one training step, mirroring NeRFSystem.training_step
+(/root/reference/train.py:159-185) + configure_optimizers (:112-139) for the default recipe
+(Synthetic-NeRF: scale 0.5, white background, no distortion loss, no pose optimisation).
+
+Two implementations of the same step:
+  * `step()`          -- the hot path: direct calls into libngp_hip.so, no autograd graph, native
+                         gradient buffers consumed by optim.FusedAdam.  ~20 kernel launches, one
+                         4-byte host sync (the packed sample count), the next step's ray march
+                         enqueued behind the current step so the GPU never waits for the host.
+  * `step_autograd()` -- the same maths through render() + NeRFLoss + torch autograd, i.e. what
+                         the reference's train.py drives; used to check the hot path (tests).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib, tcnn
+from ._lib import call, ptr, stream
+from .losses import NeRFLoss
+from .optim import FusedAdam, cosine_lr
+from .rendering import MAX_SAMPLES, NEAR_DISTANCE, render
+
+
+class Trainer:
+    def __init__(self, model, lr=1e-2, num_epochs=30, steps_per_epoch=1000, T_threshold=1e-4,
+                 lambda_opacity=1e-3, grad_scale=1.0, warmup_steps=256, update_interval=16):
+        self.model = model
+        if not hasattr(model, "density_grid"):
+            model.register_training_buffers()
+        self.opt = FusedAdam(model, lr=lr, eps=1e-15)
+        self.base_lr, self.num_epochs, self.steps_per_epoch = lr, num_epochs, steps_per_epoch
+        self.T_threshold, self.lambda_opacity = T_threshold, lambda_opacity
+        self.warmup_steps, self.update_interval = warmup_steps, update_interval
+        self.grad_scale = grad_scale
+        self.global_step = 0
+        self.exp_step_factor = 1 / 256 if model.scale > 0.5 else 0.0      # train.py:95-96
+        self.bg = torch.ones(3, device=model.center.device) if self.exp_step_factor == 0 else None
+        self.loss_fn = NeRFLoss(lambda_opacity=lambda_opacity, lambda_distortion=0)
+        self._pending = None     # marched-but-not-consumed batch (software pipelining)
+        self.last = {}
+
+    # -- pieces --------------------------------------------------------------------------------
+    def _maybe_update_grid(self):
+        if self.global_step % self.update_interval == 0:                  # train.py:160-163
+            self.model.update_density_grid(0.01 * MAX_SAMPLES / 3 ** 0.5, warmup=self.global_step < self.warmup_steps)
+
+    def _march(self, rays_o, rays_d):
+        """AABB + near clamp + pass 1 of the march; returns the record the main part consumes."""
+        m = self.model
+        n, dev = rays_o.shape[0], rays_o.device
+        hits_t = torch.empty(n, 2, dtype=torch.float32, device=dev)
+        noise = torch.rand(n, dtype=torch.float32, device=dev)
+        rays_a = torch.empty(n, 3, dtype=torch.int64, device=dev)
+        counter = torch.empty(2, dtype=torch.int32, device=dev)
+        scratch = torch.empty(n * MAX_SAMPLES, dtype=torch.float32, device=dev)
+        call("ngp_ray_aabb_near", ptr(rays_o), ptr(rays_d), ptr(m.center), ptr(m.half_size), NEAR_DISTANCE, n, ptr(hits_t), stream())
+        call("ngp_raymarching_train_count", ptr(rays_o), ptr(rays_d), ptr(hits_t), ptr(m.density_bitfield), m.cascades,
+             float(m.scale), self.exp_step_factor, ptr(noise), m.grid_size, MAX_SAMPLES, n, ptr(rays_a), ptr(counter),
+             ptr(scratch), stream())
+        return dict(rays_o=rays_o, rays_d=rays_d, rays_a=rays_a, counter=counter, scratch=scratch, hits_t=hits_t, noise=noise)
+
+    # -- the hot path --------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self, rays_o, rays_d, rgb_gt, next_batch=None):
+        """One optimisation step on a batch of rays.  `next_batch` = (rays_o, rays_d) of the
+        following step, if known: its march is enqueued behind this step's work."""
+        m = self.model
+        dev = rays_o.device
+        enc, net = m.xyz_encoder, m.rgb_net
+        with torch.cuda.device(dev):
+            if self._pending is not None and self._pending["rays_o"] is rays_o:
+                rec = self._pending
+            else:
+                self._maybe_update_grid()
+                rec = self._march(rays_o.contiguous(), rays_d.contiguous())
+            self._pending = None
+            n = rays_o.shape[0]
+            S = int(rec["counter"][0].item())             # the step's only host sync
+            f32 = dict(dtype=torch.float32, device=dev)
+            f16 = dict(dtype=torch.float16, device=dev)
+            xyzs = torch.empty(S, 3, **f32); dirs = torch.empty(S, 3, **f32)
+            deltas = torch.empty(S, **f32); ts = torch.empty(S, **f32)
+            call("ngp_raymarching_train_write", ptr(rec["rays_o"]), ptr(rec["rays_d"]), ptr(rec["rays_a"]), ptr(rec["scratch"]),
+                 float(m.scale), self.exp_step_factor, m.grid_size, MAX_SAMPLES, n, ptr(xyzs), ptr(dirs), ptr(deltas), ptr(ts), stream())
+            rays_a = rec["rays_a"]
+            eh, rh = enc._half.get(enc.params), net._half.get(net.params)
+            feats = torch.empty(16, S, 2, **f16); h = torch.empty(S, 16, **f16)
+            sigmas = torch.empty(S, **f32); rgbs = torch.empty(S, 3, **f32)
+            total = torch.empty(n, dtype=torch.int64, device=dev)
+            opacity = torch.empty(n, **f32); depth = torch.empty(n, **f32); rgb = torch.empty(n, 3, **f32); ws = torch.empty(S, **f32)
+            stats = torch.zeros(2, **f32)                  # loss, sum of squared error
+            dL_drgb = torch.empty(n, 3, **f32); dL_dopacity = torch.empty(n, **f32); dL_ddepth = torch.zeros(n, **f32)
+            dL_dsigmas = torch.empty(S, **f32); dL_drgbs = torch.empty(S, 3, **f32)
+            if S > 0:
+                call("ngp_hashgrid_fwd", ptr(xyzs), ptr(m.xyz_min), ptr(m.xyz_max), ptr(eh[enc.n_mlp:]), C.byref(enc.meta), S, ptr(feats), stream())
+                call("ngp_field_fwd", ptr(feats), ptr(dirs), ptr(eh), ptr(rh), S, ptr(sigmas), ptr(rgbs), ptr(h), stream())
+            call("ngp_composite_train_fw", ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(ts), ptr(rays_a), self.T_threshold, n, S,
+                 ptr(total), ptr(opacity), ptr(depth), ptr(rgb), ptr(ws), stream())
+            call("ngp_nerf_loss", ptr(rgb), ptr(opacity), ptr(rgb_gt), ptr(self.bg), self.lambda_opacity, self.grad_scale, n,
+                 ptr(stats), ptr(stats[1:]), ptr(dL_drgb), ptr(dL_dopacity), stream())
+            if S > 0:
+                call("ngp_composite_train_bw", ptr(dL_dopacity), ptr(dL_ddepth), ptr(dL_drgb), None, ptr(sigmas), ptr(rgbs), ptr(ws),
+                     ptr(deltas), ptr(ts), ptr(rays_a), ptr(opacity), ptr(depth), ptr(rgb), self.T_threshold, n, S,
+                     ptr(dL_dsigmas), ptr(dL_drgbs), stream())
+                n_part = call("ngp_field_bwd_partials", S)
+                partials = torch.empty(n_part * (enc.n_mlp + net.params.numel()), **f32)
+                dh = torch.empty(S, 16, **f16); dfeats = torch.empty(16, S, 2, **f16)
+                call("ngp_field_bwd", ptr(feats), ptr(dirs), ptr(h), ptr(eh), ptr(rh), ptr(dL_dsigmas), ptr(dL_drgbs), tcnn.LOSS_SCALE, S,
+                     ptr(dh), ptr(dfeats), ptr(partials), stream())
+                g16 = m._grid_grad16(dev)
+                call("ngp_hashgrid_bwd_sliced", ptr(xyzs), ptr(m.xyz_min), ptr(m.xyz_max), ptr(dfeats), C.byref(enc.meta), S, ptr(g16), stream())
+                m._native = dict(grid16=g16, density_partials=partials[:n_part * enc.n_mlp], rgb_partials=partials[n_part * enc.n_mlp:],
+                                 n_partials=n_part, scale=tcnn.LOSS_SCALE)
+                epoch = self.global_step // self.steps_per_epoch
+                self.opt.param_groups[0]["lr"] = cosine_lr(self.base_lr, epoch, self.num_epochs)
+                self.opt.step(grad_scale=self.grad_scale)
+            self.global_step += 1
+            self.last = dict(stats=stats, rm_samples=S, total=total, n_rays=n, rgb=rgb, opacity=opacity)
+            if next_batch is not None:
+                self._maybe_update_grid()
+                self._pending = self._march(next_batch[0], next_batch[1])
+        return self.last
+
+    def metrics(self):
+        """Host-side readout of the last step (syncs): loss, psnr, rm_s, vr_s as train.py:177-183 logs them."""
+        st = self.last["stats"].tolist()
+        n = self.last["n_rays"]
+        mse = st[1] / (3 * n)
+        return dict(loss=st[0], psnr=-10 * math.log10(max(mse, 1e-12)), rm_s=self.last["rm_samples"] / n,
+                    vr_s=float(self.last["total"].sum().item()) / n)
+
+    # -- the reference-shaped path ---------------------------------------------------------------
+    def step_autograd(self, rays_o, rays_d, rgb_gt):
+        """render() -> NeRFLoss -> backward -> FusedAdam, as train.py:159-185 (no GradScaler: the
+        tcnn modules carry their own loss scale)."""
+        self._maybe_update_grid()
+        kwargs = {"test_time": False}
+        if self.exp_step_factor:
+            kwargs["exp_step_factor"] = self.exp_step_factor
+        results = render(self.model, rays_o, rays_d, **kwargs)
+        loss_d = self.loss_fn(results, {"rgb": rgb_gt})
+        loss = sum(lo.mean() for lo in loss_d.values())
+        loss.backward()
+        epoch = self.global_step // self.steps_per_epoch
+        self.opt.param_groups[0]["lr"] = cosine_lr(self.base_lr, epoch, self.num_epochs)
+        self.opt.step()
+        self.global_step += 1
+        return results, loss
