@@ -39,6 +39,20 @@ class Trainer:
         self.loss_fn = NeRFLoss(lambda_opacity=lambda_opacity, lambda_distortion=0)
         self._pending = None     # marched-but-not-consumed batch (software pipelining)
         self.last = {}
+        self.grad_hook = None    # called between backward and optimizer (multi-GPU gradient all-reduce)
+        self.events = None       # list of (stage, event) when stage timing is on (bench.py roofline)
+
+    def _mark(self, name):
+        if self.events is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()           # torch's current stream == the stream every kernel here is launched on
+            self.events.append((name, e))
+
+    def stage_times_ms(self):
+        """Elapsed time between consecutive stage marks of the last profiled step (syncs)."""
+        torch.cuda.synchronize()
+        ev = self.events
+        return [(ev[i + 1][0], ev[i][1].elapsed_time(ev[i + 1][1])) for i in range(len(ev) - 1)]
 
     # -- pieces --------------------------------------------------------------------------------
     def _maybe_update_grid(self):
@@ -77,12 +91,16 @@ class Trainer:
             self._pending = None
             n = rays_o.shape[0]
             S = int(rec["counter"][0].item())             # the step's only host sync
+            if self.events is not None:
+                self.events = []
+            self._mark("start")
             f32 = dict(dtype=torch.float32, device=dev)
             f16 = dict(dtype=torch.float16, device=dev)
             xyzs = torch.empty(S, 3, **f32); dirs = torch.empty(S, 3, **f32)
             deltas = torch.empty(S, **f32); ts = torch.empty(S, **f32)
             call("ngp_raymarching_train_write", ptr(rec["rays_o"]), ptr(rec["rays_d"]), ptr(rec["rays_a"]), ptr(rec["scratch"]),
                  float(m.scale), self.exp_step_factor, m.grid_size, MAX_SAMPLES, n, ptr(xyzs), ptr(dirs), ptr(deltas), ptr(ts), stream())
+            self._mark("march_write")
             rays_a = rec["rays_a"]
             eh, rh = enc._half.get(enc.params), net._half.get(net.params)
             feats = torch.empty(16, S, 2, **f16); h = torch.empty(S, 16, **f16)
@@ -94,32 +112,43 @@ class Trainer:
             dL_dsigmas = torch.empty(S, **f32); dL_drgbs = torch.empty(S, 3, **f32)
             if S > 0:
                 call("ngp_hashgrid_fwd", ptr(xyzs), ptr(m.xyz_min), ptr(m.xyz_max), ptr(eh[enc.n_mlp:]), C.byref(enc.meta), S, ptr(feats), stream())
+                self._mark("hashgrid_fwd")
                 call("ngp_field_fwd", ptr(feats), ptr(dirs), ptr(eh), ptr(rh), S, ptr(sigmas), ptr(rgbs), ptr(h), stream())
+                self._mark("mlp_fwd")
             call("ngp_composite_train_fw", ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(ts), ptr(rays_a), self.T_threshold, n, S,
                  ptr(total), ptr(opacity), ptr(depth), ptr(rgb), ptr(ws), stream())
             call("ngp_nerf_loss", ptr(rgb), ptr(opacity), ptr(rgb_gt), ptr(self.bg), self.lambda_opacity, self.grad_scale, n,
                  ptr(stats), ptr(stats[1:]), ptr(dL_drgb), ptr(dL_dopacity), stream())
+            self._mark("composite_fw+loss")
             if S > 0:
                 call("ngp_composite_train_bw", ptr(dL_dopacity), ptr(dL_ddepth), ptr(dL_drgb), None, ptr(sigmas), ptr(rgbs), ptr(ws),
                      ptr(deltas), ptr(ts), ptr(rays_a), ptr(opacity), ptr(depth), ptr(rgb), self.T_threshold, n, S,
                      ptr(dL_dsigmas), ptr(dL_drgbs), stream())
+                self._mark("composite_bw")
                 n_part = call("ngp_field_bwd_partials", S)
                 partials = torch.empty(n_part * (enc.n_mlp + net.params.numel()), **f32)
                 dh = torch.empty(S, 16, **f16); dfeats = torch.empty(16, S, 2, **f16)
                 call("ngp_field_bwd", ptr(feats), ptr(dirs), ptr(h), ptr(eh), ptr(rh), ptr(dL_dsigmas), ptr(dL_drgbs), tcnn.LOSS_SCALE, S,
                      ptr(dh), ptr(dfeats), ptr(partials), stream())
+                self._mark("mlp_bwd")
                 g16 = m._grid_grad16(dev)
                 call("ngp_hashgrid_bwd_sliced", ptr(xyzs), ptr(m.xyz_min), ptr(m.xyz_max), ptr(dfeats), C.byref(enc.meta), S, ptr(g16), stream())
+                self._mark("hashgrid_bwd")
                 m._native = dict(grid16=g16, density_partials=partials[:n_part * enc.n_mlp], rgb_partials=partials[n_part * enc.n_mlp:],
                                  n_partials=n_part, scale=tcnn.LOSS_SCALE)
                 epoch = self.global_step // self.steps_per_epoch
                 self.opt.param_groups[0]["lr"] = cosine_lr(self.base_lr, epoch, self.num_epochs)
+                if self.grad_hook is not None:
+                    self.grad_hook()
                 self.opt.step(grad_scale=self.grad_scale)
+                self._mark("adam")
             self.global_step += 1
             self.last = dict(stats=stats, rm_samples=S, total=total, n_rays=n, rgb=rgb, opacity=opacity)
             if next_batch is not None:
                 self._maybe_update_grid()
+                self._mark("grid_update")
                 self._pending = self._march(next_batch[0], next_batch[1])
+                self._mark("march_count")
         return self.last
 
     def metrics(self):
