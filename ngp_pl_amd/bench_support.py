@@ -88,8 +88,8 @@ def all_reduce_native(model, dist, world):
     if nat is None:
         return
     enc, net = model.xyz_encoder, model.rgb_net
-    gd = tcnn.reduce_partials(nat["density_partials"], nat["n_partials"], enc.n_mlp)
-    gr = tcnn.reduce_partials(nat["rgb_partials"], nat["n_partials"], net.params.numel())
+    gd = nat["density_partials"].view(nat["n_partials"], enc.n_mlp).sum(0)
+    gr = nat["rgb_partials"].view(nat["n_partials"], net.params.numel()).sum(0)
     small = torch.cat([gd, gr])
     dist.all_reduce(small)
     dist.all_reduce(nat["grid16"])

@@ -1,0 +1,87 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/ngp_hip.h declares; host
+side logic (argument validation, level table) works without a GPU.  No compute calls here."""
+import ctypes as C
+import math
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    hdr = open(os.path.join(ROOT, "include", "ngp_hip.h")).read()
+    return sorted(set(re.findall(r"^(?:int|const char\*) (ngp_\w+)\(", hdr, re.M)))
+
+
+def test_library_exports_every_declared_symbol():
+    from ngp_pl_amd import _lib
+    lib = _lib.lib()
+    names = header_symbols()
+    assert len(names) >= 40
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], stdout=subprocess.PIPE, text=True, check=True).stdout
+    exported = set(re.findall(r" T (ngp_\w+)", out))
+    assert set(names) <= exported, sorted(set(names) - exported)
+    assert exported <= set(names), "exported but undeclared: %s" % sorted(exported - set(names))
+    assert set(_lib.exported_symbols()) == set(names)          # the ctypes table covers the whole header
+    assert lib.ngp_abi_version() == 1 and lib.ngp_build_arch() == b"gfx950"
+
+
+def test_code_object_is_gfx950_only():
+    from ngp_pl_amd import _lib
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", _lib.LIB_PATH], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"gfx942" not in blob and b"sm_" not in blob, out[:200]
+
+
+def test_argument_validation_needs_no_gpu():
+    from ngp_pl_amd import _lib
+    # empty inputs are a no-op (the reference handles N = 0 by launching zero blocks)
+    assert _lib.call("ngp_morton3D", None, 0, None, None) == 0
+    assert _lib.call("ngp_composite_train_fw", None, None, None, None, None, 1e-4, 0, 0, None, None, None, None, None, None) == 0
+    with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
+        _lib.call("ngp_morton3D", None, 5, None, None)                      # null pointers with n > 0
+    with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
+        _lib.call("ngp_raymarching_test", None, None, None, None, None, 1, 0.5, 0.0, 128, 1024, 0, 4, None, None, None, None, None, None)
+    with pytest.raises(_lib.NgpError, match="NGP_EUNSUP"):
+        fake = C.c_void_p(4096)     # never dereferenced: the configuration is rejected before any launch
+        _lib.call("ngp_mlp_fwd", fake, fake, 48, 1, 3, 0, 10, fake, None)   # width 48 is not a supported input size
+    with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
+        _lib.call("ngp_adam_step", None, None, None, 0, None, None, 10, 1e-2, 0.9, 0.999, 1e-15, 0.0, 0, 1.0, None, None)   # step is 1-based
+
+
+def test_vren_rejects_cpu_tensors():
+    """CHECK_CUDA / CHECK_CONTIGUOUS of the reference (include/utils.h:4-6): no silent CPU path."""
+    import torch
+    import ngp_pl_amd.vren as vren
+    with pytest.raises(RuntimeError, match="CUDA"):
+        vren.morton3D(torch.zeros(4, 3, dtype=torch.int32))
+    with pytest.raises(RuntimeError, match="CUDA"):
+        vren.composite_train_fw(torch.zeros(3), torch.zeros(3, 3), torch.zeros(3), torch.zeros(3), torch.zeros(1, 3, dtype=torch.int64), 1e-4)
+
+
+@pytest.mark.parametrize("scale", [0.5, 2.0, 16.0])
+def test_level_table_matches_oracle(scale):
+    """ngp_grid_meta_init is pure host code: compare with the oracle's float32 restatement of
+    tiny-cuda-nn's level table for the reference's per_level_scale (networks.py:33)."""
+    from ngp_pl_amd import _lib
+    from oracle.tcnn_oracle import GridMeta
+    b = math.exp(math.log(2048 * scale / 16) / 15)
+    m = _lib.GridMeta()
+    _lib.call("ngp_grid_meta_init", C.byref(m), 16, 2, 19, 16, float(b))
+    o = GridMeta(16, 2, 19, 16, b)
+    assert [m.resolution[i] for i in range(16)] == o.resolution
+    assert [m.offset[i] for i in range(17)] == o.offset
+    assert [float(m.scale[i]) for i in range(16)] == o.scale
+    assert m.resolution[0] == 16 and all(m.offset[i + 1] - m.offset[i] <= 1 << 19 for i in range(16))
+    assert all((m.offset[i + 1] - m.offset[i]) % 8 == 0 for i in range(16))
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    from ngp_pl_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU/eager fallback"):
+        _lib.lib()

@@ -237,7 +237,8 @@ def test_generic_mlp(lib, n_in, n_hidden, n_out, act):
 
 def test_unsupported_config_is_loud(lib):
     with pytest.raises(lib.NgpError):
-        lib.call("ngp_mlp_fwd", None, None, 48, 1, 3, 0, 10, None, lib.stream())
+        x = torch.zeros(16, device="cuda")
+        lib.call("ngp_mlp_fwd", lib.ptr(x), lib.ptr(x), 48, 1, 3, 0, 10, lib.ptr(x), lib.stream())
     from ngp_pl_amd import tcnn
     with pytest.raises(NotImplementedError):
         tcnn.Network(32, 3, {"otype": "FullyFusedMLP", "activation": "Tanh", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 2})

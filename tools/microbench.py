@@ -1,5 +1,6 @@
 """Scratch GPU micro-benchmarks used to steer kernel design (not part of the product or tests)."""
-import time
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ngp_pl_amd import _lib
 from ngp_pl_amd._lib import call, ptr, stream, GridMeta
