@@ -64,7 +64,7 @@ def kernel_roofline(trainer, draw, n_steps=10):
     trainer.events = None
     S = S_acc / n_steps
     algo = {   # bytes per launch
-        "march_count": 60.0 * R + 4.0 * S, "march_write": 32.0 * S, "hashgrid_fwd": 588.0 * S, "mlp_fwd": 210.0 * S,
+        "march_count(side stream)": 60.0 * R + 4.0 * S, "march_write": 32.0 * S, "hashgrid_fwd": 588.0 * S, "mlp_fwd": 210.0 * S,
         "composite_fw+loss": 28.0 * S + 52.0 * R, "composite_bw": 52.0 * S + 64.0 * R, "mlp_bwd": 300.0 * S,
         "hashgrid_bwd": 1100.0 * S, "adam": 46.0 * n_params, "grid_update": 0.0,
     }
@@ -73,7 +73,7 @@ def kernel_roofline(trainer, draw, n_steps=10):
         ms /= n_steps
         stages.append({"stage": name, "ms": round(ms, 4), "GB/s": round(algo.get(name, 0.0) / (ms * 1e-3) / 1e9, 1) if ms > 0 else None})
     stages.sort(key=lambda d: -d["ms"])
-    top = next(d for d in stages if d["stage"] != "grid_update")
+    top = next(d for d in stages if d["stage"] not in ("grid_update", "march_count(side stream)"))   # the march overlaps the main stream
     achieved = top["GB/s"]
     return {"bound": "hbm", "kernel": top["stage"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_ms": top["ms"], "samples_per_launch": S, "stages": stages}

@@ -209,10 +209,18 @@ int ngp_hashgrid_bwd(const float* x, const float* xyz_min, const float* xyz_max,
 /* The same gradient without global atomics (the fast path; DESIGN.md "hash grid backward"):
  * every workgroup owns a 32768-entry slice of the table in LDS, scans all samples of its level
  * and keeps the updates that fall in its slice (ds_pk_add_f16), then stores the slice.
- * grad_table (total,2) f16 is OVERWRITTEN entirely (no zero-fill needed, no accumulation). */
+ * grad_table (total,2) f16 is OVERWRITTEN entirely (no zero-fill needed, no accumulation).
+ * active_idx / n_active (both NULL, or both set): compacted backward -- column j of dfeats
+ * belongs to sample active_idx[j], j < *n_active (device i32); see ngp_active_samples. */
 int ngp_hashgrid_bwd_sliced(const float* x, const float* xyz_min, const float* xyz_max,
                             const ngp_half* dfeats /* [L][S] half2 */, const ngp_grid_meta* meta,
-                            int n_samples, ngp_half* grad_table, ngp_stream_t stream);
+                            int n_samples, const int32_t* active_idx, const int32_t* n_active,
+                            ngp_half* grad_table, ngp_stream_t stream);
+/* The samples that can carry gradient after compositing: the first min(N, total_samples+1) of
+ * every ray (later ones have w = 0 exactly, volumerendering.cu:41).  Writes their ids in ray
+ * order to active_idx (capacity S) and the count to n_active (device i32).  No host sync. */
+int ngp_active_samples(const int64_t* rays_a, const int64_t* total_samples, int n_rays,
+                       int32_t* active_idx, int32_t* n_active, ngp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * tinycudann: FullyFusedMLP + SphericalHarmonics  (call sites networks.py:49-77)
@@ -250,18 +258,24 @@ int ngp_field_fwd(const ngp_half* feats, const float* dirs,
  *                    unscaled (may be NULL; TruncExp backward custom_functions.py:168-173 is
  *                    applied here) -> dfeats [L][S] half2, partials (.,3072)
  *   ngp_field_bwd:   both; wgrad_partial = [n_partials x 3072 | n_partials x 7168],
- *                    h = forward's h_out, dh_scratch (S,16) f16 workspace. */
+ *                    h = forward's h_out, dh_scratch (S,16) f16 workspace.
+ * active_idx / n_active (both NULL or both set) compact the backward as in
+ * ngp_hashgrid_bwd_sliced: inputs and f32 seeds are addressed by sample id, dL_dh / dfeats by
+ * compact position. */
 int ngp_field_bwd_partials(int n_samples);
 int ngp_rgb_bwd(const ngp_half* h, const float* dirs, const ngp_half* rgb_w,
                 const float* dL_drgbs, float loss_scale, int n_samples,
+                const int32_t* active_idx, const int32_t* n_active,
                 ngp_half* dL_dh, float* wgrad_partial, ngp_stream_t stream);
 int ngp_density_bwd(const ngp_half* feats, const ngp_half* density_w, const ngp_half* dL_dh,
                     const float* dL_dsigmas, float loss_scale, int n_samples,
+                    const int32_t* active_idx, const int32_t* n_active,
                     ngp_half* dfeats, float* wgrad_partial, ngp_stream_t stream);
 int ngp_field_bwd(const ngp_half* feats, const float* dirs, const ngp_half* h,
                   const ngp_half* density_w, const ngp_half* rgb_w,
                   const float* dL_dsigmas, const float* dL_drgbs, float loss_scale,
-                  int n_samples, ngp_half* dh_scratch, ngp_half* dfeats, float* wgrad_partial,
+                  int n_samples, const int32_t* active_idx, const int32_t* n_active,
+                  ngp_half* dh_scratch, ngp_half* dfeats, float* wgrad_partial,
                   ngp_stream_t stream);
 
 /* Generic tcnn.Network / the MLP half of NetworkWithInputEncoding:

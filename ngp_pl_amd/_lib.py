@@ -49,14 +49,15 @@ _PROTOS = {
     "ngp_grid_meta_init": [C.POINTER(GridMeta), I, I, I, I, F],
     "ngp_hashgrid_fwd": [P, P, P, P, C.POINTER(GridMeta), I, P, P],
     "ngp_hashgrid_bwd": [P, P, P, P, C.POINTER(GridMeta), I, P, I, P],
-    "ngp_hashgrid_bwd_sliced": [P, P, P, P, C.POINTER(GridMeta), I, P, P],
+    "ngp_hashgrid_bwd_sliced": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P, P],
+    "ngp_active_samples": [P, P, I, P, P, P],
     "ngp_density_fwd": [P, P, I, P, P, P],
     "ngp_rgb_fwd": [P, P, P, I, P, P],
     "ngp_field_fwd": [P, P, P, P, I, P, P, P, P],
-    "ngp_rgb_bwd": [P, P, P, P, F, I, P, P, P],
-    "ngp_density_bwd": [P, P, P, P, F, I, P, P, P],
+    "ngp_rgb_bwd": [P, P, P, P, F, I, P, P, P, P, P],
+    "ngp_density_bwd": [P, P, P, P, F, I, P, P, P, P, P],
     "ngp_field_bwd_partials": [I],
-    "ngp_field_bwd": [P, P, P, P, P, P, P, F, I, P, P, P, P],
+    "ngp_field_bwd": [P, P, P, P, P, P, P, F, I, P, P, P, P, P, P],
     "ngp_mlp_fwd": [P, P, I, I, I, I, I, P, P],
     "ngp_mlp_bwd_partials": [I],
     "ngp_mlp_bwd": [P, P, P, I, I, I, I, I, P, P, P],

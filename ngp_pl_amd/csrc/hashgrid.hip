@@ -18,13 +18,17 @@
 //     contiguous 256 B per wave (the row-major (S,32) layout would be 4-byte writes at a
 //     64-byte stride);
 //   * the per-sample position/feature streams use non-temporal accesses so they do not evict
-//     the table from L2.
+//     the table from L2;
+//   * backward: no global atomics (measured 19 G/s on MI355X whatever the pattern): the
+//     gradient table is privatised slice by slice in LDS (see hashgrid_bwd_sliced_kernel).
 #include "ngp_common.h"
 #include <hip/hip_fp16.h>
 
 namespace {
 
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+constexpr uint32_t PRIME_Y = 2654435761u, PRIME_Z = 805459861u;
 
 struct GridMeta {
     int32_t n_levels;
@@ -44,26 +48,25 @@ __device__ __forceinline__ bool map_block(int n_levels, int n_chunks, int& level
     return level < n_levels;
 }
 
-__device__ __forceinline__ void cell_of(const float* __restrict__ x, const float* __restrict__ xyz_min,
-                                        const float* __restrict__ xyz_max, int i, float scale,
-                                        uint32_t& px, uint32_t& py, uint32_t& pz, float& fx, float& fy, float& fz) {
-    const float mnx = xyz_min[0], mny = xyz_min[1], mnz = xyz_min[2];
-    const float x0 = (__builtin_nontemporal_load(x + 3 * (size_t)i) - mnx) / (xyz_max[0] - mnx);
-    const float x1 = (__builtin_nontemporal_load(x + 3 * (size_t)i + 1) - mny) / (xyz_max[1] - mny);
-    const float x2 = (__builtin_nontemporal_load(x + 3 * (size_t)i + 2) - mnz) / (xyz_max[2] - mnz);
-    // pos_fract: pos = x*scale + 0.5; cell = floor(pos); frac = pos - cell
-    const float p0 = fmaf(x0, scale, 0.5f), p1 = fmaf(x1, scale, 0.5f), p2 = fmaf(x2, scale, 0.5f);
-    const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
-    px = (uint32_t)(int)f0; py = (uint32_t)(int)f1; pz = (uint32_t)(int)f2;
-    fx = p0 - f0; fy = p1 - f1; fz = p2 - f2;
+// x01 = (x - min) * (1/(max - min))  [networks.py:103 divides; the reciprocal is exact for the
+// power-of-two extents the reference uses], pos = x01*scale + 0.5, cell = floor(pos).
+struct Box { float mn[3], inv[3]; };
+__device__ __forceinline__ Box load_box(const float* __restrict__ xyz_min, const float* __restrict__ xyz_max) {
+    Box b;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { b.mn[k] = xyz_min[k]; b.inv[k] = 1.0f / (xyz_max[k] - xyz_min[k]); }
+    return b;
 }
-
-template <bool HASHED>
-__device__ __forceinline__ uint32_t grid_index(uint32_t x, uint32_t y, uint32_t z, uint32_t res, uint32_t size) {
-    uint32_t idx;
-    if (HASHED) idx = x ^ (y * 2654435761u) ^ (z * 805459861u);
-    else idx = x + y * res + z * res * res;
-    return idx % size;
+__device__ __forceinline__ void cell_of(const float* __restrict__ x, const Box& box, size_t i, float scale,
+                                        uint32_t (&p)[3], float (&f)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float x01 = (__builtin_nontemporal_load(x + 3 * i + k) - box.mn[k]) * box.inv[k];
+        const float pos = fmaf(x01, scale, 0.5f);
+        const float fl = floorf(pos);
+        p[k] = (uint32_t)(int)fl;
+        f[k] = pos - fl;
+    }
 }
 
 // tiny-cuda-nn grid_index(): the dense stride walk uses the hash iff res^3 overflows the level
@@ -73,20 +76,44 @@ __device__ __forceinline__ bool level_is_hashed(uint32_t res, uint32_t size) {
     return size < stride;
 }
 
+// The 8 corner indices of a cell.  Hashed levels always have a power-of-two size (the cap
+// 2^log2_hashmap_size), so `% size` is a mask; dense indices stay below 2*size, so `% size`
+// is one conditional subtract.
+template <bool HASHED>
+__device__ __forceinline__ void corner_indices(const uint32_t (&p)[3], uint32_t res, uint32_t size, uint32_t (&idx)[8]) {
+    if (HASHED) {
+        const uint32_t hx[2] = {p[0], p[0] + 1u};
+        const uint32_t hy0 = p[1] * PRIME_Y, hz0 = p[2] * PRIME_Z;
+        const uint32_t hy[2] = {hy0, hy0 + PRIME_Y}, hz[2] = {hz0, hz0 + PRIME_Z};
+        const uint32_t mask = size - 1u;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) idx[c] = (hx[c & 1] ^ hy[(c >> 1) & 1] ^ hz[c >> 2]) & mask;
+    } else {
+        const uint32_t r2 = res * res;
+        const uint32_t base = p[0] + p[1] * res + p[2] * r2;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            uint32_t i = base + (c & 1) + ((c >> 1) & 1) * res + (c >> 2) * r2;
+            idx[c] = (i >= size) ? i - size : i;
+        }
+    }
+}
+__device__ __forceinline__ float corner_weight(int c, const float (&f)[3]) {
+    return ((c & 1) ? f[0] : 1.f - f[0]) * (((c >> 1) & 1) ? f[1] : 1.f - f[1]) * ((c >> 2) ? f[2] : 1.f - f[2]);
+}
+
 template <bool HASHED>
 __device__ __forceinline__ void encode_one(const half2_t* __restrict__ tab, uint32_t res, uint32_t size,
-                                           uint32_t px, uint32_t py, uint32_t pz, float fx, float fy, float fz,
-                                           float& o0, float& o1) {
+                                           const uint32_t (&p)[3], const float (&f)[3], float& o0, float& o1) {
+    uint32_t idx[8];
+    corner_indices<HASHED>(p, res, size, idx);
     half2_t v[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const uint32_t idx = grid_index<HASHED>(px + (c & 1), py + ((c >> 1) & 1), pz + (c >> 2), res, size);
-        v[c] = tab[idx];
-    }
+    for (int c = 0; c < 8; ++c) v[c] = tab[idx[c]];
     o0 = 0.f; o1 = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        const float w = ((c & 1) ? fx : 1.f - fx) * (((c >> 1) & 1) ? fy : 1.f - fy) * ((c >> 2) ? fz : 1.f - fz);
+        const float w = corner_weight(c, f);
         o0 = fmaf(w, (float)v[c][0], o0);
         o1 = fmaf(w, (float)v[c][1], o1);
     }
@@ -103,29 +130,31 @@ hashgrid_fwd_kernel(const float* __restrict__ x, const float* __restrict__ xyz_m
     const uint32_t res = meta.resolution[level];
     const uint32_t size = meta.offset[level + 1] - meta.offset[level];
     const half2_t* __restrict__ tab = table + meta.offset[level];
-    uint32_t px, py, pz; float fx, fy, fz;
-    cell_of(x, xyz_min, xyz_max, i, meta.scale[level], px, py, pz, fx, fy, fz);
+    const Box box = load_box(xyz_min, xyz_max);
+    uint32_t p[3]; float f[3];
+    cell_of(x, box, (size_t)i, meta.scale[level], p, f);
     float o0, o1;
-    if (level_is_hashed(res, size)) encode_one<true>(tab, res, size, px, py, pz, fx, fy, fz, o0, o1);
-    else encode_one<false>(tab, res, size, px, py, pz, fx, fy, fz, o0, o1);
+    if (level_is_hashed(res, size)) encode_one<true>(tab, res, size, p, f, o0, o1);
+    else encode_one<false>(tab, res, size, p, f, o0, o1);
     half2_t out; out[0] = (_Float16)o0; out[1] = (_Float16)o1;
     __builtin_nontemporal_store(out, feats + (size_t)level * n_samples + i);
 }
 
+// ---- backward, global-atomic flavour (kept for A/B and for accumulate semantics) ----------------
 template <bool HASHED, bool F32>
 __device__ __forceinline__ void scatter_one(void* __restrict__ grad_level, uint32_t res, uint32_t size,
-                                            uint32_t px, uint32_t py, uint32_t pz, float fx, float fy, float fz,
-                                            float g0, float g1) {
+                                            const uint32_t (&p)[3], const float (&f)[3], float g0, float g1) {
+    uint32_t idx[8];
+    corner_indices<HASHED>(p, res, size, idx);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        const uint32_t idx = grid_index<HASHED>(px + (c & 1), py + ((c >> 1) & 1), pz + (c >> 2), res, size);
-        const float w = ((c & 1) ? fx : 1.f - fx) * (((c >> 1) & 1) ? fy : 1.f - fy) * ((c >> 2) ? fz : 1.f - fz);
+        const float w = corner_weight(c, f);
         if (F32) {
-            float* g = reinterpret_cast<float*>(grad_level) + 2 * (size_t)idx;
+            float* g = reinterpret_cast<float*>(grad_level) + 2 * (size_t)idx[c];
             unsafeAtomicAdd(g, w * g0);
             unsafeAtomicAdd(g + 1, w * g1);
         } else {
-            __half2* g = reinterpret_cast<__half2*>(grad_level) + idx;
+            __half2* g = reinterpret_cast<__half2*>(grad_level) + idx[c];
             unsafeAtomicAdd(g, __floats2half2_rn(w * g0, w * g1));   // global_atomic_pk_add_f16
         }
     }
@@ -147,10 +176,11 @@ hashgrid_bwd_kernel(const float* __restrict__ x, const float* __restrict__ xyz_m
     const uint32_t size = meta.offset[level + 1] - meta.offset[level];
     void* grad_level = F32 ? (void*)(reinterpret_cast<float*>(grad_table) + 2 * (size_t)meta.offset[level])
                            : (void*)(reinterpret_cast<__half2*>(grad_table) + meta.offset[level]);
-    uint32_t px, py, pz; float fx, fy, fz;
-    cell_of(x, xyz_min, xyz_max, i, meta.scale[level], px, py, pz, fx, fy, fz);
-    if (level_is_hashed(res, size)) scatter_one<true, F32>(grad_level, res, size, px, py, pz, fx, fy, fz, g0, g1);
-    else scatter_one<false, F32>(grad_level, res, size, px, py, pz, fx, fy, fz, g0, g1);
+    const Box box = load_box(xyz_min, xyz_max);
+    uint32_t p[3]; float f[3];
+    cell_of(x, box, (size_t)i, meta.scale[level], p, f);
+    if (level_is_hashed(res, size)) scatter_one<true, F32>(grad_level, res, size, p, f, g0, g1);
+    else scatter_one<false, F32>(grad_level, res, size, p, f, g0, g1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -164,22 +194,33 @@ hashgrid_bwd_kernel(const float* __restrict__ x, const float* __restrict__ xyz_m
 // fall into its slice with ds_pk_add_f16.  The whole 22.9 MB gradient table lives in the
 // chip's 40 MB of LDS for the duration of the kernel and is written out once with plain
 // coalesced stores -- the output is OVERWRITTEN (no zero-fill, no accumulate).
+//
+// `active` (optional) lists the samples that can carry gradient (those up to a ray's early
+// stop): dfeats columns are then compact (column j belongs to sample active[j]).
 // ------------------------------------------------------------------------------------------
 constexpr int SLICE_LOG2 = 15;
 constexpr uint32_t SLICE = 1u << SLICE_LOG2;   // entries per workgroup: 32768 x 4 B = 128 KiB
 
 template <bool HASHED>
-__device__ __forceinline__ void scatter_lds(half2_t* lds, uint32_t lo, uint32_t res, uint32_t size,
-                                            uint32_t px, uint32_t py, uint32_t pz, float fx, float fy, float fz,
-                                            float g0, float g1) {
+__device__ __forceinline__ void sliced_scan(half2_t* lds, uint32_t lo, uint32_t res, uint32_t size, float scale,
+                                            const float* __restrict__ x, const Box& box,
+                                            const half2_t* __restrict__ g_level, const int32_t* __restrict__ active, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const half2_t g = g_level[i];
+        const float g0 = (float)g[0], g1 = (float)g[1];
+        if (g0 == 0.f && g1 == 0.f) continue;
+        const size_t src = active ? (size_t)active[i] : (size_t)i;
+        uint32_t p[3]; float f[3];
+        cell_of(x, box, src, scale, p, f);
+        uint32_t idx[8];
+        corner_indices<HASHED>(p, res, size, idx);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const uint32_t idx = grid_index<HASHED>(px + (c & 1), py + ((c >> 1) & 1), pz + (c >> 2), res, size);
-        const uint32_t local = idx - lo;
-        if (local < SLICE) {
-            const float w = ((c & 1) ? fx : 1.f - fx) * (((c >> 1) & 1) ? fy : 1.f - fy) * ((c >> 2) ? fz : 1.f - fz);
+        for (int c = 0; c < 8; ++c) {
+            const float w = corner_weight(c, f);
             half2_t v; v[0] = (_Float16)(w * g0); v[1] = (_Float16)(w * g1);
-            __builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) half2_t*)(lds + local), v);
+            const uint32_t local = idx[c] - lo;
+            if (local < SLICE)
+                __builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) half2_t*)(lds + local), v);
         }
     }
 }
@@ -187,6 +228,7 @@ __device__ __forceinline__ void scatter_lds(half2_t* lds, uint32_t lo, uint32_t 
 __global__ void __launch_bounds__(1024)
 hashgrid_bwd_sliced_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const float* __restrict__ xyz_max,
                            const half2_t* __restrict__ dfeats, GridMeta meta, int n_samples,
+                           const int32_t* __restrict__ active, const int32_t* __restrict__ n_active,
                            half2_t* __restrict__ grad_table) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     half2_t* lds = reinterpret_cast<half2_t*>(smem_raw);
@@ -205,21 +247,60 @@ hashgrid_bwd_sliced_kernel(const float* __restrict__ x, const float* __restrict_
     const half2_t z = {0, 0};
     for (uint32_t k = threadIdx.x; k < n_here; k += blockDim.x) lds[k] = z;
     __syncthreads();
-    const bool hashed = level_is_hashed(res, size);
-    const float scale = meta.scale[level];
+    const int n = (active && n_active) ? min(*n_active, n_samples) : n_samples;
+    const Box box = load_box(xyz_min, xyz_max);
     const half2_t* __restrict__ g_level = dfeats + (size_t)level * n_samples;
-    for (int i = threadIdx.x; i < n_samples; i += blockDim.x) {
-        const half2_t g = g_level[i];
-        const float g0 = (float)g[0], g1 = (float)g[1];
-        if (g0 == 0.f && g1 == 0.f) continue;
-        uint32_t px, py, pz; float fx, fy, fz;
-        cell_of(x, xyz_min, xyz_max, i, scale, px, py, pz, fx, fy, fz);
-        if (hashed) scatter_lds<true>(lds, lo, res, size, px, py, pz, fx, fy, fz, g0, g1);
-        else scatter_lds<false>(lds, lo, res, size, px, py, pz, fx, fy, fz, g0, g1);
-    }
+    if (level_is_hashed(res, size)) sliced_scan<true>(lds, lo, res, size, meta.scale[level], x, box, g_level, active, n);
+    else sliced_scan<false>(lds, lo, res, size, meta.scale[level], x, box, g_level, active, n);
     __syncthreads();
     half2_t* __restrict__ out = grad_table + meta.offset[level] + lo;
     for (uint32_t k = threadIdx.x; k < n_here; k += blockDim.x) out[k] = lds[k];
+}
+
+// Samples that can carry gradient: the first min(N, total+1) of every ray (composite stops a
+// ray once T <= threshold; later samples have w = 0 and exactly zero gradient).  Single
+// workgroup: scan of the per-ray counts, then each thread lists its rays' samples.
+__global__ void __launch_bounds__(1024)
+active_samples_kernel(const int64_t* __restrict__ rays_a, const int64_t* __restrict__ total_samples, int n_rays,
+                      int32_t* __restrict__ active, int32_t* __restrict__ n_active) {
+    __shared__ int s_wave[16];
+    const int tid = threadIdx.x;
+    const int per = (n_rays + 1023) / 1024;
+    const int begin = min(tid * per, n_rays), end = min(begin + per, n_rays);
+    int local = 0;
+    for (int r = begin; r < end; ++r) {
+        const int N = (int)rays_a[3 * (size_t)r + 2];
+        const int tot = (int)total_samples[rays_a[3 * (size_t)r]];
+        local += min(N, tot + 1);
+    }
+    int incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if ((tid & 63) >= o) incl += v;
+    }
+    if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+    __syncthreads();
+    if (tid < 64) {
+        int w = (tid < 16) ? s_wave[tid] : 0;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const int v = __shfl_up(w, o, 64);
+            if (tid >= o) w += v;
+        }
+        if (tid < 16) s_wave[tid] = w;
+    }
+    __syncthreads();
+    int run = ((tid >> 6) ? s_wave[(tid >> 6) - 1] : 0) + incl - local;
+    for (int r = begin; r < end; ++r) {
+        const int start = (int)rays_a[3 * (size_t)r + 1];
+        const int N = (int)rays_a[3 * (size_t)r + 2];
+        const int tot = (int)total_samples[rays_a[3 * (size_t)r]];
+        const int na = min(N, tot + 1);
+        for (int k = 0; k < na; ++k) active[run + k] = start + k;
+        run += na;
+    }
+    if (tid == 1023) *n_active = run;
 }
 
 __global__ void __launch_bounds__(256)
@@ -314,10 +395,17 @@ int ngp_hashgrid_bwd(const float* x, const float* xyz_min, const float* xyz_max,
 }
 
 int ngp_hashgrid_bwd_sliced(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* dfeats,
-                            const ngp_grid_meta* meta, int n_samples, ngp_half* grad_table, ngp_stream_t stream) {
+                            const ngp_grid_meta* meta, int n_samples, const int32_t* active_idx,
+                            const int32_t* n_active, ngp_half* grad_table, ngp_stream_t stream) {
     if (n_samples < 0 || !meta || meta->n_features != 2) return NGP_EINVAL;
     NGP_CHECK_PTR(grad_table);
     if (n_samples > 0) { NGP_CHECK_PTR(x); NGP_CHECK_PTR(xyz_min); NGP_CHECK_PTR(xyz_max); NGP_CHECK_PTR(dfeats); }
+    if ((active_idx == nullptr) != (n_active == nullptr)) return NGP_EINVAL;
+    for (int l = 0; l < meta->n_levels; ++l) {   // hashed levels must have a power-of-two size (see corner_indices)
+        const uint32_t size = meta->offset[l + 1] - meta->offset[l], res = meta->resolution[l];
+        const bool hashed = (uint64_t)res * res * res > size;
+        if (hashed && (size & (size - 1)) != 0) return NGP_EUNSUP;
+    }
     int n_blocks = 0;
     for (int l = 0; l < meta->n_levels; ++l) n_blocks += (int)((meta->offset[l + 1] - meta->offset[l] + SLICE - 1) >> SLICE_LOG2);
     constexpr int smem = (int)(SLICE * sizeof(half2_t));
@@ -329,7 +417,16 @@ int ngp_hashgrid_bwd_sliced(const float* x, const float* xyz_min, const float* x
         attr_set = true;
     }
     hashgrid_bwd_sliced_kernel<<<dim3(n_blocks), dim3(1024), smem, ngp_stream(stream)>>>(
-        x, xyz_min, xyz_max, (const half2_t*)dfeats, to_dev_meta(meta), n_samples, (half2_t*)grad_table);
+        x, xyz_min, xyz_max, (const half2_t*)dfeats, to_dev_meta(meta), n_samples, active_idx, n_active, (half2_t*)grad_table);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_active_samples(const int64_t* rays_a, const int64_t* total_samples, int n_rays, int32_t* active_idx,
+                       int32_t* n_active, ngp_stream_t stream) {
+    if (n_rays < 0) return NGP_EINVAL;
+    NGP_CHECK_PTR(n_active);
+    if (n_rays > 0) { NGP_CHECK_PTR(rays_a); NGP_CHECK_PTR(total_samples); NGP_CHECK_PTR(active_idx); }
+    hipLaunchKernelGGL(active_samples_kernel, dim3(1), dim3(1024), 0, ngp_stream(stream), rays_a, total_samples, n_rays, active_idx, n_active);
     return NGP_LAUNCH_RESULT();
 }
 

@@ -247,14 +247,18 @@ __device__ __forceinline__ Ray load_ray(const float* __restrict__ rays_o, const 
 }
 
 // Pass 1 of train marching (raymarching.cu:184-234): one march, t of every emitted sample goes
-// to the ray's scratch row.  64-thread blocks: 8192 rays -> 128 workgroups spread over the CUs
-// instead of the reference's 32 blocks of 256.
+// to the ray's scratch row.  The loop is a chain of dependent bitfield loads with per-ray trip
+// counts from 0 to ~600, so a wave costs as much as its slowest ray and both branches of every
+// step.  Rays per wave are therefore kept to MARCH_RAYS_PER_WAVE (lanes above stay idle): 8192
+// rays become 512 waves spread over all 256 CUs instead of the reference's 32 blocks of 256.
+constexpr int MARCH_RAYS_PER_WAVE = 16;
 __global__ void __launch_bounds__(64)
 march_train_count_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                          const float* __restrict__ hits_t, const float* __restrict__ noise,
                          MarchParams p, int max_samples, int n_rays,
                          int64_t* __restrict__ rays_a, float* __restrict__ t_scratch) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadIdx.x >= MARCH_RAYS_PER_WAVE) return;
+    const int r = blockIdx.x * MARCH_RAYS_PER_WAVE + threadIdx.x;
     if (r >= n_rays) return;
     const Ray ray = load_ray(rays_o, rays_d, r);
     float t1 = hits_t[2 * r];
@@ -511,7 +515,7 @@ int ngp_raymarching_train_count(const float* rays_o, const float* rays_d, const 
         NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d); NGP_CHECK_PTR(hits_t); NGP_CHECK_PTR(density_bitfield);
         NGP_CHECK_PTR(noise); NGP_CHECK_PTR(rays_a); NGP_CHECK_PTR(t_scratch);
         const MarchParams p = make_march_params(density_bitfield, cascades, grid_size, scale, scale, exp_step_factor, max_samples);
-        hipLaunchKernelGGL(march_train_count_kernel, dim3(ngp_div_up(n_rays, 64)), dim3(64), 0, ngp_stream(stream),
+        hipLaunchKernelGGL(march_train_count_kernel, dim3(ngp_div_up(n_rays, MARCH_RAYS_PER_WAVE)), dim3(64), 0, ngp_stream(stream),
                            rays_o, rays_d, hits_t, noise, p, max_samples, n_rays, rays_a, t_scratch);
     }
     hipLaunchKernelGGL(march_train_scan_kernel, dim3(1), dim3(1024), 0, ngp_stream(stream), rays_a, n_rays, counter);

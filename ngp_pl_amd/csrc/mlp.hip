@@ -277,6 +277,11 @@ struct MlpBwdIO {
     float loss_scale;
     h1* dL_din;              // IN_ROWMAJOR: (S,N_IN); IN_LEVELMAJOR: [16][S] half2; IN_SH_H: dh (S,16); may be null
     float* wgrad_partial;    // (gridDim.x, G_SIZE) f32
+    // Optional compaction: only the samples active[0 .. *n_active) are processed.  Network inputs
+    // and the f32 seeds are addressed by the sample id, the f16 gradient chain (dL_dout16 in,
+    // dL_din out) by the compact position, so rgb-net -> density-net -> grid scatter stay dense.
+    const int32_t* active;
+    const int32_t* n_active;
 };
 
 // wave-private transpose tile: [unit][sample], pitch 40 halves (80 B)
@@ -372,7 +377,8 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
     const int wave = threadIdx.x >> 6;
     h1* tx = lds + OFF_TR + wave * TR_PER_WAVE;
     h1* tdy = tx + 64 * TP;
-    const int n_tiles = (n_samples + TILE - 1) / TILE;
+    const int n_eff = io.active ? min(*io.n_active, n_samples) : n_samples;
+    const int n_tiles = (n_eff + TILE - 1) / TILE;
 
     f32x16 gW0[2][N_IN / 32 > 0 ? N_IN / 32 : 1];
     f32x16 gW1[2][2];
@@ -386,8 +392,9 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
     gWo[0][0] = zero16(); gWo[0][1] = zero16();
 
     for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
-        const long long s = (long long)tile * TILE + i;
-        const bool valid = s < n_samples;
+        const long long j = (long long)tile * TILE + i;       // compact position
+        const bool valid = j < n_eff;
+        const long long s = (io.active && valid) ? (long long)io.active[j] : j;   // sample id
         // ---- forward recompute ----
         half8_t xb[N_IN / 16];
         load_input<N_IN, IN_MODE>(io.fwd, s, valid, n_samples, hh, xb);
@@ -426,7 +433,7 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
 #pragma unroll
                     for (int r = 0; r < 8; ++r) {
                         const int u = 4 * hh + (r & 3) + 8 * (r >> 2);
-                        g[r] = (io.dL_dout16 && u < io.fwd.n_out) ? (float)io.dL_dout16[s * io.dout_ld + u] : 0.f;
+                        g[r] = (io.dL_dout16 && u < io.fwd.n_out) ? (float)io.dL_dout16[j * io.dout_ld + u] : 0.f;
                     }
                     if (OUT_MODE == OUT_DENSITY) {
                         if (hh == 0 && io.dL_dsigmas) {
@@ -502,21 +509,21 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
                     for (int r = 0; r < 16; r += 2) {
                         const int f = (r & 3) + 8 * (r >> 2) + 4 * hh;
                         half2_t v; v[0] = (h1)d[0][r]; v[1] = (h1)d[0][r + 1];
-                        __builtin_nontemporal_store(v, df + (size_t)(f >> 1) * n_samples + s);
+                        __builtin_nontemporal_store(v, df + (size_t)(f >> 1) * n_samples + j);
                     }
                 } else if (IN_MODE == IN_SH_H) {
                     half4_t lo, hi;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { lo[e] = (h1)d[0][e]; hi[e] = (h1)d[0][4 + e]; }
-                    *reinterpret_cast<half4_t*>(io.dL_din + s * 16 + 4 * hh) = lo;
-                    *reinterpret_cast<half4_t*>(io.dL_din + s * 16 + 8 + 4 * hh) = hi;
+                    *reinterpret_cast<half4_t*>(io.dL_din + j * 16 + 4 * hh) = lo;
+                    *reinterpret_cast<half4_t*>(io.dL_din + j * 16 + 8 + 4 * hh) = hi;
                 } else {
 #pragma unroll
                     for (int m = 0; m < MT_IN; ++m)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int u = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                            if (u < N_IN) io.dL_din[s * N_IN + u] = (h1)d[m][r];
+                            if (u < N_IN) io.dL_din[j * N_IN + u] = (h1)d[m][r];
                         }
                 }
             }
@@ -650,18 +657,22 @@ int ngp_field_fwd(const ngp_half* feats, const float* dirs, const ngp_half* dens
 int ngp_field_bwd_partials(int n_samples) { return n_samples <= 0 ? 0 : bwd_grid(n_samples); }
 
 int ngp_rgb_bwd(const ngp_half* h, const float* dirs, const ngp_half* rgb_w, const float* dL_drgbs, float loss_scale,
-                int n_samples, ngp_half* dL_dh, float* wgrad_partial, ngp_stream_t stream) {
+                int n_samples, const int32_t* active_idx, const int32_t* n_active, ngp_half* dL_dh, float* wgrad_partial,
+                ngp_stream_t stream) {
     if (n_samples < 0) return NGP_EINVAL;
     if (n_samples == 0) return 0;
     NGP_CHECK_PTR(h); NGP_CHECK_PTR(dirs); NGP_CHECK_PTR(rgb_w); NGP_CHECK_PTR(dL_drgbs); NGP_CHECK_PTR(dL_dh); NGP_CHECK_PTR(wgrad_partial);
     MlpBwdIO r = {};
     r.fwd.in = (const h1*)h; r.fwd.dirs = dirs; r.fwd.n_out = 3;
     r.dL_drgbs = dL_drgbs; r.loss_scale = loss_scale; r.dL_din = (h1*)dL_dh; r.wgrad_partial = wgrad_partial;
+    if ((active_idx == nullptr) != (n_active == nullptr)) return NGP_EINVAL;
+    r.active = active_idx; r.n_active = n_active;
     return launch_bwd<32, 2, IN_SH_H, OUT_RGB>(r, (const h1*)rgb_w, n_samples, ngp_stream(stream));
 }
 
 int ngp_density_bwd(const ngp_half* feats, const ngp_half* density_w, const ngp_half* dL_dh, const float* dL_dsigmas,
-                    float loss_scale, int n_samples, ngp_half* dfeats, float* wgrad_partial, ngp_stream_t stream) {
+                    float loss_scale, int n_samples, const int32_t* active_idx, const int32_t* n_active,
+                    ngp_half* dfeats, float* wgrad_partial, ngp_stream_t stream) {
     if (n_samples < 0) return NGP_EINVAL;
     if (n_samples == 0) return 0;
     NGP_CHECK_PTR(feats); NGP_CHECK_PTR(density_w); NGP_CHECK_PTR(dfeats); NGP_CHECK_PTR(wgrad_partial);
@@ -669,20 +680,24 @@ int ngp_density_bwd(const ngp_half* feats, const ngp_half* density_w, const ngp_
     d.fwd.in = (const h1*)feats; d.fwd.n_out = 16; d.fwd.out_ld = 16;
     d.dL_dout16 = (const h1*)dL_dh; d.dout_ld = 16;
     d.dL_dsigmas = dL_dsigmas; d.loss_scale = loss_scale; d.dL_din = (h1*)dfeats; d.wgrad_partial = wgrad_partial;
+    if ((active_idx == nullptr) != (n_active == nullptr)) return NGP_EINVAL;
+    d.active = active_idx; d.n_active = n_active;
     return launch_bwd<32, 1, IN_LEVELMAJOR, OUT_DENSITY>(d, (const h1*)density_w, n_samples, ngp_stream(stream));
 }
 
 int ngp_field_bwd(const ngp_half* feats, const float* dirs, const ngp_half* h, const ngp_half* density_w,
                   const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale,
-                  int n_samples, ngp_half* dh_scratch, ngp_half* dfeats, float* wgrad_partial, ngp_stream_t stream) {
+                  int n_samples, const int32_t* active_idx, const int32_t* n_active,
+                  ngp_half* dh_scratch, ngp_half* dfeats, float* wgrad_partial, ngp_stream_t stream) {
     if (n_samples < 0) return NGP_EINVAL;
     if (n_samples == 0) return 0;
     NGP_CHECK_PTR(wgrad_partial);
     const int n_part = bwd_grid(n_samples);
-    const int rc = ngp_rgb_bwd(h, dirs, rgb_w, dL_drgbs, loss_scale, n_samples, dh_scratch,
+    const int rc = ngp_rgb_bwd(h, dirs, rgb_w, dL_drgbs, loss_scale, n_samples, active_idx, n_active, dh_scratch,
                                wgrad_partial + (size_t)n_part * NGP_DENSITY_NET_PARAMS, stream);
     if (rc) return rc;
-    return ngp_density_bwd(feats, density_w, dh_scratch, dL_dsigmas, loss_scale, n_samples, dfeats, wgrad_partial, stream);
+    return ngp_density_bwd(feats, density_w, dh_scratch, dL_dsigmas, loss_scale, n_samples, active_idx, n_active, dfeats,
+                           wgrad_partial, stream);
 }
 
 int ngp_mlp_fwd(const ngp_half* in, const ngp_half* weights, int n_in, int n_hidden, int n_out, int out_act,

@@ -74,13 +74,19 @@ adam_kernel(float* __restrict__ param, h1* __restrict__ param_h, void* __restric
     }
 }
 
+// out[i] = sum_p partials[p][i].  64 columns per workgroup, 4 row lanes per column: every thread
+// keeps n_partials/4 independent loads in flight (a thread per column walking all rows serially
+// measured 62 us for 256 x 10240 on MI355X; this is ~5).
 __global__ void __launch_bounds__(256)
 reduce_partials_kernel(const float* __restrict__ partials, int n_partials, int n, float* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    __shared__ float s_acc[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), lane_row = threadIdx.x >> 6;
     float acc = 0.f;
-    for (int p = 0; p < n_partials; ++p) acc += partials[(size_t)p * n + i];
-    out[i] = acc;
+    if (col < n)
+        for (int p = lane_row; p < n_partials; p += 4) acc += partials[(size_t)p * n + col];
+    s_acc[lane_row][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (lane_row == 0 && col < n) out[col] = (s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x]) + (s_acc[2][threadIdx.x] + s_acc[3][threadIdx.x]);
 }
 
 __global__ void __launch_bounds__(256)
@@ -159,7 +165,7 @@ int ngp_reduce_partials(const float* partials, int n_partials, int n, float* out
     if (n == 0) return 0;
     NGP_CHECK_PTR(out);
     if (n_partials > 0) NGP_CHECK_PTR(partials);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ngp_div_up(n, 256)), dim3(256), 0, ngp_stream(stream), partials, n_partials, n, out);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ngp_div_up(n, 64)), dim3(256), 0, ngp_stream(stream), partials, n_partials, n, out);
     return NGP_LAUNCH_RESULT();
 }
 

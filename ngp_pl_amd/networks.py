@@ -61,10 +61,10 @@ class _FusedField(torch.autograd.Function):
             dh = torch.empty(n, 16, dtype=torch.float16, device=dev)
             dfeats = torch.empty(16, n, 2, dtype=torch.float16, device=dev)
             call("ngp_field_bwd", ptr(feats), ptr(d), ptr(h), ptr(eh), ptr(rh), ptr(dL_dsigmas), ptr(dL_drgbs), scale, n,
-                 ptr(dh), ptr(dfeats), ptr(partials), stream())
+                 None, None, ptr(dh), ptr(dfeats), ptr(partials), stream())
             g16 = model._grid_grad16(dev)
             call("ngp_hashgrid_bwd_sliced", ptr(x), ptr(model.xyz_min), ptr(model.xyz_max), ptr(dfeats), C.byref(enc.meta), n,
-                 ptr(g16), stream())
+                 None, None, ptr(g16), stream())
             p_density = partials[:n_part * enc.n_mlp]
             p_rgb = partials[n_part * enc.n_mlp:]
             if model.native_grads:

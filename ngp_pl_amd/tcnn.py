@@ -129,11 +129,11 @@ class _EncodeAndNet(torch.autograd.Function):
             n_part = call("ngp_field_bwd_partials", n)
             partials = torch.empty(n_part, mod.n_mlp, dtype=torch.float32, device=dev)
             dfeats = torch.empty(mod.n_levels, n, 2, dtype=torch.float16, device=dev)
-            call("ngp_density_bwd", ptr(feats), ptr(ph), ptr(dh), None, 1.0, n, ptr(dfeats), ptr(partials), stream())
+            call("ngp_density_bwd", ptr(feats), ptr(ph), ptr(dh), None, 1.0, n, None, None, ptr(dfeats), ptr(partials), stream())
             grad[:mod.n_mlp] = reduce_partials(partials, n_part, mod.n_mlp) / LOSS_SCALE
             g16 = torch.empty(mod.n_grid, dtype=torch.float16, device=dev)
             call("ngp_hashgrid_bwd_sliced", ptr(x), ptr(mod._zero3), ptr(mod._one3), ptr(dfeats), C.byref(mod.meta), n,
-                 ptr(g16), stream())
+                 None, None, ptr(g16), stream())
             call("ngp_cast_f16_to_f32", ptr(g16), mod.n_grid, 1.0 / LOSS_SCALE, ptr(grad[mod.n_mlp:]), stream())
         return None, grad, None
 

@@ -4,9 +4,12 @@
 
 Two implementations of the same step:
   * `step()`          -- the hot path: direct calls into libngp_hip.so, no autograd graph, native
-                         gradient buffers consumed by optim.FusedAdam.  ~20 kernel launches, one
-                         4-byte host sync (the packed sample count), the next step's ray march
-                         enqueued behind the current step so the GPU never waits for the host.
+                         gradient buffers consumed by optim.FusedAdam.  ~20 kernel launches and one
+                         8-byte host read (the packed sample count).  The ray march of step k+1
+                         only needs the occupancy bitfield, so it runs on a SECOND HIP stream
+                         concurrently with step k's encode/MLP/backward kernels (the march is a
+                         latency-bound chain of dependent loads that occupies a fraction of the
+                         CUs) and its count lands in pinned host memory before step k+1 starts.
   * `step_autograd()` -- the same maths through render() + NeRFLoss + torch autograd, i.e. what
                          the reference's train.py drives; used to check the hot path (tests).
 """
@@ -24,7 +27,7 @@ from .rendering import MAX_SAMPLES, NEAR_DISTANCE, render
 
 class Trainer:
     def __init__(self, model, lr=1e-2, num_epochs=30, steps_per_epoch=1000, T_threshold=1e-4,
-                 lambda_opacity=1e-3, grad_scale=1.0, warmup_steps=256, update_interval=16):
+                 lambda_opacity=1e-3, grad_scale=1.0, warmup_steps=256, update_interval=16, overlap_march=True):
         self.model = model
         if not hasattr(model, "density_grid"):
             model.register_training_buffers()
@@ -35,13 +38,17 @@ class Trainer:
         self.grad_scale = grad_scale
         self.global_step = 0
         self.exp_step_factor = 1 / 256 if model.scale > 0.5 else 0.0      # train.py:95-96
-        self.bg = torch.ones(3, device=model.center.device) if self.exp_step_factor == 0 else None
+        dev = model.center.device
+        self.bg = torch.ones(3, device=dev) if self.exp_step_factor == 0 else None
         self.loss_fn = NeRFLoss(lambda_opacity=lambda_opacity, lambda_distortion=0)
-        self._pending = None     # marched-but-not-consumed batch (software pipelining)
+        self.side = torch.cuda.Stream(device=dev) if (overlap_march and dev.type == "cuda") else None
+        self._pending = None     # marched-but-not-consumed batch
         self.last = {}
         self.grad_hook = None    # called between backward and optimizer (multi-GPU gradient all-reduce)
         self.events = None       # list of (stage, event) when stage timing is on (bench.py roofline)
+        self.march_ms = None
 
+    # -- stage timing ----------------------------------------------------------------------------
     def _mark(self, name):
         if self.events is not None:
             e = torch.cuda.Event(enable_timing=True)
@@ -52,7 +59,10 @@ class Trainer:
         """Elapsed time between consecutive stage marks of the last profiled step (syncs)."""
         torch.cuda.synchronize()
         ev = self.events
-        return [(ev[i + 1][0], ev[i][1].elapsed_time(ev[i + 1][1])) for i in range(len(ev) - 1)]
+        out = [(ev[i + 1][0], ev[i][1].elapsed_time(ev[i + 1][1])) for i in range(len(ev) - 1)]
+        if self.march_ms is not None:
+            out.append(("march_count(side stream)", self.march_ms[0].elapsed_time(self.march_ms[1])))
+        return out
 
     # -- pieces --------------------------------------------------------------------------------
     def _maybe_update_grid(self):
@@ -60,29 +70,47 @@ class Trainer:
             self.model.update_density_grid(0.01 * MAX_SAMPLES / 3 ** 0.5, warmup=self.global_step < self.warmup_steps)
 
     def _march(self, rays_o, rays_d):
-        """AABB + near clamp + pass 1 of the march; returns the record the main part consumes."""
+        """AABB + near clamp + pass 1 of the march (+ ray-ordered scan).  Enqueued on the side
+        stream behind everything the main stream has queued so far; the packed sample count is
+        copied to pinned host memory there."""
         m = self.model
         n, dev = rays_o.shape[0], rays_o.device
         hits_t = torch.empty(n, 2, dtype=torch.float32, device=dev)
-        noise = torch.rand(n, dtype=torch.float32, device=dev)
+        noise = torch.rand(n, dtype=torch.float32, device=dev)            # jitter of the first sample (custom_functions.py:83)
         rays_a = torch.empty(n, 3, dtype=torch.int64, device=dev)
         counter = torch.empty(2, dtype=torch.int32, device=dev)
         scratch = torch.empty(n * MAX_SAMPLES, dtype=torch.float32, device=dev)
-        call("ngp_ray_aabb_near", ptr(rays_o), ptr(rays_d), ptr(m.center), ptr(m.half_size), NEAR_DISTANCE, n, ptr(hits_t), stream())
-        call("ngp_raymarching_train_count", ptr(rays_o), ptr(rays_d), ptr(hits_t), ptr(m.density_bitfield), m.cascades,
-             float(m.scale), self.exp_step_factor, ptr(noise), m.grid_size, MAX_SAMPLES, n, ptr(rays_a), ptr(counter),
-             ptr(scratch), stream())
-        return dict(rays_o=rays_o, rays_d=rays_d, rays_a=rays_a, counter=counter, scratch=scratch, hits_t=hits_t, noise=noise)
+        counter_host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+        main = torch.cuda.current_stream()
+        st = self.side if self.side is not None else main
+        if st is not main:
+            ready = torch.cuda.Event(); ready.record(main)
+            st.wait_event(ready)
+        with torch.cuda.stream(st):
+            t0 = t1 = None
+            if self.events is not None:
+                t0 = torch.cuda.Event(enable_timing=True); t0.record()
+            call("ngp_ray_aabb_near", ptr(rays_o), ptr(rays_d), ptr(m.center), ptr(m.half_size), NEAR_DISTANCE, n, ptr(hits_t), stream())
+            call("ngp_raymarching_train_count", ptr(rays_o), ptr(rays_d), ptr(hits_t), ptr(m.density_bitfield), m.cascades,
+                 float(m.scale), self.exp_step_factor, ptr(noise), m.grid_size, MAX_SAMPLES, n, ptr(rays_a), ptr(counter),
+                 ptr(scratch), stream())
+            if self.events is not None:
+                t1 = torch.cuda.Event(enable_timing=True); t1.record()
+            counter_host.copy_(counter, non_blocking=True)
+            done = torch.cuda.Event(); done.record()
+        return dict(rays_o=rays_o, rays_d=rays_d, rays_a=rays_a, counter=counter, counter_host=counter_host, scratch=scratch,
+                    hits_t=hits_t, noise=noise, done=done, timing=(t0, t1) if t0 is not None else None)
 
     # -- the hot path --------------------------------------------------------------------------
     @torch.no_grad()
     def step(self, rays_o, rays_d, rgb_gt, next_batch=None):
         """One optimisation step on a batch of rays.  `next_batch` = (rays_o, rays_d) of the
-        following step, if known: its march is enqueued behind this step's work."""
+        following step, if known: its march overlaps this step's kernels."""
         m = self.model
         dev = rays_o.device
         enc, net = m.xyz_encoder, m.rgb_net
         with torch.cuda.device(dev):
+            main = torch.cuda.current_stream()
             if self._pending is not None and self._pending["rays_o"] is rays_o:
                 rec = self._pending
             else:
@@ -90,7 +118,15 @@ class Trainer:
                 rec = self._march(rays_o.contiguous(), rays_d.contiguous())
             self._pending = None
             n = rays_o.shape[0]
-            S = int(rec["counter"][0].item())             # the step's only host sync
+            rec["done"].synchronize()                      # the step's only host wait: the march of THIS batch
+            S = int(rec["counter_host"][0])
+            main.wait_event(rec["done"])
+            self.march_ms = rec["timing"]
+            # march of the next batch: concurrent with this step unless the occupancy grid is due
+            # for an update first (that needs this step's optimizer result)
+            next_needs_update = (self.global_step + 1) % self.update_interval == 0
+            if next_batch is not None and not next_needs_update:
+                self._pending = self._march(next_batch[0], next_batch[1])
             if self.events is not None:
                 self.events = []
             self._mark("start")
@@ -124,15 +160,19 @@ class Trainer:
                 call("ngp_composite_train_bw", ptr(dL_dopacity), ptr(dL_ddepth), ptr(dL_drgb), None, ptr(sigmas), ptr(rgbs), ptr(ws),
                      ptr(deltas), ptr(ts), ptr(rays_a), ptr(opacity), ptr(depth), ptr(rgb), self.T_threshold, n, S,
                      ptr(dL_dsigmas), ptr(dL_drgbs), stream())
+                # backward only over the samples up to each ray's early stop (the rest have zero gradient)
+                active = torch.empty(S, dtype=torch.int32, device=dev); n_active = torch.empty(1, dtype=torch.int32, device=dev)
+                call("ngp_active_samples", ptr(rays_a), ptr(total), n, ptr(active), ptr(n_active), stream())
                 self._mark("composite_bw")
                 n_part = call("ngp_field_bwd_partials", S)
                 partials = torch.empty(n_part * (enc.n_mlp + net.params.numel()), **f32)
                 dh = torch.empty(S, 16, **f16); dfeats = torch.empty(16, S, 2, **f16)
                 call("ngp_field_bwd", ptr(feats), ptr(dirs), ptr(h), ptr(eh), ptr(rh), ptr(dL_dsigmas), ptr(dL_drgbs), tcnn.LOSS_SCALE, S,
-                     ptr(dh), ptr(dfeats), ptr(partials), stream())
+                     ptr(active), ptr(n_active), ptr(dh), ptr(dfeats), ptr(partials), stream())
                 self._mark("mlp_bwd")
                 g16 = m._grid_grad16(dev)
-                call("ngp_hashgrid_bwd_sliced", ptr(xyzs), ptr(m.xyz_min), ptr(m.xyz_max), ptr(dfeats), C.byref(enc.meta), S, ptr(g16), stream())
+                call("ngp_hashgrid_bwd_sliced", ptr(xyzs), ptr(m.xyz_min), ptr(m.xyz_max), ptr(dfeats), C.byref(enc.meta), S,
+                     ptr(active), ptr(n_active), ptr(g16), stream())
                 self._mark("hashgrid_bwd")
                 m._native = dict(grid16=g16, density_partials=partials[:n_part * enc.n_mlp], rgb_partials=partials[n_part * enc.n_mlp:],
                                  n_partials=n_part, scale=tcnn.LOSS_SCALE)
@@ -144,11 +184,10 @@ class Trainer:
                 self._mark("adam")
             self.global_step += 1
             self.last = dict(stats=stats, rm_samples=S, total=total, n_rays=n, rgb=rgb, opacity=opacity)
-            if next_batch is not None:
+            if next_batch is not None and next_needs_update:
                 self._maybe_update_grid()
                 self._mark("grid_update")
                 self._pending = self._march(next_batch[0], next_batch[1])
-                self._mark("march_count")
         return self.last
 
     def metrics(self):

@@ -110,7 +110,7 @@ def test_hashgrid_backward(lib, field, mode):
     mnt = torch.full((3,), -0.5, device="cuda"); mxt = torch.full((3,), 0.5, device="cuda")
     if mode == "sliced":
         grad = torch.full((field.meta.total, 2), float("nan"), dtype=torch.float16, device="cuda")   # must be fully overwritten
-        lib.call("ngp_hashgrid_bwd_sliced", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), n, lib.ptr(grad), lib.stream())
+        lib.call("ngp_hashgrid_bwd_sliced", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), n, None, None, lib.ptr(grad), lib.stream())
     else:
         f32 = mode == "atomic_f32"
         grad = torch.zeros(field.meta.total, 2, dtype=torch.float32 if f32 else torch.float16, device="cuda")
@@ -191,7 +191,7 @@ def test_field_backward(lib, field):
     partials = torch.empty(n_part * 10240, device="cuda")
     dh = torch.empty(n, 16, dtype=torch.float16, device="cuda"); dfeats = torch.empty(16, n, 2, dtype=torch.float16, device="cuda")
     lib.call("ngp_field_bwd", lib.ptr(feats), lib.ptr(ds), lib.ptr(h), lib.ptr(dw), lib.ptr(rw), lib.ptr(dsig.cuda()), lib.ptr(drgb.cuda().contiguous()),
-             scale, n, lib.ptr(dh), lib.ptr(dfeats), lib.ptr(partials), lib.stream())
+             scale, n, None, None, lib.ptr(dh), lib.ptr(dfeats), lib.ptr(partials), lib.stream())
     gd = torch.empty(3072, device="cuda"); gr = torch.empty(7168, device="cuda")
     lib.call("ngp_reduce_partials", lib.ptr(partials), n_part, 3072, lib.ptr(gd), lib.stream())
     lib.call("ngp_reduce_partials", lib.ptr(partials[n_part * 3072:]), n_part, 7168, lib.ptr(gr), lib.stream())
@@ -242,3 +242,45 @@ def test_unsupported_config_is_loud(lib):
     from ngp_pl_amd import tcnn
     with pytest.raises(NotImplementedError):
         tcnn.Network(32, 3, {"otype": "FullyFusedMLP", "activation": "Tanh", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 2})
+
+
+def test_active_sample_compaction(lib, field):
+    """Backward over the compacted active-sample list == backward over all samples when the
+    skipped samples carry zero seeds (what compositing guarantees past a ray's early stop)."""
+    meta = native_meta(lib)
+    g = torch.Generator().manual_seed(12)
+    n_rays = 700
+    counts = torch.randint(0, 60, (n_rays,), generator=g)
+    counts[5] = 0
+    start = torch.cumsum(counts, 0) - counts
+    n = int(counts.sum())
+    rays_a = torch.stack([torch.arange(n_rays), start, counts], 1).contiguous()
+    total = torch.minimum(counts, torch.randint(0, 70, (n_rays,), generator=g))      # samples before the stop
+    n_act = torch.minimum(counts, total + 1)
+    mask = torch.zeros(n, dtype=torch.bool)
+    for r in range(n_rays):
+        mask[start[r]:start[r] + n_act[r]] = True
+    x, d = sample_points(n, seed=13, edges=False)
+    feats, sig, rgb, h, dw, rw, ds = field_native(lib, field, x, d)
+    dsig = torch.randn(n, generator=g) * 1e-3 * mask
+    drgb = torch.randn(n, 3, generator=g) * 1e-2 * mask[:, None]
+    xs = x.cuda().contiguous()
+    mnt = torch.full((3,), -0.5, device="cuda"); mxt = torch.full((3,), 0.5, device="cuda")
+    active = torch.full((n,), -1, dtype=torch.int32, device="cuda"); n_active = torch.zeros(1, dtype=torch.int32, device="cuda")
+    lib.call("ngp_active_samples", lib.ptr(rays_a.cuda()), lib.ptr(total.cuda()), n_rays, lib.ptr(active), lib.ptr(n_active), lib.stream())
+    assert int(n_active.item()) == int(mask.sum())
+    assert torch.equal(active[:int(n_active.item())].cpu().long(), torch.nonzero(mask)[:, 0])      # ray order, bit-exact
+    outs = []
+    for use_active in (False, True):
+        n_part = lib.call("ngp_field_bwd_partials", n)
+        partials = torch.zeros(n_part * 10240, device="cuda")
+        dh = torch.zeros(n, 16, dtype=torch.float16, device="cuda"); dfeats = torch.zeros(16, n, 2, dtype=torch.float16, device="cuda")
+        a, na = (lib.ptr(active), lib.ptr(n_active)) if use_active else (None, None)
+        lib.call("ngp_field_bwd", lib.ptr(feats), lib.ptr(ds), lib.ptr(h), lib.ptr(dw), lib.ptr(rw), lib.ptr(dsig.cuda()), lib.ptr(drgb.cuda().contiguous()),
+                 128.0, n, a, na, lib.ptr(dh), lib.ptr(dfeats), lib.ptr(partials), lib.stream())
+        grad = torch.full((field.meta.total, 2), float("nan"), dtype=torch.float16, device="cuda")
+        lib.call("ngp_hashgrid_bwd_sliced", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfeats), C.byref(meta), n, a, na, lib.ptr(grad), lib.stream())
+        outs.append((partials.view(n_part, 10240).sum(0).cpu(), grad.float().cpu()))
+    (w0, g0), (w1, g1) = outs
+    assert ((w0 - w1).abs().max() / w0.abs().max()).item() < 1e-4       # same terms, different partial-sum grouping
+    assert ((g0 - g1).abs().max() / g0.abs().max()).item() < 5e-3       # f16 accumulation order differs
