@@ -218,9 +218,11 @@ int ngp_hashgrid_bwd_sliced(const float* x, const float* xyz_min, const float* x
                             ngp_half* grad_table, ngp_stream_t stream);
 /* The samples that can carry gradient after compositing: the first min(N, total_samples+1) of
  * every ray (later ones have w = 0 exactly, volumerendering.cu:41).  Writes their ids in ray
- * order to active_idx (capacity S) and the count to n_active (device i32).  No host sync. */
+ * order to active_idx (capacity S) and the count to n_active (device i32); ray_offsets (R) i32
+ * receives each ray's offset into the list.  No host sync. */
 int ngp_active_samples(const int64_t* rays_a, const int64_t* total_samples, int n_rays,
-                       int32_t* active_idx, int32_t* n_active, ngp_stream_t stream);
+                       int32_t* ray_offsets, int32_t* active_idx, int32_t* n_active,
+                       ngp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * tinycudann: FullyFusedMLP + SphericalHarmonics  (call sites networks.py:49-77)

@@ -50,7 +50,7 @@ _PROTOS = {
     "ngp_hashgrid_fwd": [P, P, P, P, C.POINTER(GridMeta), I, P, P],
     "ngp_hashgrid_bwd": [P, P, P, P, C.POINTER(GridMeta), I, P, I, P],
     "ngp_hashgrid_bwd_sliced": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P, P],
-    "ngp_active_samples": [P, P, I, P, P, P],
+    "ngp_active_samples": [P, P, I, P, P, P, P],
     "ngp_density_fwd": [P, P, I, P, P, P],
     "ngp_rgb_fwd": [P, P, P, I, P, P],
     "ngp_field_fwd": [P, P, P, P, I, P, P, P, P],

@@ -225,6 +225,60 @@ __device__ __forceinline__ void sliced_scan(half2_t* lds, uint32_t lo, uint32_t 
     }
 }
 
+// Dense (coarse) levels: consecutive samples of a ray sit in the same cell for 10-40 steps, so a
+// wave of 64 consecutive samples hammers the same 8 LDS words (same-address atomics serialise:
+// this made the level-0..2 workgroups 5x slower than the hashed ones).  Here a thread walks RUN
+// consecutive samples, accumulates the 8 corner sums in registers while the cell stays the same
+// and touches LDS only when the cell changes.
+constexpr int RUN = 16;
+__device__ __forceinline__ void flush_run(half2_t* lds, uint32_t lo, uint32_t res, uint32_t size, uint32_t key,
+                                          const float (&a0)[8], const float (&a1)[8]) {
+    const uint32_t r2 = res * res;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        uint32_t i = key + (c & 1) + ((c >> 1) & 1) * res + (c >> 2) * r2;
+        i = (i >= size) ? i - size : i;
+        const uint32_t local = i - lo;
+        if (local < SLICE && (a0[c] != 0.f || a1[c] != 0.f)) {
+            half2_t v; v[0] = (_Float16)a0[c]; v[1] = (_Float16)a1[c];
+            __builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) half2_t*)(lds + local), v);
+        }
+    }
+}
+__device__ __forceinline__ void sliced_scan_dense_runs(half2_t* lds, uint32_t lo, uint32_t res, uint32_t size, float scale,
+                                                       const float* __restrict__ x, const Box& box,
+                                                       const half2_t* __restrict__ g_level, const int32_t* __restrict__ active, int n) {
+    const uint32_t r2 = res * res;
+    for (int base = threadIdx.x * RUN; base < n; base += blockDim.x * RUN) {
+        float a0[8], a1[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { a0[c] = 0.f; a1[c] = 0.f; }
+        uint32_t cur = 0xFFFFFFFFu;
+        const int end = min(base + RUN, n);
+        for (int i = base; i < end; ++i) {
+            const half2_t g = g_level[i];
+            const float g0 = (float)g[0], g1 = (float)g[1];
+            if (g0 == 0.f && g1 == 0.f) continue;
+            const size_t src = active ? (size_t)active[i] : (size_t)i;
+            uint32_t p[3]; float f[3];
+            cell_of(x, box, src, scale, p, f);
+            const uint32_t key = p[0] + p[1] * res + p[2] * r2;
+            if (key != cur) {
+                if (cur != 0xFFFFFFFFu) flush_run(lds, lo, res, size, cur, a0, a1);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { a0[c] = 0.f; a1[c] = 0.f; }
+                cur = key;
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float w = corner_weight(c, f);
+                a0[c] = fmaf(w, g0, a0[c]); a1[c] = fmaf(w, g1, a1[c]);
+            }
+        }
+        if (cur != 0xFFFFFFFFu) flush_run(lds, lo, res, size, cur, a0, a1);
+    }
+}
+
 __global__ void __launch_bounds__(1024)
 hashgrid_bwd_sliced_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const float* __restrict__ xyz_max,
                            const half2_t* __restrict__ dfeats, GridMeta meta, int n_samples,
@@ -251,28 +305,33 @@ hashgrid_bwd_sliced_kernel(const float* __restrict__ x, const float* __restrict_
     const Box box = load_box(xyz_min, xyz_max);
     const half2_t* __restrict__ g_level = dfeats + (size_t)level * n_samples;
     if (level_is_hashed(res, size)) sliced_scan<true>(lds, lo, res, size, meta.scale[level], x, box, g_level, active, n);
-    else sliced_scan<false>(lds, lo, res, size, meta.scale[level], x, box, g_level, active, n);
+    else sliced_scan_dense_runs(lds, lo, res, size, meta.scale[level], x, box, g_level, active, n);
     __syncthreads();
     half2_t* __restrict__ out = grad_table + meta.offset[level] + lo;
     for (uint32_t k = threadIdx.x; k < n_here; k += blockDim.x) out[k] = lds[k];
 }
 
 // Samples that can carry gradient: the first min(N, total+1) of every ray (composite stops a
-// ray once T <= threshold; later samples have w = 0 and exactly zero gradient).  Single
-// workgroup: scan of the per-ray counts, then each thread lists its rays' samples.
+// ray once T <= threshold; later samples have w = 0 and exactly zero gradient).  Three small
+// kernels: per-ray count, single-workgroup scan, wave-per-ray listing (ray order, deterministic).
+__global__ void __launch_bounds__(256)
+active_count_kernel(const int64_t* __restrict__ rays_a, const int64_t* __restrict__ total_samples, int n_rays,
+                    int32_t* __restrict__ n_act) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const int N = (int)rays_a[3 * (size_t)r + 2];
+    const int tot = (int)total_samples[rays_a[3 * (size_t)r]];
+    n_act[r] = min(N, tot + 1);
+}
+// in place: n_act[r] <- exclusive prefix; *n_active <- total
 __global__ void __launch_bounds__(1024)
-active_samples_kernel(const int64_t* __restrict__ rays_a, const int64_t* __restrict__ total_samples, int n_rays,
-                      int32_t* __restrict__ active, int32_t* __restrict__ n_active) {
+active_scan_kernel(int32_t* __restrict__ n_act, int n_rays, int32_t* __restrict__ n_active) {
     __shared__ int s_wave[16];
     const int tid = threadIdx.x;
     const int per = (n_rays + 1023) / 1024;
     const int begin = min(tid * per, n_rays), end = min(begin + per, n_rays);
     int local = 0;
-    for (int r = begin; r < end; ++r) {
-        const int N = (int)rays_a[3 * (size_t)r + 2];
-        const int tot = (int)total_samples[rays_a[3 * (size_t)r]];
-        local += min(N, tot + 1);
-    }
+    for (int r = begin; r < end; ++r) local += n_act[r];
     int incl = local;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -292,15 +351,20 @@ active_samples_kernel(const int64_t* __restrict__ rays_a, const int64_t* __restr
     }
     __syncthreads();
     int run = ((tid >> 6) ? s_wave[(tid >> 6) - 1] : 0) + incl - local;
-    for (int r = begin; r < end; ++r) {
-        const int start = (int)rays_a[3 * (size_t)r + 1];
-        const int N = (int)rays_a[3 * (size_t)r + 2];
-        const int tot = (int)total_samples[rays_a[3 * (size_t)r]];
-        const int na = min(N, tot + 1);
-        for (int k = 0; k < na; ++k) active[run + k] = start + k;
-        run += na;
-    }
+    for (int r = begin; r < end; ++r) { const int c = n_act[r]; n_act[r] = run; run += c; }
     if (tid == 1023) *n_active = run;
+}
+__global__ void __launch_bounds__(256)
+active_write_kernel(const int64_t* __restrict__ rays_a, const int64_t* __restrict__ total_samples,
+                    const int32_t* __restrict__ offs, int n_rays, int32_t* __restrict__ active) {
+    const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (r >= n_rays) return;
+    const int start = (int)rays_a[3 * (size_t)r + 1];
+    const int N = (int)rays_a[3 * (size_t)r + 2];
+    const int tot = (int)total_samples[rays_a[3 * (size_t)r]];
+    const int na = min(N, tot + 1), off = offs[r];
+    for (int k = lane; k < na; k += 64) active[off + k] = start + k;
 }
 
 __global__ void __launch_bounds__(256)
@@ -421,12 +485,18 @@ int ngp_hashgrid_bwd_sliced(const float* x, const float* xyz_min, const float* x
     return NGP_LAUNCH_RESULT();
 }
 
-int ngp_active_samples(const int64_t* rays_a, const int64_t* total_samples, int n_rays, int32_t* active_idx,
-                       int32_t* n_active, ngp_stream_t stream) {
+int ngp_active_samples(const int64_t* rays_a, const int64_t* total_samples, int n_rays, int32_t* ray_offsets,
+                       int32_t* active_idx, int32_t* n_active, ngp_stream_t stream) {
     if (n_rays < 0) return NGP_EINVAL;
     NGP_CHECK_PTR(n_active);
-    if (n_rays > 0) { NGP_CHECK_PTR(rays_a); NGP_CHECK_PTR(total_samples); NGP_CHECK_PTR(active_idx); }
-    hipLaunchKernelGGL(active_samples_kernel, dim3(1), dim3(1024), 0, ngp_stream(stream), rays_a, total_samples, n_rays, active_idx, n_active);
+    if (n_rays > 0) { NGP_CHECK_PTR(rays_a); NGP_CHECK_PTR(total_samples); NGP_CHECK_PTR(active_idx); NGP_CHECK_PTR(ray_offsets); }
+    hipStream_t st = ngp_stream(stream);
+    if (n_rays > 0)
+        hipLaunchKernelGGL(active_count_kernel, dim3(ngp_div_up(n_rays, 256)), dim3(256), 0, st, rays_a, total_samples, n_rays, ray_offsets);
+    hipLaunchKernelGGL(active_scan_kernel, dim3(1), dim3(1024), 0, st, ray_offsets, n_rays, n_active);
+    if (n_rays > 0)
+        hipLaunchKernelGGL(active_write_kernel, dim3(ngp_div_up((long long)n_rays * 64, 256)), dim3(256), 0, st,
+                           rays_a, total_samples, ray_offsets, n_rays, active_idx);
     return NGP_LAUNCH_RESULT();
 }
 

@@ -162,7 +162,8 @@ class Trainer:
                      ptr(dL_dsigmas), ptr(dL_drgbs), stream())
                 # backward only over the samples up to each ray's early stop (the rest have zero gradient)
                 active = torch.empty(S, dtype=torch.int32, device=dev); n_active = torch.empty(1, dtype=torch.int32, device=dev)
-                call("ngp_active_samples", ptr(rays_a), ptr(total), n, ptr(active), ptr(n_active), stream())
+                ray_offs = torch.empty(n, dtype=torch.int32, device=dev)
+                call("ngp_active_samples", ptr(rays_a), ptr(total), n, ptr(ray_offs), ptr(active), ptr(n_active), stream())
                 self._mark("composite_bw")
                 n_part = call("ngp_field_bwd_partials", S)
                 partials = torch.empty(n_part * (enc.n_mlp + net.params.numel()), **f32)

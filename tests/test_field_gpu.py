@@ -190,7 +190,8 @@ def test_field_backward(lib, field):
     n_part = lib.call("ngp_field_bwd_partials", n)
     partials = torch.empty(n_part * 10240, device="cuda")
     dh = torch.empty(n, 16, dtype=torch.float16, device="cuda"); dfeats = torch.empty(16, n, 2, dtype=torch.float16, device="cuda")
-    lib.call("ngp_field_bwd", lib.ptr(feats), lib.ptr(ds), lib.ptr(h), lib.ptr(dw), lib.ptr(rw), lib.ptr(dsig.cuda()), lib.ptr(drgb.cuda().contiguous()),
+    dsig_d, drgb_d = dsig.cuda(), drgb.cuda().contiguous()      # named: a temporary would be freed before the kernel runs
+    lib.call("ngp_field_bwd", lib.ptr(feats), lib.ptr(ds), lib.ptr(h), lib.ptr(dw), lib.ptr(rw), lib.ptr(dsig_d), lib.ptr(drgb_d),
              scale, n, None, None, lib.ptr(dh), lib.ptr(dfeats), lib.ptr(partials), lib.stream())
     gd = torch.empty(3072, device="cuda"); gr = torch.empty(7168, device="cuda")
     lib.call("ngp_reduce_partials", lib.ptr(partials), n_part, 3072, lib.ptr(gd), lib.stream())
@@ -228,7 +229,8 @@ def test_generic_mlp(lib, n_in, n_hidden, n_out, act):
     n_part = lib.call("ngp_mlp_bwd_partials", n)
     partials = torch.empty(n_part, w.numel(), device="cuda")
     din = torch.empty(n, n_in, dtype=torch.float16, device="cuda")
-    lib.call("ngp_mlp_bwd", lib.ptr(xc), lib.ptr(wh), lib.ptr(dout.cuda()), n_in, n_hidden, n_out, act, n, lib.ptr(din), lib.ptr(partials), lib.stream())
+    dout_d = dout.cuda()
+    lib.call("ngp_mlp_bwd", lib.ptr(xc), lib.ptr(wh), lib.ptr(dout_d), n_in, n_hidden, n_out, act, n, lib.ptr(din), lib.ptr(partials), lib.stream())
     gw = partials.sum(0).cpu()
     assert ((gw - wp.grad).abs().max() / wp.grad.abs().max()).item() < 1e-2
     dgot = din.float().cpu()
@@ -267,7 +269,9 @@ def test_active_sample_compaction(lib, field):
     xs = x.cuda().contiguous()
     mnt = torch.full((3,), -0.5, device="cuda"); mxt = torch.full((3,), 0.5, device="cuda")
     active = torch.full((n,), -1, dtype=torch.int32, device="cuda"); n_active = torch.zeros(1, dtype=torch.int32, device="cuda")
-    lib.call("ngp_active_samples", lib.ptr(rays_a.cuda()), lib.ptr(total.cuda()), n_rays, lib.ptr(active), lib.ptr(n_active), lib.stream())
+    rays_a_d, total_d = rays_a.cuda(), total.cuda()
+    n_act_d = torch.empty(n_rays, dtype=torch.int32, device="cuda")
+    lib.call("ngp_active_samples", lib.ptr(rays_a_d), lib.ptr(total_d), n_rays, lib.ptr(n_act_d), lib.ptr(active), lib.ptr(n_active), lib.stream())
     assert int(n_active.item()) == int(mask.sum())
     assert torch.equal(active[:int(n_active.item())].cpu().long(), torch.nonzero(mask)[:, 0])      # ray order, bit-exact
     outs = []
@@ -276,7 +280,8 @@ def test_active_sample_compaction(lib, field):
         partials = torch.zeros(n_part * 10240, device="cuda")
         dh = torch.zeros(n, 16, dtype=torch.float16, device="cuda"); dfeats = torch.zeros(16, n, 2, dtype=torch.float16, device="cuda")
         a, na = (lib.ptr(active), lib.ptr(n_active)) if use_active else (None, None)
-        lib.call("ngp_field_bwd", lib.ptr(feats), lib.ptr(ds), lib.ptr(h), lib.ptr(dw), lib.ptr(rw), lib.ptr(dsig.cuda()), lib.ptr(drgb.cuda().contiguous()),
+        dsig_d, drgb_d = dsig.cuda(), drgb.cuda().contiguous()
+        lib.call("ngp_field_bwd", lib.ptr(feats), lib.ptr(ds), lib.ptr(h), lib.ptr(dw), lib.ptr(rw), lib.ptr(dsig_d), lib.ptr(drgb_d),
                  128.0, n, a, na, lib.ptr(dh), lib.ptr(dfeats), lib.ptr(partials), lib.stream())
         grad = torch.full((field.meta.total, 2), float("nan"), dtype=torch.float16, device="cuda")
         lib.call("ngp_hashgrid_bwd_sliced", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfeats), C.byref(meta), n, a, na, lib.ptr(grad), lib.stream())
