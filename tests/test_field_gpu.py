@@ -285,7 +285,8 @@ def test_active_sample_compaction(lib, field):
                  128.0, n, a, na, lib.ptr(dh), lib.ptr(dfeats), lib.ptr(partials), lib.stream())
         grad = torch.full((field.meta.total, 2), float("nan"), dtype=torch.float16, device="cuda")
         lib.call("ngp_hashgrid_bwd_sliced", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfeats), C.byref(meta), n, a, na, lib.ptr(grad), lib.stream())
-        outs.append((partials.view(n_part, 10240).sum(0).cpu(), grad.float().cpu()))
+        wsum = torch.cat([partials[:n_part * 3072].view(n_part, 3072).sum(0), partials[n_part * 3072:].view(n_part, 7168).sum(0)])
+        outs.append((wsum.cpu(), grad.float().cpu()))
     (w0, g0), (w1, g1) = outs
     assert ((w0 - w1).abs().max() / w0.abs().max()).item() < 1e-4       # same terms, different partial-sum grouping
     assert ((g0 - g1).abs().max() / g0.abs().max()).item() < 5e-3       # f16 accumulation order differs
