@@ -23,6 +23,7 @@
 //     gradient table is privatised slice by slice in LDS (see hashgrid_bwd_sliced_kernel).
 #include "ngp_common.h"
 #include <hip/hip_fp16.h>
+#include <cstdlib>
 
 namespace {
 
@@ -198,29 +199,69 @@ hashgrid_bwd_kernel(const float* __restrict__ x, const float* __restrict__ xyz_m
 // `active` (optional) lists the samples that can carry gradient (those up to a ray's early
 // stop): dfeats columns are then compact (column j belongs to sample active[j]).
 // ------------------------------------------------------------------------------------------
-constexpr int SLICE_LOG2 = 15;
-constexpr uint32_t SLICE = 1u << SLICE_LOG2;   // entries per workgroup: 32768 x 4 B = 128 KiB
+// Decomposition (measured on MI355X, tools/lds_atomic_bench.hip: an LDS *float* atomic costs ~3
+// cycles per active lane -- integer ones run at full rate -- so a workgroup's time is ~3 cycles x
+// the corner updates that land in its slice; the split below equalises that over ~253 CUs):
+//   hashed levels : 20 slices of SLICE entries each, every slice owner scans all samples;
+//   dense levels  : few slices, but all of a level's updates land in them, so their samples are
+//                   ALSO split over K workgroups whose private copies are merged with global
+//                   packed-f16 atomics (non-zero words only; <1 M atomics per step in total).
+constexpr uint32_t SLICE = 27600;               // entries per workgroup: 19 slices per 2^19-entry level, 107.8 KiB of LDS
+struct SlicePlan { int32_t n_slices[NGP_MAX_LEVELS]; int32_t k_split[NGP_MAX_LEVELS]; int32_t run_max_res; };
+
+// Every trip of the scan loop needs g, (active,) and x from global memory before it can do
+// anything, and a workgroup only has 4 waves per SIMD to hide that (LDS caps it at one workgroup
+// per CU): measured, the loop ran at one global-load round trip (~2800 cycles) per trip.  So each
+// thread handles BATCH samples per trip and issues all their loads before touching any of them.
+constexpr int BATCH = 4;
+struct SampleIn { float g0, g1, x[3]; };
+__device__ __forceinline__ SampleIn load_sample(const float* __restrict__ x, const half2_t* __restrict__ g_level,
+                                                const int32_t* __restrict__ active, int i, int n) {
+    SampleIn s;
+    const int ic = min(i, n - 1);                               // clamp: the load is unconditional
+    const half2_t g = g_level[ic];
+    const size_t src = active ? (size_t)active[ic] : (size_t)ic;
+    s.g0 = (i < n) ? (float)g[0] : 0.f; s.g1 = (i < n) ? (float)g[1] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s.x[k] = x[3 * src + k];       // plain loads: x is re-read by every slice owner, keep it in L2
+    return s;
+}
+__device__ __forceinline__ void cell_of_loaded(const float (&xin)[3], const Box& box, float scale, uint32_t (&p)[3], float (&f)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float pos = fmaf((xin[k] - box.mn[k]) * box.inv[k], scale, 0.5f);
+        const float fl = floorf(pos);
+        p[k] = (uint32_t)(int)fl;
+        f[k] = pos - fl;
+    }
+}
 
 template <bool HASHED>
-__device__ __forceinline__ void sliced_scan(half2_t* lds, uint32_t lo, uint32_t res, uint32_t size, float scale,
+__device__ __forceinline__ void sliced_scan(half2_t* lds, uint32_t lo, uint32_t len, uint32_t res, uint32_t size, float scale,
                                             const float* __restrict__ x, const Box& box,
-                                            const half2_t* __restrict__ g_level, const int32_t* __restrict__ active, int n) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const half2_t g = g_level[i];
-        const float g0 = (float)g[0], g1 = (float)g[1];
-        if (g0 == 0.f && g1 == 0.f) continue;
-        const size_t src = active ? (size_t)active[i] : (size_t)i;
-        uint32_t p[3]; float f[3];
-        cell_of(x, box, src, scale, p, f);
-        uint32_t idx[8];
-        corner_indices<HASHED>(p, res, size, idx);
+                                            const half2_t* __restrict__ g_level, const int32_t* __restrict__ active,
+                                            int n_begin, int n) {
+    if (n <= n_begin) return;
+    for (int base = n_begin + threadIdx.x; base < n; base += BATCH * blockDim.x) {
+        SampleIn in[BATCH];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float w = corner_weight(c, f);
-            half2_t v; v[0] = (_Float16)(w * g0); v[1] = (_Float16)(w * g1);
-            const uint32_t local = idx[c] - lo;
-            if (local < SLICE)
-                __builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) half2_t*)(lds + local), v);
+        for (int b = 0; b < BATCH; ++b) in[b] = load_sample(x, g_level, active, base + b * (int)blockDim.x, n);
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b) {
+            const float g0 = in[b].g0, g1 = in[b].g1;
+            if (g0 == 0.f && g1 == 0.f) continue;
+            uint32_t p[3]; float f[3];
+            cell_of_loaded(in[b].x, box, scale, p, f);
+            uint32_t idx[8];
+            corner_indices<HASHED>(p, res, size, idx);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float w = corner_weight(c, f);
+                half2_t v; v[0] = (_Float16)(w * g0); v[1] = (_Float16)(w * g1);
+                const uint32_t local = idx[c] - lo;
+                if (local < len)
+                    __builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) half2_t*)(lds + local), v);
+            }
         }
     }
 }
@@ -231,7 +272,7 @@ __device__ __forceinline__ void sliced_scan(half2_t* lds, uint32_t lo, uint32_t 
 // consecutive samples, accumulates the 8 corner sums in registers while the cell stays the same
 // and touches LDS only when the cell changes.
 constexpr int RUN = 16;
-__device__ __forceinline__ void flush_run(half2_t* lds, uint32_t lo, uint32_t res, uint32_t size, uint32_t key,
+__device__ __forceinline__ void flush_run(half2_t* lds, uint32_t lo, uint32_t len, uint32_t res, uint32_t size, uint32_t key,
                                           const float (&a0)[8], const float (&a1)[8]) {
     const uint32_t r2 = res * res;
 #pragma unroll
@@ -245,70 +286,92 @@ __device__ __forceinline__ void flush_run(half2_t* lds, uint32_t lo, uint32_t re
         }
     }
 }
-__device__ __forceinline__ void sliced_scan_dense_runs(half2_t* lds, uint32_t lo, uint32_t res, uint32_t size, float scale,
+__device__ __forceinline__ void sliced_scan_dense_runs(half2_t* lds, uint32_t lo, uint32_t len, uint32_t res, uint32_t size, float scale,
                                                        const float* __restrict__ x, const Box& box,
-                                                       const half2_t* __restrict__ g_level, const int32_t* __restrict__ active, int n) {
+                                                       const half2_t* __restrict__ g_level, const int32_t* __restrict__ active,
+                                                       int n_begin, int n) {
     const uint32_t r2 = res * res;
-    for (int base = threadIdx.x * RUN; base < n; base += blockDim.x * RUN) {
+    if (n <= n_begin) return;
+    for (int base = n_begin + threadIdx.x * RUN; base < n; base += blockDim.x * RUN) {
         float a0[8], a1[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) { a0[c] = 0.f; a1[c] = 0.f; }
         uint32_t cur = 0xFFFFFFFFu;
-        const int end = min(base + RUN, n);
-        for (int i = base; i < end; ++i) {
-            const half2_t g = g_level[i];
-            const float g0 = (float)g[0], g1 = (float)g[1];
-            if (g0 == 0.f && g1 == 0.f) continue;
-            const size_t src = active ? (size_t)active[i] : (size_t)i;
-            uint32_t p[3]; float f[3];
-            cell_of(x, box, src, scale, p, f);
-            const uint32_t key = p[0] + p[1] * res + p[2] * r2;
-            if (key != cur) {
-                if (cur != 0xFFFFFFFFu) flush_run(lds, lo, res, size, cur, a0, a1);
+        for (int half = 0; half < RUN; half += 8) {          // loads of 8 samples in flight at a time
+            if (base + half >= n) break;
+            SampleIn in[8];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) { a0[c] = 0.f; a1[c] = 0.f; }
-                cur = key;
-            }
+            for (int b = 0; b < 8; ++b) in[b] = load_sample(x, g_level, active, base + half + b, n);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float w = corner_weight(c, f);
-                a0[c] = fmaf(w, g0, a0[c]); a1[c] = fmaf(w, g1, a1[c]);
+            for (int b = 0; b < 8; ++b) {
+                const float g0 = in[b].g0, g1 = in[b].g1;
+                if (g0 == 0.f && g1 == 0.f) continue;
+                uint32_t p[3]; float f[3];
+                cell_of_loaded(in[b].x, box, scale, p, f);
+                const uint32_t key = p[0] + p[1] * res + p[2] * r2;
+                if (key != cur) {
+                    if (cur != 0xFFFFFFFFu) flush_run(lds, lo, len, res, size, cur, a0, a1);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) { a0[c] = 0.f; a1[c] = 0.f; }
+                    cur = key;
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float w = corner_weight(c, f);
+                    a0[c] = fmaf(w, g0, a0[c]); a1[c] = fmaf(w, g1, a1[c]);
+                }
             }
         }
-        if (cur != 0xFFFFFFFFu) flush_run(lds, lo, res, size, cur, a0, a1);
+        if (cur != 0xFFFFFFFFu) flush_run(lds, lo, len, res, size, cur, a0, a1);
     }
 }
 
 __global__ void __launch_bounds__(1024)
 hashgrid_bwd_sliced_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const float* __restrict__ xyz_max,
-                           const half2_t* __restrict__ dfeats, GridMeta meta, int n_samples,
+                           const half2_t* __restrict__ dfeats, GridMeta meta, SlicePlan plan, int n_samples,
                            const int32_t* __restrict__ active, const int32_t* __restrict__ n_active,
                            half2_t* __restrict__ grad_table) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     half2_t* lds = reinterpret_cast<half2_t*>(smem_raw);
-    // workgroup -> (level, slice)
-    int level = 0, slice = (int)blockIdx.x;
+    // workgroup -> (level, slice, sample split)
+    int level = 0, rem = (int)blockIdx.x;
     for (; level < meta.n_levels; ++level) {
-        const int n_slices = (int)((meta.offset[level + 1] - meta.offset[level] + SLICE - 1) >> SLICE_LOG2);
-        if (slice < n_slices) break;
-        slice -= n_slices;
+        const int nb = plan.n_slices[level] * plan.k_split[level];
+        if (rem < nb) break;
+        rem -= nb;
     }
     if (level >= meta.n_levels) return;
+    const int K = plan.k_split[level];
+    const int slice = rem / K, part = rem - slice * K;
     const uint32_t res = meta.resolution[level];
     const uint32_t size = meta.offset[level + 1] - meta.offset[level];
-    const uint32_t lo = (uint32_t)slice << SLICE_LOG2;
-    const uint32_t n_here = min(SLICE, size - lo);
+    const uint32_t lo = (uint32_t)slice * SLICE;
+    const uint32_t len = min(SLICE, size - lo);
     const half2_t z = {0, 0};
-    for (uint32_t k = threadIdx.x; k < n_here; k += blockDim.x) lds[k] = z;
+    for (uint32_t k = threadIdx.x; k < len; k += blockDim.x) lds[k] = z;
     __syncthreads();
     const int n = (active && n_active) ? min(*n_active, n_samples) : n_samples;
+    // sample range of this split, aligned to the run length so runs are never cut
+    const int per = ((n + K - 1) / K + RUN - 1) / RUN * RUN;
+    const int n_begin = min(part * per, n), n_end = min(n_begin + per, n);
     const Box box = load_box(xyz_min, xyz_max);
     const half2_t* __restrict__ g_level = dfeats + (size_t)level * n_samples;
-    if (level_is_hashed(res, size)) sliced_scan<true>(lds, lo, res, size, meta.scale[level], x, box, g_level, active, n);
-    else sliced_scan_dense_runs(lds, lo, res, size, meta.scale[level], x, box, g_level, active, n);
+    if (level_is_hashed(res, size)) sliced_scan<true>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, n_begin, n_end);
+    else if ((int)res > plan.run_max_res) sliced_scan<false>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, n_begin, n_end);
+    else sliced_scan_dense_runs(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, n_begin, n_end);
     __syncthreads();
     half2_t* __restrict__ out = grad_table + meta.offset[level] + lo;
-    for (uint32_t k = threadIdx.x; k < n_here; k += blockDim.x) out[k] = lds[k];
+    if (K == 1) {
+        for (uint32_t k = threadIdx.x; k < len; k += blockDim.x) out[k] = lds[k];
+    } else {   // merge the K private copies (the host zero-filled this level's range)
+        for (uint32_t k = threadIdx.x; k < len; k += blockDim.x) {
+            const half2_t v = lds[k];
+            if (v[0] != (_Float16)0 || v[1] != (_Float16)0) {
+                __half2 hv; __builtin_memcpy(&hv, &v, 4);
+                unsafeAtomicAdd(reinterpret_cast<__half2*>(out) + k, hv);
+            }
+        }
+    }
 }
 
 // Samples that can carry gradient: the first min(N, total+1) of every ray (composite stops a
@@ -465,13 +528,29 @@ int ngp_hashgrid_bwd_sliced(const float* x, const float* xyz_min, const float* x
     NGP_CHECK_PTR(grad_table);
     if (n_samples > 0) { NGP_CHECK_PTR(x); NGP_CHECK_PTR(xyz_min); NGP_CHECK_PTR(xyz_max); NGP_CHECK_PTR(dfeats); }
     if ((active_idx == nullptr) != (n_active == nullptr)) return NGP_EINVAL;
-    for (int l = 0; l < meta->n_levels; ++l) {   // hashed levels must have a power-of-two size (see corner_indices)
+    SlicePlan plan;
+    static int run_max_res = -1;
+    if (run_max_res < 0) { const char* e = getenv("NGP_DENSE_RUN_MAX_RES"); run_max_res = e ? atoi(e) : 1 << 20; }   // run accumulation on every dense level (per-sample float atomics measured 4x slower there)
+    plan.run_max_res = run_max_res;
+    int n_blocks = 0;
+    hipStream_t st = ngp_stream(stream);
+    for (int l = 0; l < NGP_MAX_LEVELS; ++l) { plan.n_slices[l] = 0; plan.k_split[l] = 1; }
+    for (int l = 0; l < meta->n_levels; ++l) {
         const uint32_t size = meta->offset[l + 1] - meta->offset[l], res = meta->resolution[l];
         const bool hashed = (uint64_t)res * res * res > size;
-        if (hashed && (size & (size - 1)) != 0) return NGP_EUNSUP;
+        if (hashed && (size & (size - 1)) != 0) return NGP_EUNSUP;   // corner_indices masks instead of %
+        const int ns = (int)((size + SLICE - 1) / SLICE);
+        // dense levels concentrate every sample's 8 updates in `ns` workgroups: give them about as
+        // many workgroups (ns*K) as half a hashed level has slices
+        int K = 1;
+        if (!hashed) K = (ns == 1) ? 4 : 2;   // measured: a dense workgroup scanning all samples takes ~1.5x a hashed one
+        plan.n_slices[l] = ns; plan.k_split[l] = K;
+        n_blocks += ns * K;
+        if (K > 1) {
+            hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(grad_table) + (size_t)meta->offset[l] * 4, 0, (size_t)size * 4, st);
+            if (e != hipSuccess) return (int)e;
+        }
     }
-    int n_blocks = 0;
-    for (int l = 0; l < meta->n_levels; ++l) n_blocks += (int)((meta->offset[l + 1] - meta->offset[l] + SLICE - 1) >> SLICE_LOG2);
     constexpr int smem = (int)(SLICE * sizeof(half2_t));
     static bool attr_set = false;
     if (!attr_set) {
@@ -480,8 +559,8 @@ int ngp_hashgrid_bwd_sliced(const float* x, const float* xyz_min, const float* x
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hashgrid_bwd_sliced_kernel<<<dim3(n_blocks), dim3(1024), smem, ngp_stream(stream)>>>(
-        x, xyz_min, xyz_max, (const half2_t*)dfeats, to_dev_meta(meta), n_samples, active_idx, n_active, (half2_t*)grad_table);
+    hashgrid_bwd_sliced_kernel<<<dim3(n_blocks), dim3(1024), smem, st>>>(
+        x, xyz_min, xyz_max, (const half2_t*)dfeats, to_dev_meta(meta), plan, n_samples, active_idx, n_active, (half2_t*)grad_table);
     return NGP_LAUNCH_RESULT();
 }
 

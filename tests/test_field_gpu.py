@@ -118,7 +118,7 @@ def test_hashgrid_backward(lib, field, mode):
     got = grad.float().cpu()
     assert torch.isfinite(got).all()
     # packed-f16 accumulation: each add rounds to 2^-11 relative of the running sum
-    tol = 1e-5 if mode == "atomic_f32" else 1e-2      # up to ~100 contributions per entry, each add rounds at 2^-11
+    tol = 3e-5 if mode == "atomic_f32" else 1e-2      # up to ~100 contributions per entry, each add rounds at 2^-11
     scale = want.abs().max().item()
     err = (got - want).abs().max().item() / scale
     assert err < tol, "max error %g of max |grad| %g" % (err, scale)
