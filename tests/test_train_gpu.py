@@ -92,24 +92,40 @@ def test_render_train_and_test_paths():
 
 
 def test_fused_step_equals_autograd_step():
-    """Trainer.step (direct native calls) and Trainer.step_autograd (render() + autograd) take the
-    same optimisation step from the same state."""
+    """Trainer.step (direct native calls, compacted backward) and Trainer.step_autograd (render() +
+    NeRFLoss + torch autograd) produce the same gradients from the same state.  Gradients are
+    captured instead of compared after Adam: the first Adam step moves a parameter by lr*sign(g),
+    which turns f16 accumulation-order noise on near-zero entries into full-size differences."""
     from ngp_pl_amd.trainer import Trainer
+    from ngp_pl_amd import tcnn
     ro, rd, gt = batch(4096, seed=3)
-    params = []
+    grads = []
     for mode in ("native", "autograd"):
         m = make_model(seed=11)
         tr = Trainer(m)
+        captured = {}
+
+        def capture(grad_scale=1.0, found_inf=None, m=m, captured=captured):
+            nat = m._native
+            enc, net = m.xyz_encoder, m.rgb_net
+            captured["grid"] = nat["grid16"].float().clone() / nat["scale"]
+            captured["density"] = nat["density_partials"].view(nat["n_partials"], enc.n_mlp).sum(0) / nat["scale"]
+            captured["rgb"] = nat["rgb_partials"].view(nat["n_partials"], net.params.numel()).sum(0) / nat["scale"]
+            m._native = None
+        tr.opt.step = capture
         torch.manual_seed(5)            # same jitter noise and grid-update noise in both runs
         if mode == "native":
             tr.step(ro, rd, gt)
         else:
             tr.step_autograd(ro, rd, gt)
-        params.append((m.xyz_encoder.params.detach().clone(), m.rgb_net.params.detach().clone()))
-    (e0, r0), (e1, r1) = params
-    # Adam's first step moves every touched parameter by ~lr*sign(g); untouched ones not at all
-    assert ((e0 - e1).abs() > 5e-3).float().mean().item() < 2e-3
-    assert ((r0 - r1).abs() > 5e-3).float().mean().item() < 2e-2
+        grads.append(captured)
+    a, b = grads
+    for k, tol in (("rgb", 2e-3), ("density", 2e-3), ("grid", 1e-2)):
+        scale = b[k].abs().max().item()
+        assert scale > 0
+        err = (a[k] - b[k]).abs().max().item() / scale
+        assert err < tol, "%s gradient: max error %g of max |g| %g" % (k, err, scale)
+    assert ((a["grid"] != 0) != (b["grid"] != 0)).float().mean().item() < 1e-2      # same support up to f16 underflow
 
 
 def test_training_converges():
