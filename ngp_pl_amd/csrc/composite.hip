@@ -1,52 +1,93 @@
 // Volumetric compositing (train fwd/bwd, test fwd) and distortion loss for gfx950.
 //
 // Semantics: /root/reference/models/csrc/volumerendering.cu and losses.cu (cited per kernel).
-// Arithmetic order inside a ray is the reference's front-to-back order (no contraction), so
-// the only divergence from the CPU oracle is the fast exponential (__expf, as the reference).
-// Differences in structure: outputs are fully written by the kernels (no host-side zero fill),
-// the backward's prefix sum of dL/dw*w runs in registers in the same pass order instead of an
-// in-thread thrust::inclusive_scan over a pre-multiplied global buffer.
+// The training kernels run ONE WAVE PER RAY with the samples on the lanes: transmittance and the
+// running sums are wave scans, so products/sums associate differently from the reference's
+// serial loop (differences of a few 1e-7 relative; tests bound composited outputs at 1e-5 abs)
+// and the fast exponential is __expf as in the reference.  Outputs are fully written by the
+// kernels (no host-side zero fill).  Test-time compositing and the distortion loss keep the
+// thread-per-ray form.
 #pragma clang fp contract(off)
 
 #include "ngp_common.h"
 
 namespace {
 
-// volumerendering.cu:20-44
-__global__ void __launch_bounds__(64)
+// ---- wave64 scan helpers -----------------------------------------------------------------------
+__device__ __forceinline__ float wave_incl_prod(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float u = __shfl_up(v, o, 64); if (lane >= o) v *= u; }
+    return v;
+}
+__device__ __forceinline__ float wave_incl_sum(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float u = __shfl_up(v, o, 64); if (lane >= o) v += u; }
+    return v;
+}
+
+// Per-sample transmittance state of one 64-sample chunk of a ray (volumerendering.cu:28-43):
+// T_before/T_after of every sample by an inclusive product scan of (1 - alpha) across the wave,
+// carried from chunk to chunk.  A sample is composited iff the transmittance BEFORE it is still
+// above the threshold (the sample that crosses it is composited, then the ray stops).
+struct ChunkT { float a, T_before, T_after; bool live; };
+__device__ __forceinline__ ChunkT chunk_transmittance(float sigma, float delta, bool valid, float T_carry, float thr, int lane) {
+    ChunkT c;
+    c.a = valid ? 1.0f - __expf(-sigma * delta) : 0.0f;
+    const float incl = wave_incl_prod(1.0f - c.a, lane);
+    const float excl = __shfl_up(incl, 1, 64);
+    c.T_before = T_carry * (lane == 0 ? 1.0f : excl);
+    c.T_after = T_carry * incl;
+    c.live = valid && (c.T_before > thr);
+    return c;
+}
+
+// volumerendering.cu:20-44.  One wave per ray: samples on lanes (coalesced streams), front-to-back
+// order kept by the scans.  (The reference runs one THREAD per ray: 8192 serial chains of
+// dependent strided loads, 70-90 us on MI355X for a 300 k-sample batch.)
+__global__ void __launch_bounds__(256)
 composite_train_fw_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
                           const float* __restrict__ deltas, const float* __restrict__ ts,
                           const int64_t* __restrict__ rays_a, float T_threshold, int n_rays,
                           int64_t* __restrict__ total_samples, float* __restrict__ opacity,
                           float* __restrict__ depth, float* __restrict__ rgb, float* __restrict__ ws) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
     if (n >= n_rays) return;
     const int64_t ray_idx = rays_a[3 * (size_t)n];
     const int64_t start = rays_a[3 * (size_t)n + 1];
     const int N = (int)rays_a[3 * (size_t)n + 2];
+    float R = 0.f, G = 0.f, B = 0.f, D = 0.f, O = 0.f, T_carry = 1.0f;
     int samples = 0;
-    float T = 1.0f, R = 0.f, G = 0.f, B = 0.f, D = 0.f, O = 0.f;
-    int k = 0;
-    for (; k < N; ++k) {
-        const size_t s = (size_t)start + k;
-        const float a = 1.0f - __expf(-sigmas[s] * deltas[s]);
-        const float w = a * T;
-        R += w * rgbs[3 * s]; G += w * rgbs[3 * s + 1]; B += w * rgbs[3 * s + 2];
-        D += w * ts[s];
-        O += w;
-        ws[s] = w;
-        T *= 1.0f - a;
-        if (T <= T_threshold) { ++k; break; }
-        ++samples;
+    bool stopped = false;
+    int base = 0;
+    for (; base < N && !stopped; base += 64) {
+        const int k = base + lane;
+        const bool valid = k < N;
+        const size_t s = (size_t)start + (valid ? k : 0);
+        const float sigma = valid ? sigmas[s] : 0.f, delta = valid ? deltas[s] : 0.f;
+        const ChunkT c = chunk_transmittance(sigma, delta, valid, T_carry, T_threshold, lane);
+        const float w = c.live ? c.a * c.T_before : 0.0f;
+        if (valid) ws[s] = w;
+        if (c.live) {
+            R += w * rgbs[3 * s]; G += w * rgbs[3 * s + 1]; B += w * rgbs[3 * s + 2];
+            D += w * ts[s]; O += w;
+        }
+        samples += __popcll(__ballot(c.live && c.T_after > T_threshold));
+        stopped = __ballot(valid && c.T_after <= T_threshold) != 0ull;
+        T_carry = __shfl(c.T_after, 63, 64);
     }
-    for (; k < N; ++k) ws[(size_t)start + k] = 0.0f;   // samples past the stop keep w = 0
-    rgb[3 * ray_idx] = R; rgb[3 * ray_idx + 1] = G; rgb[3 * ray_idx + 2] = B;
-    depth[ray_idx] = D; opacity[ray_idx] = O;
-    total_samples[ray_idx] = samples;
+    for (int k = base + lane; k < N; k += 64) ws[(size_t)start + k] = 0.0f;   // chunks past the stop
+    R = ngp_wave_sum(R); G = ngp_wave_sum(G); B = ngp_wave_sum(B); D = ngp_wave_sum(D); O = ngp_wave_sum(O);
+    if (lane == 0) {
+        rgb[3 * ray_idx] = R; rgb[3 * ray_idx + 1] = G; rgb[3 * ray_idx + 2] = B;
+        depth[ray_idx] = D; opacity[ray_idx] = O;
+        total_samples[ray_idx] = samples;
+    }
 }
 
-// volumerendering.cu:106-150 (+ host pre-multiply :175)
-__global__ void __launch_bounds__(64)
+// volumerendering.cu:106-150 (+ host pre-multiply :175), one wave per ray.  The running prefixes
+// r,g,b,d and the prefix of dL/dw*w are wave scans; T is updated before use as in the reference.
+__global__ void __launch_bounds__(256)
 composite_train_bw_kernel(const float* __restrict__ dL_dopacity, const float* __restrict__ dL_ddepth,
                           const float* __restrict__ dL_drgb, const float* __restrict__ dL_dws,
                           const float* __restrict__ sigmas, const float* __restrict__ rgbs,
@@ -55,43 +96,52 @@ composite_train_bw_kernel(const float* __restrict__ dL_dopacity, const float* __
                           const float* __restrict__ opacity, const float* __restrict__ depth,
                           const float* __restrict__ rgb, float T_threshold, int n_rays,
                           float* __restrict__ dL_dsigmas, float* __restrict__ dL_drgbs) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
     if (n >= n_rays) return;
     const int64_t ray_idx = rays_a[3 * (size_t)n];
     const int64_t start = rays_a[3 * (size_t)n + 1];
     const int N = (int)rays_a[3 * (size_t)n + 2];
+    if (N <= 0) return;
     const float R = rgb[3 * ray_idx], G = rgb[3 * ray_idx + 1], B = rgb[3 * ray_idx + 2];
     const float O = opacity[ray_idx], D = depth[ray_idx];
     const float gR = dL_drgb[3 * ray_idx], gG = dL_drgb[3 * ray_idx + 1], gB = dL_drgb[3 * ray_idx + 2];
     const float gO = dL_dopacity[ray_idx], gD = dL_ddepth[ray_idx];
-    // total of dL/dw * w over the whole segment, summed front to back like the inclusive scan
-    float P_total = 0.f;
-    if (dL_dws != nullptr)
-        for (int k = 0; k < N; ++k) { const size_t s = (size_t)start + k; P_total += dL_dws[s] * ws[s]; }
-    float T = 1.0f, r = 0.f, g = 0.f, b = 0.f, d = 0.f, P = 0.f;
-    int k = 0;
-    for (; k < N; ++k) {
-        const size_t s = (size_t)start + k;
-        const float a = 1.0f - __expf(-sigmas[s] * deltas[s]);
-        const float w = a * T;
-        const float cr = rgbs[3 * s], cg = rgbs[3 * s + 1], cb = rgbs[3 * s + 2];
-        const float tk = ts[s];
-        const float gw = dL_dws ? dL_dws[s] : 0.f;
-        r += w * cr; g += w * cg; b += w * cb;
-        d += w * tk;
-        T *= 1.0f - a;
-        if (dL_dws) P += gw * ws[s];
-        dL_drgbs[3 * s] = gR * w; dL_drgbs[3 * s + 1] = gG * w; dL_drgbs[3 * s + 2] = gB * w;
-        dL_dsigmas[s] = deltas[s] * (
-            gR * (cr * T - (R - r)) +
-            gG * (cg * T - (G - g)) +
-            gB * (cb * T - (B - b)) +
-            gO * (1 - O) +
-            gD * (tk * T - (D - d)) +
-            T * gw - (P_total - P));
-        if (T <= T_threshold) { ++k; break; }
+    float P_total = 0.f;   // sum of dL/dw * w over the whole segment (w = 0 past the stop)
+    if (dL_dws != nullptr) {
+        for (int k = lane; k < N; k += 64) { const size_t s = (size_t)start + k; P_total += dL_dws[s] * ws[s]; }
+        P_total = ngp_wave_sum(P_total);
     }
-    for (; k < N; ++k) {
+    float T_carry = 1.0f, r0 = 0.f, g0 = 0.f, b0 = 0.f, d0 = 0.f, P0 = 0.f;
+    bool stopped = false;
+    int base = 0;
+    for (; base < N && !stopped; base += 64) {
+        const int k = base + lane;
+        const bool valid = k < N;
+        const size_t s = (size_t)start + (valid ? k : 0);
+        const float sigma = valid ? sigmas[s] : 0.f, delta = valid ? deltas[s] : 0.f;
+        const ChunkT c = chunk_transmittance(sigma, delta, valid, T_carry, T_threshold, lane);
+        const float w = c.live ? c.a * c.T_before : 0.0f;
+        float cr = 0.f, cg = 0.f, cb = 0.f, tk = 0.f, gw = 0.f;
+        if (c.live) { cr = rgbs[3 * s]; cg = rgbs[3 * s + 1]; cb = rgbs[3 * s + 2]; tk = ts[s]; if (dL_dws) gw = dL_dws[s]; }
+        const float r = r0 + wave_incl_sum(w * cr, lane), g = g0 + wave_incl_sum(w * cg, lane);
+        const float b = b0 + wave_incl_sum(w * cb, lane), d = d0 + wave_incl_sum(w * tk, lane);
+        const float P = dL_dws ? P0 + wave_incl_sum(gw * w, lane) : 0.f;
+        if (valid) {
+            float ds = 0.f, dr = 0.f, dg = 0.f, db = 0.f;
+            if (c.live) {
+                const float T = c.T_after;
+                dr = gR * w; dg = gG * w; db = gB * w;
+                ds = delta * (gR * (cr * T - (R - r)) + gG * (cg * T - (G - g)) + gB * (cb * T - (B - b)) +
+                              gO * (1 - O) + gD * (tk * T - (D - d)) + T * gw - (P_total - P));
+            }
+            dL_dsigmas[s] = ds; dL_drgbs[3 * s] = dr; dL_drgbs[3 * s + 1] = dg; dL_drgbs[3 * s + 2] = db;
+        }
+        stopped = __ballot(valid && c.T_after <= T_threshold) != 0ull;
+        T_carry = __shfl(c.T_after, 63, 64);
+        r0 = __shfl(r, 63, 64); g0 = __shfl(g, 63, 64); b0 = __shfl(b, 63, 64); d0 = __shfl(d, 63, 64); P0 = __shfl(P, 63, 64);
+    }
+    for (int k = base + lane; k < N; k += 64) {
         const size_t s = (size_t)start + k;
         dL_dsigmas[s] = 0.f; dL_drgbs[3 * s] = 0.f; dL_drgbs[3 * s + 1] = 0.f; dL_drgbs[3 * s + 2] = 0.f;
     }
@@ -189,7 +239,7 @@ int ngp_composite_train_fw(const float* sigmas, const float* rgbs, const float* 
     if (n_rays == 0) return 0;
     NGP_CHECK_PTR(rays_a); NGP_CHECK_PTR(total_samples); NGP_CHECK_PTR(opacity); NGP_CHECK_PTR(depth); NGP_CHECK_PTR(rgb);
     if (n_samples > 0) { NGP_CHECK_PTR(sigmas); NGP_CHECK_PTR(rgbs); NGP_CHECK_PTR(deltas); NGP_CHECK_PTR(ts); NGP_CHECK_PTR(ws); }
-    hipLaunchKernelGGL(composite_train_fw_kernel, dim3(ngp_div_up(n_rays, 64)), dim3(64), 0, ngp_stream(stream),
+    hipLaunchKernelGGL(composite_train_fw_kernel, dim3(ngp_div_up((long long)n_rays * 64, 256)), dim3(256), 0, ngp_stream(stream),
                        sigmas, rgbs, deltas, ts, rays_a, T_threshold, n_rays, total_samples, opacity, depth, rgb, ws);
     return NGP_LAUNCH_RESULT();
 }
@@ -204,7 +254,7 @@ int ngp_composite_train_bw(const float* dL_dopacity, const float* dL_ddepth, con
     NGP_CHECK_PTR(dL_dopacity); NGP_CHECK_PTR(dL_ddepth); NGP_CHECK_PTR(dL_drgb); NGP_CHECK_PTR(sigmas);
     NGP_CHECK_PTR(rgbs); NGP_CHECK_PTR(ws); NGP_CHECK_PTR(deltas); NGP_CHECK_PTR(ts); NGP_CHECK_PTR(rays_a);
     NGP_CHECK_PTR(opacity); NGP_CHECK_PTR(depth); NGP_CHECK_PTR(rgb); NGP_CHECK_PTR(dL_dsigmas); NGP_CHECK_PTR(dL_drgbs);
-    hipLaunchKernelGGL(composite_train_bw_kernel, dim3(ngp_div_up(n_rays, 64)), dim3(64), 0, ngp_stream(stream),
+    hipLaunchKernelGGL(composite_train_bw_kernel, dim3(ngp_div_up((long long)n_rays * 64, 256)), dim3(256), 0, ngp_stream(stream),
                        dL_dopacity, dL_ddepth, dL_drgb, dL_dws, sigmas, rgbs, ws, deltas, ts, rays_a,
                        opacity, depth, rgb, T_threshold, n_rays, dL_dsigmas, dL_drgbs);
     return NGP_LAUNCH_RESULT();

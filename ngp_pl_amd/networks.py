@@ -116,6 +116,7 @@ class NGP(nn.Module):
         # fused-path switches
         self.fused = True            # one autograd node for the whole field (False: module by module, as the reference)
         self.native_grads = False    # leave gradients in native f16/partial buffers for optim.FusedAdam
+        self.sync_free_sampling = True   # occupancy-cell sampling without the reference's nonzero() host sync
         self._native = None
         self._g16 = None
 
@@ -199,9 +200,19 @@ class NGP(nn.Module):
         for c in range(self.cascades):
             coords1 = torch.randint(self.grid_size, (M, 3), dtype=torch.int32, device=dev)
             indices1 = vren.morton3D(coords1).long()
-            indices2 = torch.nonzero(self.density_grid[c] > density_threshold)[:, 0]
-            if len(indices2) > 0:
-                indices2 = indices2[torch.randint(len(indices2), (M,), device=dev)]
+            occ = self.density_grid[c] > density_threshold
+            if self.sync_free_sampling:
+                # the reference's nonzero() + randint(len) costs a host sync (and a pipeline drain)
+                # every update; the same draw -- uniform over the occupied cells, with replacement --
+                # by inverse-CDF lookup stays on the device.  Empty grid: rank 0 maps past the end,
+                # clamped to the last cell (the reference adds no occupied samples then).
+                csum = torch.cumsum(occ, 0, dtype=torch.int32)
+                rank = (torch.rand(M, device=dev) * csum[-1]).to(torch.int32)
+                indices2 = torch.searchsorted(csum, rank, right=True).clamp_(max=occ.numel() - 1)
+            else:
+                indices2 = torch.nonzero(occ)[:, 0]
+                if len(indices2) > 0:
+                    indices2 = indices2[torch.randint(len(indices2), (M,), device=dev)]
             coords2 = vren.morton3D_invert(indices2.int())
             cells.append((torch.cat([indices1, indices2]), torch.cat([coords1, coords2])))
         return cells
