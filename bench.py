@@ -139,7 +139,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
     from ngp_pl_amd import synthetic as syn
@@ -151,7 +151,7 @@ def main():
     model = NGP(scale=0.5).to(dev)
     model.register_training_buffers()
     trainer = Trainer(model, lr=1e-2, num_epochs=30)
-    if world > 1:
+    if dist is not None:   # also with a 1-rank process group (torchrun --nproc-per-node 1): exercises the collective path
         trainer.grad_hook = lambda: all_reduce_native(model, dist, world)
         # identical initial parameters on every rank (DDP broadcasts rank 0's)
         for p in model.parameters():
@@ -159,8 +159,11 @@ def main():
     data = GpuDataset(args.res, args.images, dev, seed=0)                 # synthetic Lego-like scene, GT resident in HBM
     gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)       # per-rank independent batches (base.py:25-29)
 
+    draw_count = [0]
+
     def draw():
-        return data.sample(args.rays, gen)
+        draw_count[0] += 1
+        return data.sample_native(args.rays, draw_count[0], seed=1234 + rank)
 
     cur = draw()
     for _ in range(args.warmup):

@@ -334,6 +334,19 @@ int ngp_nerf_loss(const float* rgb, const float* opacity, const float* gt_rgb, c
                   float* loss, float* sq_err, float* dL_drgb, float* dL_dopacity,
                   ngp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * batch sampling (datasets/base.py:22-35 'all_images' + train.py:78-91 + ray_utils.py:46-70)
+ * ------------------------------------------------------------------------------------------ */
+
+/* Draws n (image, pixel) pairs uniformly (counter-based RNG keyed by seed), gathers the pixel
+ * colour and forms the world-space ray: rays_d = R * direction (not normalised), rays_o = camera
+ * centre.  poses (n_images,3,4) f32 c2w; directions (n_pixels,3) f32; images (n_images,n_pixels,3)
+ * f32.  Optional outputs: noise (n) f32 in [0,1) for the marcher's jitter; img_idx, pix_idx (n) i32. */
+int ngp_sample_rays(const float* poses, const float* directions, const float* images,
+                    int n_images, int n_pixels, int n, uint64_t seed,
+                    float* rays_o, float* rays_d, float* rgb, float* noise,
+                    int32_t* img_idx, int32_t* pix_idx, ngp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,19 @@ class GpuDataset:
             self.rgb[i] = surface_ground_truth(ro, rd)
         self.device = device
 
+    def sample_native(self, n, step, seed=0, want_indices=False):
+        """Same draw as `sample` in ONE kernel (ngp_sample_rays): indices from a counter-based RNG
+        keyed by (seed, step), colour gather, pose rotation.  Returns rays_o, rays_d, rgb[, img, pix]."""
+        from ._lib import call, ptr, stream
+        dev = self.device
+        ro = torch.empty(n, 3, device=dev); rd = torch.empty(n, 3, device=dev); rgb = torch.empty(n, 3, device=dev)
+        img = pix = None
+        if want_indices:
+            img = torch.empty(n, dtype=torch.int32, device=dev); pix = torch.empty(n, dtype=torch.int32, device=dev)
+        call("ngp_sample_rays", ptr(self.poses), ptr(self.directions), ptr(self.rgb), self.poses.shape[0], self.W * self.H, n,
+             (int(seed) << 32) | (int(step) & 0xFFFFFFFF), ptr(ro), ptr(rd), ptr(rgb), None, ptr(img), ptr(pix), stream())
+        return (ro, rd, rgb, img, pix) if want_indices else (ro, rd, rgb)
+
     def sample(self, n, gen):
         img = torch.randint(self.poses.shape[0], (n,), device=self.device, generator=gen)
         pix = torch.randint(self.W * self.H, (n,), device=self.device, generator=gen)

@@ -533,6 +533,7 @@ int ngp_hashgrid_bwd_sliced(const float* x, const float* xyz_min, const float* x
     if (run_max_res < 0) { const char* e = getenv("NGP_DENSE_RUN_MAX_RES"); run_max_res = e ? atoi(e) : 1 << 20; }   // run accumulation on every dense level (per-sample float atomics measured 4x slower there)
     plan.run_max_res = run_max_res;
     int n_blocks = 0;
+    uint32_t zero_lo = 0, zero_hi = 0;   // pending [lo, hi) entry range to zero-fill
     hipStream_t st = ngp_stream(stream);
     for (int l = 0; l < NGP_MAX_LEVELS; ++l) { plan.n_slices[l] = 0; plan.k_split[l] = 1; }
     for (int l = 0; l < meta->n_levels; ++l) {
@@ -546,10 +547,19 @@ int ngp_hashgrid_bwd_sliced(const float* x, const float* xyz_min, const float* x
         if (!hashed) K = (ns == 1) ? 4 : 2;   // measured: a dense workgroup scanning all samples takes ~1.5x a hashed one
         plan.n_slices[l] = ns; plan.k_split[l] = K;
         n_blocks += ns * K;
-        if (K > 1) {
-            hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(grad_table) + (size_t)meta->offset[l] * 4, 0, (size_t)size * 4, st);
-            if (e != hipSuccess) return (int)e;
+        if (K > 1) {   // merged by atomics: needs zeros.  Dense levels are contiguous -> one fill for all of them
+            if (zero_lo == zero_hi) zero_lo = meta->offset[l];
+            if (meta->offset[l] != zero_hi && zero_lo != meta->offset[l]) {   // not adjacent to the pending range: flush it
+                hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(grad_table) + (size_t)zero_lo * 4, 0, (size_t)(zero_hi - zero_lo) * 4, st);
+                if (e != hipSuccess) return (int)e;
+                zero_lo = meta->offset[l];
+            }
+            zero_hi = meta->offset[l + 1];
         }
+    }
+    if (zero_hi > zero_lo) {
+        hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(grad_table) + (size_t)zero_lo * 4, 0, (size_t)(zero_hi - zero_lo) * 4, st);
+        if (e != hipSuccess) return (int)e;
     }
     constexpr int smem = (int)(SLICE * sizeof(half2_t));
     static bool attr_set = false;

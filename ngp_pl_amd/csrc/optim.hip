@@ -74,19 +74,31 @@ adam_kernel(float* __restrict__ param, h1* __restrict__ param_h, void* __restric
     }
 }
 
-// out[i] = sum_p partials[p][i].  64 columns per workgroup, 4 row lanes per column: every thread
-// keeps n_partials/4 independent loads in flight (a thread per column walking all rows serially
-// measured 62 us for 256 x 10240 on MI355X; this is ~5).
+// out[i] = sum_p partials[p][i].  32 columns x 8 row lanes per workgroup, 4 independent loads in
+// flight per thread (a thread per column walking all rows serially measured 62 us for 256 x 10240
+// on MI355X, 64 columns x 4 row lanes 21 us).
 __global__ void __launch_bounds__(256)
 reduce_partials_kernel(const float* __restrict__ partials, int n_partials, int n, float* __restrict__ out) {
-    __shared__ float s_acc[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), lane_row = threadIdx.x >> 6;
-    float acc = 0.f;
-    if (col < n)
-        for (int p = lane_row; p < n_partials; p += 4) acc += partials[(size_t)p * n + col];
-    s_acc[lane_row][threadIdx.x & 63] = acc;
+    __shared__ float s_acc[8][32];
+    const int c = threadIdx.x & 31, lane_row = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + c;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (col < n) {
+        int p = lane_row;
+        for (; p + 24 < n_partials; p += 32) {
+            a0 += partials[(size_t)p * n + col]; a1 += partials[(size_t)(p + 8) * n + col];
+            a2 += partials[(size_t)(p + 16) * n + col]; a3 += partials[(size_t)(p + 24) * n + col];
+        }
+        for (; p < n_partials; p += 8) a0 += partials[(size_t)p * n + col];
+    }
+    s_acc[lane_row][c] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (lane_row == 0 && col < n) out[col] = (s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x]) + (s_acc[2][threadIdx.x] + s_acc[3][threadIdx.x]);
+    if (lane_row == 0 && col < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += s_acc[r][c];
+        out[col] = t;
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -137,6 +149,39 @@ nerf_loss_kernel(const float* __restrict__ rgb, const float* __restrict__ opacit
     }
 }
 
+// GPU-resident batch sampler: the reference draws img/pix indices with np.random.choice in 16
+// dataloader workers, gathers rays[img, pix] from a CPU tensor and ships the batch over PCIe
+// (datasets/base.py:22-35, train.py:141-146), then forms rays on the GPU (train.py:78-91,
+// ray_utils.py:46-70).  Here one kernel draws the indices (counter-based hash RNG), gathers the
+// ground-truth colour and rotates the pixel direction by the camera pose.
+__device__ __forceinline__ uint32_t pcg_hash(uint32_t v) {
+    uint32_t state = v * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+__global__ void __launch_bounds__(256)
+sample_rays_kernel(const float* __restrict__ poses, const float* __restrict__ directions, const float* __restrict__ images,
+                   int n_images, int n_pixels, int n, uint32_t seed_lo, uint32_t seed_hi,
+                   float* __restrict__ rays_o, float* __restrict__ rays_d, float* __restrict__ rgb,
+                   float* __restrict__ noise, int32_t* __restrict__ img_idx, int32_t* __restrict__ pix_idx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t base = pcg_hash(seed_lo ^ pcg_hash(seed_hi + 0x9E3779B9u)) + 3u * (uint32_t)i;
+    const uint32_t r0 = pcg_hash(base), r1 = pcg_hash(base + 1u), r2 = pcg_hash(base + 2u);
+    const int img = (int)(((uint64_t)r0 * (uint64_t)n_images) >> 32);     // uniform in [0, n_images)
+    const int pix = (int)(((uint64_t)r1 * (uint64_t)n_pixels) >> 32);
+    const float* P = poses + 12 * (size_t)img;                            // (3,4) row-major c2w
+    const float dx = directions[3 * (size_t)pix], dy = directions[3 * (size_t)pix + 1], dz = directions[3 * (size_t)pix + 2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        rays_d[3 * (size_t)i + k] = (dx * P[4 * k] + dy * P[4 * k + 1]) + dz * P[4 * k + 2];   // sum order of (d * R).sum(-1)
+        rays_o[3 * (size_t)i + k] = P[4 * k + 3];
+        rgb[3 * (size_t)i + k] = images[((size_t)img * n_pixels + pix) * 3 + k];
+    }
+    if (noise) noise[i] = (float)(r2 >> 8) * (1.0f / 16777216.0f);         // [0,1), 24 bits like torch.rand
+    if (img_idx) { img_idx[i] = img; pix_idx[i] = pix; }
+}
+
 }  // namespace
 
 extern "C" {
@@ -165,7 +210,7 @@ int ngp_reduce_partials(const float* partials, int n_partials, int n, float* out
     if (n == 0) return 0;
     NGP_CHECK_PTR(out);
     if (n_partials > 0) NGP_CHECK_PTR(partials);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ngp_div_up(n, 64)), dim3(256), 0, ngp_stream(stream), partials, n_partials, n, out);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ngp_div_up(n, 32)), dim3(256), 0, ngp_stream(stream), partials, n_partials, n, out);
     return NGP_LAUNCH_RESULT();
 }
 
@@ -195,6 +240,18 @@ int ngp_nerf_loss(const float* rgb, const float* opacity, const float* gt_rgb, c
     NGP_CHECK_PTR(rgb); NGP_CHECK_PTR(opacity); NGP_CHECK_PTR(gt_rgb); NGP_CHECK_PTR(loss); NGP_CHECK_PTR(dL_drgb); NGP_CHECK_PTR(dL_dopacity);
     hipLaunchKernelGGL(nerf_loss_kernel, dim3(ngp_div_up(n_rays, 256)), dim3(256), 0, ngp_stream(stream),
                        rgb, opacity, gt_rgb, bg, lambda_opacity, grad_scale, n_rays, loss, sq_err, dL_drgb, dL_dopacity);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_sample_rays(const float* poses, const float* directions, const float* images, int n_images, int n_pixels,
+                    int n, uint64_t seed, float* rays_o, float* rays_d, float* rgb, float* noise,
+                    int32_t* img_idx, int32_t* pix_idx, ngp_stream_t stream) {
+    if (n < 0 || n_images < 1 || n_pixels < 1) return NGP_EINVAL;
+    if (n == 0) return 0;
+    NGP_CHECK_PTR(poses); NGP_CHECK_PTR(directions); NGP_CHECK_PTR(images); NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d); NGP_CHECK_PTR(rgb);
+    if ((img_idx == nullptr) != (pix_idx == nullptr)) return NGP_EINVAL;
+    hipLaunchKernelGGL(sample_rays_kernel, dim3(ngp_div_up(n, 256)), dim3(256), 0, ngp_stream(stream), poses, directions, images,
+                       n_images, n_pixels, n, (uint32_t)seed, (uint32_t)(seed >> 32), rays_o, rays_d, rgb, noise, img_idx, pix_idx);
     return NGP_LAUNCH_RESULT();
 }
 

@@ -148,3 +148,18 @@ def test_training_converges():
     occ = (m.density_bitfield.cpu().numpy()[:, None] >> np.arange(8) & 1).mean()
     assert 0.0 < occ < 0.5, occ
     assert last["rm_s"] < first["rm_s"]
+
+
+def test_native_ray_sampler_matches_torch_path():
+    """ngp_sample_rays == GpuDataset.sample given the same (img, pix) draws; indices are uniform."""
+    from ngp_pl_amd.bench_support import GpuDataset
+    data = GpuDataset(64, 5, torch.device("cuda"), seed=0)
+    ro, rd, rgb, img, pix = data.sample_native(20000, step=3, seed=9, want_indices=True)
+    assert int(img.min()) >= 0 and int(img.max()) == 4 and int(pix.max()) < 64 * 64 and int(pix.min()) >= 0
+    ro2, rd2 = syn.get_rays(data.directions[pix.long()], data.poses[img.long()])
+    assert torch.equal(ro, ro2) and torch.allclose(rd, rd2, rtol=0, atol=1e-6)
+    assert torch.equal(rgb, data.rgb[img.long(), pix.long()])
+    counts = torch.bincount(img.long(), minlength=5).float()
+    assert (counts / 20000 - 0.2).abs().max() < 0.02
+    a = data.sample_native(100, step=4, seed=9); b = data.sample_native(100, step=4, seed=9); c = data.sample_native(100, step=5, seed=9)
+    assert torch.equal(a[1], b[1]) and not torch.equal(a[1], c[1])          # deterministic in (seed, step)
