@@ -131,6 +131,13 @@ int ngp_raymarching_test(const float* rays_o, const float* rays_d, float* hits_t
                          float* xyzs, float* dirs, float* deltas, float* ts,
                          int32_t* n_eff_samples, ngp_stream_t stream);
 
+/* `alive_indices = alive_indices[alive_indices >= 0]` of the test-time loop (rendering.py:105)
+ * on device: survivors of alive_in (n) are appended to alive_out (order not preserved), their
+ * number ADDED to count[0] (device i32, caller zeroes); if total_samples is given, the sum of
+ * n_eff (n) is ADDED to total_samples[0] (device i64; rendering.py:88). */
+int ngp_compact_alive(const int64_t* alive_in, const int32_t* n_eff, int n, int64_t* alive_out,
+                      int32_t* count, int64_t* total_samples, ngp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * vren: volume rendering        (reference: models/csrc/volumerendering.cu)
  * ------------------------------------------------------------------------------------------ */

@@ -386,6 +386,30 @@ march_test_kernel(const float* __restrict__ rays_o, const float* __restrict__ ra
     }
 }
 
+// Alive-ray compaction of the test-time loop (`alive_indices[alive_indices>=0]`,
+// rendering.py:105) without torch's nonzero(): wave ballot + one atomic per wave.  The order of
+// the survivors is not preserved (rays are independent, nothing depends on it).  Also sums the
+// rays' N_eff into total[0] (rendering.py:88).
+__global__ void __launch_bounds__(256)
+compact_alive_kernel(const int64_t* __restrict__ alive_in, const int32_t* __restrict__ n_eff, int n,
+                     int64_t* __restrict__ alive_out, int32_t* __restrict__ count, int64_t* __restrict__ total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t a = (i < n) ? alive_in[i] : -1;
+    const bool keep = a >= 0;
+    const unsigned long long m = __ballot(keep);
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(count, __popcll(m));
+    base = __shfl(base, 0, 64);
+    if (keep) alive_out[base + __popcll(m & ((1ull << lane) - 1ull))] = a;
+    if (total != nullptr) {
+        int e = (i < n && n_eff != nullptr) ? n_eff[i] : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
+        if (lane == 0 && e) atomicAdd(reinterpret_cast<unsigned long long*>(total), (unsigned long long)e);
+    }
+}
+
 MarchParams make_march_params(const uint8_t* bitfield, int cascades, int grid_size, float scale,
                               float scale_for_dt, float esf, int max_samples) {
     MarchParams p;
@@ -551,6 +575,16 @@ int ngp_raymarching_test(const float* rays_o, const float* rays_d, float* hits_t
     const MarchParams p = make_march_params(density_bitfield, cascades, grid_size, scale, (float)cascades, exp_step_factor, max_samples);
     hipLaunchKernelGGL(march_test_kernel, dim3(ngp_div_up(n_alive, 64)), dim3(64), 0, ngp_stream(stream),
                        rays_o, rays_d, hits_t, alive_indices, p, n_samples, n_alive, xyzs, dirs, deltas, ts, n_eff_samples);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_compact_alive(const int64_t* alive_in, const int32_t* n_eff, int n, int64_t* alive_out, int32_t* count,
+                      int64_t* total_samples, ngp_stream_t stream) {
+    if (n < 0) return NGP_EINVAL;
+    if (n == 0) return 0;
+    NGP_CHECK_PTR(alive_in); NGP_CHECK_PTR(alive_out); NGP_CHECK_PTR(count);
+    hipLaunchKernelGGL(compact_alive_kernel, dim3(ngp_div_up(n, 256)), dim3(256), 0, ngp_stream(stream),
+                       alive_in, n_eff, n, alive_out, count, total_samples);
     return NGP_LAUNCH_RESULT();
 }
 
