@@ -1,39 +1,62 @@
-"""Loss glue of the reference (/root/reference/losses.py:6-60) on `ngp_pl_amd.vren`."""
+"""Training losses of the hot path, API-compatible with the reference's `losses.py`
+(NeRFLoss at losses.py:40-60, DistortionLoss at losses.py:6-37), on top of `ngp_pl_amd.vren`.
+
+`NeRFLoss(lambda_opacity, lambda_distortion)(results, target)` returns the same dictionary of
+per-element terms; the trainer's fused kernel `ngp_nerf_loss` computes the default recipe
+(rgb + opacity terms, mean-reduced, with analytic backward seeds) in one launch.
+"""
 import torch
 from torch import nn
 
 from . import vren
 
+_EPS = 1e-10
+
+
+def squared_error(pred_rgb, gt_rgb):
+    """(R,3) photometric term."""
+    diff = pred_rgb - gt_rgb
+    return diff * diff
+
+
+def opacity_entropy(opacity, weight):
+    """-o log o, pushes a ray's opacity towards 0 or 1 (floaters)."""
+    o = opacity + _EPS
+    return -weight * o * torch.log(o)
+
 
 class DistortionLoss(torch.autograd.Function):
-    """Mip-NeRF 360 distortion loss in its DVGO-v2 prefix-sum form (losses.py:6-37).
-    ws, deltas, ts (S), rays_a (R,3) -> loss (R)."""
+    """Mip-NeRF 360's distortion regulariser evaluated with DVGO-v2's prefix sums.
+
+    Arguments: ws (S) sample weights, deltas (S) interval lengths, ts (S) interval mid-points,
+    rays_a (R,3) rows of [ray_idx, start_idx, N_samples].  Output: (R) loss per ray.  Only `ws`
+    receives a gradient."""
 
     @staticmethod
     def forward(ctx, ws, deltas, ts, rays_a):
-        loss, ws_incl, wts_incl = vren.distortion_loss_fw(ws.contiguous(), deltas, ts, rays_a)
-        ctx.save_for_backward(ws_incl, wts_incl, ws, deltas, ts, rays_a)
-        return loss
+        ws = ws.contiguous()
+        per_ray, w_cum, wt_cum = vren.distortion_loss_fw(ws, deltas, ts, rays_a)
+        ctx.save_for_backward(w_cum, wt_cum, ws, deltas, ts, rays_a)
+        return per_ray
 
     @staticmethod
-    def backward(ctx, dL_dloss):
-        ws_incl, wts_incl, ws, deltas, ts, rays_a = ctx.saved_tensors
-        return vren.distortion_loss_bw(dL_dloss.contiguous(), ws_incl, wts_incl, ws.contiguous(), deltas, ts, rays_a), None, None, None
+    def backward(ctx, grad_per_ray):
+        w_cum, wt_cum, ws, deltas, ts, rays_a = ctx.saved_tensors
+        g = vren.distortion_loss_bw(grad_per_ray.contiguous(), w_cum, wt_cum, ws, deltas, ts, rays_a)
+        return g, None, None, None
 
 
 class NeRFLoss(nn.Module):
-    """rgb MSE + opacity entropy (+ distortion), per-element terms in a dict (losses.py:40-60)."""
-
     def __init__(self, lambda_opacity=1e-3, lambda_distortion=1e-3):
         super().__init__()
-        self.lambda_opacity = lambda_opacity
-        self.lambda_distortion = lambda_distortion
+        self.lambda_opacity, self.lambda_distortion = lambda_opacity, lambda_distortion
 
     def forward(self, results, target, **kwargs):
-        d = {"rgb": (results["rgb"] - target["rgb"]) ** 2}
-        o = results["opacity"] + 1e-10
-        d["opacity"] = self.lambda_opacity * (-o * torch.log(o))
+        terms = {
+            "rgb": squared_error(results["rgb"], target["rgb"]),
+            "opacity": opacity_entropy(results["opacity"], self.lambda_opacity),
+        }
         if self.lambda_distortion > 0:
-            d["distortion"] = self.lambda_distortion * DistortionLoss.apply(
-                results["ws"], results["deltas"], results["ts"], results["rays_a"])
-        return d
+            per_ray = DistortionLoss.apply(results["ws"], results["deltas"], results["ts"], results["rays_a"])
+            terms["distortion"] = self.lambda_distortion * per_ray
+        return terms

@@ -1,0 +1,154 @@
+"""GPU, BASELINE.json full sizes (one 800x800 frame = 640 000 rays; 8192-ray batches): size-independent
+properties of the HIP path -- packing/sortedness, determinism, recomputation identities, linearity,
+gradient checksums -- where the CPU oracle would take minutes."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from ngp_pl_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def frame():
+    K = syn.intrinsics(800)
+    dirs = syn.get_ray_directions(800, 800, K, device="cuda")
+    pose = syn.hemisphere_poses(3, seed=5)[1].cuda()
+    ro, rd = syn.get_rays(dirs, pose)
+    grid = syn.analytic_density_grid(1, 0.5, 128)
+    bf = torch.from_numpy(syn.pack_bitfield_np(grid, 10.0)).cuda()
+    return ro, rd, bf
+
+
+def occupied(bf, xyz, scale=0.5, G=128):
+    """bit lookup of raymarching.cu:214-220 for cascade 0 in torch."""
+    n = (0.5 * (xyz / scale + 1) * G).clamp(0, G - 1).to(torch.int64)
+    def ex(v):
+        v = (v * 0x00010001) & 0xFF0000FF; v = (v * 0x00000101) & 0x0F00F00F
+        v = (v * 0x00000011) & 0xC30C30C3; v = (v * 0x00000005) & 0x49249249
+        return v
+    idx = ex(n[:, 0]) | (ex(n[:, 1]) << 1) | (ex(n[:, 2]) << 2)
+    return ((bf[idx >> 3].to(torch.int64) >> (idx & 7)) & 1).bool()
+
+
+def test_full_frame_march_properties(frame):
+    import ngp_pl_amd.vren as vren
+    ro, rd, bf = frame
+    n = ro.shape[0]
+    assert n == 640000
+    _, hits_t, _ = vren.ray_aabb_intersect(ro, rd, torch.zeros(1, 3).cuda(), torch.full((1, 3), 0.5).cuda(), 1)
+    ht = hits_t[:, 0].contiguous()
+    ht[(ht[:, 0] >= 0) & (ht[:, 0] < 0.01), 0] = 0.01
+    noise = torch.rand(n, device="cuda")
+    out1 = vren.raymarching_train(ro, rd, ht, bf, 1, 0.5, 0.0, noise, 128, 1024)
+    out2 = vren.raymarching_train(ro, rd, ht, bf, 1, 0.5, 0.0, noise, 128, 1024)
+    for a, b in zip(out1, out2):                      # deterministic, ray-ordered packing (the reference's is atomics-ordered)
+        assert torch.equal(a, b)
+    rays_a, xyzs, dirs, deltas, ts, counter = out1
+    S = int(counter[0])
+    assert int(counter[1]) == n and xyzs.shape[0] == S and S > 1_000_000
+    cnt = rays_a[:, 2]
+    assert torch.equal(rays_a[:, 0], torch.arange(n, device="cuda"))
+    assert torch.equal(rays_a[:, 1], torch.cumsum(cnt, 0) - cnt) and int(cnt.sum()) == S     # exclusive scan = packing offsets
+    assert int(cnt.max()) <= 1024 and int(cnt[ht[:, 0] < 0].sum()) == 0                       # misses emit nothing
+    ray = torch.repeat_interleave(torch.arange(n, device="cuda"), cnt)
+    # recomputation identities, bit for bit: xyz = fma(t, d, o), dir = d, delta = sqrt3/1024
+    exp_xyz = torch.addcmul(ro[ray].double(), ts[:, None].double(), rd[ray].double()).float()   # fma == correctly rounded o + t*d
+    assert torch.equal(xyzs, exp_xyz)
+    assert torch.equal(dirs, rd[ray])
+    assert torch.equal(deltas, torch.full_like(deltas, np.float32(1.73205080757) / np.float32(1024)))
+    # samples lie inside their ray's [t1, t2) and strictly increase along the ray
+    assert bool((ts >= ht[ray, 0]).all()) and bool((ts < ht[ray, 1]).all())
+    same = ray[1:] == ray[:-1]
+    assert bool((ts[1:][same] > ts[:-1][same]).all())
+    assert bool(occupied(bf, xyzs).all())              # every emitted sample sits in an occupied cell
+    # test-time marching visits the same samples when it starts unjittered: first sample of each ray
+    h2 = ht.clone()
+    alive = torch.arange(n, device="cuda")
+    x2, d2, de2, t2, ne = vren.raymarching_test(ro, rd, h2, alive, bf, 1, 0.5, 0.0, 128, 1024, 2)
+    assert bool(occupied(bf, x2.view(-1, 3)[(d2.view(-1, 3) != 0).any(1)]).all())
+    assert bool((h2[:, 0] >= ht[:, 0]).all()) and int(ne.max()) <= 2
+
+
+def test_composite_linearity_and_closed_form(frame):
+    import ngp_pl_amd.vren as vren
+    ro, rd, bf = frame
+    sel = torch.randperm(ro.shape[0], device="cuda")[:8192]
+    ro, rd = ro[sel].contiguous(), rd[sel].contiguous()
+    _, hits_t, _ = vren.ray_aabb_intersect(ro, rd, torch.zeros(1, 3).cuda(), torch.full((1, 3), 0.5).cuda(), 1)
+    rays_a, xyzs, dirs, deltas, ts, _ = vren.raymarching_train(ro, rd, hits_t[:, 0].contiguous(), bf, 1, 0.5, 0.0,
+                                                               torch.rand(8192, device="cuda"), 128, 1024)
+    S = ts.shape[0]
+    sig = torch.rand(S, device="cuda") ** 2 * 60
+    c1, c2 = torch.rand(S, 3, device="cuda"), torch.rand(S, 3, device="cuda")
+    o1 = vren.composite_train_fw(sig, c1, deltas, ts, rays_a, 1e-4)
+    o2 = vren.composite_train_fw(sig, c2, deltas, ts, rays_a, 1e-4)
+    o3 = vren.composite_train_fw(sig, 0.3 * c1 + 0.7 * c2, deltas, ts, rays_a, 1e-4)
+    assert torch.allclose(o3[3], 0.3 * o1[3] + 0.7 * o2[3], atol=2e-6)            # rgb is linear in the sample colours
+    assert torch.equal(o1[1], o2[1]) and torch.equal(o1[4], o2[4])                 # opacity / weights do not depend on them
+    assert torch.allclose(o1[1], o1[4].new_zeros(8192).index_add_(0, torch.repeat_interleave(torch.arange(8192, device="cuda"), rays_a[:, 2]), o1[4]), atol=1e-5)   # opacity = sum of weights
+    assert bool((o1[1] <= 1 + 1e-5).all()) and bool((o1[4] >= 0).all())
+    # constant sigma: opacity = 1 - exp(-sigma * sum(delta)) for rays that do not hit the early stop
+    o4 = vren.composite_train_fw(torch.full_like(sig, 2.0), c1, deltas, ts, rays_a, 0.0)
+    want = 1 - torch.exp(-2.0 * float(deltas[0]) * rays_a[:, 2].float())
+    assert torch.allclose(o4[1], want, atol=2e-5)
+    assert torch.equal(o4[0], rays_a[:, 2])                                        # threshold 0 never stops: all samples counted
+
+
+def test_hashgrid_linearity_and_gradient_checksum():
+    from ngp_pl_amd import _lib
+    from ngp_pl_amd._lib import call, ptr, stream
+    meta = _lib.GridMeta()
+    call("ngp_grid_meta_init", C.byref(meta), 16, 2, 19, 16, float(math.exp(math.log(2048 * 0.5 / 16) / 15)))
+    total = meta.offset[16]
+    S = 300000
+    x = (torch.rand(S, 3, device="cuda") - 0.5).contiguous()
+    mn = torch.full((3,), -0.5, device="cuda"); mx = torch.full((3,), 0.5, device="cuda")
+
+    def enc(table):
+        f = torch.empty(16, S, 2, dtype=torch.float16, device="cuda")
+        call("ngp_hashgrid_fwd", ptr(x), ptr(mn), ptr(mx), ptr(table), C.byref(meta), S, ptr(f), stream())
+        return f.float()
+    t1 = (torch.rand(total, 2, device="cuda") - 0.5).half(); t2 = (torch.rand(total, 2, device="cuda") - 0.5).half()
+    assert torch.allclose(enc((t1.float() + t2.float()).half()), enc(t1) + enc(t2), atol=3e-3)     # linear in the table (f16 rounding)
+    ones = enc(torch.full((total, 2), 0.25, device="cuda").half())
+    assert torch.allclose(ones, torch.full_like(ones, 0.25), atol=1e-3)                            # trilinear weights sum to 1
+    # checksum of the scatter: sum over a level's gradient entries == sum over samples of that level's feature gradient
+    g = (torch.randn(16, S, 2, device="cuda") * 0.01).half()
+    grad = torch.empty(total, 2, dtype=torch.float16, device="cuda")
+    call("ngp_hashgrid_bwd_sliced", ptr(x), ptr(mn), ptr(mx), ptr(g), C.byref(meta), S, None, None, ptr(grad), stream())
+    for l in range(16):
+        got = grad[meta.offset[l]:meta.offset[l + 1]].double().sum(0)
+        want = g[l].double().sum(0)
+        scale = g[l].double().abs().sum(0)
+        assert bool(((got - want).abs() <= 2e-3 * scale).all()), (l, got, want)
+
+
+def test_adam_matches_torch_adam():
+    """ngp_adam_step == torch.optim.Adam(eps=1e-15) (= apex FusedAdam's update, train.py:131), incl.
+    gradient unscale, f16 copy and gradient zeroing; skipped when found_inf is set."""
+    from ngp_pl_amd._lib import call, ptr, stream
+    n = 1_000_003
+    g = torch.Generator(device="cuda").manual_seed(0)
+    p0 = torch.randn(n, device="cuda", generator=g)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-2, eps=1e-15)
+    p = p0.clone(); ph = torch.empty(n, dtype=torch.float16, device="cuda")
+    m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    for step in range(1, 4):
+        grad = torch.randn(n, device="cuda", generator=g) * 10 ** float(step - 3)
+        grad16 = (grad * 128).half()
+        ref.grad = grad16.float() / 128
+        opt.step()
+        call("ngp_adam_step", ptr(p), ptr(ph), ptr(grad16), 0, ptr(m), ptr(v), n, 1e-2, 0.9, 0.999, 1e-15, 0.0, step, 128.0, None, stream())
+        assert torch.allclose(p, ref.detach(), rtol=1e-5, atol=1e-6)
+        assert torch.equal(ph, p.half()) and int((grad16 != 0).sum()) == 0            # f16 working copy refreshed, gradient consumed
+    flag = torch.ones(1, dtype=torch.int32, device="cuda")
+    before = p.clone()
+    g2 = torch.ones(n, device="cuda")
+    call("ngp_adam_step", ptr(p), ptr(ph), ptr(g2), 1, ptr(m), ptr(v), n, 1e-2, 0.9, 0.999, 1e-15, 0.0, 4, 1.0, ptr(flag), stream())
+    assert torch.equal(p, before) and int((g2 != 0).sum()) == 0                        # GradScaler semantics: skip but clear
