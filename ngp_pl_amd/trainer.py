@@ -100,7 +100,7 @@ class Trainer:
             counter_host.copy_(counter, non_blocking=True)
             done = torch.cuda.Event(); done.record()
         return dict(rays_o=rays_o, rays_d=rays_d, rays_a=rays_a, counter=counter, counter_host=counter_host, scratch=scratch,
-                    hits_t=hits_t, noise=noise, coarse=coarse, done=done, timing=(t0, t1) if t0 is not None else None)   # everything the side stream touches stays referenced
+                    hits_t=hits_t, noise=noise, done=done, timing=(t0, t1) if t0 is not None else None)
 
     # -- the hot path --------------------------------------------------------------------------
     @torch.no_grad()
