@@ -107,17 +107,13 @@ int ngp_cells_to_xyz(const int32_t* coords, const float* noise, int n, int grid_
  *  2. the caller reads counter[0] (the only host sync) and allocates S-sized outputs;
  *  3. ngp_raymarching_train_write expands the scratch into xyzs,dirs (S,3), deltas,ts (S).
  *
- * hits_t (R,2) f32, noise (R) f32 in [0,1), density_bitfield (cascades*G^3/8) u8.
- * coarse_ws: optional workspace of cascades*G^3/512 bytes (NULL to disable).  The call first
- * reduces the bitfield to one bit per 4x4x4 cells into it; the march keeps that 4 KiB/cascade mask
- * in LDS and skips the global bit load wherever the block is empty (same occupancy decisions,
- * same samples -- only the dependent-load latency of empty space goes away). */
+ * hits_t (R,2) f32, noise (R) f32 in [0,1), density_bitfield (cascades*G^3/8) u8. */
 int ngp_raymarching_train_count(const float* rays_o, const float* rays_d, const float* hits_t,
                                 const uint8_t* density_bitfield, int cascades, float scale,
                                 float exp_step_factor, const float* noise, int grid_size,
                                 int max_samples, int n_rays,
                                 int64_t* rays_a, int32_t* counter, float* t_scratch,
-                                uint8_t* coarse_ws, ngp_stream_t stream);
+                                ngp_stream_t stream);
 int ngp_raymarching_train_write(const float* rays_o, const float* rays_d, const int64_t* rays_a,
                                 const float* t_scratch, float scale, float exp_step_factor,
                                 int grid_size, int max_samples, int n_rays,
@@ -133,8 +129,7 @@ int ngp_raymarching_test(const float* rays_o, const float* rays_d, float* hits_t
                          int cascades, float scale, float exp_step_factor, int grid_size,
                          int max_samples, int n_samples, int n_alive,
                          float* xyzs, float* dirs, float* deltas, float* ts,
-                         int32_t* n_eff_samples, uint8_t* coarse_ws /* as above, may be NULL */,
-                         ngp_stream_t stream);
+                         int32_t* n_eff_samples, ngp_stream_t stream);
 
 /* `alive_indices = alive_indices[alive_indices >= 0]` of the test-time loop (rendering.py:105)
  * on device: survivors of alive_in (n) are appended to alive_out (order not preserved), their

@@ -188,8 +188,6 @@ cells_to_xyz_kernel(const int32_t* __restrict__ coords, const float* __restrict_
 // ------------------------------------------------------------------------------------------
 struct MarchParams {
     const uint8_t* __restrict__ bitfield;
-    const uint8_t* __restrict__ coarse;   // optional: 1 bit per 4x4x4 cells (= 64 consecutive Morton bits), see coarsen_kernel
-    int coarse_bytes;
     int cascades;
     int grid_size;
     float scale;        // scene scale: bound of the finest cascade is min(2^(mip-1), scale)
@@ -208,7 +206,7 @@ struct Ray {
 
 // Evaluates the cell containing the sample at parameter t.  Returns whether it is occupied,
 // the sample position, dt, and (when empty) the next t on the step lattice past the cell.
-__device__ __forceinline__ bool march_probe(const Ray& ray, const MarchParams& p, const uint8_t* lds_coarse, float t,
+__device__ __forceinline__ bool march_probe(const Ray& ray, const MarchParams& p, float t,
                                             float& x, float& y, float& z, float& dt, float& t_next) {
     x = fmaf(t, ray.dx, ray.ox); y = fmaf(t, ray.dy, ray.oy); z = fmaf(t, ray.dz, ray.oz);
     dt = calc_dt(t, p);
@@ -226,12 +224,7 @@ __device__ __forceinline__ bool march_probe(const Ray& ray, const MarchParams& p
     const int nz = (int)fmaxf(0.0f, fminf(0.5f * (z * mip_bound_inv + 1) * G, gm1));
     const uint32_t g3 = (uint32_t)(p.grid_size * p.grid_size * p.grid_size);
     const uint32_t idx = (uint32_t)mip * g3 + ngp_morton3D((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
-    // Same decision as the reference's single bit test (raymarching.cu:219-220).  When the LDS copy
-    // of the coarse mask says the surrounding 4x4x4 block is empty, the bit is known to be 0 and
-    // the dependent global load (the latency that bounds this loop) is skipped.
-    bool occ;
-    if (lds_coarse != nullptr && !((lds_coarse[idx >> 9] >> ((idx >> 6) & 7)) & 1)) occ = false;
-    else occ = (p.bitfield[idx >> 3] >> (idx & 7)) & 1;
+    const bool occ = (p.bitfield[idx >> 3] >> (idx & 7)) & 1;
     if (!occ) {
         const float ginv = 1.0f / G;
         const float tx = (((nx + 0.5f + 0.5f * copysignf(1.0f, ray.dx)) * ginv * 2 - 1) * mip_bound - x) * ray.ix;
@@ -253,28 +246,6 @@ __device__ __forceinline__ Ray load_ray(const float* __restrict__ rays_o, const 
     return ray;
 }
 
-// coarse[c] bit = any of the fine bits [64c, 64c+64) set.  In Morton order those 64 cells are one
-// aligned 4x4x4 block, i.e. 8 consecutive bytes of the bitfield.
-__global__ void __launch_bounds__(256)
-coarsen_kernel(const uint8_t* __restrict__ bitfield, int n_coarse_bytes, uint8_t* __restrict__ coarse) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_coarse_bytes) return;
-    const uint2* src = reinterpret_cast<const uint2*>(bitfield) + (size_t)i * 8;   // 8 coarse bits x 8 bytes
-    uint32_t bits = 0;
-#pragma unroll
-    for (int b = 0; b < 8; ++b) { const uint2 v = src[b]; bits |= ((v.x | v.y) != 0u) ? (1u << b) : 0u; }
-    coarse[i] = (uint8_t)bits;
-}
-// whole workgroup copies the coarse mask (4 KiB per cascade) into LDS; returns nullptr if absent
-__device__ __forceinline__ const uint8_t* stage_coarse(const MarchParams& p, uint8_t* lds) {
-    if (p.coarse == nullptr) return nullptr;
-    for (int i = threadIdx.x * 4; i < p.coarse_bytes; i += blockDim.x * 4)
-        *reinterpret_cast<uint32_t*>(lds + i) = *reinterpret_cast<const uint32_t*>(p.coarse + i);
-    __syncthreads();
-    return lds;
-}
-constexpr int MAX_COARSE_BYTES = 8 * 4096;   // up to 8 cascades of 128^3
-
 // Pass 1 of train marching (raymarching.cu:184-234): one march, t of every emitted sample goes
 // to the ray's scratch row.  The loop is a chain of dependent bitfield loads with per-ray trip
 // counts from 0 to ~600, so a wave costs as much as its slowest ray and both branches of every
@@ -286,8 +257,6 @@ march_train_count_kernel(const float* __restrict__ rays_o, const float* __restri
                          const float* __restrict__ hits_t, const float* __restrict__ noise,
                          MarchParams p, int max_samples, int n_rays,
                          int64_t* __restrict__ rays_a, float* __restrict__ t_scratch) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_coarse[MAX_COARSE_BYTES];
-    const uint8_t* lc = stage_coarse(p, s_coarse);
     if (threadIdx.x >= MARCH_RAYS_PER_WAVE) return;
     const int r = blockIdx.x * MARCH_RAYS_PER_WAVE + threadIdx.x;
     if (r >= n_rays) return;
@@ -300,7 +269,7 @@ march_train_count_kernel(const float* __restrict__ rays_o, const float* __restri
     int n = 0;
     while (0 <= t && t < t2 && n < max_samples) {
         float x, y, z, dt, t_next;
-        if (march_probe(ray, p, lc, t, x, y, z, dt, t_next)) {
+        if (march_probe(ray, p, t, x, y, z, dt, t_next)) {
             row[n] = t;
             t += dt; ++n;
         } else {
@@ -385,8 +354,6 @@ march_test_kernel(const float* __restrict__ rays_o, const float* __restrict__ ra
                   MarchParams p, int n_samples, int n_alive,
                   float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas,
                   float* __restrict__ ts, int32_t* __restrict__ n_eff) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_coarse[MAX_COARSE_BYTES];
-    const uint8_t* lc = stage_coarse(p, s_coarse);
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= n_alive) return;
     const size_t r = (size_t)alive[n];
@@ -398,7 +365,7 @@ march_test_kernel(const float* __restrict__ rays_o, const float* __restrict__ ra
     float t_resume = t;
     while (t < t2 && s < n_samples) {
         float x, y, z, dt, t_next;
-        if (march_probe(ray, p, lc, t, x, y, z, dt, t_next)) {
+        if (march_probe(ray, p, t, x, y, z, dt, t_next)) {
             const size_t o = base + s;
             xyzs[3 * o] = x; xyzs[3 * o + 1] = y; xyzs[3 * o + 2] = z;
             dirs[3 * o] = ray.dx; dirs[3 * o + 1] = ray.dy; dirs[3 * o + 2] = ray.dz;
@@ -446,20 +413,10 @@ compact_alive_kernel(const int64_t* __restrict__ alive_in, const int32_t* __rest
 MarchParams make_march_params(const uint8_t* bitfield, int cascades, int grid_size, float scale,
                               float scale_for_dt, float esf, int max_samples) {
     MarchParams p;
-    p.bitfield = bitfield; p.coarse = nullptr; p.coarse_bytes = 0; p.cascades = cascades; p.grid_size = grid_size; p.scale = scale; p.esf = esf;
+    p.bitfield = bitfield; p.cascades = cascades; p.grid_size = grid_size; p.scale = scale; p.esf = esf;
     p.dt_lo = NGP_SQRT3 / max_samples;                 // raymarching.cu:12, float / int
     p.dt_hi = NGP_SQRT3 * 2 * scale_for_dt / grid_size;
     return p;
-}
-
-// Fills `ws` (cascades*G^3/512 bytes) with the coarse mask and attaches it; no-op when ws is null
-// or the grid is not 128^3-like (needs G^3 divisible by 512 and <= MAX_COARSE_BYTES in total).
-void attach_coarse(MarchParams& p, uint8_t* ws, hipStream_t st) {
-    const long long cells = (long long)p.cascades * p.grid_size * p.grid_size * p.grid_size;
-    if (ws == nullptr || cells % 512 != 0 || cells / 512 > MAX_COARSE_BYTES || (cells / 512) % 4 != 0) return;
-    const int nb = (int)(cells / 512);
-    hipLaunchKernelGGL(coarsen_kernel, dim3(ngp_div_up(nb, 256)), dim3(256), 0, st, p.bitfield, nb, ws);
-    p.coarse = ws; p.coarse_bytes = nb;
 }
 
 }  // namespace
@@ -575,14 +532,13 @@ int ngp_raymarching_train_count(const float* rays_o, const float* rays_d, const 
                                 const uint8_t* density_bitfield, int cascades, float scale,
                                 float exp_step_factor, const float* noise, int grid_size,
                                 int max_samples, int n_rays, int64_t* rays_a, int32_t* counter,
-                                float* t_scratch, uint8_t* coarse_ws, ngp_stream_t stream) {
+                                float* t_scratch, ngp_stream_t stream) {
     if (n_rays < 0 || cascades < 1 || grid_size < 1 || grid_size > 1024 || max_samples < 1) return NGP_EINVAL;
     NGP_CHECK_PTR(counter);
     if (n_rays > 0) {
         NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d); NGP_CHECK_PTR(hits_t); NGP_CHECK_PTR(density_bitfield);
         NGP_CHECK_PTR(noise); NGP_CHECK_PTR(rays_a); NGP_CHECK_PTR(t_scratch);
-        MarchParams p = make_march_params(density_bitfield, cascades, grid_size, scale, scale, exp_step_factor, max_samples);
-        attach_coarse(p, coarse_ws, ngp_stream(stream));
+        const MarchParams p = make_march_params(density_bitfield, cascades, grid_size, scale, scale, exp_step_factor, max_samples);
         hipLaunchKernelGGL(march_train_count_kernel, dim3(ngp_div_up(n_rays, MARCH_RAYS_PER_WAVE)), dim3(64), 0, ngp_stream(stream),
                            rays_o, rays_d, hits_t, noise, p, max_samples, n_rays, rays_a, t_scratch);
     }
@@ -609,15 +565,14 @@ int ngp_raymarching_test(const float* rays_o, const float* rays_d, float* hits_t
                          int cascades, float scale, float exp_step_factor, int grid_size,
                          int max_samples, int n_samples, int n_alive,
                          float* xyzs, float* dirs, float* deltas, float* ts,
-                         int32_t* n_eff_samples, uint8_t* coarse_ws, ngp_stream_t stream) {
+                         int32_t* n_eff_samples, ngp_stream_t stream) {
     if (n_alive < 0 || cascades < 1 || grid_size < 1 || grid_size > 1024 || max_samples < 1 || n_samples < 1) return NGP_EINVAL;
     if (n_alive == 0) return 0;
     NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d); NGP_CHECK_PTR(hits_t); NGP_CHECK_PTR(alive_indices);
     NGP_CHECK_PTR(density_bitfield); NGP_CHECK_PTR(xyzs); NGP_CHECK_PTR(dirs); NGP_CHECK_PTR(deltas);
     NGP_CHECK_PTR(ts); NGP_CHECK_PTR(n_eff_samples);
     // the reference passes `cascades` where calc_dt expects `scale` (raymarching.cu:370,399)
-    MarchParams p = make_march_params(density_bitfield, cascades, grid_size, scale, (float)cascades, exp_step_factor, max_samples);
-    attach_coarse(p, coarse_ws, ngp_stream(stream));
+    const MarchParams p = make_march_params(density_bitfield, cascades, grid_size, scale, (float)cascades, exp_step_factor, max_samples);
     hipLaunchKernelGGL(march_test_kernel, dim3(ngp_div_up(n_alive, 64)), dim3(64), 0, ngp_stream(stream),
                        rays_o, rays_d, hits_t, alive_indices, p, n_samples, n_alive, xyzs, dirs, deltas, ts, n_eff_samples);
     return NGP_LAUNCH_RESULT();

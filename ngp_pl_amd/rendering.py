@@ -105,7 +105,6 @@ def _render_test_native(model, rays_o, rays_d, hits_t, **kwargs):
     enc, net = model.xyz_encoder, model.rgb_net
     eh, rh = enc._half.get(enc.params), net._half.get(net.params)
     total = torch.zeros(1, dtype=torch.int64, device=dev)
-    coarse = torch.empty(model.density_bitfield.numel() // 64, dtype=torch.uint8, device=dev)
     count_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
     samples, n_alive = 0, n_rays
     f32 = dict(dtype=torch.float32, device=dev)
@@ -118,7 +117,7 @@ def _render_test_native(model, rays_o, rays_d, hits_t, **kwargs):
             n_eff = torch.empty(n_alive, dtype=torch.int32, device=dev)
             call("ngp_raymarching_test", ptr(rays_o), ptr(rays_d), ptr(hits), ptr(alive), ptr(model.density_bitfield), model.cascades,
                  float(model.scale), float(esf), model.grid_size, MAX_SAMPLES, N, n_alive, ptr(xyzs), ptr(dirs), ptr(deltas), ptr(ts),
-                 ptr(n_eff), ptr(coarse), stream())
+                 ptr(n_eff), stream())
             feats = torch.empty(16, M, 2, dtype=torch.float16, device=dev); h = torch.empty(M, 16, dtype=torch.float16, device=dev)
             sigmas = torch.empty(M, **f32); rgbs = torch.empty(M, 3, **f32)
             call("ngp_hashgrid_fwd", ptr(xyzs), ptr(model.xyz_min), ptr(model.xyz_max), ptr(eh[enc.n_mlp:]), C.byref(enc.meta), M, ptr(feats), stream())

@@ -81,7 +81,6 @@ class Trainer:
         counter = torch.empty(2, dtype=torch.int32, device=dev)
         scratch = torch.empty(n * MAX_SAMPLES, dtype=torch.float32, device=dev)
         counter_host = torch.empty(2, dtype=torch.int32, pin_memory=True)
-        coarse = torch.empty(m.density_bitfield.numel() // 64, dtype=torch.uint8, device=dev)
         main = torch.cuda.current_stream()
         st = self.side if self.side is not None else main
         if st is not main:
@@ -94,7 +93,7 @@ class Trainer:
             call("ngp_ray_aabb_near", ptr(rays_o), ptr(rays_d), ptr(m.center), ptr(m.half_size), NEAR_DISTANCE, n, ptr(hits_t), stream())
             call("ngp_raymarching_train_count", ptr(rays_o), ptr(rays_d), ptr(hits_t), ptr(m.density_bitfield), m.cascades,
                  float(m.scale), self.exp_step_factor, ptr(noise), m.grid_size, MAX_SAMPLES, n, ptr(rays_a), ptr(counter),
-                 ptr(scratch), ptr(coarse), stream())
+                 ptr(scratch), stream())
             if self.events is not None:
                 t1 = torch.cuda.Event(enable_timing=True); t1.record()
             counter_host.copy_(counter, non_blocking=True)

@@ -22,11 +22,6 @@ def _f32(*ts):
             raise RuntimeError("expected a float32 tensor, got %s" % t.dtype)
 
 
-def _coarse_ws(density_bitfield):
-    """Workspace for the marcher's coarse occupancy mask (1 bit per 4x4x4 cells)."""
-    return torch.empty(max(density_bitfield.numel() // 64, 4), dtype=torch.uint8, device=density_bitfield.device)
-
-
 def ray_aabb_intersect(rays_o, rays_d, centers, half_sizes, max_hits):
     require_cuda(rays_o, rays_d, centers, half_sizes); _f32(rays_o, rays_d, centers, half_sizes)
     n, v = rays_o.shape[0], centers.shape[0]
@@ -90,11 +85,10 @@ def raymarching_train(rays_o, rays_d, hits_t, density_bitfield, cascades, scale,
     rays_a = torch.empty(n, 3, dtype=torch.int64, device=dev)
     counter = torch.empty(2, dtype=torch.int32, device=dev)
     scratch = torch.empty(max(n, 1) * max_samples, dtype=torch.float32, device=dev)
-    coarse = _coarse_ws(density_bitfield)
     with torch.cuda.device(dev):
         call("ngp_raymarching_train_count", ptr(rays_o), ptr(rays_d), ptr(hits_t), ptr(density_bitfield), int(cascades),
              float(scale), float(exp_step_factor), ptr(noise), int(grid_size), int(max_samples), n,
-             ptr(rays_a), ptr(counter), ptr(scratch), ptr(coarse), stream())
+             ptr(rays_a), ptr(counter), ptr(scratch), stream())
         S = int(counter[0].item())   # the one host sync of the step (the reference syncs here too)
         xyzs = torch.empty(S, 3, dtype=torch.float32, device=dev)
         dirs = torch.empty(S, 3, dtype=torch.float32, device=dev)
@@ -115,11 +109,10 @@ def raymarching_test(rays_o, rays_d, hits_t, alive_indices, density_bitfield, ca
     deltas = torch.empty(na, N_samples, dtype=torch.float32, device=dev)
     ts = torch.empty(na, N_samples, dtype=torch.float32, device=dev)
     n_eff = torch.empty(na, dtype=torch.int32, device=dev)
-    coarse = _coarse_ws(density_bitfield)
     with torch.cuda.device(dev):
         call("ngp_raymarching_test", ptr(rays_o), ptr(rays_d), ptr(hits_t), ptr(alive_indices), ptr(density_bitfield),
              int(cascades), float(scale), float(exp_step_factor), int(grid_size), int(max_samples), int(N_samples), na,
-             ptr(xyzs), ptr(dirs), ptr(deltas), ptr(ts), ptr(n_eff), ptr(coarse), stream())
+             ptr(xyzs), ptr(dirs), ptr(deltas), ptr(ts), ptr(n_eff), stream())
     return [xyzs, dirs, deltas, ts, n_eff]
 
 

@@ -44,7 +44,7 @@ def test_argument_validation_needs_no_gpu():
     with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
         _lib.call("ngp_morton3D", None, 5, None, None)                      # null pointers with n > 0
     with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
-        _lib.call("ngp_raymarching_test", None, None, None, None, None, 1, 0.5, 0.0, 128, 1024, 0, 4, None, None, None, None, None, None, None)
+        _lib.call("ngp_raymarching_test", None, None, None, None, None, 1, 0.5, 0.0, 128, 1024, 0, 4, None, None, None, None, None, None)
     with pytest.raises(_lib.NgpError, match="NGP_EUNSUP"):
         fake = C.c_void_p(4096)     # never dereferenced: the configuration is rejected before any launch
         _lib.call("ngp_mlp_fwd", fake, fake, 48, 1, 3, 0, 10, fake, None)   # width 48 is not a supported input size
