@@ -194,6 +194,8 @@ struct MarchParams {
     float esf;          // exp_step_factor
     float dt_lo;        // SQRT3 / max_samples
     float dt_hi;        // SQRT3 * 2 * scale_for_dt / grid_size
+    float bound0, bound0_inv;   // mip 0: fminf(scalbnf(1, -1), scale) and its reciprocal (SIMPLE path)
+    int simple;         // cascades == 1 && esf == 0
 };
 
 __device__ __forceinline__ float calc_dt(float t, const MarchParams& p) {
@@ -206,18 +208,29 @@ struct Ray {
 
 // Evaluates the cell containing the sample at parameter t.  Returns whether it is occupied,
 // the sample position, dt, and (when empty) the next t on the step lattice past the cell.
+// SIMPLE = one cascade and exp_step_factor 0 (the Synthetic-NeRF setting): then mip is 0 for every
+// sample (min(cascades-1, .) = 0), mip_bound is the constant min(0.5, scale) and
+// dt = max(dt_lo, min(t*0, dt_hi)) = dt_lo for every t >= 0, so the two frexp, the scalbn, the
+// division and the clamp leave the dependent chain; every value that remains is computed by
+// the same operations as in the general case.
+template <bool SIMPLE>
 __device__ __forceinline__ bool march_probe(const Ray& ray, const MarchParams& p, float t,
                                             float& x, float& y, float& z, float& dt, float& t_next) {
     x = fmaf(t, ray.dx, ray.ox); y = fmaf(t, ray.dy, ray.oy); z = fmaf(t, ray.dz, ray.oz);
-    dt = calc_dt(t, p);
     const float G = (float)p.grid_size;
-    int e_pos; frexpf(fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))), &e_pos);
-    int e_dt; frexpf(dt * G, &e_dt);
-    const int mip_pos = min(p.cascades - 1, max(0, e_pos + 1));
-    const int mip_dt = min(p.cascades - 1, max(0, e_dt));
-    const int mip = max(mip_pos, mip_dt);
-    const float mip_bound = fminf(scalbnf(1.0f, mip - 1), p.scale);
-    const float mip_bound_inv = 1 / mip_bound;
+    int mip = 0;
+    if (SIMPLE) {
+        dt = p.dt_lo;
+    } else {
+        dt = calc_dt(t, p);
+        int e_pos; frexpf(fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))), &e_pos);
+        int e_dt; frexpf(dt * G, &e_dt);
+        const int mip_pos = min(p.cascades - 1, max(0, e_pos + 1));
+        const int mip_dt = min(p.cascades - 1, max(0, e_dt));
+        mip = max(mip_pos, mip_dt);
+    }
+    const float mip_bound = SIMPLE ? p.bound0 : fminf(scalbnf(1.0f, mip - 1), p.scale);
+    const float mip_bound_inv = SIMPLE ? p.bound0_inv : 1 / mip_bound;
     const float gm1 = G - 1.0f;
     const int nx = (int)fmaxf(0.0f, fminf(0.5f * (x * mip_bound_inv + 1) * G, gm1));
     const int ny = (int)fmaxf(0.0f, fminf(0.5f * (y * mip_bound_inv + 1) * G, gm1));
@@ -232,7 +245,8 @@ __device__ __forceinline__ bool march_probe(const Ray& ray, const MarchParams& p
         const float tz = (((nz + 0.5f + 0.5f * copysignf(1.0f, ray.dz)) * ginv * 2 - 1) * mip_bound - z) * ray.iz;
         const float t_target = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
         float tt = t;
-        do { tt += calc_dt(tt, p); } while (tt < t_target);
+        if (SIMPLE) { do { tt += p.dt_lo; } while (tt < t_target); }
+        else { do { tt += calc_dt(tt, p); } while (tt < t_target); }
         t_next = tt;
     }
     return occ;
@@ -252,6 +266,7 @@ __device__ __forceinline__ Ray load_ray(const float* __restrict__ rays_o, const 
 // step.  Rays per wave are therefore kept to MARCH_RAYS_PER_WAVE (lanes above stay idle): 8192
 // rays become 512 waves spread over all 256 CUs instead of the reference's 32 blocks of 256.
 constexpr int MARCH_RAYS_PER_WAVE = 16;
+template <bool SIMPLE>
 __global__ void __launch_bounds__(64)
 march_train_count_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                          const float* __restrict__ hits_t, const float* __restrict__ noise,
@@ -263,13 +278,13 @@ march_train_count_kernel(const float* __restrict__ rays_o, const float* __restri
     const Ray ray = load_ray(rays_o, rays_d, r);
     float t1 = hits_t[2 * r];
     const float t2 = hits_t[2 * r + 1];
-    if (t1 >= 0) t1 = fmaf(calc_dt(t1, p), noise[r], t1);
+    if (t1 >= 0) t1 = fmaf(calc_dt(t1, p), noise[r], t1);   // general formula also on the SIMPLE path (== dt_lo there)
     float* __restrict__ row = t_scratch + (size_t)r * max_samples;
     float t = t1;
     int n = 0;
     while (0 <= t && t < t2 && n < max_samples) {
         float x, y, z, dt, t_next;
-        if (march_probe(ray, p, t, x, y, z, dt, t_next)) {
+        if (march_probe<SIMPLE>(ray, p, t, x, y, z, dt, t_next)) {
             row[n] = t;
             t += dt; ++n;
         } else {
@@ -348,6 +363,7 @@ march_train_write_kernel(const float* __restrict__ rays_o, const float* __restri
 
 // Test-time marching (raymarching.cu:353-403).  Dense (n_alive, n_samples) outputs are fully
 // written here (the reference zero-fills them on the host first).
+template <bool SIMPLE>
 __global__ void __launch_bounds__(64)
 march_test_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                   float* __restrict__ hits_t, const int64_t* __restrict__ alive,
@@ -365,7 +381,7 @@ march_test_kernel(const float* __restrict__ rays_o, const float* __restrict__ ra
     float t_resume = t;
     while (t < t2 && s < n_samples) {
         float x, y, z, dt, t_next;
-        if (march_probe(ray, p, t, x, y, z, dt, t_next)) {
+        if (march_probe<SIMPLE>(ray, p, t, x, y, z, dt, t_next)) {
             const size_t o = base + s;
             xyzs[3 * o] = x; xyzs[3 * o + 1] = y; xyzs[3 * o + 2] = z;
             dirs[3 * o] = ray.dx; dirs[3 * o + 1] = ray.dy; dirs[3 * o + 2] = ray.dz;
@@ -416,6 +432,9 @@ MarchParams make_march_params(const uint8_t* bitfield, int cascades, int grid_si
     p.bitfield = bitfield; p.cascades = cascades; p.grid_size = grid_size; p.scale = scale; p.esf = esf;
     p.dt_lo = NGP_SQRT3 / max_samples;                 // raymarching.cu:12, float / int
     p.dt_hi = NGP_SQRT3 * 2 * scale_for_dt / grid_size;
+    p.bound0 = fminf(scalbnf(1.0f, -1), scale);
+    p.bound0_inv = 1 / p.bound0;
+    p.simple = (cascades == 1 && esf == 0.0f) ? 1 : 0;
     return p;
 }
 
@@ -539,8 +558,12 @@ int ngp_raymarching_train_count(const float* rays_o, const float* rays_d, const 
         NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d); NGP_CHECK_PTR(hits_t); NGP_CHECK_PTR(density_bitfield);
         NGP_CHECK_PTR(noise); NGP_CHECK_PTR(rays_a); NGP_CHECK_PTR(t_scratch);
         const MarchParams p = make_march_params(density_bitfield, cascades, grid_size, scale, scale, exp_step_factor, max_samples);
-        hipLaunchKernelGGL(march_train_count_kernel, dim3(ngp_div_up(n_rays, MARCH_RAYS_PER_WAVE)), dim3(64), 0, ngp_stream(stream),
-                           rays_o, rays_d, hits_t, noise, p, max_samples, n_rays, rays_a, t_scratch);
+        if (p.simple)
+            hipLaunchKernelGGL(march_train_count_kernel<true>, dim3(ngp_div_up(n_rays, MARCH_RAYS_PER_WAVE)), dim3(64), 0, ngp_stream(stream),
+                               rays_o, rays_d, hits_t, noise, p, max_samples, n_rays, rays_a, t_scratch);
+        else
+            hipLaunchKernelGGL(march_train_count_kernel<false>, dim3(ngp_div_up(n_rays, MARCH_RAYS_PER_WAVE)), dim3(64), 0, ngp_stream(stream),
+                               rays_o, rays_d, hits_t, noise, p, max_samples, n_rays, rays_a, t_scratch);
     }
     hipLaunchKernelGGL(march_train_scan_kernel, dim3(1), dim3(1024), 0, ngp_stream(stream), rays_a, n_rays, counter);
     return NGP_LAUNCH_RESULT();
@@ -573,8 +596,13 @@ int ngp_raymarching_test(const float* rays_o, const float* rays_d, float* hits_t
     NGP_CHECK_PTR(ts); NGP_CHECK_PTR(n_eff_samples);
     // the reference passes `cascades` where calc_dt expects `scale` (raymarching.cu:370,399)
     const MarchParams p = make_march_params(density_bitfield, cascades, grid_size, scale, (float)cascades, exp_step_factor, max_samples);
-    hipLaunchKernelGGL(march_test_kernel, dim3(ngp_div_up(n_alive, 64)), dim3(64), 0, ngp_stream(stream),
-                       rays_o, rays_d, hits_t, alive_indices, p, n_samples, n_alive, xyzs, dirs, deltas, ts, n_eff_samples);
+    // NB: the test kernel's dt clamp uses `cascades` as scale (reference quirk); with esf == 0 dt is dt_lo either way
+    if (p.simple)
+        hipLaunchKernelGGL(march_test_kernel<true>, dim3(ngp_div_up(n_alive, 64)), dim3(64), 0, ngp_stream(stream),
+                           rays_o, rays_d, hits_t, alive_indices, p, n_samples, n_alive, xyzs, dirs, deltas, ts, n_eff_samples);
+    else
+        hipLaunchKernelGGL(march_test_kernel<false>, dim3(ngp_div_up(n_alive, 64)), dim3(64), 0, ngp_stream(stream),
+                           rays_o, rays_d, hits_t, alive_indices, p, n_samples, n_alive, xyzs, dirs, deltas, ts, n_eff_samples);
     return NGP_LAUNCH_RESULT();
 }
 
