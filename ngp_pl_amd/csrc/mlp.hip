@@ -74,11 +74,17 @@ __device__ __forceinline__ half8_t d_to_b(const f32x16& d, int c2) {
 // Stage a (rows, cols) row-major f16 matrix from global into LDS with padded pitch, optionally
 // transposed (LDS gets (cols, rows)).  Whole workgroup participates.
 __device__ __forceinline__ void stage_weights(const h1* __restrict__ g, h1* lds, int rows, int cols, bool transpose) {
-    const int n = rows * cols;
-    for (int t = threadIdx.x; t < n; t += blockDim.x) {
-        const int r = t / cols, c = t - r * cols;
-        if (transpose) lds[c * (rows + PAD) + r] = g[t];
-        else lds[r * (cols + PAD) + c] = g[t];
+    // 16-byte global loads (cols is a multiple of 8, blobs are 16 B aligned)
+    const int n8 = rows * cols / 8;
+    for (int t = threadIdx.x; t < n8; t += blockDim.x) {
+        const half8_t v = *reinterpret_cast<const half8_t*>(g + 8 * t);
+        const int r = (8 * t) / cols, c = 8 * t - r * cols;
+        if (transpose) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) lds[(c + e) * (rows + PAD) + r] = v[e];
+        } else {
+            *reinterpret_cast<half8_t*>(lds + r * (cols + PAD) + c) = v;
+        }
     }
 }
 
@@ -331,8 +337,11 @@ __device__ __forceinline__ void wgrad_tile(const h1* tdy, const h1* tx, int i, i
             for (int n = 0; n < NT; ++n) acc[m][n] = mfma(a[m], b[n], acc[m][n]);
     }
 }
-// add a wave's dW accumulators into the workgroup's f32 LDS partial (row-major (rows, ld))
-template <int MT, int NT>
+// Add a wave's dW accumulators into the workgroup's f32 LDS partial (row-major (rows, ld)).
+// Called by ONE wave at a time (the caller serialises the waves with barriers): plain
+// read-modify-write, no LDS float atomics (those cost ~3 cycles per lane on gfx950 and made this
+// epilogue 40 us per workgroup).  FIRST: store instead of accumulate (no zero-fill needed).
+template <int MT, int NT, bool FIRST>
 __device__ __forceinline__ void wgrad_flush(float* part, int ld, int n_rows, int n_cols, int j, int hh,
                                             const f32x16 (&acc)[MT][NT]) {
 #pragma unroll
@@ -342,7 +351,10 @@ __device__ __forceinline__ void wgrad_flush(float* part, int ld, int n_rows, int
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * hh, col = 32 * n + j;
-                if (row < n_rows && col < n_cols) atomicAdd(part + row * ld + col, acc[m][n][r]);
+                if (row < n_rows && col < n_cols) {
+                    float* q = part + row * ld + col;
+                    *q = FIRST ? acc[m][n][r] : *q + acc[m][n][r];
+                }
             }
 }
 
@@ -370,7 +382,6 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
     stage_weights(weights, lds + OFF_T0, HID, N_IN, true);
     if (N_HIDDEN == 2) stage_weights(weights + L::G_W1, lds + OFF_T1, HID, HID, true);
     stage_weights(weights + L::G_WO, lds + OFF_TO, 16, HID, true);
-    for (int t = threadIdx.x; t < L::G_SIZE; t += blockDim.x) part[t] = 0.f;
     __syncthreads();
 
     const int lane = threadIdx.x & 63, i = lane & 31, hh = lane >> 5;
@@ -558,11 +569,22 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
         wgrad_tile<1, 2>(tdy, tx, i, hh, gWo);
         wave_lds_sync();
     }
-    // ---- reduce the 4 waves' dW into LDS, then one coalesced partial row per workgroup ----
-    wgrad_flush<2, (N_IN / 32 > 0 ? N_IN / 32 : 1)>(part, N_IN, HID, N_IN, i, hh, gW0);
-    if (N_HIDDEN == 2) wgrad_flush<2, 2>(part + L::G_W1, HID, HID, HID, i, hh, gW1);
-    wgrad_flush<1, 2>(part + L::G_WO, HID, 16, HID, i, hh, gWo);
-    __syncthreads();
+    // ---- reduce the 4 waves' dW into LDS (one wave at a time), then one coalesced partial row per workgroup ----
+    constexpr int NT0 = (N_IN / 32 > 0 ? N_IN / 32 : 1);
+    for (int w = 0; w < WAVES; ++w) {
+        if (wave == w) {
+            if (w == 0) {
+                wgrad_flush<2, NT0, true>(part, N_IN, HID, N_IN, i, hh, gW0);
+                if (N_HIDDEN == 2) wgrad_flush<2, 2, true>(part + L::G_W1, HID, HID, HID, i, hh, gW1);
+                wgrad_flush<1, 2, true>(part + L::G_WO, HID, 16, HID, i, hh, gWo);
+            } else {
+                wgrad_flush<2, NT0, false>(part, N_IN, HID, N_IN, i, hh, gW0);
+                if (N_HIDDEN == 2) wgrad_flush<2, 2, false>(part + L::G_W1, HID, HID, HID, i, hh, gW1);
+                wgrad_flush<1, 2, false>(part + L::G_WO, HID, 16, HID, i, hh, gWo);
+            }
+        }
+        __syncthreads();
+    }
     float* out = io.wgrad_partial + (size_t)blockIdx.x * L::G_SIZE;
     for (int t = threadIdx.x; t < L::G_SIZE; t += blockDim.x) out[t] = part[t];
 }
@@ -579,7 +601,7 @@ constexpr int bwd_smem_bytes() {
 int fwd_grid(int n_samples) {
     const int n_tiles = (n_samples + TILE - 1) / TILE;
     const int blocks = (n_tiles + WAVES - 1) / WAVES;
-    return blocks < 1024 ? (blocks < 1 ? 1 : blocks) : 1024;
+    return blocks < 512 ? (blocks < 1 ? 1 : blocks) : 512;   // <= 2 workgroups per CU: the per-workgroup weight staging is amortised over more tiles
 }
 int bwd_grid(int n_samples) {
     const int n_tiles = (n_samples + TILE - 1) / TILE;
