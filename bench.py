@@ -75,8 +75,12 @@ def kernel_roofline(trainer, draw, n_steps=10):
     stages.sort(key=lambda d: -d["ms"])
     top = next(d for d in stages if d["stage"] not in ("grid_update", "march_count(side stream)"))   # the march overlaps the main stream
     achieved = top["GB/s"]
+    # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this
+    # same command; summary and calibration in profiles/r01_pmc_hbm_traffic.txt).  Not measurable from inside this process.
+    pmc = {"hashgrid_bwd": (54662.6 + 21104.8) * 1024, "hashgrid_fwd": (40195.3 + 27011.6) * 1024, "adam": (2 * 78269.2 + 178828.8) * 1024}
     return {"bound": "hbm", "kernel": top["stage"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_ms": top["ms"], "samples_per_launch": S, "stages": stages}
+            "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get(top["stage"]), "traffic_source": "profiles/r01_pmc_hbm_traffic.txt",
+            "avg_ms": top["ms"], "samples_per_launch": S, "stages": stages}
 
 
 def cpu_baseline(model, data, budget_s=20.0):
@@ -201,6 +205,7 @@ def main():
                    "samples_per_ray_marched": met["rm_s"], "samples_per_ray_composited": met["vr_s"], "train_psnr": met["psnr"],
                    "parallelism": "dp%d (per-ray data parallel, native-gradient all-reduce)" % world},
     }
+    trainer.grad_hook = None      # what follows runs on rank 0 only: no collectives from here on
     if rank == 0:
         if not args.no_render:
             out["render_fps_800x800"] = render_fps(model, data, n_frames=5)

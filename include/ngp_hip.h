@@ -319,6 +319,13 @@ int ngp_adam_step(float* param, ngp_half* param_h, void* grad, int grad_is_f32,
                   float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int step, float grad_scale, const int32_t* found_inf,
                   ngp_stream_t stream);
+/* The same update for a parameter block whose gradient is still spread over n_partials rows of
+ * per-workgroup partial sums (n_partials, n) f32 (ngp_*_bwd's wgrad_partial): reduces the column
+ * and applies Adam in one launch. */
+int ngp_adam_step_partials(float* param, ngp_half* param_h, const float* partials, int n_partials,
+                           float* m, float* v, int n, float lr, float beta1, float beta2, float eps,
+                           float weight_decay, int step, float grad_scale, const int32_t* found_inf,
+                           ngp_stream_t stream);
 /* Sum n_partials rows of (n) f32 into out (n) f32 (out = sum, not accumulated). */
 int ngp_reduce_partials(const float* partials, int n_partials, int n, float* out,
                         ngp_stream_t stream);

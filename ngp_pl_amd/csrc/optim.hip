@@ -101,6 +101,36 @@ reduce_partials_kernel(const float* __restrict__ partials, int n_partials, int n
     }
 }
 
+// Adam for the small MLP blocks straight from the per-workgroup partial sums: one thread per
+// parameter sums its column of `partials` (n_partials x n) and applies the update.
+__global__ void __launch_bounds__(256)
+adam_partials_kernel(float* __restrict__ param, h1* __restrict__ param_h, const float* __restrict__ partials, int n_partials,
+                     float* __restrict__ m, float* __restrict__ v, int n, float lr, float beta1, float beta2, float eps,
+                     float wd, float bc1, float bc2, float inv_scale, const int32_t* __restrict__ found_inf) {
+    __shared__ float s_acc[8][32];
+    const int c = threadIdx.x & 31, lane_row = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + c;
+    float a0 = 0.f, a1 = 0.f;
+    if (i < n) {
+        int p = lane_row;
+        for (; p + 8 < n_partials; p += 16) { a0 += partials[(size_t)p * n + i]; a1 += partials[(size_t)(p + 8) * n + i]; }
+        for (; p < n_partials; p += 8) a0 += partials[(size_t)p * n + i];
+    }
+    s_acc[lane_row][c] = a0 + a1;
+    __syncthreads();
+    if (lane_row != 0 || i >= n) return;
+    if (found_inf != nullptr && *found_inf != 0) return;
+    float g = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) g += s_acc[r][c];
+    g *= inv_scale;
+    const float mk = beta1 * m[i] + (1.f - beta1) * g;
+    const float vk = beta2 * v[i] + (1.f - beta2) * g * g;
+    const float pk = param[i] - lr * ((mk / bc1) / (sqrtf(vk / bc2) + eps) + wd * param[i]);
+    m[i] = mk; v[i] = vk; param[i] = pk;
+    if (param_h) param_h[i] = (h1)pk;
+}
+
 __global__ void __launch_bounds__(256)
 cast_f32_f16_kernel(const float* __restrict__ in, long long n, h1* __restrict__ out) {
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -202,6 +232,19 @@ int ngp_adam_step(float* param, ngp_half* param_h, void* grad, int grad_is_f32, 
     else
         hipLaunchKernelGGL(adam_kernel<false>, dim3(blocks), dim3(256), 0, ngp_stream(stream), param, (h1*)param_h, grad, m, v,
                            n4, (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, 1.0f / grad_scale, found_inf);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_adam_step_partials(float* param, ngp_half* param_h, const float* partials, int n_partials, float* m, float* v,
+                           int n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                           float grad_scale, const int32_t* found_inf, ngp_stream_t stream) {
+    if (n < 0 || n_partials < 0 || step < 1 || grad_scale == 0.f) return NGP_EINVAL;
+    if (n == 0) return 0;
+    NGP_CHECK_PTR(param); NGP_CHECK_PTR(m); NGP_CHECK_PTR(v);
+    if (n_partials > 0) NGP_CHECK_PTR(partials);
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_partials_kernel, dim3(ngp_div_up(n, 32)), dim3(256), 0, ngp_stream(stream), param, (h1*)param_h, partials,
+                       n_partials, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, 1.0f / grad_scale, found_inf);
     return NGP_LAUNCH_RESULT();
 }
 

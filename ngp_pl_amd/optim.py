@@ -44,19 +44,17 @@ class FusedAdam:
         total_scale = nat["scale"] * grad_scale
         dev = enc.params.device
         with torch.cuda.device(dev):
-            g_density = tcnn.reduce_partials(nat["density_partials"], nat["n_partials"], enc.n_mlp)
-            g_rgb = tcnn.reduce_partials(nat["rgb_partials"], nat["n_partials"], net.params.numel())
             m, v = self.state["enc"]
             ph = enc._half.t
             fi = ptr(found_inf)
-            call("ngp_adam_step", ptr(enc.params.data), ptr(ph), ptr(g_density), 1, ptr(m), ptr(v), enc.n_mlp,
-                 lr, b1, b2, self.eps, self.weight_decay, self.t, total_scale, fi, stream())
+            call("ngp_adam_step_partials", ptr(enc.params.data), ptr(ph), ptr(nat["density_partials"]), nat["n_partials"], ptr(m), ptr(v),
+                 enc.n_mlp, lr, b1, b2, self.eps, self.weight_decay, self.t, total_scale, fi, stream())
             call("ngp_adam_step", ptr(enc.params.data[enc.n_mlp:]), ptr(ph[enc.n_mlp:]), ptr(nat["grid16"]), 0,
                  ptr(m[enc.n_mlp:]), ptr(v[enc.n_mlp:]), enc.n_grid, lr, b1, b2, self.eps, self.weight_decay, self.t,
                  total_scale, fi, stream())
             m, v = self.state["rgb"]
-            call("ngp_adam_step", ptr(net.params.data), ptr(net._half.t), ptr(g_rgb), 1, ptr(m), ptr(v), net.params.numel(),
-                 lr, b1, b2, self.eps, self.weight_decay, self.t, total_scale, fi, stream())
+            call("ngp_adam_step_partials", ptr(net.params.data), ptr(net._half.t), ptr(nat["rgb_partials"]), nat["n_partials"], ptr(m), ptr(v),
+                 net.params.numel(), lr, b1, b2, self.eps, self.weight_decay, self.t, total_scale, fi, stream())
         model._native = None
 
 
