@@ -83,6 +83,19 @@ def kernel_roofline(trainer, draw, n_steps=10):
             "avg_ms": top["ms"], "samples_per_launch": S, "stages": stages}
 
 
+def api_path_rate(trainer, draw, n_steps=30):
+    """The same step driven through the reference-shaped surface: render() -> NeRFLoss -> torch autograd -> FusedAdam
+    (Trainer.step_autograd), i.e. what train.py would exercise.  Secondary number, not `value`."""
+    for _ in range(5):
+        b = draw(); trainer.step_autograd(b[0], b[1], b[2])
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n_steps):
+        b = draw(); trainer.step_autograd(b[0], b[1], b[2])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / n_steps
+    return {"rays_per_s": b[0].shape[0] / dt, "ms_per_step": dt * 1e3, "what": "render()+NeRFLoss+autograd+FusedAdam, same kernels"}
+
+
 def cpu_baseline(model, data, budget_s=20.0):
     """The CPU oracle timed on the host cores on BASELINE.json configs[0] (256 rays/batch): full
     step = AABB + march + composite fwd/bwd with the reference's own kernels compiled for the CPU
@@ -199,7 +212,7 @@ def main():
         "metric": "train rays/sec (800x800 Lego-like, 8192 rays/batch/GPU, full step incl. optimizer)",
         "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16 storage / f32 accumulate (grid, MLP); f32 march+composite", "data": "synthetic (procedural Lego-like scene, random-init weights)",
+        "dtype": "f16/f32", "dtype_detail": "hash tables, features, MLP operands f16 with f32 MFMA/blend accumulation; march, composite, Adam f32", "data": "synthetic (procedural Lego-like scene, random-init weights)",
         "config": {"workload": "configs[1]: Synthetic-NeRF Lego-like, 1xMI355X per rank, 8192 rays/batch, 800x800, scale 0.5",
                    "rays_per_gpu": args.rays, "image_res": args.res, "n_images": args.images,
                    "samples_per_ray_marched": met["rm_s"], "samples_per_ray_composited": met["vr_s"], "train_psnr": met["psnr"],
@@ -210,6 +223,7 @@ def main():
         if not args.no_render:
             out["render_fps_800x800"] = render_fps(model, data, n_frames=5)
         out["roofline"] = kernel_roofline(trainer, draw)
+        out["api_path"] = api_path_rate(trainer, draw)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, data)
         print(json.dumps(out))
