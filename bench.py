@@ -38,7 +38,7 @@ def parse():
     p.add_argument("--images", type=int, default=100)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-render", action="store_true")
-    p.add_argument("--profile-kernels", action="store_true", help="time the dominant kernels in isolation (roofline)")
+    p.add_argument("--timed-only", action="store_true", help="stop after the timed loop (for rocprofv3 runs: the trace then ends with the K timed steps)")
     return p.parse_args()
 
 
@@ -219,7 +219,9 @@ def main():
                    "parallelism": "dp%d (per-ray data parallel, native-gradient all-reduce)" % world},
     }
     trainer.grad_hook = None      # what follows runs on rank 0 only: no collectives from here on
-    if rank == 0:
+    if rank == 0 and args.timed_only:
+        print(json.dumps(out))
+    elif rank == 0:
         if not args.no_render:
             out["render_fps_800x800"] = render_fps(model, data, n_frames=5)
         out["roofline"] = kernel_roofline(trainer, draw)
