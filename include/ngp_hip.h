@@ -149,7 +149,8 @@ int ngp_composite_train_fw(const float* sigmas, const float* rgbs, const float* 
                            const float* ts, const int64_t* rays_a, float T_threshold,
                            int n_rays, int n_samples,
                            int64_t* total_samples, float* opacity, float* depth, float* rgb,
-                           float* ws, ngp_stream_t stream);
+                           float* ws, int32_t* n_active_per_ray /* optional (R) i32: min(N, total+1) per row */,
+                           ngp_stream_t stream);
 
 /* vren.composite_train_bw (binding.cpp:129-163, volumerendering.cu:87-202).
  * dL_dws may be NULL (treated as zeros).  out: dL_dsigmas (S), dL_drgbs (S,3), fully written. */
@@ -158,7 +159,10 @@ int ngp_composite_train_bw(const float* dL_dopacity, const float* dL_ddepth, con
                            const float* ws, const float* deltas, const float* ts,
                            const int64_t* rays_a, const float* opacity, const float* depth,
                            const float* rgb, float T_threshold, int n_rays, int n_samples,
-                           float* dL_dsigmas, float* dL_drgbs, ngp_stream_t stream);
+                           float* dL_dsigmas, float* dL_drgbs,
+                           const int32_t* ray_offsets, int32_t* active_idx /* both optional: also list the
+                           live samples of row n at active_idx[ray_offsets[n] ...] (see ngp_active_scan) */,
+                           ngp_stream_t stream);
 
 /* vren.composite_test_fw (binding.cpp:166-194, volumerendering.cu:205-285).
  * sigmas,deltas,ts (N_alive,N_samples); rgbs (N_alive,N_samples,3); alive_indices, opacity,
@@ -230,6 +234,10 @@ int ngp_hashgrid_bwd_sliced(const float* x, const float* xyz_min, const float* x
 int ngp_active_samples(const int64_t* rays_a, const int64_t* total_samples, int n_rays,
                        int32_t* ray_offsets, int32_t* active_idx, int32_t* n_active,
                        ngp_stream_t stream);
+/* The fused form used by the trainer: ngp_composite_train_fw emits n_active_per_ray, this call
+ * turns it IN PLACE into exclusive offsets (+ the total in n_active), and ngp_composite_train_bw
+ * writes the list while it walks the rays anyway. */
+int ngp_active_scan(int32_t* n_active_per_ray, int n_rays, int32_t* n_active, ngp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * tinycudann: FullyFusedMLP + SphericalHarmonics  (call sites networks.py:49-77)
@@ -339,10 +347,10 @@ int ngp_cast_f16_to_f32(const ngp_half* in, int64_t n, float scale, float* out,
  * ------------------------------------------------------------------------------------------ */
 
 /* With rgb_f = rgb + bg*(1-opacity) (bg (3) f32 or NULL = black; rendering.py:153-161):
- *   loss[0] += mean((rgb_f-gt)^2) + mean(lambda_o * -(o+1e-10) log(o+1e-10))
+ *   loss[0] = mean((rgb_f-gt)^2) + mean(lambda_o * -(o+1e-10) log(o+1e-10))
  * and the backward seeds dL_drgb (R,3), dL_dopacity (R) w.r.t. the COMPOSITED rgb/opacity, both
- * multiplied by grad_scale.  loss (1) f32 accumulates (caller zeroes); sq_err (1) f32 (may be
- * NULL) accumulates sum((rgb_f-gt)^2) for PSNR. */
+ * multiplied by grad_scale.  loss (1) f32 and sq_err (1) f32 (may be NULL; sum((rgb_f-gt)^2), for
+ * PSNR) are OVERWRITTEN. */
 int ngp_nerf_loss(const float* rgb, const float* opacity, const float* gt_rgb, const float* bg,
                   float lambda_opacity, float grad_scale, int n_rays,
                   float* loss, float* sq_err, float* dL_drgb, float* dL_dopacity,

@@ -41,8 +41,9 @@ _PROTOS = {
     "ngp_raymarching_train_count": [P, P, P, P, I, F, F, P, I, I, I, P, P, P, P],
     "ngp_raymarching_train_write": [P, P, P, P, F, F, I, I, I, P, P, P, P, P],
     "ngp_raymarching_test": [P, P, P, P, P, I, F, F, I, I, I, I, P, P, P, P, P, P],
-    "ngp_composite_train_fw": [P, P, P, P, P, F, I, I, P, P, P, P, P, P],
-    "ngp_composite_train_bw": [P] * 13 + [F, I, I, P, P, P],
+    "ngp_composite_train_fw": [P, P, P, P, P, F, I, I, P, P, P, P, P, P, P],
+    "ngp_composite_train_bw": [P] * 13 + [F, I, I, P, P, P, P, P],
+    "ngp_active_scan": [P, I, P, P],
     "ngp_composite_test_fw": [P, P, P, P, P, F, P, I, I, P, P, P, P],
     "ngp_distortion_loss_fw": [P, P, P, P, I, I, P, P, P, P],
     "ngp_distortion_loss_bw": [P, P, P, P, P, P, P, I, I, P, P],

@@ -49,7 +49,8 @@ composite_train_fw_kernel(const float* __restrict__ sigmas, const float* __restr
                           const float* __restrict__ deltas, const float* __restrict__ ts,
                           const int64_t* __restrict__ rays_a, float T_threshold, int n_rays,
                           int64_t* __restrict__ total_samples, float* __restrict__ opacity,
-                          float* __restrict__ depth, float* __restrict__ rgb, float* __restrict__ ws) {
+                          float* __restrict__ depth, float* __restrict__ rgb, float* __restrict__ ws,
+                          int32_t* __restrict__ n_active_per_ray) {
     const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (n >= n_rays) return;
@@ -82,6 +83,7 @@ composite_train_fw_kernel(const float* __restrict__ sigmas, const float* __restr
         rgb[3 * ray_idx] = R; rgb[3 * ray_idx + 1] = G; rgb[3 * ray_idx + 2] = B;
         depth[ray_idx] = D; opacity[ray_idx] = O;
         total_samples[ray_idx] = samples;
+        if (n_active_per_ray) n_active_per_ray[n] = min(N, samples + 1);   // samples that can carry gradient (row order)
     }
 }
 
@@ -95,7 +97,8 @@ composite_train_bw_kernel(const float* __restrict__ dL_dopacity, const float* __
                           const float* __restrict__ ts, const int64_t* __restrict__ rays_a,
                           const float* __restrict__ opacity, const float* __restrict__ depth,
                           const float* __restrict__ rgb, float T_threshold, int n_rays,
-                          float* __restrict__ dL_dsigmas, float* __restrict__ dL_drgbs) {
+                          float* __restrict__ dL_dsigmas, float* __restrict__ dL_drgbs,
+                          const int32_t* __restrict__ ray_offsets, int32_t* __restrict__ active_idx) {
     const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (n >= n_rays) return;
@@ -103,6 +106,7 @@ composite_train_bw_kernel(const float* __restrict__ dL_dopacity, const float* __
     const int64_t start = rays_a[3 * (size_t)n + 1];
     const int N = (int)rays_a[3 * (size_t)n + 2];
     if (N <= 0) return;
+    const int a_off = active_idx ? ray_offsets[n] : 0;
     const float R = rgb[3 * ray_idx], G = rgb[3 * ray_idx + 1], B = rgb[3 * ray_idx + 2];
     const float O = opacity[ray_idx], D = depth[ray_idx];
     const float gR = dL_drgb[3 * ray_idx], gG = dL_drgb[3 * ray_idx + 1], gB = dL_drgb[3 * ray_idx + 2];
@@ -136,6 +140,7 @@ composite_train_bw_kernel(const float* __restrict__ dL_dopacity, const float* __
                               gO * (1 - O) + gD * (tk * T - (D - d)) + T * gw - (P_total - P));
             }
             dL_dsigmas[s] = ds; dL_drgbs[3 * s] = dr; dL_drgbs[3 * s + 1] = dg; dL_drgbs[3 * s + 2] = db;
+            if (active_idx && c.live) active_idx[a_off + k] = (int32_t)s;   // live samples are the first min(N, total+1) of the ray
         }
         stopped = __ballot(valid && c.T_after <= T_threshold) != 0ull;
         T_carry = __shfl(c.T_after, 63, 64);
@@ -234,13 +239,13 @@ extern "C" {
 int ngp_composite_train_fw(const float* sigmas, const float* rgbs, const float* deltas, const float* ts,
                            const int64_t* rays_a, float T_threshold, int n_rays, int n_samples,
                            int64_t* total_samples, float* opacity, float* depth, float* rgb, float* ws,
-                           ngp_stream_t stream) {
+                           int32_t* n_active_per_ray, ngp_stream_t stream) {
     if (n_rays < 0 || n_samples < 0) return NGP_EINVAL;
     if (n_rays == 0) return 0;
     NGP_CHECK_PTR(rays_a); NGP_CHECK_PTR(total_samples); NGP_CHECK_PTR(opacity); NGP_CHECK_PTR(depth); NGP_CHECK_PTR(rgb);
     if (n_samples > 0) { NGP_CHECK_PTR(sigmas); NGP_CHECK_PTR(rgbs); NGP_CHECK_PTR(deltas); NGP_CHECK_PTR(ts); NGP_CHECK_PTR(ws); }
     hipLaunchKernelGGL(composite_train_fw_kernel, dim3(ngp_div_up((long long)n_rays * 64, 256)), dim3(256), 0, ngp_stream(stream),
-                       sigmas, rgbs, deltas, ts, rays_a, T_threshold, n_rays, total_samples, opacity, depth, rgb, ws);
+                       sigmas, rgbs, deltas, ts, rays_a, T_threshold, n_rays, total_samples, opacity, depth, rgb, ws, n_active_per_ray);
     return NGP_LAUNCH_RESULT();
 }
 
@@ -248,15 +253,17 @@ int ngp_composite_train_bw(const float* dL_dopacity, const float* dL_ddepth, con
                            const float* dL_dws, const float* sigmas, const float* rgbs, const float* ws,
                            const float* deltas, const float* ts, const int64_t* rays_a,
                            const float* opacity, const float* depth, const float* rgb, float T_threshold,
-                           int n_rays, int n_samples, float* dL_dsigmas, float* dL_drgbs, ngp_stream_t stream) {
+                           int n_rays, int n_samples, float* dL_dsigmas, float* dL_drgbs,
+                           const int32_t* ray_offsets, int32_t* active_idx, ngp_stream_t stream) {
     if (n_rays < 0 || n_samples < 0) return NGP_EINVAL;
     if (n_rays == 0 || n_samples == 0) return 0;
     NGP_CHECK_PTR(dL_dopacity); NGP_CHECK_PTR(dL_ddepth); NGP_CHECK_PTR(dL_drgb); NGP_CHECK_PTR(sigmas);
     NGP_CHECK_PTR(rgbs); NGP_CHECK_PTR(ws); NGP_CHECK_PTR(deltas); NGP_CHECK_PTR(ts); NGP_CHECK_PTR(rays_a);
     NGP_CHECK_PTR(opacity); NGP_CHECK_PTR(depth); NGP_CHECK_PTR(rgb); NGP_CHECK_PTR(dL_dsigmas); NGP_CHECK_PTR(dL_drgbs);
+    if ((ray_offsets == nullptr) != (active_idx == nullptr)) return NGP_EINVAL;
     hipLaunchKernelGGL(composite_train_bw_kernel, dim3(ngp_div_up((long long)n_rays * 64, 256)), dim3(256), 0, ngp_stream(stream),
                        dL_dopacity, dL_ddepth, dL_drgb, dL_dws, sigmas, rgbs, ws, deltas, ts, rays_a,
-                       opacity, depth, rgb, T_threshold, n_rays, dL_dsigmas, dL_drgbs);
+                       opacity, depth, rgb, T_threshold, n_rays, dL_dsigmas, dL_drgbs, ray_offsets, active_idx);
     return NGP_LAUNCH_RESULT();
 }
 

@@ -614,6 +614,14 @@ int ngp_active_samples(const int64_t* rays_a, const int64_t* total_samples, int 
     return NGP_LAUNCH_RESULT();
 }
 
+int ngp_active_scan(int32_t* n_active_per_ray, int n_rays, int32_t* n_active, ngp_stream_t stream) {
+    if (n_rays < 0) return NGP_EINVAL;
+    NGP_CHECK_PTR(n_active);
+    if (n_rays > 0) NGP_CHECK_PTR(n_active_per_ray);
+    hipLaunchKernelGGL(active_scan_kernel, dim3(1), dim3(1024), 0, ngp_stream(stream), n_active_per_ray, n_rays, n_active);
+    return NGP_LAUNCH_RESULT();
+}
+
 int ngp_feats_to_rowmajor(const ngp_half* feats, int n_levels, int n_samples, ngp_half* out, ngp_stream_t stream) {
     if (n_samples < 0 || n_levels < 1) return NGP_EINVAL;
     if (n_samples == 0) return 0;

@@ -142,40 +142,44 @@ cast_f16_f32_kernel(const h1* __restrict__ in, long long n, float scale, float* 
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (float)in[i] * scale;
 }
 
-__global__ void __launch_bounds__(256)
+template <bool SINGLE>
+__global__ void __launch_bounds__(SINGLE ? 1024 : 256)
 nerf_loss_kernel(const float* __restrict__ rgb, const float* __restrict__ opacity, const float* __restrict__ gt,
                  const float* __restrict__ bg, float lambda_o, float grad_scale, int n_rays,
                  float* __restrict__ loss, float* __restrict__ sq_err,
                  float* __restrict__ dL_drgb, float* __restrict__ dL_dopacity) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
     float l = 0.f, se = 0.f;
-    if (r < n_rays) {
+    // SINGLE: one workgroup walks all rays and WRITES the sums (no zero-fill, no atomics)
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += SINGLE ? (int)blockDim.x : n_rays) {
         const float o = opacity[r];
         const float inv_r = 1.0f / (float)n_rays, inv_3r = 1.0f / (3.0f * (float)n_rays);
-        float go = 0.f;
+        float go = 0.f, se_ray = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float b = bg ? bg[c] : 0.f;
             const float diff = rgb[3 * r + c] + b * (1.0f - o) - gt[3 * r + c];
-            se += diff * diff;
+            se_ray += diff * diff;
             const float g = 2.0f * diff * inv_3r;
             dL_drgb[3 * r + c] = g * grad_scale;
             go -= g * b;
         }
         const float oe = o + 1e-10f;
         const float lg = __logf(oe);
-        l = se * inv_3r + lambda_o * (-oe * lg) * inv_r;
+        l += se_ray * inv_3r + lambda_o * (-oe * lg) * inv_r;
+        se += se_ray;
         go += lambda_o * (-(lg + 1.0f)) * inv_r;
         dL_dopacity[r] = go * grad_scale;
     }
     l = ngp_wave_sum(l); se = ngp_wave_sum(se);
-    __shared__ float s_l[4], s_e[4];
-    const int w = threadIdx.x >> 6;
+    __shared__ float s_l[16], s_e[16];
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     if ((threadIdx.x & 63) == 0) { s_l[w] = l; s_e[w] = se; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(loss, s_l[0] + s_l[1] + s_l[2] + s_l[3]);
-        if (sq_err) atomicAdd(sq_err, s_e[0] + s_e[1] + s_e[2] + s_e[3]);
+        float tl = 0.f, te = 0.f;
+        for (int k = 0; k < nw; ++k) { tl += s_l[k]; te += s_e[k]; }
+        if (SINGLE) { *loss = tl; if (sq_err) *sq_err = te; }
+        else { atomicAdd(loss, tl); if (sq_err) atomicAdd(sq_err, te); }
     }
 }
 
@@ -281,8 +285,16 @@ int ngp_nerf_loss(const float* rgb, const float* opacity, const float* gt_rgb, c
     if (n_rays < 0) return NGP_EINVAL;
     if (n_rays == 0) return 0;
     NGP_CHECK_PTR(rgb); NGP_CHECK_PTR(opacity); NGP_CHECK_PTR(gt_rgb); NGP_CHECK_PTR(loss); NGP_CHECK_PTR(dL_drgb); NGP_CHECK_PTR(dL_dopacity);
-    hipLaunchKernelGGL(nerf_loss_kernel, dim3(ngp_div_up(n_rays, 256)), dim3(256), 0, ngp_stream(stream),
-                       rgb, opacity, gt_rgb, bg, lambda_opacity, grad_scale, n_rays, loss, sq_err, dL_drgb, dL_dopacity);
+    if (n_rays <= 16384)   // overwrite mode: the caller does not have to zero loss / sq_err
+        hipLaunchKernelGGL(nerf_loss_kernel<true>, dim3(1), dim3(1024), 0, ngp_stream(stream),
+                           rgb, opacity, gt_rgb, bg, lambda_opacity, grad_scale, n_rays, loss, sq_err, dL_drgb, dL_dopacity);
+    else {
+        hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), ngp_stream(stream));
+        if (e == hipSuccess && sq_err) e = hipMemsetAsync(sq_err, 0, sizeof(float), ngp_stream(stream));
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(nerf_loss_kernel<false>, dim3(ngp_div_up(n_rays, 256)), dim3(256), 0, ngp_stream(stream),
+                           rgb, opacity, gt_rgb, bg, lambda_opacity, grad_scale, n_rays, loss, sq_err, dL_drgb, dL_dopacity);
+    }
     return NGP_LAUNCH_RESULT();
 }
 

@@ -47,6 +47,7 @@ class Trainer:
         self.grad_hook = None    # called between backward and optimizer (multi-GPU gradient all-reduce)
         self.events = None       # list of (stage, event) when stage timing is on (bench.py roofline)
         self.march_ms = None
+        self._zeros = None
 
     # -- stage timing ----------------------------------------------------------------------------
     def _mark(self, name):
@@ -143,8 +144,12 @@ class Trainer:
             sigmas = torch.empty(S, **f32); rgbs = torch.empty(S, 3, **f32)
             total = torch.empty(n, dtype=torch.int64, device=dev)
             opacity = torch.empty(n, **f32); depth = torch.empty(n, **f32); rgb = torch.empty(n, 3, **f32); ws = torch.empty(S, **f32)
-            stats = torch.zeros(2, **f32)                  # loss, sum of squared error
-            dL_drgb = torch.empty(n, 3, **f32); dL_dopacity = torch.empty(n, **f32); dL_ddepth = torch.zeros(n, **f32)
+            stats = torch.empty(2, **f32)                  # loss, sum of squared error (written by ngp_nerf_loss)
+            dL_drgb = torch.empty(n, 3, **f32); dL_dopacity = torch.empty(n, **f32)
+            if self._zeros is None or self._zeros.shape[0] != n:
+                self._zeros = torch.zeros(n, **f32)        # dL/ddepth: the loss has no depth term
+            dL_ddepth = self._zeros
+            ray_offs = torch.empty(n, dtype=torch.int32, device=dev); n_active = torch.empty(1, dtype=torch.int32, device=dev)
             dL_dsigmas = torch.empty(S, **f32); dL_drgbs = torch.empty(S, 3, **f32)
             if S > 0:
                 call("ngp_hashgrid_fwd", ptr(xyzs), ptr(m.xyz_min), ptr(m.xyz_max), ptr(eh[enc.n_mlp:]), C.byref(enc.meta), S, ptr(feats), stream())
@@ -152,18 +157,18 @@ class Trainer:
                 call("ngp_field_fwd", ptr(feats), ptr(dirs), ptr(eh), ptr(rh), S, ptr(sigmas), ptr(rgbs), ptr(h), stream())
                 self._mark("mlp_fwd")
             call("ngp_composite_train_fw", ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(ts), ptr(rays_a), self.T_threshold, n, S,
-                 ptr(total), ptr(opacity), ptr(depth), ptr(rgb), ptr(ws), stream())
+                 ptr(total), ptr(opacity), ptr(depth), ptr(rgb), ptr(ws), ptr(ray_offs), stream())
+            call("ngp_active_scan", ptr(ray_offs), n, ptr(n_active), stream())
             call("ngp_nerf_loss", ptr(rgb), ptr(opacity), ptr(rgb_gt), ptr(self.bg), self.lambda_opacity, self.grad_scale, n,
                  ptr(stats), ptr(stats[1:]), ptr(dL_drgb), ptr(dL_dopacity), stream())
             self._mark("composite_fw+loss")
             if S > 0:
+                # backward only over the samples up to each ray's early stop (the rest have zero gradient):
+                # composite_fw counted them per ray, the scan above placed them, composite_bw lists them
+                active = torch.empty(S, dtype=torch.int32, device=dev)
                 call("ngp_composite_train_bw", ptr(dL_dopacity), ptr(dL_ddepth), ptr(dL_drgb), None, ptr(sigmas), ptr(rgbs), ptr(ws),
                      ptr(deltas), ptr(ts), ptr(rays_a), ptr(opacity), ptr(depth), ptr(rgb), self.T_threshold, n, S,
-                     ptr(dL_dsigmas), ptr(dL_drgbs), stream())
-                # backward only over the samples up to each ray's early stop (the rest have zero gradient)
-                active = torch.empty(S, dtype=torch.int32, device=dev); n_active = torch.empty(1, dtype=torch.int32, device=dev)
-                ray_offs = torch.empty(n, dtype=torch.int32, device=dev)
-                call("ngp_active_samples", ptr(rays_a), ptr(total), n, ptr(ray_offs), ptr(active), ptr(n_active), stream())
+                     ptr(dL_dsigmas), ptr(dL_drgbs), ptr(ray_offs), ptr(active), stream())
                 self._mark("composite_bw")
                 n_part = call("ngp_field_bwd_partials", S)
                 partials = torch.empty(n_part * (enc.n_mlp + net.params.numel()), **f32)

@@ -40,7 +40,7 @@ def test_argument_validation_needs_no_gpu():
     from ngp_pl_amd import _lib
     # empty inputs are a no-op (the reference handles N = 0 by launching zero blocks)
     assert _lib.call("ngp_morton3D", None, 0, None, None) == 0
-    assert _lib.call("ngp_composite_train_fw", None, None, None, None, None, 1e-4, 0, 0, None, None, None, None, None, None) == 0
+    assert _lib.call("ngp_composite_train_fw", None, None, None, None, None, 1e-4, 0, 0, None, None, None, None, None, None, None) == 0
     with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
         _lib.call("ngp_morton3D", None, 5, None, None)                      # null pointers with n > 0
     with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
