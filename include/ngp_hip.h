@@ -17,6 +17,7 @@
 #ifndef NGP_HIP_H
 #define NGP_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -211,6 +212,11 @@ int ngp_grid_meta_init(ngp_grid_meta* meta, int n_levels, int n_features, int lo
 int ngp_hashgrid_fwd(const float* x, const float* xyz_min, const float* xyz_max,
                      const ngp_half* table, const ngp_grid_meta* meta, int n_samples,
                      ngp_half* feats, ngp_stream_t stream);
+/* Same with a DEVICE-side sample count (sync-free callers): the launch covers n_samples_max,
+ * n_dev[0] (i32, <= n_samples_max) is the real count and the level stride of feats. */
+int ngp_hashgrid_fwd_n(const float* x, const float* xyz_min, const float* xyz_max,
+                       const ngp_half* table, const ngp_grid_meta* meta, int n_samples_max,
+                       const int32_t* n_dev, ngp_half* feats, ngp_stream_t stream);
 /* Encode backward w.r.t. the table: scatter-add of w*dL/dfeat into grad_table (total,2) f16
  * (packed f16 atomics, as tiny-cuda-nn) or f32 when grad_is_f32.  Accumulates (caller zeroes). */
 int ngp_hashgrid_bwd(const float* x, const float* xyz_min, const float* xyz_max,
@@ -265,6 +271,11 @@ int ngp_rgb_fwd(const ngp_half* h, const float* dirs, const ngp_half* rgb_w, int
 int ngp_field_fwd(const ngp_half* feats, const float* dirs,
                   const ngp_half* density_w, const ngp_half* rgb_w, int n_samples,
                   float* sigmas, float* rgbs, ngp_half* h_out, ngp_stream_t stream);
+/* same with a device-side sample count (see ngp_hashgrid_fwd_n); n_dev may be NULL */
+int ngp_field_fwd_n(const ngp_half* feats, const float* dirs,
+                    const ngp_half* density_w, const ngp_half* rgb_w, int n_samples_max,
+                    const int32_t* n_dev, float* sigmas, float* rgbs, ngp_half* h_out,
+                    ngp_stream_t stream);
 
 /* Backward of the two halves.  Each recomputes its forward, runs dgrad in registers and emits
  * per-workgroup partial weight gradients (n_partials, n_params) f32, n_partials =
@@ -368,6 +379,40 @@ int ngp_sample_rays(const float* poses, const float* directions, const float* im
                     int n_images, int n_pixels, int n, uint64_t seed,
                     float* rays_o, float* rays_d, float* rgb, float* noise,
                     int32_t* img_idx, int32_t* pix_idx, ngp_stream_t stream);
+
+/* ---- test-time frame loop -------------------------------------------------------------- */
+
+/* The whole test-time loop `__render_rays_test` (rendering.py:46-118) for one batch of rays,
+ * device-driven: the alive-ray count, N_samples (rendering.py:69-70) and the batch sizes live in
+ * device memory, every kernel of an iteration is launched for an upper bound that the host learns
+ * two iterations late, so the GPU never waits for the host.  Field = hash grid + the two MLPs as
+ * in ngp_hashgrid_fwd / ngp_field_fwd.
+ *   hits_t (R,2) f32: (near, far) per ray after the NEAR_DISTANCE clamp (rendering.py:27-29);
+ *     read only.  min_samples = exp_step_factor == 0 ? 1 : 4 (rendering.py:60).
+ *   chunk_scale >= 1 multiplies the reference's N_samples = N_rays // N_alive (fewer, larger
+ *     iterations); probe_cap > 0 bounds the grid probes of one ray in one iteration and retires a
+ *     ray as soon as it reaches its far hit.  chunk_scale == 1 && probe_cap == 0 reproduces the
+ *     reference's chunking exactly (bit-identical to the loop over ngp_raymarching_test /
+ *     ngp_composite_test_fw); other settings emit the SAME samples per ray and differ only in
+ *     where `T = 1 - opacity` is re-read between chunks (volumerendering.cu:229), i.e. by float
+ *     rounding of the composite.
+ *   bg: HOST pointer to 3 floats, rgb += bg * (1 - opacity) at the end (rendering.py:112-116);
+ *     NULL = no blend.
+ *   workspace: device scratch of ngp_render_test_workspace_bytes(n_rays, chunk_scale,
+ *     exp_step_factor) bytes.
+ *   out: opacity, depth (R) f32, rgb (R,3) f32, total_samples (1) i64 on device (sum of
+ *     N_eff_samples, rendering.py:88); n_iterations (HOST i32, may be NULL).
+ * Returns after all work is enqueued on `stream` (it waits on its own lagged events only). */
+size_t ngp_render_test_workspace_bytes(int n_rays, int chunk_scale, float exp_step_factor);
+int ngp_render_test_frame(const float* rays_o, const float* rays_d, const float* hits_t,
+                          const uint8_t* density_bitfield, int cascades, float scale,
+                          float exp_step_factor, int grid_size, int max_samples, float T_threshold,
+                          const float* xyz_min, const float* xyz_max, const ngp_half* table,
+                          const ngp_grid_meta* meta, const ngp_half* density_w, const ngp_half* rgb_w,
+                          int n_rays, int chunk_scale, int probe_cap, const float* bg,
+                          void* workspace, size_t workspace_bytes,
+                          float* opacity, float* depth, float* rgb, int64_t* total_samples,
+                          int32_t* n_iterations, ngp_stream_t stream);
 
 #ifdef __cplusplus
 }

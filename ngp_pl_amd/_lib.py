@@ -74,6 +74,10 @@ _PROTOS = {
     "ngp_compact_alive": [P, P, I, P, P, P, P],
     "ngp_sample_rays": [P, P, P, I, I, I, C.c_uint64, P, P, P, P, P, P, P],
     "ngp_abi_version": [],
+    "ngp_hashgrid_fwd_n": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P],
+    "ngp_field_fwd_n": [P, P, P, P, I, P, P, P, P, P],
+    "ngp_render_test_frame": [P, P, P, P, I, F, F, I, I, F, P, P, P, C.POINTER(GridMeta), P, P, I, I, I,
+                              C.POINTER(C.c_float), P, C.c_size_t, P, P, P, P, C.POINTER(C.c_int32), P],
 }
 _COUNT_QUERIES = ("ngp_field_bwd_partials", "ngp_mlp_bwd_partials", "ngp_abi_version")
 
@@ -94,12 +98,14 @@ def lib():
             f.restype = I
         h.ngp_build_arch.argtypes = []
         h.ngp_build_arch.restype = C.c_char_p
+        h.ngp_render_test_workspace_bytes.argtypes = [I, I, F]
+        h.ngp_render_test_workspace_bytes.restype = C.c_size_t
         _lib = h
     return _lib
 
 
 def exported_symbols():
-    return list(_PROTOS) + ["ngp_build_arch"]
+    return list(_PROTOS) + ["ngp_build_arch", "ngp_render_test_workspace_bytes"]
 
 
 class NgpError(RuntimeError):

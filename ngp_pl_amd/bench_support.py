@@ -76,7 +76,7 @@ class GpuDataset:
 
 
 @torch.no_grad()
-def render_fps(model, data, n_frames=5):
+def render_fps(model, data, n_frames=5, **render_kwargs):
     """Frames/s of render(test_time=True) on full res x res images incl. ray generation, as the
     reference measures it (test.ipynb cell 2, show_gui.py:73-93)."""
     times = []
@@ -85,13 +85,16 @@ def render_fps(model, data, n_frames=5):
         torch.cuda.synchronize()
         t = time.perf_counter()
         ro, rd = syn.get_rays(data.directions, data.poses[i % data.poses.shape[0]])
-        out = render(model, ro, rd, test_time=True)
+        out = render(model, ro, rd, test_time=True, **render_kwargs)
         torch.cuda.synchronize()
         if i > 0:                      # first frame warms the allocator
             times.append(time.perf_counter() - t)
             n_total += float(out["total_samples"])
     mean = sum(times) / len(times)
-    return {"fps": 1.0 / mean, "ms_per_frame": mean * 1e3, "samples_per_ray": n_total / len(times) / (data.W * data.H)}
+    res = {"fps": 1.0 / mean, "ms_per_frame": mean * 1e3, "samples_per_ray": n_total / len(times) / (data.W * data.H)}
+    if "n_iterations" in out:
+        res["iterations"] = out["n_iterations"]
+    return res
 
 
 def all_reduce_native(model, dist, world):

@@ -125,9 +125,15 @@ template <int SPT>
 __global__ void __launch_bounds__(256)
 hashgrid_fwd_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const float* __restrict__ xyz_max,
                     const half2_t* __restrict__ table, GridMeta meta, int n_samples, int n_chunks,
-                    half2_t* __restrict__ feats) {
+                    const int32_t* __restrict__ n_dev, half2_t* __restrict__ feats) {
     int level, chunk;
     if (!map_block(meta.n_levels, n_chunks, level, chunk)) return;
+    // device-sized batches (sync-free callers): the launch covers an upper bound, *n_dev is the
+    // real sample count and also the level stride of `feats`
+    if (n_dev != nullptr) {
+        n_samples = min(*n_dev, n_samples);
+        if (chunk * SPT * 256 >= n_samples) return;
+    }
     const uint32_t res = meta.resolution[level];
     const uint32_t size = meta.offset[level + 1] - meta.offset[level];
     const half2_t* __restrict__ tab = table + meta.offset[level];
@@ -518,6 +524,12 @@ int ngp_grid_meta_init(ngp_grid_meta* meta, int n_levels, int n_features, int lo
 
 int ngp_hashgrid_fwd(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* table,
                      const ngp_grid_meta* meta, int n_samples, ngp_half* feats, ngp_stream_t stream) {
+    return ngp_hashgrid_fwd_n(x, xyz_min, xyz_max, table, meta, n_samples, nullptr, feats, stream);
+}
+
+int ngp_hashgrid_fwd_n(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* table,
+                       const ngp_grid_meta* meta, int n_samples, const int32_t* n_dev, ngp_half* feats,
+                       ngp_stream_t stream) {
     if (n_samples < 0 || !meta || meta->n_features != 2) return NGP_EINVAL;
     if (n_samples == 0) return 0;
     NGP_CHECK_PTR(x); NGP_CHECK_PTR(xyz_min); NGP_CHECK_PTR(xyz_max); NGP_CHECK_PTR(table); NGP_CHECK_PTR(feats);
@@ -525,7 +537,7 @@ int ngp_hashgrid_fwd(const float* x, const float* xyz_min, const float* xyz_max,
     // the kernel is bound by L2 gather transactions, not by loads in flight per lane.
     const int n_chunks = ngp_div_up(n_samples, 256);
     hipLaunchKernelGGL(hashgrid_fwd_kernel<1>, dim3(n_blocks_for(meta->n_levels, n_chunks)), dim3(256), 0, ngp_stream(stream),
-                       x, xyz_min, xyz_max, (const half2_t*)table, to_dev_meta(meta), n_samples, n_chunks, (half2_t*)feats);
+                       x, xyz_min, xyz_max, (const half2_t*)table, to_dev_meta(meta), n_samples, n_chunks, n_dev, (half2_t*)feats);
     return NGP_LAUNCH_RESULT();
 }
 

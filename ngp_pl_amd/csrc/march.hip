@@ -438,6 +438,303 @@ MarchParams make_march_params(const uint8_t* bitfield, int cascades, int grid_si
     return p;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Device-driven test-time frame loop (rendering.py:46-118).  Per iteration: march -> hash grid
+// -> MLPs -> composite+compaction; the alive count, N_samples and the batch size are device
+// state (RenderPlan), so no kernel waits for a host read.
+// ------------------------------------------------------------------------------------------
+struct RenderPlan {            // one per loop iteration
+    int32_t n_alive_raw;       // survivors of the previous iteration (atomically counted)
+    int32_t samples_done;      // `samples` (rendering.py:71) before this iteration
+    int32_t n_alive;           // rays marched this iteration (0 once samples_done >= max_samples)
+    int32_t n_step;            // N_samples of this iteration (rendering.py:69)
+    int32_t m;                 // n_alive * n_step sample slots
+    int32_t blocks_done;       // composite workgroups that have added their survivors
+    int32_t pad[2];
+};
+constexpr int RENDER_RETIRE = 1 << 16;      // n_eff flag: drop the ray after compositing its samples
+constexpr int RENDER_MAX_ITERS = 2048;
+constexpr int RENDER_RING = 4;
+
+__global__ void __launch_bounds__(256)
+render_begin_kernel(const float* __restrict__ hits_in, int n_rays, float* __restrict__ hits,
+                    int32_t* __restrict__ alive, int32_t* __restrict__ emitted, float* __restrict__ opacity, float* __restrict__ depth,
+                    float* __restrict__ rgb, RenderPlan* __restrict__ plan, unsigned long long* __restrict__ total) {
+    const int stride = gridDim.x * blockDim.x;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = tid; i < n_rays; i += stride) {
+        hits[2 * i] = hits_in[2 * i]; hits[2 * i + 1] = hits_in[2 * i + 1];
+        alive[i] = i; emitted[i] = 0;
+        opacity[i] = 0.f; depth[i] = 0.f;
+        rgb[3 * i] = 0.f; rgb[3 * i + 1] = 0.f; rgb[3 * i + 2] = 0.f;
+    }
+    int32_t* pl = reinterpret_cast<int32_t*>(plan);
+    for (int i = tid; i < (RENDER_MAX_ITERS + 1) * (int)(sizeof(RenderPlan) / 4); i += stride) pl[i] = (i == 0) ? n_rays : 0;
+    if (tid == 0) *total = 0ull;
+}
+
+// One thread per alive ray, up to N_samples samples each (raymarching.cu:353-403 arithmetic,
+// including the calc_dt(..., cascades) quirk via p).  The marching loop only records t in LDS
+// (DS traffic does not sit in the vmcnt queue of the dependent bitfield loads); afterwards the
+// wave reserves a PACKED range for its samples (one atomic per wave) and every lane expands its
+// own samples, so the field is evaluated on real samples only — the reference's dense
+// (N_alive, N_samples) buffers carry zero padding for rays that leave early.
+// probe_cap == 0: the reference's chunking (a ray marches until it has N samples or leaves, the
+// resume point moves only past emitted samples, a ray without samples is retired).
+// probe_cap  > 0: at most that many grid probes per ray per iteration (bounds the serial tail of
+// rays crossing empty space), the resume point is the next untested lattice point, and a ray is
+// retired the moment it reaches its far hit.  Same samples per ray either way.
+// lanes of ONE wave exchange data through LDS: DS operations of a wave execute in program order,
+// only the compiler has to be kept from reordering them
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool SIMPLE>
+__global__ void __launch_bounds__(64)
+render_march_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                    float* __restrict__ hits, const int32_t* __restrict__ alive, int32_t* __restrict__ emitted,
+                    MarchParams p, RenderPlan* __restrict__ plan, int n_rays, int chunk_scale, int min_samples,
+                    int max_samples_total, int probe_cap,
+                    float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas,
+                    float* __restrict__ ts, int32_t* __restrict__ n_eff, int32_t* __restrict__ offsets) {
+    __shared__ float s_t[64 * 64];          // [sample][lane]
+    __shared__ float s_ray[6 * 64];
+    __shared__ int s_incl[64];
+    // rendering.py:65 `while samples < max_samples`: `samples` grows by N per iteration.  With a probe
+    // cap a ray can advance by fewer than N samples per iteration, so that mode budgets the samples
+    // per ray instead (emitted[r]); both bound a ray to max_samples (+ at most one chunk).
+    const int done = (probe_cap <= 0) ? plan->samples_done : 0;
+    const int n_alive = (done < max_samples_total) ? plan->n_alive_raw : 0;
+    int N = 0;
+    if (n_alive > 0) N = max(min((int)(((long long)chunk_scale * n_rays) / n_alive), 64), min_samples);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        plan->n_alive = n_alive; plan->n_step = N;
+        plan[1].samples_done = done + N;
+    }
+    if (blockIdx.x * 64 >= n_alive) return;
+    const int lane = threadIdx.x;
+    const int n = blockIdx.x * 64 + lane;
+    const bool active = n < n_alive;
+    int s = 0, flags = 0;
+    Ray ray = {};
+    size_t r = 0;
+    if (active) {
+        r = (size_t)alive[n];
+        ray = load_ray(rays_o, rays_d, r);
+        float t = hits[2 * r];
+        const float t2 = hits[2 * r + 1];
+        if (probe_cap <= 0) {
+            float t_resume = t;
+            while (t < t2 && s < N) {
+                float x, y, z, dt, t_next;
+                if (march_probe<SIMPLE>(ray, p, t, x, y, z, dt, t_next)) {
+                    s_t[s * 64 + lane] = t;
+                    t += dt; ++s;
+                    t_resume = t;
+                } else {
+                    t = t_next;
+                }
+            }
+            if (s > 0) hits[2 * r] = t_resume;
+            else flags = RENDER_RETIRE;                    // N_eff == 0 (volumerendering.cu:222)
+        } else {
+            int probes = 0;
+            for (;;) {
+                if (!(t < t2)) { flags = RENDER_RETIRE; break; }
+                if (s >= N || probes >= probe_cap) break;
+                ++probes;
+                float x, y, z, dt, t_next;
+                if (march_probe<SIMPLE>(ray, p, t, x, y, z, dt, t_next)) {
+                    s_t[s * 64 + lane] = t;
+                    t += dt; ++s;
+                } else {
+                    t = t_next;
+                }
+            }
+            hits[2 * r] = t;
+            const int e = emitted[r] + s;
+            emitted[r] = e;
+            if (e >= max_samples_total) flags = RENDER_RETIRE;
+        }
+    }
+    // packed placement: exclusive wave scan of s, one atomic per wave on the iteration's counter
+    int incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    const int total = __shfl(incl, 63, 64);
+    int base = 0;
+    if (lane == 63 && total > 0) base = atomicAdd(&plan->m, total);
+    base = __shfl(base, 63, 64);
+    if (active) { offsets[n] = base + incl - s; n_eff[n] = s | flags; }
+    // cooperative expansion: packed position j of the wave's range -> (ray, k) by a search in the
+    // inclusive counts; consecutive lanes write consecutive samples (coalesced streams) instead
+    // of every lane scattering its own 8 words per sample
+    s_incl[lane] = incl;
+    s_ray[lane] = ray.ox; s_ray[64 + lane] = ray.oy; s_ray[128 + lane] = ray.oz;
+    s_ray[192 + lane] = ray.dx; s_ray[256 + lane] = ray.dy; s_ray[320 + lane] = ray.dz;
+    wave_lds_fence();
+    for (int j = lane; j < total; j += 64) {
+        int lo = 0;                                   // first ray with incl > j
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1)
+            if (s_incl[lo + step - 1] <= j) lo += step;
+        const int k = j - (lo ? s_incl[lo - 1] : 0);
+        const float t = s_t[k * 64 + lo];
+        const float ox = s_ray[lo], oy = s_ray[64 + lo], oz = s_ray[128 + lo];
+        const float dx = s_ray[192 + lo], dy = s_ray[256 + lo], dz = s_ray[320 + lo];
+        const size_t o = (size_t)base + j;
+        xyzs[3 * o] = fmaf(t, dx, ox); xyzs[3 * o + 1] = fmaf(t, dy, oy); xyzs[3 * o + 2] = fmaf(t, dz, oz);
+        dirs[3 * o] = dx; dirs[3 * o + 1] = dy; dirs[3 * o + 2] = dz;
+        ts[o] = t; deltas[o] = SIMPLE ? p.dt_lo : calc_dt(t, p);
+    }
+}
+
+// composite_test_fw (volumerendering.cu:219-248) for one iteration, fused with the alive-ray
+// compaction (rendering.py:105), the N_eff sum (rendering.py:88) and the hand-over of the
+// survivor count to the next iteration's plan and to the host (pinned, lag-polled).
+constexpr int RC_THREADS = 1024, RC_WAVES = RC_THREADS / 64, RC_BATCH = 8;
+__global__ void __launch_bounds__(RC_THREADS)
+render_composite_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                        const float* __restrict__ deltas, const float* __restrict__ ts,
+                        const int32_t* __restrict__ alive_in, int32_t* __restrict__ alive_out,
+                        const int32_t* __restrict__ n_eff, const int32_t* __restrict__ offsets, float T_threshold,
+                        RenderPlan* __restrict__ plan, float* __restrict__ opacity,
+                        float* __restrict__ depth, float* __restrict__ rgb,
+                        unsigned long long* __restrict__ total, int32_t* __restrict__ host_count) {
+    __shared__ int s_keep[RC_WAVES], s_cnt[RC_WAVES], s_base;
+    const int n_alive = plan->n_alive;
+    if (n_alive == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { *host_count = 0; __threadfence_system(); }
+        return;
+    }
+    if (blockIdx.x * RC_THREADS >= n_alive) return;
+    const int n = blockIdx.x * RC_THREADS + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool keep = false;
+    int cnt = 0, r = 0;
+    if (n < n_alive) {
+        const int e = n_eff[n];
+        cnt = e & 0xffff;
+        bool retire = (e & RENDER_RETIRE) != 0;
+        r = alive_in[n];
+        if (cnt > 0) {
+            const size_t base = (size_t)offsets[n];
+            float O = opacity[r], D = depth[r], R = rgb[3 * (size_t)r], G = rgb[3 * (size_t)r + 1], B = rgb[3 * (size_t)r + 2];
+            float T = 1 - O;
+            // the per-sample arithmetic is sequential (volumerendering.cu:229-246); the loads are not:
+            // fetch RC_BATCH samples ahead so the chain does not pay one memory latency per sample
+            bool stop = false;
+            for (int s0 = 0; s0 < cnt && !stop; s0 += RC_BATCH) {
+                float sg[RC_BATCH], dl[RC_BATCH], tt[RC_BATCH], cr[RC_BATCH], cg[RC_BATCH], cb[RC_BATCH];
+#pragma unroll
+                for (int k = 0; k < RC_BATCH; ++k) {
+                    const size_t o = base + min(s0 + k, cnt - 1);
+                    sg[k] = sigmas[o]; dl[k] = deltas[o]; tt[k] = ts[o];
+                    cr[k] = rgbs[3 * o]; cg[k] = rgbs[3 * o + 1]; cb[k] = rgbs[3 * o + 2];
+                }
+#pragma unroll
+                for (int k = 0; k < RC_BATCH; ++k) {
+                    if (s0 + k < cnt && !stop) {
+                        const float a = 1.0f - __expf(-sg[k] * dl[k]);
+                        const float w = a * T;
+                        R += w * cr[k]; G += w * cg[k]; B += w * cb[k];
+                        D += w * tt[k];
+                        O += w;
+                        T *= 1.0f - a;
+                        if (T <= T_threshold) stop = true;
+                    }
+                }
+            }
+            retire = retire || stop;
+            opacity[r] = O; depth[r] = D; rgb[3 * (size_t)r] = R; rgb[3 * (size_t)r + 1] = G; rgb[3 * (size_t)r + 2] = B;
+        }
+        keep = !retire;
+    }
+    const unsigned long long m = __ballot(keep);
+    int c = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) { s_keep[wave] = __popcll(m); s_cnt[wave] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int k = 0, q = 0;
+        for (int w = 0; w < RC_WAVES; ++w) { k += s_keep[w]; q += s_cnt[w]; }
+        s_base = k ? atomicAdd(&plan[1].n_alive_raw, k) : 0;
+        if (q) atomicAdd(total, (unsigned long long)q);
+    }
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; ++w) off += s_keep[w];
+    if (keep) alive_out[off + __popcll(m & ((1ull << lane) - 1ull))] = r;
+    // last workgroup publishes the survivor count to the host
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int ticket = atomicAdd(&plan->blocks_done, 1);
+        if (ticket == (n_alive + RC_THREADS - 1) / RC_THREADS - 1) {
+            *host_count = atomicAdd(&plan[1].n_alive_raw, 0);
+            __threadfence_system();
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+render_finish_kernel(const float* __restrict__ opacity, float* __restrict__ rgb, int n_rays,
+                     float bg_r, float bg_g, float bg_b, int blend,
+                     const unsigned long long* __restrict__ total, int64_t* __restrict__ total_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && total_out != nullptr) *total_out = (int64_t)*total;
+    if (i >= n_rays || !blend) return;
+    const float rest = 1 - opacity[i];
+    rgb[3 * (size_t)i] = rgb[3 * (size_t)i] + bg_r * rest;
+    rgb[3 * (size_t)i + 1] = rgb[3 * (size_t)i + 1] + bg_g * rest;
+    rgb[3 * (size_t)i + 2] = rgb[3 * (size_t)i + 2] + bg_b * rest;
+}
+
+struct RenderLayout {
+    size_t hits, alive0, alive1, n_eff, offsets, emitted, plan, total, xyzs, dirs, deltas, ts, feats, h, sigmas, rgbs, bytes;
+    long long m_cap;
+};
+RenderLayout render_layout(int n_rays, int chunk_scale, float esf) {
+    RenderLayout L;
+    const int min_samples = (esf == 0.0f) ? 1 : 4;
+    const long long R = n_rays;
+    L.m_cap = R * (chunk_scale > min_samples ? chunk_scale : min_samples);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    L.hits = take(R * 8); L.alive0 = take(R * 4); L.alive1 = take(R * 4); L.n_eff = take(R * 4); L.offsets = take(R * 4); L.emitted = take(R * 4);
+    L.plan = take((RENDER_MAX_ITERS + 1) * sizeof(RenderPlan)); L.total = take(8);
+    L.xyzs = take(L.m_cap * 12); L.dirs = take(L.m_cap * 12); L.deltas = take(L.m_cap * 4); L.ts = take(L.m_cap * 4);
+    L.feats = take(L.m_cap * 64); L.h = take(L.m_cap * 32); L.sigmas = take(L.m_cap * 4); L.rgbs = take(L.m_cap * 12);
+    L.bytes = off;
+    return L;
+}
+
+// pinned survivor counts + events of the lag-polled frame loop, one set per host thread
+struct RenderHost {
+    int32_t* counts = nullptr;
+    hipEvent_t ev[RENDER_RING] = {};
+    bool ok = false;
+    int init() {
+        if (ok) return 0;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&counts), RENDER_RING * sizeof(int32_t), hipHostMallocDefault);
+        if (e != hipSuccess) return (int)e;
+        for (int i = 0; i < RENDER_RING; ++i) {
+            e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+            if (e != hipSuccess) return (int)e;
+        }
+        ok = true;
+        return 0;
+    }
+};
+thread_local RenderHost g_render_host;
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -613,6 +910,89 @@ int ngp_compact_alive(const int64_t* alive_in, const int32_t* n_eff, int n, int6
     NGP_CHECK_PTR(alive_in); NGP_CHECK_PTR(alive_out); NGP_CHECK_PTR(count);
     hipLaunchKernelGGL(compact_alive_kernel, dim3(ngp_div_up(n, 256)), dim3(256), 0, ngp_stream(stream),
                        alive_in, n_eff, n, alive_out, count, total_samples);
+    return NGP_LAUNCH_RESULT();
+}
+
+
+size_t ngp_render_test_workspace_bytes(int n_rays, int chunk_scale, float exp_step_factor) {
+    if (n_rays <= 0 || chunk_scale < 1) return 0;
+    return render_layout(n_rays, chunk_scale, exp_step_factor).bytes;
+}
+
+int ngp_render_test_frame(const float* rays_o, const float* rays_d, const float* hits_t,
+                          const uint8_t* density_bitfield, int cascades, float scale,
+                          float exp_step_factor, int grid_size, int max_samples, float T_threshold,
+                          const float* xyz_min, const float* xyz_max, const ngp_half* table,
+                          const ngp_grid_meta* meta, const ngp_half* density_w, const ngp_half* rgb_w,
+                          int n_rays, int chunk_scale, int probe_cap, const float* bg,
+                          void* workspace, size_t workspace_bytes,
+                          float* opacity, float* depth, float* rgb, int64_t* total_samples,
+                          int32_t* n_iterations, ngp_stream_t stream) {
+    if (n_iterations) *n_iterations = 0;
+    if (n_rays < 0 || chunk_scale < 1 || chunk_scale > 64 || probe_cap < 0 || max_samples <= 0 || !meta) return NGP_EINVAL;
+    if (n_rays == 0) return 0;
+    NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d); NGP_CHECK_PTR(hits_t); NGP_CHECK_PTR(density_bitfield);
+    NGP_CHECK_PTR(xyz_min); NGP_CHECK_PTR(xyz_max); NGP_CHECK_PTR(table); NGP_CHECK_PTR(density_w); NGP_CHECK_PTR(rgb_w);
+    NGP_CHECK_PTR(workspace); NGP_CHECK_PTR(opacity); NGP_CHECK_PTR(depth); NGP_CHECK_PTR(rgb);
+    const RenderLayout L = render_layout(n_rays, chunk_scale, exp_step_factor);
+    if (workspace_bytes < L.bytes) return NGP_EINVAL;
+    RenderHost& H = g_render_host;
+    int rc = H.init();
+    if (rc) return rc;
+    char* ws = static_cast<char*>(workspace);
+    float* hits = reinterpret_cast<float*>(ws + L.hits);
+    int32_t* alive[2] = {reinterpret_cast<int32_t*>(ws + L.alive0), reinterpret_cast<int32_t*>(ws + L.alive1)};
+    int32_t* n_eff = reinterpret_cast<int32_t*>(ws + L.n_eff);
+    int32_t* emitted = reinterpret_cast<int32_t*>(ws + L.emitted);
+    int32_t* offsets = reinterpret_cast<int32_t*>(ws + L.offsets);
+    RenderPlan* plan = reinterpret_cast<RenderPlan*>(ws + L.plan);
+    unsigned long long* total = reinterpret_cast<unsigned long long*>(ws + L.total);
+    float* xyzs = reinterpret_cast<float*>(ws + L.xyzs); float* dirs = reinterpret_cast<float*>(ws + L.dirs);
+    float* deltas = reinterpret_cast<float*>(ws + L.deltas); float* ts = reinterpret_cast<float*>(ws + L.ts);
+    ngp_half* feats = reinterpret_cast<ngp_half*>(ws + L.feats); ngp_half* h = reinterpret_cast<ngp_half*>(ws + L.h);
+    float* sigmas = reinterpret_cast<float*>(ws + L.sigmas); float* rgbs = reinterpret_cast<float*>(ws + L.rgbs);
+    hipStream_t st = ngp_stream(stream);
+    const int min_samples = (exp_step_factor == 0.0f) ? 1 : 4;           // rendering.py:60
+    // the reference passes `cascades` where calc_dt expects `scale` (raymarching.cu:370,399)
+    const MarchParams p = make_march_params(density_bitfield, cascades, grid_size, scale, (float)cascades, exp_step_factor, max_samples);
+
+    hipLaunchKernelGGL(render_begin_kernel, dim3(1024), dim3(256), 0, st, hits_t, n_rays, hits, alive[0], emitted, opacity, depth, rgb, plan, total);
+    constexpr int LAG = 2;
+    long long bound = n_rays;
+    int it = 0;
+    for (; it < RENDER_MAX_ITERS; ++it) {
+        if (it >= LAG) {
+            const int j = (it - LAG) % RENDER_RING;
+            hipError_t e = hipEventSynchronize(H.ev[j]);
+            if (e != hipSuccess) return (int)e;
+            bound = H.counts[j];               // survivors after iteration it-LAG >= alive rays now
+            if (bound <= 0) break;
+        }
+        RenderPlan* pl = plan + it;
+        const dim3 mgrid(ngp_div_up(bound, 64));
+        if (p.simple)
+            hipLaunchKernelGGL(render_march_kernel<true>, mgrid, dim3(64), 0, st, rays_o, rays_d, hits, alive[it & 1], emitted, p, pl, n_rays,
+                               chunk_scale, min_samples, max_samples, probe_cap, xyzs, dirs, deltas, ts, n_eff, offsets);
+        else
+            hipLaunchKernelGGL(render_march_kernel<false>, mgrid, dim3(64), 0, st, rays_o, rays_d, hits, alive[it & 1], emitted, p, pl, n_rays,
+                               chunk_scale, min_samples, max_samples, probe_cap, xyzs, dirs, deltas, ts, n_eff, offsets);
+        long long m_bound = (long long)chunk_scale * n_rays;
+        if (64 * bound < m_bound) m_bound = 64 * bound;
+        if ((long long)min_samples * bound > m_bound) m_bound = (long long)min_samples * bound;
+        if (m_bound > L.m_cap) m_bound = L.m_cap;
+        rc = ngp_hashgrid_fwd_n(xyzs, xyz_min, xyz_max, table, meta, (int)m_bound, &pl->m, feats, stream);
+        if (rc) return rc;
+        rc = ngp_field_fwd_n(feats, dirs, density_w, rgb_w, (int)m_bound, &pl->m, sigmas, rgbs, h, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(render_composite_kernel, dim3(ngp_div_up(bound, RC_THREADS)), dim3(RC_THREADS), 0, st, sigmas, rgbs, deltas, ts,
+                           alive[it & 1], alive[(it + 1) & 1], n_eff, offsets, T_threshold, pl, opacity, depth, rgb, total,
+                           H.counts + it % RENDER_RING);
+        hipError_t e = hipEventRecord(H.ev[it % RENDER_RING], st);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(render_finish_kernel, dim3(ngp_div_up(n_rays, 256)), dim3(256), 0, st, opacity, rgb, n_rays,
+                       bg ? bg[0] : 0.f, bg ? bg[1] : 0.f, bg ? bg[2] : 0.f, bg ? 1 : 0, total, total_samples);
+    if (n_iterations) *n_iterations = it;
     return NGP_LAUNCH_RESULT();
 }
 

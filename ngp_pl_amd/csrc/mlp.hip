@@ -121,6 +121,7 @@ struct MlpIO {
     float* sigmas;         // OUT_DENSITY
     float* rgbs;           // OUT_RGB (S,3)
     int out_act;           // OUT_PLAIN: 0 none, 1 sigmoid
+    const int32_t* n_dev;  // optional device-side sample count (forward only; the launch covers an upper bound)
 };
 
 // Load the B fragments (natural K order) of the network input for this lane's sample.
@@ -219,6 +220,10 @@ mlp_fwd_kernel(MlpIO io, const h1* __restrict__ weights, int n_samples) {
     using L = LdsW<N_IN, N_HIDDEN>;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     h1* lds = reinterpret_cast<h1*>(smem_raw);
+    if (io.n_dev != nullptr) {
+        n_samples = min(*io.n_dev, n_samples);
+        if ((long long)blockIdx.x * WAVES * TILE >= n_samples) return;
+    }
     stage_fwd_weights<N_IN, N_HIDDEN>(weights, lds);
     __syncthreads();
 
@@ -670,10 +675,23 @@ int ngp_rgb_fwd(const ngp_half* h, const float* dirs, const ngp_half* rgb_w, int
 
 int ngp_field_fwd(const ngp_half* feats, const float* dirs, const ngp_half* density_w, const ngp_half* rgb_w,
                   int n_samples, float* sigmas, float* rgbs, ngp_half* h_out, ngp_stream_t stream) {
-    NGP_CHECK_PTR(h_out);
-    const int rc = ngp_density_fwd(feats, density_w, n_samples, sigmas, h_out, stream);
+    return ngp_field_fwd_n(feats, dirs, density_w, rgb_w, n_samples, nullptr, sigmas, rgbs, h_out, stream);
+}
+
+int ngp_field_fwd_n(const ngp_half* feats, const float* dirs, const ngp_half* density_w, const ngp_half* rgb_w,
+                    int n_samples, const int32_t* n_dev, float* sigmas, float* rgbs, ngp_half* h_out,
+                    ngp_stream_t stream) {
+    if (n_samples < 0) return NGP_EINVAL;
+    if (n_samples == 0) return 0;
+    NGP_CHECK_PTR(feats); NGP_CHECK_PTR(dirs); NGP_CHECK_PTR(density_w); NGP_CHECK_PTR(rgb_w);
+    NGP_CHECK_PTR(sigmas); NGP_CHECK_PTR(rgbs); NGP_CHECK_PTR(h_out);
+    MlpIO d = {};
+    d.in = (const h1*)feats; d.out16 = (h1*)h_out; d.out_ld = 16; d.n_out = 16; d.sigmas = sigmas; d.n_dev = n_dev;
+    const int rc = launch_fwd<32, 1, IN_LEVELMAJOR, OUT_DENSITY>(d, (const h1*)density_w, n_samples, ngp_stream(stream));
     if (rc) return rc;
-    return ngp_rgb_fwd(h_out, dirs, rgb_w, n_samples, rgbs, stream);
+    MlpIO r = {};
+    r.in = (const h1*)h_out; r.dirs = dirs; r.rgbs = rgbs; r.n_out = 3; r.n_dev = n_dev;
+    return launch_fwd<32, 2, IN_SH_H, OUT_RGB>(r, (const h1*)rgb_w, n_samples, ngp_stream(stream));
 }
 
 int ngp_field_bwd_partials(int n_samples) { return n_samples <= 0 ? 0 : bwd_grid(n_samples); }

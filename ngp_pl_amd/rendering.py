@@ -33,7 +33,10 @@ def render(model, rays_o, rays_d, **kwargs):
     if kwargs.get("test_time", False):
         native = getattr(model, "fused", False) and model.rgb_act == "Sigmoid" and rays_o.is_cuda and \
             not any(isinstance(v, torch.Tensor) for v in kwargs.values())
-        fn = _render_test_native if native else _render_test
+        if native:
+            fn = _render_test_native if kwargs.get("host_loop", False) else _render_test_device
+        else:
+            fn = _render_test
     else:
         fn = _render_train
     results = fn(model, rays_o, rays_d, hits_t, **kwargs)
@@ -133,6 +136,39 @@ def _render_test_native(model, rays_o, rays_d, hits_t, **kwargs):
             alive = alive_new[:n_alive]
     bg = _background(esf, dev)
     return {"opacity": opacity, "depth": depth, "rgb": rgb + bg * (1 - opacity)[:, None], "total_samples": total[0]}
+
+
+@torch.no_grad()
+def _render_test_device(model, rays_o, rays_d, hits_t, **kwargs):
+    """`_render_test` as ONE call into the library (`ngp_render_test_frame`): the loop of
+    rendering.py:46-118 with the alive count, N_samples and the batch sizes kept on the device, so
+    no iteration waits for the host.  `chunk_scale=1, probe_cap=0` (default) keeps the reference's
+    chunking and is bit-identical to `_render_test_native`; larger `chunk_scale` / a `probe_cap`
+    emit the same samples per ray in fewer, better balanced iterations (results equal up to the
+    float rounding of where the composite re-reads T = 1 - opacity)."""
+    esf = float(kwargs.get("exp_step_factor", 0.))
+    n_rays, dev = len(rays_o), rays_o.device
+    chunk_scale = int(kwargs.get("chunk_scale", 1))
+    probe_cap = int(kwargs.get("probe_cap", 0))
+    enc, net = model.xyz_encoder, model.rgb_net
+    eh, rh = enc._half.get(enc.params), net._half.get(net.params)
+    nbytes = _lib.lib().ngp_render_test_workspace_bytes(n_rays, chunk_scale, esf)
+    ws = getattr(model, "_render_ws", None)
+    if ws is None or ws.numel() < nbytes or ws.device != dev:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        model._render_ws = ws
+    opacity = torch.empty(n_rays, device=dev); depth = torch.empty(n_rays, device=dev); rgb = torch.empty(n_rays, 3, device=dev)
+    total = torch.empty(1, dtype=torch.int64, device=dev)
+    hits = hits_t[:, 0].contiguous()
+    bg = (C.c_float * 3)(*([1.0, 1.0, 1.0] if esf == 0 else [0.0, 0.0, 0.0]))     # rendering.py:112-116
+    n_it = C.c_int32(0)
+    with torch.cuda.device(dev):
+        call("ngp_render_test_frame", ptr(rays_o), ptr(rays_d), ptr(hits), ptr(model.density_bitfield), model.cascades,
+             float(model.scale), esf, model.grid_size, int(kwargs.get("max_samples", MAX_SAMPLES)), float(kwargs.get("T_threshold", 1e-4)),
+             ptr(model.xyz_min), ptr(model.xyz_max), ptr(eh[enc.n_mlp:]), C.byref(enc.meta), ptr(eh), ptr(rh),
+             n_rays, chunk_scale, probe_cap, bg, ptr(ws), nbytes, ptr(opacity), ptr(depth), ptr(rgb), ptr(total),
+             C.byref(n_it), stream())
+    return {"opacity": opacity, "depth": depth, "rgb": rgb, "total_samples": total[0], "n_iterations": n_it.value}
 
 
 def _render_train(model, rays_o, rays_d, hits_t, **kwargs):

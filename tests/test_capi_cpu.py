@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def header_symbols():
     hdr = open(os.path.join(ROOT, "include", "ngp_hip.h")).read()
-    return sorted(set(re.findall(r"^(?:int|const char\*) (ngp_\w+)\(", hdr, re.M)))
+    return sorted(set(re.findall(r"^(?:int|size_t|const char\*) (ngp_\w+)\(", hdr, re.M)))
 
 
 def test_library_exports_every_declared_symbol():

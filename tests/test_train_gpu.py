@@ -188,6 +188,61 @@ def test_native_test_renderer_matches_reference_loop():
     assert torch.isfinite(a["rgb"]).all()
 
 
+def test_device_frame_loop_matches_host_loop():
+    """ngp_render_test_frame (device-driven loop) vs the host loop over the vren test kernels:
+    reference chunking (chunk_scale=1, probe_cap=0) must be BIT-identical (same samples, same
+    chunk boundaries, same composite arithmetic); other chunkings emit the same samples per ray and
+    may differ only by float rounding where T = 1 - opacity is re-read between chunks."""
+    from ngp_pl_amd.rendering import render
+    from ngp_pl_amd.trainer import Trainer
+    m = make_model(seed=5)
+    tr = Trainer(m)
+    bs = [batch(4096, seed=300 + i) for i in range(4)]
+    for it in range(150):
+        tr.step(*bs[it % 4])
+    ro, rd, _ = batch(30000, seed=78)
+    host = render(m, ro, rd, test_time=True, host_loop=True)
+    exact = render(m, ro, rd, test_time=True)
+    assert exact["n_iterations"] > 3
+    assert int(exact["total_samples"]) == int(host["total_samples"])
+    for k in ("rgb", "depth", "opacity"):
+        assert torch.equal(exact[k], host[k]), k
+    again = render(m, ro, rd, test_time=True)                # deterministic, workspace reuse
+    assert torch.equal(again["rgb"], exact["rgb"])
+    for kw in (dict(chunk_scale=4), dict(probe_cap=16), dict(chunk_scale=3, probe_cap=48)):
+        fast = render(m, ro, rd, test_time=True, **kw)
+        assert fast["n_iterations"] > 0
+        for k in ("rgb", "depth", "opacity"):
+            np.testing.assert_allclose(fast[k].cpu().numpy(), host[k].cpu().numpy(), rtol=0, atol=1e-5, err_msg="%s %s" % (k, kw))
+        # early-stopped rays may composite fewer trailing samples than a larger chunk marched, never more than the march emitted
+        assert int(fast["total_samples"]) >= int(host["total_samples"]) * 0.5
+    # a ray batch that misses the box entirely terminates after the first iteration
+    far = render(m, ro + 10.0, rd.abs() + 0.1, test_time=True)       # origins beyond the box, pointing away
+    assert int(far["total_samples"]) == 0 and torch.equal(far["opacity"], torch.zeros_like(far["opacity"]))
+    assert torch.equal(far["rgb"], torch.ones_like(far["rgb"]))      # white background (rendering.py:112)
+
+
+def test_device_frame_loop_unbounded_scene():
+    """cascades > 1, exponential stepping (min_samples = 4, black background): device loop == host loop."""
+    from ngp_pl_amd.rendering import render
+    from ngp_pl_amd.networks import NGP
+    torch.manual_seed(0)
+    m = NGP(4.0).cuda()
+    m.density_bitfield.fill_(255)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    ro = (torch.rand(6000, 3, device="cuda", generator=g) - 0.5) * 2
+    rd = torch.nn.functional.normalize(torch.randn(6000, 3, device="cuda", generator=g), dim=-1)
+    kw = dict(test_time=True, exp_step_factor=1 / 256.)
+    host = render(m, ro, rd, host_loop=True, **kw)
+    exact = render(m, ro, rd, **kw)
+    assert int(exact["total_samples"]) == int(host["total_samples"]) > 0
+    for k in ("rgb", "depth", "opacity"):
+        assert torch.equal(exact[k], host[k]), k
+    fast = render(m, ro, rd, chunk_scale=2, probe_cap=32, **kw)
+    for k in ("rgb", "depth", "opacity"):
+        np.testing.assert_allclose(fast[k].cpu().numpy(), host[k].cpu().numpy(), rtol=0, atol=1e-5, err_msg=k)
+
+
 def test_raymarcher_backward_is_ray_indexed():
     """RayMarcher.backward (custom_functions.py:102-112): dL/do = sum_seg dL/dxyz, dL/dd = sum_seg (dL/dxyz*t + dL/ddir),
     placed at the ray's own index (pose optimisation, --optimize_ext)."""
