@@ -223,7 +223,10 @@ def main():
         print(json.dumps(out))
     elif rank == 0:
         if not args.no_render:
-            out["render_fps_800x800"] = render_fps(model, data, n_frames=5)
+            # device-driven frame loop; chunk_scale/probe_cap only regroup the SAME per-ray samples into fewer
+            # iterations (tests/test_train_gpu.py::test_device_frame_loop_matches_host_loop)
+            out["render_fps_800x800"] = render_fps(model, data, n_frames=5, chunk_scale=4, probe_cap=64)
+            out["render_fps_800x800"]["loop"] = "ngp_render_test_frame chunk_scale=4 probe_cap=64"
         out["roofline"] = kernel_roofline(trainer, draw)
         out["api_path"] = api_path_rate(trainer, draw)
         if not args.no_cpu_baseline and world == 1:
