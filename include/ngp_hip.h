@@ -224,7 +224,7 @@ int ngp_hashgrid_bwd(const float* x, const float* xyz_min, const float* xyz_max,
                      int n_samples, void* grad_table, int grad_is_f32, ngp_stream_t stream);
 
 /* The same gradient without global atomics (the fast path; DESIGN.md "hash grid backward"):
- * every workgroup owns a 32768-entry slice of the table in LDS, scans all samples of its level
+ * every workgroup owns a <=27600-entry slice of the table in LDS, scans the samples of its level
  * and keeps the updates that fall in its slice (ds_pk_add_f16), then stores the slice.
  * grad_table (total,2) f16 is OVERWRITTEN entirely (no zero-fill needed, no accumulation).
  * active_idx / n_active (both NULL, or both set): compacted backward -- column j of dfeats
@@ -267,7 +267,8 @@ int ngp_density_fwd(const ngp_half* feats, const ngp_half* density_w, int n_samp
                     float* sigmas, ngp_half* h_out, ngp_stream_t stream);
 int ngp_rgb_fwd(const ngp_half* h, const float* dirs, const ngp_half* rgb_w, int n_samples,
                 float* rgbs, ngp_stream_t stream);
-/* both, back to back */
+/* both in ONE kernel: h stays in registers between the two nets and is only stored when h_out
+ * is given (training needs it for the backward; inference passes NULL) */
 int ngp_field_fwd(const ngp_half* feats, const float* dirs,
                   const ngp_half* density_w, const ngp_half* rgb_w, int n_samples,
                   float* sigmas, float* rgbs, ngp_half* h_out, ngp_stream_t stream);
@@ -361,7 +362,8 @@ int ngp_cast_f16_to_f32(const ngp_half* in, int64_t n, float scale, float* out,
  *   loss[0] = mean((rgb_f-gt)^2) + mean(lambda_o * -(o+1e-10) log(o+1e-10))
  * and the backward seeds dL_drgb (R,3), dL_dopacity (R) w.r.t. the COMPOSITED rgb/opacity, both
  * multiplied by grad_scale.  loss (1) f32 and sq_err (1) f32 (may be NULL; sum((rgb_f-gt)^2), for
- * PSNR) are OVERWRITTEN. */
+ * PSNR) are OVERWRITTEN.  Batches of up to 16384 rays reduce through a library-owned scratch
+ * (deterministic, no atomics): do not run two of these launches concurrently on different streams. */
 int ngp_nerf_loss(const float* rgb, const float* opacity, const float* gt_rgb, const float* bg,
                   float lambda_opacity, float grad_scale, int n_rays,
                   float* loss, float* sq_err, float* dL_drgb, float* dL_dopacity,

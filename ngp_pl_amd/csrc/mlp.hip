@@ -276,6 +276,91 @@ mlp_fwd_kernel(MlpIO io, const h1* __restrict__ weights, int n_samples) {
 }
 
 // ------------------------------------------------------------------------------------------
+// fused field forward: density net -> (sigma, h) -> rgb net in ONE pass.  h never leaves
+// registers: the density net's D fragment (16 outputs, D order) is chunk 1 of the colour net's
+// input (chunk 0 = SH of the direction), consumed through D-order A fragments of W0.
+// ------------------------------------------------------------------------------------------
+struct FieldIO {
+    const h1* feats;       // [16][S] half2
+    const float* dirs;     // (S,3)
+    float* sigmas;         // (S)
+    float* rgbs;           // (S,3)
+    h1* h_out;             // (S,16), may be null (inference)
+    const int32_t* n_dev;  // optional device-side sample count
+};
+
+__global__ void __launch_bounds__(64 * WAVES)
+field_fwd_kernel(FieldIO io, const h1* __restrict__ density_w, const h1* __restrict__ rgb_w, int n_samples) {
+    using LD = LdsW<32, 1>;
+    using LR = LdsW<32, 2>;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    h1* ldsd = reinterpret_cast<h1*>(smem_raw);
+    h1* ldsr = ldsd + LD::SIZE;
+    if (io.n_dev != nullptr) {
+        n_samples = min(*io.n_dev, n_samples);
+        if ((long long)blockIdx.x * WAVES * TILE >= n_samples) return;
+    }
+    stage_fwd_weights<32, 1>(density_w, ldsd);
+    stage_fwd_weights<32, 2>(rgb_w, ldsr);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, i = lane & 31, hh = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    const int n_tiles = (n_samples + TILE - 1) / TILE;
+    MlpIO din = {};
+    din.in = io.feats;
+    for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
+        const long long s = (long long)tile * TILE + i;
+        const bool valid = s < n_samples;
+        half8_t xb[2];
+        load_input<32, IN_LEVELMAJOR>(din, s, valid, n_samples, hh, xb);
+        f32x16 acc[2];
+        half8_t hb[4];
+        layer_in<32>(ldsd + LD::OFF_W0, xb, i, hh, acc);
+        acc_to_frag<true>(acc, hb);
+        f32x16 o[1];
+        layer_hid<1>(ldsd + LD::OFF_WO, LD::LDH, 16, hb, i, hh, o);
+        // h (f16): register e of lane-half hh is unit 4hh + (e&3) + 8(e>>2)
+        half8_t hfrag;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hfrag[e] = (h1)o[0][e];
+        // colour net input chunk 0: SH(d/|d|), natural K order
+        half8_t shfrag = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (valid) {
+            const float dx = io.dirs[3 * s], dy = io.dirs[3 * s + 1], dz = io.dirs[3 * s + 2];
+            const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+            float sh[16];
+            sh4(dx * inv, dy * inv, dz * inv, sh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) shfrag[e] = (h1)(hh ? sh[8 + e] : sh[e]);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            acc[m] = mfma(ldsA_nat(ldsr + LR::OFF_W0, LR::LD0, 32 * m + i, true, 0, hh), shfrag, zero16());
+            acc[m] = mfma(ldsA_dl(ldsr + LR::OFF_W0, LR::LD0, 32 * m + i, true, 1, hh), hfrag, acc[m]);
+        }
+        acc_to_frag<true>(acc, hb);
+        layer_hid<2>(ldsr + LR::OFF_W1, LR::LDH, 64, hb, i, hh, acc);
+        acc_to_frag<true>(acc, hb);
+        f32x16 c[1];
+        layer_hid<1>(ldsr + LR::OFF_WO, LR::LDH, 16, hb, i, hh, c);
+        if (!valid) continue;
+        if (io.h_out) {
+            half4_t lo, hi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lo[e] = hfrag[e]; hi[e] = hfrag[4 + e]; }
+            *reinterpret_cast<half4_t*>(io.h_out + s * 16 + 4 * hh) = lo;
+            *reinterpret_cast<half4_t*>(io.h_out + s * 16 + 8 + 4 * hh) = hi;
+        }
+        if (hh == 0) {
+            io.sigmas[s] = __expf((float)hfrag[0]);          // TruncExp fwd on the f16 h[0] (networks.py:105)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) io.rgbs[3 * s + k] = (float)(h1)sigmoidf(c[0][k]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // backward kernel: recompute forward, dgrad in registers, wgrad through a wave-private LDS
 // transpose, per-workgroup partial weight gradients.
 // ------------------------------------------------------------------------------------------
@@ -684,14 +769,13 @@ int ngp_field_fwd_n(const ngp_half* feats, const float* dirs, const ngp_half* de
     if (n_samples < 0) return NGP_EINVAL;
     if (n_samples == 0) return 0;
     NGP_CHECK_PTR(feats); NGP_CHECK_PTR(dirs); NGP_CHECK_PTR(density_w); NGP_CHECK_PTR(rgb_w);
-    NGP_CHECK_PTR(sigmas); NGP_CHECK_PTR(rgbs); NGP_CHECK_PTR(h_out);
-    MlpIO d = {};
-    d.in = (const h1*)feats; d.out16 = (h1*)h_out; d.out_ld = 16; d.n_out = 16; d.sigmas = sigmas; d.n_dev = n_dev;
-    const int rc = launch_fwd<32, 1, IN_LEVELMAJOR, OUT_DENSITY>(d, (const h1*)density_w, n_samples, ngp_stream(stream));
-    if (rc) return rc;
-    MlpIO r = {};
-    r.in = (const h1*)h_out; r.dirs = dirs; r.rgbs = rgbs; r.n_out = 3; r.n_dev = n_dev;
-    return launch_fwd<32, 2, IN_SH_H, OUT_RGB>(r, (const h1*)rgb_w, n_samples, ngp_stream(stream));
+    NGP_CHECK_PTR(sigmas); NGP_CHECK_PTR(rgbs);          // h_out may be NULL (inference: h stays in registers)
+    FieldIO io = {};
+    io.feats = (const h1*)feats; io.dirs = dirs; io.sigmas = sigmas; io.rgbs = rgbs; io.h_out = (h1*)h_out; io.n_dev = n_dev;
+    constexpr int smem = fwd_smem_bytes<32, 1>() + fwd_smem_bytes<32, 2>();
+    field_fwd_kernel<<<dim3(fwd_grid(n_samples)), dim3(64 * WAVES), smem, ngp_stream(stream)>>>(
+        io, (const h1*)density_w, (const h1*)rgb_w, n_samples);
+    return NGP_LAUNCH_RESULT();
 }
 
 int ngp_field_bwd_partials(int n_samples) { return n_samples <= 0 ? 0 : bwd_grid(n_samples); }

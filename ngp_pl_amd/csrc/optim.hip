@@ -142,44 +142,80 @@ cast_f16_f32_kernel(const h1* __restrict__ in, long long n, float scale, float* 
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (float)in[i] * scale;
 }
 
-template <bool SINGLE>
-__global__ void __launch_bounds__(SINGLE ? 1024 : 256)
+// per-ray loss terms + backward seeds (losses.py:47-60, train.py:173, bg blend rendering.py:153-161)
+__device__ __forceinline__ void nerf_loss_ray(float o, const float (&c)[3], const float (&g)[3], const float* __restrict__ bg,
+                                              float lambda_o, float grad_scale, float inv_r, float inv_3r,
+                                              float (&d_rgb)[3], float& d_o, float& l, float& se) {
+    float go = 0.f, se_ray = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float b = bg ? bg[k] : 0.f;
+        const float diff = c[k] + b * (1.0f - o) - g[k];
+        se_ray += diff * diff;
+        const float gr = 2.0f * diff * inv_3r;
+        d_rgb[k] = gr * grad_scale;
+        go -= gr * b;
+    }
+    const float oe = o + 1e-10f;
+    const float lg = __logf(oe);
+    l += se_ray * inv_3r + lambda_o * (-oe * lg) * inv_r;
+    se += se_ray;
+    go += lambda_o * (-(lg + 1.0f)) * inv_r;
+    d_o = go * grad_scale;
+}
+
+// OVERWRITE mode (n_rays <= 16384): workgroups park their partial sums in a library-owned scratch,
+// the last one to finish (self-resetting ticket: atomicInc wraps at the workgroup count) adds them
+// in workgroup order and WRITES loss / sq_err -- no zero-fill by the caller, no float atomics,
+// deterministic.  The scratch is shared by all launches of this kernel: callers must not run two
+// of them concurrently on different streams.
+constexpr int LOSS_MAX_BLOCKS = 64;
+__device__ unsigned int g_loss_ticket = 0;
+__device__ float g_loss_partial[2 * LOSS_MAX_BLOCKS];
+
+template <bool OVERWRITE>
+__global__ void __launch_bounds__(256)
 nerf_loss_kernel(const float* __restrict__ rgb, const float* __restrict__ opacity, const float* __restrict__ gt,
                  const float* __restrict__ bg, float lambda_o, float grad_scale, int n_rays,
                  float* __restrict__ loss, float* __restrict__ sq_err,
                  float* __restrict__ dL_drgb, float* __restrict__ dL_dopacity) {
     float l = 0.f, se = 0.f;
-    // SINGLE: one workgroup walks all rays and WRITES the sums (no zero-fill, no atomics)
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += SINGLE ? (int)blockDim.x : n_rays) {
-        const float o = opacity[r];
-        const float inv_r = 1.0f / (float)n_rays, inv_3r = 1.0f / (3.0f * (float)n_rays);
-        float go = 0.f, se_ray = 0.f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float b = bg ? bg[c] : 0.f;
-            const float diff = rgb[3 * r + c] + b * (1.0f - o) - gt[3 * r + c];
-            se_ray += diff * diff;
-            const float g = 2.0f * diff * inv_3r;
-            dL_drgb[3 * r + c] = g * grad_scale;
-            go -= g * b;
-        }
-        const float oe = o + 1e-10f;
-        const float lg = __logf(oe);
-        l += se_ray * inv_3r + lambda_o * (-oe * lg) * inv_r;
-        se += se_ray;
-        go += lambda_o * (-(lg + 1.0f)) * inv_r;
-        dL_dopacity[r] = go * grad_scale;
+    const float inv_r = 1.0f / (float)n_rays, inv_3r = 1.0f / (3.0f * (float)n_rays);
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_rays) {
+        const float c[3] = {rgb[3 * r], rgb[3 * r + 1], rgb[3 * r + 2]}, g[3] = {gt[3 * r], gt[3 * r + 1], gt[3 * r + 2]};
+        float d_rgb[3], d_o;
+        nerf_loss_ray(opacity[r], c, g, bg, lambda_o, grad_scale, inv_r, inv_3r, d_rgb, d_o, l, se);
+        dL_drgb[3 * r] = d_rgb[0]; dL_drgb[3 * r + 1] = d_rgb[1]; dL_drgb[3 * r + 2] = d_rgb[2];
+        dL_dopacity[r] = d_o;
     }
     l = ngp_wave_sum(l); se = ngp_wave_sum(se);
-    __shared__ float s_l[16], s_e[16];
-    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __shared__ float s_l[4], s_e[4];
+    __shared__ bool s_last;
+    const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { s_l[w] = l; s_e[w] = se; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        float tl = 0.f, te = 0.f;
-        for (int k = 0; k < nw; ++k) { tl += s_l[k]; te += s_e[k]; }
-        if (SINGLE) { *loss = tl; if (sq_err) *sq_err = te; }
-        else { atomicAdd(loss, tl); if (sq_err) atomicAdd(sq_err, te); }
+        const float tl = (s_l[0] + s_l[1]) + (s_l[2] + s_l[3]), te = (s_e[0] + s_e[1]) + (s_e[2] + s_e[3]);
+        if (OVERWRITE) {
+            g_loss_partial[2 * blockIdx.x] = tl; g_loss_partial[2 * blockIdx.x + 1] = te;
+            __threadfence();
+            s_last = atomicInc(&g_loss_ticket, gridDim.x - 1) == gridDim.x - 1;
+        } else {
+            atomicAdd(loss, tl); if (sq_err) atomicAdd(sq_err, te);
+        }
+    }
+    if (!OVERWRITE) return;
+    __syncthreads();
+    if (s_last && threadIdx.x < 64) {
+        __threadfence();
+        float a = 0.f, b = 0.f;
+        if (threadIdx.x < gridDim.x) {
+            a = __builtin_nontemporal_load(&g_loss_partial[2 * threadIdx.x]);
+            b = __builtin_nontemporal_load(&g_loss_partial[2 * threadIdx.x + 1]);
+        }
+        a = ngp_wave_sum(a); b = ngp_wave_sum(b);
+        if (threadIdx.x == 0) { *loss = a; if (sq_err) *sq_err = b; }
     }
 }
 
@@ -285,8 +321,8 @@ int ngp_nerf_loss(const float* rgb, const float* opacity, const float* gt_rgb, c
     if (n_rays < 0) return NGP_EINVAL;
     if (n_rays == 0) return 0;
     NGP_CHECK_PTR(rgb); NGP_CHECK_PTR(opacity); NGP_CHECK_PTR(gt_rgb); NGP_CHECK_PTR(loss); NGP_CHECK_PTR(dL_drgb); NGP_CHECK_PTR(dL_dopacity);
-    if (n_rays <= 16384)   // overwrite mode: the caller does not have to zero loss / sq_err
-        hipLaunchKernelGGL(nerf_loss_kernel<true>, dim3(1), dim3(1024), 0, ngp_stream(stream),
+    if (n_rays <= 256 * LOSS_MAX_BLOCKS)   // overwrite mode: the caller does not have to zero loss / sq_err
+        hipLaunchKernelGGL(nerf_loss_kernel<true>, dim3(ngp_div_up(n_rays, 256)), dim3(256), 0, ngp_stream(stream),
                            rgb, opacity, gt_rgb, bg, lambda_opacity, grad_scale, n_rays, loss, sq_err, dL_drgb, dL_dopacity);
     else {
         hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), ngp_stream(stream));
