@@ -382,6 +382,32 @@ int ngp_sample_rays(const float* poses, const float* directions, const float* im
                     float* rays_o, float* rays_d, float* rgb, float* noise,
                     int32_t* img_idx, int32_t* pix_idx, ngp_stream_t stream);
 
+/* ---- occupancy-grid maintenance -------------------------------------------------------- */
+
+/* density-only forward whose sigma of sample s is stored at sigmas_out[scatter_idx[s]]
+ * (`density_grid_tmp[c, indices] = self.density(xyzs_w)`, networks.py:256-258; duplicate indices:
+ * one of the values survives, as with index_put). */
+int ngp_density_fwd_scatter(const ngp_half* feats, const ngp_half* density_w, int n_samples,
+                            const int32_t* scatter_idx, float* sigmas_out, ngp_stream_t stream);
+
+/* NGP.update_density_grid (networks.py:240-269 with get_all_cells :155-167 and
+ * sample_uniform_and_occupied_cells :169-195) in one call, no host sync:
+ *   per cascade: warmup ? every cell : G^3/4 uniform cells + G^3/4 cells uniform over
+ *   {density_grid > density_threshold} (inverse-CDF lookup instead of nonzero()+randint());
+ *   sigma at the jittered cell centres (hash grid + density MLP); then
+ *   grid = (grid < 0) ? grid : max(grid * decay, sigma or 0), threshold = min(mean(grid > 0),
+ *   density_threshold), pack bits.
+ * density_grid (C, G^3) f32 Morton order, density_bitfield (C*G^3/8) u8, both updated in place;
+ * decay_grid (C, G^3) f32 per-cell decay or NULL (erode, networks.py:262-264); seed keys the
+ * counter-based RNG (pass the step number).  workspace: ngp_occupancy_update_workspace_bytes. */
+size_t ngp_occupancy_update_workspace_bytes(int cascades, int grid_size);
+int ngp_occupancy_update(float* density_grid, uint8_t* density_bitfield, int cascades, int grid_size,
+                         float scale, float density_threshold, float decay, const float* decay_grid,
+                         int warmup, uint64_t seed,
+                         const float* xyz_min, const float* xyz_max, const ngp_half* table,
+                         const ngp_grid_meta* meta, const ngp_half* density_w,
+                         void* workspace, size_t workspace_bytes, ngp_stream_t stream);
+
 /* ---- test-time frame loop -------------------------------------------------------------- */
 
 /* The whole test-time loop `__render_rays_test` (rendering.py:46-118) for one batch of rays,

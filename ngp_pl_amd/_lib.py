@@ -76,6 +76,8 @@ _PROTOS = {
     "ngp_abi_version": [],
     "ngp_hashgrid_fwd_n": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P],
     "ngp_field_fwd_n": [P, P, P, P, I, P, P, P, P, P],
+    "ngp_density_fwd_scatter": [P, P, I, P, P, P],
+    "ngp_occupancy_update": [P, P, I, I, F, F, F, P, I, C.c_uint64, P, P, P, C.POINTER(GridMeta), P, P, C.c_size_t, P],
     "ngp_render_test_frame": [P, P, P, P, I, F, F, I, I, F, P, P, P, C.POINTER(GridMeta), P, P, I, I, I,
                               C.POINTER(C.c_float), P, C.c_size_t, P, P, P, P, C.POINTER(C.c_int32), P],
 }
@@ -100,12 +102,14 @@ def lib():
         h.ngp_build_arch.restype = C.c_char_p
         h.ngp_render_test_workspace_bytes.argtypes = [I, I, F]
         h.ngp_render_test_workspace_bytes.restype = C.c_size_t
+        h.ngp_occupancy_update_workspace_bytes.argtypes = [I, I]
+        h.ngp_occupancy_update_workspace_bytes.restype = C.c_size_t
         _lib = h
     return _lib
 
 
 def exported_symbols():
-    return list(_PROTOS) + ["ngp_build_arch", "ngp_render_test_workspace_bytes"]
+    return list(_PROTOS) + ["ngp_build_arch", "ngp_render_test_workspace_bytes", "ngp_occupancy_update_workspace_bytes"]
 
 
 class NgpError(RuntimeError):

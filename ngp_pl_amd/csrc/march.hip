@@ -846,7 +846,7 @@ int ngp_density_grid_update(float* density_grid, const float* density_grid_tmp, 
     if (n_cells < 0) return NGP_EINVAL;
     if (n_cells == 0) return 0;
     NGP_CHECK_PTR(density_grid); NGP_CHECK_PTR(density_grid_tmp); NGP_CHECK_PTR(stats);
-    const int blocks = min(ngp_div_up(n_cells, 256), 2048);
+    const int blocks = min(ngp_div_up(n_cells, 256), 512);   // two same-address float atomics per workgroup: keep them few
     hipLaunchKernelGGL(density_grid_update_kernel, dim3(blocks), dim3(256), 0, ngp_stream(stream),
                        density_grid, density_grid_tmp, decay_grid, decay, n_cells, stats);
     return NGP_LAUNCH_RESULT();

@@ -122,6 +122,7 @@ struct MlpIO {
     float* rgbs;           // OUT_RGB (S,3)
     int out_act;           // OUT_PLAIN: 0 none, 1 sigmoid
     const int32_t* n_dev;  // optional device-side sample count (forward only; the launch covers an upper bound)
+    const int32_t* scatter;// OUT_DENSITY, optional: sigma of sample s goes to sigmas[scatter[s]]
 };
 
 // Load the B fragments (natural K order) of the network input for this lane's sample.
@@ -255,7 +256,7 @@ mlp_fwd_kernel(MlpIO io, const h1* __restrict__ weights, int n_samples) {
                 *reinterpret_cast<half4_t*>(io.out16 + s * 16 + 4 * hh) = lo;
                 *reinterpret_cast<half4_t*>(io.out16 + s * 16 + 8 + 4 * hh) = hi;
             }
-            if (hh == 0) io.sigmas[s] = __expf((float)lo[0]);   // TruncExp fwd on the f16 h[0] (networks.py:105)
+            if (hh == 0) io.sigmas[io.scatter ? (long long)io.scatter[s] : s] = __expf((float)lo[0]);   // TruncExp fwd on the f16 h[0] (networks.py:105)
         } else if (OUT_MODE == OUT_RGB) {
             if (hh == 0) {
 #pragma unroll
@@ -745,6 +746,16 @@ int ngp_density_fwd(const ngp_half* feats, const ngp_half* density_w, int n_samp
     NGP_CHECK_PTR(feats); NGP_CHECK_PTR(density_w); NGP_CHECK_PTR(sigmas);
     MlpIO d = {};
     d.in = (const h1*)feats; d.out16 = (h1*)h_out; d.out_ld = 16; d.n_out = 16; d.sigmas = sigmas;
+    return launch_fwd<32, 1, IN_LEVELMAJOR, OUT_DENSITY>(d, (const h1*)density_w, n_samples, ngp_stream(stream));
+}
+
+int ngp_density_fwd_scatter(const ngp_half* feats, const ngp_half* density_w, int n_samples,
+                            const int32_t* scatter_idx, float* sigmas_out, ngp_stream_t stream) {
+    if (n_samples < 0) return NGP_EINVAL;
+    if (n_samples == 0) return 0;
+    NGP_CHECK_PTR(feats); NGP_CHECK_PTR(density_w); NGP_CHECK_PTR(scatter_idx); NGP_CHECK_PTR(sigmas_out);
+    MlpIO d = {};
+    d.in = (const h1*)feats; d.out_ld = 16; d.n_out = 16; d.sigmas = sigmas_out; d.scatter = scatter_idx;
     return launch_fwd<32, 1, IN_LEVELMAJOR, OUT_DENSITY>(d, (const h1*)density_w, n_samples, ngp_stream(stream));
 }
 

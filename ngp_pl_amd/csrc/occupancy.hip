@@ -1,0 +1,200 @@
+// Occupancy-grid maintenance on the device (reference: NGP.update_density_grid and its helpers,
+// /root/reference/models/networks.py:155-195, 240-269; train.py:160-163 calls it every 16 steps).
+//
+// The reference does this with ~100 small torch launches and two host syncs (nonzero(), .item()).
+// Here one call enqueues, per cascade: occupancy words + prefix (2 launches), cell sampling with
+// jittered positions (1), the density-only field forward (hash grid + density MLP whose epilogue
+// scatters sigma straight into the scratch grid, 2), then the decay/max merge with the masked
+// mean (1) and the bit packing with the device-side threshold (1).
+//
+// Sampling semantics (networks.py:169-195): per cascade M = G^3/4 cells uniform over the grid plus
+// M cells uniform over {cell : density_grid > density_threshold} (with replacement); warm-up: every
+// cell once (networks.py:155-167).  The occupied draw is an inverse-CDF lookup over the 64-cell
+// occupancy words (prefix of popcounts + select-in-word) instead of nonzero()+randint().  An empty
+// occupied set maps every draw to the last cell (the reference adds no samples then; the extra
+// evaluations only refresh that cell).  Random numbers: counter-based hash keyed by (seed, i).
+#include "ngp_common.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t occ_hash(uint32_t v) {
+    uint32_t state = v * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+__device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
+
+// one wave per 64-cell word: occupancy bits + popcount
+__global__ void __launch_bounds__(256)
+occ_words_kernel(const float* __restrict__ grid, float threshold, int n_words,
+                 unsigned long long* __restrict__ words, int32_t* __restrict__ counts) {
+    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (w >= n_words) return;
+    const unsigned long long m = __ballot(grid[(size_t)w * 64 + lane] > threshold);
+    if (lane == 0) { words[w] = m; counts[w] = __popcll(m); }
+}
+
+// exclusive scan of counts in one workgroup; prefix[n] = total.  Tiles of 1024 counts: coalesced
+// loads, wave shuffle scan, carry across tiles (32 tiles for G = 128).
+__global__ void __launch_bounds__(1024)
+occ_scan_kernel(const int32_t* __restrict__ counts, int n, int32_t* __restrict__ prefix) {
+    __shared__ int s_wave[16];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const int v = (i < n) ? counts[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += u;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int off = s_carry;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        if (i < n) prefix[i] = off + incl - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = off + incl;
+        __syncthreads();
+    }
+    if (tid == 0) prefix[n] = s_carry;
+}
+
+// position of the r-th (0-based) set bit of m
+__device__ __forceinline__ int select_bit(unsigned long long m, int r) {
+    int pos = 0;
+#pragma unroll
+    for (int width = 32; width > 0; width >>= 1) {
+        const unsigned long long low = (m >> pos) & ((1ull << width) - 1ull);
+        const int c = __popcll(low);
+        if (r >= c) { r -= c; pos += width; }
+    }
+    return pos;
+}
+
+// cell i of the update -> (Morton index, jittered world position)
+//   mode 0 (warm-up): cell i itself, n = G^3
+//   mode 1: i < M uniform coordinates (networks.py:181-184), i >= M the occupied draw (:186-192)
+__global__ void __launch_bounds__(256)
+occ_sample_kernel(int mode, int n, int M, int grid_size, int n_words, const unsigned long long* __restrict__ words,
+                  const int32_t* __restrict__ prefix, float s_minus_hgs, float hgs, uint32_t seed_lo, uint32_t seed_hi,
+                  int32_t* __restrict__ cell_idx, float* __restrict__ xyzs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t base = occ_hash(seed_lo ^ occ_hash(seed_hi + 0x9E3779B9u)) + 7u * (uint32_t)i;
+    uint32_t idx, cx, cy, cz;
+    if (mode == 0) {
+        idx = (uint32_t)i;
+    } else if (i < M) {
+        cx = (uint32_t)(((uint64_t)occ_hash(base) * (uint64_t)grid_size) >> 32);
+        cy = (uint32_t)(((uint64_t)occ_hash(base + 1u) * (uint64_t)grid_size) >> 32);
+        cz = (uint32_t)(((uint64_t)occ_hash(base + 2u) * (uint64_t)grid_size) >> 32);
+        idx = ngp_morton3D(cx, cy, cz);
+    } else {
+        const int total = prefix[n_words];
+        if (total == 0) {
+            idx = (uint32_t)n_words * 64u - 1u;
+        } else {
+            int rank = (int)(u01(occ_hash(base + 3u)) * (float)total);        // (rand * count).int()
+            rank = min(rank, total - 1);
+            int lo = 0, hi = n_words;                                          // last word with prefix <= rank
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (prefix[mid] <= rank) lo = mid; else hi = mid;
+            }
+            idx = (uint32_t)lo * 64u + (uint32_t)select_bit(words[lo], rank - prefix[lo]);
+        }
+    }
+    if (mode == 0 || i >= M) {
+        cx = ngp_compact_bits(idx); cy = ngp_compact_bits(idx >> 1); cz = ngp_compact_bits(idx >> 2);
+    }
+    cell_idx[i] = (int32_t)idx;
+    // (coords/(G-1)*2-1)*(s-hgs) + (rand*2-1)*hgs   (networks.py:253-255), torch op order
+    const float gm1 = (float)(grid_size - 1);
+    const uint32_t c[3] = {cx, cy, cz};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float centre = ((float)c[k] / gm1 * 2.0f - 1.0f) * s_minus_hgs;
+        xyzs[3 * (size_t)i + k] = centre + (u01(occ_hash(base + 4u + k)) * 2.0f - 1.0f) * hgs;
+    }
+}
+
+struct OccLayout { size_t tmp, words, counts, prefix, idx, xyzs, feats, stats, bytes; };
+OccLayout occ_layout(int cascades, int grid_size) {
+    OccLayout L;
+    const size_t cells = (size_t)grid_size * grid_size * grid_size, n_words = cells / 64;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    L.tmp = take((size_t)cascades * cells * 4);
+    L.words = take(n_words * 8); L.counts = take(n_words * 4); L.prefix = take((n_words + 1) * 4);
+    L.idx = take(cells * 4); L.xyzs = take(cells * 12); L.feats = take(cells * 64); L.stats = take(8);
+    L.bytes = off;
+    return L;
+}
+
+}  // namespace
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+size_t ngp_occupancy_update_workspace_bytes(int cascades, int grid_size) {
+    if (cascades < 1 || grid_size < 4 || grid_size > 256 || (grid_size & (grid_size - 1))) return 0;
+    return occ_layout(cascades, grid_size).bytes;
+}
+
+int ngp_occupancy_update(float* density_grid, uint8_t* density_bitfield, int cascades, int grid_size, float scale,
+                         float density_threshold, float decay, const float* decay_grid, int warmup, uint64_t seed,
+                         const float* xyz_min, const float* xyz_max, const ngp_half* table, const ngp_grid_meta* meta,
+                         const ngp_half* density_w, void* workspace, size_t workspace_bytes, ngp_stream_t stream) {
+    if (cascades < 1 || grid_size < 4 || grid_size > 256 || (grid_size & (grid_size - 1)) || !meta) return NGP_EINVAL;
+    NGP_CHECK_PTR(density_grid); NGP_CHECK_PTR(density_bitfield); NGP_CHECK_PTR(xyz_min); NGP_CHECK_PTR(xyz_max);
+    NGP_CHECK_PTR(table); NGP_CHECK_PTR(density_w); NGP_CHECK_PTR(workspace);
+    const OccLayout L = occ_layout(cascades, grid_size);
+    if (workspace_bytes < L.bytes) return NGP_EINVAL;
+    char* ws = static_cast<char*>(workspace);
+    float* tmp = reinterpret_cast<float*>(ws + L.tmp);
+    unsigned long long* words = reinterpret_cast<unsigned long long*>(ws + L.words);
+    int32_t* counts = reinterpret_cast<int32_t*>(ws + L.counts);
+    int32_t* prefix = reinterpret_cast<int32_t*>(ws + L.prefix);
+    int32_t* idx = reinterpret_cast<int32_t*>(ws + L.idx);
+    float* xyzs = reinterpret_cast<float*>(ws + L.xyzs);
+    ngp_half* feats = reinterpret_cast<ngp_half*>(ws + L.feats);
+    float* stats = reinterpret_cast<float*>(ws + L.stats);
+    hipStream_t st = ngp_stream(stream);
+    const int cells = grid_size * grid_size * grid_size, n_words = cells / 64;
+    const int M = cells / 4;                                   // networks.py:254
+    const int n = warmup ? cells : 2 * M;
+    hipError_t e = hipMemsetAsync(tmp, 0, (size_t)cascades * cells * 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync(stats, 0, 8, st);
+    if (e != hipSuccess) return (int)e;
+    for (int c = 0; c < cascades; ++c) {
+        float* grid_c = density_grid + (size_t)c * cells;
+        if (!warmup) {
+            hipLaunchKernelGGL(occ_words_kernel, dim3(ngp_div_up((long long)n_words * 64, 256)), dim3(256), 0, st,
+                               grid_c, density_threshold, n_words, words, counts);
+            hipLaunchKernelGGL(occ_scan_kernel, dim3(1), dim3(1024), 0, st, counts, n_words, prefix);
+        }
+        // s = min(2^(c-1), scale), half_grid_size = s / G in Python doubles (networks.py:251-253)
+        double s = 1.0; for (int k = 0; k < c - 1; ++k) s *= 2.0; if (c == 0) s = 0.5;
+        if ((double)scale < s) s = (double)scale;
+        const double hgs = s / grid_size;
+        const uint64_t sd = seed * 0x9E3779B97F4A7C15ull + (uint64_t)c;
+        hipLaunchKernelGGL(occ_sample_kernel, dim3(ngp_div_up(n, 256)), dim3(256), 0, st, warmup ? 0 : 1, n, M, grid_size, n_words,
+                           words, prefix, (float)(s - hgs), (float)hgs, (uint32_t)sd, (uint32_t)(sd >> 32), idx, xyzs);
+        int rc = ngp_hashgrid_fwd(xyzs, xyz_min, xyz_max, table, meta, n, feats, stream);
+        if (rc) return rc;
+        rc = ngp_density_fwd_scatter(feats, density_w, n, idx, tmp + (size_t)c * cells, stream);
+        if (rc) return rc;
+    }
+    int rc = ngp_density_grid_update(density_grid, tmp, decay_grid, decay, cascades * cells, stats, stream);
+    if (rc) return rc;
+    return ngp_packbits_auto(density_grid, cascades * cells / 8, stats, density_threshold, density_bitfield, stream);
+}
+
+#pragma GCC visibility pop
+}  // extern "C"

@@ -244,11 +244,39 @@ class NGP(nn.Module):
                 self.density_grid[c, indices[i:i + chunk]] = torch.where(valid, 0., -1.)
 
     @torch.no_grad()
+    def _update_density_grid_native(self, density_threshold, warmup, decay, erode):
+        """The whole update as one library call (`ngp_occupancy_update`): cell sampling, jitter,
+        density-only forward with scatter epilogue, merge, mean, bit packing -- 7 launches per
+        cascade instead of ~100 torch ops, no host sync.  Same distribution of sampled cells as
+        the torch path below; the random stream is the library's counter-based one."""
+        dev = self.density_grid.device
+        enc = self.xyz_encoder
+        eh = enc._half.get(enc.params)
+        lib = _lib.lib()
+        nbytes = lib.ngp_occupancy_update_workspace_bytes(self.cascades, self.grid_size)
+        ws = getattr(self, "_occ_ws", None)
+        if ws is None or ws.numel() < nbytes or ws.device != dev:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self._occ_ws = ws
+        decay_grid = None
+        if erode:
+            decay_grid = torch.clamp(decay ** (1 / self.count_grid), 0.1, 0.95).contiguous()
+        self._occ_updates = getattr(self, "_occ_updates", 0) + 1
+        with torch.cuda.device(dev):
+            call("ngp_occupancy_update", ptr(self.density_grid), ptr(self.density_bitfield), self.cascades, self.grid_size,
+                 float(self.scale), float(density_threshold), float(decay), ptr(decay_grid), 1 if warmup else 0,
+                 int(getattr(self, "occ_seed", 0)) * 1000003 + self._occ_updates,
+                 ptr(self.xyz_min), ptr(self.xyz_max), ptr(eh[enc.n_mlp:]), C.byref(enc.meta), ptr(eh),
+                 ptr(ws), nbytes, stream())
+
+    @torch.no_grad()
     def update_density_grid(self, density_threshold, warmup=False, decay=0.95, erode=False):
         """Every 16 steps (train.py:160-163): sigma at jittered centres of the chosen cells,
         grid = max(grid*decay, sigma) where grid >= 0, threshold = min(mean(grid>0), thr), pack
         (networks.py:240-269).  The merge + mean + pack run as two kernels with the mean kept on
         device -- no .item() sync."""
+        if getattr(self, "native_grid_update", True) and self.density_grid.is_cuda and self.fused:
+            return self._update_density_grid_native(density_threshold, warmup, decay, erode)
         tmp = torch.zeros_like(self.density_grid)
         cells = self.get_all_cells() if warmup else \
             self.sample_uniform_and_occupied_cells(self.grid_size ** 3 // 4, density_threshold)

@@ -243,6 +243,97 @@ def test_device_frame_loop_unbounded_scene():
         np.testing.assert_allclose(fast[k].cpu().numpy(), host[k].cpu().numpy(), rtol=0, atol=1e-5, err_msg=k)
 
 
+def _occ_workspace_views(m):
+    """Views into the ngp_occupancy_update workspace (layout of csrc/occupancy.hip: 256-byte aligned
+    tmp, words, counts, prefix, idx, xyzs, ...) for cascade-count 1."""
+    cells = m.grid_size ** 3
+    n_words = cells // 64
+    off = 0
+
+    def take(nbytes):
+        nonlocal off
+        o = off
+        off += (nbytes + 255) // 256 * 256
+        return o
+    o_tmp = take(m.cascades * cells * 4); take(n_words * 8); take(n_words * 4); take((n_words + 1) * 4)
+    o_idx = take(cells * 4); o_xyz = take(cells * 12)
+    ws = m._occ_ws
+    idx = ws[o_idx:o_idx + cells * 4].view(torch.int32)
+    xyz = ws[o_xyz:o_xyz + cells * 12].view(torch.float32).view(-1, 3)
+    tmp = ws[o_tmp:o_tmp + cells * 4].view(torch.float32)
+    return idx, xyz, tmp
+
+
+def test_native_occupancy_update_matches_reference_semantics():
+    """ngp_occupancy_update vs networks.py:240-269 restated in torch on the SAME sampled cells and
+    jittered positions (read back from the workspace): merged grid identical, bitfield identical up
+    to cells within rounding of the device-side mean threshold; sampled cells follow the reference's
+    distribution (M uniform + M uniform over the occupied set; warm-up: every cell once)."""
+    from ngp_pl_amd import vren
+    from ngp_pl_amd.trainer import Trainer
+    m = make_model(seed=6)
+    tr = Trainer(m)
+    bs = [batch(4096, seed=400 + i) for i in range(4)]
+    for it in range(60):
+        tr.step(*bs[it % 4])
+    G, cells = m.grid_size, m.grid_size ** 3
+    M = cells // 4
+    thr = 0.01 * 1024 / 3 ** 0.5
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for warmup in (True, False):
+        grid0 = torch.rand(1, cells, device="cuda", generator=g) * 12.0          # ~half the cells above thr
+        grid0[0, torch.randint(cells, (5000,), device="cuda", generator=g)] = -1.0     # invisible cells stay -1
+        m.density_grid.copy_(grid0)
+        m.update_density_grid(thr, warmup=warmup)
+        idx, xyz, _ = _occ_workspace_views(m)
+        n = cells if warmup else 2 * M
+        idx = idx[:n].long(); xyz = xyz[:n].clone()
+        # positions: inside their cell (centre +- half_grid_size), networks.py:253-255
+        coords = vren.morton3D_invert(idx.int()).float()
+        s = 0.5; hgs = s / G
+        centre = (coords / (G - 1) * 2 - 1) * (s - hgs)
+        assert ((xyz - centre).abs() <= hgs * (1 + 1e-5)).all()
+        assert (xyz - centre).abs().max() > 0.9 * hgs and ((xyz - centre).mean(0).abs() < 0.02 * hgs).all()     # jitter is there and centred
+        if warmup:
+            assert torch.equal(idx, torch.arange(cells, device="cuda"))
+        else:
+            uni, occ = idx[:M], idx[M:]
+            c1 = vren.morton3D_invert(uni.int())
+            for k in range(3):                                                 # uniform coordinates per axis
+                hist = torch.bincount(c1[:, k].long(), minlength=G).float()
+                assert hist.min() > 0 and ((hist - M / G).abs() < 6 * (M / G) ** 0.5).all()
+            assert (grid0[0, occ] > thr).all()                                 # drawn from the occupied set only
+            n_occ = int((grid0[0] > thr).sum())
+            seen = torch.unique(occ).numel()
+            expect = n_occ * (1 - np.exp(-M / n_occ))                          # distinct cells of M draws with replacement
+            assert abs(seen - expect) < 0.02 * expect, (seen, expect)
+        # merge: same sigma kernels on the same positions -> exact
+        with torch.no_grad():                                              # the density-only kernels the update itself runs
+            sigma = m.density(xyz).float()
+        dec = grid0[0] * 0.95
+        hi = torch.zeros(cells, device="cuda").scatter_reduce_(0, idx, sigma, "amax", include_self=True)
+        lo = torch.full((cells,), float("inf"), device="cuda").scatter_reduce_(0, idx, sigma, "amin", include_self=True)
+        lo = torch.where(torch.isinf(lo), torch.zeros_like(lo), lo)
+        got = m.density_grid[0]
+        neg = grid0[0] < 0
+        assert torch.equal(got[neg], grid0[0][neg])
+        up, dn = torch.maximum(dec, hi), torch.maximum(dec, lo)                # duplicates: one of the draws survives
+        assert ((got >= dn) & (got <= up))[~neg].all()
+        single = (~neg) & (hi == lo)
+        assert torch.equal(got[single], up[single])
+        # bitfield: threshold min(mean(grid > 0), thr) (networks.py:266-268)
+        mean = got[got > 0].mean()
+        want = torch.zeros_like(m.density_bitfield)
+        vren.packbits(got.view(1, -1), min(float(mean), thr), want)
+        diff = (want ^ m.density_bitfield)
+        assert int(torch.count_nonzero(diff)) <= 2
+    # an empty occupied set is legal (start of training): every occupied draw lands on the last cell
+    m.density_grid.zero_()
+    m.update_density_grid(thr, warmup=False)
+    idx, _, _ = _occ_workspace_views(m)
+    assert (idx[M:2 * M] == cells - 1).all() and torch.isfinite(m.density_grid).all()
+
+
 def test_raymarcher_backward_is_ray_indexed():
     """RayMarcher.backward (custom_functions.py:102-112): dL/do = sum_seg dL/dxyz, dL/dd = sum_seg (dL/dxyz*t + dL/ddir),
     placed at the ray's own index (pose optimisation, --optimize_ext)."""
