@@ -223,6 +223,14 @@ int ngp_hashgrid_bwd(const float* x, const float* xyz_min, const float* xyz_max,
                      const ngp_half* dfeats /* [L][S] half2 */, const ngp_grid_meta* meta,
                      int n_samples, void* grad_table, int grad_is_f32, ngp_stream_t stream);
 
+/* Encode backward w.r.t. the INPUT positions (pose optimisation, train.py:86-89; tiny-cuda-nn computes it
+ * when the encoding input requires grad): dL_dx (S,3) f32 = out_scale * sum over levels/features of
+ * dfeats * d feat / d x, linear interpolation, table values as stored (f16). */
+int ngp_hashgrid_bwd_input(const float* x, const float* xyz_min, const float* xyz_max,
+                           const ngp_half* table, const ngp_half* dfeats /* [L][S] half2 */,
+                           const ngp_grid_meta* meta, int n_samples, float out_scale,
+                           float* dL_dx, ngp_stream_t stream);
+
 /* The same gradient without global atomics (the fast path; DESIGN.md "hash grid backward"):
  * every workgroup owns a <=27600-entry slice of the table in LDS, scans the samples of its level
  * and keeps the updates that fall in its slice (ds_pk_add_f16), then stores the slice.
@@ -320,6 +328,9 @@ int ngp_mlp_bwd(const ngp_half* in, const ngp_half* weights, const ngp_half* dL_
 /* tcnn.Encoding SphericalHarmonics degree 4 (networks.py:58-65): in (S,3) f32 in [0,1]
  * (the module maps it back to [-1,1]), out (S,16) f16. */
 int ngp_sh4_fwd(const float* dirs01, int n_samples, ngp_half* out, ngp_stream_t stream);
+/* its backward w.r.t. the input: dL_ddirs01 (S,3) f32 = out_scale * 2 * dSH/d(xyz) . dL_dsh (S,16) f16 */
+int ngp_sh4_bwd(const float* dirs01, const ngp_half* dL_dsh, int n_samples, float out_scale,
+                float* dL_ddirs01, ngp_stream_t stream);
 
 /* Layout converters between the level-major feature layout and tcnn's (S,32) row-major one. */
 int ngp_feats_to_rowmajor(const ngp_half* feats, int n_levels, int n_samples, ngp_half* out,

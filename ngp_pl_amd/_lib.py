@@ -76,6 +76,8 @@ _PROTOS = {
     "ngp_abi_version": [],
     "ngp_hashgrid_fwd_n": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P],
     "ngp_field_fwd_n": [P, P, P, P, I, P, P, P, P, P],
+    "ngp_hashgrid_bwd_input": [P, P, P, P, P, C.POINTER(GridMeta), I, F, P, P],
+    "ngp_sh4_bwd": [P, P, I, F, P, P],
     "ngp_density_fwd_scatter": [P, P, I, P, P, P],
     "ngp_occupancy_update": [P, P, I, I, F, F, F, P, I, C.c_uint64, P, P, P, C.POINTER(GridMeta), P, P, C.c_size_t, P],
     "ngp_render_test_frame": [P, P, P, P, I, F, F, I, I, F, P, P, P, C.POINTER(GridMeta), P, P, I, I, I,

@@ -170,6 +170,50 @@ hashgrid_fwd_kernel(const float* __restrict__ x, const float* __restrict__ xyz_m
     }
 }
 
+// ---- backward w.r.t. the input positions (pose optimisation, train.py:86-89,117-122) -------------
+// tiny-cuda-nn's grid backward-input for linear interpolation: d feat / d pos_k =
+// sum over corners of (+-1 along k) * (the other two weights) * value; chain: pos = x01*scale + 0.5,
+// x01 = (x - min) / (max - min).  One thread per sample walks the levels (this path is off unless
+// the rays carry gradients, it is not on the throughput-critical path).
+__global__ void __launch_bounds__(256)
+hashgrid_bwd_input_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const float* __restrict__ xyz_max,
+                          const half2_t* __restrict__ table, const half2_t* __restrict__ dfeats, GridMeta meta,
+                          int n_samples, float out_scale, float* __restrict__ dL_dx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_samples) return;
+    const Box box = load_box(xyz_min, xyz_max);
+    float g[3] = {0.f, 0.f, 0.f};
+    for (int level = 0; level < meta.n_levels; ++level) {
+        const uint32_t res = meta.resolution[level];
+        const uint32_t size = meta.offset[level + 1] - meta.offset[level];
+        const half2_t* __restrict__ tab = table + meta.offset[level];
+        const float scale = meta.scale[level];
+        uint32_t p[3], idx[8]; float f[3];
+        cell_of(x, box, (size_t)i, scale, p, f);
+        if (level_is_hashed(res, size)) corner_indices<true>(p, res, size, idx);
+        else corner_indices<false>(p, res, size, idx);
+        const half2_t d = dfeats[(size_t)level * n_samples + i];
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { const half2_t t = tab[idx[c]]; v[c] = (float)t[0] * (float)d[0] + (float)t[1] * (float)d[1]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float w = ((c >> k) & 1) ? 1.f : -1.f;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (j != k) w *= ((c >> j) & 1) ? f[j] : 1.f - f[j];
+                acc = fmaf(w, v[c], acc);
+            }
+            g[k] = fmaf(acc, scale * box.inv[k], g[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dL_dx[3 * (size_t)i + k] = g[k] * out_scale;
+}
+
 // ---- backward, global-atomic flavour (kept for A/B and for accumulate semantics) ----------------
 template <bool HASHED, bool F32>
 __device__ __forceinline__ void scatter_one(void* __restrict__ grad_level, uint32_t res, uint32_t size,
@@ -538,6 +582,17 @@ int ngp_hashgrid_fwd_n(const float* x, const float* xyz_min, const float* xyz_ma
     const int n_chunks = ngp_div_up(n_samples, 256);
     hipLaunchKernelGGL(hashgrid_fwd_kernel<1>, dim3(n_blocks_for(meta->n_levels, n_chunks)), dim3(256), 0, ngp_stream(stream),
                        x, xyz_min, xyz_max, (const half2_t*)table, to_dev_meta(meta), n_samples, n_chunks, n_dev, (half2_t*)feats);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_hashgrid_bwd_input(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* table,
+                           const ngp_half* dfeats, const ngp_grid_meta* meta, int n_samples, float out_scale,
+                           float* dL_dx, ngp_stream_t stream) {
+    if (n_samples < 0 || !meta || meta->n_features != 2) return NGP_EINVAL;
+    if (n_samples == 0) return 0;
+    NGP_CHECK_PTR(x); NGP_CHECK_PTR(xyz_min); NGP_CHECK_PTR(xyz_max); NGP_CHECK_PTR(table); NGP_CHECK_PTR(dfeats); NGP_CHECK_PTR(dL_dx);
+    hipLaunchKernelGGL(hashgrid_bwd_input_kernel, dim3(ngp_div_up(n_samples, 256)), dim3(256), 0, ngp_stream(stream),
+                       x, xyz_min, xyz_max, (const half2_t*)table, (const half2_t*)dfeats, to_dev_meta(meta), n_samples, out_scale, dL_dx);
     return NGP_LAUNCH_RESULT();
 }
 

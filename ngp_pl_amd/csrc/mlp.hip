@@ -734,6 +734,41 @@ sh4_kernel(const float* __restrict__ d01, int n, h1* __restrict__ out) {
     *reinterpret_cast<half8_t*>(out + (size_t)s * 16 + 8) = b;
 }
 
+// d SH / d (x,y,z) contracted with dL/dSH (tiny-cuda-nn SphericalHarmonics backward-input);
+// the encoding receives (d+1)/2, hence the factor 2 (networks.py:144).
+__global__ void __launch_bounds__(256)
+sh4_bwd_kernel(const float* __restrict__ d01, const h1* __restrict__ dL_dsh, int n, float out_scale, float* __restrict__ dL_dd01) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const float x = d01[3 * s] * 2.f - 1.f, y = d01[3 * s + 1] * 2.f - 1.f, z = d01[3 * s + 2] * 2.f - 1.f;
+    float g[16];
+    const half8_t a = *reinterpret_cast<const half8_t*>(dL_dsh + (size_t)s * 16);
+    const half8_t b = *reinterpret_cast<const half8_t*>(dL_dsh + (size_t)s * 16 + 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { g[e] = (float)a[e]; g[8 + e] = (float)b[e]; }
+    const float A = 0.48860251190291987f, B = 1.0925484305920792f, Cc = 0.94617469575755997f, E = 0.54627421529603959f,
+                F = 0.59004358992664352f, G = 2.8906114426405538f, H = 0.45704579946446572f, K = 0.3731763325901154f,
+                M = 1.4453057213202769f;
+    const float x2 = x * x, y2 = y * y, z2 = z * z;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    gy += g[1] * -A;
+    gz += g[2] * A;
+    gx += g[3] * -A;
+    gx += g[4] * B * y; gy += g[4] * B * x;
+    gy += g[5] * -B * z; gz += g[5] * -B * y;
+    gz += g[6] * 2.f * Cc * z;
+    gx += g[7] * -B * z; gz += g[7] * -B * x;
+    gx += g[8] * 2.f * E * x; gy += g[8] * -2.f * E * y;
+    gx += g[9] * -6.f * F * x * y; gy += g[9] * F * (-3.f * x2 + 3.f * y2);
+    gx += g[10] * G * y * z; gy += g[10] * G * x * z; gz += g[10] * G * x * y;
+    gy += g[11] * H * (1.f - 5.f * z2); gz += g[11] * -10.f * H * y * z;
+    gz += g[12] * K * (15.f * z2 - 3.f);
+    gx += g[13] * H * (1.f - 5.f * z2); gz += g[13] * -10.f * H * x * z;
+    gx += g[14] * 2.f * M * x * z; gy += g[14] * -2.f * M * y * z; gz += g[14] * M * (x2 - y2);
+    gx += g[15] * F * (-3.f * x2 + 3.f * y2); gy += g[15] * 6.f * F * x * y;
+    dL_dd01[3 * s] = 2.f * gx * out_scale; dL_dd01[3 * s + 1] = 2.f * gy * out_scale; dL_dd01[3 * s + 2] = 2.f * gz * out_scale;
+}
+
 }  // namespace
 
 extern "C" {
@@ -882,6 +917,16 @@ int ngp_sh4_fwd(const float* dirs01, int n_samples, ngp_half* out, ngp_stream_t 
     if (n_samples == 0) return 0;
     NGP_CHECK_PTR(dirs01); NGP_CHECK_PTR(out);
     hipLaunchKernelGGL(sh4_kernel, dim3(ngp_div_up(n_samples, 256)), dim3(256), 0, ngp_stream(stream), dirs01, n_samples, (h1*)out);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_sh4_bwd(const float* dirs01, const ngp_half* dL_dsh, int n_samples, float out_scale, float* dL_ddirs01,
+                ngp_stream_t stream) {
+    if (n_samples < 0) return NGP_EINVAL;
+    if (n_samples == 0) return 0;
+    NGP_CHECK_PTR(dirs01); NGP_CHECK_PTR(dL_dsh); NGP_CHECK_PTR(dL_ddirs01);
+    hipLaunchKernelGGL(sh4_bwd_kernel, dim3(ngp_div_up(n_samples, 256)), dim3(256), 0, ngp_stream(stream), dirs01, (const h1*)dL_dsh,
+                       n_samples, out_scale, dL_ddirs01);
     return NGP_LAUNCH_RESULT();
 }
 

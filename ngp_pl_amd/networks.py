@@ -171,7 +171,8 @@ class NGP(nn.Module):
 
     def forward(self, x, d, **kwargs):
         """x (N,3), d (N,3) -> sigmas (N), rgbs (N,3)   (networks.py:132-153)."""
-        if self.fused and self.rgb_act == "Sigmoid":
+        rays_need_grad = torch.is_grad_enabled() and (x.requires_grad or d.requires_grad)     # pose optimisation (train.py:86-89)
+        if self.fused and self.rgb_act == "Sigmoid" and not rays_need_grad:
             return _FusedField.apply(x, d, self.xyz_encoder.params, self.rgb_net.params, self)
         sigmas, h = self.density(x, return_feat=True)
         d = d / torch.norm(d, dim=1, keepdim=True)

@@ -120,8 +120,9 @@ class _EncodeAndNet(torch.autograd.Function):
         n = x.shape[0]
         dev = x.device
         grad = torch.zeros(mod.params.numel(), dtype=torch.float32, device=dev)
+        want_dx = ctx.needs_input_grad[0]
         if n == 0:
-            return None, grad, None
+            return (torch.zeros(0, 3, dtype=torch.float32, device=dev) if want_dx else None), grad, None
         dh = torch.zeros(n, 16, dtype=torch.float16, device=dev)
         dh[:, :mod.n_output_dims] = (dL_dh.float() * LOSS_SCALE).half()
         ph = mod._half.get(mod.params)
@@ -135,7 +136,12 @@ class _EncodeAndNet(torch.autograd.Function):
             call("ngp_hashgrid_bwd_sliced", ptr(x), ptr(mod._zero3), ptr(mod._one3), ptr(dfeats), C.byref(mod.meta), n,
                  None, None, ptr(g16), stream())
             call("ngp_cast_f16_to_f32", ptr(g16), mod.n_grid, 1.0 / LOSS_SCALE, ptr(grad[mod.n_mlp:]), stream())
-        return None, grad, None
+            dx = None
+            if want_dx:          # pose optimisation: the sample positions carry gradients (train.py:86-89)
+                dx = torch.empty(n, 3, dtype=torch.float32, device=dev)
+                call("ngp_hashgrid_bwd_input", ptr(x), ptr(mod._zero3), ptr(mod._one3), ptr(ph[mod.n_mlp:]), ptr(dfeats),
+                     C.byref(mod.meta), n, 1.0 / LOSS_SCALE, ptr(dx), stream())
+        return dx, grad, None
 
 
 class NetworkWithInputEncoding(nn.Module):
@@ -176,14 +182,34 @@ class Encoding(nn.Module):
         self.n_input_dims, self.n_output_dims = 3, 16
         self.params = nn.Parameter(torch.zeros(0))
 
-    @torch.no_grad()
     def forward(self, x):
-        x = x.float().contiguous()
-        _lib.require_cuda(x)
-        out = torch.empty(x.shape[0], 16, dtype=torch.float16, device=x.device)
-        with torch.cuda.device(x.device):
-            call("ngp_sh4_fwd", ptr(x), x.shape[0], ptr(out), stream())
+        return _SH4.apply(x)
+
+
+class _SH4(torch.autograd.Function):
+    """x in [0,1]^3 = (d+1)/2 -> 16 SH values f16; backward w.r.t. x for pose optimisation."""
+
+    @staticmethod
+    def forward(ctx, x):
+        xin = x.detach().float().contiguous()
+        _lib.require_cuda(xin)
+        out = torch.empty(xin.shape[0], 16, dtype=torch.float16, device=xin.device)
+        with torch.cuda.device(xin.device):
+            call("ngp_sh4_fwd", ptr(xin), xin.shape[0], ptr(out), stream())
+        ctx.save_for_backward(xin)
+        ctx.in_dtype = x.dtype
         return out
+
+    @staticmethod
+    def backward(ctx, dL_dout):
+        (xin,) = ctx.saved_tensors
+        n, dev = xin.shape[0], xin.device
+        dx = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        if n:
+            g = (dL_dout.float() * LOSS_SCALE).half().contiguous()       # f16 transport with the modules' loss scale
+            with torch.cuda.device(dev):
+                call("ngp_sh4_bwd", ptr(xin), ptr(g), n, 1.0 / LOSS_SCALE, ptr(dx), stream())
+        return dx.to(ctx.in_dtype)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -170,6 +170,49 @@ def test_sh_encoding(lib):
     assert abs(o1[0, 0].item() - 0.2821) < 1e-3 and abs(o1[0, 2].item() - 0.4886) < 1e-3 and abs(o1[0, 6].item() - 0.6308) < 1e-3
 
 
+def test_hashgrid_input_gradient(lib, field):
+    """dL/dx through the encoding (pose optimisation, train.py:86-89): native kernel vs autograd of the
+    fp32 oracle.  The interpolant is piecewise linear: away from cell faces the derivative is exact up
+    to f16 rounding of the table/dfeats products."""
+    meta = native_meta(lib)
+    n = 6000
+    x, _ = sample_points(n, seed=11, edges=False)
+    g = torch.Generator().manual_seed(12)
+    dfe = (torch.randn(n, 32, generator=g) * 0.05).half()            # upstream gradient, f16 like the MLP's dgrad
+    x01 = (x + 0.5).clone().requires_grad_(True)
+    out = T.hash_encode(x01, field.table, field.meta)
+    (out * dfe.float()).sum().backward()
+    want = x01.grad / 1.0                                              # d/dx = d/dx01 / (max - min), extent 1
+    table_h = field.table.half().cuda()
+    dfeats = dfe.view(n, 16, 2).permute(1, 0, 2).contiguous().cuda()
+    xs = x.cuda().contiguous()
+    mnt = torch.full((3,), -0.5, device="cuda"); mxt = torch.full((3,), 0.5, device="cuda")
+    dx = torch.empty(n, 3, device="cuda")
+    lib.call("ngp_hashgrid_bwd_input", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(table_h), lib.ptr(dfeats), C.byref(meta), n, 1.0,
+             lib.ptr(dx), lib.stream())
+    scale = want.abs().max().item()
+    np.testing.assert_allclose(dx.cpu().numpy(), want.numpy(), rtol=2e-3, atol=2e-4 * scale)
+    # scaling argument and a non-unit box: d/dx scales with 1/(max-min)
+    mnt2 = torch.full((3,), -1.0, device="cuda"); mxt2 = torch.full((3,), 1.0, device="cuda")
+    xs2 = (xs * 2).contiguous()
+    dx2 = torch.empty(n, 3, device="cuda")
+    lib.call("ngp_hashgrid_bwd_input", lib.ptr(xs2), lib.ptr(mnt2), lib.ptr(mxt2), lib.ptr(table_h), lib.ptr(dfeats), C.byref(meta), n, 4.0,
+             lib.ptr(dx2), lib.stream())
+    np.testing.assert_allclose(dx2.cpu().numpy(), 2.0 * dx.cpu().numpy(), rtol=1e-5, atol=1e-6 * scale)
+
+
+def test_sh_input_gradient(lib):
+    g = torch.Generator().manual_seed(13)
+    d = torch.randn(4000, 3, generator=g); d /= d.norm(dim=1, keepdim=True)
+    d01 = ((d + 1) / 2).clone().requires_grad_(True)
+    gsh = (torch.randn(4000, 16, generator=g) * 0.1).half()
+    (T.sh4(d01 * 2 - 1) * gsh.float()).sum().backward()
+    out = torch.empty(4000, 3, device="cuda")
+    d01c = d01.detach().cuda().contiguous(); gc = gsh.cuda().contiguous()
+    lib.call("ngp_sh4_bwd", lib.ptr(d01c), lib.ptr(gc), 4000, 1.0, lib.ptr(out), lib.stream())
+    np.testing.assert_allclose(out.cpu().numpy(), d01.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
 def test_field_backward(lib, field):
     n = 20011
     x, d = sample_points(n, seed=6)

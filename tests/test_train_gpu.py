@@ -334,6 +334,40 @@ def test_native_occupancy_update_matches_reference_semantics():
     assert (idx[M:2 * M] == cells - 1).all() and torch.isfinite(m.density_grid).all()
 
 
+def test_pose_gradients_flow_through_the_field():
+    """--optimize_ext (train.py:86-89,117-122): rays that require grad get dL/drays_o, dL/drays_d through
+    RayMarcher.backward, the hash grid's input gradient and the SH encoding.  Checked against a central
+    finite difference of the loss along a random perturbation of the ray origins (the field is smooth
+    at the f16 level only: tolerance 15 % on the directional derivative)."""
+    from ngp_pl_amd.rendering import render
+    from ngp_pl_amd.trainer import Trainer
+    m = make_model(seed=8)
+    tr = Trainer(m)
+    bs = [batch(4096, seed=500 + i) for i in range(4)]
+    for it in range(150):
+        tr.step(*bs[it % 4])
+    ro, rd, gt = batch(2048, seed=91)
+    torch.manual_seed(0)
+
+    def loss_of(o, d):
+        torch.manual_seed(1)                                              # same marching jitter in every evaluation
+        res = render(m, o, d, test_time=False)
+        return ((res["rgb"] - gt) ** 2).mean()
+    o = ro.clone().requires_grad_(True); d = rd.clone().requires_grad_(True)
+    loss = loss_of(o, d)
+    loss.backward()
+    assert o.grad is not None and d.grad is not None
+    assert torch.isfinite(o.grad).all() and torch.isfinite(d.grad).all() and o.grad.abs().sum() > 0 and d.grad.abs().sum() > 0
+    # a common translation of all origins (what a pose offset dT does): directional derivative vs finite difference
+    v = torch.tensor([0.6, -0.5, 0.62], device="cuda")
+    analytic = float((o.grad * v).sum())
+    eps = 2e-3
+    with torch.no_grad():
+        lp = float(loss_of(ro + eps * v, rd)); lm = float(loss_of(ro - eps * v, rd))
+    numeric = (lp - lm) / (2 * eps)
+    assert abs(analytic - numeric) <= 0.15 * abs(numeric) + 1e-4, (analytic, numeric)
+
+
 def test_raymarcher_backward_is_ray_indexed():
     """RayMarcher.backward (custom_functions.py:102-112): dL/do = sum_seg dL/dxyz, dL/dd = sum_seg (dL/dxyz*t + dL/ddir),
     placed at the ray's own index (pose optimisation, --optimize_ext)."""
