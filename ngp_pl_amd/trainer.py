@@ -27,7 +27,8 @@ from .rendering import MAX_SAMPLES, NEAR_DISTANCE, render
 
 class Trainer:
     def __init__(self, model, lr=1e-2, num_epochs=30, steps_per_epoch=1000, T_threshold=1e-4,
-                 lambda_opacity=1e-3, grad_scale=1.0, warmup_steps=256, update_interval=16, overlap_march=True):
+                 lambda_opacity=1e-3, grad_scale=1.0, warmup_steps=256, update_interval=16, overlap_march=True,
+                 lambda_distortion=0.0):
         self.model = model
         if not hasattr(model, "density_grid"):
             model.register_training_buffers()
@@ -40,7 +41,9 @@ class Trainer:
         self.exp_step_factor = 1 / 256 if model.scale > 0.5 else 0.0      # train.py:95-96
         dev = model.center.device
         self.bg = torch.ones(3, device=dev) if self.exp_step_factor == 0 else None
-        self.loss_fn = NeRFLoss(lambda_opacity=lambda_opacity, lambda_distortion=0)
+        self.lambda_distortion = lambda_distortion                          # opt.py:25-29 suggests 1e-3 for real scenes
+        self.loss_fn = NeRFLoss(lambda_opacity=lambda_opacity, lambda_distortion=lambda_distortion)
+        self._dist_seed = None
         self.side = torch.cuda.Stream(device=dev) if (overlap_march and dev.type == "cuda") else None
         self._pending = None     # marched-but-not-consumed batch
         self.last = {}
@@ -166,7 +169,18 @@ class Trainer:
                 # backward only over the samples up to each ray's early stop (the rest have zero gradient):
                 # composite_fw counted them per ray, the scan above placed them, composite_bw lists them
                 active = torch.empty(S, dtype=torch.int32, device=dev)
-                call("ngp_composite_train_bw", ptr(dL_dopacity), ptr(dL_ddepth), ptr(dL_drgb), None, ptr(sigmas), ptr(rgbs), ptr(ws),
+                dL_dws = dist = None
+                if self.lambda_distortion > 0:
+                    # losses.py:6-37,58-59: lambda * distortion per ray, mean over rays; its gradient enters the composite as dL/dws
+                    dist = torch.empty(n, **f32); ws_incl = torch.empty(S, **f32); wts_incl = torch.empty(S, **f32)
+                    call("ngp_distortion_loss_fw", ptr(ws), ptr(deltas), ptr(ts), ptr(rays_a), n, S, ptr(dist), ptr(ws_incl), ptr(wts_incl), stream())
+                    seed_val = self.lambda_distortion / n * self.grad_scale
+                    if self._dist_seed is None or self._dist_seed[0] != (n, seed_val):
+                        self._dist_seed = ((n, seed_val), torch.full((n,), seed_val, **f32))
+                    dL_dws = torch.empty(S, **f32)
+                    call("ngp_distortion_loss_bw", ptr(self._dist_seed[1]), ptr(ws_incl), ptr(wts_incl), ptr(ws), ptr(deltas), ptr(ts),
+                         ptr(rays_a), n, S, ptr(dL_dws), stream())
+                call("ngp_composite_train_bw", ptr(dL_dopacity), ptr(dL_ddepth), ptr(dL_drgb), ptr(dL_dws), ptr(sigmas), ptr(rgbs), ptr(ws),
                      ptr(deltas), ptr(ts), ptr(rays_a), ptr(opacity), ptr(depth), ptr(rgb), self.T_threshold, n, S,
                      ptr(dL_dsigmas), ptr(dL_drgbs), ptr(ray_offs), ptr(active), stream())
                 self._mark("composite_bw")
@@ -189,7 +203,8 @@ class Trainer:
                 self.opt.step(grad_scale=self.grad_scale)
                 self._mark("adam")
             self.global_step += 1
-            self.last = dict(stats=stats, rm_samples=S, total=total, n_rays=n, rgb=rgb, opacity=opacity)
+            self.last = dict(stats=stats, rm_samples=S, total=total, n_rays=n, rgb=rgb, opacity=opacity,
+                             distortion=dist if S > 0 else None)
             if next_batch is not None and next_needs_update:
                 self._maybe_update_grid()
                 self._mark("grid_update")
@@ -201,6 +216,8 @@ class Trainer:
         st = self.last["stats"].tolist()
         n = self.last["n_rays"]
         mse = st[1] / (3 * n)
+        if self.last.get("distortion") is not None:
+            st[0] += self.lambda_distortion * float(self.last["distortion"].mean())
         return dict(loss=st[0], psnr=-10 * math.log10(max(mse, 1e-12)), rm_s=self.last["rm_samples"] / n,
                     vr_s=float(self.last["total"].sum().item()) / n)
 

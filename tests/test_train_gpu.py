@@ -91,7 +91,8 @@ def test_render_train_and_test_paths():
     assert isinstance(out["rgb"], np.ndarray)
 
 
-def test_fused_step_equals_autograd_step():
+@pytest.mark.parametrize("lambda_distortion", [0.0, 1e-2])
+def test_fused_step_equals_autograd_step(lambda_distortion):
     """Trainer.step (direct native calls, compacted backward) and Trainer.step_autograd (render() +
     NeRFLoss + torch autograd) produce the same gradients from the same state.  Gradients are
     captured instead of compared after Adam: the first Adam step moves a parameter by lr*sign(g),
@@ -102,7 +103,7 @@ def test_fused_step_equals_autograd_step():
     grads = []
     for mode in ("native", "autograd"):
         m = make_model(seed=11)
-        tr = Trainer(m)
+        tr = Trainer(m, lambda_distortion=lambda_distortion)
         captured = {}
 
         def capture(grad_scale=1.0, found_inf=None, m=m, captured=captured):
@@ -335,37 +336,42 @@ def test_native_occupancy_update_matches_reference_semantics():
 
 
 def test_pose_gradients_flow_through_the_field():
-    """--optimize_ext (train.py:86-89,117-122): rays that require grad get dL/drays_o, dL/drays_d through
-    RayMarcher.backward, the hash grid's input gradient and the SH encoding.  Checked against a central
-    finite difference of the loss along a random perturbation of the ray origins (the field is smooth
-    at the f16 level only: tolerance 15 % on the directional derivative)."""
-    from ngp_pl_amd.rendering import render
-    from ngp_pl_amd.trainer import Trainer
-    m = make_model(seed=8)
-    tr = Trainer(m)
-    bs = [batch(4096, seed=500 + i) for i in range(4)]
-    for it in range(150):
-        tr.step(*bs[it % 4])
-    ro, rd, gt = batch(2048, seed=91)
-    torch.manual_seed(0)
-
-    def loss_of(o, d):
-        torch.manual_seed(1)                                              # same marching jitter in every evaluation
-        res = render(m, o, d, test_time=False)
-        return ((res["rgb"] - gt) ** 2).mean()
-    o = ro.clone().requires_grad_(True); d = rd.clone().requires_grad_(True)
-    loss = loss_of(o, d)
-    loss.backward()
-    assert o.grad is not None and d.grad is not None
-    assert torch.isfinite(o.grad).all() and torch.isfinite(d.grad).all() and o.grad.abs().sum() > 0 and d.grad.abs().sum() > 0
-    # a common translation of all origins (what a pose offset dT does): directional derivative vs finite difference
-    v = torch.tensor([0.6, -0.5, 0.62], device="cuda")
-    analytic = float((o.grad * v).sum())
-    eps = 2e-3
+    """--optimize_ext (train.py:86-89,117-122): sample positions / directions that require grad get
+    dL/dx through the hash grid's input gradient and dL/dd through the SH encoding (module path of
+    NGP.forward).  Parity against autograd of the fp32 oracle field with the same parameters and the
+    kernels' f16 rounding points (straight-through); RayMarcher.backward then sums these per ray
+    (test_raymarcher_backward_is_ray_indexed)."""
+    from oracle import tcnn_oracle as T
+    f = T.Field(scale=0.5, seed=7)
+    g = torch.Generator().manual_seed(8)
+    f.table = ((torch.rand(f.meta.total, 2, generator=g) * 2 - 1) * 0.8).half().float()
+    f.density_w = (f.density_w * 1.5).half().float()
+    f.rgb_w = (f.rgb_w * 1.5).half().float()
+    m = make_model(seed=0)
     with torch.no_grad():
-        lp = float(loss_of(ro + eps * v, rd)); lm = float(loss_of(ro - eps * v, rd))
-    numeric = (lp - lm) / (2 * eps)
-    assert abs(analytic - numeric) <= 0.15 * abs(numeric) + 1e-4, (analytic, numeric)
+        m.xyz_encoder.params.copy_(torch.cat([f.density_w, f.table.reshape(-1)]).cuda())
+        m.rgb_net.params.copy_(f.rgb_w.cuda())
+    n = 3000
+    x = torch.rand(n, 3, generator=g) - 0.5
+    d = torch.randn(n, 3, generator=g) * 1.3
+    gs = torch.randn(n, generator=g) * 1e-2; gc = torch.randn(n, 3, generator=g)
+    xo = x.clone().requires_grad_(True); do = d.clone().requires_grad_(True)
+    so, co, _ = f.forward(xo, do, quantize=True)
+    ((so * gs).sum() + (co * gc).sum()).backward()
+    xn = x.cuda().requires_grad_(True); dn = d.cuda().requires_grad_(True)
+    sn, cn = m(xn, dn)
+    ((sn.float() * gs.cuda()).sum() + (cn.float() * gc.cuda()).sum()).backward()
+    assert xn.grad is not None and dn.grad is not None
+    for got, want, name in ((xn.grad, xo.grad, "dL/dx"), (dn.grad, do.grad, "dL/dd")):
+        scale = want.abs().max().item()
+        err = (got.cpu() - want).abs()
+        # f16 transport of dL/dh, dL/dfeat and dL/dSH between the modules: 3 % of the largest component,
+        # and no more than 1 % of the samples (ReLU-boundary flips of the f16 activations) beyond 1 %
+        assert err.max().item() < 3e-2 * scale, (name, err.max().item(), scale)
+        assert (err.max(dim=1).values > 1e-2 * scale).float().mean().item() < 1e-2, name
+    # the fused node is used again as soon as the rays carry no gradient
+    s2, c2 = m(x.cuda(), d.cuda())
+    assert s2.grad_fn is not None and type(s2.grad_fn).__name__.startswith("_FusedField")
 
 
 def test_raymarcher_backward_is_ray_indexed():
