@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (must precede the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libngp_hip.so")
+LIB_PATH = os.environ.get("NGP_HIP_LIB") or os.path.join(_HERE, "csrc", "libngp_hip.so")   # override: A/B builds while profiling
 
 P = C.c_void_p
 I = C.c_int
