@@ -241,6 +241,18 @@ int ngp_hashgrid_bwd_sliced(const float* x, const float* xyz_min, const float* x
                             const ngp_half* dfeats /* [L][S] half2 */, const ngp_grid_meta* meta,
                             int n_samples, const int32_t* active_idx, const int32_t* n_active,
                             ngp_half* grad_table, ngp_stream_t stream);
+/* ngp_hashgrid_bwd_sliced with a binning pre-pass: one cheap pass per hashed level writes, per
+ * slice, the list of samples whose corners touch it (a sample touches ~4 of a level's 19 slices),
+ * and every slice owner then walks its own list instead of all samples.  Same result (f16
+ * accumulation order aside), same arguments plus a scratch of
+ * ngp_hashgrid_bwd_binned_workspace_bytes(meta, n_samples) bytes. */
+size_t ngp_hashgrid_bwd_binned_workspace_bytes(const ngp_grid_meta* meta, int n_samples);
+int ngp_hashgrid_bwd_binned(const float* x, const float* xyz_min, const float* xyz_max,
+                            const ngp_half* dfeats, const ngp_grid_meta* meta, int n_samples,
+                            const int32_t* active_idx, const int32_t* n_active,
+                            void* workspace, size_t workspace_bytes,
+                            ngp_half* grad_table, ngp_stream_t stream);
+
 /* The samples that can carry gradient after compositing: the first min(N, total_samples+1) of
  * every ray (later ones have w = 0 exactly, volumerendering.cu:41).  Writes their ids in ray
  * order to active_idx (capacity S) and the count to n_active (device i32); ray_offsets (R) i32

@@ -76,6 +76,7 @@ _PROTOS = {
     "ngp_abi_version": [],
     "ngp_hashgrid_fwd_n": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P],
     "ngp_field_fwd_n": [P, P, P, P, I, P, P, P, P, P],
+    "ngp_hashgrid_bwd_binned": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P, C.c_size_t, P, P],
     "ngp_hashgrid_bwd_input": [P, P, P, P, P, C.POINTER(GridMeta), I, F, P, P],
     "ngp_sh4_bwd": [P, P, I, F, P, P],
     "ngp_density_fwd_scatter": [P, P, I, P, P, P],
@@ -104,6 +105,8 @@ def lib():
         h.ngp_build_arch.restype = C.c_char_p
         h.ngp_render_test_workspace_bytes.argtypes = [I, I, F]
         h.ngp_render_test_workspace_bytes.restype = C.c_size_t
+        h.ngp_hashgrid_bwd_binned_workspace_bytes.argtypes = [C.POINTER(GridMeta), I]
+        h.ngp_hashgrid_bwd_binned_workspace_bytes.restype = C.c_size_t
         h.ngp_occupancy_update_workspace_bytes.argtypes = [I, I]
         h.ngp_occupancy_update_workspace_bytes.restype = C.c_size_t
         _lib = h
@@ -111,7 +114,8 @@ def lib():
 
 
 def exported_symbols():
-    return list(_PROTOS) + ["ngp_build_arch", "ngp_render_test_workspace_bytes", "ngp_occupancy_update_workspace_bytes"]
+    return list(_PROTOS) + ["ngp_build_arch", "ngp_render_test_workspace_bytes", "ngp_occupancy_update_workspace_bytes",
+                                  "ngp_hashgrid_bwd_binned_workspace_bytes"]
 
 
 class NgpError(RuntimeError):

@@ -1,0 +1,366 @@
+// Hash-grid backward w.r.t. the table, binned variant (reference semantics: tiny-cuda-nn's
+// kernel_grid_backward scatter-add as configured at /root/reference/models/networks.py:36-48).
+//
+// What was measured on MI355X (profiles/r01_hashgrid_bwd_experiments.txt, tools/lds_atomic_bench.hip):
+//  * a slice owner of the one-pass kernel (hashgrid_bwd_sliced_kernel) walks ALL samples of its
+//    level to find the 1/19 of the corner updates that land in its slice, and it issues 8 LDS
+//    float atomics per wave and sample; both cost about the same (VALU ~130 us, LDS ~106 us);
+//  * an LDS FLOAT atomic costs ~3 cycles per active lane, an LDS 64-bit INTEGER atomic ~8-12
+//    cycles per wave instruction whatever the lane count (16x cheaper on a full wave, and 4x
+//    cheaper when all lanes hit the same address);
+//  * the 8 corners of a sample fall into only ~4 slices of a level (x and x+1 are neighbours in
+//    the table, the four (y,z) combinations scatter).
+// Hence:
+//  1. a binning pass writes, per (level, slice), the list of samples that touch the slice;
+//  2. slice owners walk only their list and accumulate in 64-bit fixed point (2^-24 units,
+//     exact sums, deterministic: integer adds commute -- the f16 atomics of the one-pass kernel
+//     and of tiny-cuda-nn round after every add, in arrival order);
+//  3. slices are small (16 B per entry: 6912 entries in 108 KiB of LDS) and numerous (~860), so
+//     they are tasks pulled from a queue by 256 persistent workgroups, largest first.
+// Levels with few slices (the coarse dense ones) additionally split their lists over K tasks whose
+// partial sums are merged with global packed-f16 atomics (a few hundred thousand per step).
+#include "hashgrid_common.h"
+#include <hip/hip_fp16.h>
+
+using namespace ngp_grid;
+
+namespace {
+
+constexpr uint32_t SLICE2 = 6912;            // entries per task: 2 x int64 each -> 108 KiB of LDS
+constexpr int MAX_SLICES = 80;               // ceil(2^19 / SLICE2) = 76
+constexpr float FIX_SCALE = 16777216.0f;     // 2^24 units per 1.0 (f16 subnormal spacing is 2^-24)
+constexpr int BIN_THREADS = 1024;            // samples per binning workgroup ("chunk")
+constexpr int CHUNK_SLOTS = BIN_THREADS * 8; // list entries a chunk can produce for one level (<= 8 slices per sample)
+constexpr int DIR_STRIDE = MAX_SLICES + 1;
+constexpr int MAX_CHUNKS = 1024;             // the slice owners scan the chunk directory in one pass
+constexpr int APPLY_THREADS = 1024;
+
+struct BinPlan {
+    int32_t n_levels;
+    int32_t n_slices[NGP_MAX_LEVELS];
+    int32_t k_split[NGP_MAX_LEVELS];
+    int32_t first_task[NGP_MAX_LEVELS + 1];  // tasks are numbered level by level in `order`
+    int32_t order[NGP_MAX_LEVELS];           // levels, most expensive tasks first
+    int32_t n_tasks, n_chunks;
+};
+
+// Lists are stored chunk-wise: the binning workgroup of (level, chunk) owns the fixed slot
+// pool[(level * n_chunks + chunk) * CHUNK_SLOTS ...] and writes its entries there grouped by slice;
+// dir[(level * n_chunks + chunk) * DIR_STRIDE + s] is where slice s starts inside the slot
+// (dir[.. + n_slices] = entries used).  No atomics, no capacity to exceed, deterministic.
+struct BinWs {
+    int32_t* queue;      // [0] next task
+    int32_t* dir;
+    int32_t* pool;
+};
+
+// ---- pass 1: which slices does a sample touch ------------------------------------------------
+__global__ void __launch_bounds__(BIN_THREADS)
+bin_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const float* __restrict__ xyz_max,
+           const half2_t* __restrict__ dfeats, GridMeta meta, BinPlan plan, BinWs ws, int n_samples,
+           const int32_t* __restrict__ active, const int32_t* __restrict__ n_active) {
+    __shared__ int s_cnt[MAX_SLICES], s_pre[MAX_SLICES + 1];
+    __shared__ int32_t s_stage[CHUNK_SLOTS];
+    const int n_chunks = plan.n_chunks;
+    const int level = (int)blockIdx.x / n_chunks;
+    const int chunk = (int)blockIdx.x - level * n_chunks;
+    const int n = n_active ? min(*n_active, n_samples) : n_samples;
+    const int ns = plan.n_slices[level];
+    int32_t* __restrict__ dir = ws.dir + (size_t)blockIdx.x * DIR_STRIDE;
+    if (chunk * BIN_THREADS >= n) {                                // nothing here: an empty directory row
+        for (int i = threadIdx.x; i <= ns; i += BIN_THREADS) dir[i] = 0;
+        return;
+    }
+    for (int i = threadIdx.x; i < ns; i += BIN_THREADS) s_cnt[i] = 0;
+    __syncthreads();
+    const int j = chunk * BIN_THREADS + (int)threadIdx.x;
+    int sid[8], loc[8];
+    int n_mine = 0;
+    if (j < n) {
+        const half2_t g = dfeats[(size_t)level * n_samples + j];
+        if (g[0] != (_Float16)0 || g[1] != (_Float16)0) {
+            const int src = active ? active[j] : j;
+            const uint32_t res = meta.resolution[level];
+            const uint32_t size = meta.offset[level + 1] - meta.offset[level];
+            const Box box = load_box(xyz_min, xyz_max);
+            const float xin[3] = {x[3 * (size_t)src], x[3 * (size_t)src + 1], x[3 * (size_t)src + 2]};
+            uint32_t p[3], idx[8]; float f[3];
+            cell_of_loaded(xin, box, meta.scale[level], p, f);
+            if (level_is_hashed(res, size)) corner_indices<true>(p, res, size, idx);
+            else corner_indices<false>(p, res, size, idx);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int sl = (int)(idx[c] / SLICE2);
+                bool dup = false;
+#pragma unroll
+                for (int q = 0; q < c; ++q) dup = dup || (q < n_mine && sid[q] == sl);
+                if (!dup) {
+                    // compact the distinct slice ids to the front (n_mine is small: typically 4)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) if (q == n_mine) sid[q] = sl;
+                    ++n_mine;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) if (q < n_mine) loc[q] = atomicAdd(&s_cnt[sid[q]], 1);
+    __syncthreads();
+    if (threadIdx.x < 64) {                       // exclusive prefix of the per-slice counts (ns <= 80): two wave scans
+        int run = 0;
+        for (int b0 = 0; b0 < ns; b0 += 64) {
+            const int i = b0 + (int)threadIdx.x;
+            const int v = (i < ns) ? s_cnt[i] : 0;
+            int incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if ((int)threadIdx.x >= o) incl += u; }
+            if (i < ns) s_pre[i] = run + incl - v;
+            run += __shfl(incl, 63, 64);
+        }
+        if (threadIdx.x == 0) s_pre[ns] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) if (q < n_mine) s_stage[s_pre[sid[q]] + loc[q]] = j;
+    __syncthreads();
+    const int total = s_pre[ns];
+    int32_t* __restrict__ slot = ws.pool + (size_t)blockIdx.x * CHUNK_SLOTS;
+    for (int i = threadIdx.x; i < total; i += BIN_THREADS) slot[i] = s_stage[i];
+    for (int i = threadIdx.x; i <= ns; i += BIN_THREADS) dir[i] = s_pre[i];
+}
+
+// ---- pass 2: slice owners -------------------------------------------------------------------
+__device__ __forceinline__ void lds_add_fixed(long long* acc, float v) {
+    const int q = __float2int_rn(v * FIX_SCALE);                   // saturates; |w*g| < 128 by a wide margin
+    atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)(long long)q);   // ds_add_u64
+}
+
+// entry i of the slice's (virtual, concatenated) list -> sample position j.
+// s_first[c] = index of chunk c's first entry, s_src[c] = where chunk c's segment starts in the pool.
+__device__ __forceinline__ int list_entry(const int32_t* __restrict__ pool, const int* s_first, const long long* s_src, int n_chunks, int i) {
+    int lo = 0, hi = n_chunks;                    // last chunk with s_first <= i
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_first[mid] <= i) lo = mid; else hi = mid; }
+    return pool[s_src[lo] + (i - s_first[lo])];
+}
+
+// BLOCKED = false: thread t takes entries t, t + 1024, ... (neighbouring lanes work on neighbouring
+// samples: coalesced gradient / position streams).  Right for the hashed levels.
+// BLOCKED = true: thread t takes a contiguous run of entries.  On the dense coarse levels dozens of
+// consecutive samples of a ray sit in the same cell, i.e. neighbouring lanes would hit the same 8
+// accumulators in the same instruction (measured: an LDS add_u64 with 8 lanes per address costs
+// 64 cycles instead of 11.5); with contiguous runs per thread the lanes of a wave are a whole run
+// apart, on different rays.
+template <bool HASHED, bool BLOCKED>
+__device__ __forceinline__ void apply_list(long long* lds, uint32_t lo, uint32_t len, uint32_t res, uint32_t size, float scale,
+                                           const float* __restrict__ x, const Box& box, const half2_t* __restrict__ g_level,
+                                           const int32_t* __restrict__ active, const int32_t* __restrict__ pool,
+                                           const int* s_first, const long long* s_src, int n_chunks, int begin, int end) {
+    constexpr int B = BLOCKED ? 4 : 8;
+    const int n = end - begin;
+    const int run = (n + APPLY_THREADS - 1) / APPLY_THREADS;               // BLOCKED: entries per thread
+    const int first = BLOCKED ? begin + (int)threadIdx.x * run : begin + (int)threadIdx.x;
+    const int step = BLOCKED ? 1 : APPLY_THREADS;
+    const int last = BLOCKED ? min(first + run, end) : end;                // exclusive bound of this thread's entries
+    const int trips = BLOCKED ? (run + B - 1) / B : (n + B * APPLY_THREADS - 1) / (B * APPLY_THREADS);
+    for (int trip = 0; trip < trips; ++trip) {
+        const int base = first + trip * B * step;
+        int jj[B], src[B]; half2_t g[B]; float px[B][3];
+#pragma unroll
+        for (int b = 0; b < B; ++b) jj[b] = list_entry(pool, s_first, s_src, n_chunks, max(min(base + b * step, end - 1), begin));   // clamp: unconditional loads
+#pragma unroll
+        for (int b = 0; b < B; ++b) { g[b] = g_level[jj[b]]; src[b] = active ? active[jj[b]] : jj[b]; }
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const float* __restrict__ xp = x + 3 * (size_t)src[b];
+            px[b][0] = xp[0]; px[b][1] = xp[1]; px[b][2] = xp[2];
+        }
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            if (base + b * step >= last) break;
+            const float g0 = (float)g[b][0], g1 = (float)g[b][1];
+            uint32_t p[3], idx[8]; float f[3];
+            cell_of_loaded(px[b], box, scale, p, f);
+            corner_indices<HASHED>(p, res, size, idx);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint32_t local = idx[c] - lo;
+                if (local < len) {
+                    const float w = corner_weight(c, f);
+                    lds_add_fixed(lds + 2 * local, w * g0);
+                    lds_add_fixed(lds + 2 * local + 1, w * g1);
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(APPLY_THREADS)
+apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const float* __restrict__ xyz_max,
+             const half2_t* __restrict__ dfeats, GridMeta meta, BinPlan plan, BinWs ws, int n_samples,
+             const int32_t* __restrict__ active, half2_t* __restrict__ grad_table) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    long long* lds = reinterpret_cast<long long*>(smem_raw);
+    __shared__ int s_task, s_wave[16];
+    __shared__ int s_first[MAX_CHUNKS + 1];
+    __shared__ long long s_src[MAX_CHUNKS];
+    const Box box = load_box(xyz_min, xyz_max);
+    const int n_chunks = plan.n_chunks;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (;;) {
+        __syncthreads();                                           // previous task's LDS reads are done
+        if (tid == 0) s_task = atomicAdd(&ws.queue[0], 1);
+        __syncthreads();
+        const int task = s_task;
+        if (task >= plan.n_tasks) return;
+        int oi = 0;
+        while (task >= plan.first_task[oi + 1]) ++oi;
+        const int level = plan.order[oi];
+        const int K = plan.k_split[level];
+        const int t = task - plan.first_task[oi];
+        const int slice = t / K, part = t - slice * K;
+        const uint32_t res = meta.resolution[level];
+        const uint32_t size = meta.offset[level + 1] - meta.offset[level];
+        const uint32_t lo = (uint32_t)slice * SLICE2;
+        const uint32_t len = min(SLICE2, size - lo);
+        // directory of this slice: per chunk (start in its slot, count) -> exclusive prefix over chunks
+        int cnt = 0;
+        if (tid < n_chunks) {
+            const size_t row = (size_t)level * n_chunks + tid;
+            const int32_t* __restrict__ d = ws.dir + row * DIR_STRIDE + slice;
+            const int a = d[0];
+            cnt = d[1] - a;
+            s_src[tid] = (long long)row * CHUNK_SLOTS + a;
+        }
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+        if (lane == 63) s_wave[wave] = incl;
+        for (uint32_t k = tid; k < 2 * len; k += APPLY_THREADS) lds[k] = 0;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += s_wave[w];
+        if (tid < n_chunks) s_first[tid] = woff + incl - cnt;
+        if (tid == APPLY_THREADS - 1) s_first[n_chunks] = woff + incl;
+        __syncthreads();
+        const int total = s_first[n_chunks];
+        const int per = (total + K - 1) / K;
+        const int begin = min(part * per, total), end = min(begin + per, total);
+        const half2_t* __restrict__ g_level = dfeats + (size_t)level * n_samples;
+        if (end > begin) {
+            if (level_is_hashed(res, size)) apply_list<true, false>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, ws.pool, s_first, s_src, n_chunks, begin, end);
+            else apply_list<false, true>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, ws.pool, s_first, s_src, n_chunks, begin, end);
+        }
+        __syncthreads();
+        half2_t* __restrict__ out = grad_table + meta.offset[level] + lo;
+        const float inv = 1.0f / FIX_SCALE;
+        for (uint32_t k = tid; k < len; k += APPLY_THREADS) {
+            half2_t v;
+            v[0] = (_Float16)((float)lds[2 * k] * inv); v[1] = (_Float16)((float)lds[2 * k + 1] * inv);
+            if (K == 1) {
+                out[k] = v;
+            } else if (v[0] != (_Float16)0 || v[1] != (_Float16)0) {   // merge the K partial sums (range zero-filled by the host)
+                __half2 hv; __builtin_memcpy(&hv, &v, 4);
+                unsafeAtomicAdd(reinterpret_cast<__half2*>(out) + k, hv);
+            }
+        }
+    }
+}
+
+struct BinLayout { size_t queue, dir, pool, bytes; };
+
+// Plan: slices of SLICE2 entries; the levels with few slices (coarse, dense) split their lists over
+// K tasks so that every level yields at least ~16 tasks.
+bool make_plan(const ngp_grid_meta* meta, int n_samples, BinPlan& P, BinLayout& L) {
+    P.n_levels = meta->n_levels;
+    P.n_chunks = ngp_div_up(n_samples > 0 ? n_samples : 1, BIN_THREADS);
+    double cost[NGP_MAX_LEVELS];
+    for (int l = 0; l < NGP_MAX_LEVELS; ++l) { P.n_slices[l] = 0; P.k_split[l] = 1; P.order[l] = l; cost[l] = 0; }
+    for (int l = 0; l < meta->n_levels; ++l) {
+        const uint32_t size = meta->offset[l + 1] - meta->offset[l], res = meta->resolution[l];
+        const bool hashed = (uint64_t)res * res * res > size;
+        const int ns = (int)((size + SLICE2 - 1) / SLICE2);
+        P.n_slices[l] = ns;
+        P.k_split[l] = hashed ? 1 : (16 + ns - 1) / ns;
+        // relative cost of one task: a dense slice (a slab of the grid) gets all 8 corners of its samples, a hashed one ~2
+        cost[l] = hashed ? 1.0 : 4.0;
+    }
+    for (int a = 0; a < meta->n_levels; ++a)      // order levels by decreasing task cost (stable)
+        for (int b = a + 1; b < meta->n_levels; ++b)
+            if (cost[P.order[b]] > cost[P.order[a]]) { const int t = P.order[a]; P.order[a] = P.order[b]; P.order[b] = t; }
+    int nt = 0;
+    for (int a = 0; a < meta->n_levels; ++a) { P.first_task[a] = nt; nt += P.n_slices[P.order[a]] * P.k_split[P.order[a]]; }
+    for (int a = meta->n_levels; a <= NGP_MAX_LEVELS; ++a) P.first_task[a] = nt;
+    P.n_tasks = nt;
+    const size_t rows = (size_t)meta->n_levels * P.n_chunks;
+    L.queue = 0;
+    L.dir = 256;
+    L.pool = L.dir + (rows * DIR_STRIDE * 4 + 255) / 256 * 256;
+    L.bytes = L.pool + rows * CHUNK_SLOTS * 4;
+    return P.n_chunks <= MAX_CHUNKS;
+}
+
+}  // namespace
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+size_t ngp_hashgrid_bwd_binned_workspace_bytes(const ngp_grid_meta* meta, int n_samples) {
+    if (!meta || n_samples < 0 || meta->n_features != 2 || meta->n_levels < 1 || meta->n_levels > NGP_MAX_LEVELS) return 0;
+    BinPlan P; BinLayout L;
+    if (!make_plan(meta, n_samples, P, L)) return 0;               // more than MAX_CHUNKS * 1024 samples: use ngp_hashgrid_bwd_sliced
+    return L.bytes;
+}
+
+int ngp_hashgrid_bwd_binned(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* dfeats,
+                            const ngp_grid_meta* meta, int n_samples, const int32_t* active_idx,
+                            const int32_t* n_active, void* workspace, size_t workspace_bytes,
+                            ngp_half* grad_table, ngp_stream_t stream) {
+    if (n_samples < 0 || !meta || meta->n_features != 2 || meta->n_levels < 1 || meta->n_levels > NGP_MAX_LEVELS) return NGP_EINVAL;
+    NGP_CHECK_PTR(grad_table); NGP_CHECK_PTR(workspace);
+    if (n_samples > 0) { NGP_CHECK_PTR(x); NGP_CHECK_PTR(xyz_min); NGP_CHECK_PTR(xyz_max); NGP_CHECK_PTR(dfeats); }
+    if ((active_idx == nullptr) != (n_active == nullptr)) return NGP_EINVAL;
+    BinPlan P; BinLayout L;
+    if (!make_plan(meta, n_samples, P, L)) return NGP_EUNSUP;
+    if (workspace_bytes < L.bytes) return NGP_EINVAL;
+    for (int l = 0; l < meta->n_levels; ++l) {
+        const uint32_t size = meta->offset[l + 1] - meta->offset[l], res = meta->resolution[l];
+        if ((uint64_t)res * res * res > size && (size & (size - 1)) != 0) return NGP_EUNSUP;   // corner_indices masks instead of %
+        if (P.n_slices[l] > MAX_SLICES) return NGP_EUNSUP;
+    }
+    hipStream_t st = ngp_stream(stream);
+    char* wsb = static_cast<char*>(workspace);
+    BinWs ws;
+    ws.queue = reinterpret_cast<int32_t*>(wsb + L.queue);
+    ws.dir = reinterpret_cast<int32_t*>(wsb + L.dir);
+    ws.pool = reinterpret_cast<int32_t*>(wsb + L.pool);
+    hipError_t e = hipMemsetAsync(ws.queue, 0, 256, st);
+    if (e != hipSuccess) return (int)e;
+    // K-split levels are merged by atomics: their range of the gradient table starts from zero
+    for (int l = 0; l < meta->n_levels; ++l) {
+        if (P.k_split[l] > 1) {
+            int m = l;
+            while (m + 1 < meta->n_levels && P.k_split[m + 1] > 1) ++m;
+            e = hipMemsetAsync(reinterpret_cast<char*>(grad_table) + (size_t)meta->offset[l] * 4, 0,
+                               (size_t)(meta->offset[m + 1] - meta->offset[l]) * 4, st);
+            if (e != hipSuccess) return (int)e;
+            l = m;
+        }
+    }
+    const GridMeta dm = to_dev_meta(meta);
+    bin_kernel<<<dim3(meta->n_levels * P.n_chunks), dim3(BIN_THREADS), 0, st>>>(
+        x, xyz_min, xyz_max, (const half2_t*)dfeats, dm, P, ws, n_samples, active_idx, n_active);
+    constexpr int smem = (int)(SLICE2 * 2 * sizeof(long long));
+    static bool attr_set = false;
+    if (!attr_set) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int n_wg = P.n_tasks < 256 ? P.n_tasks : 256;
+    apply_kernel<<<dim3(n_wg), dim3(APPLY_THREADS), smem, st>>>(
+        x, xyz_min, xyz_max, (const half2_t*)dfeats, dm, P, ws, n_samples, active_idx, (half2_t*)grad_table);
+    return NGP_LAUNCH_RESULT();
+}
+
+#pragma GCC visibility pop
+}  // extern "C"

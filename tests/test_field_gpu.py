@@ -90,7 +90,7 @@ def test_hashgrid_forward(lib, field):
     assert torch.equal(back, feats)
 
 
-@pytest.mark.parametrize("mode", ["sliced", "atomic_f16", "atomic_f32"])
+@pytest.mark.parametrize("mode", ["sliced", "binned", "atomic_f16", "atomic_f32"])
 def test_hashgrid_backward(lib, field, mode):
     meta = native_meta(lib)
     n = 30000
@@ -111,6 +111,12 @@ def test_hashgrid_backward(lib, field, mode):
     if mode == "sliced":
         grad = torch.full((field.meta.total, 2), float("nan"), dtype=torch.float16, device="cuda")   # must be fully overwritten
         lib.call("ngp_hashgrid_bwd_sliced", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), n, None, None, lib.ptr(grad), lib.stream())
+    elif mode == "binned":
+        grad = torch.full((field.meta.total, 2), float("nan"), dtype=torch.float16, device="cuda")
+        nbytes = lib.lib().ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(meta), n)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        lib.call("ngp_hashgrid_bwd_binned", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), n, None, None,
+                 lib.ptr(ws), nbytes, lib.ptr(grad), lib.stream())
     else:
         f32 = mode == "atomic_f32"
         grad = torch.zeros(field.meta.total, 2, dtype=torch.float32 if f32 else torch.float16, device="cuda")

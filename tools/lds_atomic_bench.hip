@@ -5,13 +5,13 @@
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 #define AS3 __attribute__((address_space(3)))
 
-template <int MODE, int ACTIVE>
+template <int MODE, int ACTIVE, int GROUP = 1>
 __global__ void __launch_bounds__(1024) k(uint32_t seed, int iters, float* out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* lds = (uint32_t*)smem;
     for (int i = threadIdx.x; i < 32768; i += blockDim.x) lds[i] = 0;
     __syncthreads();
-    uint32_t r = seed + threadIdx.x * 2654435761u;
+    uint32_t r = seed + (threadIdx.x / GROUP) * 2654435761u;      // GROUP consecutive lanes share their addresses (same-address conflicts)
     const bool act = (threadIdx.x & 63) < ACTIVE;
     half2_t hv = {(_Float16)0.001f, (_Float16)0.002f};
     for (int i = 0; i < iters; ++i) {
@@ -24,6 +24,8 @@ __global__ void __launch_bounds__(1024) k(uint32_t seed, int iters, float* out) 
                 else if (MODE == 1) atomicAdd((float*)(lds + idx), 0.001f);
                 else if (MODE == 2) atomicAdd(lds + idx, 3u);
                 else if (MODE == 3) lds[idx] = r;          // plain store for reference
+                else if (MODE == 4) atomicAdd((unsigned long long*)(lds + (idx & ~1u)), (unsigned long long)r);   // ds_add_u64
+                else if (MODE == 5) { atomicAdd(lds + (idx & ~1u), r); atomicAdd(lds + (idx | 1u), r >> 3); }   // two ds_add_u32
             }
         }
     }
@@ -32,10 +34,11 @@ __global__ void __launch_bounds__(1024) k(uint32_t seed, int iters, float* out) 
     if (s == 12345.f) out[0] = s;
 }
 
-template <int MODE, int ACTIVE>
+template <int MODE, int ACTIVE, int GROUP = 1>
 void run(const char* name) {
     float* out; hipMalloc(&out, 4);
-    auto kern = k<MODE, ACTIVE>;
+    auto kern = k<MODE, ACTIVE, GROUP>;
+    if (GROUP > 1) printf("[%d lanes per address] ", GROUP);
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     const int iters = 200;
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -54,5 +57,9 @@ int main() {
     run<1, 64>("add_f32"); run<1, 4>("add_f32");
     run<2, 64>("add_u32"); run<2, 4>("add_u32");
     run<3, 64>("store_b32"); run<3, 4>("store_b32");
+    run<4, 64>("add_u64"); run<4, 16>("add_u64"); run<4, 4>("add_u64"); run<4, 2>("add_u64");
+    run<5, 64>("2x add_u32"); run<5, 4>("2x add_u32");
+    run<0, 2>("pk_add_f16"); run<2, 16>("add_u32"); run<2, 2>("add_u32");
+    run<4, 64, 8>("add_u64"); run<4, 64, 64>("add_u64"); run<0, 64, 8>("pk_add_f16"); run<0, 64, 64>("pk_add_f16"); run<2, 64, 8>("add_u32");
     return 0;
 }

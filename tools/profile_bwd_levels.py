@@ -36,6 +36,9 @@ def bench(fn, iters=10):
 total = meta.offset[16]
 g16 = torch.zeros(total, 2, dtype=torch.half, device=dev)
 dfe = (torch.randn(16, S, 2, device=dev) * 1e-2).half()
+nb = _lib.lib().ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(meta), S)
+ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+print("binned, all levels: %.1f us (workspace %.0f MB)" % (bench(lambda: call("ngp_hashgrid_bwd_binned", ptr(x), ptr(mn), ptr(mx), ptr(dfe), C.byref(meta), S, None, None, ptr(ws), nb, ptr(g16), stream())), nb / 1e6))
 print("all levels: %.1f us" % bench(lambda: call("ngp_hashgrid_bwd_sliced", ptr(x), ptr(mn), ptr(mx), ptr(dfe), C.byref(meta), S, None, None, ptr(g16), stream())))
 for l in range(16):
     m1 = GridMeta()
@@ -46,4 +49,6 @@ for l in range(16):
     m1.resolution[0] = meta.resolution[l]; m1.scale[0] = meta.scale[l]
     d1 = dfe[l].contiguous()
     us = bench(lambda: call("ngp_hashgrid_bwd_sliced", ptr(x), ptr(mn), ptr(mx), ptr(d1), C.byref(m1), S, None, None, ptr(g16), stream()))
-    print("level %2d res %4d size %7d: %8.1f us" % (l, meta.resolution[l], m1.offset[1], us))
+    nb1 = _lib.lib().ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(m1), S)
+    usb = bench(lambda: call("ngp_hashgrid_bwd_binned", ptr(x), ptr(mn), ptr(mx), ptr(d1), C.byref(m1), S, None, None, ptr(ws), max(nb1, 1), ptr(g16), stream())) if nb1 <= nb else float("nan")
+    print("level %2d res %4d size %7d: %8.1f us   binned (bin + apply) %8.1f us" % (l, meta.resolution[l], m1.offset[1], us, usb))
