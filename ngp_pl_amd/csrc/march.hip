@@ -150,6 +150,15 @@ packbits_kernel(const T* __restrict__ grid, int n_bytes, float thr, const float*
     bitfield[n] = (uint8_t)bits;
 }
 
+// The masked mean decides the occupancy threshold (min(mean, thr), networks.py:266-268); at the
+// start of training every cell's density is within a few ulp of the mean, so the SUM must not
+// depend on the arrival order of atomics: workgroups park their partial sums in a library-owned
+// scratch and the last one to finish (self-resetting ticket) adds them in workgroup order.
+// Like ngp_nerf_loss: do not run two of these launches concurrently on different streams.
+constexpr int GRID_UPDATE_BLOCKS = 512;
+__device__ unsigned int g_grid_ticket = 0;
+__device__ float g_grid_partial[2 * GRID_UPDATE_BLOCKS];
+
 __global__ void __launch_bounds__(256)
 density_grid_update_kernel(float* __restrict__ grid, const float* __restrict__ tmp,
                            const float* __restrict__ decay_grid, float decay, int n,
@@ -164,12 +173,26 @@ density_grid_update_kernel(float* __restrict__ grid, const float* __restrict__ t
     }
     sum = ngp_wave_sum(sum); cnt = ngp_wave_sum(cnt);
     __shared__ float s_sum[4], s_cnt[4];
+    __shared__ bool s_last;
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { s_sum[w] = sum; s_cnt[w] = cnt; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&stats[0], s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
-        atomicAdd(&stats[1], s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]);
+        g_grid_partial[2 * blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+        g_grid_partial[2 * blockIdx.x + 1] = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+        __threadfence();
+        s_last = atomicInc(&g_grid_ticket, gridDim.x - 1) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x < 64) {
+        __threadfence();
+        float a = 0.f, b = 0.f;
+        for (int k = threadIdx.x; k < (int)gridDim.x; k += 64) {      // fixed order: lane k sums workgroups k, k+64, ...
+            a += __builtin_nontemporal_load(&g_grid_partial[2 * k]);
+            b += __builtin_nontemporal_load(&g_grid_partial[2 * k + 1]);
+        }
+        a = ngp_wave_sum(a); b = ngp_wave_sum(b);
+        if (threadIdx.x == 0) { stats[0] += a; stats[1] += b; }        // stats keeps its "caller zeroes, call adds" contract
     }
 }
 
@@ -846,7 +869,7 @@ int ngp_density_grid_update(float* density_grid, const float* density_grid_tmp, 
     if (n_cells < 0) return NGP_EINVAL;
     if (n_cells == 0) return 0;
     NGP_CHECK_PTR(density_grid); NGP_CHECK_PTR(density_grid_tmp); NGP_CHECK_PTR(stats);
-    const int blocks = min(ngp_div_up(n_cells, 256), 512);   // two same-address float atomics per workgroup: keep them few
+    const int blocks = min(ngp_div_up(n_cells, 256), GRID_UPDATE_BLOCKS);
     hipLaunchKernelGGL(density_grid_update_kernel, dim3(blocks), dim3(256), 0, ngp_stream(stream),
                        density_grid, density_grid_tmp, decay_grid, decay, n_cells, stats);
     return NGP_LAUNCH_RESULT();

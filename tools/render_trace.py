@@ -4,7 +4,7 @@ db = sqlite3.connect(sys.argv[1])
 rows = list(db.execute("select name,start,end,grid_x from kernels order by start"))
 idx = [i for i, r in enumerate(rows) if 'render_begin' in r[0]]
 st = idx[-1]; t0 = rows[st][1]; it = 0; line = []
-keys = ('render_begin', 'render_march', 'hashgrid_fwd', 'mlp_fwd_kernelILi32ELi1', 'mlp_fwd_kernelILi32ELi2', 'render_composite', 'render_finish', 'render_field')
+keys = ('render_begin', 'render_march', 'hashgrid_fwd', 'mlp_fwd_kernelILi32ELi1', 'mlp_fwd_kernelILi32ELi2', 'render_composite', 'render_finish', 'field_fwd_kernel')
 tot = {}
 for r in rows[st:]:
     k = next((key for key in keys if key in r[0]), None)
