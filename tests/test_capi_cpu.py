@@ -85,3 +85,44 @@ def test_missing_library_is_loud(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU/eager fallback"):
         _lib.lib()
+
+
+def test_workspace_queries_and_new_entry_points_validate_on_host():
+    """The size queries of the workspace-taking entry points are pure host functions, and the entry
+    points reject bad arguments before touching the device."""
+    import ctypes as C
+    import math
+    from ngp_pl_amd import _lib
+    lib = _lib.lib()
+    meta = _lib.GridMeta()
+    _lib.call("ngp_grid_meta_init", C.byref(meta), 16, 2, 19, 16, float(math.exp(math.log(2048 * 0.5 / 16) / 15)))
+    # test-time frame loop: grows with rays and chunk_scale; min_samples = 4 when exp_step_factor > 0 (rendering.py:60)
+    a = lib.ngp_render_test_workspace_bytes(640000, 1, 0.0)
+    b = lib.ngp_render_test_workspace_bytes(640000, 4, 0.0)
+    c = lib.ngp_render_test_workspace_bytes(640000, 1, 1 / 256.)
+    assert 0 < a < b and c == b and lib.ngp_render_test_workspace_bytes(0, 1, 0.0) == 0
+    assert a > 640000 * (12 + 12 + 4 + 4 + 64 + 4 + 12)          # per-slot sample buffers
+    # occupancy update: tmp grid + cell buffers, power-of-two grids only
+    o = lib.ngp_occupancy_update_workspace_bytes(1, 128)
+    assert o > 128 ** 3 * (4 + 4 + 12 + 64) and lib.ngp_occupancy_update_workspace_bytes(6, 128) > o
+    assert lib.ngp_occupancy_update_workspace_bytes(1, 100) == 0
+    # binned backward: chunk slots of 8 entries per sample and level; refuses batches beyond 1024 chunks
+    w = lib.ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(meta), 300000)
+    assert 16 * 300000 * 8 * 4 <= w < 16 * 300000 * 8 * 4 * 1.2
+    assert lib.ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(meta), 2_000_000) == 0
+    with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
+        _lib.call("ngp_render_test_frame", None, None, None, None, 1, 0.5, 0.0, 128, 1024, 1e-4, None, None, None, C.byref(meta), None, None,
+                  100, 1, 0, None, None, 0, None, None, None, None, None, None)
+    with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
+        _lib.call("ngp_render_test_frame", None, None, None, None, 1, 0.5, 0.0, 128, 1024, 1e-4, None, None, None, C.byref(meta), None, None,
+                  100, 0, 0, None, None, 0, None, None, None, None, None, None)         # chunk_scale < 1
+    assert _lib.call("ngp_render_test_frame", None, None, None, None, 1, 0.5, 0.0, 128, 1024, 1e-4, None, None, None, C.byref(meta), None, None,
+                     0, 1, 0, None, None, 0, None, None, None, None, None, None) == 0   # no rays: no-op
+    with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
+        _lib.call("ngp_occupancy_update", None, None, 1, 128, 0.5, 5.9, 0.95, None, 0, 1, None, None, None, C.byref(meta), None, None, 0, None)
+    with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
+        _lib.call("ngp_hashgrid_bwd_binned", None, None, None, None, C.byref(meta), 10, None, None, None, 0, None, None)
+    with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
+        _lib.call("ngp_hashgrid_bwd_input", None, None, None, None, None, C.byref(meta), 10, 1.0, None, None)
+    assert _lib.call("ngp_sh4_bwd", None, None, 0, 1.0, None, None) == 0
+    assert _lib.call("ngp_density_fwd_scatter", None, None, 0, None, None, None) == 0

@@ -374,6 +374,23 @@ def test_pose_gradients_flow_through_the_field():
     assert s2.grad_fn is not None and type(s2.grad_fn).__name__.startswith("_FusedField")
 
 
+def test_step_without_samples_is_a_noop_for_the_parameters():
+    """A batch whose rays all miss the box marches zero samples (S = 0): the step must neither fail nor touch
+    the parameters (the reference's kernels launch zero blocks; its loss is the background colour error)."""
+    from ngp_pl_amd.trainer import Trainer
+    m = make_model(seed=2)
+    tr = Trainer(m)
+    ro, rd, gt = batch(1024, seed=5)
+    before = m.xyz_encoder.params.detach().clone()
+    out = tr.step(ro + 10.0, rd.abs() + 0.1, gt)                 # origins far outside, pointing away
+    assert out["rm_samples"] == 0
+    met = tr.metrics()
+    assert math.isfinite(met["loss"]) and met["rm_s"] == 0
+    assert torch.equal(m.xyz_encoder.params.detach(), before)
+    out = tr.step(ro, rd, gt)                                      # and the trainer keeps working afterwards
+    assert out["rm_samples"] > 0 and math.isfinite(tr.metrics()["loss"])
+
+
 def test_raymarcher_backward_is_ray_indexed():
     """RayMarcher.backward (custom_functions.py:102-112): dL/do = sum_seg dL/dxyz, dL/dd = sum_seg (dL/dxyz*t + dL/ddir),
     placed at the ray's own index (pose optimisation, --optimize_ext)."""
