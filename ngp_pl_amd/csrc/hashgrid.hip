@@ -583,12 +583,15 @@ int ngp_hashgrid_bwd_sliced(const float* x, const float* xyz_min, const float* x
         if (e != hipSuccess) return (int)e;
     }
     constexpr int smem = (int)(SLICE * sizeof(half2_t));
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};              // per device: the attribute belongs to the device's code object
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    if (!attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hashgrid_bwd_sliced_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     hashgrid_bwd_sliced_kernel<<<dim3(n_blocks), dim3(1024), smem, st>>>(
         x, xyz_min, xyz_max, (const half2_t*)dfeats, to_dev_meta(meta), plan, n_samples, active_idx, n_active, (half2_t*)grad_table);

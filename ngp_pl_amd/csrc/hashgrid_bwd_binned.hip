@@ -350,11 +350,14 @@ int ngp_hashgrid_bwd_binned(const float* x, const float* xyz_min, const float* x
     bin_kernel<<<dim3(meta->n_levels * P.n_chunks), dim3(BIN_THREADS), 0, st>>>(
         x, xyz_min, xyz_max, (const half2_t*)dfeats, dm, P, ws, n_samples, active_idx, n_active);
     constexpr int smem = (int)(SLICE2 * 2 * sizeof(long long));
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};              // per device: the attribute belongs to the device's code object
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    if (!attr_set[dev]) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     const int n_wg = P.n_tasks < 256 ? P.n_tasks : 256;
     apply_kernel<<<dim3(n_wg), dim3(APPLY_THREADS), smem, st>>>(

@@ -762,16 +762,24 @@ RenderLayout render_layout(int n_rays, int chunk_scale, float esf) {
 struct RenderHost {
     int32_t* counts = nullptr;
     hipEvent_t ev[RENDER_RING] = {};
-    bool ok = false;
+    int device = -1;
     int init() {
-        if (ok) return 0;
-        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&counts), RENDER_RING * sizeof(int32_t), hipHostMallocDefault);
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return (int)e;
+        if (dev == device) return 0;
+        if (device >= 0) {                                   // the calling thread moved to another GPU: events are per device
+            for (int i = 0; i < RENDER_RING; ++i) (void)hipEventDestroy(ev[i]);
+            (void)hipHostFree(counts);
+            device = -1;
+        }
+        e = hipHostMalloc(reinterpret_cast<void**>(&counts), RENDER_RING * sizeof(int32_t), hipHostMallocDefault);
         if (e != hipSuccess) return (int)e;
         for (int i = 0; i < RENDER_RING; ++i) {
             e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
             if (e != hipSuccess) return (int)e;
         }
-        ok = true;
+        device = dev;
         return 0;
     }
 };
