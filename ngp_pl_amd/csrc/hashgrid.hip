@@ -398,36 +398,34 @@ active_count_kernel(const int64_t* __restrict__ rays_a, const int64_t* __restric
     const int tot = (int)total_samples[rays_a[3 * (size_t)r]];
     n_act[r] = min(N, tot + 1);
 }
-// in place: n_act[r] <- exclusive prefix; *n_active <- total
+// in place: n_act[r] <- exclusive prefix; *n_active <- total.  One workgroup, tiles of 1024 counts:
+// coalesced loads, wave shuffle scan, carry across tiles.
 __global__ void __launch_bounds__(1024)
 active_scan_kernel(int32_t* __restrict__ n_act, int n_rays, int32_t* __restrict__ n_active) {
     __shared__ int s_wave[16];
-    const int tid = threadIdx.x;
-    const int per = (n_rays + 1023) / 1024;
-    const int begin = min(tid * per, n_rays), end = min(begin + per, n_rays);
-    int local = 0;
-    for (int r = begin; r < end; ++r) local += n_act[r];
-    int incl = local;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o, 64);
-        if ((tid & 63) >= o) incl += v;
-    }
-    if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+    __shared__ int s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
     __syncthreads();
-    if (tid < 64) {
-        int w = (tid < 16) ? s_wave[tid] : 0;
+    for (int base = 0; base < n_rays; base += 1024) {
+        const int i = base + tid;
+        const int v = (i < n_rays) ? n_act[i] : 0;
+        int incl = v;
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            const int v = __shfl_up(w, o, 64);
-            if (tid >= o) w += v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += u;
         }
-        if (tid < 16) s_wave[tid] = w;
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int off = s_carry;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        if (i < n_rays) n_act[i] = off + incl - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = off + incl;
+        __syncthreads();
     }
-    __syncthreads();
-    int run = ((tid >> 6) ? s_wave[(tid >> 6) - 1] : 0) + incl - local;
-    for (int r = begin; r < end; ++r) { const int c = n_act[r]; n_act[r] = run; run += c; }
-    if (tid == 1023) *n_active = run;
+    if (tid == 0) *n_active = s_carry;
 }
 __global__ void __launch_bounds__(256)
 active_write_kernel(const int64_t* __restrict__ rays_a, const int64_t* __restrict__ total_samples,

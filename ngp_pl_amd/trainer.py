@@ -80,7 +80,6 @@ class Trainer:
         m = self.model
         n, dev = rays_o.shape[0], rays_o.device
         hits_t = torch.empty(n, 2, dtype=torch.float32, device=dev)
-        noise = torch.rand(n, dtype=torch.float32, device=dev)            # jitter of the first sample (custom_functions.py:83)
         rays_a = torch.empty(n, 3, dtype=torch.int64, device=dev)
         counter = torch.empty(2, dtype=torch.int32, device=dev)
         scratch = torch.empty(n * MAX_SAMPLES, dtype=torch.float32, device=dev)
@@ -94,6 +93,7 @@ class Trainer:
             t0 = t1 = None
             if self.events is not None:
                 t0 = torch.cuda.Event(enable_timing=True); t0.record()
+            noise = torch.rand(n, dtype=torch.float32, device=dev)        # jitter of the first sample (custom_functions.py:83); drawn on the marching stream
             call("ngp_ray_aabb_near", ptr(rays_o), ptr(rays_d), ptr(m.center), ptr(m.half_size), NEAR_DISTANCE, n, ptr(hits_t), stream())
             call("ngp_raymarching_train_count", ptr(rays_o), ptr(rays_d), ptr(hits_t), ptr(m.density_bitfield), m.cascades,
                  float(m.scale), self.exp_step_factor, ptr(noise), m.grid_size, MAX_SAMPLES, n, ptr(rays_a), ptr(counter),
