@@ -31,7 +31,6 @@ constexpr int MAX_SLICES = 80;               // ceil(2^19 / SLICE2) = 76
 constexpr float FIX_SCALE = 16777216.0f;     // 2^24 units per 1.0 (f16 subnormal spacing is 2^-24)
 constexpr int BIN_THREADS = 1024;            // samples per binning workgroup ("chunk")
 constexpr int CHUNK_SLOTS = BIN_THREADS * 8; // list entries a chunk can produce for one level (<= 8 slices per sample)
-constexpr int DIR_STRIDE = MAX_SLICES + 1;
 constexpr int MAX_CHUNKS = 1024;             // the slice owners scan the chunk directory in one pass
 constexpr int APPLY_THREADS = 1024;
 
@@ -46,9 +45,10 @@ struct BinPlan {
 
 // Lists are stored chunk-wise: the binning workgroup of (level, chunk) owns the fixed slot
 // pool[(level * n_chunks + chunk) * CHUNK_SLOTS ...] and writes its entries there grouped by slice;
-// dir[(level * n_chunks + chunk) * DIR_STRIDE + s] is where slice s starts inside the slot
-// (dir[.. + n_slices] = entries used).  No atomics, no capacity to exceed, deterministic.
+// dir[((level * MAX_SLICES + s) * n_chunks + chunk] = (start in the slot << 16) | count of slice s's
+// segment (one coalesced row per slice owner).  No atomics, no capacity to exceed, deterministic.
 struct BinWs {
+    long long* timing;   // NGP_BIN_TIMING builds only: [task][4] timestamps
     int32_t* queue;      // [0] next task
     int32_t* dir;
     int32_t* pool;
@@ -66,9 +66,9 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const
     const int chunk = (int)blockIdx.x - level * n_chunks;
     const int n = n_active ? min(*n_active, n_samples) : n_samples;
     const int ns = plan.n_slices[level];
-    int32_t* __restrict__ dir = ws.dir + (size_t)blockIdx.x * DIR_STRIDE;
-    if (chunk * BIN_THREADS >= n) {                                // nothing here: an empty directory row
-        for (int i = threadIdx.x; i <= ns; i += BIN_THREADS) dir[i] = 0;
+    int32_t* __restrict__ dir = ws.dir + (size_t)level * MAX_SLICES * n_chunks + chunk;     // + s * n_chunks
+    if (chunk * BIN_THREADS >= n) {                                // nothing here: empty segments
+        for (int i = threadIdx.x; i < ns; i += BIN_THREADS) dir[(size_t)i * n_chunks] = 0;
         return;
     }
     for (int i = threadIdx.x; i < ns; i += BIN_THREADS) s_cnt[i] = 0;
@@ -126,7 +126,7 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const
     const int total = s_pre[ns];
     int32_t* __restrict__ slot = ws.pool + (size_t)blockIdx.x * CHUNK_SLOTS;
     for (int i = threadIdx.x; i < total; i += BIN_THREADS) slot[i] = s_stage[i];
-    for (int i = threadIdx.x; i <= ns; i += BIN_THREADS) dir[i] = s_pre[i];
+    for (int i = threadIdx.x; i < ns; i += BIN_THREADS) dir[(size_t)i * n_chunks] = (s_pre[i] << 16) | s_cnt[i];
 }
 
 // ---- pass 2: slice owners -------------------------------------------------------------------
@@ -135,61 +135,94 @@ __device__ __forceinline__ void lds_add_fixed(long long* acc, float v) {
     atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)(long long)q);   // ds_add_u64
 }
 
-// entry i of the slice's (virtual, concatenated) list -> sample position j.
-// s_first[c] = index of chunk c's first entry, s_src[c] = where chunk c's segment starts in the pool.
-__device__ __forceinline__ int list_entry(const int32_t* __restrict__ pool, const int* s_first, const long long* s_src, int n_chunks, int i) {
-    int lo = 0, hi = n_chunks;                    // last chunk with s_first <= i
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_first[mid] <= i) lo = mid; else hi = mid; }
-    return pool[s_src[lo] + (i - s_first[lo])];
+// One corner-update pass for the lanes of a wave: lane holds sample position j (or ok = false).
+template <bool HASHED, int B>
+__device__ __forceinline__ void apply_entries(long long* lds, uint32_t lo, uint32_t len, uint32_t res, uint32_t size, float scale,
+                                              const float* __restrict__ x, const Box& box, const half2_t* __restrict__ g_level,
+                                              const int32_t* __restrict__ active, const int (&jj)[B], const bool (&ok)[B]) {
+    int src[B]; half2_t g[B]; float px[B][3];
+#pragma unroll
+    for (int b = 0; b < B; ++b) { g[b] = g_level[jj[b]]; src[b] = active ? active[jj[b]] : jj[b]; }
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const float* __restrict__ xp = x + 3 * (size_t)src[b];
+        px[b][0] = xp[0]; px[b][1] = xp[1]; px[b][2] = xp[2];
+    }
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        if (!ok[b]) continue;
+        const float g0 = (float)g[b][0], g1 = (float)g[b][1];
+        uint32_t p[3], idx[8]; float f[3];
+        cell_of_loaded(px[b], box, scale, p, f);
+        corner_indices<HASHED>(p, res, size, idx);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint32_t local = idx[c] - lo;
+            if (local < len) {
+                const float w = corner_weight(c, f);
+                lds_add_fixed(lds + 2 * local, w * g0);
+                lds_add_fixed(lds + 2 * local + 1, w * g1);
+            }
+        }
+    }
 }
 
-// BLOCKED = false: thread t takes entries t, t + 1024, ... (neighbouring lanes work on neighbouring
-// samples: coalesced gradient / position streams).  Right for the hashed levels.
-// BLOCKED = true: thread t takes a contiguous run of entries.  On the dense coarse levels dozens of
-// consecutive samples of a ray sit in the same cell, i.e. neighbouring lanes would hit the same 8
-// accumulators in the same instruction (measured: an LDS add_u64 with 8 lanes per address costs
-// 64 cycles instead of 11.5); with contiguous runs per thread the lanes of a wave are a whole run
-// apart, on different rays.
-template <bool HASHED, bool BLOCKED>
-__device__ __forceinline__ void apply_list(long long* lds, uint32_t lo, uint32_t len, uint32_t res, uint32_t size, float scale,
-                                           const float* __restrict__ x, const Box& box, const half2_t* __restrict__ g_level,
-                                           const int32_t* __restrict__ active, const int32_t* __restrict__ pool,
-                                           const int* s_first, const long long* s_src, int n_chunks, int begin, int end) {
-    constexpr int B = BLOCKED ? 4 : 8;
-    const int n = end - begin;
-    const int run = (n + APPLY_THREADS - 1) / APPLY_THREADS;               // BLOCKED: entries per thread
-    const int first = BLOCKED ? begin + (int)threadIdx.x * run : begin + (int)threadIdx.x;
-    const int step = BLOCKED ? 1 : APPLY_THREADS;
-    const int last = BLOCKED ? min(first + run, end) : end;                // exclusive bound of this thread's entries
-    const int trips = BLOCKED ? (run + B - 1) / B : (n + B * APPLY_THREADS - 1) / (B * APPLY_THREADS);
-    for (int trip = 0; trip < trips; ++trip) {
-        const int base = first + trip * B * step;
-        int jj[B], src[B]; half2_t g[B]; float px[B][3];
-#pragma unroll
-        for (int b = 0; b < B; ++b) jj[b] = list_entry(pool, s_first, s_src, n_chunks, max(min(base + b * step, end - 1), begin));   // clamp: unconditional loads
-#pragma unroll
-        for (int b = 0; b < B; ++b) { g[b] = g_level[jj[b]]; src[b] = active ? active[jj[b]] : jj[b]; }
+// Hashed levels: a wave takes B chunk segments per trip (typically ~57 entries each), lane = entry:
+// coalesced entry / gradient / position streams, all of a trip's loads in flight together.
+template <int B>
+__device__ __forceinline__ void apply_segments_hashed(long long* lds, uint32_t lo, uint32_t len, uint32_t res, uint32_t size, float scale,
+                                                      const float* __restrict__ x, const Box& box, const half2_t* __restrict__ g_level,
+                                                      const int32_t* __restrict__ active, const int32_t* __restrict__ pool_level,
+                                                      const int* s_dir, int n_chunks, int part, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = APPLY_THREADS / 64;
+    for (int c0 = part + K * wave; c0 < n_chunks; c0 += K * NW * B) {
+        int start[B], cnt[B], maxcnt = 0;
 #pragma unroll
         for (int b = 0; b < B; ++b) {
-            const float* __restrict__ xp = x + 3 * (size_t)src[b];
-            px[b][0] = xp[0]; px[b][1] = xp[1]; px[b][2] = xp[2];
+            const int c = c0 + b * K * NW;
+            const int d = (c < n_chunks) ? s_dir[c] : 0;
+            start[b] = c * CHUNK_SLOTS + (d >> 16); cnt[b] = d & 0xffff;
+            maxcnt = max(maxcnt, cnt[b]);
         }
+        for (int off = 0; off < maxcnt; off += 64) {               // one pass unless a segment has more than 64 entries
+            int jj[B]; bool ok[B];
 #pragma unroll
-        for (int b = 0; b < B; ++b) {
-            if (base + b * step >= last) break;
-            const float g0 = (float)g[b][0], g1 = (float)g[b][1];
-            uint32_t p[3], idx[8]; float f[3];
-            cell_of_loaded(px[b], box, scale, p, f);
-            corner_indices<HASHED>(p, res, size, idx);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const uint32_t local = idx[c] - lo;
-                if (local < len) {
-                    const float w = corner_weight(c, f);
-                    lds_add_fixed(lds + 2 * local, w * g0);
-                    lds_add_fixed(lds + 2 * local + 1, w * g1);
-                }
+            for (int b = 0; b < B; ++b) {
+                ok[b] = off + lane < cnt[b];
+                jj[b] = ok[b] ? pool_level[(size_t)start[b] + off + lane] : 0;
             }
+            apply_entries<true, B>(lds, lo, len, res, size, scale, x, box, g_level, active, jj, ok);
+        }
+    }
+}
+
+// Dense (coarse) levels: a segment holds up to every sample of its chunk, and dozens of consecutive
+// samples of a ray sit in the same cell, i.e. consecutive entries hit the same 8 accumulators
+// (measured: an LDS add_u64 with 8 lanes per address costs 64 cycles instead of 11.5).  Lane L
+// therefore walks the contiguous run [L*R, (L+1)*R) of the segment: the lanes of a wave are a whole
+// run apart, on different rays.
+template <int B>
+__device__ __forceinline__ void apply_segments_dense(long long* lds, uint32_t lo, uint32_t len, uint32_t res, uint32_t size, float scale,
+                                                     const float* __restrict__ x, const Box& box, const half2_t* __restrict__ g_level,
+                                                     const int32_t* __restrict__ active, const int32_t* __restrict__ pool_level,
+                                                     const int* s_dir, int n_chunks, int part, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = APPLY_THREADS / 64;
+    for (int c = part + K * wave; c < n_chunks; c += K * NW) {
+        const int d = s_dir[c];
+        const int cnt = d & 0xffff;
+        const size_t start = (size_t)c * CHUNK_SLOTS + (d >> 16);
+        const int R = (cnt + 63) >> 6;
+        for (int t0 = 0; t0 < R; t0 += B) {
+            int jj[B]; bool ok[B];
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                const int i = lane * R + t0 + b;
+                ok[b] = (t0 + b < R) && i < cnt;
+                jj[b] = ok[b] ? pool_level[start + i] : 0;
+            }
+            apply_entries<false, B>(lds, lo, len, res, size, scale, x, box, g_level, active, jj, ok);
         }
     }
 }
@@ -200,18 +233,20 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
              const int32_t* __restrict__ active, half2_t* __restrict__ grad_table) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     long long* lds = reinterpret_cast<long long*>(smem_raw);
-    __shared__ int s_task, s_wave[16];
-    __shared__ int s_first[MAX_CHUNKS + 1];
-    __shared__ long long s_src[MAX_CHUNKS];
+    __shared__ int s_task;
+    __shared__ int s_dir[MAX_CHUNKS];
     const Box box = load_box(xyz_min, xyz_max);
     const int n_chunks = plan.n_chunks;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     for (;;) {
         __syncthreads();                                           // previous task's LDS reads are done
         if (tid == 0) s_task = atomicAdd(&ws.queue[0], 1);
         __syncthreads();
         const int task = s_task;
         if (task >= plan.n_tasks) return;
+#ifdef NGP_BIN_TIMING
+        if (tid == 0) ws.timing[4 * task + 0] = (long long)wall_clock64();
+#endif
         int oi = 0;
         while (task >= plan.first_task[oi + 1]) ++oi;
         const int level = plan.order[oi];
@@ -222,35 +257,21 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
         const uint32_t size = meta.offset[level + 1] - meta.offset[level];
         const uint32_t lo = (uint32_t)slice * SLICE2;
         const uint32_t len = min(SLICE2, size - lo);
-        // directory of this slice: per chunk (start in its slot, count) -> exclusive prefix over chunks
-        int cnt = 0;
-        if (tid < n_chunks) {
-            const size_t row = (size_t)level * n_chunks + tid;
-            const int32_t* __restrict__ d = ws.dir + row * DIR_STRIDE + slice;
-            const int a = d[0];
-            cnt = d[1] - a;
-            s_src[tid] = (long long)row * CHUNK_SLOTS + a;
-        }
-        int incl = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
-        if (lane == 63) s_wave[wave] = incl;
+        const int32_t* __restrict__ dir = ws.dir + ((size_t)level * MAX_SLICES + slice) * n_chunks;
+        for (int c = tid; c < n_chunks; c += APPLY_THREADS) s_dir[c] = dir[c];
         for (uint32_t k = tid; k < 2 * len; k += APPLY_THREADS) lds[k] = 0;
         __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < wave; ++w) woff += s_wave[w];
-        if (tid < n_chunks) s_first[tid] = woff + incl - cnt;
-        if (tid == APPLY_THREADS - 1) s_first[n_chunks] = woff + incl;
-        __syncthreads();
-        const int total = s_first[n_chunks];
-        const int per = (total + K - 1) / K;
-        const int begin = min(part * per, total), end = min(begin + per, total);
+#ifdef NGP_BIN_TIMING
+        if (tid == 0) ws.timing[4 * task + 1] = (long long)wall_clock64();
+#endif
         const half2_t* __restrict__ g_level = dfeats + (size_t)level * n_samples;
-        if (end > begin) {
-            if (level_is_hashed(res, size)) apply_list<true, false>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, ws.pool, s_first, s_src, n_chunks, begin, end);
-            else apply_list<false, true>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, ws.pool, s_first, s_src, n_chunks, begin, end);
-        }
+        const int32_t* __restrict__ pool_level = ws.pool + (size_t)level * n_chunks * CHUNK_SLOTS;
+        if (level_is_hashed(res, size)) apply_segments_hashed<8>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
+        else apply_segments_dense<4>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
         __syncthreads();
+#ifdef NGP_BIN_TIMING
+        if (tid == 0) ws.timing[4 * task + 2] = (long long)wall_clock64();
+#endif
         half2_t* __restrict__ out = grad_table + meta.offset[level] + lo;
         const float inv = 1.0f / FIX_SCALE;
         for (uint32_t k = tid; k < len; k += APPLY_THREADS) {
@@ -263,10 +284,14 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
                 unsafeAtomicAdd(reinterpret_cast<__half2*>(out) + k, hv);
             }
         }
+#ifdef NGP_BIN_TIMING
+        __syncthreads();
+        if (tid == 0) ws.timing[4 * task + 3] = (long long)wall_clock64();
+#endif
     }
 }
 
-struct BinLayout { size_t queue, dir, pool, bytes; };
+struct BinLayout { size_t queue, timing, dir, pool, bytes; };
 
 // Plan: slices of SLICE2 entries; the levels with few slices (coarse, dense) split their lists over
 // K tasks so that every level yields at least ~16 tasks.
@@ -293,8 +318,9 @@ bool make_plan(const ngp_grid_meta* meta, int n_samples, BinPlan& P, BinLayout& 
     P.n_tasks = nt;
     const size_t rows = (size_t)meta->n_levels * P.n_chunks;
     L.queue = 0;
-    L.dir = 256;
-    L.pool = L.dir + (rows * DIR_STRIDE * 4 + 255) / 256 * 256;
+    L.timing = 256;                               // 1024 tasks x 4 x 8 B (NGP_BIN_TIMING builds)
+    L.dir = 256 + 32768;
+    L.pool = L.dir + ((size_t)meta->n_levels * MAX_SLICES * P.n_chunks * 4 + 255) / 256 * 256;
     L.bytes = L.pool + rows * CHUNK_SLOTS * 4;
     return P.n_chunks <= MAX_CHUNKS;
 }
@@ -331,6 +357,7 @@ int ngp_hashgrid_bwd_binned(const float* x, const float* xyz_min, const float* x
     char* wsb = static_cast<char*>(workspace);
     BinWs ws;
     ws.queue = reinterpret_cast<int32_t*>(wsb + L.queue);
+    ws.timing = reinterpret_cast<long long*>(wsb + L.timing);
     ws.dir = reinterpret_cast<int32_t*>(wsb + L.dir);
     ws.pool = reinterpret_cast<int32_t*>(wsb + L.pool);
     hipError_t e = hipMemsetAsync(ws.queue, 0, 256, st);
