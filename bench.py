@@ -160,7 +160,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
     from ngp_pl_amd import synthetic as syn
-    from ngp_pl_amd.bench_support import GpuDataset, all_reduce_native, render_fps
+    from ngp_pl_amd.bench_support import GpuDataset, all_reduce_native, all_reduce_native_mlp, render_fps
     from ngp_pl_amd.networks import NGP
     from ngp_pl_amd.trainer import Trainer
 
@@ -170,6 +170,7 @@ def main():
     trainer = Trainer(model, lr=1e-2, num_epochs=30)
     if dist is not None:   # also with a 1-rank process group (torchrun --nproc-per-node 1): exercises the collective path
         trainer.grad_hook = lambda: all_reduce_native(model, dist, world)
+        trainer.mlp_grad_hook = lambda: all_reduce_native_mlp(model, dist)      # small collective hidden under the hash-grid backward
         # identical initial parameters on every rank (DDP broadcasts rank 0's)
         for p in model.parameters():
             dist.broadcast(p.data, 0)
@@ -218,7 +219,7 @@ def main():
                    "samples_per_ray_marched": met["rm_s"], "samples_per_ray_composited": met["vr_s"], "train_psnr": met["psnr"],
                    "parallelism": "dp%d (per-ray data parallel, native-gradient all-reduce)" % world},
     }
-    trainer.grad_hook = None      # what follows runs on rank 0 only: no collectives from here on
+    trainer.grad_hook = trainer.mlp_grad_hook = None      # what follows runs on rank 0 only: no collectives from here on
     if rank == 0 and args.timed_only:
         print(json.dumps(out))
     elif rank == 0:

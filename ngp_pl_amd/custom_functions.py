@@ -13,27 +13,28 @@ _fwd = custom_fwd(device_type="cuda", cast_inputs=torch.float32)
 _bwd = custom_bwd(device_type="cuda")
 
 
-class RayAABBIntersector(torch.autograd.Function):
-    """rays x axis-aligned boxes -> (hit_cnt (R), hits_t (R,max_hits,2), hits_voxel_idx (R,max_hits)),
-    near to far, -1 where empty (custom_functions.py:8-29)."""
+def _intersector(native_fn, summary):
+    """Both intersection operators are the same shell around one native call: no gradients, three
+    outputs (hit count (R), hit intervals (R,max_hits,2) near to far with -1 padding, primitive
+    index (R,max_hits))."""
 
-    @staticmethod
-    @_fwd
-    def forward(ctx, rays_o, rays_d, center, half_size, max_hits):
-        out = vren.ray_aabb_intersect(rays_o, rays_d, center, half_size, max_hits)
-        ctx.mark_non_differentiable(*out)
-        return tuple(out)
+    class _Op(torch.autograd.Function):
+        __doc__ = summary
+
+        @staticmethod
+        @_fwd
+        def forward(ctx, origins, directions, centres, extents, max_hits):
+            found = tuple(native_fn(origins, directions, centres, extents, max_hits))
+            ctx.mark_non_differentiable(*found)
+            return found
+
+    return _Op
 
 
-class RaySphereIntersector(torch.autograd.Function):
-    """rays x spheres, same outputs (custom_functions.py:32-52)."""
-
-    @staticmethod
-    @_fwd
-    def forward(ctx, rays_o, rays_d, center, radii, max_hits):
-        out = vren.ray_sphere_intersect(rays_o, rays_d, center, radii, max_hits)
-        ctx.mark_non_differentiable(*out)
-        return tuple(out)
+RayAABBIntersector = _intersector(vren.ray_aabb_intersect, "rays x axis-aligned boxes (custom_functions.py:8-29)")
+RayAABBIntersector.__name__ = RayAABBIntersector.__qualname__ = "RayAABBIntersector"
+RaySphereIntersector = _intersector(vren.ray_sphere_intersect, "rays x spheres, extents = radii (custom_functions.py:32-52)")
+RaySphereIntersector.__name__ = RaySphereIntersector.__qualname__ = "RaySphereIntersector"
 
 
 def segment_sum(values, rays_a):
@@ -41,34 +42,36 @@ def segment_sum(values, rays_a):
     RayMarcher.backward (custom_functions.py:107-110).  Results are placed at ray_idx, so the
     gradient lands on the right ray whatever the row order of rays_a (the reference returns them
     in row order, which is only right when rows happen to be ray-ordered)."""
-    n_rays = rays_a.shape[0]
-    seg = torch.repeat_interleave(rays_a[:, 0], rays_a[:, 2])
-    out = torch.zeros((n_rays,) + values.shape[1:], dtype=values.dtype, device=values.device)
-    return out.index_add_(0, seg, values)
+    owner = torch.repeat_interleave(rays_a[:, 0], rays_a[:, 2])
+    acc = values.new_zeros((rays_a.shape[0],) + tuple(values.shape[1:]))
+    acc.index_add_(0, owner, values)
+    return acc
 
 
 class RayMarcher(torch.autograd.Function):
     """March rays through the occupancy bitfield (custom_functions.py:55-112).
     Returns rays_a (R,3) [ray_idx, start_idx, N_samples], xyzs (S,3), dirs (S,3), deltas (S), ts (S),
-    total_samples (0-dim)."""
+    total_samples (0-dim).  Gradients reach the ray origins/directions only (pose optimisation):
+    x = o + t d  =>  dL/do = sum_seg dL/dx, dL/dd = sum_seg (t dL/dx + dL/ddir)."""
 
     @staticmethod
     @_fwd
-    def forward(ctx, rays_o, rays_d, hits_t, density_bitfield, cascades, scale, exp_step_factor, grid_size, max_samples):
-        noise = torch.rand_like(rays_o[:, 0])        # jitter of the first sample (custom_functions.py:83)
-        rays_a, xyzs, dirs, deltas, ts, counter = vren.raymarching_train(
-            rays_o, rays_d, hits_t, density_bitfield, cascades, scale, exp_step_factor, noise, grid_size, max_samples)
-        ctx.save_for_backward(rays_a, ts)
+    def forward(ctx, origins, directions, hits_t, bitfield, cascades, scale, exp_step_factor, grid_size, max_samples):
+        jitter = torch.rand_like(origins[:, 0])              # first-sample jitter (custom_functions.py:83)
+        packed = vren.raymarching_train(origins, directions, hits_t, bitfield, cascades, scale, exp_step_factor,
+                                        jitter, grid_size, max_samples)
+        rays_a, xyzs, dirs, deltas, ts, counter = packed
         ctx.mark_non_differentiable(rays_a, deltas, ts)
+        ctx.save_for_backward(rays_a, ts)
         return rays_a, xyzs, dirs, deltas, ts, counter[0]
 
     @staticmethod
     @_bwd
-    def backward(ctx, dL_drays_a, dL_dxyzs, dL_ddirs, dL_ddeltas, dL_dts, dL_dtotal_samples):
+    def backward(ctx, _g_rays_a, g_xyz, g_dir, _g_deltas, _g_ts, _g_total):
         rays_a, ts = ctx.saved_tensors
-        dL_drays_o = segment_sum(dL_dxyzs, rays_a)
-        dL_drays_d = segment_sum(dL_dxyzs * ts[:, None] + dL_ddirs, rays_a)
-        return dL_drays_o, dL_drays_d, None, None, None, None, None, None, None
+        g_origin = segment_sum(g_xyz, rays_a)
+        g_direction = segment_sum(g_dir + ts.unsqueeze(1) * g_xyz, rays_a)
+        return (g_origin, g_direction) + (None,) * 7
 
 
 class VolumeRenderer(torch.autograd.Function):
@@ -78,33 +81,31 @@ class VolumeRenderer(torch.autograd.Function):
     @staticmethod
     @_fwd
     def forward(ctx, sigmas, rgbs, deltas, ts, rays_a, T_threshold):
-        total_samples, opacity, depth, rgb, ws = vren.composite_train_fw(
-            sigmas.contiguous(), rgbs.contiguous(), deltas, ts, rays_a, T_threshold)
-        ctx.save_for_backward(sigmas, rgbs, deltas, ts, rays_a, opacity, depth, rgb, ws)
+        sigmas, rgbs = sigmas.contiguous(), rgbs.contiguous()
+        per_ray_samples, opacity, depth, rgb, ws = vren.composite_train_fw(sigmas, rgbs, deltas, ts, rays_a, T_threshold)
         ctx.T_threshold = T_threshold
-        return total_samples.sum(), opacity, depth, rgb, ws
+        ctx.save_for_backward(sigmas, rgbs, ws, deltas, ts, rays_a, opacity, depth, rgb)
+        return per_ray_samples.sum(), opacity, depth, rgb, ws
 
     @staticmethod
     @_bwd
-    def backward(ctx, dL_dtotal_samples, dL_dopacity, dL_ddepth, dL_drgb, dL_dws):
-        sigmas, rgbs, deltas, ts, rays_a, opacity, depth, rgb, ws = ctx.saved_tensors
-        dL_dsigmas, dL_drgbs = vren.composite_train_bw(
-            dL_dopacity.contiguous(), dL_ddepth.contiguous(), dL_drgb.contiguous(), dL_dws.contiguous(),
-            sigmas.contiguous(), rgbs.contiguous(), ws, deltas, ts, rays_a, opacity, depth, rgb, ctx.T_threshold)
-        return dL_dsigmas, dL_drgbs, None, None, None, None
+    def backward(ctx, _g_total, g_opacity, g_depth, g_rgb, g_ws):
+        seeds = [g.contiguous() for g in (g_opacity, g_depth, g_rgb, g_ws)]
+        g_sigmas, g_rgbs = vren.composite_train_bw(*seeds, *ctx.saved_tensors, ctx.T_threshold)
+        return g_sigmas, g_rgbs, None, None, None, None
 
 
 class TruncExp(torch.autograd.Function):
-    """exp with the backward clamped to [-15, 15] (custom_functions.py:162-173)."""
+    """exp whose backward evaluates exp on the input clamped to [-15, 15] (custom_functions.py:162-173)."""
 
     @staticmethod
     @_fwd
-    def forward(ctx, x):
-        ctx.save_for_backward(x)
-        return torch.exp(x)
+    def forward(ctx, pre_activation):
+        ctx.save_for_backward(pre_activation)
+        return pre_activation.exp()
 
     @staticmethod
     @_bwd
-    def backward(ctx, dL_dout):
-        (x,) = ctx.saved_tensors
-        return dL_dout * torch.exp(x.clamp(-15, 15))
+    def backward(ctx, g_out):
+        (pre_activation,) = ctx.saved_tensors
+        return g_out * pre_activation.clamp(min=-15, max=15).exp()

@@ -44,10 +44,15 @@ class Trainer:
         self.lambda_distortion = lambda_distortion                          # opt.py:25-29 suggests 1e-3 for real scenes
         self.loss_fn = NeRFLoss(lambda_opacity=lambda_opacity, lambda_distortion=lambda_distortion)
         self._dist_seed = None
-        self.side = torch.cuda.Stream(device=dev) if (overlap_march and dev.type == "cuda") else None
+        # The marching stream must land on its own hardware queue or nothing overlaps: HIP multiplexes streams onto
+        # a few HSA queues (GPU_MAX_HW_QUEUES, default 4) round-robin, and once RCCL has created its streams a
+        # default-priority stream was observed to share the main stream's queue (rocprofv3: every kernel on one
+        # queue_id, step 0.52 -> 0.89 ms).  High-priority streams are served from a separate queue.
+        self.side = torch.cuda.Stream(device=dev, priority=-1) if (overlap_march and dev.type == "cuda") else None
         self._pending = None     # marched-but-not-consumed batch
         self.last = {}
         self.grad_hook = None    # called between backward and optimizer (multi-GPU gradient all-reduce)
+        self.mlp_grad_hook = None  # called once the MLP gradients exist, before the hash-grid backward is enqueued
         self.events = None       # list of (stage, event) when stage timing is on (bench.py roofline)
         self.march_ms = None
         self._zeros = None
@@ -191,11 +196,13 @@ class Trainer:
                      ptr(active), ptr(n_active), ptr(dh), ptr(dfeats), ptr(partials), stream())
                 self._mark("mlp_bwd")
                 g16 = m._grid_grad16(dev)
+                m._native = dict(grid16=g16, density_partials=partials[:n_part * enc.n_mlp], rgb_partials=partials[n_part * enc.n_mlp:],
+                                 n_partials=n_part, scale=tcnn.LOSS_SCALE)
+                if self.mlp_grad_hook is not None:
+                    self.mlp_grad_hook()
                 call("ngp_hashgrid_bwd_sliced", ptr(xyzs), ptr(m.xyz_min), ptr(m.xyz_max), ptr(dfeats), C.byref(enc.meta), S,
                      ptr(active), ptr(n_active), ptr(g16), stream())
                 self._mark("hashgrid_bwd")
-                m._native = dict(grid16=g16, density_partials=partials[:n_part * enc.n_mlp], rgb_partials=partials[n_part * enc.n_mlp:],
-                                 n_partials=n_part, scale=tcnn.LOSS_SCALE)
                 epoch = self.global_step // self.steps_per_epoch
                 self.opt.param_groups[0]["lr"] = cosine_lr(self.base_lr, epoch, self.num_epochs)
                 if self.grad_hook is not None:

@@ -27,14 +27,16 @@ class _Model:
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from ngp_pl_amd.bench_support import GpuDataset, all_reduce_native
+    from ngp_pl_amd.bench_support import GpuDataset, all_reduce_native, all_reduce_native_mlp
     torch.manual_seed(100 + rank)
     n_part = 3 + rank                                   # ranks may have different partial counts
     m = _Model()
     m._native = dict(grid16=torch.full((1000,), float(rank + 1)), density_partials=torch.ones(n_part * 3072),
                      rgb_partials=torch.full((n_part * 7168,), 2.0), n_partials=n_part, scale=128.0)
+    all_reduce_native_mlp(m, dist)                      # early, asynchronous half (trainer's mlp_grad_hook)
     all_reduce_native(m, dist, world)
     nat = m._native
+    assert "_mlp_work" not in nat and "_mlp_small" not in nat
     ok = bool((nat["grid16"] == 3.0).all())                                         # 1 + 2
     ok &= bool((nat["density_partials"] == 3 + 4).all()) and nat["n_partials"] == 1 and nat["density_partials"].numel() == 3072
     ok &= bool((nat["rgb_partials"] == 2.0 * 7).all()) and nat["scale"] == 256.0   # sum over ranks, mean folded into the unscale
