@@ -30,7 +30,7 @@ class FusedAdam:
         pass   # ngp_adam_step zeroes what it consumes; the sliced grid backward overwrites
 
     @torch.no_grad()
-    def step(self, grad_scale=1.0, found_inf=None):
+    def step(self, grad_scale=1.0, found_inf=None, stream_handle=None):
         """grad_scale: extra factor the caller put on the loss (GradScaler); the kernels' own loss
         scale is taken from the native record.  found_inf: device int32 flag (non-zero: skip)."""
         model = self.model
@@ -44,17 +44,18 @@ class FusedAdam:
         total_scale = nat["scale"] * grad_scale
         dev = enc.params.device
         with torch.cuda.device(dev):
+            sq = stream_handle if stream_handle is not None else stream()
             m, v = self.state["enc"]
             ph = enc._half.t
             fi = ptr(found_inf)
             call("ngp_adam_step_partials", ptr(enc.params.data), ptr(ph), ptr(nat["density_partials"]), nat["n_partials"], ptr(m), ptr(v),
-                 enc.n_mlp, lr, b1, b2, self.eps, self.weight_decay, self.t, total_scale, fi, stream())
+                 enc.n_mlp, lr, b1, b2, self.eps, self.weight_decay, self.t, total_scale, fi, sq)
             call("ngp_adam_step", ptr(enc.params.data[enc.n_mlp:]), ptr(ph[enc.n_mlp:]), ptr(nat["grid16"]), 0,
                  ptr(m[enc.n_mlp:]), ptr(v[enc.n_mlp:]), enc.n_grid, lr, b1, b2, self.eps, self.weight_decay, self.t,
-                 total_scale, fi, stream())
+                 total_scale, fi, sq)
             m, v = self.state["rgb"]
             call("ngp_adam_step_partials", ptr(net.params.data), ptr(net._half.t), ptr(nat["rgb_partials"]), nat["n_partials"], ptr(m), ptr(v),
-                 net.params.numel(), lr, b1, b2, self.eps, self.weight_decay, self.t, total_scale, fi, stream())
+                 net.params.numel(), lr, b1, b2, self.eps, self.weight_decay, self.t, total_scale, fi, sq)
         model._native = None
 
 

@@ -94,15 +94,16 @@ class Trainer:
         if st is not main:
             ready = torch.cuda.Event(); ready.record(main)
             st.wait_event(ready)
+        sq = st.cuda_stream                      # raw handle once: torch.cuda.current_stream() costs ~8 us per call
         with torch.cuda.stream(st):
             t0 = t1 = None
             if self.events is not None:
                 t0 = torch.cuda.Event(enable_timing=True); t0.record()
             noise = torch.rand(n, dtype=torch.float32, device=dev)        # jitter of the first sample (custom_functions.py:83); drawn on the marching stream
-            call("ngp_ray_aabb_near", ptr(rays_o), ptr(rays_d), ptr(m.center), ptr(m.half_size), NEAR_DISTANCE, n, ptr(hits_t), stream())
+            call("ngp_ray_aabb_near", ptr(rays_o), ptr(rays_d), ptr(m.center), ptr(m.half_size), NEAR_DISTANCE, n, ptr(hits_t), sq)
             call("ngp_raymarching_train_count", ptr(rays_o), ptr(rays_d), ptr(hits_t), ptr(m.density_bitfield), m.cascades,
                  float(m.scale), self.exp_step_factor, ptr(noise), m.grid_size, MAX_SAMPLES, n, ptr(rays_a), ptr(counter),
-                 ptr(scratch), stream())
+                 ptr(scratch), sq)
             if self.events is not None:
                 t1 = torch.cuda.Event(enable_timing=True); t1.record()
             counter_host.copy_(counter, non_blocking=True)
@@ -120,6 +121,7 @@ class Trainer:
         enc, net = m.xyz_encoder, m.rgb_net
         with torch.cuda.device(dev):
             main = torch.cuda.current_stream()
+            mq = main.cuda_stream
             if self._pending is not None and self._pending["rays_o"] is rays_o:
                 rec = self._pending
             else:
@@ -144,7 +146,7 @@ class Trainer:
             xyzs = torch.empty(S, 3, **f32); dirs = torch.empty(S, 3, **f32)
             deltas = torch.empty(S, **f32); ts = torch.empty(S, **f32)
             call("ngp_raymarching_train_write", ptr(rec["rays_o"]), ptr(rec["rays_d"]), ptr(rec["rays_a"]), ptr(rec["scratch"]),
-                 float(m.scale), self.exp_step_factor, m.grid_size, MAX_SAMPLES, n, ptr(xyzs), ptr(dirs), ptr(deltas), ptr(ts), stream())
+                 float(m.scale), self.exp_step_factor, m.grid_size, MAX_SAMPLES, n, ptr(xyzs), ptr(dirs), ptr(deltas), ptr(ts), mq)
             self._mark("march_write")
             rays_a = rec["rays_a"]
             eh, rh = enc._half.get(enc.params), net._half.get(net.params)
@@ -160,15 +162,15 @@ class Trainer:
             ray_offs = torch.empty(n, dtype=torch.int32, device=dev); n_active = torch.empty(1, dtype=torch.int32, device=dev)
             dL_dsigmas = torch.empty(S, **f32); dL_drgbs = torch.empty(S, 3, **f32)
             if S > 0:
-                call("ngp_hashgrid_fwd", ptr(xyzs), ptr(m.xyz_min), ptr(m.xyz_max), ptr(eh[enc.n_mlp:]), C.byref(enc.meta), S, ptr(feats), stream())
+                call("ngp_hashgrid_fwd", ptr(xyzs), ptr(m.xyz_min), ptr(m.xyz_max), ptr(eh[enc.n_mlp:]), C.byref(enc.meta), S, ptr(feats), mq)
                 self._mark("hashgrid_fwd")
-                call("ngp_field_fwd", ptr(feats), ptr(dirs), ptr(eh), ptr(rh), S, ptr(sigmas), ptr(rgbs), ptr(h), stream())
+                call("ngp_field_fwd", ptr(feats), ptr(dirs), ptr(eh), ptr(rh), S, ptr(sigmas), ptr(rgbs), ptr(h), mq)
                 self._mark("mlp_fwd")
             call("ngp_composite_train_fw", ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(ts), ptr(rays_a), self.T_threshold, n, S,
-                 ptr(total), ptr(opacity), ptr(depth), ptr(rgb), ptr(ws), ptr(ray_offs), stream())
-            call("ngp_active_scan", ptr(ray_offs), n, ptr(n_active), stream())
+                 ptr(total), ptr(opacity), ptr(depth), ptr(rgb), ptr(ws), ptr(ray_offs), mq)
+            call("ngp_active_scan", ptr(ray_offs), n, ptr(n_active), mq)
             call("ngp_nerf_loss", ptr(rgb), ptr(opacity), ptr(rgb_gt), ptr(self.bg), self.lambda_opacity, self.grad_scale, n,
-                 ptr(stats), ptr(stats[1:]), ptr(dL_drgb), ptr(dL_dopacity), stream())
+                 ptr(stats), ptr(stats[1:]), ptr(dL_drgb), ptr(dL_dopacity), mq)
             self._mark("composite_fw+loss")
             if S > 0:
                 # backward only over the samples up to each ray's early stop (the rest have zero gradient):
@@ -178,22 +180,22 @@ class Trainer:
                 if self.lambda_distortion > 0:
                     # losses.py:6-37,58-59: lambda * distortion per ray, mean over rays; its gradient enters the composite as dL/dws
                     dist = torch.empty(n, **f32); ws_incl = torch.empty(S, **f32); wts_incl = torch.empty(S, **f32)
-                    call("ngp_distortion_loss_fw", ptr(ws), ptr(deltas), ptr(ts), ptr(rays_a), n, S, ptr(dist), ptr(ws_incl), ptr(wts_incl), stream())
+                    call("ngp_distortion_loss_fw", ptr(ws), ptr(deltas), ptr(ts), ptr(rays_a), n, S, ptr(dist), ptr(ws_incl), ptr(wts_incl), mq)
                     seed_val = self.lambda_distortion / n * self.grad_scale
                     if self._dist_seed is None or self._dist_seed[0] != (n, seed_val):
                         self._dist_seed = ((n, seed_val), torch.full((n,), seed_val, **f32))
                     dL_dws = torch.empty(S, **f32)
                     call("ngp_distortion_loss_bw", ptr(self._dist_seed[1]), ptr(ws_incl), ptr(wts_incl), ptr(ws), ptr(deltas), ptr(ts),
-                         ptr(rays_a), n, S, ptr(dL_dws), stream())
+                         ptr(rays_a), n, S, ptr(dL_dws), mq)
                 call("ngp_composite_train_bw", ptr(dL_dopacity), ptr(dL_ddepth), ptr(dL_drgb), ptr(dL_dws), ptr(sigmas), ptr(rgbs), ptr(ws),
                      ptr(deltas), ptr(ts), ptr(rays_a), ptr(opacity), ptr(depth), ptr(rgb), self.T_threshold, n, S,
-                     ptr(dL_dsigmas), ptr(dL_drgbs), ptr(ray_offs), ptr(active), stream())
+                     ptr(dL_dsigmas), ptr(dL_drgbs), ptr(ray_offs), ptr(active), mq)
                 self._mark("composite_bw")
                 n_part = call("ngp_field_bwd_partials", S)
                 partials = torch.empty(n_part * (enc.n_mlp + net.params.numel()), **f32)
                 dh = torch.empty(S, 16, **f16); dfeats = torch.empty(16, S, 2, **f16)
                 call("ngp_field_bwd", ptr(feats), ptr(dirs), ptr(h), ptr(eh), ptr(rh), ptr(dL_dsigmas), ptr(dL_drgbs), tcnn.LOSS_SCALE, S,
-                     ptr(active), ptr(n_active), ptr(dh), ptr(dfeats), ptr(partials), stream())
+                     ptr(active), ptr(n_active), ptr(dh), ptr(dfeats), ptr(partials), mq)
                 self._mark("mlp_bwd")
                 g16 = m._grid_grad16(dev)
                 m._native = dict(grid16=g16, density_partials=partials[:n_part * enc.n_mlp], rgb_partials=partials[n_part * enc.n_mlp:],
@@ -201,13 +203,13 @@ class Trainer:
                 if self.mlp_grad_hook is not None:
                     self.mlp_grad_hook()
                 call("ngp_hashgrid_bwd_sliced", ptr(xyzs), ptr(m.xyz_min), ptr(m.xyz_max), ptr(dfeats), C.byref(enc.meta), S,
-                     ptr(active), ptr(n_active), ptr(g16), stream())
+                     ptr(active), ptr(n_active), ptr(g16), mq)
                 self._mark("hashgrid_bwd")
                 epoch = self.global_step // self.steps_per_epoch
                 self.opt.param_groups[0]["lr"] = cosine_lr(self.base_lr, epoch, self.num_epochs)
                 if self.grad_hook is not None:
                     self.grad_hook()
-                self.opt.step(grad_scale=self.grad_scale)
+                self.opt.step(grad_scale=self.grad_scale, stream_handle=mq)
                 self._mark("adam")
             self.global_step += 1
             self.last = dict(stats=stats, rm_samples=S, total=total, n_rays=n, rgb=rgb, opacity=opacity,

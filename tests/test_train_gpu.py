@@ -106,7 +106,7 @@ def test_fused_step_equals_autograd_step(lambda_distortion):
         tr = Trainer(m, lambda_distortion=lambda_distortion)
         captured = {}
 
-        def capture(grad_scale=1.0, found_inf=None, m=m, captured=captured):
+        def capture(grad_scale=1.0, found_inf=None, stream_handle=None, m=m, captured=captured):
             nat = m._native
             enc, net = m.xyz_encoder, m.rgb_net
             captured["grid"] = nat["grid16"].float().clone() / nat["scale"]
