@@ -211,6 +211,19 @@ class Trainer:
                     self.grad_hook()
                 self.opt.step(grad_scale=self.grad_scale, stream_handle=mq)
                 self._mark("adam")
+            elif self.grad_hook is not None or self.mlp_grad_hook is not None:
+                # no samples on THIS rank: the other ranks still expect it in the gradient collectives (DDP semantics:
+                # every rank joins every all-reduce), so it contributes zeros and applies the averaged update like them
+                g16 = m._grid_grad16(dev).zero_()
+                m._native = dict(grid16=g16, density_partials=torch.zeros(enc.n_mlp, **f32), rgb_partials=torch.zeros(net.params.numel(), **f32),
+                                 n_partials=1, scale=tcnn.LOSS_SCALE)
+                if self.mlp_grad_hook is not None:
+                    self.mlp_grad_hook()
+                epoch = self.global_step // self.steps_per_epoch
+                self.opt.param_groups[0]["lr"] = cosine_lr(self.base_lr, epoch, self.num_epochs)
+                if self.grad_hook is not None:
+                    self.grad_hook()
+                self.opt.step(grad_scale=self.grad_scale, stream_handle=mq)
             self.global_step += 1
             self.last = dict(stats=stats, rm_samples=S, total=total, n_rays=n, rgb=rgb, opacity=opacity,
                              distortion=dist if S > 0 else None)

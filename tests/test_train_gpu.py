@@ -389,6 +389,12 @@ def test_step_without_samples_is_a_noop_for_the_parameters():
     assert torch.equal(m.xyz_encoder.params.detach(), before)
     out = tr.step(ro, rd, gt)                                      # and the trainer keeps working afterwards
     assert out["rm_samples"] > 0 and math.isfinite(tr.metrics()["loss"])
+    # under data parallelism a rank without samples still joins both gradient collectives (with zeros)
+    calls = []
+    tr.mlp_grad_hook = lambda: calls.append(("mlp", float(m._native["density_partials"].abs().sum())))
+    tr.grad_hook = lambda: calls.append(("grid", float(m._native["grid16"].float().abs().sum())))
+    tr.step(ro + 10.0, rd.abs() + 0.1, gt)
+    assert calls == [("mlp", 0.0), ("grid", 0.0)]
 
 
 def test_raymarcher_backward_is_ray_indexed():
