@@ -15,6 +15,7 @@ Two implementations of the same step:
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -48,7 +49,7 @@ class Trainer:
         # a few HSA queues (GPU_MAX_HW_QUEUES, default 4) round-robin, and once RCCL has created its streams a
         # default-priority stream was observed to share the main stream's queue (rocprofv3: every kernel on one
         # queue_id, step 0.52 -> 0.89 ms).  High-priority streams are served from a separate queue.
-        self.side = torch.cuda.Stream(device=dev, priority=-1) if (overlap_march and dev.type == "cuda") else None
+        self.side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("NGP_MARCH_PRIORITY", "-1"))) if (overlap_march and dev.type == "cuda") else None
         self._pending = None     # marched-but-not-consumed batch
         self.last = {}
         self.grad_hook = None    # called between backward and optimizer (multi-GPU gradient all-reduce)
