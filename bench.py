@@ -77,7 +77,8 @@ def kernel_roofline(trainer, draw, n_steps=10):
     achieved = top["GB/s"]
     # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this
     # same command; summary and calibration in profiles/r01_pmc_hbm_traffic.txt).  Not measurable from inside this process.
-    pmc = {"hashgrid_bwd": (54662.6 + 21104.8) * 1024, "hashgrid_fwd": (40195.3 + 27011.6) * 1024, "adam": (2 * 78269.2 + 178828.8) * 1024}
+    # hashgrid_bwd = binning pass + slice owners of the binned variant (merge and gather kernels are below the summary's cut)
+    pmc = {"hashgrid_bwd": (116758 + 20018 + 39305 + 41436) * 1024, "hashgrid_fwd": (43901 + 30061) * 1024, "adam": (2 * 78269.2 + 178828.8) * 1024}
     return {"bound": "hbm", "kernel": top["stage"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get(top["stage"]), "traffic_source": "profiles/r01_pmc_hbm_traffic.txt",
             "avg_ms": top["ms"], "samples_per_launch": S, "stages": stages}

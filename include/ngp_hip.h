@@ -241,12 +241,18 @@ int ngp_hashgrid_bwd_sliced(const float* x, const float* xyz_min, const float* x
                             const ngp_half* dfeats /* [L][S] half2 */, const ngp_grid_meta* meta,
                             int n_samples, const int32_t* active_idx, const int32_t* n_active,
                             ngp_half* grad_table, ngp_stream_t stream);
+/* out[j] = x[idx[j]] for j < n_dev[0] (n_dev NULL: n_max): (S,3) positions of the active samples in compact
+ * order, so that the table backward streams them instead of going through the index. */
+int ngp_gather_xyz(const float* x, const int32_t* idx, const int32_t* n_dev, int n_max, float* out,
+                   ngp_stream_t stream);
+
 /* ngp_hashgrid_bwd_sliced with a binning pre-pass: one cheap pass per hashed level writes, per
  * slice, the list of samples whose corners touch it (a sample touches ~4 of a level's 19 slices),
  * and every slice owner then walks its own list instead of all samples.  Same result (f16
  * accumulation order aside), same arguments plus a scratch of
  * ngp_hashgrid_bwd_binned_workspace_bytes(meta, n_samples) bytes. */
 size_t ngp_hashgrid_bwd_binned_workspace_bytes(const ngp_grid_meta* meta, int n_samples);
+/* active_idx NULL with n_active given: x is already in compact order too (see ngp_gather_xyz). */
 int ngp_hashgrid_bwd_binned(const float* x, const float* xyz_min, const float* xyz_max,
                             const ngp_half* dfeats, const ngp_grid_meta* meta, int n_samples,
                             const int32_t* active_idx, const int32_t* n_active,

@@ -76,6 +76,7 @@ _PROTOS = {
     "ngp_abi_version": [],
     "ngp_hashgrid_fwd_n": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P],
     "ngp_field_fwd_n": [P, P, P, P, I, P, P, P, P, P],
+    "ngp_gather_xyz": [P, P, P, I, P, P],
     "ngp_hashgrid_bwd_binned": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P, C.c_size_t, P, P],
     "ngp_hashgrid_bwd_input": [P, P, P, P, P, C.POINTER(GridMeta), I, F, P, P],
     "ngp_sh4_bwd": [P, P, I, F, P, P],

@@ -440,6 +440,18 @@ active_write_kernel(const int64_t* __restrict__ rays_a, const int64_t* __restric
     for (int k = lane; k < na; k += 64) active[off + k] = start + k;
 }
 
+// x_out[j] = x[idx[j]], j < *n_dev: positions of the active samples in compact order, so the table backward reads
+// them as a stream instead of through the index (one dependent load less per sample in its scan loops)
+__global__ void __launch_bounds__(256)
+gather_xyz_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx, const int32_t* __restrict__ n_dev, int n_max,
+                  float* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = n_dev ? min(*n_dev, n_max) : n_max;
+    if (j >= n) return;
+    const size_t s = (size_t)idx[j];
+    out[3 * (size_t)j] = x[3 * s]; out[3 * (size_t)j + 1] = x[3 * s + 1]; out[3 * (size_t)j + 2] = x[3 * s + 2];
+}
+
 __global__ void __launch_bounds__(256)
 feats_to_rowmajor_kernel(const half2_t* __restrict__ feats, int n_levels, int n_samples, half2_t* __restrict__ out) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over (sample, level), level fastest
@@ -520,6 +532,14 @@ int ngp_hashgrid_bwd_input(const float* x, const float* xyz_min, const float* xy
     NGP_CHECK_PTR(x); NGP_CHECK_PTR(xyz_min); NGP_CHECK_PTR(xyz_max); NGP_CHECK_PTR(table); NGP_CHECK_PTR(dfeats); NGP_CHECK_PTR(dL_dx);
     hipLaunchKernelGGL(hashgrid_bwd_input_kernel, dim3(ngp_div_up(n_samples, 256)), dim3(256), 0, ngp_stream(stream),
                        x, xyz_min, xyz_max, (const half2_t*)table, (const half2_t*)dfeats, to_dev_meta(meta), n_samples, out_scale, dL_dx);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_gather_xyz(const float* x, const int32_t* idx, const int32_t* n_dev, int n_max, float* out, ngp_stream_t stream) {
+    if (n_max < 0) return NGP_EINVAL;
+    if (n_max == 0) return 0;
+    NGP_CHECK_PTR(x); NGP_CHECK_PTR(idx); NGP_CHECK_PTR(out);
+    hipLaunchKernelGGL(gather_xyz_kernel, dim3(ngp_div_up(n_max, 256)), dim3(256), 0, ngp_stream(stream), x, idx, n_dev, n_max, out);
     return NGP_LAUNCH_RESULT();
 }
 

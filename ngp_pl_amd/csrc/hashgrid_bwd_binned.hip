@@ -17,8 +17,8 @@
 //     and of tiny-cuda-nn round after every add, in arrival order);
 //  3. slices are small (16 B per entry: 6912 entries in 108 KiB of LDS) and numerous (~860), so
 //     they are tasks pulled from a queue by 256 persistent workgroups, largest first.
-// Levels with few slices (the coarse dense ones) additionally split their lists over K tasks whose
-// partial sums are merged with global packed-f16 atomics (a few hundred thousand per step).
+// Levels with few slices (the coarse dense ones: a z-slab can hold most of the scene) additionally split
+// their lists over K tasks whose partial tables are summed by a small merge kernel (no atomics anywhere).
 #include "hashgrid_common.h"
 #include <hip/hip_fp16.h>
 
@@ -40,6 +40,7 @@ struct BinPlan {
     int32_t k_split[NGP_MAX_LEVELS];
     int32_t first_task[NGP_MAX_LEVELS + 1];  // tasks are numbered level by level in `order`
     int32_t order[NGP_MAX_LEVELS];           // levels, most expensive tasks first
+    int64_t part_off[NGP_MAX_LEVELS];        // K-split levels: entry offset of the level's K partial tables in ws.partial
     int32_t n_tasks, n_chunks;
 };
 
@@ -48,6 +49,7 @@ struct BinPlan {
 // dir[((level * MAX_SLICES + s) * n_chunks + chunk] = (start in the slot << 16) | count of slice s's
 // segment (one coalesced row per slice owner).  No atomics, no capacity to exceed, deterministic.
 struct BinWs {
+    float2* partial;     // partial gradient tables (f32) of the K-split (dense) levels, merged by merge_kernel
     long long* timing;   // NGP_BIN_TIMING builds only: [task][4] timestamps
     int32_t* queue;      // [0] next task
     int32_t* dir;
@@ -74,7 +76,9 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const
     for (int i = threadIdx.x; i < ns; i += BIN_THREADS) s_cnt[i] = 0;
     __syncthreads();
     const int j = chunk * BIN_THREADS + (int)threadIdx.x;
-    int sid[8], loc[8];
+    int sid[8], loc[8], tag[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { sid[q] = -1; tag[q] = 0; }
     int n_mine = 0;
     if (j < n) {
         const half2_t g = dfeats[(size_t)level * n_samples + j];
@@ -86,25 +90,39 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const
             const float xin[3] = {x[3 * (size_t)src], x[3 * (size_t)src + 1], x[3 * (size_t)src + 2]};
             uint32_t p[3], idx[8]; float f[3];
             cell_of_loaded(xin, box, meta.scale[level], p, f);
-            if (level_is_hashed(res, size)) corner_indices<true>(p, res, size, idx);
+            const bool hashed = level_is_hashed(res, size);
+            if (hashed) corner_indices<true>(p, res, size, idx);
             else corner_indices<false>(p, res, size, idx);
+            if (hashed) {
+                // entry per (sample, corner pair): the corners (x, .) and (x+1, .) are table neighbours and almost
+                // always share a slice; the slice owner then forms only that pair (half the index and LDS work of a
+                // whole-sample entry, and no in-slice test that fails 3 times out of 4)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int sl = (int)(idx[c] / SLICE2);
-                bool dup = false;
+                for (int k = 0; k < 4; ++k) {
+                    const int s0 = (int)(idx[2 * k] / SLICE2), s1 = (int)(idx[2 * k + 1] / SLICE2);
+                    sid[2 * k] = s0; tag[2 * k] = k;
+                    sid[2 * k + 1] = (s1 != s0) ? s1 : -1; tag[2 * k + 1] = k;
+                }
+                n_mine = 8;
+            } else {
 #pragma unroll
-                for (int q = 0; q < c; ++q) dup = dup || (q < n_mine && sid[q] == sl);
-                if (!dup) {
-                    // compact the distinct slice ids to the front (n_mine is small: typically 4)
+                for (int c = 0; c < 8; ++c) {
+                    const int sl = (int)(idx[c] / SLICE2);
+                    bool dup = false;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) if (q == n_mine) sid[q] = sl;
-                    ++n_mine;
+                    for (int q = 0; q < c; ++q) dup = dup || (q < n_mine && sid[q] == sl);
+                    if (!dup) {
+                        // compact the distinct slice ids to the front (n_mine is small: 1 or 2 slabs)
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) if (q == n_mine) sid[q] = sl;
+                        ++n_mine;
+                    }
                 }
             }
         }
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) if (q < n_mine) loc[q] = atomicAdd(&s_cnt[sid[q]], 1);
+    for (int q = 0; q < 8; ++q) if (q < n_mine && sid[q] >= 0) loc[q] = atomicAdd(&s_cnt[sid[q]], 1);
     __syncthreads();
     if (threadIdx.x < 64) {                       // exclusive prefix of the per-slice counts (ns <= 80): two wave scans
         int run = 0;
@@ -121,7 +139,7 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 8; ++q) if (q < n_mine) s_stage[s_pre[sid[q]] + loc[q]] = j;
+    for (int q = 0; q < 8; ++q) if (q < n_mine && sid[q] >= 0) s_stage[s_pre[sid[q]] + loc[q]] = (j << 2) | tag[q];
     __syncthreads();
     const int total = s_pre[ns];
     int32_t* __restrict__ slot = ws.pool + (size_t)blockIdx.x * CHUNK_SLOTS;
@@ -135,14 +153,14 @@ __device__ __forceinline__ void lds_add_fixed(long long* acc, float v) {
     atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)(long long)q);   // ds_add_u64
 }
 
-// One corner-update pass for the lanes of a wave: lane holds sample position j (or ok = false).
-template <bool HASHED, int B>
+// One pass for the lanes of a wave over whole-sample entries (dense levels): all 8 corners, in-slice test each.
+template <int B>
 __device__ __forceinline__ void apply_entries(long long* lds, uint32_t lo, uint32_t len, uint32_t res, uint32_t size, float scale,
                                               const float* __restrict__ x, const Box& box, const half2_t* __restrict__ g_level,
-                                              const int32_t* __restrict__ active, const int (&jj)[B], const bool (&ok)[B]) {
+                                              const int32_t* __restrict__ active, const int (&ee)[B], const bool (&ok)[B]) {
     int src[B]; half2_t g[B]; float px[B][3];
 #pragma unroll
-    for (int b = 0; b < B; ++b) { g[b] = g_level[jj[b]]; src[b] = active ? active[jj[b]] : jj[b]; }
+    for (int b = 0; b < B; ++b) { const int jj = ee[b] >> 2; g[b] = g_level[jj]; src[b] = active ? active[jj] : jj; }
 #pragma unroll
     for (int b = 0; b < B; ++b) {
         const float* __restrict__ xp = x + 3 * (size_t)src[b];
@@ -154,7 +172,7 @@ __device__ __forceinline__ void apply_entries(long long* lds, uint32_t lo, uint3
         const float g0 = (float)g[b][0], g1 = (float)g[b][1];
         uint32_t p[3], idx[8]; float f[3];
         cell_of_loaded(px[b], box, scale, p, f);
-        corner_indices<HASHED>(p, res, size, idx);
+        corner_indices<false>(p, res, size, idx);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const uint32_t local = idx[c] - lo;
@@ -164,6 +182,37 @@ __device__ __forceinline__ void apply_entries(long long* lds, uint32_t lo, uint3
                 lds_add_fixed(lds + 2 * local + 1, w * g1);
             }
         }
+    }
+}
+
+// The same for (sample, corner pair) entries of a hashed level: entry = (j << 2) | (cy + 2 cz); only the pair
+// (x, y+cy, z+cz), (x+1, y+cy, z+cz) is formed -- index arithmetic and weight order of corner_indices()/corner_weight().
+template <int B>
+__device__ __forceinline__ void apply_pairs(long long* lds, uint32_t lo, uint32_t len, uint32_t size, float scale,
+                                            const float* __restrict__ x, const Box& box, const half2_t* __restrict__ g_level,
+                                            const int32_t* __restrict__ active, const int (&ee)[B], const bool (&ok)[B]) {
+    int src[B]; half2_t g[B]; float px[B][3];
+#pragma unroll
+    for (int b = 0; b < B; ++b) { const int jj = ee[b] >> 2; g[b] = g_level[jj]; src[b] = active ? active[jj] : jj; }
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const float* __restrict__ xp = x + 3 * (size_t)src[b];
+        px[b][0] = xp[0]; px[b][1] = xp[1]; px[b][2] = xp[2];
+    }
+    const uint32_t mask = size - 1u;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        if (!ok[b]) continue;
+        const float g0 = (float)g[b][0], g1 = (float)g[b][1];
+        uint32_t p[3]; float f[3];
+        cell_of_loaded(px[b], box, scale, p, f);
+        const uint32_t cy = (uint32_t)ee[b] & 1u, cz = ((uint32_t)ee[b] >> 1) & 1u;
+        const uint32_t h = ((p[1] + cy) * PRIME_Y) ^ ((p[2] + cz) * PRIME_Z);
+        const uint32_t l0 = ((p[0] ^ h) & mask) - lo, l1 = (((p[0] + 1u) ^ h) & mask) - lo;
+        const float wy = cy ? f[1] : 1.f - f[1], wz = cz ? f[2] : 1.f - f[2];
+        const float w0 = ((1.f - f[0]) * wy) * wz, w1 = (f[0] * wy) * wz;
+        if (l0 < len) { lds_add_fixed(lds + 2 * l0, w0 * g0); lds_add_fixed(lds + 2 * l0 + 1, w0 * g1); }
+        if (l1 < len) { lds_add_fixed(lds + 2 * l1, w1 * g0); lds_add_fixed(lds + 2 * l1 + 1, w1 * g1); }
     }
 }
 
@@ -186,13 +235,13 @@ __device__ __forceinline__ void apply_segments_hashed(long long* lds, uint32_t l
             maxcnt = max(maxcnt, cnt[b]);
         }
         for (int off = 0; off < maxcnt; off += 64) {               // one pass unless a segment has more than 64 entries
-            int jj[B]; bool ok[B];
+            int ee[B]; bool ok[B];
 #pragma unroll
             for (int b = 0; b < B; ++b) {
                 ok[b] = off + lane < cnt[b];
-                jj[b] = ok[b] ? pool_level[(size_t)start[b] + off + lane] : 0;
+                ee[b] = ok[b] ? pool_level[(size_t)start[b] + off + lane] : 0;
             }
-            apply_entries<true, B>(lds, lo, len, res, size, scale, x, box, g_level, active, jj, ok);
+            apply_pairs<B>(lds, lo, len, size, scale, x, box, g_level, active, ee, ok);
         }
     }
 }
@@ -222,7 +271,7 @@ __device__ __forceinline__ void apply_segments_dense(long long* lds, uint32_t lo
                 ok[b] = (t0 + b < R) && i < cnt;
                 jj[b] = ok[b] ? pool_level[start + i] : 0;
             }
-            apply_entries<false, B>(lds, lo, len, res, size, scale, x, box, g_level, active, jj, ok);
+            apply_entries<B>(lds, lo, len, res, size, scale, x, box, g_level, active, jj, ok);
         }
     }
 }
@@ -266,7 +315,7 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
 #endif
         const half2_t* __restrict__ g_level = dfeats + (size_t)level * n_samples;
         const int32_t* __restrict__ pool_level = ws.pool + (size_t)level * n_chunks * CHUNK_SLOTS;
-        if (level_is_hashed(res, size)) apply_segments_hashed<8>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
+        if (level_is_hashed(res, size)) apply_segments_hashed<11>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
         else apply_segments_dense<4>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
         __syncthreads();
 #ifdef NGP_BIN_TIMING
@@ -277,12 +326,8 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
         for (uint32_t k = tid; k < len; k += APPLY_THREADS) {
             half2_t v;
             v[0] = (_Float16)((float)lds[2 * k] * inv); v[1] = (_Float16)((float)lds[2 * k + 1] * inv);
-            if (K == 1) {
-                out[k] = v;
-            } else if (v[0] != (_Float16)0 || v[1] != (_Float16)0) {   // merge the K partial sums (range zero-filled by the host)
-                __half2 hv; __builtin_memcpy(&hv, &v, 4);
-                unsafeAtomicAdd(reinterpret_cast<__half2*>(out) + k, hv);
-            }
+            if (K == 1) out[k] = v;
+            else ws.partial[plan.part_off[level] + (size_t)part * size + lo + k] = make_float2((float)lds[2 * k] * inv, (float)lds[2 * k + 1] * inv);
         }
 #ifdef NGP_BIN_TIMING
         __syncthreads();
@@ -291,7 +336,30 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
     }
 }
 
-struct BinLayout { size_t queue, timing, dir, pool, bytes; };
+// K-split levels: grad[i] = sum over the K partial tables, in part order (deterministic, no atomics).
+__global__ void __launch_bounds__(256)
+merge_kernel(GridMeta meta, BinPlan plan, BinWs ws, half2_t* __restrict__ grad_table) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;        // entry index inside the span of K-split levels
+    uint32_t base = 0;
+    for (int l = 0; l < meta.n_levels; ++l) {
+        if (plan.k_split[l] <= 1) continue;
+        const uint32_t size = meta.offset[l + 1] - meta.offset[l];
+        if (i - base < size) {
+            const uint32_t e = i - base;
+            float a = 0.f, b = 0.f;
+            for (int p = 0; p < plan.k_split[l]; ++p) {
+                const float2 v = ws.partial[plan.part_off[l] + (size_t)p * size + e];
+                a += v.x; b += v.y;
+            }
+            half2_t o; o[0] = (_Float16)a; o[1] = (_Float16)b;
+            grad_table[meta.offset[l] + e] = o;
+            return;
+        }
+        base += size;
+    }
+}
+
+struct BinLayout { size_t queue, timing, dir, pool, partial, bytes; long long merge_entries; };
 
 // Plan: slices of SLICE2 entries; the levels with few slices (coarse, dense) split their lists over
 // K tasks so that every level yields at least ~16 tasks.
@@ -305,7 +373,7 @@ bool make_plan(const ngp_grid_meta* meta, int n_samples, BinPlan& P, BinLayout& 
         const bool hashed = (uint64_t)res * res * res > size;
         const int ns = (int)((size + SLICE2 - 1) / SLICE2);
         P.n_slices[l] = ns;
-        P.k_split[l] = hashed ? 1 : (16 + ns - 1) / ns;
+        P.k_split[l] = hashed ? 1 : (ns == 1 ? 16 : ns == 2 ? 8 : 4);      // dense: a z-slab can hold most of the scene's samples (64/ns tasks measured slower)
         // relative cost of one task: a dense slice (a slab of the grid) gets all 8 corners of its samples, a hashed one ~2
         cost[l] = hashed ? 1.0 : 4.0;
     }
@@ -316,12 +384,22 @@ bool make_plan(const ngp_grid_meta* meta, int n_samples, BinPlan& P, BinLayout& 
     for (int a = 0; a < meta->n_levels; ++a) { P.first_task[a] = nt; nt += P.n_slices[P.order[a]] * P.k_split[P.order[a]]; }
     for (int a = meta->n_levels; a <= NGP_MAX_LEVELS; ++a) P.first_task[a] = nt;
     P.n_tasks = nt;
+    long long part_entries = 0; L.merge_entries = 0;
+    for (int l = 0; l < NGP_MAX_LEVELS; ++l) P.part_off[l] = 0;
+    for (int l = 0; l < meta->n_levels; ++l) {
+        if (P.k_split[l] <= 1) continue;
+        const long long size = meta->offset[l + 1] - meta->offset[l];
+        P.part_off[l] = part_entries;
+        part_entries += size * P.k_split[l];
+        L.merge_entries += size;
+    }
     const size_t rows = (size_t)meta->n_levels * P.n_chunks;
     L.queue = 0;
-    L.timing = 256;                               // 1024 tasks x 4 x 8 B (NGP_BIN_TIMING builds)
-    L.dir = 256 + 32768;
+    L.timing = 256;                               // 2048 tasks x 4 x 8 B (NGP_BIN_TIMING builds)
+    L.dir = 256 + 65536;
     L.pool = L.dir + ((size_t)meta->n_levels * MAX_SLICES * P.n_chunks * 4 + 255) / 256 * 256;
-    L.bytes = L.pool + rows * CHUNK_SLOTS * 4;
+    L.partial = L.pool + rows * CHUNK_SLOTS * 4;
+    L.bytes = L.partial + (size_t)part_entries * sizeof(float2);
     return P.n_chunks <= MAX_CHUNKS;
 }
 
@@ -344,7 +422,7 @@ int ngp_hashgrid_bwd_binned(const float* x, const float* xyz_min, const float* x
     if (n_samples < 0 || !meta || meta->n_features != 2 || meta->n_levels < 1 || meta->n_levels > NGP_MAX_LEVELS) return NGP_EINVAL;
     NGP_CHECK_PTR(grad_table); NGP_CHECK_PTR(workspace);
     if (n_samples > 0) { NGP_CHECK_PTR(x); NGP_CHECK_PTR(xyz_min); NGP_CHECK_PTR(xyz_max); NGP_CHECK_PTR(dfeats); }
-    if ((active_idx == nullptr) != (n_active == nullptr)) return NGP_EINVAL;
+    if (active_idx != nullptr && n_active == nullptr) return NGP_EINVAL;      // n_active alone: x and dfeats both in compact order
     BinPlan P; BinLayout L;
     if (!make_plan(meta, n_samples, P, L)) return NGP_EUNSUP;
     if (workspace_bytes < L.bytes) return NGP_EINVAL;
@@ -360,19 +438,9 @@ int ngp_hashgrid_bwd_binned(const float* x, const float* xyz_min, const float* x
     ws.timing = reinterpret_cast<long long*>(wsb + L.timing);
     ws.dir = reinterpret_cast<int32_t*>(wsb + L.dir);
     ws.pool = reinterpret_cast<int32_t*>(wsb + L.pool);
+    ws.partial = reinterpret_cast<float2*>(wsb + L.partial);
     hipError_t e = hipMemsetAsync(ws.queue, 0, 256, st);
     if (e != hipSuccess) return (int)e;
-    // K-split levels are merged by atomics: their range of the gradient table starts from zero
-    for (int l = 0; l < meta->n_levels; ++l) {
-        if (P.k_split[l] > 1) {
-            int m = l;
-            while (m + 1 < meta->n_levels && P.k_split[m + 1] > 1) ++m;
-            e = hipMemsetAsync(reinterpret_cast<char*>(grad_table) + (size_t)meta->offset[l] * 4, 0,
-                               (size_t)(meta->offset[m + 1] - meta->offset[l]) * 4, st);
-            if (e != hipSuccess) return (int)e;
-            l = m;
-        }
-    }
     const GridMeta dm = to_dev_meta(meta);
     bin_kernel<<<dim3(meta->n_levels * P.n_chunks), dim3(BIN_THREADS), 0, st>>>(
         x, xyz_min, xyz_max, (const half2_t*)dfeats, dm, P, ws, n_samples, active_idx, n_active);
@@ -389,6 +457,8 @@ int ngp_hashgrid_bwd_binned(const float* x, const float* xyz_min, const float* x
     const int n_wg = P.n_tasks < 256 ? P.n_tasks : 256;
     apply_kernel<<<dim3(n_wg), dim3(APPLY_THREADS), smem, st>>>(
         x, xyz_min, xyz_max, (const half2_t*)dfeats, dm, P, ws, n_samples, active_idx, (half2_t*)grad_table);
+    if (L.merge_entries > 0)
+        merge_kernel<<<dim3(ngp_div_up(L.merge_entries, 256)), dim3(256), 0, st>>>(dm, P, ws, (half2_t*)grad_table);
     return NGP_LAUNCH_RESULT();
 }
 

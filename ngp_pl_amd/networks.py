@@ -63,8 +63,7 @@ class _FusedField(torch.autograd.Function):
             call("ngp_field_bwd", ptr(feats), ptr(d), ptr(h), ptr(eh), ptr(rh), ptr(dL_dsigmas), ptr(dL_drgbs), scale, n,
                  None, None, ptr(dh), ptr(dfeats), ptr(partials), stream())
             g16 = model._grid_grad16(dev)
-            call("ngp_hashgrid_bwd_sliced", ptr(x), ptr(model.xyz_min), ptr(model.xyz_max), ptr(dfeats), C.byref(enc.meta), n,
-                 None, None, ptr(g16), stream())
+            tcnn.grid_backward(x, model.xyz_min, model.xyz_max, dfeats, enc.meta, n, g16)
             p_density = partials[:n_part * enc.n_mlp]
             p_rgb = partials[n_part * enc.n_mlp:]
             if model.native_grads:

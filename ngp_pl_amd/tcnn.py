@@ -85,6 +85,25 @@ class _HalfCache:
         self.key = (params.data_ptr(), params._version)
 
 
+_BIN_WS = {}
+
+
+def grid_backward(x, xyz_min, xyz_max, dfeats, meta, n, g16):
+    """dL/dtable (packed f16, overwritten) for the full batch: the binned kernel (exact fixed-point sums,
+    deterministic) when the batch fits it, else the one-pass sliced kernel.  NGP_BINNED_BWD=0 forces the latter."""
+    import os
+    lib = _lib.lib()
+    nbytes = lib.ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(meta), n) if os.environ.get("NGP_BINNED_BWD", "1") != "0" else 0
+    if nbytes:
+        ws = _BIN_WS.get(x.device)
+        if ws is None or ws.numel() < nbytes:
+            ws = _BIN_WS[x.device] = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=x.device)
+        call("ngp_hashgrid_bwd_binned", ptr(x), ptr(xyz_min), ptr(xyz_max), ptr(dfeats), C.byref(meta), n, None, None,
+             ptr(ws), ws.numel(), ptr(g16), stream())
+    else:
+        call("ngp_hashgrid_bwd_sliced", ptr(x), ptr(xyz_min), ptr(xyz_max), ptr(dfeats), C.byref(meta), n, None, None, ptr(g16), stream())
+
+
 def reduce_partials(partials, n_partials, n):
     out = torch.empty(n, dtype=torch.float32, device=partials.device)
     call("ngp_reduce_partials", ptr(partials), n_partials, n, ptr(out), stream())
@@ -133,8 +152,7 @@ class _EncodeAndNet(torch.autograd.Function):
             call("ngp_density_bwd", ptr(feats), ptr(ph), ptr(dh), None, 1.0, n, None, None, ptr(dfeats), ptr(partials), stream())
             grad[:mod.n_mlp] = reduce_partials(partials, n_part, mod.n_mlp) / LOSS_SCALE
             g16 = torch.empty(mod.n_grid, dtype=torch.float16, device=dev)
-            call("ngp_hashgrid_bwd_sliced", ptr(x), ptr(mod._zero3), ptr(mod._one3), ptr(dfeats), C.byref(mod.meta), n,
-                 None, None, ptr(g16), stream())
+            grid_backward(x, mod._zero3, mod._one3, dfeats, mod.meta, n, g16)
             call("ngp_cast_f16_to_f32", ptr(g16), mod.n_grid, 1.0 / LOSS_SCALE, ptr(grad[mod.n_mlp:]), stream())
             dx = None
             if want_dx:          # pose optimisation: the sample positions carry gradients (train.py:86-89)

@@ -29,7 +29,7 @@ from .rendering import MAX_SAMPLES, NEAR_DISTANCE, render
 class Trainer:
     def __init__(self, model, lr=1e-2, num_epochs=30, steps_per_epoch=1000, T_threshold=1e-4,
                  lambda_opacity=1e-3, grad_scale=1.0, warmup_steps=256, update_interval=16, overlap_march=True,
-                 lambda_distortion=0.0):
+                 lambda_distortion=0.0, binned_backward=None):
         self.model = model
         if not hasattr(model, "density_grid"):
             model.register_training_buffers()
@@ -45,6 +45,10 @@ class Trainer:
         self.lambda_distortion = lambda_distortion                          # opt.py:25-29 suggests 1e-3 for real scenes
         self.loss_fn = NeRFLoss(lambda_opacity=lambda_opacity, lambda_distortion=lambda_distortion)
         self._dist_seed = None
+        # table backward: the binned variant (exact fixed-point sums, deterministic; measured 5 % faster per step) unless
+        # NGP_BINNED_BWD=0 / binned_backward=False selects the one-pass sliced kernel
+        self.binned_backward = bool(int(os.environ.get("NGP_BINNED_BWD", "1"))) if binned_backward is None else binned_backward
+        self._bin_ws = None
         # The marching stream must land on its own hardware queue or nothing overlaps: HIP multiplexes streams onto
         # a few HSA queues (GPU_MAX_HW_QUEUES, default 4) round-robin, and once RCCL has created its streams a
         # default-priority stream was observed to share the main stream's queue (rocprofv3: every kernel on one
@@ -203,8 +207,17 @@ class Trainer:
                                  n_partials=n_part, scale=tcnn.LOSS_SCALE)
                 if self.mlp_grad_hook is not None:
                     self.mlp_grad_hook()
-                call("ngp_hashgrid_bwd_sliced", ptr(xyzs), ptr(m.xyz_min), ptr(m.xyz_max), ptr(dfeats), C.byref(enc.meta), S,
-                     ptr(active), ptr(n_active), ptr(g16), mq)
+                nbytes = _lib.lib().ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(enc.meta), S) if self.binned_backward else 0
+                if nbytes:                              # 0: batch too large for the binned variant (occupancy warm-up)
+                    if self._bin_ws is None or self._bin_ws.numel() < nbytes:
+                        self._bin_ws = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=dev)
+                    x_act = torch.empty(S, 3, **f32)
+                    call("ngp_gather_xyz", ptr(xyzs), ptr(active), ptr(n_active), S, ptr(x_act), mq)
+                    call("ngp_hashgrid_bwd_binned", ptr(x_act), ptr(m.xyz_min), ptr(m.xyz_max), ptr(dfeats), C.byref(enc.meta), S,
+                         None, ptr(n_active), ptr(self._bin_ws), self._bin_ws.numel(), ptr(g16), mq)
+                else:
+                    call("ngp_hashgrid_bwd_sliced", ptr(xyzs), ptr(m.xyz_min), ptr(m.xyz_max), ptr(dfeats), C.byref(enc.meta), S,
+                         ptr(active), ptr(n_active), ptr(g16), mq)
                 self._mark("hashgrid_bwd")
                 epoch = self.global_step // self.steps_per_epoch
                 self.opt.param_groups[0]["lr"] = cosine_lr(self.base_lr, epoch, self.num_epochs)

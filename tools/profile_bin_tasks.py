@@ -20,10 +20,16 @@ ws = torch.zeros(nb, dtype=torch.uint8, device=dev)
 for _ in range(3):
     call("ngp_hashgrid_bwd_binned", ptr(x), ptr(mn), ptr(mx), ptr(dfe), C.byref(meta), S, None, None, ptr(ws), nb, ptr(g16), stream())
 torch.cuda.synchronize()
-tm = ws[256:256 + 32768].view(torch.int64).view(-1, 4).cpu().double()
+tm = ws[256:256 + 65536].view(torch.int64).view(-1, 4).cpu().double()
 tm = tm[tm[:, 0] > 0]
 t0 = tm[:, 0].min()
 print("tasks", len(tm), "span %.1f us (100 MHz clock)" % ((tm[:, 3].max() - t0) / 100))
-for name, sel in (("dense tasks (first 96)", tm[:96]), ("hashed tasks", tm[96:])):
+nd = len(tm) - 760
+for name, sel in (("dense tasks", tm[:nd]), ("hashed tasks", tm[nd:])):
     pro = (sel[:, 1] - sel[:, 0]).mean() / 100; scan = (sel[:, 2] - sel[:, 1]).mean() / 100; wr = (sel[:, 3] - sel[:, 2]).mean() / 100
     print("%s: n=%d prologue %.1f us, scan %.1f us (max %.1f), write-out %.1f us" % (name, len(sel), pro, scan, (sel[:, 2] - sel[:, 1]).max() / 100, wr))
+scan = (tm[:, 2] - tm[:, 1]) / 100
+bounds = [("L0", 0, 16), ("L1", 16, 32), ("L2", 32, 48), ("L3", 48, 80), ("L4", 80, 152), ("L5", 152, 312)]
+for name, a, b in bounds:
+    sel = scan[a:b]
+    print("%s: %d tasks, scan mean %.1f max %.1f us, start of first %.1f us" % (name, b - a, sel.mean(), sel.max(), (tm[a, 0] - t0) / 100))
