@@ -492,3 +492,9 @@ def test_hdr_branch_and_unbounded_scene_smoke():
     assert math.isfinite(met["loss"]) and met["rm_s"] > 0
     out = render(big, ro * 2.0, rd, test_time=True, exp_step_factor=1 / 256)
     assert torch.isfinite(out["rgb"]).all() and out["rgb"].shape == (1024, 3)
+    # steady-state occupancy update (uniform + occupied cells) on all four cascades
+    before = big.density_grid.clone()
+    big.update_density_grid(0.01 * 1024 / 3 ** 0.5, warmup=False)
+    assert torch.isfinite(big.density_grid).all() and not torch.equal(before, big.density_grid)
+    assert (big.density_grid >= 0.95 * before - 1e-6).all()             # decay-max merge never drops a cell below its decayed value
+    assert int(torch.count_nonzero(big.density_bitfield)) > 0
