@@ -11,12 +11,15 @@
 //  * the 8 corners of a sample fall into only ~4 slices of a level (x and x+1 are neighbours in
 //    the table, the four (y,z) combinations scatter).
 // Hence:
-//  1. a binning pass writes, per (level, slice), the list of samples that touch the slice;
-//  2. slice owners walk only their list and accumulate in 64-bit fixed point (2^-24 units,
+//  1. a binning pass writes, per (level, slice), the list of samples that touch the slice -- on
+//     hashed levels as (sample, corner pair) entries, so that an owner forms 2 corners, not 8;
+//  2. slice owners walk only their list and accumulate in 64-bit fixed point (2^-24 units; one
+//     update saturates at |w*g| = 128 in loss-scaled units, typical values are 1e-5..1e-1;
 //     exact sums, deterministic: integer adds commute -- the f16 atomics of the one-pass kernel
 //     and of tiny-cuda-nn round after every add, in arrival order);
-//  3. slices are small (16 B per entry: 6912 entries in 108 KiB of LDS) and numerous (~860), so
-//     they are tasks pulled from a queue by 256 persistent workgroups, largest first.
+//  3. slices are small (16 B per entry: 6912 entries in 108 KiB of LDS) and numerous (~1070 tasks
+//     with the dense levels' splits), pulled from a queue by 256 persistent workgroups, the
+//     expensive (dense) ones first.
 // Levels with few slices (the coarse dense ones: a z-slab can hold most of the scene) additionally split
 // their lists over K tasks whose partial tables are summed by a small merge kernel (no atomics anywhere).
 #include "hashgrid_common.h"
