@@ -117,6 +117,12 @@ def test_hashgrid_backward(lib, field, mode):
         ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
         lib.call("ngp_hashgrid_bwd_binned", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), n, None, None,
                  lib.ptr(ws), nbytes, lib.ptr(grad), lib.stream())
+        # fixed-point integer accumulation: the result does not depend on the order in which updates arrive
+        again = torch.full_like(grad, float("nan"))
+        ws.zero_()
+        lib.call("ngp_hashgrid_bwd_binned", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), n, None, None,
+                 lib.ptr(ws), nbytes, lib.ptr(again), lib.stream())
+        assert torch.equal(grad, again)
     else:
         f32 = mode == "atomic_f32"
         grad = torch.zeros(field.meta.total, 2, dtype=torch.float32 if f32 else torch.float16, device="cuda")
