@@ -130,7 +130,7 @@ def test_hashgrid_backward(lib, field, mode):
     got = grad.float().cpu()
     assert torch.isfinite(got).all()
     # packed-f16 accumulation: each add rounds to 2^-11 relative of the running sum
-    tol = 3e-5 if mode == "atomic_f32" else 1e-2      # up to ~100 contributions per entry, each add rounds at 2^-11
+    tol = {"atomic_f32": 3e-5, "binned": 1e-3}.get(mode, 1e-2)   # f16 atomics: up to ~100 contributions per entry, each add rounds at 2^-11; binned: exact sums, one final f16 rounding (+ the f16 dfeats x f32 weights products in 2^-24 units)
     scale = want.abs().max().item()
     err = (got - want).abs().max().item() / scale
     assert err < tol, "max error %g of max |grad| %g" % (err, scale)
