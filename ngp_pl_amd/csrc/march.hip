@@ -319,42 +319,33 @@ march_train_count_kernel(const float* __restrict__ rays_o, const float* __restri
 }
 
 // Exclusive scan of rays_a[:,2] into rays_a[:,1] in ray order; counter = {S, R}.
-// Single 1024-thread workgroup; each thread owns a contiguous run of rays.
+// Single 1024-thread workgroup, tiles of 1024 rays: coalesced loads, wave shuffle scan, carry across tiles.
 __global__ void __launch_bounds__(1024)
 march_train_scan_kernel(int64_t* __restrict__ rays_a, int n_rays, int32_t* __restrict__ counter) {
     __shared__ int s_wave[16];
-    const int tid = threadIdx.x;
-    const int per = (n_rays + 1023) / 1024;
-    const int begin = min(tid * per, n_rays), end = min(begin + per, n_rays);
-    int local = 0;
-    for (int r = begin; r < end; ++r) local += (int)rays_a[3 * (size_t)r + 2];
-    // inclusive scan across the workgroup: wave shuffle scan + scan of wave totals
-    int incl = local;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o, 64);
-        if ((tid & 63) >= o) incl += v;
-    }
-    if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+    __shared__ int s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
     __syncthreads();
-    if (tid < 64) {
-        int w = (tid < 16) ? s_wave[tid] : 0;
+    for (int base = 0; base < n_rays; base += 1024) {
+        const int r = base + tid;
+        const int v = (r < n_rays) ? (int)rays_a[3 * (size_t)r + 2] : 0;
+        int incl = v;
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            const int v = __shfl_up(w, o, 64);
-            if (tid >= o) w += v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += u;
         }
-        if (tid < 16) s_wave[tid] = w;   // inclusive wave totals
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int off = s_carry;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        if (r < n_rays) rays_a[3 * (size_t)r + 1] = off + incl - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = off + incl;
+        __syncthreads();
     }
-    __syncthreads();
-    const int wave_off = (tid >> 6) ? s_wave[(tid >> 6) - 1] : 0;
-    int run = wave_off + incl - local;   // exclusive offset of this thread's run
-    for (int r = begin; r < end; ++r) {
-        const int n = (int)rays_a[3 * (size_t)r + 2];
-        rays_a[3 * (size_t)r + 1] = run;
-        run += n;
-    }
-    if (tid == 1023) { counter[0] = run; counter[1] = n_rays; }
+    if (tid == 0) { counter[0] = s_carry; counter[1] = n_rays; }
 }
 
 // Pass 2 of train marching: expand (ray, k) -> packed sample.  One wave per ray, lanes stride
