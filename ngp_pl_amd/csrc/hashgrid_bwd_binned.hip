@@ -32,8 +32,10 @@ namespace {
 constexpr uint32_t SLICE2 = 6912;            // entries per task: 2 x int64 each -> 108 KiB of LDS
 constexpr int MAX_SLICES = 80;               // ceil(2^19 / SLICE2) = 76
 constexpr float FIX_SCALE = 16777216.0f;     // 2^24 units per 1.0 (f16 subnormal spacing is 2^-24)
-constexpr int BIN_THREADS = 1024;            // samples per binning workgroup ("chunk")
-constexpr int CHUNK_SLOTS = BIN_THREADS * 8; // list entries a chunk can produce for one level (<= 8 slices per sample)
+constexpr int BIN_THREADS = 512;             // binning workgroup: 4 of them are resident per CU (the pass is latency-bound)
+constexpr int BIN_SPT = 2;                   // samples per thread
+constexpr int CHUNK = BIN_THREADS * BIN_SPT; // samples per binning workgroup ("chunk")
+constexpr int CHUNK_SLOTS = CHUNK * 8;       // list entries a chunk can produce for one level (<= 8 slices per sample)
 constexpr int MAX_CHUNKS = 1024;             // the slice owners scan the chunk directory in one pass
 constexpr int APPLY_THREADS = 1024;
 
@@ -72,28 +74,35 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const
     const int n = n_active ? min(*n_active, n_samples) : n_samples;
     const int ns = plan.n_slices[level];
     int32_t* __restrict__ dir = ws.dir + (size_t)level * MAX_SLICES * n_chunks + chunk;     // + s * n_chunks
-    if (chunk * BIN_THREADS >= n) {                                // nothing here: empty segments
+    if (chunk * CHUNK >= n) {                                      // nothing here: empty segments
         for (int i = threadIdx.x; i < ns; i += BIN_THREADS) dir[(size_t)i * n_chunks] = 0;
         return;
     }
     for (int i = threadIdx.x; i < ns; i += BIN_THREADS) s_cnt[i] = 0;
     __syncthreads();
-    const int j = chunk * BIN_THREADS + (int)threadIdx.x;
-    int sid[8], loc[8], tag[8];
+    const uint32_t res = meta.resolution[level];
+    const uint32_t size = meta.offset[level + 1] - meta.offset[level];
+    const bool hashed = level_is_hashed(res, size);
+    const Box box = load_box(xyz_min, xyz_max);
+    int jj[BIN_SPT], sid[BIN_SPT][8], loc[BIN_SPT][8], tag[BIN_SPT][8], n_mine[BIN_SPT];
+    half2_t gg[BIN_SPT]; int src[BIN_SPT]; float xin[BIN_SPT][3];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { sid[q] = -1; tag[q] = 0; }
-    int n_mine = 0;
-    if (j < n) {
-        const half2_t g = dfeats[(size_t)level * n_samples + j];
-        if (g[0] != (_Float16)0 || g[1] != (_Float16)0) {
-            const int src = active ? active[j] : j;
-            const uint32_t res = meta.resolution[level];
-            const uint32_t size = meta.offset[level + 1] - meta.offset[level];
-            const Box box = load_box(xyz_min, xyz_max);
-            const float xin[3] = {x[3 * (size_t)src], x[3 * (size_t)src + 1], x[3 * (size_t)src + 2]};
+    for (int t = 0; t < BIN_SPT; ++t) {               // all loads of the thread's samples before any use
+        jj[t] = chunk * CHUNK + t * BIN_THREADS + (int)threadIdx.x;
+        const int jc = min(jj[t], n - 1);
+        gg[t] = dfeats[(size_t)level * n_samples + jc];
+        src[t] = active ? active[jc] : jc;
+    }
+#pragma unroll
+    for (int t = 0; t < BIN_SPT; ++t) { xin[t][0] = x[3 * (size_t)src[t]]; xin[t][1] = x[3 * (size_t)src[t] + 1]; xin[t][2] = x[3 * (size_t)src[t] + 2]; }
+#pragma unroll
+    for (int t = 0; t < BIN_SPT; ++t) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { sid[t][q] = -1; tag[t][q] = 0; }
+        n_mine[t] = 0;
+        if (jj[t] < n && (gg[t][0] != (_Float16)0 || gg[t][1] != (_Float16)0)) {
             uint32_t p[3], idx[8]; float f[3];
-            cell_of_loaded(xin, box, meta.scale[level], p, f);
-            const bool hashed = level_is_hashed(res, size);
+            cell_of_loaded(xin[t], box, meta.scale[level], p, f);
             if (hashed) corner_indices<true>(p, res, size, idx);
             else corner_indices<false>(p, res, size, idx);
             if (hashed) {
@@ -103,29 +112,31 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int s0 = (int)(idx[2 * k] / SLICE2), s1 = (int)(idx[2 * k + 1] / SLICE2);
-                    sid[2 * k] = s0; tag[2 * k] = k;
-                    sid[2 * k + 1] = (s1 != s0) ? s1 : -1; tag[2 * k + 1] = k;
+                    sid[t][2 * k] = s0; tag[t][2 * k] = k;
+                    sid[t][2 * k + 1] = (s1 != s0) ? s1 : -1; tag[t][2 * k + 1] = k;
                 }
-                n_mine = 8;
+                n_mine[t] = 8;
             } else {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const int sl = (int)(idx[c] / SLICE2);
                     bool dup = false;
 #pragma unroll
-                    for (int q = 0; q < c; ++q) dup = dup || (q < n_mine && sid[q] == sl);
+                    for (int q = 0; q < c; ++q) dup = dup || (q < n_mine[t] && sid[t][q] == sl);
                     if (!dup) {
                         // compact the distinct slice ids to the front (n_mine is small: 1 or 2 slabs)
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) if (q == n_mine) sid[q] = sl;
-                        ++n_mine;
+                        for (int q = 0; q < 8; ++q) if (q == n_mine[t]) sid[t][q] = sl;
+                        ++n_mine[t];
                     }
                 }
             }
         }
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) if (q < n_mine && sid[q] >= 0) loc[q] = atomicAdd(&s_cnt[sid[q]], 1);
+    for (int t = 0; t < BIN_SPT; ++t)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) if (q < n_mine[t] && sid[t][q] >= 0) loc[t][q] = atomicAdd(&s_cnt[sid[t][q]], 1);
     __syncthreads();
     if (threadIdx.x < 64) {                       // exclusive prefix of the per-slice counts (ns <= 80): two wave scans
         int run = 0;
@@ -142,7 +153,9 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 8; ++q) if (q < n_mine && sid[q] >= 0) s_stage[s_pre[sid[q]] + loc[q]] = (j << 2) | tag[q];
+    for (int t = 0; t < BIN_SPT; ++t)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) if (q < n_mine[t] && sid[t][q] >= 0) s_stage[s_pre[sid[t][q]] + loc[t][q]] = (jj[t] << 2) | tag[t][q];
     __syncthreads();
     const int total = s_pre[ns];
     int32_t* __restrict__ slot = ws.pool + (size_t)blockIdx.x * CHUNK_SLOTS;
@@ -368,7 +381,7 @@ struct BinLayout { size_t queue, timing, dir, pool, partial, bytes; long long me
 // K tasks so that every level yields at least ~16 tasks.
 bool make_plan(const ngp_grid_meta* meta, int n_samples, BinPlan& P, BinLayout& L) {
     P.n_levels = meta->n_levels;
-    P.n_chunks = ngp_div_up(n_samples > 0 ? n_samples : 1, BIN_THREADS);
+    P.n_chunks = ngp_div_up(n_samples > 0 ? n_samples : 1, CHUNK);
     double cost[NGP_MAX_LEVELS];
     for (int l = 0; l < NGP_MAX_LEVELS; ++l) { P.n_slices[l] = 0; P.k_split[l] = 1; P.order[l] = l; cost[l] = 0; }
     for (int l = 0; l < meta->n_levels; ++l) {
