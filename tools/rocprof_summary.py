@@ -1,6 +1,8 @@
 """Summarise a rocprofv3 --kernel-trace run (rocpd sqlite .db) into a small text table:
 per-kernel calls / average / total over the steady-state window (the last N training steps, found
-by counting launches of the grid Adam kernel).  Usage: rocprof_summary.py <results.db> [n_steps] > profiles/xyz.txt"""
+by counting launches of the grid Adam kernel; `skip_last` steps after the window are left out, e.g. the
+module-path steps bench.py runs after the timed region).
+Usage: rocprof_summary.py <results.db> [n_steps] [skip_last] > profiles/xyz.txt"""
 import collections
 import re
 import sqlite3
@@ -21,6 +23,9 @@ def main():
     n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
     rows = list(db.execute("select name, start, end, grid_x, workgroup_x, vgpr_count, accum_vgpr_count, lds_size from kernels order by start"))
     marks = [i for i, r in enumerate(rows) if "adam_kernelILb0" in r[0]]
+    skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    if skip:
+        rows = rows[:marks[-skip - 1] + 1]; marks = marks[:-skip]
     sel = rows[marks[-n_steps]:] if len(marks) >= n_steps else rows
     agg = collections.OrderedDict()
     for name, s, e, gx, wx, vg, ag, lds in sel:
