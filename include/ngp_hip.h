@@ -375,6 +375,20 @@ int ngp_adam_step_partials(float* param, ngp_half* param_h, const float* partial
                            float* m, float* v, int n, float lr, float beta1, float beta2, float eps,
                            float weight_decay, int step, float grad_scale, const int32_t* found_inf,
                            ngp_stream_t stream);
+/* The optimizer step of the whole field in ONE launch (train.py:131 hands every parameter of the
+ * model to one FusedAdam): ngp_adam_step (f16 gradient) on the grid table and
+ * ngp_adam_step_partials on the density and rgb MLP blocks, bit-identical to the three separate
+ * calls.  The MLP workgroups are dispatched first and run underneath the HBM-bound grid pass. */
+int ngp_adam_step_field(float* grid_param, ngp_half* grid_param_h, ngp_half* grid_grad,
+                        float* grid_m, float* grid_v, int64_t n_grid,
+                        float* density_param, ngp_half* density_param_h,
+                        const float* density_partials, float* density_m, float* density_v,
+                        int n_density,
+                        float* rgb_param, ngp_half* rgb_param_h, const float* rgb_partials,
+                        float* rgb_m, float* rgb_v, int n_rgb,
+                        int n_partials, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, float grad_scale, const int32_t* found_inf,
+                        ngp_stream_t stream);
 /* Sum n_partials rows of (n) f32 into out (n) f32 (out = sum, not accumulated). */
 int ngp_reduce_partials(const float* partials, int n_partials, int n, float* out,
                         ngp_stream_t stream);

@@ -398,32 +398,27 @@ active_count_kernel(const int64_t* __restrict__ rays_a, const int64_t* __restric
     const int tot = (int)total_samples[rays_a[3 * (size_t)r]];
     n_act[r] = min(N, tot + 1);
 }
-// in place: n_act[r] <- exclusive prefix; *n_active <- total.  One workgroup, tiles of 1024 counts:
-// coalesced loads, wave shuffle scan, carry across tiles.
+// in place: n_act[r] <- exclusive prefix; *n_active <- total.  One workgroup, tiles of 8192 counts (8 consecutive
+// counts per thread, loaded before anything else): the usual batch of 8192 rays is one load latency + one scan.
 __global__ void __launch_bounds__(1024)
 active_scan_kernel(int32_t* __restrict__ n_act, int n_rays, int32_t* __restrict__ n_active) {
     __shared__ int s_wave[16];
     __shared__ int s_carry;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     if (tid == 0) s_carry = 0;
     __syncthreads();
-    for (int base = 0; base < n_rays; base += 1024) {
-        const int i = base + tid;
-        const int v = (i < n_rays) ? n_act[i] : 0;
-        int incl = v;
+    for (int base = 0; base < n_rays; base += 8192) {
+        const int i0 = base + 8 * tid;
+        int v[8];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int u = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += u;
+        for (int k = 0; k < 8; ++k) v[k] = (i0 + k < n_rays) ? n_act[i0 + k] : 0;
+        int run = ngp_block_scan_tile<8>(v, s_wave, &s_carry);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (i0 + k < n_rays) n_act[i0 + k] = run;
+            run += v[k];
         }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        int off = s_carry;
-        for (int w = 0; w < wave; ++w) off += s_wave[w];
-        if (i < n_rays) n_act[i] = off + incl - v;
-        __syncthreads();
-        if (tid == 1023) s_carry = off + incl;
-        __syncthreads();
+        __syncthreads();                               // the carry of this tile is visible to the next
     }
     if (tid == 0) *n_active = s_carry;
 }

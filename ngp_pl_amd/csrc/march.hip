@@ -319,30 +319,25 @@ march_train_count_kernel(const float* __restrict__ rays_o, const float* __restri
 }
 
 // Exclusive scan of rays_a[:,2] into rays_a[:,1] in ray order; counter = {S, R}.
-// Single 1024-thread workgroup, tiles of 1024 rays: coalesced loads, wave shuffle scan, carry across tiles.
+// Single 1024-thread workgroup, tiles of 8192 rays (8 consecutive rays per thread, all loads first).
 __global__ void __launch_bounds__(1024)
 march_train_scan_kernel(int64_t* __restrict__ rays_a, int n_rays, int32_t* __restrict__ counter) {
     __shared__ int s_wave[16];
     __shared__ int s_carry;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     if (tid == 0) s_carry = 0;
     __syncthreads();
-    for (int base = 0; base < n_rays; base += 1024) {
-        const int r = base + tid;
-        const int v = (r < n_rays) ? (int)rays_a[3 * (size_t)r + 2] : 0;
-        int incl = v;
+    for (int base = 0; base < n_rays; base += 8192) {
+        const int r0 = base + 8 * tid;
+        int v[8];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int u = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += u;
+        for (int k = 0; k < 8; ++k) v[k] = (r0 + k < n_rays) ? (int)rays_a[3 * (size_t)(r0 + k) + 2] : 0;
+        int run = ngp_block_scan_tile<8>(v, s_wave, &s_carry);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (r0 + k < n_rays) rays_a[3 * (size_t)(r0 + k) + 1] = run;
+            run += v[k];
         }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        int off = s_carry;
-        for (int w = 0; w < wave; ++w) off += s_wave[w];
-        if (r < n_rays) rays_a[3 * (size_t)r + 1] = off + incl - v;
-        __syncthreads();
-        if (tid == 1023) s_carry = off + incl;
         __syncthreads();
     }
     if (tid == 0) { counter[0] = s_carry; counter[1] = n_rays; }

@@ -38,3 +38,28 @@ __device__ __forceinline__ float ngp_wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// Exclusive scan across a 1024-thread workgroup where every thread owns ITEMS consecutive counts (v, already
+// loaded: all of a tile's loads are in flight together, one memory latency per tile of 1024*ITEMS counts).
+// Returns the exclusive prefix of the thread's first item, carry-in included; *s_carry is advanced by the tile
+// total.  s_wave: 16 ints, s_carry: 1 int of LDS (zeroed by the caller before the first tile).
+template <int ITEMS>
+__device__ __forceinline__ int ngp_block_scan_tile(const int (&v)[ITEMS], int* s_wave, int* s_carry) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) mine += v[k];
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += u;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int off = *s_carry;
+    for (int w = 0; w < wave; ++w) off += s_wave[w];
+    __syncthreads();                                   // everyone has read the carry and the wave totals
+    if (tid == 1023) *s_carry = off + incl;
+    return off + incl - mine;
+}

@@ -14,15 +14,17 @@ namespace {
 typedef _Float16 h1;
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 
+struct AdamHyper { float lr, beta1, beta2, eps, wd, bc1, bc2, inv_scale; const int32_t* found_inf; };
+
+// Dense (streaming) update of n parameters by workgroups `block` of `n_blocks`, 4 parameters per thread and trip.
 template <bool GRAD_F32>
-__global__ void __launch_bounds__(256)
-adam_kernel(float* __restrict__ param, h1* __restrict__ param_h, void* __restrict__ grad,
-            float* __restrict__ m, float* __restrict__ v, long long n4, long long n,
-            float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2,
-            float inv_scale, const int32_t* __restrict__ found_inf) {
-    const bool skip = found_inf != nullptr && *found_inf != 0;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
+__device__ __forceinline__ void adam_dense(float* __restrict__ param, h1* __restrict__ param_h, void* __restrict__ grad,
+                                           float* __restrict__ m, float* __restrict__ v, long long n4, long long n,
+                                           const AdamHyper& hp, int block, int n_blocks) {
+    const float lr = hp.lr, beta1 = hp.beta1, beta2 = hp.beta2, eps = hp.eps, wd = hp.wd, bc1 = hp.bc1, bc2 = hp.bc2, inv_scale = hp.inv_scale;
+    const bool skip = hp.found_inf != nullptr && *hp.found_inf != 0;
+    const long long stride = (long long)n_blocks * blockDim.x;
+    for (long long q = (long long)block * blockDim.x + threadIdx.x; q < n4; q += stride) {
         const long long base = q * 4;
         float g[4];
         const int cnt = (int)((n - base) < 4 ? (n - base) : 4);
@@ -74,6 +76,13 @@ adam_kernel(float* __restrict__ param, h1* __restrict__ param_h, void* __restric
     }
 }
 
+template <bool GRAD_F32>
+__global__ void __launch_bounds__(256)
+adam_kernel(float* __restrict__ param, h1* __restrict__ param_h, void* __restrict__ grad,
+            float* __restrict__ m, float* __restrict__ v, long long n4, long long n, AdamHyper hp) {
+    adam_dense<GRAD_F32>(param, param_h, grad, m, v, n4, n, hp, blockIdx.x, gridDim.x);
+}
+
 // out[i] = sum_p partials[p][i].  32 columns x 8 row lanes per workgroup, 4 independent loads in
 // flight per thread (a thread per column walking all rows serially measured 62 us for 256 x 10240
 // on MI355X, 64 columns x 4 row lanes 21 us).
@@ -103,13 +112,11 @@ reduce_partials_kernel(const float* __restrict__ partials, int n_partials, int n
 
 // Adam for the small MLP blocks straight from the per-workgroup partial sums: one thread per
 // parameter sums its column of `partials` (n_partials x n) and applies the update.
-__global__ void __launch_bounds__(256)
-adam_partials_kernel(float* __restrict__ param, h1* __restrict__ param_h, const float* __restrict__ partials, int n_partials,
-                     float* __restrict__ m, float* __restrict__ v, int n, float lr, float beta1, float beta2, float eps,
-                     float wd, float bc1, float bc2, float inv_scale, const int32_t* __restrict__ found_inf) {
-    __shared__ float s_acc[8][32];
+__device__ __forceinline__ void adam_from_partials(float* __restrict__ param, h1* __restrict__ param_h, const float* __restrict__ partials,
+                                                   int n_partials, float* __restrict__ m, float* __restrict__ v, int n,
+                                                   const AdamHyper& hp, int block, float (*s_acc)[32]) {
     const int c = threadIdx.x & 31, lane_row = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + c;
+    const int i = block * 32 + c;
     float a0 = 0.f, a1 = 0.f;
     if (i < n) {
         int p = lane_row;
@@ -119,16 +126,36 @@ adam_partials_kernel(float* __restrict__ param, h1* __restrict__ param_h, const 
     s_acc[lane_row][c] = a0 + a1;
     __syncthreads();
     if (lane_row != 0 || i >= n) return;
-    if (found_inf != nullptr && *found_inf != 0) return;
+    if (hp.found_inf != nullptr && *hp.found_inf != 0) return;
     float g = 0.f;
 #pragma unroll
     for (int r = 0; r < 8; ++r) g += s_acc[r][c];
-    g *= inv_scale;
-    const float mk = beta1 * m[i] + (1.f - beta1) * g;
-    const float vk = beta2 * v[i] + (1.f - beta2) * g * g;
-    const float pk = param[i] - lr * ((mk / bc1) / (sqrtf(vk / bc2) + eps) + wd * param[i]);
+    g *= hp.inv_scale;
+    const float mk = hp.beta1 * m[i] + (1.f - hp.beta1) * g;
+    const float vk = hp.beta2 * v[i] + (1.f - hp.beta2) * g * g;
+    const float pk = param[i] - hp.lr * ((mk / hp.bc1) / (sqrtf(vk / hp.bc2) + hp.eps) + hp.wd * param[i]);
     m[i] = mk; v[i] = vk; param[i] = pk;
     if (param_h) param_h[i] = (h1)pk;
+}
+
+__global__ void __launch_bounds__(256)
+adam_partials_kernel(float* __restrict__ param, h1* __restrict__ param_h, const float* __restrict__ partials, int n_partials,
+                     float* __restrict__ m, float* __restrict__ v, int n, AdamHyper hp) {
+    __shared__ float s_acc[8][32];
+    adam_from_partials(param, param_h, partials, n_partials, m, v, n, hp, blockIdx.x, s_acc);
+}
+
+// The whole field in ONE launch: the two MLP blocks (from their partial sums; latency-bound, a few hundred
+// workgroups) are dispatched first and run underneath the HBM-bound stream over the grid parameters.
+struct AdamMlp { float* param; h1* param_h; const float* partials; float* m; float* v; int n; int blocks; };
+__global__ void __launch_bounds__(256)
+adam_field_kernel(float* __restrict__ param, h1* __restrict__ param_h, void* __restrict__ grad16, float* __restrict__ m,
+                  float* __restrict__ v, long long n4, long long n, AdamMlp a, AdamMlp b, int n_partials, AdamHyper hp) {
+    __shared__ float s_acc[8][32];
+    const int blk = blockIdx.x;
+    if (blk < a.blocks) adam_from_partials(a.param, a.param_h, a.partials, n_partials, a.m, a.v, a.n, hp, blk, s_acc);
+    else if (blk < a.blocks + b.blocks) adam_from_partials(b.param, b.param_h, b.partials, n_partials, b.m, b.v, b.n, hp, blk - a.blocks, s_acc);
+    else adam_dense<false>(param, param_h, grad16, m, v, n4, n, hp, blk - a.blocks - b.blocks, (int)gridDim.x - a.blocks - b.blocks);
 }
 
 __global__ void __launch_bounds__(256)
@@ -252,6 +279,14 @@ sample_rays_kernel(const float* __restrict__ poses, const float* __restrict__ di
     if (img_idx) { img_idx[i] = img; pix_idx[i] = pix; }
 }
 
+AdamHyper adam_hyper(float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale, const int32_t* found_inf) {
+    AdamHyper hp;
+    hp.lr = lr; hp.beta1 = beta1; hp.beta2 = beta2; hp.eps = eps; hp.wd = wd;
+    hp.bc1 = 1.0f - powf(beta1, (float)step); hp.bc2 = 1.0f - powf(beta2, (float)step);
+    hp.inv_scale = 1.0f / grad_scale; hp.found_inf = found_inf;
+    return hp;
+}
+
 }  // namespace
 
 extern "C" {
@@ -263,15 +298,15 @@ int ngp_adam_step(float* param, ngp_half* param_h, void* grad, int grad_is_f32, 
     if (n < 0 || step < 1 || grad_scale == 0.f) return NGP_EINVAL;
     if (n == 0) return 0;
     NGP_CHECK_PTR(param); NGP_CHECK_PTR(grad); NGP_CHECK_PTR(m); NGP_CHECK_PTR(v);
-    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    const AdamHyper hp = adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale, found_inf);
     const long long n4 = (n + 3) / 4;
     const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
     if (grad_is_f32)
         hipLaunchKernelGGL(adam_kernel<true>, dim3(blocks), dim3(256), 0, ngp_stream(stream), param, (h1*)param_h, grad, m, v,
-                           n4, (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, 1.0f / grad_scale, found_inf);
+                           n4, (long long)n, hp);
     else
         hipLaunchKernelGGL(adam_kernel<false>, dim3(blocks), dim3(256), 0, ngp_stream(stream), param, (h1*)param_h, grad, m, v,
-                           n4, (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, 1.0f / grad_scale, found_inf);
+                           n4, (long long)n, hp);
     return NGP_LAUNCH_RESULT();
 }
 
@@ -282,9 +317,29 @@ int ngp_adam_step_partials(float* param, ngp_half* param_h, const float* partial
     if (n == 0) return 0;
     NGP_CHECK_PTR(param); NGP_CHECK_PTR(m); NGP_CHECK_PTR(v);
     if (n_partials > 0) NGP_CHECK_PTR(partials);
-    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    const AdamHyper hp = adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale, found_inf);
     hipLaunchKernelGGL(adam_partials_kernel, dim3(ngp_div_up(n, 32)), dim3(256), 0, ngp_stream(stream), param, (h1*)param_h, partials,
-                       n_partials, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, 1.0f / grad_scale, found_inf);
+                       n_partials, m, v, n, hp);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_adam_step_field(float* grid_param, ngp_half* grid_param_h, ngp_half* grid_grad, float* grid_m, float* grid_v, int64_t n_grid,
+                        float* density_param, ngp_half* density_param_h, const float* density_partials, float* density_m,
+                        float* density_v, int n_density, float* rgb_param, ngp_half* rgb_param_h, const float* rgb_partials,
+                        float* rgb_m, float* rgb_v, int n_rgb, int n_partials, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, float grad_scale, const int32_t* found_inf, ngp_stream_t stream) {
+    if (n_grid <= 0 || n_density <= 0 || n_rgb <= 0 || n_partials < 0 || step < 1 || grad_scale == 0.f) return NGP_EINVAL;
+    NGP_CHECK_PTR(grid_param); NGP_CHECK_PTR(grid_grad); NGP_CHECK_PTR(grid_m); NGP_CHECK_PTR(grid_v);
+    NGP_CHECK_PTR(density_param); NGP_CHECK_PTR(density_m); NGP_CHECK_PTR(density_v);
+    NGP_CHECK_PTR(rgb_param); NGP_CHECK_PTR(rgb_m); NGP_CHECK_PTR(rgb_v);
+    if (n_partials > 0) { NGP_CHECK_PTR(density_partials); NGP_CHECK_PTR(rgb_partials); }
+    const AdamHyper hp = adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale, found_inf);
+    const long long n4 = (n_grid + 3) / 4;
+    const int dense_blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    const AdamMlp a = {density_param, (h1*)density_param_h, density_partials, density_m, density_v, n_density, ngp_div_up(n_density, 32)};
+    const AdamMlp b = {rgb_param, (h1*)rgb_param_h, rgb_partials, rgb_m, rgb_v, n_rgb, ngp_div_up(n_rgb, 32)};
+    hipLaunchKernelGGL(adam_field_kernel, dim3(a.blocks + b.blocks + dense_blocks), dim3(256), 0, ngp_stream(stream), grid_param,
+                       (h1*)grid_param_h, (void*)grid_grad, grid_m, grid_v, n4, (long long)n_grid, a, b, n_partials, hp);
     return NGP_LAUNCH_RESULT();
 }
 

@@ -2,7 +2,8 @@
 /root/reference/train.py:131: lr 1e-2, eps 1e-15, adam_w_mode, bias correction) applied by
 ngp_adam_step directly to the native gradient buffers the fused backward leaves behind
 (packed-f16 grid gradient, f32 per-workgroup MLP partials): unscale + Adam + f32->f16 parameter
-cast + gradient zeroing in ONE pass over the 11.4 M parameters.
+cast + gradient zeroing in ONE pass over the 11.4 M parameters and ONE launch for the grid table and
+both MLP blocks (ngp_adam_step_field).
 """
 import math
 
@@ -46,16 +47,13 @@ class FusedAdam:
         with torch.cuda.device(dev):
             sq = stream_handle if stream_handle is not None else stream()
             m, v = self.state["enc"]
+            rm, rv = self.state["rgb"]
             ph = enc._half.t
-            fi = ptr(found_inf)
-            call("ngp_adam_step_partials", ptr(enc.params.data), ptr(ph), ptr(nat["density_partials"]), nat["n_partials"], ptr(m), ptr(v),
-                 enc.n_mlp, lr, b1, b2, self.eps, self.weight_decay, self.t, total_scale, fi, sq)
-            call("ngp_adam_step", ptr(enc.params.data[enc.n_mlp:]), ptr(ph[enc.n_mlp:]), ptr(nat["grid16"]), 0,
-                 ptr(m[enc.n_mlp:]), ptr(v[enc.n_mlp:]), enc.n_grid, lr, b1, b2, self.eps, self.weight_decay, self.t,
-                 total_scale, fi, sq)
-            m, v = self.state["rgb"]
-            call("ngp_adam_step_partials", ptr(net.params.data), ptr(net._half.t), ptr(nat["rgb_partials"]), nat["n_partials"], ptr(m), ptr(v),
-                 net.params.numel(), lr, b1, b2, self.eps, self.weight_decay, self.t, total_scale, fi, sq)
+            ne = enc.n_mlp
+            call("ngp_adam_step_field", ptr(enc.params.data[ne:]), ptr(ph[ne:]), ptr(nat["grid16"]), ptr(m[ne:]), ptr(v[ne:]), enc.n_grid,
+                 ptr(enc.params.data), ptr(ph), ptr(nat["density_partials"]), ptr(m), ptr(v), ne,
+                 ptr(net.params.data), ptr(net._half.t), ptr(nat["rgb_partials"]), ptr(rm), ptr(rv), net.params.numel(),
+                 nat["n_partials"], lr, b1, b2, self.eps, self.weight_decay, self.t, total_scale, ptr(found_inf), sq)
         model._native = None
 
 

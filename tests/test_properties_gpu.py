@@ -152,3 +152,36 @@ def test_adam_matches_torch_adam():
     g2 = torch.ones(n, device="cuda")
     call("ngp_adam_step", ptr(p), ptr(ph), ptr(g2), 1, ptr(m), ptr(v), n, 1e-2, 0.9, 0.999, 1e-15, 0.0, 4, 1.0, ptr(flag), stream())
     assert torch.equal(p, before) and int((g2 != 0).sum()) == 0                        # GradScaler semantics: skip but clear
+
+
+def test_adam_field_launch_is_bit_identical_to_the_three_separate_launches():
+    """ngp_adam_step_field (grid table + both MLP blocks in one launch) == ngp_adam_step on the grid and
+    ngp_adam_step_partials on each MLP block: every parameter, moment, working copy and the zeroed gradient."""
+    from ngp_pl_amd._lib import call, ptr, stream
+    DEV = "cuda"
+    torch.manual_seed(5)
+    n_grid, n_d, n_r, rows = 1_000_003, 3072, 7168, 37        # grid size not a multiple of 4: the scalar tail is covered too
+
+    def state(n):
+        return [torch.randn(n, device=DEV) * 0.1, torch.zeros(n, dtype=torch.float16, device=DEV),
+                torch.rand(n, device=DEV) * 1e-3, torch.rand(n, device=DEV) * 1e-6]          # param, param_h, m, v
+    grid, dens, rgb = state(n_grid), state(n_d), state(n_r)
+    grad = (torch.randn(n_grid, device=DEV) * 0.3).half()
+    grad[::3] = 0
+    pd = torch.randn(rows, n_d, device=DEV); pr = torch.randn(rows, n_r, device=DEV)
+    ref = [[t.clone() for t in s] for s in (grid, dens, rgb)]
+    ref_grad = grad.clone()
+    hyper = (1e-2, 0.9, 0.999, 1e-15, 0.0, 7, 128.0, None, stream())
+    g, d, r = ref
+    call("ngp_adam_step_partials", ptr(d[0]), ptr(d[1]), ptr(pd), rows, ptr(d[2]), ptr(d[3]), n_d, *hyper)
+    call("ngp_adam_step", ptr(g[0]), ptr(g[1]), ptr(ref_grad), 0, ptr(g[2]), ptr(g[3]), n_grid, *hyper)
+    call("ngp_adam_step_partials", ptr(r[0]), ptr(r[1]), ptr(pr), rows, ptr(r[2]), ptr(r[3]), n_r, *hyper)
+    call("ngp_adam_step_field", ptr(grid[0]), ptr(grid[1]), ptr(grad), ptr(grid[2]), ptr(grid[3]), n_grid,
+         ptr(dens[0]), ptr(dens[1]), ptr(pd), ptr(dens[2]), ptr(dens[3]), n_d,
+         ptr(rgb[0]), ptr(rgb[1]), ptr(pr), ptr(rgb[2]), ptr(rgb[3]), n_r, rows, *hyper)
+    torch.cuda.synchronize()
+    for got, want in zip((grid, dens, rgb), ref):
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+    assert torch.equal(grad, ref_grad) and not grad.any()
+    assert torch.equal(grid[1], grid[0].half()) and bool(grid[1].any())    # the update happened and refreshed the working copy
