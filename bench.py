@@ -66,7 +66,7 @@ def kernel_roofline(trainer, draw, n_steps=10):
     algo = {   # bytes per launch
         "march_count(side stream)": 60.0 * R + 4.0 * S, "march_write": 32.0 * S, "hashgrid_fwd": 588.0 * S, "mlp_fwd": 210.0 * S,
         "composite_fw+loss": 28.0 * S + 52.0 * R, "composite_bw": 52.0 * S + 64.0 * R, "mlp_bwd": 300.0 * S,
-        "hashgrid_bwd": 1100.0 * S, "adam": 46.0 * n_params, "grid_update": 0.0,
+        "hashgrid_bwd": 1100.0 * S, "adam": 30.0 * n_params, "grid_update": 0.0,
     }
     stages = []
     for name, ms in acc.items():
@@ -179,10 +179,19 @@ def main():
     gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)       # per-rank independent batches (base.py:25-29)
 
     draw_count = [0]
+    main_stream = torch.cuda.current_stream()
 
-    def draw():
+    def draw(on_side=True):
+        # the batch sampler runs on the trainer's marching stream, in front of the march that consumes its rays (the
+        # main stream picks the batch up behind that march's event); record_stream: the main stream reads them too
         draw_count[0] += 1
-        return data.sample_native(args.rays, draw_count[0], seed=1234 + rank)
+        if trainer.side is None or not on_side:
+            return data.sample_native(args.rays, draw_count[0], seed=1234 + rank)
+        with torch.cuda.stream(trainer.side):
+            batch = data.sample_native(args.rays, draw_count[0], seed=1234 + rank)
+        for t in batch:
+            t.record_stream(main_stream)
+        return batch
 
     cur = draw()
     for _ in range(args.warmup):
@@ -230,7 +239,7 @@ def main():
             out["render_fps_800x800"] = render_fps(model, data, n_frames=5, chunk_scale=4, probe_cap=64)
             out["render_fps_800x800"]["loop"] = "ngp_render_test_frame chunk_scale=4 probe_cap=64"
         out["roofline"] = kernel_roofline(trainer, draw)
-        out["api_path"] = api_path_rate(trainer, draw)
+        out["api_path"] = api_path_rate(trainer, lambda: draw(on_side=False))
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, data)
         print(json.dumps(out))

@@ -105,7 +105,8 @@ int ngp_cells_to_xyz(const int32_t* coords, const float* noise, int n, int grid_
  *     [ray_idx, start_idx, N_samples] with start_idx the exclusive prefix sum of N_samples in
  *     ray order, counter[0] = S, counter[1] = R (i32), and each ray's sample t values into
  *     t_scratch[r*max_samples + k] (caller provides R*max_samples floats; not zero-filled).
- *  2. the caller reads counter[0] (the only host sync) and allocates S-sized outputs;
+ *  2. the caller reads counter[0] (the only host sync) and allocates S-sized outputs
+ *     (counter may be device-mapped pinned host memory: the count then needs no copy);
  *  3. ngp_raymarching_train_write expands the scratch into xyzs,dirs (S,3), deltas,ts (S).
  *
  * hits_t (R,2) f32, noise (R) f32 in [0,1), density_bitfield (cascades*G^3/8) u8. */
@@ -153,6 +154,24 @@ int ngp_composite_train_fw(const float* sigmas, const float* rgbs, const float* 
                            float* ws, int32_t* n_active_per_ray /* optional (R) i32: min(N, total+1) per row */,
                            ngp_stream_t stream);
 
+/* ngp_composite_train_fw + ngp_active_scan + ngp_nerf_loss for the training step in two launches
+ * instead of three (train.py:159-176: render -> NeRFLoss -> mean): every wave also forms its
+ * ray's loss terms and backward seeds (dL_drgb (R,3), dL_dopacity (R), already multiplied by
+ * grad_scale); one small kernel behind it turns the per-row live-sample counts into ray_offsets
+ * (exclusive, row order, total in *n_active) and writes *loss and *sq_err (may be NULL), summed
+ * in row order (deterministic).  rays_a must hold exactly one row per ray, as
+ * ngp_raymarching_train_count writes it.  bg: 3 floats or NULL.  ray_offsets and workspace
+ * (ngp_composite_train_fw_loss_workspace_bytes bytes, scratch) must be 16-byte aligned. */
+size_t ngp_composite_train_fw_loss_workspace_bytes(int n_rays);
+int ngp_composite_train_fw_loss(const float* sigmas, const float* rgbs, const float* deltas,
+                                const float* ts, const int64_t* rays_a, float T_threshold,
+                                int n_rays, int n_samples, int64_t* total_samples, float* opacity,
+                                float* depth, float* rgb, float* ws, int32_t* ray_offsets,
+                                int32_t* n_active, const float* gt_rgb, const float* bg,
+                                float lambda_opacity, float grad_scale, float* loss, float* sq_err,
+                                float* dL_drgb, float* dL_dopacity, void* workspace,
+                                size_t workspace_bytes, ngp_stream_t stream);
+
 /* vren.composite_train_bw (binding.cpp:129-163, volumerendering.cu:87-202).
  * dL_dws may be NULL (treated as zeros).  out: dL_dsigmas (S), dL_drgbs (S,3), fully written. */
 int ngp_composite_train_bw(const float* dL_dopacity, const float* dL_ddepth, const float* dL_drgb,
@@ -163,6 +182,8 @@ int ngp_composite_train_bw(const float* dL_dopacity, const float* dL_ddepth, con
                            float* dL_dsigmas, float* dL_drgbs,
                            const int32_t* ray_offsets, int32_t* active_idx /* both optional: also list the
                            live samples of row n at active_idx[ray_offsets[n] ...] (see ngp_active_scan) */,
+                           const float* xyzs, float* x_active /* both optional, with active_idx: also copy the
+                           listed samples' positions (S,3) to x_active in list order (= ngp_gather_xyz) */,
                            ngp_stream_t stream);
 
 /* vren.composite_test_fw (binding.cpp:166-194, volumerendering.cu:205-285).

@@ -42,8 +42,9 @@ _PROTOS = {
     "ngp_raymarching_train_write": [P, P, P, P, F, F, I, I, I, P, P, P, P, P],
     "ngp_raymarching_test": [P, P, P, P, P, I, F, F, I, I, I, I, P, P, P, P, P, P],
     "ngp_composite_train_fw": [P, P, P, P, P, F, I, I, P, P, P, P, P, P, P],
-    "ngp_composite_train_bw": [P] * 13 + [F, I, I, P, P, P, P, P],
+    "ngp_composite_train_bw": [P] * 13 + [F, I, I, P, P, P, P, P, P, P],
     "ngp_active_scan": [P, I, P, P],
+    "ngp_composite_train_fw_loss": [P, P, P, P, P, F, I, I, P, P, P, P, P, P, P, P, P, F, F, P, P, P, P, P, C.c_size_t, P],
     "ngp_composite_test_fw": [P, P, P, P, P, F, P, I, I, P, P, P, P],
     "ngp_distortion_loss_fw": [P, P, P, P, I, I, P, P, P, P],
     "ngp_distortion_loss_bw": [P, P, P, P, P, P, P, I, I, P, P],
@@ -109,6 +110,8 @@ def lib():
         h.ngp_render_test_workspace_bytes.restype = C.c_size_t
         h.ngp_hashgrid_bwd_binned_workspace_bytes.argtypes = [C.POINTER(GridMeta), I]
         h.ngp_hashgrid_bwd_binned_workspace_bytes.restype = C.c_size_t
+        h.ngp_composite_train_fw_loss_workspace_bytes.argtypes = [I]
+        h.ngp_composite_train_fw_loss_workspace_bytes.restype = C.c_size_t
         h.ngp_occupancy_update_workspace_bytes.argtypes = [I, I]
         h.ngp_occupancy_update_workspace_bytes.restype = C.c_size_t
         _lib = h
@@ -117,7 +120,7 @@ def lib():
 
 def exported_symbols():
     return list(_PROTOS) + ["ngp_build_arch", "ngp_render_test_workspace_bytes", "ngp_occupancy_update_workspace_bytes",
-                                  "ngp_hashgrid_bwd_binned_workspace_bytes"]
+                                  "ngp_hashgrid_bwd_binned_workspace_bytes", "ngp_composite_train_fw_loss_workspace_bytes"]
 
 
 class NgpError(RuntimeError):

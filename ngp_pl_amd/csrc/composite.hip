@@ -10,6 +10,7 @@
 #pragma clang fp contract(off)
 
 #include "ngp_common.h"
+#include "loss_common.h"
 
 namespace {
 
@@ -44,16 +45,24 @@ __device__ __forceinline__ ChunkT chunk_transmittance(float sigma, float delta, 
 // volumerendering.cu:20-44.  One wave per ray: samples on lanes (coalesced streams), front-to-back
 // order kept by the scans.  (The reference runs one THREAD per ray: 8192 serial chains of
 // dependent strided loads, 70-90 us on MI355X for a 300 k-sample batch.)
-__global__ void __launch_bounds__(256)
-composite_train_fw_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
-                          const float* __restrict__ deltas, const float* __restrict__ ts,
-                          const int64_t* __restrict__ rays_a, float T_threshold, int n_rays,
-                          int64_t* __restrict__ total_samples, float* __restrict__ opacity,
-                          float* __restrict__ depth, float* __restrict__ rgb, float* __restrict__ ws,
-                          int32_t* __restrict__ n_active_per_ray) {
-    const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (n >= n_rays) return;
+//
+// LOSS (ngp_composite_train_fw_loss): the wave also evaluates its ray's loss terms and backward seeds; one small
+// kernel behind it (composite_fw_tail_kernel) turns the per-row live-sample counts into exclusive offsets and adds
+// the per-row loss terms in row order -- ngp_active_scan and ngp_nerf_loss in one launch instead of two.  (Doing
+// that in the last workgroup of THIS kernel behind a ticket was measured: the device-scope fences of 2048 workgroups
+// cost 266 us and slowed the concurrent march by 70 %.)
+struct FwTail {
+    const float* gt; const float* bg; float lambda_o, grad_scale;
+    float* loss; float* sq_err; float* dL_drgb; float* dL_dopacity;
+    int32_t* n_active; float* row_loss; float* row_sq;
+};
+
+__device__ __forceinline__ void composite_fw_ray(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                 const float* __restrict__ deltas, const float* __restrict__ ts,
+                                                 const int64_t* __restrict__ rays_a, float T_threshold, int n, int lane,
+                                                 int64_t* __restrict__ total_samples, float* __restrict__ opacity,
+                                                 float* __restrict__ depth, float* __restrict__ rgb, float* __restrict__ ws,
+                                                 int32_t* __restrict__ n_active_per_ray, const FwTail* tail, int n_rays) {
     const int64_t ray_idx = rays_a[3 * (size_t)n];
     const int64_t start = rays_a[3 * (size_t)n + 1];
     const int N = (int)rays_a[3 * (size_t)n + 2];
@@ -84,7 +93,87 @@ composite_train_fw_kernel(const float* __restrict__ sigmas, const float* __restr
         depth[ray_idx] = D; opacity[ray_idx] = O;
         total_samples[ray_idx] = samples;
         if (n_active_per_ray) n_active_per_ray[n] = min(N, samples + 1);   // samples that can carry gradient (row order)
+        if (tail) {
+            const float c[3] = {R, G, B};
+            const float g[3] = {tail->gt[3 * ray_idx], tail->gt[3 * ray_idx + 1], tail->gt[3 * ray_idx + 2]};
+            float d_rgb[3], d_o, l = 0.f, se = 0.f;
+            nerf_loss_ray(O, c, g, tail->bg, tail->lambda_o, tail->grad_scale, 1.0f / (float)n_rays, 1.0f / (3.0f * (float)n_rays),
+                          d_rgb, d_o, l, se);
+            tail->dL_drgb[3 * ray_idx] = d_rgb[0]; tail->dL_drgb[3 * ray_idx + 1] = d_rgb[1]; tail->dL_drgb[3 * ray_idx + 2] = d_rgb[2];
+            tail->dL_dopacity[ray_idx] = d_o;
+            tail->row_loss[n] = l; tail->row_sq[n] = se;
+        }
     }
+}
+
+// One workgroup of 1024 threads, tiles of 8192 rows, 8 consecutive rows per thread (vector loads, all in flight
+// together): counts -> exclusive offsets in place, total -> *n_active; loss terms added in row order.
+constexpr int TAIL_ITEMS = 8;
+__global__ void __launch_bounds__(1024)
+composite_fw_tail_kernel(FwTail t, int32_t* __restrict__ n_act, int n_rays) {
+    __shared__ int s_wave[16];
+    __shared__ int s_carry;
+    __shared__ float s_l[16], s_e[16];
+    const int tid = threadIdx.x;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    float l = 0.f, se = 0.f;
+    for (int base = 0; base < n_rays; base += 1024 * TAIL_ITEMS) {
+        const int i0 = base + TAIL_ITEMS * tid;
+        int v[TAIL_ITEMS]; float rl[TAIL_ITEMS], rs[TAIL_ITEMS];
+        if (i0 + TAIL_ITEMS <= n_rays) {
+#pragma unroll
+            for (int q = 0; q < TAIL_ITEMS / 4; ++q) {
+                const int4 a = *reinterpret_cast<const int4*>(n_act + i0 + 4 * q);
+                const float4 b = *reinterpret_cast<const float4*>(t.row_loss + i0 + 4 * q);
+                const float4 c = *reinterpret_cast<const float4*>(t.row_sq + i0 + 4 * q);
+                v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+                rl[4 * q] = b.x; rl[4 * q + 1] = b.y; rl[4 * q + 2] = b.z; rl[4 * q + 3] = b.w;
+                rs[4 * q] = c.x; rs[4 * q + 1] = c.y; rs[4 * q + 2] = c.z; rs[4 * q + 3] = c.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < TAIL_ITEMS; ++k) {
+                const bool in = i0 + k < n_rays;
+                v[k] = in ? n_act[i0 + k] : 0; rl[k] = in ? t.row_loss[i0 + k] : 0.f; rs[k] = in ? t.row_sq[i0 + k] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < TAIL_ITEMS; ++k) { l += rl[k]; se += rs[k]; }
+        int run = ngp_block_scan_tile<TAIL_ITEMS>(v, s_wave, &s_carry);
+#pragma unroll
+        for (int k = 0; k < TAIL_ITEMS; ++k) {
+            if (i0 + k < n_rays) n_act[i0 + k] = run;
+            run += v[k];
+        }
+        __syncthreads();                               // the carry of this tile is visible to the next
+    }
+    l = ngp_wave_sum(l); se = ngp_wave_sum(se);
+    if ((tid & 63) == 0) { s_l[tid >> 6] = l; s_e[tid >> 6] = se; }
+    __syncthreads();
+    if (tid == 0) {
+        float tl = 0.f, te = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { tl += s_l[w]; te += s_e[w]; }
+        *t.n_active = s_carry;
+        *t.loss = tl;
+        if (t.sq_err) *t.sq_err = te;
+    }
+}
+
+template <bool LOSS>
+__global__ void __launch_bounds__(256)
+composite_train_fw_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                          const float* __restrict__ deltas, const float* __restrict__ ts,
+                          const int64_t* __restrict__ rays_a, float T_threshold, int n_rays,
+                          int64_t* __restrict__ total_samples, float* __restrict__ opacity,
+                          float* __restrict__ depth, float* __restrict__ rgb, float* __restrict__ ws,
+                          int32_t* __restrict__ n_active_per_ray, FwTail tail) {
+    const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (n >= n_rays) return;
+    composite_fw_ray(sigmas, rgbs, deltas, ts, rays_a, T_threshold, n, lane, total_samples, opacity, depth, rgb, ws,
+                     n_active_per_ray, LOSS ? &tail : nullptr, n_rays);
 }
 
 // volumerendering.cu:106-150 (+ host pre-multiply :175), one wave per ray.  The running prefixes
@@ -98,7 +187,8 @@ composite_train_bw_kernel(const float* __restrict__ dL_dopacity, const float* __
                           const float* __restrict__ opacity, const float* __restrict__ depth,
                           const float* __restrict__ rgb, float T_threshold, int n_rays,
                           float* __restrict__ dL_dsigmas, float* __restrict__ dL_drgbs,
-                          const int32_t* __restrict__ ray_offsets, int32_t* __restrict__ active_idx) {
+                          const int32_t* __restrict__ ray_offsets, int32_t* __restrict__ active_idx,
+                          const float* __restrict__ xyzs, float* __restrict__ x_active) {
     const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (n >= n_rays) return;
@@ -140,7 +230,13 @@ composite_train_bw_kernel(const float* __restrict__ dL_dopacity, const float* __
                               gO * (1 - O) + gD * (tk * T - (D - d)) + T * gw - (P_total - P));
             }
             dL_dsigmas[s] = ds; dL_drgbs[3 * s] = dr; dL_drgbs[3 * s + 1] = dg; dL_drgbs[3 * s + 2] = db;
-            if (active_idx && c.live) active_idx[a_off + k] = (int32_t)s;   // live samples are the first min(N, total+1) of the ray
+            if (active_idx && c.live) {                                     // live samples are the first min(N, total+1) of the ray
+                active_idx[a_off + k] = (int32_t)s;
+                if (x_active) {                                             // their positions in the same compact order
+                    float* __restrict__ xo = x_active + 3 * (size_t)(a_off + k);
+                    xo[0] = xyzs[3 * s]; xo[1] = xyzs[3 * s + 1]; xo[2] = xyzs[3 * s + 2];
+                }
+            }
         }
         stopped = __ballot(valid && c.T_after <= T_threshold) != 0ull;
         T_carry = __shfl(c.T_after, 63, 64);
@@ -244,8 +340,34 @@ int ngp_composite_train_fw(const float* sigmas, const float* rgbs, const float* 
     if (n_rays == 0) return 0;
     NGP_CHECK_PTR(rays_a); NGP_CHECK_PTR(total_samples); NGP_CHECK_PTR(opacity); NGP_CHECK_PTR(depth); NGP_CHECK_PTR(rgb);
     if (n_samples > 0) { NGP_CHECK_PTR(sigmas); NGP_CHECK_PTR(rgbs); NGP_CHECK_PTR(deltas); NGP_CHECK_PTR(ts); NGP_CHECK_PTR(ws); }
-    hipLaunchKernelGGL(composite_train_fw_kernel, dim3(ngp_div_up((long long)n_rays * 64, 256)), dim3(256), 0, ngp_stream(stream),
-                       sigmas, rgbs, deltas, ts, rays_a, T_threshold, n_rays, total_samples, opacity, depth, rgb, ws, n_active_per_ray);
+    hipLaunchKernelGGL(composite_train_fw_kernel<false>, dim3(ngp_div_up((long long)n_rays * 64, 256)), dim3(256), 0, ngp_stream(stream),
+                       sigmas, rgbs, deltas, ts, rays_a, T_threshold, n_rays, total_samples, opacity, depth, rgb, ws, n_active_per_ray,
+                       FwTail{});
+    return NGP_LAUNCH_RESULT();
+}
+
+size_t ngp_composite_train_fw_loss_workspace_bytes(int n_rays) { return n_rays < 0 ? 0 : 8 * (((size_t)n_rays + 3) & ~(size_t)3); }
+
+int ngp_composite_train_fw_loss(const float* sigmas, const float* rgbs, const float* deltas, const float* ts,
+                                const int64_t* rays_a, float T_threshold, int n_rays, int n_samples,
+                                int64_t* total_samples, float* opacity, float* depth, float* rgb, float* ws,
+                                int32_t* ray_offsets, int32_t* n_active, const float* gt_rgb, const float* bg,
+                                float lambda_opacity, float grad_scale, float* loss, float* sq_err, float* dL_drgb,
+                                float* dL_dopacity, void* workspace, size_t workspace_bytes, ngp_stream_t stream) {
+    if (n_rays <= 0 || n_samples < 0) return NGP_EINVAL;
+    NGP_CHECK_PTR(rays_a); NGP_CHECK_PTR(total_samples); NGP_CHECK_PTR(opacity); NGP_CHECK_PTR(depth); NGP_CHECK_PTR(rgb);
+    NGP_CHECK_PTR(ray_offsets); NGP_CHECK_PTR(n_active); NGP_CHECK_PTR(gt_rgb); NGP_CHECK_PTR(loss); NGP_CHECK_PTR(dL_drgb);
+    NGP_CHECK_PTR(dL_dopacity); NGP_CHECK_PTR(workspace);
+    if (n_samples > 0) { NGP_CHECK_PTR(sigmas); NGP_CHECK_PTR(rgbs); NGP_CHECK_PTR(deltas); NGP_CHECK_PTR(ts); NGP_CHECK_PTR(ws); }
+    if (workspace_bytes < ngp_composite_train_fw_loss_workspace_bytes(n_rays) || ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(ray_offsets)) & 15) != 0) return NGP_EINVAL;
+    FwTail t;
+    t.gt = gt_rgb; t.bg = bg; t.lambda_o = lambda_opacity; t.grad_scale = grad_scale;
+    t.loss = loss; t.sq_err = sq_err; t.dL_drgb = dL_drgb; t.dL_dopacity = dL_dopacity; t.n_active = n_active;
+    t.row_loss = static_cast<float*>(workspace);
+    t.row_sq = t.row_loss + ((n_rays + 3) & ~3);                          // keeps the float4 loads of the tail aligned
+    hipLaunchKernelGGL(composite_train_fw_kernel<true>, dim3(ngp_div_up((long long)n_rays * 64, 256)), dim3(256), 0, ngp_stream(stream),
+                       sigmas, rgbs, deltas, ts, rays_a, T_threshold, n_rays, total_samples, opacity, depth, rgb, ws, ray_offsets, t);
+    hipLaunchKernelGGL(composite_fw_tail_kernel, dim3(1), dim3(1024), 0, ngp_stream(stream), t, ray_offsets, n_rays);
     return NGP_LAUNCH_RESULT();
 }
 
@@ -254,16 +376,18 @@ int ngp_composite_train_bw(const float* dL_dopacity, const float* dL_ddepth, con
                            const float* deltas, const float* ts, const int64_t* rays_a,
                            const float* opacity, const float* depth, const float* rgb, float T_threshold,
                            int n_rays, int n_samples, float* dL_dsigmas, float* dL_drgbs,
-                           const int32_t* ray_offsets, int32_t* active_idx, ngp_stream_t stream) {
+                           const int32_t* ray_offsets, int32_t* active_idx, const float* xyzs, float* x_active,
+                           ngp_stream_t stream) {
     if (n_rays < 0 || n_samples < 0) return NGP_EINVAL;
     if (n_rays == 0 || n_samples == 0) return 0;
     NGP_CHECK_PTR(dL_dopacity); NGP_CHECK_PTR(dL_ddepth); NGP_CHECK_PTR(dL_drgb); NGP_CHECK_PTR(sigmas);
     NGP_CHECK_PTR(rgbs); NGP_CHECK_PTR(ws); NGP_CHECK_PTR(deltas); NGP_CHECK_PTR(ts); NGP_CHECK_PTR(rays_a);
     NGP_CHECK_PTR(opacity); NGP_CHECK_PTR(depth); NGP_CHECK_PTR(rgb); NGP_CHECK_PTR(dL_dsigmas); NGP_CHECK_PTR(dL_drgbs);
     if ((ray_offsets == nullptr) != (active_idx == nullptr)) return NGP_EINVAL;
+    if ((xyzs == nullptr) != (x_active == nullptr) || (x_active != nullptr && active_idx == nullptr)) return NGP_EINVAL;
     hipLaunchKernelGGL(composite_train_bw_kernel, dim3(ngp_div_up((long long)n_rays * 64, 256)), dim3(256), 0, ngp_stream(stream),
                        dL_dopacity, dL_ddepth, dL_drgb, dL_dws, sigmas, rgbs, ws, deltas, ts, rays_a,
-                       opacity, depth, rgb, T_threshold, n_rays, dL_dsigmas, dL_drgbs, ray_offsets, active_idx);
+                       opacity, depth, rgb, T_threshold, n_rays, dL_dsigmas, dL_drgbs, ray_offsets, active_idx, xyzs, x_active);
     return NGP_LAUNCH_RESULT();
 }
 

@@ -73,6 +73,7 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const
     const int chunk = (int)blockIdx.x - level * n_chunks;
     const int n = n_active ? min(*n_active, n_samples) : n_samples;
     const int ns = plan.n_slices[level];
+    if (blockIdx.x == 0 && threadIdx.x == 0) ws.queue[0] = 0;       // the slice owners' task counter (they start after this kernel)
     int32_t* __restrict__ dir = ws.dir + (size_t)level * MAX_SLICES * n_chunks + chunk;     // + s * n_chunks
     if (chunk * CHUNK >= n) {                                      // nothing here: empty segments
         for (int i = threadIdx.x; i < ns; i += BIN_THREADS) dir[(size_t)i * n_chunks] = 0;
@@ -455,8 +456,7 @@ int ngp_hashgrid_bwd_binned(const float* x, const float* xyz_min, const float* x
     ws.dir = reinterpret_cast<int32_t*>(wsb + L.dir);
     ws.pool = reinterpret_cast<int32_t*>(wsb + L.pool);
     ws.partial = reinterpret_cast<float2*>(wsb + L.partial);
-    hipError_t e = hipMemsetAsync(ws.queue, 0, 256, st);
-    if (e != hipSuccess) return (int)e;
+    hipError_t e = hipSuccess;
     const GridMeta dm = to_dev_meta(meta);
     bin_kernel<<<dim3(meta->n_levels * P.n_chunks), dim3(BIN_THREADS), 0, st>>>(
         x, xyz_min, xyz_max, (const half2_t*)dfeats, dm, P, ws, n_samples, active_idx, n_active);

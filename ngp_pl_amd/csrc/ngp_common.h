@@ -39,8 +39,8 @@ __device__ __forceinline__ float ngp_wave_sum(float v) {
     return v;
 }
 
-// Exclusive scan across a 1024-thread workgroup where every thread owns ITEMS consecutive counts (v, already
-// loaded: all of a tile's loads are in flight together, one memory latency per tile of 1024*ITEMS counts).
+// Exclusive scan across a workgroup (up to 1024 threads) where every thread owns ITEMS consecutive counts (v, already
+// loaded: all of a tile's loads are in flight together, one memory latency per tile of blockDim.x*ITEMS counts).
 // Returns the exclusive prefix of the thread's first item, carry-in included; *s_carry is advanced by the tile
 // total.  s_wave: 16 ints, s_carry: 1 int of LDS (zeroed by the caller before the first tile).
 template <int ITEMS>
@@ -60,6 +60,6 @@ __device__ __forceinline__ int ngp_block_scan_tile(const int (&v)[ITEMS], int* s
     int off = *s_carry;
     for (int w = 0; w < wave; ++w) off += s_wave[w];
     __syncthreads();                                   // everyone has read the carry and the wave totals
-    if (tid == 1023) *s_carry = off + incl;
+    if (tid == (int)blockDim.x - 1) *s_carry = off + incl;
     return off + incl - mine;
 }

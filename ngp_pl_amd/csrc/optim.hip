@@ -7,6 +7,7 @@
 //  * ngp_nerf_loss    NeRFLoss (losses.py:47-60) + mean reduction (train.py:173) + background
 //                     blend (rendering.py:153-161) with analytic backward seeds.
 #include "ngp_common.h"
+#include "loss_common.h"
 #include <hip/hip_fp16.h>
 
 namespace {
@@ -167,28 +168,6 @@ __global__ void __launch_bounds__(256)
 cast_f16_f32_kernel(const h1* __restrict__ in, long long n, float scale, float* __restrict__ out) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (float)in[i] * scale;
-}
-
-// per-ray loss terms + backward seeds (losses.py:47-60, train.py:173, bg blend rendering.py:153-161)
-__device__ __forceinline__ void nerf_loss_ray(float o, const float (&c)[3], const float (&g)[3], const float* __restrict__ bg,
-                                              float lambda_o, float grad_scale, float inv_r, float inv_3r,
-                                              float (&d_rgb)[3], float& d_o, float& l, float& se) {
-    float go = 0.f, se_ray = 0.f;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float b = bg ? bg[k] : 0.f;
-        const float diff = c[k] + b * (1.0f - o) - g[k];
-        se_ray += diff * diff;
-        const float gr = 2.0f * diff * inv_3r;
-        d_rgb[k] = gr * grad_scale;
-        go -= gr * b;
-    }
-    const float oe = o + 1e-10f;
-    const float lg = __logf(oe);
-    l += se_ray * inv_3r + lambda_o * (-oe * lg) * inv_r;
-    se += se_ray;
-    go += lambda_o * (-(lg + 1.0f)) * inv_r;
-    d_o = go * grad_scale;
 }
 
 // OVERWRITE mode (n_rays <= 16384): workgroups park their partial sums in a library-owned scratch,

@@ -49,6 +49,7 @@ class Trainer:
         # NGP_BINNED_BWD=0 / binned_backward=False selects the one-pass sliced kernel
         self.binned_backward = bool(int(os.environ.get("NGP_BINNED_BWD", "1"))) if binned_backward is None else binned_backward
         self._bin_ws = None
+        self._fw_ws = None               # per-row loss terms of ngp_composite_train_fw_loss
         # The marching stream must land on its own hardware queue or nothing overlaps: HIP multiplexes streams onto
         # a few HSA queues (GPU_MAX_HW_QUEUES, default 4) round-robin, and once RCCL has created its streams a
         # default-priority stream was observed to share the main stream's queue (rocprofv3: every kernel on one
@@ -85,14 +86,15 @@ class Trainer:
 
     def _march(self, rays_o, rays_d):
         """AABB + near clamp + pass 1 of the march (+ ray-ordered scan).  Enqueued on the side
-        stream behind everything the main stream has queued so far; the packed sample count is
-        copied to pinned host memory there."""
+        stream behind everything the main stream has queued so far; the packed sample count
+        lands in pinned host memory."""
         m = self.model
         n, dev = rays_o.shape[0], rays_o.device
         hits_t = torch.empty(n, 2, dtype=torch.float32, device=dev)
         rays_a = torch.empty(n, 3, dtype=torch.int64, device=dev)
-        counter = torch.empty(2, dtype=torch.int32, device=dev)
         scratch = torch.empty(n * MAX_SAMPLES, dtype=torch.float32, device=dev)
+        # {S, R} is written by the scan kernel straight into pinned (device-mapped) host memory: no copy kernel and no
+        # extra launch between the march and the event the host waits on
         counter_host = torch.empty(2, dtype=torch.int32, pin_memory=True)
         main = torch.cuda.current_stream()
         st = self.side if self.side is not None else main
@@ -107,13 +109,12 @@ class Trainer:
             noise = torch.rand(n, dtype=torch.float32, device=dev)        # jitter of the first sample (custom_functions.py:83); drawn on the marching stream
             call("ngp_ray_aabb_near", ptr(rays_o), ptr(rays_d), ptr(m.center), ptr(m.half_size), NEAR_DISTANCE, n, ptr(hits_t), sq)
             call("ngp_raymarching_train_count", ptr(rays_o), ptr(rays_d), ptr(hits_t), ptr(m.density_bitfield), m.cascades,
-                 float(m.scale), self.exp_step_factor, ptr(noise), m.grid_size, MAX_SAMPLES, n, ptr(rays_a), ptr(counter),
+                 float(m.scale), self.exp_step_factor, ptr(noise), m.grid_size, MAX_SAMPLES, n, ptr(rays_a), ptr(counter_host),
                  ptr(scratch), sq)
             if self.events is not None:
                 t1 = torch.cuda.Event(enable_timing=True); t1.record()
-            counter_host.copy_(counter, non_blocking=True)
             done = torch.cuda.Event(); done.record()
-        return dict(rays_o=rays_o, rays_d=rays_d, rays_a=rays_a, counter=counter, counter_host=counter_host, scratch=scratch,
+        return dict(rays_o=rays_o, rays_d=rays_d, rays_a=rays_a, counter_host=counter_host, scratch=scratch,
                     hits_t=hits_t, noise=noise, done=done, timing=(t0, t1) if t0 is not None else None)
 
     # -- the hot path --------------------------------------------------------------------------
@@ -134,15 +135,22 @@ class Trainer:
                 rec = self._march(rays_o.contiguous(), rays_d.contiguous())
             self._pending = None
             n = rays_o.shape[0]
-            rec["done"].synchronize()                      # the step's only host wait: the march of THIS batch
-            S = int(rec["counter_host"][0])
-            main.wait_event(rec["done"])
-            self.march_ms = rec["timing"]
             # march of the next batch: concurrent with this step unless the occupancy grid is due
-            # for an update first (that needs this step's optimizer result)
+            # for an update first (that needs this step's optimizer result).  Enqueued BEFORE the
+            # host blocks on this batch's march: the marching stream then runs the marches back to
+            # back instead of idling for a host round trip (wake-up + enqueue) between them.
             next_needs_update = (self.global_step + 1) % self.update_interval == 0
             if next_batch is not None and not next_needs_update:
                 self._pending = self._march(next_batch[0], next_batch[1])
+            # the step's only host wait: the march of THIS batch.  Polled, not Event.synchronize(): the blocking wait
+            # sleeps on an interrupt and wakes tens of microseconds late, which left the main stream idle at every step
+            done = rec["done"]
+            while not done.query():
+                pass
+            S = int(rec["counter_host"][0])
+            # no main.wait_event(done): the host has just observed the event, so everything enqueued from here on is
+            # ordered behind the march already; the barrier packet measured ~20 us of idle main stream per step
+            self.march_ms = rec["timing"]
             if self.events is not None:
                 self.events = []
             self._mark("start")
@@ -171,11 +179,13 @@ class Trainer:
                 self._mark("hashgrid_fwd")
                 call("ngp_field_fwd", ptr(feats), ptr(dirs), ptr(eh), ptr(rh), S, ptr(sigmas), ptr(rgbs), ptr(h), mq)
                 self._mark("mlp_fwd")
-            call("ngp_composite_train_fw", ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(ts), ptr(rays_a), self.T_threshold, n, S,
-                 ptr(total), ptr(opacity), ptr(depth), ptr(rgb), ptr(ws), ptr(ray_offs), mq)
-            call("ngp_active_scan", ptr(ray_offs), n, ptr(n_active), mq)
-            call("ngp_nerf_loss", ptr(rgb), ptr(opacity), ptr(rgb_gt), ptr(self.bg), self.lambda_opacity, self.grad_scale, n,
-                 ptr(stats), ptr(stats[1:]), ptr(dL_drgb), ptr(dL_dopacity), mq)
+            # composite + per-ray loss seeds, then one small kernel: offsets of the live samples and the loss sums
+            if self._fw_ws is None or self._fw_ws.numel() < 8 * (n + 3):
+                self._fw_ws = torch.empty(8 * (n + 3), dtype=torch.uint8, device=dev)
+            call("ngp_composite_train_fw_loss", ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(ts), ptr(rays_a), self.T_threshold, n, S,
+                 ptr(total), ptr(opacity), ptr(depth), ptr(rgb), ptr(ws), ptr(ray_offs), ptr(n_active), ptr(rgb_gt), ptr(self.bg),
+                 self.lambda_opacity, self.grad_scale, ptr(stats), ptr(stats[1:]), ptr(dL_drgb), ptr(dL_dopacity),
+                 ptr(self._fw_ws), self._fw_ws.numel(), mq)
             self._mark("composite_fw+loss")
             if S > 0:
                 # backward only over the samples up to each ray's early stop (the rest have zero gradient):
@@ -192,9 +202,12 @@ class Trainer:
                     dL_dws = torch.empty(S, **f32)
                     call("ngp_distortion_loss_bw", ptr(self._dist_seed[1]), ptr(ws_incl), ptr(wts_incl), ptr(ws), ptr(deltas), ptr(ts),
                          ptr(rays_a), n, S, ptr(dL_dws), mq)
+                # the binned table backward reads the live samples' positions as a stream: composite_bw copies them in list order
+                nbytes = _lib.lib().ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(enc.meta), S) if self.binned_backward else 0
+                x_act = torch.empty(S, 3, **f32) if nbytes else None      # 0: batch too large for the binned variant (occupancy warm-up)
                 call("ngp_composite_train_bw", ptr(dL_dopacity), ptr(dL_ddepth), ptr(dL_drgb), ptr(dL_dws), ptr(sigmas), ptr(rgbs), ptr(ws),
                      ptr(deltas), ptr(ts), ptr(rays_a), ptr(opacity), ptr(depth), ptr(rgb), self.T_threshold, n, S,
-                     ptr(dL_dsigmas), ptr(dL_drgbs), ptr(ray_offs), ptr(active), mq)
+                     ptr(dL_dsigmas), ptr(dL_drgbs), ptr(ray_offs), ptr(active), ptr(xyzs) if nbytes else None, ptr(x_act), mq)
                 self._mark("composite_bw")
                 n_part = call("ngp_field_bwd_partials", S)
                 partials = torch.empty(n_part * (enc.n_mlp + net.params.numel()), **f32)
@@ -207,12 +220,9 @@ class Trainer:
                                  n_partials=n_part, scale=tcnn.LOSS_SCALE)
                 if self.mlp_grad_hook is not None:
                     self.mlp_grad_hook()
-                nbytes = _lib.lib().ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(enc.meta), S) if self.binned_backward else 0
-                if nbytes:                              # 0: batch too large for the binned variant (occupancy warm-up)
+                if nbytes:
                     if self._bin_ws is None or self._bin_ws.numel() < nbytes:
                         self._bin_ws = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=dev)
-                    x_act = torch.empty(S, 3, **f32)
-                    call("ngp_gather_xyz", ptr(xyzs), ptr(active), ptr(n_active), S, ptr(x_act), mq)
                     call("ngp_hashgrid_bwd_binned", ptr(x_act), ptr(m.xyz_min), ptr(m.xyz_max), ptr(dfeats), C.byref(enc.meta), S,
                          None, ptr(n_active), ptr(self._bin_ws), self._bin_ws.numel(), ptr(g16), mq)
                 else:

@@ -140,7 +140,7 @@ def composite_train_bw(dL_dopacity, dL_ddepth, dL_drgb, dL_dws, sigmas, rgbs, ws
     dsig = torch.empty(S, dtype=torch.float32, device=dev)
     drgbs = torch.empty(S, 3, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        call("ngp_composite_train_bw", *[ptr(a) for a in args], float(T_threshold), R, S, ptr(dsig), ptr(drgbs), None, None, stream())
+        call("ngp_composite_train_bw", *[ptr(a) for a in args], float(T_threshold), R, S, ptr(dsig), ptr(drgbs), None, None, None, None, stream())
     return [dsig, drgbs]
 
 

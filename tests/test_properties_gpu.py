@@ -185,3 +185,47 @@ def test_adam_field_launch_is_bit_identical_to_the_three_separate_launches():
             assert torch.equal(a, b)
     assert torch.equal(grad, ref_grad) and not grad.any()
     assert torch.equal(grid[1], grid[0].half()) and bool(grid[1].any())    # the update happened and refreshed the working copy
+
+
+@pytest.mark.parametrize("n_rays", [1, 777, 8192, 20000])
+def test_fused_composite_loss_launch_equals_the_three_separate_launches(n_rays):
+    """ngp_composite_train_fw_loss == ngp_composite_train_fw + ngp_active_scan + ngp_nerf_loss: composited outputs,
+    offsets, live count and backward seeds bit for bit; the two scalar sums to float rounding (different, but
+    fixed, summation order)."""
+    from ngp_pl_amd._lib import call, lib, ptr, stream
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(n_rays)
+    counts = torch.randint(0, 90, (n_rays,), device=dev, generator=g)
+    counts[::7] = 0                                                       # rays that miss everything
+    S = int(counts.sum())
+    rays_a = torch.stack([torch.arange(n_rays, device=dev), torch.cumsum(counts, 0) - counts, counts], 1).contiguous()
+    sigmas = torch.rand(S, device=dev, generator=g) * 60; rgbs = torch.rand(S, 3, device=dev, generator=g)
+    deltas = torch.full((S,), 1.7e-3, device=dev); ts = torch.rand(S, device=dev, generator=g) + 0.5
+    gt = torch.rand(n_rays, 3, device=dev, generator=g); bg = torch.ones(3, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+
+    def outputs():
+        return dict(total=torch.empty(n_rays, dtype=torch.int64, device=dev), opacity=torch.empty(n_rays, **f32),
+                    depth=torch.empty(n_rays, **f32), rgb=torch.empty(n_rays, 3, **f32), ws=torch.empty(S, **f32),
+                    offs=torch.empty(n_rays, dtype=torch.int32, device=dev), n_active=torch.empty(1, dtype=torch.int32, device=dev),
+                    stats=torch.empty(2, **f32), d_rgb=torch.empty(n_rays, 3, **f32), d_o=torch.empty(n_rays, **f32))
+    a = outputs()
+    call("ngp_composite_train_fw", ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(ts), ptr(rays_a), 1e-4, n_rays, S, ptr(a["total"]),
+         ptr(a["opacity"]), ptr(a["depth"]), ptr(a["rgb"]), ptr(a["ws"]), ptr(a["offs"]), stream())
+    call("ngp_active_scan", ptr(a["offs"]), n_rays, ptr(a["n_active"]), stream())
+    call("ngp_nerf_loss", ptr(a["rgb"]), ptr(a["opacity"]), ptr(gt), ptr(bg), 1e-3, 128.0, n_rays, ptr(a["stats"]), ptr(a["stats"][1:]),
+         ptr(a["d_rgb"]), ptr(a["d_o"]), stream())
+    nbytes = lib().ngp_composite_train_fw_loss_workspace_bytes(n_rays)
+    assert 8 * n_rays <= nbytes <= 8 * n_rays + 24
+    wsp = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    for _ in range(2):
+        b = outputs()
+        call("ngp_composite_train_fw_loss", ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(ts), ptr(rays_a), 1e-4, n_rays, S, ptr(b["total"]),
+             ptr(b["opacity"]), ptr(b["depth"]), ptr(b["rgb"]), ptr(b["ws"]), ptr(b["offs"]), ptr(b["n_active"]), ptr(gt), ptr(bg),
+             1e-3, 128.0, ptr(b["stats"]), ptr(b["stats"][1:]), ptr(b["d_rgb"]), ptr(b["d_o"]), ptr(wsp), nbytes, stream())
+        torch.cuda.synchronize()
+        for k in a:
+            if k == "stats":
+                assert torch.allclose(a[k], b[k], rtol=1e-5, atol=0), (a[k], b[k])
+            else:
+                assert torch.equal(a[k], b[k]), k
