@@ -2,8 +2,9 @@
 (NeRFLoss at losses.py:40-60, DistortionLoss at losses.py:6-37), on top of `ngp_pl_amd.vren`.
 
 `NeRFLoss(lambda_opacity, lambda_distortion)(results, target)` returns the same dictionary of
-per-element terms; the trainer's fused kernel `ngp_nerf_loss` computes the default recipe
-(rgb + opacity terms, mean-reduced, with analytic backward seeds) in one launch.
+per-element terms; the native step computes the default recipe (rgb + opacity terms, mean-reduced,
+with analytic backward seeds) inside the compositing kernel (`ngp_composite_train_fw_loss`;
+`ngp_nerf_loss` is the stand-alone form).
 """
 import torch
 from torch import nn

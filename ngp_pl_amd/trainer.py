@@ -4,7 +4,7 @@
 
 Two implementations of the same step:
   * `step()`          -- the hot path: direct calls into libngp_hip.so, no autograd graph, native
-                         gradient buffers consumed by optim.FusedAdam.  ~20 kernel launches and one
+                         gradient buffers consumed by optim.FusedAdam.  12 kernel launches and one
                          8-byte host read (the packed sample count).  The ray march of step k+1
                          only needs the occupancy bitfield, so it runs on a SECOND HIP stream
                          concurrently with step k's encode/MLP/backward kernels (the march is a
@@ -167,7 +167,7 @@ class Trainer:
             sigmas = torch.empty(S, **f32); rgbs = torch.empty(S, 3, **f32)
             total = torch.empty(n, dtype=torch.int64, device=dev)
             opacity = torch.empty(n, **f32); depth = torch.empty(n, **f32); rgb = torch.empty(n, 3, **f32); ws = torch.empty(S, **f32)
-            stats = torch.empty(2, **f32)                  # loss, sum of squared error (written by ngp_nerf_loss)
+            stats = torch.empty(2, **f32)                  # loss, sum of squared error (written by ngp_composite_train_fw_loss)
             dL_drgb = torch.empty(n, 3, **f32); dL_dopacity = torch.empty(n, **f32)
             if self._zeros is None or self._zeros.shape[0] != n:
                 self._zeros = torch.zeros(n, **f32)        # dL/ddepth: the loss has no depth term
