@@ -126,3 +126,25 @@ def test_workspace_queries_and_new_entry_points_validate_on_host():
         _lib.call("ngp_hashgrid_bwd_input", None, None, None, None, None, C.byref(meta), 10, 1.0, None, None)
     assert _lib.call("ngp_sh4_bwd", None, None, 0, 1.0, None, None) == 0
     assert _lib.call("ngp_density_fwd_scatter", None, None, 0, None, None, None) == 0
+    # fused composite + loss: two float rows padded to whole float4s; needs rays, every pointer and 16-byte alignment
+    assert lib.ngp_composite_train_fw_loss_workspace_bytes(8192) == 8 * 8192
+    assert lib.ngp_composite_train_fw_loss_workspace_bytes(777) == 8 * 780 and lib.ngp_composite_train_fw_loss_workspace_bytes(-1) == 0
+    fw_loss_null = [None] * 5 + [1e-4, 16, 0] + [None] * 9 + [1e-3, 1.0] + [None] * 5 + [0, None]
+    with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
+        _lib.call("ngp_composite_train_fw_loss", *fw_loss_null)
+    with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
+        _lib.call("ngp_composite_train_fw_loss", *(fw_loss_null[:6] + [0, 0] + fw_loss_null[8:]))       # no rays: nothing to average
+    # composite backward: the position copy comes with the active list only
+    bw = [0x1000] * 13 + [1e-4, 4, 8, 0x1000, 0x1000]
+    with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
+        _lib.call("ngp_composite_train_bw", *(bw + [None, None, 0x1000, 0x1000, None]))
+    with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
+        _lib.call("ngp_composite_train_bw", *(bw + [0x1000, 0x1000, 0x1000, None, None]))
+    # whole-field Adam: all three blocks must exist, step is 1-based
+    field = [0x1000] * 5 + [100] + [0x1000] * 5 + [64] + [0x1000] * 5 + [64, 4, 1e-2, 0.9, 0.999, 1e-15, 0.0]
+    with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
+        _lib.call("ngp_adam_step_field", *(field + [0, 1.0, None, None]))
+    with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
+        _lib.call("ngp_adam_step_field", *(field[:5] + [0] + field[6:] + [1, 1.0, None, None]))
+    with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
+        _lib.call("ngp_adam_step_field", *([None] + field[1:] + [1, 1.0, None, None]))
