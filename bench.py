@@ -175,6 +175,7 @@ def main():
         # identical initial parameters on every rank (DDP broadcasts rank 0's)
         for p in model.parameters():
             dist.broadcast(p.data, 0)
+        model.xyz_encoder._half.invalidate(); model.rgb_net._half.invalidate()     # f16 working copies follow the broadcast
     data = GpuDataset(args.res, args.images, dev, seed=0)                 # synthetic Lego-like scene, GT resident in HBM
     gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)       # per-rank independent batches (base.py:25-29)
 

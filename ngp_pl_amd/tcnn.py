@@ -80,6 +80,10 @@ class _HalfCache:
             self.key = key
         return self.t
 
+    def invalidate(self):
+        """The master params were rewritten behind autograd's back (`.data` writes do not bump the version)."""
+        self.key = None
+
     def mark_fresh(self, params):
         """The fused optimizer already rewrote the f16 copy."""
         self.key = (params.data_ptr(), params._version)
