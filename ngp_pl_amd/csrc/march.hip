@@ -14,6 +14,7 @@
 // so contraction cannot change them.  The CPU oracle makes the same choice (oracle/ngp_oracle.c).
 #pragma clang fp contract(off)
 
+#include <cstdlib>
 #include "ngp_common.h"
 
 #define NGP_SQRT3 1.73205080757f
@@ -238,7 +239,7 @@ struct Ray {
 // the same operations as in the general case.
 template <bool SIMPLE>
 __device__ __forceinline__ bool march_probe(const Ray& ray, const MarchParams& p, float t,
-                                            float& x, float& y, float& z, float& dt, float& t_next) {
+                                            float& x, float& y, float& z, float& dt, float& t_next, int* steps = nullptr) {
     x = fmaf(t, ray.dx, ray.ox); y = fmaf(t, ray.dy, ray.oy); z = fmaf(t, ray.dz, ray.oz);
     const float G = (float)p.grid_size;
     int mip = 0;
@@ -268,9 +269,11 @@ __device__ __forceinline__ bool march_probe(const Ray& ray, const MarchParams& p
         const float tz = (((nz + 0.5f + 0.5f * copysignf(1.0f, ray.dz)) * ginv * 2 - 1) * mip_bound - z) * ray.iz;
         const float t_target = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
         float tt = t;
-        if (SIMPLE) { do { tt += p.dt_lo; } while (tt < t_target); }
-        else { do { tt += calc_dt(tt, p); } while (tt < t_target); }
+        int k = 0;                                   // elements of the ray's t sequence the skip advances by (>= 1)
+        if (SIMPLE) { do { tt += p.dt_lo; ++k; } while (tt < t_target); }
+        else { do { tt += calc_dt(tt, p); ++k; } while (tt < t_target); }
         t_next = tt;
+        if (steps) *steps = k;
     }
     return occ;
 }
@@ -316,6 +319,102 @@ march_train_count_kernel(const float* __restrict__ rays_o, const float* __restri
     }
     rays_a[3 * (size_t)r] = r;
     rays_a[3 * (size_t)r + 2] = n;
+}
+
+// The same pass with ONE WAVE PER RAY, bit-identical to the serial loop above.  The loop visits a subsequence of one
+// fixed sequence per ray, T[0] = t1, T[j+1] = T[j] + calc_dt(T[j]): an occupied cell advances by one element, an empty
+// cell by k >= 1 elements (the do-while of the skip).  Per tile of 64 elements the wave
+//   1. generates the 64 elements (a chain of adds, no memory) -- lane j keeps T[j];
+//   2. probes all 64 candidates in parallel (march_probe, the serial kernel's own arithmetic): occupancy bit and, for
+//      empty cells, the skip length k, i.e. the successor index j + k;
+//   3. follows the orbit of the tile's entry index under `successor` with wave-uniform scalar code: runs of occupied
+//      lanes are taken at once from the ballot mask, each visited empty lane costs one cross-lane read.  Candidates the
+//      serial loop jumps over are never emitted, whatever their own bit says (next to a voxel face the computed skip
+//      target can reach a rounding error into the neighbour cell);
+//   4. writes the visited occupied candidates' t to the ray's scratch row (coalesced, ranked by popcount).
+// A skip that leaves the tile carries its landing value into the following tiles.  tools/march_parallel_proto.py is
+// this algorithm in numpy against the oracle.  8192 rays = 8192 waves instead of 512 serial chains of dependent loads.
+template <bool SIMPLE>
+__global__ void __launch_bounds__(256)
+march_train_count_wave_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                              const float* __restrict__ hits_t, const float* __restrict__ noise,
+                              MarchParams p, int max_samples, int n_rays,
+                              int64_t* __restrict__ rays_a, float* __restrict__ t_scratch) {
+    // the ray index is wave-uniform; saying so keeps the ray, its hit interval and the whole tile walk on the scalar unit
+    const int r = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const int lane = threadIdx.x & 63;
+    if (r >= n_rays) return;
+    const Ray ray = load_ray(rays_o, rays_d, r);
+    float t1 = hits_t[2 * r];
+    const float t2 = hits_t[2 * r + 1];
+    if (t1 >= 0) t1 = fmaf(calc_dt(t1, p), noise[r], t1);
+    float* __restrict__ row = t_scratch + (size_t)r * max_samples;
+    int n = 0;
+    float t_start = t1;
+    float pending = -1.0f;                              // landing value of a skip that left the previous tile (< 0: none)
+    bool done = !(t1 >= 0);
+    while (!done) {
+        // 1. the tile's elements
+        float tt = t_start, mine = t_start;
+#pragma unroll 8
+        for (int j = 0; j < 64; ++j) {
+            mine = (lane == j) ? tt : mine;
+            tt += SIMPLE ? p.dt_lo : calc_dt(tt, p);
+        }
+        const float t_end = tt;                         // T[64]: first element of the next tile
+        const int nvalid = __popcll(__ballot(0 <= mine && mine < t2));        // the sequence increases: valid lanes are a prefix
+        const int entry = pending >= 0 ? __popcll(__ballot(mine < pending)) : 0;
+        if (entry >= 64) {                              // the carried skip jumps over the whole tile
+            if (nvalid < 64) break;                     // ... and over the end of the ray
+            t_start = t_end;
+            continue;
+        }
+        // 2. all candidates at once
+        float x, y, z, dt, t_next = 0.f;
+        int k = 1;
+        const bool occ = march_probe<SIMPLE>(ray, p, mine, x, y, z, dt, t_next, &k);
+        const unsigned long long occ_mask = __ballot(occ);
+        const int succ = lane + k;
+        // 3. the orbit of `entry` (wave-uniform)
+        unsigned long long emit = 0ull;
+        float next_pending = -1.0f;
+        bool finished = false;
+        int v = entry;
+        while (v < 64) {
+            if (v >= nvalid) { finished = true; break; }
+            const unsigned long long un = (~occ_mask) >> v;
+            const int u = un ? v + (int)__builtin_ctzll(un) : 64;            // lanes v .. u-1 are occupied
+            const int hi = u < nvalid ? u : nvalid;
+            if (hi > v) {
+                const int len = hi - v;
+                emit |= (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << v;
+            }
+            if (nvalid < 64 && u >= nvalid) { finished = true; break; }     // the run (or the empty lane behind it) reaches the far hit
+            if (u >= 64) { v = 64; break; }
+            const int s_u = __builtin_amdgcn_readlane(succ, u);             // u is wave-uniform: the walk stays on the scalar unit
+            if (s_u >= 64) {
+                next_pending = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t_next), u));
+                v = s_u;
+                break;
+            }
+            v = s_u;
+        }
+        // 4. write out, capped at max_samples like the serial loop's N_samples < max_samples
+        const int room = max_samples - n;
+        const bool my = (emit >> lane) & 1ull;
+        const int rank = __popcll(emit & ((1ull << lane) - 1ull));
+        if (my && rank < room) row[n + rank] = mine;
+        const int cnt = __popcll(emit);
+        n += cnt < room ? cnt : room;
+        if (finished || n >= max_samples) break;
+        pending = next_pending;
+        if (pending >= 0 && !(pending < t2)) break;     // the skip lands beyond the far hit
+        t_start = t_end;
+    }
+    if (lane == 0) {
+        rays_a[3 * (size_t)r] = r;
+        rays_a[3 * (size_t)r + 2] = n;
+    }
 }
 
 // Exclusive scan of rays_a[:,2] into rays_a[:,1] in ray order; counter = {S, R}.
@@ -891,7 +990,19 @@ int ngp_raymarching_train_count(const float* rays_o, const float* rays_d, const 
         NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d); NGP_CHECK_PTR(hits_t); NGP_CHECK_PTR(density_bitfield);
         NGP_CHECK_PTR(noise); NGP_CHECK_PTR(rays_a); NGP_CHECK_PTR(t_scratch);
         const MarchParams p = make_march_params(density_bitfield, cascades, grid_size, scale, scale, exp_step_factor, max_samples);
-        if (p.simple)
+        // NGP_MARCH_WAVE=1 selects the wave-per-ray kernel (bit-identical, 101 us instead of 280 us per 8192-ray batch in the
+        // training step, profiles/r01_v20_wave_march_kernel_trace.txt); the serial-chain kernel stays the default until the
+        // placement of the march inside the step is retuned for it
+        static const bool wave_per_ray = [] { const char* e = getenv("NGP_MARCH_WAVE"); return e ? atoi(e) != 0 : false; }();
+        if (wave_per_ray) {
+            const dim3 grid(ngp_div_up((long long)n_rays * 64, 256));
+            if (p.simple)
+                hipLaunchKernelGGL(march_train_count_wave_kernel<true>, grid, dim3(256), 0, ngp_stream(stream),
+                                   rays_o, rays_d, hits_t, noise, p, max_samples, n_rays, rays_a, t_scratch);
+            else
+                hipLaunchKernelGGL(march_train_count_wave_kernel<false>, grid, dim3(256), 0, ngp_stream(stream),
+                                   rays_o, rays_d, hits_t, noise, p, max_samples, n_rays, rays_a, t_scratch);
+        } else if (p.simple)
             hipLaunchKernelGGL(march_train_count_kernel<true>, dim3(ngp_div_up(n_rays, MARCH_RAYS_PER_WAVE)), dim3(64), 0, ngp_stream(stream),
                                rays_o, rays_d, hits_t, noise, p, max_samples, n_rays, rays_a, t_scratch);
         else

@@ -56,6 +56,9 @@ class Trainer:
         # queue_id, step 0.52 -> 0.89 ms).  High-priority streams are served from a separate queue.
         self.side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("NGP_MARCH_PRIORITY", "-1"))) if (overlap_march and dev.type == "cuda") else None
         self._pending = None     # marched-but-not-consumed batch
+        # where in the step the next batch's march is enqueued: at the top (next to the hash forward) or behind the MLP
+        # backward (next to the table backward's latency-bound slice owners)
+        self.march_late = bool(int(os.environ.get("NGP_MARCH_LATE", "0")))
         self.last = {}
         self.grad_hook = None    # called between backward and optimizer (multi-GPU gradient all-reduce)
         self.mlp_grad_hook = None  # called once the MLP gradients exist, before the hash-grid backward is enqueued
@@ -140,7 +143,8 @@ class Trainer:
             # host blocks on this batch's march: the marching stream then runs the marches back to
             # back instead of idling for a host round trip (wake-up + enqueue) between them.
             next_needs_update = (self.global_step + 1) % self.update_interval == 0
-            if next_batch is not None and not next_needs_update:
+            prefetch = next_batch is not None and not next_needs_update
+            if prefetch and not self.march_late:
                 self._pending = self._march(next_batch[0], next_batch[1])
             # the step's only host wait: the march of THIS batch.  Polled, not Event.synchronize(): the blocking wait
             # sleeps on an interrupt and wakes tens of microseconds late, which left the main stream idle at every step
@@ -215,6 +219,8 @@ class Trainer:
                 call("ngp_field_bwd", ptr(feats), ptr(dirs), ptr(h), ptr(eh), ptr(rh), ptr(dL_dsigmas), ptr(dL_drgbs), tcnn.LOSS_SCALE, S,
                      ptr(active), ptr(n_active), ptr(dh), ptr(dfeats), ptr(partials), mq)
                 self._mark("mlp_bwd")
+                if prefetch and self.march_late:         # the next march starts behind the MLP backward: next to the table backward
+                    self._pending = self._march(next_batch[0], next_batch[1])
                 g16 = m._grid_grad16(dev)
                 m._native = dict(grid16=g16, density_partials=partials[:n_part * enc.n_mlp], rgb_partials=partials[n_part * enc.n_mlp:],
                                  n_partials=n_part, scale=tcnn.LOSS_SCALE)
@@ -248,6 +254,8 @@ class Trainer:
                 if self.grad_hook is not None:
                     self.grad_hook()
                 self.opt.step(grad_scale=self.grad_scale, stream_handle=mq)
+            if prefetch and self._pending is None:       # march_late and no samples in this batch
+                self._pending = self._march(next_batch[0], next_batch[1])
             self.global_step += 1
             self.last = dict(stats=stats, rm_samples=S, total=total, n_rays=n, rgb=rgb, opacity=opacity,
                              distortion=dist if S > 0 else None)

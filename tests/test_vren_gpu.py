@@ -205,3 +205,17 @@ def test_rejects_cpu_and_noncontiguous(vren):
     y = torch.zeros(3, 4, dtype=torch.int32).cuda().t()
     with pytest.raises(RuntimeError):      # CHECK_CONTIGUOUS (include/utils.h:5)
         vren.morton3D(y)
+
+
+def test_wave_per_ray_march_is_bit_identical_too():
+    """NGP_MARCH_WAVE=1 selects the wave-per-ray pass-1 kernel (march_train_count_wave_kernel): the same oracle and
+    golden comparisons must hold bit for bit.  The switch is read once per process, hence the child interpreter."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NGP_MARCH_WAVE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_vren_gpu.py::test_raymarching_train", "tests/test_golden.py",
+                        "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"], cwd=root, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "6 passed" in r.stdout, r.stdout[-2000:]
