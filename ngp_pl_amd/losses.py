@@ -26,6 +26,27 @@ def opacity_entropy(opacity, weight):
     return -weight * o * torch.log(o)
 
 
+def mean_loss_and_seeds(rgb, opacity, gt_rgb, bg=None, lambda_opacity=1e-3, grad_scale=1.0):
+    """What the native step's compositing kernel produces for the default recipe, written with torch (fp32, any
+    device): the scalar the trainer minimises, `sum_k mean(term_k)` over the rgb and opacity terms (train.py:173) with
+    the background blended in first (rendering.py:153-161, `rgb + bg * (1 - opacity)`), the sum of squared errors
+    (PSNR bookkeeping, train.py:177-180) and the analytic backward seeds dL/d(rgb) (R,3), dL/d(opacity) (R), both
+    multiplied by `grad_scale`.  Used as the plain-torch statement of `ngp_composite_train_fw_loss`'s loss half."""
+    n_rays = rgb.shape[0]
+    transparency = (1.0 - opacity).unsqueeze(1)
+    blended = rgb if bg is None else rgb + bg.view(1, 3) * transparency
+    residual = blended - gt_rgb
+    o = opacity + _EPS
+    log_o = torch.log(o)
+    sq_err = (residual * residual).sum()
+    loss = sq_err / (3 * n_rays) + (-lambda_opacity * o * log_o).sum() / n_rays
+    d_rgb = residual * (2.0 / (3 * n_rays))
+    d_opacity = -lambda_opacity * (log_o + 1.0) / n_rays
+    if bg is not None:
+        d_opacity = d_opacity - (d_rgb * bg.view(1, 3)).sum(1)
+    return loss, sq_err, d_rgb * grad_scale, d_opacity * grad_scale
+
+
 class DistortionLoss(torch.autograd.Function):
     """Mip-NeRF 360's distortion regulariser evaluated with DVGO-v2's prefix sums.
 

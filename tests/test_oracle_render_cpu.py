@@ -73,3 +73,24 @@ def test_occupancy_merge_known_answers():
     assert abs(thr - min(mean, 5.9)) < 1e-6
     occupied = [i for i in range(64) if bits[i // 8] >> (i % 8) & 1]
     assert occupied == [1, 2]                               # > 5.575: 9.5 and 7.0
+
+
+def test_loss_seeds_statement_matches_autograd_of_the_reference_shaped_loss():
+    """losses.mean_loss_and_seeds (the torch statement of the fused kernel's loss half) == autograd through
+    NeRFLoss + background blend + mean, the way train.py:159-176 forms the scalar."""
+    import torch
+    from ngp_pl_amd.losses import NeRFLoss, mean_loss_and_seeds
+    g = torch.Generator().manual_seed(3)
+    n = 257
+    rgb = torch.rand(n, 3, generator=g, dtype=torch.float64).requires_grad_(True)
+    opacity = torch.rand(n, generator=g, dtype=torch.float64).requires_grad_(True)
+    gt = torch.rand(n, 3, generator=g, dtype=torch.float64)
+    for bg in (None, torch.ones(3, dtype=torch.float64), torch.tensor([0.2, 0.5, 0.9], dtype=torch.float64)):
+        blended = rgb if bg is None else rgb + bg.view(1, 3) * (1 - opacity).unsqueeze(1)       # rendering.py:153-161
+        terms = NeRFLoss(lambda_opacity=1e-3, lambda_distortion=0)({"rgb": blended, "opacity": opacity}, {"rgb": gt})
+        loss = sum(t.mean() for t in terms.values())                                             # train.py:173
+        want = torch.autograd.grad(loss * 128.0, (rgb, opacity))
+        got = mean_loss_and_seeds(rgb.detach(), opacity.detach(), gt, bg, 1e-3, 128.0)
+        assert torch.allclose(got[0], loss.detach(), rtol=1e-12)
+        assert torch.allclose(got[1], ((blended - gt) ** 2).sum().detach(), rtol=1e-12)
+        assert torch.allclose(got[2], want[0], rtol=1e-10, atol=1e-15) and torch.allclose(got[3], want[1], rtol=1e-10, atol=1e-15)
