@@ -6,9 +6,13 @@
   * the field    : `tcnn_oracle.Field` (fp32 torch-CPU restatement of the tiny-cuda-nn modules;
                    PARITY UNPINNED, see its header).
 
-Each function follows the reference file:line it cites.  Only tests/, __graft_entry__.smoke()
-and bench.py's cpu_baseline leg may import this module; sizes are meant to stay small (pure
-Python loop over iterations, C kernels and torch-CPU inside).
+Each function follows the reference file:line it cites.  PINNED: tests/test_reference_python_cpu.py compares these
+functions with what the reference's OWN rendering.py / networks.py / custom_functions.py / losses.py produce when they are
+run on the CPU over the reference's kernels compiled for the host (tests/golden/ref_harness.py, fixture
+tests/golden/render_golden.npz): sample counts, packing, t and dt bit for bit, composited outputs to 2e-6, the occupancy
+merge and packed bits bit for bit.  (The tiny-cuda-nn modules were stood in by tcnn_oracle on both sides: that half stays
+unpinned.)  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; sizes are meant
+to stay small (pure Python loop over iterations, C kernels and torch-CPU inside).
 """
 import numpy as np
 import torch
@@ -96,7 +100,8 @@ def update_density_grid(vr, density_grid, cells, sigmas, density_threshold, deca
     """The merge half of `NGP.update_density_grid` (networks.py:256-268) for ONE cascade given the
     sampled cell indices and the densities evaluated there: tmp[cells] = sigma; grid = where(grid < 0,
     grid, max(grid * decay, tmp)); threshold = min(mean(grid > 0), density_threshold); pack bits.
-    Returns (new grid, bitfield, threshold).  Duplicate cells: the last write wins, like index_put."""
+    Returns (new grid, bitfield, threshold).  Duplicate cells: the last write wins here; torch's indexed assignment
+    leaves the winner unspecified (tests/test_reference_python_cpu.py checks those cells for membership)."""
     grid = np.asarray(density_grid, np.float32).copy()
     tmp = np.zeros_like(grid)
     tmp[np.asarray(cells, np.int64)] = np.asarray(sigmas, np.float32)

@@ -1,0 +1,104 @@
+"""CPU: the oracle's restatement of the reference's Python hot path (oracle/render_oracle.py: render() test and train
+branches, the occupancy merge; ngp_pl_amd.losses) against vectors produced by the reference's OWN rendering.py /
+networks.py / custom_functions.py / losses.py, run on the CPU by tests/golden/make_render_golden.py.  The tiny-cuda-nn
+modules were stood in by oracle/tcnn_oracle.py on both sides, so these tests pin the logic AROUND the field: AABB +
+near clamp, the marcher's jitter, the iterative test-time loop with its sample regrouping and ray dropping, background
+blend, loss terms, cell merge / threshold / bit packing."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from render_cases import CONFIGS, field_checksum, make_field, make_rays      # noqa: E402
+
+from ngp_pl_amd import synthetic as syn                                      # noqa: E402
+from oracle import render_oracle as R                                        # noqa: E402
+from oracle.vren_oracle import Oracle                                        # noqa: E402
+
+G = np.load(os.path.join(HERE, "golden", "render_golden.npz"))
+
+
+@pytest.fixture(scope="module", params=["syn", "real"])
+def case(request):
+    tag = request.param
+    c = CONFIGS[tag]
+    field = make_field(c["scale"])
+    if not np.allclose(field_checksum(field), G[tag + "_field_checksum"], rtol=1e-12):
+        pytest.skip("torch's CPU random stream differs from the one the fixture was generated with")
+    cascades = max(1 + int(np.ceil(np.log2(2 * c["scale"]))), 1)                 # networks.py:27
+    bf = syn.random_blob_bitfield(cascades, 128, c["fill"], seed=31)
+    assert int(bf.astype(np.int64).sum()) == int(G[tag + "_bitfield_sum"])
+    ro, rd = make_rays(c["n"], c["scale"], seed=7)
+    return tag, c, field, cascades, bf, ro.numpy(), rd.numpy()
+
+
+def test_test_time_loop_matches_the_reference_python(case):
+    tag, c, field, cascades, bf, ro, rd = case
+    opacity, depth, rgb, total, iters = R.render_rays_test(Oracle(True), field, ro, rd, bf, cascades, c["scale"], 128, c["esf"], 1e-4)
+    assert total == int(G[tag + "_test_total_samples"]) and iters > 3            # regrouped several times
+    np.testing.assert_allclose(opacity, G[tag + "_test_opacity"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(depth, G[tag + "_test_depth"], rtol=0, atol=1e-5)
+    # colours go through the SH encoding, which tiny-cuda-nn feeds with (d+1)/2*2-1 instead of d: a few f16 roundings differ
+    np.testing.assert_allclose(rgb, G[tag + "_test_rgb"], rtol=0, atol=3e-3)
+
+
+def test_train_branch_matches_the_reference_python(case):
+    tag, c, field, cascades, bf, ro, rd = case
+    out = R.render_rays_train(Oracle(True), field, ro, rd, bf, G[tag + "_noise"], cascades, c["scale"], 128, c["esf"], 1e-4)
+    assert out["rm_samples"] == int(G[tag + "_train_rm_samples"]) and out["vr_samples"] == int(G[tag + "_train_vr_samples"])
+    # the oracle packs in ray order, the reference in the order its (serial, on the CPU) atomics ran: the same here
+    assert np.array_equal(out["rays_a"], G[tag + "_train_rays_a"])
+    for k in ("ts", "deltas"):
+        assert np.array_equal(out[k].view(np.uint32), G["%s_train_%s" % (tag, k)].view(np.uint32)), k
+    np.testing.assert_allclose(out["ws"], G[tag + "_train_ws"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out["opacity"], G[tag + "_train_opacity"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out["depth"], G[tag + "_train_depth"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(out["rgb"], G[tag + "_train_rgb"], rtol=0, atol=3e-3)
+
+
+def test_loss_terms_match_the_reference_python(case):
+    tag, c, field, cascades, bf, ro, rd = case
+    from ngp_pl_amd.losses import NeRFLoss
+    res = {"rgb": torch.from_numpy(G[tag + "_train_rgb"]), "opacity": torch.from_numpy(G[tag + "_train_opacity"])}
+    terms = NeRFLoss(lambda_opacity=1e-3, lambda_distortion=0)(res, {"rgb": torch.from_numpy(G[tag + "_gt"])})
+    assert torch.equal(terms["rgb"], torch.from_numpy(G[tag + "_loss_rgb"]))
+    np.testing.assert_allclose(terms["opacity"].numpy(), G[tag + "_loss_opacity"], rtol=1e-6, atol=1e-9)
+    # distortion term (losses.py:6-37,58-59) through the oracle's kernel restatement
+    per_ray, _, _ = Oracle(True).distortion_loss_fw(G[tag + "_train_ws"], G[tag + "_train_deltas"], G[tag + "_train_ts"], G[tag + "_train_rays_a"])
+    np.testing.assert_allclose(1e-3 * per_ray, G[tag + "_loss_distortion"], rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("step", [0, 2], ids=["all_cells_warmup", "uniform_plus_occupied"])
+def test_occupancy_update_matches_the_reference_python(step):
+    """NGP.update_density_grid on a 32^3 grid: given the cells the reference sampled and the densities it evaluated there,
+    the merge (decayed maximum), the mean-capped threshold and the packed bits."""
+    k = "occ%d_" % step
+    before, cells, sigma, want = G[k + "before"], G[k + "cells"], G[k + "sigma"], G[k + "after"]
+    grid, bitfield, thr = R.update_density_grid(Oracle(True), before, cells, sigma, float(G["occ_threshold"]), 0.95)
+    # a cell drawn twice (uniform + occupied sampling overlap) receives ONE of its densities: which one is unspecified for
+    # torch's indexed assignment (and non-deterministic on CUDA), so those cells are checked for membership instead
+    count = np.bincount(cells, minlength=len(before))
+    once = count <= 1
+    assert np.array_equal(grid[once].view(np.uint32), want[once].view(np.uint32))
+    if step == 0:
+        assert once.all() and np.array_equal(bitfield, G[k + "bitfield"])
+    else:
+        assert (~once).sum() > 100
+        decayed = (before * np.float32(0.95)).astype(np.float32)
+        order = np.argsort(cells, kind="stable")
+        sorted_cells, sorted_sigma = cells[order], sigma[order]
+        for cell in np.nonzero(~once)[0][:500]:
+            lo, hi = np.searchsorted(sorted_cells, cell), np.searchsorted(sorted_cells, cell, side="right")
+            options = np.maximum(decayed[cell], sorted_sigma[lo:hi])
+            assert want[cell] in options and grid[cell] in options
+        # with the reference's own winners substituted the threshold and the packed bits agree exactly
+        pos = want[want > 0]
+        ref_thr = min(float(pos.mean()), float(G["occ_threshold"]))
+        packed = np.zeros(len(want) // 8, np.uint8)
+        Oracle(True).packbits(want, ref_thr, packed)
+        assert np.array_equal(packed, G[k + "bitfield"])
+    assert 0 < thr <= float(G["occ_threshold"])
