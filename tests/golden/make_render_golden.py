@@ -95,6 +95,35 @@ def main():
             assert float((seen[0][0] - centre).abs().max()) <= hgs * (1 + 1e-5)
         print("occupancy step %d warmup=%s: %d cells, %d occupied bits" % (step, warmup, len(idx), int(np.unpackbits(model.density_bitfield.numpy()).sum())))
     out["occ_threshold"] = np.float64(thr)
+
+    # NGP.mark_invisible_cells (networks.py:197-238) for a three-cascade scene, again on a 32^3 grid
+    vis = networks.NGP(scale=2.0)
+    vis.grid_size = G
+    vis.register_buffer("density_grid", torch.zeros(vis.cascades, G ** 3))
+    vis.register_buffer("grid_coords", kornia.utils.grid.create_meshgrid3d(G, G, G, False, dtype=torch.int32).reshape(-1, 3))
+    K = syn.intrinsics(64)
+    poses = syn.hemisphere_poses(6, radius=2.5, seed=4)
+    vis.mark_invisible_cells(K, poses, (64, 64))
+    out["vis_K"] = K.numpy(); out["vis_poses"] = poses.numpy()
+    out["vis_density_grid"] = vis.density_grid.numpy().astype(np.int8)              # 0 / -1
+    out["vis_count_grid"] = np.round(vis.count_grid.numpy() * 6).astype(np.uint8)  # cameras that see the cell
+    print("mark_invisible_cells: %d of %d cells invisible" % (int((vis.density_grid < 0).sum()), vis.density_grid.numel()))
+
+    # RayMarcher.backward (custom_functions.py:98-112): gradients of the packed sample positions/directions -> rays
+    from models.custom_functions import RayMarcher
+    c = CONFIGS["syn"]
+    model = networks.NGP(scale=c["scale"])
+    bf = syn.random_blob_bitfield(model.cascades, 128, c["fill"], seed=31)
+    ro, rd = make_rays(c["n"], c["scale"], seed=7)
+    ro.requires_grad_(True); rd.requires_grad_(True)
+    _, hits_t, _ = sys.modules["vren"].ray_aabb_intersect(ro.detach(), rd.detach(), model.center, model.half_size, 1)
+    torch.manual_seed(3)
+    rays_a, xyzs, dirs, deltas, ts, total = RayMarcher.apply(ro, rd, hits_t[:, 0].contiguous(), torch.from_numpy(bf), model.cascades, c["scale"],
+                                                             0.0, 128, 1024)
+    gx = torch.randn(xyzs.shape, generator=torch.Generator().manual_seed(12)); gd = torch.randn(dirs.shape, generator=torch.Generator().manual_seed(13))
+    torch.autograd.backward([xyzs, dirs], [gx, gd])
+    out["rmb_rays_a"] = rays_a.detach().numpy(); out["rmb_ts"] = ts.detach().numpy(); out["rmb_gx"] = gx.numpy(); out["rmb_gd"] = gd.numpy()
+    out["rmb_d_rays_o"] = ro.grad.numpy(); out["rmb_d_rays_d"] = rd.grad.numpy()
     path = os.path.join(HERE, "render_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KB")

@@ -102,3 +102,32 @@ def test_occupancy_update_matches_the_reference_python(step):
         Oracle(True).packbits(want, ref_thr, packed)
         assert np.array_equal(packed, G[k + "bitfield"])
     assert 0 < thr <= float(G["occ_threshold"])
+
+
+def test_mark_invisible_cells_matches_the_reference_python(monkeypatch):
+    """ngp_pl_amd.networks.NGP.mark_invisible_cells (host logic, torch) against the reference's on a 32^3, three-cascade grid.
+    Only the Morton kernel is swapped for the oracle's (the native one needs a GPU); everything else is the product code."""
+    from ngp_pl_amd import networks
+    o = Oracle(True)
+    monkeypatch.setattr(networks.vren, "morton3D", lambda coords: torch.from_numpy(o.morton3D(coords.numpy().astype(np.int32))))
+    m = networks.NGP(scale=2.0)
+    m.grid_size = 32
+    m.register_training_buffers()
+    m.mark_invisible_cells(torch.from_numpy(G["vis_K"]), torch.from_numpy(G["vis_poses"]), (64, 64))
+    assert np.array_equal(m.density_grid.numpy().astype(np.int8), G["vis_density_grid"])
+    assert np.array_equal(np.round(m.count_grid.numpy() * 6).astype(np.uint8), G["vis_count_grid"])
+    assert 0 < int((G["vis_density_grid"] < 0).sum()) < G["vis_density_grid"].size
+
+
+def test_raymarcher_backward_matches_the_reference_python():
+    """custom_functions.segment_sum (what RayMarcher.backward is made of) against the gradients the reference's RayMarcher
+    returned for the same upstream gradients: dL/do = sum_seg dL/dx, dL/dd = sum_seg (t dL/dx + dL/ddir)."""
+    from ngp_pl_amd.custom_functions import segment_sum
+    rays_a, ts = torch.from_numpy(G["rmb_rays_a"]), torch.from_numpy(G["rmb_ts"])
+    gx, gd = torch.from_numpy(G["rmb_gx"]), torch.from_numpy(G["rmb_gd"])
+    assert torch.equal(rays_a[:, 0], torch.arange(len(rays_a)))                   # serial CPU "atomics": rows are in ray order
+    d_o = segment_sum(gx, rays_a)
+    d_d = segment_sum(gd + ts[:, None] * gx, rays_a)
+    np.testing.assert_allclose(d_o.numpy(), G["rmb_d_rays_o"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(d_d.numpy(), G["rmb_d_rays_d"], rtol=1e-5, atol=1e-5)
+    assert float(np.abs(G["rmb_d_rays_o"]).max()) > 1
