@@ -56,9 +56,12 @@ class Trainer:
         # queue_id, step 0.52 -> 0.89 ms).  High-priority streams are served from a separate queue.
         self.side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("NGP_MARCH_PRIORITY", "-1"))) if (overlap_march and dev.type == "cuda") else None
         self._pending = None     # marched-but-not-consumed batch
-        # where in the step the next batch's march is enqueued: at the top (next to the hash forward) or behind the MLP
-        # backward (next to the table backward's latency-bound slice owners)
-        self.march_late = bool(int(os.environ.get("NGP_MARCH_LATE", "0")))
+        # where in the step the next batch's march is enqueued (it starts behind whatever the main stream has queued by
+        # then): "top" = next to the hash forward (default), "hashgrid_fwd" / "mlp_fwd" / "mlp_bwd" / "hashgrid_bwd" = behind
+        # that stage.  NGP_MARCH_LATE=1 is "mlp_bwd" (next to the table backward's latency-bound slice owners).
+        self.march_at = os.environ.get("NGP_MARCH_AT", "mlp_bwd" if int(os.environ.get("NGP_MARCH_LATE", "0")) else "top")
+        if self.march_at not in ("top", "hashgrid_fwd", "mlp_fwd", "mlp_bwd", "hashgrid_bwd"):
+            raise ValueError("NGP_MARCH_AT: unknown stage %r" % self.march_at)
         self.last = {}
         self.grad_hook = None    # called between backward and optimizer (multi-GPU gradient all-reduce)
         self.mlp_grad_hook = None  # called once the MLP gradients exist, before the hash-grid backward is enqueued
@@ -144,8 +147,11 @@ class Trainer:
             # back instead of idling for a host round trip (wake-up + enqueue) between them.
             next_needs_update = (self.global_step + 1) % self.update_interval == 0
             prefetch = next_batch is not None and not next_needs_update
-            if prefetch and not self.march_late:
-                self._pending = self._march(next_batch[0], next_batch[1])
+
+            def march_next_if_at(stage):
+                if prefetch and self.march_at == stage and self._pending is None:
+                    self._pending = self._march(next_batch[0], next_batch[1])
+            march_next_if_at("top")
             # the step's only host wait: the march of THIS batch.  Polled, not Event.synchronize(): the blocking wait
             # sleeps on an interrupt and wakes tens of microseconds late, which left the main stream idle at every step
             done = rec["done"]
@@ -181,8 +187,10 @@ class Trainer:
             if S > 0:
                 call("ngp_hashgrid_fwd", ptr(xyzs), ptr(m.xyz_min), ptr(m.xyz_max), ptr(eh[enc.n_mlp:]), C.byref(enc.meta), S, ptr(feats), mq)
                 self._mark("hashgrid_fwd")
+                march_next_if_at("hashgrid_fwd")
                 call("ngp_field_fwd", ptr(feats), ptr(dirs), ptr(eh), ptr(rh), S, ptr(sigmas), ptr(rgbs), ptr(h), mq)
                 self._mark("mlp_fwd")
+                march_next_if_at("mlp_fwd")
             # composite + per-ray loss seeds, then one small kernel: offsets of the live samples and the loss sums
             if self._fw_ws is None or self._fw_ws.numel() < 8 * (n + 3):
                 self._fw_ws = torch.empty(8 * (n + 3), dtype=torch.uint8, device=dev)
@@ -219,8 +227,7 @@ class Trainer:
                 call("ngp_field_bwd", ptr(feats), ptr(dirs), ptr(h), ptr(eh), ptr(rh), ptr(dL_dsigmas), ptr(dL_drgbs), tcnn.LOSS_SCALE, S,
                      ptr(active), ptr(n_active), ptr(dh), ptr(dfeats), ptr(partials), mq)
                 self._mark("mlp_bwd")
-                if prefetch and self.march_late:         # the next march starts behind the MLP backward: next to the table backward
-                    self._pending = self._march(next_batch[0], next_batch[1])
+                march_next_if_at("mlp_bwd")
                 g16 = m._grid_grad16(dev)
                 m._native = dict(grid16=g16, density_partials=partials[:n_part * enc.n_mlp], rgb_partials=partials[n_part * enc.n_mlp:],
                                  n_partials=n_part, scale=tcnn.LOSS_SCALE)
@@ -235,6 +242,7 @@ class Trainer:
                     call("ngp_hashgrid_bwd_sliced", ptr(xyzs), ptr(m.xyz_min), ptr(m.xyz_max), ptr(dfeats), C.byref(enc.meta), S,
                          ptr(active), ptr(n_active), ptr(g16), mq)
                 self._mark("hashgrid_bwd")
+                march_next_if_at("hashgrid_bwd")
                 epoch = self.global_step // self.steps_per_epoch
                 self.opt.param_groups[0]["lr"] = cosine_lr(self.base_lr, epoch, self.num_epochs)
                 if self.grad_hook is not None:
@@ -254,7 +262,7 @@ class Trainer:
                 if self.grad_hook is not None:
                     self.grad_hook()
                 self.opt.step(grad_scale=self.grad_scale, stream_handle=mq)
-            if prefetch and self._pending is None:       # march_late and no samples in this batch
+            if prefetch and self._pending is None:       # a later stage was asked for and this batch had no samples
                 self._pending = self._march(next_batch[0], next_batch[1])
             self.global_step += 1
             self.last = dict(stats=stats, rm_samples=S, total=total, n_rays=n, rgb=rgb, opacity=opacity,
