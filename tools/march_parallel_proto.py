@@ -26,7 +26,7 @@ TILE = 64
 
 def calc_dt(t, esf, max_samples, G, scale):
     lo = SQRT3 / F(max_samples); hi = SQRT3 * F(2) * F(scale) / F(G)
-    return np.minimum(np.maximum(t * F(esf), lo), hi).astype(F)
+    return np.maximum(lo, np.minimum(t * F(esf), hi)).astype(F)       # helper_math.h clamp(f, a, b) = max(a, min(f, b)): lo wins if lo > hi
 
 
 def expand_bits(v):
