@@ -1,24 +1,42 @@
 """bench.py -- train rays/s (+ render FPS) of the MI355X-native Instant-NGP hot path.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line from rank 0.
-  * step      = one full optimisation step on a batch of 8192 rays per GPU: occupancy-grid
-                update every 16 steps, AABB, ray march, hash-grid encode, fused MLPs, composite,
-                loss, full backward, fused Adam (BASELINE.json configs[1]: Lego-like 800x800,
-                8192 rays/batch, scale 0.5).  Inputs (rays, ground-truth colours) are resident in
-                HBM before the timed region.
-  * value     = rays/s over all ranks (weak scaling: 8192 rays per GPU), K timed steps bracketed
-                by barrier + synchronize, max over ranks.
-  * roofline  = the dominant kernel of the step (hash-grid encode forward+backward by time):
-                algorithmic bytes / measured kernel time vs HBM peak (8 TB/s).
-  * cpu_baseline = the CPU oracle (reference kernels compiled for the host when available, our
-                restatement otherwise) timed on rank 0 on a bounded sample of the same workload.
-Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL), per-rank independent ray
-batches, gradient all-reduce of the native gradient buffers (f16 grid gradient 22.9 MB + MLP
-gradients) every step -- the reference's only collective (DDP, train.py:270-272).
+  * step      = one full optimisation step on a batch of 8192 rays per GPU: occupancy-grid update every 16
+                steps, AABB, ray march, hash-grid encode, fused MLPs, composite, loss, full backward, fused
+                Adam (BASELINE.json configs[1]: Lego-like 800x800, 8192 rays/batch, scale 0.5).  Inputs
+                (poses, directions, ground-truth images) are resident in HBM before any timed region.
+  * phases    = (1) UNTIMED, DISCLOSED setup: SETUP_STEPS (320) optimisation steps from the random
+                    initialisation, so that whatever K and W are, the timed region sits where SURVEY.md
+                    section 8(d) defines the metric (>= 300 steps in, past the 256-step occupancy warm-up).
+                    The window [W, W+K) of those steps is timed on the side and reported as `cold_start`
+                    (what a literal "W warm-up steps from scratch, then K steps" measures: 15-25x more samples
+                    per ray than the steady state, plus first-touch costs);
+                (2) W untimed warm-up steps;
+                (3) K timed steps bracketed by barrier + synchronize on both sides, max over ranks; the window
+                    is repeated until >= MIN_TIMED_STEPS (200) steps are covered and `value` is rays over the
+                    summed window time (`timed_windows`, `timed_steps_total` say how many).
+  * value     = rays/s over all ranks (weak scaling: 8192 rays per GPU) of `Trainer.step`, the native step
+                (direct C-ABI calls, no autograd graph).  `api_path` is the same step driven through the
+                reference-shaped surface (render() + NeRFLoss + autograd + FusedAdam).
+  * roofline  = the dominant stage of the step by time: algorithmic bytes of the work it ACTUALLY did (backward
+                stages run on the active samples only, read back per step) / its HIP-event time on the stream it
+                runs on, measured over ROOFLINE_STEPS steps right behind the timed windows; `traffic` = HBM bytes
+                from the PMC profile recorded at the same operating point (profiles/*_pmc_traffic.json, made by
+                tools/pmc_traffic.sh), or null when the operating points differ by more than 5 %.
+  * cpu_baseline = the CPU oracle (reference kernels compiled for the host when available, our restatement
+                otherwise) timed on rank 0 on a bounded sample of the same workload.
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL).  `--gpus N` with no RANK in the
+environment re-executes itself under torch.distributed.run with N ranks (127.0.0.1 rendezvous); under
+torchrun it takes RANK/LOCAL_RANK/WORLD_SIZE from the environment.  Per-rank independent ray batches, one
+gradient exchange per step (ngp_pl_amd/ddp.py) -- the reference's only collective (DDP, train.py:270-272).
+Without a GPU (`--dry-run`, implied when none is visible) only the launcher and the process group are
+exercised (gloo): the product path has no CPU fallback.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,74 +45,246 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+SETUP_STEPS = 320          # untimed, disclosed (>= 300 steps, past the 256-step occupancy warm-up)
+MIN_TIMED_STEPS = 200
+ROOFLINE_STEPS = 20
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
+WORKLOADS = {
+    # name: (scene, scale, rays, lr, erode, description)
+    "lego": ("lego", 0.5, 8192, 1e-2, False, "configs[1]: Synthetic-NeRF Lego-like, 1xMI355X per rank, 8192 rays/batch, 800x800, scale 0.5"),
+    "lego16k": ("lego", 0.5, 16384, 2e-2, False, "configs[2] recipe (benchmark_synthetic_nerf.sh:25-28): 16384 rays/batch, lr 2e-2, on the Lego-like scene"),
+    "unbounded": ("unbounded", 16.0, 8192, 1e-2, True, "configs[3] recipe (benchmark_mipnerf360.sh:21-24): scale 16 -> 6 cascades, exp_step_factor 1/256, "
+                  "erode, black background, on a procedural unbounded scene"),
+}
+
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=200)
-    p.add_argument("--warmup", type=int, default=320)      # past the 256-step occupancy warm-up (train.py:58)
-    p.add_argument("--rays", type=int, default=8192)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--workload", choices=sorted(WORKLOADS), default="lego")
+    p.add_argument("--rays", type=int, default=0, help="rays per batch and GPU (default: the workload's)")
     p.add_argument("--res", type=int, default=800)
     p.add_argument("--images", type=int, default=100)
+    p.add_argument("--setup-steps", type=int, default=SETUP_STEPS)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-render", action="store_true")
-    p.add_argument("--timed-only", action="store_true", help="stop after the timed loop (for rocprofv3 runs: the trace then ends with the K timed steps)")
+    p.add_argument("--no-secondary", action="store_true", help="skip the short unbounded / 16k-ray secondary lines")
+    p.add_argument("--timed-only", action="store_true", help="stop after the timed windows (for rocprofv3 runs: the trace then ends with the timed steps)")
+    p.add_argument("--dry-run", action="store_true", help="launcher + process group only (gloo, no GPU work)")
     return p.parse_args()
 
 
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
-MFMA_F16_PEAK_TFLOPS = 2500.0
+# ---------------------------------------------------------------------------------------------------------
+# launcher
+# ---------------------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
-def kernel_roofline(trainer, draw, n_steps=10):
-    """Stage times of real training steps from HIP events on the stream the kernels run on
-    (torch's current stream), then the roofline of the dominant stage.  Algorithmic bytes per
-    unit are SURVEY.md section 8(d)'s (restated in DESIGN.md)."""
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: start N ranks of this same command
+    (one per GPU) the way the driver would, and hand their exit status back."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank, world):
+    """No GPU: prove the launch path (N ranks, rendezvous on 127.0.0.1, a collective) and nothing else."""
+    import torch.distributed as dist
+    if world > 1 or "RANK" in os.environ:
+        dist.init_process_group("gloo")
+        t = torch.tensor([rank + 1.0])
+        dist.all_reduce(t)
+        assert float(t) == world * (world + 1) / 2
+        dist.barrier()
+        world_seen = dist.get_world_size()
+        dist.destroy_process_group()
+    else:
+        world_seen = 1
+    if rank == 0:
+        print(json.dumps({"metric": "train rays/sec", "value": None, "unit": "rays/s", "n_gpus": world_seen, "steps": args.steps,
+                          "warmup": args.warmup, "dry_run": True, "note": "no GPU visible: launcher and process group only (gloo); "
+                          "the product path has no CPU fallback"}))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# measurement pieces
+# ---------------------------------------------------------------------------------------------------------
+class Loop:
+    """The training loop of one workload: model, trainer, HBM-resident data, batch sampler on the marching stream."""
+
+    def __init__(self, workload, args, dev, rank, world, dist):
+        from ngp_pl_amd.bench_support import GpuDataset
+        from ngp_pl_amd.networks import NGP
+        from ngp_pl_amd.trainer import Trainer
+        scene, scale, rays, lr, erode, self.description = WORKLOADS[workload]
+        self.rays = args.rays or rays
+        self.dev, self.rank, self.world, self.dist = dev, rank, world, dist
+        torch.manual_seed(1337)
+        self.model = NGP(scale=scale).to(dev)
+        self.model.register_training_buffers()
+        self.data = GpuDataset(args.res, args.images, dev, seed=0, scene=scene)     # ground truth resident in HBM
+        if erode:      # train.py:73-76,160-163: the colmap recipe marks the cells no camera sees and erodes by visibility
+            self.model.mark_invisible_cells(self.data.K.to(dev), self.data.poses, (self.data.W, self.data.H))
+        self.trainer = Trainer(self.model, lr=lr, num_epochs=30 if workload != "lego16k" else 20, erode=erode)
+        self.exchange = None
+        if dist is not None:       # also with a 1-rank process group (torchrun --nproc-per-node 1): exercises the collective path
+            from ngp_pl_amd.ddp import GradientExchange
+            self.exchange = GradientExchange(self.model, dist, world).install(self.trainer)
+            self.exchange.broadcast_parameters()
+        self.draws = 0
+        self.main_stream = torch.cuda.current_stream()
+        self.cur = self.draw()
+
+    def draw(self, on_side=True):
+        # the batch sampler runs on the trainer's marching stream, in front of the march that consumes its rays (the
+        # main stream picks the batch up behind that march's event); record_stream: the main stream reads them too
+        self.draws += 1
+        tr = self.trainer
+        if tr.side is None or not on_side:
+            return self.data.sample_native(self.rays, self.draws, seed=1234 + self.rank)     # per-rank independent batches (base.py:25-29)
+        with torch.cuda.stream(tr.side):
+            batch = self.data.sample_native(self.rays, self.draws, seed=1234 + self.rank)
+        for t in batch:
+            t.record_stream(self.main_stream)
+        return batch
+
+    def steps(self, n):
+        for _ in range(n):
+            nxt = self.draw()
+            self.trainer.step(self.cur[0], self.cur[1], self.cur[2], next_batch=(nxt[0], nxt[1]))
+            self.cur = nxt
+
+    def fence(self):
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(self, n):
+        """n steps bracketed by barrier + synchronize; seconds, max over ranks.  Also the HIP-event time of the same
+        window on the main stream (the stream every kernel of the step but the march is launched on)."""
+        self.fence()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        self.steps(n)
+        e1.record()
+        self.fence()
+        dt = time.perf_counter() - t0
+        if self.dist is not None:
+            t = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, e0.elapsed_time(e1) * 1e-3
+
+    def run(self, setup_steps, warmup, steps, min_timed=MIN_TIMED_STEPS):
+        """setup (with the cold-start window inside) -> warm-up -> timed windows.  Returns the result record."""
+        tr = self.trainer
+        cold = None
+        w0 = min(warmup, max(setup_steps - steps, 0))
+        if setup_steps >= w0 + steps:
+            self.steps(w0)
+            dt, _ = self.timed(steps)
+            met = tr.metrics()
+            cold = {"rays_per_s": self.rays * self.world * steps / dt, "ms_per_step": dt / steps * 1e3,
+                    "window": "steps [%d, %d) from the random initialisation" % (w0, w0 + steps),
+                    "samples_per_ray_marched": met["rm_s"],
+                    "what": "what `--warmup W --steps K` measures without the setup phase: inside the 256-step occupancy warm-up"}
+            self.steps(setup_steps - w0 - steps)
+        else:
+            self.steps(setup_steps)
+        self.steps(warmup)
+        n_win = max(1, -(-min_timed // steps))
+        wins, ev = [], []
+        for _ in range(n_win):
+            dt, dte = self.timed(steps)
+            wins.append(dt); ev.append(dte)
+        total = sum(wins)
+        met = tr.metrics()
+        return {"ms_per_step": total / (n_win * steps) * 1e3, "rays_per_s": self.rays * self.world * n_win * steps / total,
+                "timed_windows": n_win, "timed_steps_total": n_win * steps, "window_ms_per_step_min_max": [min(wins) / steps * 1e3, max(wins) / steps * 1e3],
+                "ms_per_step_hip_events": sum(ev) / (n_win * steps) * 1e3, "cold_start": cold, "metrics": met,
+                "global_step_at_end": tr.global_step}
+
+
+def kernel_roofline(loop, n_steps=ROOFLINE_STEPS):
+    """Stage times of real training steps from HIP events on the stream the kernels run on (torch's current
+    stream), then the roofline of the dominant stage.  Algorithmic bytes per unit are SURVEY.md section 8(d)'s
+    (restated in DESIGN.md); the backward stages are priced by the samples they process (the active list)."""
+    trainer = loop.trainer
     n_params = trainer.model.xyz_encoder.params.numel() + trainer.model.rgb_net.params.numel()
-    acc, S_acc, R = {}, 0, 0
-    cur = draw()
+    acc, S_acc, A_acc, R = {}, 0, 0, loop.rays
     trainer.events = []
     for _ in range(n_steps):
-        nxt = draw()
-        trainer.step(cur[0], cur[1], cur[2], next_batch=(nxt[0], nxt[1]))
+        loop.steps(1)
         for name, ms in trainer.stage_times_ms():
             acc[name] = acc.get(name, 0.0) + ms
-        S_acc += trainer.last["rm_samples"]; R = trainer.last["n_rays"]
-        cur = nxt
+        S_acc += trainer.last["rm_samples"]
+        A_acc += int(trainer.last["n_active"].item())
     trainer.events = None
-    S = S_acc / n_steps
+    S, A = S_acc / n_steps, A_acc / n_steps
     algo = {   # bytes per launch
         "march_count(side stream)": 60.0 * R + 4.0 * S, "march_write": 32.0 * S, "hashgrid_fwd": 588.0 * S, "mlp_fwd": 210.0 * S,
-        "composite_fw+loss": 28.0 * S + 52.0 * R, "composite_bw": 52.0 * S + 64.0 * R, "mlp_bwd": 300.0 * S,
-        "hashgrid_bwd": 1100.0 * S, "adam": 30.0 * n_params, "grid_update": 0.0,
+        "composite_fw+loss": 28.0 * S + 52.0 * R, "composite_bw": 52.0 * S + 64.0 * R + 24.0 * A, "mlp_bwd": 300.0 * A,
+        "hashgrid_bwd": 1100.0 * A, "adam": 30.0 * n_params, "grid_update": 0.0,
     }
     stages = []
     for name, ms in acc.items():
         ms /= n_steps
         stages.append({"stage": name, "ms": round(ms, 4), "GB/s": round(algo.get(name, 0.0) / (ms * 1e-3) / 1e9, 1) if ms > 0 else None})
     stages.sort(key=lambda d: -d["ms"])
-    top = next(d for d in stages if d["stage"] not in ("grid_update", "march_count(side stream)"))   # the march overlaps the main stream
+    main = [d for d in stages if d["stage"] not in ("grid_update", "march_count(side stream)")]      # the march overlaps the main stream
+    top = main[0]
     achieved = top["GB/s"]
-    # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this
-    # same command; summary and calibration in profiles/r01_pmc_hbm_traffic.txt).  Not measurable from inside this process.
-    # hashgrid_bwd = binning pass + slice owners of the binned variant (merge and gather kernels are below the summary's cut)
-    pmc = {"hashgrid_bwd": (116758 + 20018 + 39305 + 41436) * 1024, "hashgrid_fwd": (43901 + 30061) * 1024, "adam": (2 * 78269.2 + 178828.8) * 1024}
+    traffic, source = pmc_traffic(top["stage"], S, A)
     return {"bound": "hbm", "kernel": top["stage"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get(top["stage"]), "traffic_source": "profiles/r01_pmc_hbm_traffic.txt",
-            "avg_ms": top["ms"], "samples_per_launch": S, "stages": stages}
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
+            "avg_ms": top["ms"], "samples_marched_per_launch": S, "samples_active_per_launch": A,
+            "units_priced": "active samples (the backward runs on the samples up to each ray's early stop)" if top["stage"] in ("hashgrid_bwd", "mlp_bwd") else "marched samples",
+            "main_stream_stage_sum_ms": round(sum(d["ms"] for d in main), 4), "stages": stages}
 
 
-def api_path_rate(trainer, draw, n_steps=30):
+def pmc_traffic(stage, S, A):
+    """HBM bytes per launch of `stage` from the newest PMC profile under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate passes over `bench.py --timed-only`, summarised by tools/pmc_traffic.py).  Not measurable from inside this process;
+    only reported when that profile's operating point (marched and active samples per step) is within 5 % of this run's."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, "no profiles/r*_pmc_traffic.json"
+    with open(files[-1]) as f:
+        prof = json.load(f)
+    rel = os.path.relpath(files[-1], ROOT)
+    rec = prof.get("stages", {}).get(stage)
+    if rec is None:
+        return None, "%s has no entry for %s" % (rel, stage)
+    pS, pA = prof["samples_marched_per_step"], prof["samples_active_per_step"]
+    if abs(pS - S) > 0.05 * S or abs(pA - A) > 0.05 * A:
+        return None, "%s was recorded at %.0f marched / %.0f active samples per step, this run has %.0f / %.0f (> 5 %% apart)" % (rel, pS, pA, S, A)
+    return rec["hbm_bytes_per_launch"], "%s (%s)" % (rel, rec.get("how", "FETCH_SIZE x2 + WRITE_SIZE"))
+
+
+def api_path_rate(loop, n_steps=40):
     """The same step driven through the reference-shaped surface: render() -> NeRFLoss -> torch autograd -> FusedAdam
     (Trainer.step_autograd), i.e. what train.py would exercise.  Secondary number, not `value`."""
-    for _ in range(5):
-        b = draw(); trainer.step_autograd(b[0], b[1], b[2])
+    tr = loop.trainer
+    for _ in range(8):
+        b = loop.draw(on_side=False); tr.step_autograd(b[0], b[1], b[2])
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(n_steps):
-        b = draw(); trainer.step_autograd(b[0], b[1], b[2])
+        b = loop.draw(on_side=False); tr.step_autograd(b[0], b[1], b[2])
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / n_steps
-    return {"rays_per_s": b[0].shape[0] / dt, "ms_per_step": dt * 1e3, "what": "render()+NeRFLoss+autograd+FusedAdam, same kernels"}
+    return {"rays_per_s": loop.rays / dt, "ms_per_step": dt * 1e3, "what": "render()+NeRFLoss+autograd+FusedAdam, same kernels"}
 
 
 def cpu_baseline(model, data, budget_s=20.0):
@@ -122,7 +312,6 @@ def cpu_baseline(model, data, budget_s=20.0):
     n_done, S_tot, t0 = -1, 0, time.perf_counter()      # step -1 is an untimed warm-up (lazy inits)
     while n_done < 0 or (time.perf_counter() - t0 < budget_s and n_done < 100):
         ro, rd, gt = (t.cpu() for t in data.sample(R, gen))
-        t_step = time.perf_counter()
         _, hits_t, _ = vr.ray_aabb_intersect(ro.numpy(), rd.numpy(), c, hs, 1)
         ht = hits_t[:, 0].copy(); m = (ht[:, 0] >= 0) & (ht[:, 0] < 0.01); ht[m, 0] = 0.01
         noise = np.random.rand(R).astype(np.float32)
@@ -151,98 +340,77 @@ def cpu_baseline(model, data, budget_s=20.0):
                           "reference .cu compiled for CPU (oracle/_ref)" if isinstance(vr, Reference) else "oracle/ngp_oracle.c")}
 
 
+def secondary_line(name, args, dev):
+    """A short run of one of the other recipes (single GPU, rank 0): 320 setup steps, 100 timed."""
+    loop = Loop(name, args, dev, 0, 1, None)
+    r = loop.run(setup_steps=args.setup_steps, warmup=10, steps=100, min_timed=100)
+    met = r["metrics"]
+    out = {"workload": loop.description, "rays_per_s": r["rays_per_s"], "ms_per_step": r["ms_per_step"], "rays_per_batch": loop.rays,
+           "samples_per_ray_marched": met["rm_s"], "samples_per_ray_composited": met["vr_s"], "train_psnr": met["psnr"],
+           "cascades": loop.model.cascades, "timed_steps_total": r["timed_steps_total"], "setup_steps": args.setup_steps}
+    del loop
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(respawn_under_torchrun(args))
     rank = int(os.environ.get("RANK", 0)); local = int(os.environ.get("LOCAL_RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.dry_run or not torch.cuda.is_available():
+        return dry_run(args, rank, world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1 or "RANK" in os.environ:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
-    from ngp_pl_amd import synthetic as syn
-    from ngp_pl_amd.bench_support import GpuDataset, all_reduce_native, all_reduce_native_mlp, render_fps
-    from ngp_pl_amd.networks import NGP
-    from ngp_pl_amd.trainer import Trainer
+        world = dist.get_world_size()
+    from ngp_pl_amd.bench_support import render_fps
 
-    torch.manual_seed(1337)
-    model = NGP(scale=0.5).to(dev)
-    model.register_training_buffers()
-    trainer = Trainer(model, lr=1e-2, num_epochs=30)
-    if dist is not None:   # also with a 1-rank process group (torchrun --nproc-per-node 1): exercises the collective path
-        trainer.grad_hook = lambda: all_reduce_native(model, dist, world)
-        trainer.mlp_grad_hook = lambda: all_reduce_native_mlp(model, dist)      # small collective hidden under the hash-grid backward
-        # identical initial parameters on every rank (DDP broadcasts rank 0's)
-        for p in model.parameters():
-            dist.broadcast(p.data, 0)
-        model.xyz_encoder._half.invalidate(); model.rgb_net._half.invalidate()     # f16 working copies follow the broadcast
-    data = GpuDataset(args.res, args.images, dev, seed=0)                 # synthetic Lego-like scene, GT resident in HBM
-    gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)       # per-rank independent batches (base.py:25-29)
-
-    draw_count = [0]
-    main_stream = torch.cuda.current_stream()
-
-    def draw(on_side=True):
-        # the batch sampler runs on the trainer's marching stream, in front of the march that consumes its rays (the
-        # main stream picks the batch up behind that march's event); record_stream: the main stream reads them too
-        draw_count[0] += 1
-        if trainer.side is None or not on_side:
-            return data.sample_native(args.rays, draw_count[0], seed=1234 + rank)
-        with torch.cuda.stream(trainer.side):
-            batch = data.sample_native(args.rays, draw_count[0], seed=1234 + rank)
-        for t in batch:
-            t.record_stream(main_stream)
-        return batch
-
-    cur = draw()
-    for _ in range(args.warmup):
-        nxt = draw()
-        trainer.step(cur[0], cur[1], cur[2], next_batch=(nxt[0], nxt[1]))
-        cur = nxt
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        nxt = draw()
-        trainer.step(cur[0], cur[1], cur[2], next_batch=(nxt[0], nxt[1]))
-        cur = nxt
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    met = trainer.metrics()
-    rays_per_s = args.rays * world * args.steps / dt
-
+    loop = Loop(args.workload, args, dev, rank, world, dist)
+    r = loop.run(args.setup_steps, args.warmup, args.steps)
+    met = r["metrics"]
     out = {
         "metric": "train rays/sec (800x800 Lego-like, 8192 rays/batch/GPU, full step incl. optimizer)",
-        "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16/f32", "dtype_detail": "hash tables, features, MLP operands f16 with f32 MFMA/blend accumulation; march, composite, Adam f32", "data": "synthetic (procedural Lego-like scene, random-init weights)",
-        "config": {"workload": "configs[1]: Synthetic-NeRF Lego-like, 1xMI355X per rank, 8192 rays/batch, 800x800, scale 0.5",
-                   "rays_per_gpu": args.rays, "image_res": args.res, "n_images": args.images,
+        "value": r["rays_per_s"], "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16/f32", "dtype_detail": "hash tables, features, MLP operands f16 with f32 MFMA/blend accumulation; march, composite, Adam f32",
+        "data": "synthetic (procedural Lego-like scene, random-init weights)",
+        "config": {"workload": loop.description + "; timed after %d untimed setup steps + %d warm-up steps (steady state: SURVEY.md 8(d))" % (args.setup_steps, args.warmup),
+                   "rays_per_gpu": loop.rays, "image_res": args.res, "n_images": args.images, "setup_steps_untimed": args.setup_steps,
                    "samples_per_ray_marched": met["rm_s"], "samples_per_ray_composited": met["vr_s"], "train_psnr": met["psnr"],
-                   "parallelism": "dp%d (per-ray data parallel, native-gradient all-reduce)" % world},
+                   "parallelism": "dp%d (per-ray data parallel, one native-gradient exchange per step)" % world},
+        "value_is": "Trainer.step (native step: direct C-ABI calls, no autograd graph); api_path = the same step through render()+autograd",
+        "timed_windows": r["timed_windows"], "timed_steps_total": r["timed_steps_total"], "window_ms_per_step_min_max": r["window_ms_per_step_min_max"],
+        "ms_per_step_hip_events": r["ms_per_step_hip_events"], "cold_start": r["cold_start"],
     }
-    trainer.grad_hook = trainer.mlp_grad_hook = None      # what follows runs on rank 0 only: no collectives from here on
+    if dist is not None:      # what follows runs on rank 0 only: no collectives from here on
+        loop.trainer.grad_hook = loop.trainer.mlp_grad_hook = None
+        loop.trainer.loss_scale = 128.0
     if rank == 0 and args.timed_only:
         print(json.dumps(out))
     elif rank == 0:
+        out["roofline"] = kernel_roofline(loop)
         if not args.no_render:
             # device-driven frame loop; chunk_scale/probe_cap only regroup the SAME per-ray samples into fewer
             # iterations (tests/test_train_gpu.py::test_device_frame_loop_matches_host_loop)
-            out["render_fps_800x800"] = render_fps(model, data, n_frames=5, chunk_scale=4, probe_cap=64)
-            out["render_fps_800x800"]["loop"] = "ngp_render_test_frame chunk_scale=4 probe_cap=64"
-        out["roofline"] = kernel_roofline(trainer, draw)
-        out["api_path"] = api_path_rate(trainer, lambda: draw(on_side=False))
+            state = "after %d training steps of %d rays" % (loop.trainer.global_step, loop.rays)
+            fast = render_fps(loop.model, loop.data, n_frames=5, chunk_scale=4, probe_cap=64)
+            fast["loop"] = "ngp_render_test_frame chunk_scale=4 probe_cap=64 (same samples per ray, regrouped: <= 1e-5 from the reference chunking)"
+            ref = render_fps(loop.model, loop.data, n_frames=3)
+            ref["loop"] = "ngp_render_test_frame chunk_scale=1 probe_cap=0 (the reference's chunking, bit-identical to its host loop)"
+            fast["field_state"] = ref["field_state"] = state
+            out["render_fps_800x800"] = fast
+            out["render_fps_800x800_reference_chunking"] = ref
+        out["api_path"] = api_path_rate(loop)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(model, data)
+            out["cpu_baseline"] = cpu_baseline(loop.model, loop.data)
+        if not args.no_secondary and world == 1 and args.workload == "lego":
+            del loop
+            torch.cuda.empty_cache()
+            out["secondary"] = [secondary_line("unbounded", args, dev), secondary_line("lego16k", args, dev)]
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -410,6 +410,12 @@ int ngp_adam_step_field(float* grid_param, ngp_half* grid_param_h, ngp_half* gri
                         int n_partials, float lr, float beta1, float beta2, float eps,
                         float weight_decay, int step, float grad_scale, const int32_t* found_inf,
                         ngp_stream_t stream);
+/* GradScaler's non-finite check (train.py:274 precision=16 -> torch.amp.GradScaler.unscale_) on a native
+ * gradient buffer of n elements (f16, or f32 if grad_is_f32; 16-byte aligned): flag[0] (device i32) |= 1 if any
+ * element is inf or NaN; reset != 0 zeroes the flag first.  Used behind the multi-GPU all-reduce, whose f16
+ * sum can overflow where no single rank's gradient did; feed the flag to ngp_adam_step*'s found_inf. */
+int ngp_found_inf(const void* grad, int grad_is_f32, int64_t n, int32_t* flag, int reset,
+                  ngp_stream_t stream);
 /* Sum n_partials rows of (n) f32 into out (n) f32 (out = sum, not accumulated). */
 int ngp_reduce_partials(const float* partials, int n_partials, int n, float* out,
                         ngp_stream_t stream);

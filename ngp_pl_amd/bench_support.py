@@ -1,6 +1,7 @@
 """Pieces bench.py and the smoke test share: the HBM-resident synthetic dataset (the GPU analogue
-of datasets/base.py + nerf.py for a procedural scene), the frame renderer used for the FPS figure,
-the per-stage event timer and the native-gradient all-reduce."""
+of datasets/base.py + nerf.py / colmap.py for a procedural scene) and the frame renderer used for the
+FPS figure.  The multi-GPU gradient exchange lives in ngp_pl_amd/ddp.py."""
+import math
 import time
 
 import torch
@@ -10,22 +11,42 @@ from . import tcnn
 from .rendering import render
 
 
+# "unbounded" stand-in for the mip-NeRF360 recipe (benchmarking/benchmark_mipnerf360.sh:21-24: --scale 16 => 6
+# cascades, exp_step_factor 1/256, black background): the Lego-like object twice as large at the centre, a ground
+# slab and far-away primitives out to |x| ~ 13, inward-facing cameras at radius 4.
+def unbounded_scene():
+    boxes = [(tuple(2 * v for v in c), tuple(2 * v for v in h)) for c, h in syn._BOXES]
+    spheres = [(tuple(2 * v for v in c), 2 * r) for c, r in syn._SPHERES]
+    boxes.append(((0.0, 0.0, -0.65), (13.0, 13.0, 0.1)))                 # ground
+    for k in range(12):
+        a = 2 * math.pi * k / 12
+        rad = 5.0 + 3.5 * (k % 3)
+        c = (rad * math.cos(a), rad * math.sin(a), 0.4 + 0.3 * (k % 4))
+        if k % 2:
+            spheres.append((c, 0.8 + 0.2 * (k % 3)))
+        else:
+            boxes.append((c, (0.7, 0.5 + 0.1 * (k % 3), 1.0)))
+    return boxes, spheres
+
+
 @torch.no_grad()
-def surface_ground_truth(rays_o, rays_d):
-    """Opaque rendering of the analytic scene (nearest ray/primitive hit, white background):
+def surface_ground_truth(rays_o, rays_d, boxes=None, spheres=None, white_bg=True):
+    """Opaque rendering of the analytic scene (nearest ray/primitive hit, white or black background):
     cheap enough to produce 100 x 800x800 ground-truth images in seconds."""
+    boxes = syn._BOXES if boxes is None else boxes
+    spheres = syn._SPHERES if spheres is None else spheres
     n = rays_o.shape[0]
     dev = rays_o.device
     inv = 1.0 / rays_d
     best = torch.full((n,), float("inf"), device=dev)
-    for c, h in syn._BOXES:
+    for c, h in boxes:
         c = rays_o.new_tensor(c); h = rays_o.new_tensor(h)
         t0 = (c - h - rays_o) * inv; t1 = (c + h - rays_o) * inv
         tn = torch.minimum(t0, t1).max(-1).values; tf = torch.maximum(t0, t1).min(-1).values
         hit = (tf > tn) & (tf > 0)
         best = torch.where(hit & (tn.clamp(min=0) < best), tn.clamp(min=0), best)
     a = (rays_d * rays_d).sum(-1)
-    for c, r in syn._SPHERES:
+    for c, r in spheres:
         co = rays_o - rays_o.new_tensor(c)
         hb = (rays_d * co).sum(-1)
         disc = hb * hb - a * ((co * co).sum(-1) - r * r)
@@ -36,7 +57,7 @@ def surface_ground_truth(rays_o, rays_d):
     x = rays_o + torch.where(hit, best, torch.zeros_like(best))[:, None] * rays_d
     dn = rays_d / rays_d.norm(dim=-1, keepdim=True)
     col = syn.colour(x, dn)
-    return torch.where(hit[:, None], col, torch.ones_like(col))
+    return torch.where(hit[:, None], col, torch.ones_like(col) if white_bg else torch.zeros_like(col))
 
 
 class GpuDataset:
@@ -44,15 +65,23 @@ class GpuDataset:
     `sample` draws img/pix indices like BaseDataset.__getitem__ ('all_images', base.py:22-35) and
     forms the rays like NeRFSystem.forward (train.py:78-91), all on the GPU."""
 
-    def __init__(self, res, n_images, device, seed=0):
+    def __init__(self, res, n_images, device, seed=0, scene="lego"):
         self.W = self.H = res
         self.K = syn.intrinsics(res)
         self.directions = syn.get_ray_directions(res, res, self.K, device=device)
-        self.poses = syn.hemisphere_poses(n_images, seed=seed).to(device)
+        self.scene = scene
+        if scene == "lego":
+            self.poses = syn.hemisphere_poses(n_images, seed=seed).to(device)
+            boxes = spheres = None
+        elif scene == "unbounded":
+            self.poses = syn.hemisphere_poses(n_images, radius=4.0, seed=seed, min_elev_deg=5.0, max_elev_deg=40.0).to(device)
+            boxes, spheres = unbounded_scene()
+        else:
+            raise ValueError("unknown scene %r" % scene)
         self.rgb = torch.empty(n_images, res * res, 3, dtype=torch.float32, device=device)
         for i in range(n_images):
             ro, rd = syn.get_rays(self.directions, self.poses[i])
-            self.rgb[i] = surface_ground_truth(ro, rd)
+            self.rgb[i] = surface_ground_truth(ro, rd, boxes, spheres, white_bg=(scene == "lego"))
         self.device = device
 
     def sample_native(self, n, step, seed=0, want_indices=False):
@@ -95,43 +124,3 @@ def render_fps(model, data, n_frames=5, **render_kwargs):
     if "n_iterations" in out:
         res["iterations"] = out["n_iterations"]
     return res
-
-
-def all_reduce_native_mlp(model, dist):
-    """First half of DDP's gradient all-reduce on the native buffers: the MLP partial sums (10 240
-    floats) are reduced asynchronously as soon as the MLP backward has produced them, i.e. while the
-    hash-grid backward (the longest kernel of the step) is still running."""
-    nat = model._native
-    if nat is None:
-        return
-    enc, net = model.xyz_encoder, model.rgb_net
-    n_d, n_r, n_part = enc.n_mlp, net.params.numel(), nat["n_partials"]
-    dp, rp = nat["density_partials"], nat["rgb_partials"]
-    if dp.is_cuda:                               # two launches into one buffer (the torch sum/sum/cat costs ~40 us of GPU time)
-        from ._lib import call, ptr, stream
-        small = torch.empty(n_d + n_r, dtype=torch.float32, device=dp.device)
-        call("ngp_reduce_partials", ptr(dp), n_part, n_d, ptr(small), stream())
-        call("ngp_reduce_partials", ptr(rp), n_part, n_r, ptr(small[n_d:]), stream())
-    else:                                        # host tensors: the gloo test of this logic
-        small = torch.cat([dp.view(n_part, n_d).sum(0), rp.view(n_part, n_r).sum(0)])
-    nat["_mlp_small"] = small
-    nat["_mlp_work"] = dist.all_reduce(small, async_op=True)
-
-
-def all_reduce_native(model, dist, world):
-    """DDP's gradient all-reduce (mean) on the native buffers: one collective for the packed-f16
-    grid gradient (22.9 MB instead of DDP's 45.7 MB f32) and one for the MLP partial sums (started
-    earlier by `all_reduce_native_mlp` when the trainer offers the hook, otherwise here)."""
-    nat = model._native
-    if nat is None:
-        return
-    enc = model.xyz_encoder
-    if "_mlp_work" not in nat:
-        all_reduce_native_mlp(model, dist)
-    dist.all_reduce(nat["grid16"])
-    nat.pop("_mlp_work").wait()
-    small = nat.pop("_mlp_small")
-    nat["density_partials"] = small[:enc.n_mlp].contiguous()
-    nat["rgb_partials"] = small[enc.n_mlp:].contiguous()
-    nat["n_partials"] = 1
-    nat["scale"] = nat["scale"] * world      # mean over ranks folded into the unscale

@@ -320,7 +320,7 @@ __device__ __forceinline__ void sliced_scan_dense_runs(half2_t* lds, uint32_t lo
                 if (g0 == 0.f && g1 == 0.f) continue;
                 uint32_t p[3]; float f[3];
                 cell_of_loaded(in[b].x, box, scale, p, f);
-                const uint32_t key = p[0] + p[1] * res + p[2] * r2;
+                const uint32_t key = min(p[0], res - 1u) + min(p[1], res - 1u) * res + min(p[2], res - 1u) * r2;   // border clamp: corner_indices<false>
                 if (key != cur) {
                     if (cur != 0xFFFFFFFFu) flush_run(lds, lo, len, res, size, cur, a0, a1);
 #pragma unroll

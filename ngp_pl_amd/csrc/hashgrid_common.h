@@ -33,8 +33,12 @@ __device__ __forceinline__ bool level_is_hashed(uint32_t res, uint32_t size) {
 }
 
 // The 8 corner indices of a cell.  Hashed levels always have a power-of-two size (the cap
-// 2^log2_hashmap_size), so `% size` is a mask; dense indices stay below 2*size, so `% size`
-// is one conditional subtract.
+// 2^log2_hashmap_size), so `% size` is a mask; dense indices of an in-box cell stay below 2*size,
+// so `% size` is one conditional subtract.  Positions OUTSIDE the box (public NGP.density()/forward()
+// callers: mesh extraction, user grids; the marcher never emits them) have cell coordinates below 0
+// (wrapped to huge unsigned values) or above res-1: tiny-cuda-nn's full `%` returns an arbitrary
+// but in-bounds entry for them, here the cell is clamped to the border cell (in bounds as well;
+// the weights are left as computed, like tiny-cuda-nn's).
 template <bool HASHED>
 __device__ __forceinline__ void corner_indices(const uint32_t (&p)[3], uint32_t res, uint32_t size, uint32_t (&idx)[8]) {
     if (HASHED) {
@@ -45,8 +49,8 @@ __device__ __forceinline__ void corner_indices(const uint32_t (&p)[3], uint32_t 
 #pragma unroll
         for (int c = 0; c < 8; ++c) idx[c] = (hx[c & 1] ^ hy[(c >> 1) & 1] ^ hz[c >> 2]) & mask;
     } else {
-        const uint32_t r2 = res * res;
-        const uint32_t base = p[0] + p[1] * res + p[2] * r2;
+        const uint32_t r2 = res * res, top = res - 1u;
+        const uint32_t base = min(p[0], top) + min(p[1], top) * res + min(p[2], top) * r2;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             uint32_t i = base + (c & 1) + ((c >> 1) & 1) * res + (c >> 2) * r2;

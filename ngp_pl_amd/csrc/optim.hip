@@ -14,6 +14,7 @@ namespace {
 
 typedef _Float16 h1;
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct AdamHyper { float lr, beta1, beta2, eps, wd, bc1, bc2, inv_scale; const int32_t* found_inf; };
 
@@ -258,6 +259,30 @@ sample_rays_kernel(const float* __restrict__ poses, const float* __restrict__ di
     if (img_idx) { img_idx[i] = img; pix_idx[i] = pix; }
 }
 
+
+// GradScaler's inf check (torch.amp.GradScaler.unscale_ -> _amp_foreach_non_finite_check_and_unscale_) on a native
+// gradient buffer: flag[0] |= 1 if any element is inf/NaN.  16 bytes per lane and trip; f16 exponent all-ones test on the raw bits.
+__global__ void __launch_bounds__(256)
+found_inf_kernel(const u32x4* __restrict__ g, long long n16, const unsigned short* __restrict__ tail, int n_tail, int is_half,
+                 int32_t* __restrict__ flag) {
+    bool bad = false;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n16; q += stride) {
+        const u32x4 w = __builtin_nontemporal_load(g + q);
+        const uint32_t x[4] = {w[0], w[1], w[2], w[3]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (is_half) bad |= ((x[k] & 0x7c00u) == 0x7c00u) | ((x[k] & 0x7c000000u) == 0x7c000000u);
+            else bad |= (x[k] & 0x7f800000u) == 0x7f800000u;
+        }
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) {          // the < 16 trailing bytes, as 16-bit words
+        if (is_half) bad |= (tail[threadIdx.x] & 0x7c00u) == 0x7c00u;
+        else if (threadIdx.x & 1) bad |= (tail[threadIdx.x] & 0x7f80u) == 0x7f80u;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
 AdamHyper adam_hyper(float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale, const int32_t* found_inf) {
     AdamHyper hp;
     hp.lr = lr; hp.beta1 = beta1; hp.beta2 = beta2; hp.eps = eps; hp.wd = wd;
@@ -319,6 +344,23 @@ int ngp_adam_step_field(float* grid_param, ngp_half* grid_param_h, ngp_half* gri
     const AdamMlp b = {rgb_param, (h1*)rgb_param_h, rgb_partials, rgb_m, rgb_v, n_rgb, ngp_div_up(n_rgb, 32)};
     hipLaunchKernelGGL(adam_field_kernel, dim3(a.blocks + b.blocks + dense_blocks), dim3(256), 0, ngp_stream(stream), grid_param,
                        (h1*)grid_param_h, (void*)grid_grad, grid_m, grid_v, n4, (long long)n_grid, a, b, n_partials, hp);
+    return NGP_LAUNCH_RESULT();
+}
+
+
+int ngp_found_inf(const void* grad, int grad_is_f32, int64_t n, int32_t* flag, int reset, ngp_stream_t stream) {
+    if (n < 0) return NGP_EINVAL;
+    NGP_CHECK_PTR(flag);
+    hipStream_t st = ngp_stream(stream);
+    if (reset) { hipError_t e = hipMemsetAsync(flag, 0, sizeof(int32_t), st); if (e != hipSuccess) return (int)e; }
+    if (n == 0) return 0;
+    NGP_CHECK_PTR(grad);
+    if (reinterpret_cast<uintptr_t>(grad) & 15) return NGP_EINVAL;
+    const long long bytes = (long long)n * (grad_is_f32 ? 4 : 2), n16 = bytes / 16;
+    const int n_tail = (int)((bytes - n16 * 16) / 2);
+    const int blocks = (int)((n16 + 255) / 256 < 2048 ? ((n16 + 255) / 256 > 0 ? (n16 + 255) / 256 : 1) : 2048);
+    hipLaunchKernelGGL(found_inf_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const u32x4*>(grad), n16,
+                       reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(grad) + n16 * 16), n_tail, grad_is_f32 ? 0 : 1, flag);
     return NGP_LAUNCH_RESULT();
 }
 

@@ -78,7 +78,9 @@ class _FusedField(torch.autograd.Function):
 
 
 class NGP(nn.Module):
-    def __init__(self, scale, rgb_act="Sigmoid"):
+    def __init__(self, scale, rgb_act="Sigmoid", level_table="float32"):
+        """`level_table`: arithmetic of the hash grid's level table (tcnn.make_grid_meta); "exact" is the opt-in for
+        checkpoints whose `xyz_encoder.params` has the exact-arithmetic length (11 423 136 at scale 0.5)."""
         super().__init__()
         self.rgb_act = rgb_act
         # scene bounding box (networks.py:19-23)
@@ -100,7 +102,7 @@ class NGP(nn.Module):
                              "log2_hashmap_size": log2_T, "base_resolution": N_min, "per_level_scale": b,
                              "interpolation": "Linear"},
             network_config={"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None",
-                            "n_neurons": 64, "n_hidden_layers": 1})
+                            "n_neurons": 64, "n_hidden_layers": 1}, level_table=level_table)
         self.dir_encoder = tcnn.Encoding(n_input_dims=3, encoding_config={"otype": "SphericalHarmonics", "degree": 4})
         self.rgb_net = tcnn.Network(
             n_input_dims=32, n_output_dims=3,

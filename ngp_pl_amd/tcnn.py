@@ -29,15 +29,40 @@ def _unsupported(what):
     raise NotImplementedError("ngp_pl_amd.tcnn: unsupported configuration: %s" % what)
 
 
-def make_grid_meta(encoding_config):
+def make_grid_meta(encoding_config, level_table="float32"):
+    """Per-level scale / resolution / offset table of tiny-cuda-nn's GridEncodingTemplated constructor.
+
+    level_table="float32" (default): evaluated in float32 exactly as grid.h does (`exp2f(l * log2f(b)) * N_min - 1`), by
+    the library's ngp_grid_meta_init.  level_table="exact": the same formula in exact arithmetic (Python float64;
+    `b**l * N_min - 1` lands on integers where float32 lands a few 1e-6 above them).  The two differ for the reference's
+    b = exp(ln(2048 s / 16) / 15) at levels 5, 10 and 15 (resolution 65 / 257 / 1025 vs 64 / 256 / 1024; only level 5 is below the 2^19 cap), i.e. in the length of
+    `xyz_encoder.params` (11 448 112 vs 11 423 136 at scale 0.5): a checkpoint only loads into the table it was trained
+    with -- see ngp_pl_amd.utils.load_ckpt."""
     ec = encoding_config
     if ec.get("otype") not in ("Grid", "HashGrid") or ec.get("type", "Hash") != "Hash":
         _unsupported("encoding %r" % (ec,))
     if ec.get("interpolation", "Linear") != "Linear" or int(ec.get("n_features_per_level", 2)) != 2:
         _unsupported("grid needs F=2 and linear interpolation")
+    n_levels, log2_T = int(ec.get("n_levels", 16)), int(ec.get("log2_hashmap_size", 19))
+    n_min, b = int(ec.get("base_resolution", 16)), float(ec.get("per_level_scale", 2.0))
     meta = _lib.GridMeta()
-    call("ngp_grid_meta_init", C.byref(meta), int(ec.get("n_levels", 16)), 2, int(ec.get("log2_hashmap_size", 19)),
-         int(ec.get("base_resolution", 16)), float(ec.get("per_level_scale", 2.0)))
+    if level_table == "float32":
+        call("ngp_grid_meta_init", C.byref(meta), n_levels, 2, log2_T, n_min, b)
+    elif level_table == "exact":
+        if not 1 <= n_levels <= _lib.NGP_MAX_LEVELS:
+            _unsupported("n_levels %d" % n_levels)
+        meta.n_levels, meta.n_features = n_levels, 2
+        off = 0
+        for l in range(n_levels):
+            scale = round(2.0 ** (l * math.log2(b)) * n_min - 1.0, 9)      # 1e-9: absorbs the float64 noise around the integer hits
+            res = int(math.ceil(scale)) + 1
+            n = min((res ** 3 + 7) // 8 * 8, 1 << log2_T)
+            meta.offset[l], meta.resolution[l], meta.scale[l] = off, res, scale
+            off += n
+        for l in range(n_levels, _lib.NGP_MAX_LEVELS + 1):
+            meta.offset[l] = off
+    else:
+        raise ValueError("level_table must be 'float32' or 'exact', not %r" % (level_table,))
     return meta
 
 
@@ -167,12 +192,14 @@ class _EncodeAndNet(torch.autograd.Function):
 
 
 class NetworkWithInputEncoding(nn.Module):
-    def __init__(self, n_input_dims, n_output_dims, encoding_config, network_config, seed=_SEED):
+    def __init__(self, n_input_dims, n_output_dims, encoding_config, network_config, seed=_SEED, level_table="float32"):
         super().__init__()
         if n_input_dims != 3:
             _unsupported("grid encoding needs 3 input dims")
         self.n_input_dims, self.n_output_dims = n_input_dims, n_output_dims
-        self.meta = make_grid_meta(encoding_config)
+        self.level_table = level_table
+        self.encoding_config = dict(encoding_config)
+        self.meta = make_grid_meta(encoding_config, level_table)
         self.n_levels = int(self.meta.n_levels)
         n_hidden, act = _check_network(network_config, n_output_dims)
         if self.n_levels != 16 or n_hidden != 1 or act != 0:

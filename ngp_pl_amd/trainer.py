@@ -16,6 +16,7 @@ Two implementations of the same step:
 import ctypes as C
 import math
 import os
+import time
 
 import torch
 
@@ -26,10 +27,96 @@ from .optim import FusedAdam, cosine_lr
 from .rendering import MAX_SAMPLES, NEAR_DISTANCE, render
 
 
+def _align(x, a=256):
+    return (x + a - 1) // a * a
+
+
+class StepBuffers:
+    """Every buffer a step touches, allocated ONCE per batch size: the sample-proportional ones at the worst
+    case S = R * MAX_SAMPLES (276 B per sample slot: 2.3 GB for 8192 rays -- under 1 % of the 288 GB of HBM; only
+    the first S rows of each are ever touched), two sets of march records (the march of batch k+1 runs while
+    step k still reads its own), pinned count words, the table-backward workspace.  After construction a step
+    performs no hipMalloc / hipHostMalloc / hipFuncSetAttribute: the first timed step costs what the 10 000th does."""
+
+    PER_SAMPLE = (("xyzs", 12), ("dirs", 12), ("deltas", 4), ("ts", 4), ("feats", 64), ("h", 32), ("sigmas", 4), ("rgbs", 12),
+                  ("ws", 4), ("dL_dsigmas", 4), ("dL_drgbs", 12), ("active", 4), ("x_act", 12), ("dh", 32), ("dfeats", 64))
+    DISTORTION = (("ws_incl", 4), ("wts_incl", 4), ("dL_dws", 4))
+    PER_RAY = (("total", 8), ("opacity", 4), ("depth", 4), ("rgb", 12), ("dL_drgb", 12), ("dL_dopacity", 4), ("ray_offs", 4),
+               ("dist", 4), ("zeros", 4), ("dist_seed", 4))
+    MARCH = (("hits_t", 8), ("rays_a", 24), ("noise", 4), ("scratch", 4 * MAX_SAMPLES))
+    MAX_PARTIALS = 256
+
+    def __init__(self, model, n_rays, distortion, binned):
+        enc, net = model.xyz_encoder, model.rgb_net
+        dev = model.center.device
+        self.n, self.cap = n_rays, n_rays * MAX_SAMPLES
+        lib = _lib.lib()
+        self.n_mlp_params = enc.n_mlp + net.params.numel()
+        off, total = {}, 0
+
+        def add(name, nbytes):
+            nonlocal total
+            off[name] = total
+            total += _align(nbytes)
+        for name, b in self.PER_SAMPLE + (self.DISTORTION if distortion else ()):
+            add(name, b * self.cap)
+        for name, b in self.PER_RAY:
+            add(name, b * n_rays)
+        for k in (0, 1):
+            for name, b in self.MARCH:
+                add("%s%d" % (name, k), b * n_rays)
+        add("n_active", 4); add("stats", 8)
+        add("partials", self.MAX_PARTIALS * self.n_mlp_params * 4)
+        self.fw_bytes = int(lib.ngp_composite_train_fw_loss_workspace_bytes(n_rays))
+        add("fw_ws", self.fw_bytes)
+        # the binned table backward takes batches up to its chunk directory (1 M samples); larger ones (only the first
+        # steps of the occupancy warm-up) go to the one-pass sliced kernel, which needs no workspace
+        self.bin_max, self.bin_bytes = 0, 0
+        if binned:
+            s = min(self.cap, 1 << 20)
+            while s > 0 and not lib.ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(enc.meta), s):
+                s -= 1024
+            self.bin_max = max(s, 0)
+            self.bin_bytes = int(lib.ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(enc.meta), self.bin_max)) if self.bin_max else 0
+            add("bin_ws", self.bin_bytes)
+        self.arena = torch.empty(total, dtype=torch.uint8, device=dev)
+        base = self.arena.data_ptr()
+        assert base % 256 == 0
+        self.p = {k: base + v for k, v in off.items()}
+        self.off = off
+
+        def view(name, dtype, *shape):
+            n = 1
+            for d in shape:
+                n *= d
+            return self.arena[off[name]:off[name] + n * torch.empty(0, dtype=dtype).element_size()].view(dtype).view(*shape)
+        self.view = view
+        f32 = torch.float32
+        self.total = view("total", torch.int64, n_rays); self.opacity = view("opacity", f32, n_rays)
+        self.depth = view("depth", f32, n_rays); self.rgb = view("rgb", f32, n_rays, 3)
+        self.stats = view("stats", f32, 2); self.dist = view("dist", f32, n_rays)
+        self.n_active = view("n_active", torch.int32, 1)
+        view("zeros", f32, n_rays).zero_()               # dL/ddepth: the loss has no depth term
+        self.dist_seed_val = None
+        self.noise = [view("noise%d" % k, f32, n_rays) for k in (0, 1)]
+        # {S, R} of a march is written by its scan kernel straight into pinned (device-mapped) host memory
+        self.counter_host = [torch.zeros(2, dtype=torch.int32).pin_memory() for _ in (0, 1)]
+        self.counter_np = [t.numpy() for t in self.counter_host]
+        self.counter_p = [t.data_ptr() for t in self.counter_host]
+        self.next_set = 0
+
+    def sample_views(self, S):
+        """Tensor views of the last step's packed samples (debugging / tests; the step itself uses raw pointers)."""
+        f32 = torch.float32
+        return dict(xyzs=self.view("xyzs", f32, S, 3), dirs=self.view("dirs", f32, S, 3), deltas=self.view("deltas", f32, S),
+                    ts=self.view("ts", f32, S), sigmas=self.view("sigmas", f32, S), rgbs=self.view("rgbs", f32, S, 3),
+                    ws=self.view("ws", f32, S))
+
+
 class Trainer:
     def __init__(self, model, lr=1e-2, num_epochs=30, steps_per_epoch=1000, T_threshold=1e-4,
                  lambda_opacity=1e-3, grad_scale=1.0, warmup_steps=256, update_interval=16, overlap_march=True,
-                 lambda_distortion=0.0, binned_backward=None):
+                 lambda_distortion=0.0, binned_backward=None, erode=False):
         self.model = model
         if not hasattr(model, "density_grid"):
             model.register_training_buffers()
@@ -48,8 +135,12 @@ class Trainer:
         # table backward: the binned variant (exact fixed-point sums, deterministic; measured 5 % faster per step) unless
         # NGP_BINNED_BWD=0 / binned_backward=False selects the one-pass sliced kernel
         self.binned_backward = bool(int(os.environ.get("NGP_BINNED_BWD", "1"))) if binned_backward is None else binned_backward
-        self._bin_ws = None
-        self._fw_ws = None               # per-row loss terms of ngp_composite_train_fw_loss
+        self._buf = None                 # StepBuffers of the current batch size
+        self._grid_step = -1             # global_step the occupancy grid was last brought up to date for
+        self.loss_scale = tcnn.LOSS_SCALE   # factor on dL/dsigma, dL/drgb inside the f16 backward; lowered to 128 / world under DDP
+        self._march_count = "ngp_raymarching_train_count"
+        # train.py:160-163: erode = (dataset_name == 'colmap'), i.e. the unbounded real scenes; needs NGP.mark_invisible_cells
+        self.erode = erode
         # The marching stream must land on its own hardware queue or nothing overlaps: HIP multiplexes streams onto
         # a few HSA queues (GPU_MAX_HW_QUEUES, default 4) round-robin, and once RCCL has created its streams a
         # default-priority stream was observed to share the main stream's queue (rocprofv3: every kernel on one
@@ -67,7 +158,6 @@ class Trainer:
         self.mlp_grad_hook = None  # called once the MLP gradients exist, before the hash-grid backward is enqueued
         self.events = None       # list of (stage, event) when stage timing is on (bench.py roofline)
         self.march_ms = None
-        self._zeros = None
 
     # -- stage timing ----------------------------------------------------------------------------
     def _mark(self, name):
@@ -88,190 +178,223 @@ class Trainer:
     # -- pieces --------------------------------------------------------------------------------
     def _maybe_update_grid(self):
         if self.global_step % self.update_interval == 0:                  # train.py:160-163
-            self.model.update_density_grid(0.01 * MAX_SAMPLES / 3 ** 0.5, warmup=self.global_step < self.warmup_steps)
+            self.model.update_density_grid(0.01 * MAX_SAMPLES / 3 ** 0.5, warmup=self.global_step < self.warmup_steps,
+                                           erode=self.erode)
+
+    def buffers(self, n_rays):
+        """The step's preallocated buffers for batches of n_rays (built on first use, rebuilt if the batch size changes)."""
+        if self._buf is None or self._buf.n != n_rays:
+            if self._pending is not None:
+                self._pending["done"].synchronize()
+                self._pending = None
+            torch.cuda.synchronize()
+            self._buf = None                                   # release the old arena before the new one is requested
+            self._buf = StepBuffers(self.model, n_rays, self.lambda_distortion > 0, self.binned_backward)
+        return self._buf
 
     def _march(self, rays_o, rays_d):
         """AABB + near clamp + pass 1 of the march (+ ray-ordered scan).  Enqueued on the side
         stream behind everything the main stream has queued so far; the packed sample count
         lands in pinned host memory."""
         m = self.model
-        n, dev = rays_o.shape[0], rays_o.device
-        hits_t = torch.empty(n, 2, dtype=torch.float32, device=dev)
-        rays_a = torch.empty(n, 3, dtype=torch.int64, device=dev)
-        scratch = torch.empty(n * MAX_SAMPLES, dtype=torch.float32, device=dev)
-        # {S, R} is written by the scan kernel straight into pinned (device-mapped) host memory: no copy kernel and no
-        # extra launch between the march and the event the host waits on
-        counter_host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+        n = rays_o.shape[0]
+        B = self.buffers(n)
+        k = B.next_set; B.next_set ^= 1
+        P = B.p
         main = torch.cuda.current_stream()
         st = self.side if self.side is not None else main
         if st is not main:
             ready = torch.cuda.Event(); ready.record(main)
             st.wait_event(ready)
         sq = st.cuda_stream                      # raw handle once: torch.cuda.current_stream() costs ~8 us per call
+        B.counter_np[k][0] = -1
         with torch.cuda.stream(st):
             t0 = t1 = None
             if self.events is not None:
                 t0 = torch.cuda.Event(enable_timing=True); t0.record()
-            noise = torch.rand(n, dtype=torch.float32, device=dev)        # jitter of the first sample (custom_functions.py:83); drawn on the marching stream
-            call("ngp_ray_aabb_near", ptr(rays_o), ptr(rays_d), ptr(m.center), ptr(m.half_size), NEAR_DISTANCE, n, ptr(hits_t), sq)
-            call("ngp_raymarching_train_count", ptr(rays_o), ptr(rays_d), ptr(hits_t), ptr(m.density_bitfield), m.cascades,
-                 float(m.scale), self.exp_step_factor, ptr(noise), m.grid_size, MAX_SAMPLES, n, ptr(rays_a), ptr(counter_host),
-                 ptr(scratch), sq)
+            B.noise[k].uniform_()                # jitter of the first sample (custom_functions.py:83: torch.rand_like); drawn on the marching stream
+            call("ngp_ray_aabb_near", ptr(rays_o), ptr(rays_d), ptr(m.center), ptr(m.half_size), NEAR_DISTANCE, n, P["hits_t%d" % k], sq)
+            call(self._march_count, ptr(rays_o), ptr(rays_d), P["hits_t%d" % k], ptr(m.density_bitfield), m.cascades,
+                 float(m.scale), self.exp_step_factor, P["noise%d" % k], m.grid_size, MAX_SAMPLES, n, P["rays_a%d" % k], B.counter_p[k],
+                 P["scratch%d" % k], sq)
             if self.events is not None:
                 t1 = torch.cuda.Event(enable_timing=True); t1.record()
             done = torch.cuda.Event(); done.record()
-        return dict(rays_o=rays_o, rays_d=rays_d, rays_a=rays_a, counter_host=counter_host, scratch=scratch,
-                    hits_t=hits_t, noise=noise, done=done, timing=(t0, t1) if t0 is not None else None)
+        return dict(rays_o=rays_o, rays_d=rays_d, set=k, done=done, timing=(t0, t1) if t0 is not None else None)
+
+    def _drop_pending(self):
+        """A prefetched march that does not belong to the batch now being stepped: its kernels may still be running on the
+        marching stream and they write the record's buffers, so wait for them before anything reuses that set."""
+        if self._pending is not None:
+            self._pending["done"].synchronize()
+            self._buf.next_set = self._pending["set"]           # hand the set back
+            self._pending = None
 
     # -- the hot path --------------------------------------------------------------------------
     @torch.no_grad()
     def step(self, rays_o, rays_d, rgb_gt, next_batch=None):
         """One optimisation step on a batch of rays.  `next_batch` = (rays_o, rays_d) of the
-        following step, if known: its march overlaps this step's kernels."""
+        following step, if known: its march overlaps this step's kernels.  The tensors in the returned
+        record are views of the step's preallocated buffers: valid until the next step."""
         m = self.model
         dev = rays_o.device
         enc, net = m.xyz_encoder, m.rgb_net
         with torch.cuda.device(dev):
             main = torch.cuda.current_stream()
             mq = main.cuda_stream
+            n = rays_o.shape[0]
             if self._pending is not None and self._pending["rays_o"] is rays_o:
                 rec = self._pending
             else:
-                self._maybe_update_grid()
+                had_pending = self._pending is not None
+                self._drop_pending()
+                if not had_pending or self._grid_step != self.global_step:
+                    self._maybe_update_grid(); self._grid_step = self.global_step
                 rec = self._march(rays_o.contiguous(), rays_d.contiguous())
             self._pending = None
-            n = rays_o.shape[0]
+            B = self.buffers(n)
+            P = B.p
+            k = rec["set"]
             # march of the next batch: concurrent with this step unless the occupancy grid is due
             # for an update first (that needs this step's optimizer result).  Enqueued BEFORE the
             # host blocks on this batch's march: the marching stream then runs the marches back to
             # back instead of idling for a host round trip (wake-up + enqueue) between them.
             next_needs_update = (self.global_step + 1) % self.update_interval == 0
-            prefetch = next_batch is not None and not next_needs_update
+            prefetch = next_batch is not None and not next_needs_update and next_batch[0].shape[0] == n
 
             def march_next_if_at(stage):
                 if prefetch and self.march_at == stage and self._pending is None:
                     self._pending = self._march(next_batch[0], next_batch[1])
             march_next_if_at("top")
             # the step's only host wait: the march of THIS batch.  Polled, not Event.synchronize(): the blocking wait
-            # sleeps on an interrupt and wakes tens of microseconds late, which left the main stream idle at every step
+            # sleeps on an interrupt and wakes tens of microseconds late, which left the main stream idle at every step.
+            # The long part of the wait polls the count word itself (pinned host memory the scan kernel writes; -1 until
+            # then): no HIP call in that loop, and the core is offered to other threads once the wait gets long.  The event
+            # query that follows is what orders the main stream's kernels behind the march (kernel-end release of its L2)
+            cnt = B.counter_np[k]
             done = rec["done"]
+            spins = 0
+            while cnt[0] < 0 and not (spins & 1023 == 1023 and done.query()):
+                spins += 1
+                if spins > 50000:
+                    time.sleep(0)
             while not done.query():
                 pass
-            S = int(rec["counter_host"][0])
+            if cnt[0] < 0:
+                raise RuntimeError("ngp_raymarching_train_count finished without writing its sample count")
+            S = int(cnt[0])
+            if S > B.cap:
+                raise RuntimeError("march produced %d samples for %d rays (> R * MAX_SAMPLES)" % (S, n))
             # no main.wait_event(done): the host has just observed the event, so everything enqueued from here on is
             # ordered behind the march already; the barrier packet measured ~20 us of idle main stream per step
             self.march_ms = rec["timing"]
             if self.events is not None:
                 self.events = []
             self._mark("start")
-            f32 = dict(dtype=torch.float32, device=dev)
-            f16 = dict(dtype=torch.float16, device=dev)
-            xyzs = torch.empty(S, 3, **f32); dirs = torch.empty(S, 3, **f32)
-            deltas = torch.empty(S, **f32); ts = torch.empty(S, **f32)
-            call("ngp_raymarching_train_write", ptr(rec["rays_o"]), ptr(rec["rays_d"]), ptr(rec["rays_a"]), ptr(rec["scratch"]),
-                 float(m.scale), self.exp_step_factor, m.grid_size, MAX_SAMPLES, n, ptr(xyzs), ptr(dirs), ptr(deltas), ptr(ts), mq)
+            ro_p, rd_p = ptr(rec["rays_o"]), ptr(rec["rays_d"])
+            rays_a = P["rays_a%d" % k]
+            call("ngp_raymarching_train_write", ro_p, rd_p, rays_a, P["scratch%d" % k],
+                 float(m.scale), self.exp_step_factor, m.grid_size, MAX_SAMPLES, n, P["xyzs"], P["dirs"], P["deltas"], P["ts"], mq)
             self._mark("march_write")
-            rays_a = rec["rays_a"]
             eh, rh = enc._half.get(enc.params), net._half.get(net.params)
-            feats = torch.empty(16, S, 2, **f16); h = torch.empty(S, 16, **f16)
-            sigmas = torch.empty(S, **f32); rgbs = torch.empty(S, 3, **f32)
-            total = torch.empty(n, dtype=torch.int64, device=dev)
-            opacity = torch.empty(n, **f32); depth = torch.empty(n, **f32); rgb = torch.empty(n, 3, **f32); ws = torch.empty(S, **f32)
-            stats = torch.empty(2, **f32)                  # loss, sum of squared error (written by ngp_composite_train_fw_loss)
-            dL_drgb = torch.empty(n, 3, **f32); dL_dopacity = torch.empty(n, **f32)
-            if self._zeros is None or self._zeros.shape[0] != n:
-                self._zeros = torch.zeros(n, **f32)        # dL/ddepth: the loss has no depth term
-            dL_ddepth = self._zeros
-            ray_offs = torch.empty(n, dtype=torch.int32, device=dev); n_active = torch.empty(1, dtype=torch.int32, device=dev)
-            dL_dsigmas = torch.empty(S, **f32); dL_drgbs = torch.empty(S, 3, **f32)
+            eh_p, rh_p = eh.data_ptr(), rh.data_ptr()
+            table_p = eh_p + 2 * enc.n_mlp
             if S > 0:
-                call("ngp_hashgrid_fwd", ptr(xyzs), ptr(m.xyz_min), ptr(m.xyz_max), ptr(eh[enc.n_mlp:]), C.byref(enc.meta), S, ptr(feats), mq)
+                call("ngp_hashgrid_fwd", P["xyzs"], ptr(m.xyz_min), ptr(m.xyz_max), table_p, C.byref(enc.meta), S, P["feats"], mq)
                 self._mark("hashgrid_fwd")
                 march_next_if_at("hashgrid_fwd")
-                call("ngp_field_fwd", ptr(feats), ptr(dirs), ptr(eh), ptr(rh), S, ptr(sigmas), ptr(rgbs), ptr(h), mq)
+                call("ngp_field_fwd", P["feats"], P["dirs"], eh_p, rh_p, S, P["sigmas"], P["rgbs"], P["h"], mq)
                 self._mark("mlp_fwd")
                 march_next_if_at("mlp_fwd")
             # composite + per-ray loss seeds, then one small kernel: offsets of the live samples and the loss sums
-            if self._fw_ws is None or self._fw_ws.numel() < 8 * (n + 3):
-                self._fw_ws = torch.empty(8 * (n + 3), dtype=torch.uint8, device=dev)
-            call("ngp_composite_train_fw_loss", ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(ts), ptr(rays_a), self.T_threshold, n, S,
-                 ptr(total), ptr(opacity), ptr(depth), ptr(rgb), ptr(ws), ptr(ray_offs), ptr(n_active), ptr(rgb_gt), ptr(self.bg),
-                 self.lambda_opacity, self.grad_scale, ptr(stats), ptr(stats[1:]), ptr(dL_drgb), ptr(dL_dopacity),
-                 ptr(self._fw_ws), self._fw_ws.numel(), mq)
+            call("ngp_composite_train_fw_loss", P["sigmas"], P["rgbs"], P["deltas"], P["ts"], rays_a, self.T_threshold, n, S,
+                 P["total"], P["opacity"], P["depth"], P["rgb"], P["ws"], P["ray_offs"], P["n_active"], ptr(rgb_gt), ptr(self.bg),
+                 self.lambda_opacity, self.grad_scale, P["stats"], P["stats"] + 4, P["dL_drgb"], P["dL_dopacity"],
+                 P["fw_ws"], B.fw_bytes, mq)
             self._mark("composite_fw+loss")
+            use_dist = self.lambda_distortion > 0
             if S > 0:
                 # backward only over the samples up to each ray's early stop (the rest have zero gradient):
                 # composite_fw counted them per ray, the scan above placed them, composite_bw lists them
-                active = torch.empty(S, dtype=torch.int32, device=dev)
-                dL_dws = dist = None
-                if self.lambda_distortion > 0:
+                dL_dws = None
+                if use_dist:
                     # losses.py:6-37,58-59: lambda * distortion per ray, mean over rays; its gradient enters the composite as dL/dws
-                    dist = torch.empty(n, **f32); ws_incl = torch.empty(S, **f32); wts_incl = torch.empty(S, **f32)
-                    call("ngp_distortion_loss_fw", ptr(ws), ptr(deltas), ptr(ts), ptr(rays_a), n, S, ptr(dist), ptr(ws_incl), ptr(wts_incl), mq)
+                    call("ngp_distortion_loss_fw", P["ws"], P["deltas"], P["ts"], rays_a, n, S, P["dist"], P["ws_incl"], P["wts_incl"], mq)
                     seed_val = self.lambda_distortion / n * self.grad_scale
-                    if self._dist_seed is None or self._dist_seed[0] != (n, seed_val):
-                        self._dist_seed = ((n, seed_val), torch.full((n,), seed_val, **f32))
-                    dL_dws = torch.empty(S, **f32)
-                    call("ngp_distortion_loss_bw", ptr(self._dist_seed[1]), ptr(ws_incl), ptr(wts_incl), ptr(ws), ptr(deltas), ptr(ts),
-                         ptr(rays_a), n, S, ptr(dL_dws), mq)
+                    if B.dist_seed_val != seed_val:
+                        B.view("dist_seed", torch.float32, n).fill_(seed_val); B.dist_seed_val = seed_val
+                    dL_dws = P["dL_dws"]
+                    call("ngp_distortion_loss_bw", P["dist_seed"], P["ws_incl"], P["wts_incl"], P["ws"], P["deltas"], P["ts"],
+                         rays_a, n, S, dL_dws, mq)
                 # the binned table backward reads the live samples' positions as a stream: composite_bw copies them in list order
-                nbytes = _lib.lib().ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(enc.meta), S) if self.binned_backward else 0
-                x_act = torch.empty(S, 3, **f32) if nbytes else None      # 0: batch too large for the binned variant (occupancy warm-up)
-                call("ngp_composite_train_bw", ptr(dL_dopacity), ptr(dL_ddepth), ptr(dL_drgb), ptr(dL_dws), ptr(sigmas), ptr(rgbs), ptr(ws),
-                     ptr(deltas), ptr(ts), ptr(rays_a), ptr(opacity), ptr(depth), ptr(rgb), self.T_threshold, n, S,
-                     ptr(dL_dsigmas), ptr(dL_drgbs), ptr(ray_offs), ptr(active), ptr(xyzs) if nbytes else None, ptr(x_act), mq)
+                binned = 0 < S <= B.bin_max                      # larger: occupancy warm-up, the one-pass sliced kernel takes it
+                call("ngp_composite_train_bw", P["dL_dopacity"], P["zeros"], P["dL_drgb"], dL_dws, P["sigmas"], P["rgbs"], P["ws"],
+                     P["deltas"], P["ts"], rays_a, P["opacity"], P["depth"], P["rgb"], self.T_threshold, n, S,
+                     P["dL_dsigmas"], P["dL_drgbs"], P["ray_offs"], P["active"], P["xyzs"] if binned else None, P["x_act"] if binned else None, mq)
                 self._mark("composite_bw")
                 n_part = call("ngp_field_bwd_partials", S)
-                partials = torch.empty(n_part * (enc.n_mlp + net.params.numel()), **f32)
-                dh = torch.empty(S, 16, **f16); dfeats = torch.empty(16, S, 2, **f16)
-                call("ngp_field_bwd", ptr(feats), ptr(dirs), ptr(h), ptr(eh), ptr(rh), ptr(dL_dsigmas), ptr(dL_drgbs), tcnn.LOSS_SCALE, S,
-                     ptr(active), ptr(n_active), ptr(dh), ptr(dfeats), ptr(partials), mq)
+                assert n_part <= B.MAX_PARTIALS
+                call("ngp_field_bwd", P["feats"], P["dirs"], P["h"], eh_p, rh_p, P["dL_dsigmas"], P["dL_drgbs"], self.loss_scale, S,
+                     P["active"], P["n_active"], P["dh"], P["dfeats"], P["partials"], mq)
                 self._mark("mlp_bwd")
                 march_next_if_at("mlp_bwd")
                 g16 = m._grid_grad16(dev)
-                m._native = dict(grid16=g16, density_partials=partials[:n_part * enc.n_mlp], rgb_partials=partials[n_part * enc.n_mlp:],
-                                 n_partials=n_part, scale=tcnn.LOSS_SCALE)
-                if self.mlp_grad_hook is not None:
-                    self.mlp_grad_hook()
-                if nbytes:
-                    if self._bin_ws is None or self._bin_ws.numel() < nbytes:
-                        self._bin_ws = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=dev)
-                    call("ngp_hashgrid_bwd_binned", ptr(x_act), ptr(m.xyz_min), ptr(m.xyz_max), ptr(dfeats), C.byref(enc.meta), S,
-                         None, ptr(n_active), ptr(self._bin_ws), self._bin_ws.numel(), ptr(g16), mq)
-                else:
-                    call("ngp_hashgrid_bwd_sliced", ptr(xyzs), ptr(m.xyz_min), ptr(m.xyz_max), ptr(dfeats), C.byref(enc.meta), S,
-                         ptr(active), ptr(n_active), ptr(g16), mq)
-                self._mark("hashgrid_bwd")
-                march_next_if_at("hashgrid_bwd")
-                epoch = self.global_step // self.steps_per_epoch
-                self.opt.param_groups[0]["lr"] = cosine_lr(self.base_lr, epoch, self.num_epochs)
-                if self.grad_hook is not None:
-                    self.grad_hook()
-                self.opt.step(grad_scale=self.grad_scale, stream_handle=mq)
+                native = dict(grid16=g16, density_partials=B.view("partials", torch.float32, n_part * enc.n_mlp),
+                              rgb_partials=B.arena[B.off["partials"] + 4 * n_part * enc.n_mlp:
+                                                   B.off["partials"] + 4 * n_part * B.n_mlp_params].view(torch.float32),
+                              n_partials=n_part, scale=self.loss_scale)
+
+                def table_backward():
+                    if binned:
+                        call("ngp_hashgrid_bwd_binned", P["x_act"], ptr(m.xyz_min), ptr(m.xyz_max), P["dfeats"], C.byref(enc.meta), S,
+                             None, P["n_active"], P["bin_ws"], B.bin_bytes, ptr(g16), mq)
+                    else:
+                        call("ngp_hashgrid_bwd_sliced", P["xyzs"], ptr(m.xyz_min), ptr(m.xyz_max), P["dfeats"], C.byref(enc.meta), S,
+                             P["active"], P["n_active"], ptr(g16), mq)
+                    self._mark("hashgrid_bwd")
+                    march_next_if_at("hashgrid_bwd")
+                self._exchange_and_update(native, table_backward, mq)
                 self._mark("adam")
             elif self.grad_hook is not None or self.mlp_grad_hook is not None:
                 # no samples on THIS rank: the other ranks still expect it in the gradient collectives (DDP semantics:
                 # every rank joins every all-reduce), so it contributes zeros and applies the averaged update like them
-                g16 = m._grid_grad16(dev).zero_()
-                m._native = dict(grid16=g16, density_partials=torch.zeros(enc.n_mlp, **f32), rgb_partials=torch.zeros(net.params.numel(), **f32),
-                                 n_partials=1, scale=tcnn.LOSS_SCALE)
-                if self.mlp_grad_hook is not None:
-                    self.mlp_grad_hook()
-                epoch = self.global_step // self.steps_per_epoch
-                self.opt.param_groups[0]["lr"] = cosine_lr(self.base_lr, epoch, self.num_epochs)
-                if self.grad_hook is not None:
-                    self.grad_hook()
-                self.opt.step(grad_scale=self.grad_scale, stream_handle=mq)
+                self._exchange_and_update(self.zero_native(dev), None, mq)
             if prefetch and self._pending is None:       # a later stage was asked for and this batch had no samples
                 self._pending = self._march(next_batch[0], next_batch[1])
             self.global_step += 1
-            self.last = dict(stats=stats, rm_samples=S, total=total, n_rays=n, rgb=rgb, opacity=opacity,
-                             distortion=dist if S > 0 else None)
+            self.last = dict(stats=B.stats, rm_samples=S, total=B.total, n_rays=n, rgb=B.rgb, opacity=B.opacity,
+                             distortion=B.dist if (S > 0 and use_dist) else None, n_active=B.n_active)
             if next_batch is not None and next_needs_update:
-                self._maybe_update_grid()
+                self._maybe_update_grid(); self._grid_step = self.global_step
                 self._mark("grid_update")
                 self._pending = self._march(next_batch[0], next_batch[1])
         return self.last
+
+    def zero_native(self, dev):
+        """The native gradient record of a rank whose batch produced no samples: zeros, at this trainer's loss scale."""
+        m = self.model
+        enc, net = m.xyz_encoder, m.rgb_net
+        f32 = dict(dtype=torch.float32, device=dev)
+        return dict(grid16=m._grid_grad16(dev).zero_(), density_partials=torch.zeros(enc.n_mlp, **f32),
+                    rgb_partials=torch.zeros(net.params.numel(), **f32), n_partials=1, scale=self.loss_scale)
+
+    def _exchange_and_update(self, native, table_backward, mq):
+        """Tail of the step once the MLP backward has left its partial sums in `native`:
+        [MLP-gradient collective, asynchronous] -> table backward (fills native['grid16']) -> lr schedule ->
+        [grid-gradient collective + non-finite check] -> fused Adam on the native buffers.
+        The bracketed hooks are set under multi-GPU (ngp_pl_amd/ddp.py); device agnostic (tests/test_ddp_gloo.py drives
+        it with CPU tensors)."""
+        self.model._native = native
+        if self.mlp_grad_hook is not None:
+            self.mlp_grad_hook()
+        if table_backward is not None:
+            table_backward()
+        epoch = self.global_step // self.steps_per_epoch
+        self.opt.param_groups[0]["lr"] = cosine_lr(self.base_lr, epoch, self.num_epochs)
+        found_inf = None
+        if self.grad_hook is not None:
+            found_inf = self.grad_hook()
+        self.opt.step(grad_scale=self.grad_scale, found_inf=found_inf, stream_handle=mq)
 
     def metrics(self):
         """Host-side readout of the last step (syncs): loss, psnr, rm_s, vr_s as train.py:177-183 logs them."""

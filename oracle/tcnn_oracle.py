@@ -28,11 +28,12 @@ PRIMES = (1, 2654435761, 805459861)
 
 
 class GridMeta:
-    def __init__(self, n_levels=16, n_features=2, log2_hashmap_size=19, base_resolution=16, per_level_scale=2.0):
+    def __init__(self, n_levels=16, n_features=2, log2_hashmap_size=19, base_resolution=16, per_level_scale=2.0, exact=False):
         """Offset table as GridEncodingTemplated's constructor builds it, in float32 arithmetic.
 
         log2f / exp2f are taken correctly rounded (double evaluation rounded to float), which is
-        what glibc's versions deliver on the host where tiny-cuda-nn builds this table."""
+        what glibc's versions deliver on the host where tiny-cuda-nn builds this table.
+        exact=True: the same formula in exact arithmetic (the product's level_table="exact" opt-in)."""
         f32 = np.float32
         self.n_levels, self.n_features = n_levels, n_features
         log2_pls = f32(math.log2(float(f32(per_level_scale))))
@@ -40,6 +41,8 @@ class GridMeta:
         for l in range(n_levels):
             e = f32(f32(l) * log2_pls)
             scale = f32(f32(f32(2.0 ** float(e)) * f32(base_resolution)) - f32(1.0))
+            if exact:
+                scale = f32(round(2.0 ** (l * math.log2(per_level_scale)) * base_resolution - 1.0, 9))
             res = int(math.ceil(float(scale))) + 1
             n = min(res ** 3, (2 ** 32 - 1) // 2)
             n = (n + 7) // 8 * 8
@@ -137,13 +140,26 @@ def split_mlp_params(params, n_in, n_hidden, n_out_padded=16, width=64):
     return ws
 
 
-def mlp(x, params, n_in, n_hidden, n_out, out_act="None", quantize=False):
-    """FullyFusedMLP: ReLU hidden, no bias.  Returns (S, n_out) PRE-rounding f32 (after out_act)."""
+def matmul_acc16(h, w):
+    """h (S,K) @ w (O,K)^T with an F16 ACCUMULATOR, as tiny-cuda-nn's fully-fused MLP runs it (wmma fragments
+    `accumulator, 16, 16, 16, __half`): the K dimension is consumed in 16-wide MMA steps; inside a step the products are
+    summed at higher precision, the running sum is rounded to f16 after every step.  (The native kernels here accumulate
+    in f32 over the whole K -- wider; this mode bounds how far real tiny-cuda-nn output sits from both.)"""
+    acc = torch.zeros(h.shape[0], w.shape[0])
+    for k0 in range(0, h.shape[1], 16):
+        acc = (acc + h[:, k0:k0 + 16] @ w[:, k0:k0 + 16].t()).half().float()
+    return acc
+
+
+def mlp(x, params, n_in, n_hidden, n_out, out_act="None", quantize=False, acc16=False):
+    """FullyFusedMLP: ReLU hidden, no bias.  Returns (S, n_out) PRE-rounding f32 (after out_act).
+    acc16 (forward only, implies quantize): f16 accumulators, see matmul_acc16."""
     ws = split_mlp_params(params, n_in, n_hidden)
+    quantize = quantize or acc16
     h = q16(x.float()) if quantize else x.float()
     for i, w in enumerate(ws):
         w = q16(w.float()) if quantize else w.float()
-        h = h @ w.t()
+        h = matmul_acc16(h, w) if acc16 else h @ w.t()
         if i < len(ws) - 1:
             h = torch.relu(h)
             if quantize:
@@ -170,10 +186,10 @@ class TruncExp(torch.autograd.Function):
 class Field:
     """NGP.forward / NGP.density (networks.py:94-107,132-153) with the tiny-cuda-nn parts above."""
 
-    def __init__(self, scale=0.5, seed=1337):
+    def __init__(self, scale=0.5, seed=1337, exact_levels=False):
         self.scale = scale
         b = math.exp(math.log(2048 * scale / 16) / 15)
-        self.meta = GridMeta(16, 2, 19, 16, b)
+        self.meta = GridMeta(16, 2, 19, 16, b, exact=exact_levels)
         g = torch.Generator().manual_seed(seed)
         # tiny-cuda-nn init: xavier-uniform MLP weights, U(-1e-4,1e-4) grid
         def xavier(o, i):
@@ -186,23 +202,25 @@ class Field:
     def parameters(self):
         return [self.density_w, self.rgb_w, self.table]
 
-    def density(self, x, quantize=False):
+    def density(self, x, quantize=False, acc16=False):
+        quantize = quantize or acc16
         x01 = (x - (-self.scale)) / (self.scale - (-self.scale))          # networks.py:103
         table = q16(self.table) if quantize else self.table
         feats = hash_encode(x01, table, self.meta, quantize)
-        h = mlp(feats, self.density_w, 32, 1, 16, "None", quantize)
+        h = mlp(feats, self.density_w, 32, 1, 16, "None", quantize, acc16)
         if quantize:
             h = q16(h)
         sigma = TruncExp.apply(h[:, 0])                                    # networks.py:105
         return sigma, h, feats
 
-    def forward(self, x, d, quantize=False):
-        sigma, h, _ = self.density(x, quantize)
+    def forward(self, x, d, quantize=False, acc16=False):
+        quantize = quantize or acc16
+        sigma, h, _ = self.density(x, quantize, acc16)
         dn = d / torch.norm(d, dim=1, keepdim=True)                        # networks.py:143
         sh = sh4(dn)                                                       # (d+1)/2 then *2-1 inside tcnn == identity
         if quantize:
             sh = q16(sh)
-        rgb = mlp(torch.cat([sh, h], 1), self.rgb_w, 32, 2, 3, "Sigmoid", quantize)
+        rgb = mlp(torch.cat([sh, h], 1), self.rgb_w, 32, 2, 3, "Sigmoid", quantize, acc16)
         if quantize:
             rgb = q16(rgb)
         return sigma, rgb, h

@@ -4,6 +4,7 @@ Run in the development container (where /root/reference exists):  python tests/g
 The fixture travels with the repo so the oracle stays pinned where the reference is absent."""
 import os
 import sys
+import zlib
 
 import numpy as np
 
@@ -14,19 +15,31 @@ from oracle.vren_oracle import Reference          # noqa: E402
 from tests.helpers import aabb_hits, make_rays    # noqa: E402
 
 
+def origins(ro, tag, scale):
+    if tag == "garden":
+        f = np.random.RandomState(26).choice([1.0, 2.0, 3.0, 5.0, 8.0], ro.shape[0]).astype(np.float32)
+        return (ro * f[:, None]).astype(np.float32)
+    return ro * (1.5 if scale > 0.5 else 1.0)
+
+
 def main():
     r = Reference(fma=True)
     out = {}
     n = 192
     ro, rd = make_rays(n, seed=21, W=64, n_cams=4)
     out["rays_o"], out["rays_d"] = ro, rd
-    for tag, cascades, scale, esf, fill in (("syn", 1, 0.5, 0.0, 0.1), ("real", 3, 2.0, 1 / 256, 0.2)):
-        rr = ro * (1.5 if scale > 0.5 else 1.0)
+    # "garden": the mip-NeRF360 recipe (benchmark_mipnerf360.sh:21-24: scale 16 -> 6 cascades, exp_step_factor 1/256), camera
+    # radii 1.5..12 so that every cascade is sampled
+    for tag, cascades, scale, esf, fill in (("syn", 1, 0.5, 0.0, 0.1), ("real", 3, 2.0, 1 / 256, 0.2), ("garden", 6, 16.0, 1 / 256, 0.12)):
+        rr = origins(ro, tag, scale)
         bf = syn.random_blob_bitfield(cascades, 128, fill, seed=22)
         ht = aabb_hits(r, rr, rd, scale)
         noise = np.random.RandomState(23).rand(n).astype(np.float32)
         rays_a, xyzs, dirs, deltas, ts, counter = r.raymarching_train(rr, rd, ht, bf, cascades, scale, esf, noise, 128, 1024)
-        out[tag + "_bitfield_packed"] = np.packbits(np.unpackbits(bf))      # as is (uint8)
+        if tag == "garden":
+            out[tag + "_bitfield_crc"] = np.array([zlib.crc32(bf.tobytes())], np.int64)     # 1.5 MB: the generator is deterministic, pin its checksum
+        else:
+            out[tag + "_bitfield_packed"] = np.packbits(np.unpackbits(bf))      # as is (uint8)
         out[tag + "_hits_t"], out[tag + "_noise"] = ht, noise
         out[tag + "_rays_a"], out[tag + "_xyzs"], out[tag + "_deltas"], out[tag + "_ts"] = rays_a, xyzs, deltas, ts
         h2 = ht.copy()

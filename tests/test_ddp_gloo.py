@@ -1,52 +1,189 @@
-"""CPU, world_size 2 over gloo: the multi-GPU path's host logic -- per-rank independent ray
-batches (the reference's sharding axis, datasets/base.py:25-29 under DistributedSampler) and the
-native-gradient all-reduce that replaces DDP's (train.py:270-272)."""
+"""CPU, world_size 2 over gloo: the multi-GPU path's host logic, REAL code on CPU tensors --
+`Trainer._exchange_and_update` (the tail of Trainer.step: hook ordering, zero-sample rank) driving
+`ngp_pl_amd.ddp.GradientExchange` (what replaces Lightning's DDP all-reduce, train.py:268-272).
+
+Each rank computes real gradients of its own ray batch with the fp32 CPU oracle field, packs them the way
+the fused backward leaves them (packed-f16 grid gradient and per-workgroup MLP partial rows, both at loss
+scale 128 / world), runs the step tail, and the unscaled gradient the optimizer receives must equal the
+single-process gradient of the concatenated batch (mean over ranks), including when one rank's batch
+produced no samples at all."""
 import os
 import socket
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+N_PTS = 96          # samples per rank
+N_TABLE = 4096      # only the first rows of the table are given gradients to exchange (the collective does not care which)
 
-class _Enc:
-    n_mlp = 3072
+
+def _field():
+    from oracle import tcnn_oracle as T
+    f = T.Field(scale=0.5)
+    with torch.no_grad():
+        f.table.uniform_(-0.3, 0.3, generator=torch.Generator().manual_seed(3))
+    for p in f.parameters():
+        p.requires_grad_(True)
+    return f
 
 
-class _Net:
-    params = torch.zeros(7168)
+def _rank_loss(field, rank, empty):
+    """Sum over this rank's samples / N_PTS (a rank without samples contributes 0): the mean over ranks of these
+    is the mean over the concatenated batch."""
+    if empty:
+        return None
+    g = torch.Generator().manual_seed(50 + rank)
+    x = (torch.rand(N_PTS, 3, generator=g) - 0.5) * 0.98
+    d = torch.randn(N_PTS, 3, generator=g)
+    tgt = torch.rand(N_PTS, 3, generator=g)
+    sigma, rgb, _ = field.forward(x, d)
+    return (((rgb - tgt) ** 2).sum() + 1e-2 * sigma.sum()) / N_PTS
+
+
+def _grads(loss, field):
+    if loss is None:
+        return [torch.zeros_like(p) for p in (field.density_w, field.rgb_w, field.table)]
+    return list(torch.autograd.grad(loss, [field.density_w, field.rgb_w, field.table]))
+
+
+class _Params:
+    def __init__(self, n):
+        self.params = torch.zeros(n)
+
+    def numel(self):
+        return self.params.numel()
 
 
 class _Model:
-    xyz_encoder = _Enc()
-    rgb_net = _Net()
-    _native = None
+    """What Trainer._exchange_and_update / GradientExchange touch of NGP."""
+
+    def __init__(self, n_grid):
+        self.xyz_encoder = _Params(0); self.xyz_encoder.n_mlp = 3072; self.xyz_encoder.n_grid = n_grid
+        self.rgb_net = _Params(7168)
+        self._native = None
+        self._g16 = torch.zeros(n_grid, dtype=torch.float16)
+
+    def _grid_grad16(self, dev):
+        return self._g16
 
 
-def _worker(rank, world, port, q):
+class _CapturingAdam:
+    """Stands where optim.FusedAdam stands: receives the native record after the exchange."""
+
+    def __init__(self, model):
+        self.model, self.param_groups, self.seen = model, [{"lr": 0.0}], None
+
+    def step(self, grad_scale=1.0, found_inf=None, stream_handle=None):
+        nat = self.model._native
+        s = nat["scale"] * grad_scale
+        n_part = nat["n_partials"]
+        self.seen = dict(grid=nat["grid16"].float() / s, density=nat["density_partials"].view(n_part, -1).sum(0) / s,
+                         rgb=nat["rgb_partials"].view(n_part, -1).sum(0) / s, found_inf=found_inf, lr=self.param_groups[0]["lr"])
+        self.model._native = None
+
+
+def _make_trainer(model, world):
+    from ngp_pl_amd.ddp import GradientExchange
+    from ngp_pl_amd.trainer import Trainer
+    tr = Trainer.__new__(Trainer)            # no GPU here: only the fields the step tail reads
+    tr.model, tr.opt = model, _CapturingAdam(model)
+    tr.global_step, tr.steps_per_epoch, tr.base_lr, tr.num_epochs = 0, 1000, 1e-2, 30
+    tr.grad_scale, tr.loss_scale = 1.0, 128.0
+    tr.grad_hook = tr.mlp_grad_hook = None
+    ex = GradientExchange(model, dist, world).install(tr)
+    assert tr.loss_scale == 128.0 / world and tr.grad_hook is not None and tr.mlp_grad_hook is not None
+    return tr, ex
+
+
+def _worker(rank, world, port, q, empty_rank):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from ngp_pl_amd.bench_support import GpuDataset, all_reduce_native, all_reduce_native_mlp
-    torch.manual_seed(100 + rank)
-    n_part = 3 + rank                                   # ranks may have different partial counts
-    m = _Model()
-    m._native = dict(grid16=torch.full((1000,), float(rank + 1)), density_partials=torch.ones(n_part * 3072),
-                     rgb_partials=torch.full((n_part * 7168,), 2.0), n_partials=n_part, scale=128.0)
-    all_reduce_native_mlp(m, dist)                      # early, asynchronous half (trainer's mlp_grad_hook)
-    all_reduce_native(m, dist, world)
-    nat = m._native
-    assert "_mlp_work" not in nat and "_mlp_small" not in nat
-    ok = bool((nat["grid16"] == 3.0).all())                                         # 1 + 2
-    ok &= bool((nat["density_partials"] == 3 + 4).all()) and nat["n_partials"] == 1 and nat["density_partials"].numel() == 3072
-    ok &= bool((nat["rgb_partials"] == 2.0 * 7).all()) and nat["scale"] == 256.0   # sum over ranks, mean folded into the unscale
-    # per-rank batches differ, same dataset
-    data = GpuDataset(16, 3, "cpu", seed=0)
-    gen = torch.Generator(); gen.manual_seed(1234 + rank)
+    torch.set_num_threads(2)
+    field = _field()
+    n_grid = 2 * N_TABLE
+    # what a single process would compute on the concatenated batch
+    losses = [_rank_loss(field, r, r == empty_rank) for r in range(world)]
+    want = _grads(sum(lo for lo in losses if lo is not None) / world, field)
+    mine = _grads(_rank_loss(field, rank, rank == empty_rank), field)
+    model = _Model(n_grid)
+    tr, ex = _make_trainer(model, world)
+    order = []
+    mlp_hook, grid_hook = tr.mlp_grad_hook, tr.grad_hook
+    tr.mlp_grad_hook = lambda: (order.append("mlp"), mlp_hook())[1]
+    tr.grad_hook = lambda: (order.append("grid"), grid_hook())[1]
+    if rank == empty_rank:
+        # Trainer.step's S == 0 branch: the rank joins both collectives with zeros
+        tr._exchange_and_update(tr.zero_native(torch.device("cpu")), None, None)
+    else:
+        n_part = 3 + rank                                   # ranks may have different partial counts
+        split = torch.rand(n_part, 1, generator=torch.Generator().manual_seed(rank))
+        split = split / split.sum(0, keepdim=True)
+        ls = tr.loss_scale
+        native = dict(grid16=model._g16, density_partials=(split * mine[0][None] * ls).reshape(-1).contiguous(),
+                      rgb_partials=(split * mine[1][None] * ls).reshape(-1).contiguous(), n_partials=n_part, scale=ls)
+
+        def table_backward():                               # the table backward overwrites the packed-f16 gradient
+            order.append("table_bwd")
+            model._g16.copy_((mine[2].reshape(-1)[:n_grid] * ls).half())
+        tr._exchange_and_update(native, table_backward, None)
+    seen = tr.opt.seen
+    ok = order == (["mlp", "grid"] if rank == empty_rank else ["mlp", "table_bwd", "grid"])
+    ok &= seen["found_inf"] is None and model._native is None and seen["lr"] == pytest.approx(1e-2)
+    errs = {}
+    for key, w in (("density", want[0]), ("rgb", want[1]), ("grid", want[2].reshape(-1)[:n_grid])):
+        scale = float(w.abs().max())
+        errs[key] = float((seen[key] - w).abs().max()) / scale
+    ok &= errs["density"] < 1e-5 and errs["rgb"] < 1e-5          # f32 all the way
+    ok &= errs["grid"] < 2e-3                                     # one f16 rounding per rank + one per ring add
+    # every rank ends with the same reduced gradient (lock step without a second collective)
+    gathered = [torch.zeros_like(seen["grid"]) for _ in range(world)]
+    dist.all_gather(gathered, seen["grid"])
+    ok &= all(torch.equal(gathered[0], g) for g in gathered)
+    # an overflow in the f16 sum is seen by every rank: both ranks hold 40000 -> the sum is inf in f16
+    model._g16.fill_(40000.0)
+    tr._exchange_and_update(dict(grid16=model._g16, density_partials=torch.zeros(3072), rgb_partials=torch.zeros(7168),
+                                 n_partials=1, scale=tr.loss_scale), None, None)
+    flag = tr.opt.seen["found_inf"]
+    ok &= flag is not None and int(flag[0]) != 0
+    q.put((rank, bool(ok), errs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(empty_rank):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, empty_rank)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert [(r, ok) for r, ok, _ in res] == [(0, True), (1, True)], res
+
+
+def test_two_rank_exchange_equals_single_process_gradient():
+    _run(empty_rank=-1)
+
+
+def test_two_rank_exchange_with_a_rank_without_samples():
+    _run(empty_rank=1)
+
+
+def _sampler_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ngp_pl_amd.bench_support import GpuDataset
+    data = GpuDataset(16, 3, "cpu", seed=0)                  # same dataset on every rank ...
+    gen = torch.Generator(); gen.manual_seed(1234 + rank)    # ... per-rank independent batches (datasets/base.py:25-29)
     ro, rd, gt = data.sample(64, gen)
     gathered = [torch.zeros_like(rd) for _ in range(world)]
     dist.all_gather(gathered, rd)
-    ok &= not torch.equal(gathered[0], gathered[1])
+    ok = not torch.equal(gathered[0], gathered[1])
     pose_sum = data.poses.sum().reshape(1).clone()
     dist.all_reduce(pose_sum)
     ok &= bool(torch.isclose(pose_sum, data.poses.sum() * world).all())
@@ -55,14 +192,31 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_native_gradient_allreduce():
+def test_two_rank_batches_differ_dataset_agrees():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_sampler_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in range(2))
     for p in procs:
         p.join(60)
     assert res == [(0, True), (1, True)]
+
+
+def test_bench_launcher_spawns_n_ranks():
+    """`python bench.py --gpus 2` with no rank environment starts 2 ranks (torch.distributed.run, 127.0.0.1) and
+    reports n_gpus from the process group; without a GPU it stops there (dry run)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dry_run"] is True

@@ -345,3 +345,170 @@ def test_active_sample_compaction(lib, field):
     (w0, g0), (w1, g1) = outs
     assert ((w0 - w1).abs().max() / w0.abs().max()).item() < 1e-4       # same terms, different partial-sum grouping
     assert ((g0 - g1).abs().max() / g0.abs().max()).item() < 5e-3       # f16 accumulation order differs
+
+
+# ---------------------------------------------------------------------------------------------------------
+# distance to the UN-QUANTISED fp32 field: how far is the f16-storage / f32-accumulate
+# native field from "any correct tiny-cuda-nn", with numbers.  north_star asks RGB / sigma within 1e-4 abs of the
+# CUDA path; tiny-cuda-nn itself stores features, activations and outputs in f16 (ulp at 1.0: 4.9e-4, at 0.5: 2.4e-4),
+# so neither it nor this path can hold 1e-4 against exact arithmetic -- these tests state what IS held.
+# ---------------------------------------------------------------------------------------------------------
+def _dist(name, err, fh=None):
+    err = err.flatten().double()
+    q = torch.quantile(err, torch.tensor([0.5, 0.99], dtype=torch.float64))
+    rec = dict(median=float(q[0]), p99=float(q[1]), max=float(err.max()))
+    print("  %-34s median %.3e   p99 %.3e   max %.3e" % (name, rec["median"], rec["p99"], rec["max"]))
+    return rec
+
+
+def test_field_error_against_the_unquantised_fp32_oracle(lib, field):
+    """Error distribution (median / p99 / max) of the native field against the fp32 oracle WITHOUT rounding points,
+    next to (a) the oracle with the kernels' f16 rounding points and (b) the oracle with tiny-cuda-nn's f16
+    accumulators.  The asserted bounds are what DESIGN.md section 2 quotes."""
+    n = 60000
+    x, d = sample_points(n, seed=21)
+    feats, sig, rgb, h, *_ = field_native(lib, field, x, d)
+    got_f = feats.permute(1, 0, 2).reshape(n, 32).float().cpu()
+    got_s, got_c = sig.cpu(), rgb.cpu()
+    want_f = T.hash_encode(x + 0.5, field.table, field.meta)                 # fp32, no rounding
+    ws, wc, _ = field.forward(x, d)                                          # fp32 end to end
+    qs, qc, _ = field.forward(x, d, quantize=True)                           # f16 storage, f32 accumulation (this path's model)
+    as_, ac, _ = field.forward(x, d, acc16=True)                             # f16 storage, f16 accumulators (tiny-cuda-nn's model)
+    print("\nnative HIP field vs oracle variants, %d samples, |table| <= 0.8, |h0| up to %.1f:" % (n, float(field.density(x)[1][:, 0].abs().max())))
+    r = {}
+    r["feat"] = _dist("features abs (vs fp32)", (got_f - want_f).abs())
+    r["rgb"] = _dist("rgb abs (vs fp32)", (got_c - wc.detach()).abs())
+    r["sig"] = _dist("sigma rel (vs fp32)", ((got_s - ws.detach()).abs() / ws.detach().clamp(min=1e-6)))
+    r["rgb_q"] = _dist("rgb abs (vs f16-storage oracle)", (got_c - qc.detach()).abs())
+    r["sig_q"] = _dist("sigma rel (vs f16-storage oracle)", ((got_s - qs.detach()).abs() / qs.detach().clamp(min=1e-6)))
+    r["rgb_a"] = _dist("rgb abs (vs f16-accumulate oracle)", (got_c - ac.detach()).abs())
+    r["sig_a"] = _dist("sigma rel (vs f16-accumulate)", ((got_s - as_.detach()).abs() / as_.detach().clamp(min=1e-6)))
+    r["tcnn_rgb"] = _dist("f16-accumulate oracle vs fp32: rgb", (ac.detach() - wc.detach()).abs())
+    r["tcnn_sig"] = _dist("f16-accumulate oracle vs fp32: sig", ((as_.detach() - ws.detach()).abs() / ws.detach().clamp(min=1e-6)))
+    # features: one f16 rounding of a value |v| <= 0.8 on top of exact f32 interpolation: <= 2^-12 = 2.44e-4
+    assert r["feat"]["max"] <= 2.5e-4 and r["feat"]["median"] <= 7e-5
+    # rgb in [0,1] stored as f16 after a sigmoid: half an ulp (2.4e-4 near 1, 1.2e-4 near 0.5) + propagated feature/activation rounding
+    assert r["rgb"]["median"] <= 2.5e-4 and r["rgb"]["p99"] <= 1.5e-3 and r["rgb"]["max"] <= 4e-3
+    # sigma = exp(h0), h0 stored as f16: |h0| in [4, 8) has ulp 3.9e-3 -> up to 0.2 % from that rounding alone
+    assert r["sig"]["median"] <= 2e-3 and r["sig"]["p99"] <= 1e-2 and r["sig"]["max"] <= 3e-2
+    # this path sits CLOSER to exact arithmetic than the f16-accumulator model of tiny-cuda-nn does
+    assert r["rgb"]["p99"] <= r["tcnn_rgb"]["p99"] * 1.05 and r["sig"]["p99"] <= r["tcnn_sig"]["p99"] * 1.05
+
+
+def test_gradient_error_against_the_unquantised_fp32_oracle(lib, field):
+    """Same question for the backward: weight gradients and per-sample feature gradients of the native fused
+    backward against fp32 autograd of the oracle WITHOUT rounding points (the existing tests compare with the
+    rounding points inserted)."""
+    n = 20000
+    x, d = sample_points(n, seed=22)
+    feats, sig, rgb, h, dw, rw, ds = field_native(lib, field, x, d)
+    g = torch.Generator().manual_seed(23)
+    dsig = torch.randn(n, generator=g) * 1e-3; drgb = torch.randn(n, 3, generator=g) * 1e-2
+    dwp = field.density_w.clone().requires_grad_(True); rwp = field.rgb_w.clone().requires_grad_(True)
+    f_in = T.hash_encode(x + 0.5, field.table, field.meta).detach().requires_grad_(True)
+    hh = T.mlp(f_in, dwp, 32, 1, 16)
+    s_o = T.TruncExp.apply(hh[:, 0])
+    c_o = T.mlp(torch.cat([T.sh4(d / d.norm(dim=1, keepdim=True)), hh], 1), rwp, 32, 2, 3, "Sigmoid")
+    ((s_o * dsig).sum() + (c_o * drgb).sum()).backward()
+    n_part = lib.call("ngp_field_bwd_partials", n)
+    partials = torch.empty(n_part * 10240, device="cuda")
+    dh = torch.empty(n, 16, dtype=torch.float16, device="cuda"); dfeats = torch.empty(16, n, 2, dtype=torch.float16, device="cuda")
+    dsig_d, drgb_d = dsig.cuda(), drgb.cuda().contiguous()
+    lib.call("ngp_field_bwd", lib.ptr(feats), lib.ptr(ds), lib.ptr(h), lib.ptr(dw), lib.ptr(rw), lib.ptr(dsig_d), lib.ptr(drgb_d),
+             128.0, n, None, None, lib.ptr(dh), lib.ptr(dfeats), lib.ptr(partials), lib.stream())
+    gd = partials[:n_part * 3072].view(n_part, 3072).sum(0).cpu() / 128.0
+    gr = partials[n_part * 3072:].view(n_part, 7168).sum(0).cpu() / 128.0
+    got_df = dfeats.permute(1, 0, 2).reshape(n, 32).float().cpu() / 128.0
+    print("\nnative fused backward vs fp32 autograd without rounding points, %d samples (errors relative to max |gradient|):" % n)
+    r_d = _dist("density-net weight grad", (gd - dwp.grad).abs() / dwp.grad.abs().max())
+    r_r = _dist("rgb-net weight grad", (gr - rwp.grad).abs() / rwp.grad.abs().max())
+    r_f = _dist("per-sample feature grad", (got_df - f_in.grad).abs() / f_in.grad.abs().max())
+    assert r_d["max"] <= 1e-2 and r_r["max"] <= 1e-2                 # sums over 20 000 samples: rounding noise averages out
+    assert r_f["p99"] <= 1e-2 and r_f["max"] <= 0.25                 # a ReLU unit within rounding of 0 flips for single samples
+
+
+def test_points_outside_the_box_stay_in_bounds(lib, field):
+    """positions outside [xyz_min, xyz_max] (public NGP.density()/forward() callers) used to index past
+    the dense levels.  They now clamp to the border cell: forward, all table backwards and the input gradient stay in
+    bounds (finite results, untouched guard bands), and in-box rows of a mixed batch are exactly what they are alone."""
+    meta = native_meta(lib)
+    n = 8192
+    g = torch.Generator().manual_seed(31)
+    x_in = torch.rand(n, 3, generator=g) - 0.5
+    x_out = (torch.rand(n, 3, generator=g) - 0.5) * 8.0                 # up to 4x the half extent, both signs
+    x_out[:4] = torch.tensor([[-0.5001, 0.0, 0.0], [0.5001, 0.5001, 0.5001], [-30.0, 40.0, -50.0], [1e6, -1e6, 1e6]])
+    x = torch.cat([x_in, x_out])
+    guard = 4096
+    total = field.meta.total
+    buf = torch.zeros(total + 2 * guard, 2, dtype=torch.float16, device="cuda")
+    buf[guard:guard + total] = field.table.half().cuda()
+    buf[:guard] = float("nan"); buf[guard + total:] = float("nan")       # a read past either end poisons the output
+    table_h = buf[guard:guard + total]
+    feats = run_hash_fwd(lib, meta, x, table_h)
+    alone = run_hash_fwd(lib, meta, x_in, table_h)
+    assert torch.isfinite(feats.float()).all()
+    assert torch.equal(feats[:, :n], alone)
+    dfe = (torch.randn(2 * n, 32, generator=g) * 0.1).half()
+    dfl = dfe.view(2 * n, 16, 2).permute(1, 0, 2).contiguous().cuda()
+    xs = x.cuda().contiguous()
+    mnt = torch.full((3,), -0.5, device="cuda"); mxt = torch.full((3,), 0.5, device="cuda")
+    for mode in ("sliced", "binned", "atomic"):
+        gbuf = torch.zeros(total + 2 * guard, 2, dtype=torch.float16, device="cuda")
+        gbuf[:guard] = 7.0; gbuf[guard + total:] = 7.0
+        grad = gbuf[guard:guard + total]
+        if mode == "sliced":
+            lib.call("ngp_hashgrid_bwd_sliced", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), 2 * n, None, None, lib.ptr(grad), lib.stream())
+        elif mode == "binned":
+            nbytes = lib.lib().ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(meta), 2 * n)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+            lib.call("ngp_hashgrid_bwd_binned", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), 2 * n, None, None,
+                     lib.ptr(ws), nbytes, lib.ptr(grad), lib.stream())
+        else:
+            lib.call("ngp_hashgrid_bwd", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), 2 * n, lib.ptr(grad), 0, lib.stream())
+        torch.cuda.synchronize()
+        assert torch.isfinite(grad.float()).all(), mode
+        assert (gbuf[:guard] == 7.0).all() and (gbuf[guard + total:] == 7.0).all(), "%s wrote outside the table" % mode
+    dx = torch.empty(2 * n, 3, device="cuda")
+    lib.call("ngp_hashgrid_bwd_input", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(table_h), lib.ptr(dfl), C.byref(meta), 2 * n, 1.0,
+             lib.ptr(dx), lib.stream())
+    assert torch.isfinite(dx).all()
+    # the module-level entry points the advisor named
+    from ngp_pl_amd.networks import NGP
+    m = NGP(scale=0.5).cuda()
+    with torch.no_grad():
+        s = m.density(xs)
+        s2, c2 = m(xs, torch.randn(2 * n, 3, device="cuda"))
+    assert torch.isfinite(s).all() and torch.isfinite(s2).all() and torch.isfinite(c2.float()).all()
+
+
+def test_exact_level_table_option(lib):
+    """NGP(level_table='exact') (checkpoints whose xyz_encoder.params has the exact-arithmetic length, ngp_pl_amd/utils.py):
+    the kernels take the table from the meta record, so forward and table backward must match the oracle built on the same table."""
+    from ngp_pl_amd import tcnn
+    b = math.exp(math.log(2048 * 0.5 / 16) / 15)
+    meta = tcnn.make_grid_meta({"otype": "Grid", "type": "Hash", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 19,
+                                "base_resolution": 16, "per_level_scale": b, "interpolation": "Linear"}, level_table="exact")
+    om = T.GridMeta(16, 2, 19, 16, b, exact=True)
+    assert [meta.resolution[i] for i in range(16)] == om.resolution and [meta.offset[i] for i in range(17)] == om.offset
+    assert om.total * 2 + 3072 == 11_423_136
+    g = torch.Generator().manual_seed(41)
+    table = ((torch.rand(om.total, 2, generator=g) * 2 - 1) * 0.8).half().float()
+    x, _ = sample_points(20000, seed=42)
+    feats = run_hash_fwd(lib, meta, x, table.half().cuda())
+    got = feats.permute(1, 0, 2).reshape(x.shape[0], 32).float().cpu()
+    want = T.hash_encode(x + 0.5, table, om, quantize=True)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=1e-3)
+    n = x.shape[0]
+    dfe = (torch.randn(n, 32, generator=g) * 0.5).half()
+    tb = table.clone().requires_grad_(True)
+    T.hash_encode(x + 0.5, tb, om).backward(dfe.float())
+    dfl = dfe.view(n, 16, 2).permute(1, 0, 2).contiguous().cuda()
+    xs = x.cuda().contiguous()
+    mnt = torch.full((3,), -0.5, device="cuda"); mxt = torch.full((3,), 0.5, device="cuda")
+    grad = torch.full((om.total, 2), float("nan"), dtype=torch.float16, device="cuda")
+    nbytes = lib.lib().ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(meta), n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    lib.call("ngp_hashgrid_bwd_binned", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), n, None, None,
+             lib.ptr(ws), nbytes, lib.ptr(grad), lib.stream())
+    err = (grad.float().cpu() - tb.grad).abs().max().item() / tb.grad.abs().max().item()
+    assert err < 1e-3, err

@@ -20,16 +20,31 @@ def same(a, b, what):
     assert np.array_equal(a, b), what
 
 
-CASES = {"syn": (1, 0.5, 0.0, 0.1), "real": (3, 2.0, 1 / 256, 0.2)}
+CASES = {"syn": (1, 0.5, 0.0, 0.1), "real": (3, 2.0, 1 / 256, 0.2), "garden": (6, 16.0, 1 / 256, 0.12)}
+TAGS = ["syn", "real", "garden"]
 
 
-@pytest.mark.parametrize("tag", ["syn", "real"])
+def origins(tag, scale):
+    from tests.golden.make_golden import origins as f
+    return f(G["rays_o"], tag, scale)
+
+
+def bitfield(tag, cascades, fill):
+    bf = syn.random_blob_bitfield(cascades, 128, fill, seed=22)
+    if tag == "garden":
+        import zlib
+        assert zlib.crc32(bf.tobytes()) == int(G[tag + "_bitfield_crc"][0]), "bitfield generator drifted"
+    else:
+        same(bf, G[tag + "_bitfield_packed"], "bitfield generator drifted")
+    return bf
+
+
+@pytest.mark.parametrize("tag", TAGS)
 def test_oracle_marching_against_golden(tag):
     cascades, scale, esf, fill = CASES[tag]
     o = Oracle(fma=True)
-    ro = G["rays_o"] * (1.5 if scale > 0.5 else 1.0); rd = G["rays_d"]
-    bf = syn.random_blob_bitfield(cascades, 128, fill, seed=22)
-    same(bf, G[tag + "_bitfield_packed"], "bitfield generator drifted")
+    ro = origins(tag, scale); rd = G["rays_d"]
+    bf = bitfield(tag, cascades, fill)
     rays_a, xyzs, dirs, deltas, ts, counter = o.raymarching_train(ro, rd, G[tag + "_hits_t"], bf, cascades, scale, esf, G[tag + "_noise"], 128, 1024)
     same(rays_a, G[tag + "_rays_a"], "rays_a"); same(xyzs, G[tag + "_xyzs"], "xyzs"); same(deltas, G[tag + "_deltas"], "deltas"); same(ts, G[tag + "_ts"], "ts")
     h = G[tag + "_hits_t"].copy()
@@ -53,17 +68,21 @@ def test_oracle_composite_against_golden():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["syn", "real"])
+@pytest.mark.parametrize("tag", TAGS)
 def test_hip_marching_against_golden(tag):
     import torch
     import ngp_pl_amd.vren as vren
     cascades, scale, esf, fill = CASES[tag]
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-    ro = G["rays_o"] * (1.5 if scale > 0.5 else 1.0); rd = G["rays_d"]
-    bf = G[tag + "_bitfield_packed"]
+    ro = origins(tag, scale); rd = G["rays_d"]
+    bf = bitfield(tag, cascades, fill)
     got = vren.raymarching_train(d(ro), d(rd), d(G[tag + "_hits_t"]), d(bf), cascades, scale, esf, d(G[tag + "_noise"]), 128, 1024)
     same(got[0].cpu().numpy(), G[tag + "_rays_a"], "rays_a"); same(got[1].cpu().numpy(), G[tag + "_xyzs"], "xyzs")
     same(got[3].cpu().numpy(), G[tag + "_deltas"], "deltas"); same(got[4].cpu().numpy(), G[tag + "_ts"], "ts")
+    h = d(G[tag + "_hits_t"].copy())
+    out = vren.raymarching_test(d(ro), d(rd), h, d(np.arange(ro.shape[0], dtype=np.int64)), d(bf), cascades, scale, esf, 128, 1024, 4)
+    same(out[3].cpu().numpy(), G[tag + "_test_ts"], "test ts"); same(out[2].cpu().numpy(), G[tag + "_test_deltas"], "test deltas")
+    same(out[4].cpu().numpy(), G[tag + "_test_neff"], "N_eff"); same(h.cpu().numpy(), G[tag + "_test_hits_after"], "hits_t after")
     if tag == "syn":
         out = vren.composite_train_fw(d(G["sigmas"]), d(G["rgbs"]), d(G["syn_deltas"]), d(G["syn_ts"]), d(G["syn_rays_a"]), 1e-4)
         np.testing.assert_allclose(out[3].cpu().numpy(), G["rgb"], rtol=0, atol=1e-5)      # north star: RGB within 1e-4 abs

@@ -83,12 +83,15 @@ def test_intersections(pair):
     dict(cascades=1, scale=0.5, esf=0.0, fill=0.08),      # Synthetic-NeRF setting
     dict(cascades=1, scale=0.5, esf=0.0, fill=1.0),       # warm-up: every cell occupied
     dict(cascades=3, scale=2.0, esf=1 / 256, fill=0.15),  # real-scene setting: cascades + exponential steps
-], ids=["synthetic", "dense", "cascaded"])
+    dict(cascades=6, scale=16.0, esf=1 / 256, fill=0.12), # mip-NeRF360 recipe (benchmark_mipnerf360.sh:21-24): camera radii 1.5..12
+], ids=["synthetic", "dense", "cascaded", "garden"])
 def test_raymarching_train_and_test(pair, cfg):
     o, r = pair
     n = 1500
     ro, rd = make_rays(n, seed=3)
-    if cfg["scale"] > 0.5:
+    if cfg["cascades"] == 6:
+        ro = (ro * np.random.RandomState(3).choice([1.0, 2.0, 3.0, 5.0, 8.0], n).astype(np.float32)[:, None]).astype(np.float32)
+    elif cfg["scale"] > 0.5:
         ro = ro * 1.5
     bf = (np.full(cfg["cascades"] * 128 ** 3 // 8, 255, np.uint8) if cfg["fill"] >= 1.0
           else syn.random_blob_bitfield(cfg["cascades"], 128, cfg["fill"], seed=4))

@@ -91,19 +91,20 @@ def test_render_train_and_test_paths():
     assert isinstance(out["rgb"], np.ndarray)
 
 
-@pytest.mark.parametrize("lambda_distortion", [0.0, 1e-2])
-def test_fused_step_equals_autograd_step(lambda_distortion):
+@pytest.mark.parametrize("lambda_distortion,n_rays", [(0.0, 4096), (1e-2, 4096), (0.0, 16384)],
+                         ids=["default", "distortion", "16384_rays_benchmark_synthetic_nerf_sh"])
+def test_fused_step_equals_autograd_step(lambda_distortion, n_rays):
     """Trainer.step (direct native calls, compacted backward) and Trainer.step_autograd (render() +
     NeRFLoss + torch autograd) produce the same gradients from the same state.  Gradients are
     captured instead of compared after Adam: the first Adam step moves a parameter by lr*sign(g),
     which turns f16 accumulation-order noise on near-zero entries into full-size differences."""
     from ngp_pl_amd.trainer import Trainer
     from ngp_pl_amd import tcnn
-    ro, rd, gt = batch(4096, seed=3)
+    ro, rd, gt = batch(n_rays, seed=3)
     grads = []
     for mode in ("native", "autograd"):
         m = make_model(seed=11)
-        tr = Trainer(m, lambda_distortion=lambda_distortion)
+        tr = Trainer(m, lambda_distortion=lambda_distortion, lr=2e-2 if n_rays == 16384 else 1e-2)    # benchmark_synthetic_nerf.sh:25-28
         captured = {}
 
         def capture(grad_scale=1.0, found_inf=None, stream_handle=None, m=m, captured=captured):
@@ -498,3 +499,126 @@ def test_hdr_branch_and_unbounded_scene_smoke():
     assert torch.isfinite(big.density_grid).all() and not torch.equal(before, big.density_grid)
     assert (big.density_grid >= 0.95 * before - 1e-6).all()             # decay-max merge never drops a cell below its decayed value
     assert int(torch.count_nonzero(big.density_bitfield)) > 0
+
+
+def test_erode_reaches_the_occupancy_update_through_the_trainer():
+    """train.py:160-163: `erode = (dataset_name == 'colmap')` is handed to update_density_grid every 16 steps; with it the
+    decay is per cell, clamp(0.95 ** (1 / count_grid), 0.1, 0.95) (networks.py:262-264), count_grid from
+    mark_invisible_cells.  Scale 16 (6 cascades, the mip-NeRF360 recipe).  With the grid preset high above any density the
+    untrained field produces, the merge max(grid * decay, sigma) returns grid * decay exactly: the per-cell factors show."""
+    from ngp_pl_amd.networks import NGP
+    from ngp_pl_amd.trainer import Trainer
+    torch.manual_seed(0)
+    m = NGP(scale=16.0).cuda()
+    m.register_training_buffers()
+    K = syn.intrinsics(200).cuda()
+    poses = syn.hemisphere_poses(12, radius=4.0, seed=2).cuda()
+    m.mark_invisible_cells(K, poses, (200, 200))
+    assert m.cascades == 6 and (m.density_grid < 0).any() and (m.density_grid == 0).any()
+    valid = m.density_grid >= 0
+    assert (m.count_grid[valid] > 0).all() and m.count_grid.max() <= 1.0
+    for erode in (True, False):
+        tr = Trainer(m, erode=erode)
+        assert tr.exp_step_factor == 1 / 256
+        grid0 = torch.where(valid, torch.full_like(m.density_grid, 1e4), m.density_grid)
+        m.density_grid.copy_(grid0)
+        tr._maybe_update_grid()                                   # global_step 0: warm-up update over all cells
+        decay = torch.clamp(0.95 ** (1 / m.count_grid), 0.1, 0.95) if erode else torch.full_like(grid0, 0.95)
+        want = torch.where(valid, grid0 * decay, grid0)
+        assert torch.equal(m.density_grid[~valid], grid0[~valid])               # invisible cells stay -1
+        np.testing.assert_allclose(m.density_grid[valid].cpu().numpy(), want[valid].cpu().numpy(), rtol=1e-6)
+        if erode:
+            assert (decay[valid] < 0.95).any() and decay[valid].min() >= 0.1     # cells few cameras see decay faster
+    # and a real step of the native trainer runs on this model (6 cascades, exponential steps, erode on)
+    tr = Trainer(m, erode=True)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    dirs = syn.get_ray_directions(200, 200, syn.intrinsics(200)).cuda()
+    pix = torch.randint(0, 200 * 200, (2048,), device="cuda", generator=g)
+    ro, rd = syn.get_rays(dirs[pix], poses[torch.randint(0, 12, (2048,), device="cuda", generator=g)])
+    gt = torch.rand(2048, 3, device="cuda", generator=g)
+    m.density_grid.copy_(torch.where(valid, torch.full_like(m.density_grid, 1e-3), m.density_grid))
+    for _ in range(2):
+        out = tr.step(ro, rd, gt)
+    met = tr.metrics()
+    assert out["rm_samples"] > 0 and math.isfinite(met["loss"])
+
+
+def test_device_frame_loop_at_scale_16():
+    """The test-time loop on the mip-NeRF360 recipe's geometry (benchmark_mipnerf360.sh:21-24: scale 16 -> 6 cascades,
+    exp_step_factor 1/256; keeps the reference's calc_dt(..., cascades) quirk, raymarching.cu:370,399, where the upper
+    step clamp is sqrt(3)*2*6/128 instead of sqrt(3)*2*16/128): device loop == host loop over the vren kernels, bit for
+    bit, on a sparse and on a full occupancy grid, cameras at radius 1.5..12."""
+    from ngp_pl_amd.rendering import render
+    from ngp_pl_amd.networks import NGP
+    from tests.helpers import make_rays
+    torch.manual_seed(0)
+    m = NGP(16.0).cuda()
+    assert m.cascades == 6
+    ro, rd = make_rays(8000, seed=9)
+    f = np.random.RandomState(9).choice([1.0, 2.0, 3.0, 5.0, 8.0], 8000).astype(np.float32)
+    ro = torch.from_numpy(ro * f[:, None]).cuda().contiguous(); rd = torch.from_numpy(rd).cuda().contiguous()
+    kw = dict(test_time=True, exp_step_factor=1 / 256.)
+    for fill in (0.12, 1.0):
+        bf = np.full(6 * 128 ** 3 // 8, 255, np.uint8) if fill >= 1.0 else syn.random_blob_bitfield(6, 128, fill, seed=10)
+        m.density_bitfield.copy_(torch.from_numpy(bf).cuda())
+        host = render(m, ro, rd, host_loop=True, **kw)
+        exact = render(m, ro, rd, **kw)
+        assert int(exact["total_samples"]) == int(host["total_samples"]) > 0
+        for k in ("rgb", "depth", "opacity"):
+            assert torch.equal(exact[k], host[k]), (k, fill)
+        fast = render(m, ro, rd, chunk_scale=4, probe_cap=64, **kw)
+        for k in ("rgb", "depth", "opacity"):
+            np.testing.assert_allclose(fast[k].cpu().numpy(), host[k].cpu().numpy(), rtol=0, atol=1e-5, err_msg="%s fill %g" % (k, fill))
+    assert float(host["depth"].max()) > 8.0                       # samples far out in the coarse cascades were composited
+
+
+def test_hdr_exposure_branch_matches_the_oracle():
+    """rgb_act='None' (HDR-NeRF, networks.py:79-92,109-130,147-151): rgb_net emits log radiance, three 1->64->1 sigmoid
+    tonemappers map log radiance + log exposure to LDR per channel; `output_radiance` returns exp(log radiance) instead.
+    Forward and parameter gradients against the fp32 oracle restatement with the kernels' f16 rounding points."""
+    from oracle import tcnn_oracle as T
+    from ngp_pl_amd.networks import NGP
+    torch.manual_seed(3)
+    m = NGP(scale=0.5, rgb_act="None").cuda()
+    f = T.Field(scale=0.5, seed=7)
+    g = torch.Generator().manual_seed(8)
+    f.table = ((torch.rand(f.meta.total, 2, generator=g) * 2 - 1) * 0.8).half().float()
+    f.density_w = (f.density_w * 1.5).half().float(); f.rgb_w = (f.rgb_w * 1.5).half().float()
+    tone = [(T.Field(seed=20 + i).density_w[:64 * 16 + 16 * 64].clone() * 2.0).half().float() for i in range(3)]     # 16->64->16 blobs
+    with torch.no_grad():
+        m.xyz_encoder.params.copy_(torch.cat([f.density_w, f.table.reshape(-1)]).cuda())
+        m.rgb_net.params.copy_(f.rgb_w.cuda())
+        for i in range(3):
+            getattr(m, "tonemapper_net_%d" % i).params.copy_(tone[i].cuda())
+    n = 5000
+    x = torch.rand(n, 3, generator=g) - 0.5; d = torch.randn(n, 3, generator=g)
+    exposure = torch.rand(n, 1, generator=g) * 2 + 0.25
+
+    def oracle(tone_w, rgb_w, output_radiance=False):
+        sig, h, _ = f.density(x, quantize=True)
+        sh = T.q16(T.sh4(d / d.norm(dim=1, keepdim=True)))
+        logr = T.q16(T.mlp(torch.cat([sh, h], 1), rgb_w, 32, 2, 3, "None", quantize=True))       # networks.py:146: no output activation
+        if output_radiance:
+            return sig, T.TruncExp.apply(logr)                                                     # networks.py:148-149
+        outs = []
+        for i in range(3):                                                                       # networks.py:121-129
+            xin = torch.zeros(n, 16); xin = xin + torch.nn.functional.pad(logr[:, i:i + 1] + torch.log(exposure), (0, 15))
+            outs.append(T.q16(T.mlp(xin, tone_w[i], 16, 1, 1, "Sigmoid", quantize=True)))
+        return sig, torch.cat(outs, 1)
+    tw = [t.clone().requires_grad_(True) for t in tone]; rw = f.rgb_w.clone().requires_grad_(True)
+    so, co = oracle(tw, rw)
+    gc = torch.randn(n, 3, generator=g) * 1e-2
+    (co * gc).sum().backward()
+    sn, cn = m(x.cuda(), d.cuda(), exposure=exposure.cuda())
+    (cn.float() * gc.cuda()).sum().backward()
+    np.testing.assert_allclose(cn.detach().float().cpu().numpy(), co.detach().numpy(), rtol=0, atol=3e-3)
+    np.testing.assert_allclose(sn.detach().float().cpu().numpy(), so.detach().numpy(), rtol=1e-2, atol=1e-6)
+    for i in range(3):
+        got = getattr(m, "tonemapper_net_%d" % i).params.grad.cpu(); want = tw[i].grad
+        assert ((got - want).abs().max() / want.abs().max()).item() < 2e-2, "tonemapper %d weight grad" % i
+    assert ((m.rgb_net.params.grad.cpu() - rw.grad).abs().max() / rw.grad.abs().max()).item() < 2e-2
+    # output_radiance=True: exp of the log radiance, no tonemapper
+    with torch.no_grad():
+        _, rad = m(x.cuda(), d.cuda(), output_radiance=True)
+    _, want_rad = oracle(tone, f.rgb_w, output_radiance=True)
+    np.testing.assert_allclose(rad.float().cpu().numpy(), want_rad.detach().numpy(), rtol=5e-3, atol=1e-4)

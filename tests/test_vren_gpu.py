@@ -87,15 +87,28 @@ CFGS = [
     dict(cascades=1, scale=0.5, esf=0.0, fill=1.0, n=2048),
     dict(cascades=3, scale=2.0, esf=1 / 256, fill=0.15, n=4096),
     dict(cascades=1, scale=0.5, esf=0.0, fill=0.0, n=512),     # nothing occupied: S = 0
+    # the mip-NeRF360 recipe (benchmarking/benchmark_mipnerf360.sh:21-24: --scale 16 => networks.py:26 gives 6 cascades,
+    # train.py:95-96 exp_step_factor 1/256): rays start at radius 1.5..12 so that samples land in cascades 1..5, dt runs
+    # from sqrt(3)/1024 up to the sqrt(3)*2*16/128 clamp, mip_from_dt takes over from mip_from_pos far out
+    dict(cascades=6, scale=16.0, esf=1 / 256, fill=0.12, n=4096, spread=True),
+    dict(cascades=6, scale=16.0, esf=1 / 256, fill=1.0, n=1024, spread=True),
 ]
+IDS = ["synthetic", "dense", "cascaded", "empty", "garden", "garden_dense"]
 
 
-@pytest.mark.parametrize("cfg", CFGS, ids=["synthetic", "dense", "cascaded", "empty"])
+def scaled_origins(ro, cfg, seed=0):
+    """Spread the camera radii over the cascades of a large scene (per-ray factor 1..8 on the 1.5-radius hemisphere)."""
+    if cfg.get("spread"):
+        f = np.random.RandomState(seed).choice([1.0, 2.0, 3.0, 5.0, 8.0], ro.shape[0]).astype(np.float32)
+        return (ro * f[:, None]).astype(np.float32)
+    return ro * 1.5 if cfg["scale"] > 0.5 else ro
+
+
+@pytest.mark.parametrize("cfg", CFGS, ids=IDS)
 def test_raymarching_train(vren, oracle, cfg):
     n = cfg["n"]
     ro, rd = make_rays(n, seed=3)
-    if cfg["scale"] > 0.5:
-        ro = ro * 1.5
+    ro = scaled_origins(ro, cfg, seed=3)
     if cfg["fill"] >= 1.0:
         bf = np.full(cfg["cascades"] * 128 ** 3 // 8, 255, np.uint8)
     elif cfg["fill"] == 0.0:
@@ -111,14 +124,17 @@ def test_raymarching_train(vren, oracle, cfg):
         same_bits(t, a, "train " + name)
     if cfg["fill"] >= 1.0:
         assert want[0][:, 2].max() > 400      # long rays exercised (cube crossing ~591 steps)
+    if cfg["cascades"] == 6:
+        # every cascade is visited and the step size spans its whole clamp range (raymarching.cu:11-13)
+        m = np.abs(want[1]).max(1)
+        assert (m < 0.5).any() and (m > 8.0).any() and want[3].min() < 2e-3 and want[3].max() > 0.4
 
 
-@pytest.mark.parametrize("cfg", CFGS[:3], ids=["synthetic", "dense", "cascaded"])
+@pytest.mark.parametrize("cfg", CFGS[:3] + CFGS[4:], ids=IDS[:3] + IDS[4:])
 def test_raymarching_test(vren, oracle, cfg):
     n = 4096
     ro, rd = make_rays(n, seed=7)
-    if cfg["scale"] > 0.5:
-        ro = ro * 1.5
+    ro = scaled_origins(ro, cfg, seed=7)
     bf = (np.full(cfg["cascades"] * 128 ** 3 // 8, 255, np.uint8) if cfg["fill"] >= 1.0
           else syn.random_blob_bitfield(cfg["cascades"], 128, cfg["fill"], seed=8))
     ht = aabb_hits(oracle, ro, rd, cfg["scale"])
@@ -218,4 +234,4 @@ def test_wave_per_ray_march_is_bit_identical_too():
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_vren_gpu.py::test_raymarching_train", "tests/test_golden.py",
                         "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"], cwd=root, env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=600)
-    assert r.returncode == 0 and "6 passed" in r.stdout, r.stdout[-2000:]
+    assert r.returncode == 0 and "9 passed" in r.stdout, r.stdout[-2000:]

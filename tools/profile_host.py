@@ -2,7 +2,8 @@
 import cProfile, os, pstats, sys, io
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ngp_pl_amd.bench_support import GpuDataset, all_reduce_native, all_reduce_native_mlp
+from ngp_pl_amd.bench_support import GpuDataset
+from ngp_pl_amd.ddp import GradientExchange
 from ngp_pl_amd.networks import NGP
 from ngp_pl_amd.trainer import Trainer
 dev = torch.device("cuda", 0)
@@ -15,8 +16,7 @@ torch.manual_seed(0)
 model = NGP(0.5).to(dev); model.register_training_buffers()
 tr = Trainer(model)
 if dist is not None:
-    tr.grad_hook = lambda: all_reduce_native(model, dist, 1)
-    tr.mlp_grad_hook = lambda: all_reduce_native_mlp(model, dist)
+    GradientExchange(model, dist, 1).install(tr)
 data = GpuDataset(800, 20, dev)
 cur = data.sample_native(8192, 0)
 for i in range(330):
