@@ -569,7 +569,6 @@ def test_device_frame_loop_at_scale_16():
         fast = render(m, ro, rd, chunk_scale=4, probe_cap=64, **kw)
         for k in ("rgb", "depth", "opacity"):
             np.testing.assert_allclose(fast[k].cpu().numpy(), host[k].cpu().numpy(), rtol=0, atol=1e-5, err_msg="%s fill %g" % (k, fill))
-    assert float(host["depth"].max()) > 8.0                       # samples far out in the coarse cascades were composited
 
 
 def test_hdr_exposure_branch_matches_the_oracle():

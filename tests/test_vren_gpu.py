@@ -125,9 +125,10 @@ def test_raymarching_train(vren, oracle, cfg):
     if cfg["fill"] >= 1.0:
         assert want[0][:, 2].max() > 400      # long rays exercised (cube crossing ~591 steps)
     if cfg["cascades"] == 6:
-        # every cascade is visited and the step size spans its whole clamp range (raymarching.cu:11-13)
+        # every cascade is visited; the step grows from the sqrt(3)/1024 floor with t/256 (the sqrt(3)*2*16/128 = 0.43 ceiling
+        # of raymarching.cu:11-13 is out of reach inside a scale-16 box: t <= 2*16*sqrt(3) gives dt <= 0.22)
         m = np.abs(want[1]).max(1)
-        assert (m < 0.5).any() and (m > 8.0).any() and want[3].min() < 2e-3 and want[3].max() > 0.4
+        assert (m < 0.5).any() and (m > 8.0).any() and want[3].min() < 2e-3 and want[3].max() > 0.03
 
 
 @pytest.mark.parametrize("cfg", CFGS[:3] + CFGS[4:], ids=IDS[:3] + IDS[4:])
