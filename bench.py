@@ -22,7 +22,7 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JS
                 stages run on the active samples only, read back per step) / its HIP-event time on the stream it
                 runs on, measured over ROOFLINE_STEPS steps right behind the timed windows; `traffic` = HBM bytes
                 from the PMC profile recorded at the same operating point (profiles/*_pmc_traffic.json, made by
-                tools/pmc_traffic.sh), or null when the operating points differ by more than 5 %.
+                tools/profile_bench.sh + tools/pmc_traffic.py), or null when the operating points differ by more than 5 %.
   * cpu_baseline = the CPU oracle (reference kernels compiled for the host when available, our restatement
                 otherwise) timed on rank 0 on a bounded sample of the same workload.
 Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL).  `--gpus N` with no RANK in the
@@ -71,6 +71,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-render", action="store_true")
     p.add_argument("--no-secondary", action="store_true", help="skip the short unbounded / 16k-ray secondary lines")
+    p.add_argument("--no-api", action="store_true", help="skip the api_path leg")
     p.add_argument("--timed-only", action="store_true", help="stop after the timed windows (for rocprofv3 runs: the trace then ends with the timed steps)")
     p.add_argument("--dry-run", action="store_true", help="launcher + process group only (gloo, no GPU work)")
     return p.parse_args()
@@ -404,7 +405,8 @@ def main():
             fast["field_state"] = ref["field_state"] = state
             out["render_fps_800x800"] = fast
             out["render_fps_800x800_reference_chunking"] = ref
-        out["api_path"] = api_path_rate(loop)
+        if not args.no_api:
+            out["api_path"] = api_path_rate(loop)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(loop.model, loop.data)
         if not args.no_secondary and world == 1 and args.workload == "lego":

@@ -990,10 +990,11 @@ int ngp_raymarching_train_count(const float* rays_o, const float* rays_d, const 
         NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d); NGP_CHECK_PTR(hits_t); NGP_CHECK_PTR(density_bitfield);
         NGP_CHECK_PTR(noise); NGP_CHECK_PTR(rays_a); NGP_CHECK_PTR(t_scratch);
         const MarchParams p = make_march_params(density_bitfield, cascades, grid_size, scale, scale, exp_step_factor, max_samples);
-        // NGP_MARCH_WAVE=1 selects the wave-per-ray kernel (bit-identical, 101 us instead of 280 us per 8192-ray batch in the
-        // training step, profiles/r01_v20_wave_march_kernel_trace.txt); the serial-chain kernel stays the default until the
-        // placement of the march inside the step is retuned for it
-        static const bool wave_per_ray = [] { const char* e = getenv("NGP_MARCH_WAVE"); return e ? atoi(e) != 0 : false; }();
+        // Pass 1 runs one WAVE per ray (march_train_count_wave_kernel: 64 candidates of the ray's fixed t-sequence probed per pass,
+        // bit-identical to the serial loop, 101 us instead of 280-330 us per 8192-ray batch: profiles/r01_v20_wave_march_kernel_trace.txt,
+        // gpurun sweep of round 2: the step time is the same for every placement, the marching stream is busy a third as long).
+        // NGP_MARCH_WAVE=0 selects the serial-chain kernel (16 rays per wave) for A/B runs.
+        static const bool wave_per_ray = [] { const char* e = getenv("NGP_MARCH_WAVE"); return e ? atoi(e) != 0 : true; }();
         if (wave_per_ray) {
             const dim3 grid(ngp_div_up((long long)n_rays * 64, 256));
             if (p.simple)

@@ -68,7 +68,7 @@ class _FusedField(torch.autograd.Function):
             p_rgb = partials[n_part * enc.n_mlp:]
             if model.native_grads:
                 # hand the native buffers to ngp_pl_amd.optim.FusedAdam (no f32 materialisation)
-                model._native = dict(grid16=g16, density_partials=p_density, rgb_partials=p_rgb, n_partials=n_part, scale=scale)
+                model.hand_over_native(dict(grid16=g16, density_partials=p_density, rgb_partials=p_rgb, n_partials=n_part, scale=scale))
                 return None, None, None, None, None
             g_enc = torch.empty_like(enc.params)
             g_enc[:enc.n_mlp] = tcnn.reduce_partials(p_density, n_part, enc.n_mlp) / scale
@@ -122,6 +122,16 @@ class NGP(nn.Module):
         self._g16 = None
 
     # -- helpers -------------------------------------------------------------------------------
+    def hand_over_native(self, record):
+        """A backward of the fused field leaves its gradients in native buffers for optim.FusedAdam (native_grads=True).
+        The record holds ONE backward: a second one before the optimizer consumed the first (gradient accumulation, two
+        render() calls per step) would silently replace it -- refuse instead."""
+        if self._native is not None:
+            raise RuntimeError("the native gradient record of the previous backward has not been consumed by FusedAdam.step(): "
+                               "gradient accumulation over several backward passes needs model.native_grads = False "
+                               "(f32 .grad tensors, any torch optimizer)")
+        self._native = record
+
     def _grid_grad16(self, dev):
         if self._g16 is None or self._g16.device != dev:
             self._g16 = torch.empty(self.xyz_encoder.n_grid, dtype=torch.float16, device=dev)

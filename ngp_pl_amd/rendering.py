@@ -171,10 +171,145 @@ def _render_test_device(model, rays_o, rays_d, hits_t, **kwargs):
     return {"opacity": opacity, "depth": depth, "rgb": rgb, "total_samples": total[0], "n_iterations": n_it.value}
 
 
+class _FusedTrainRender(torch.autograd.Function):
+    """`__render_rays_train` (rendering.py:121-163) as ONE autograd node when the model is in its fused configuration:
+    march -> hash grid -> MLPs -> composite -> background blend in the forward; in the backward the composite gradient,
+    then the field backward and the table backward on the ACTIVE samples only (those up to each ray's early stop; the rest
+    have exactly zero gradient) -- the same kernels in the same order as the native step (trainer.Trainer.step), so that
+    the reference-shaped surface render() + NeRFLoss + autograd + FusedAdam runs what `Trainer.step` runs.  Results and
+    gradients equal the node-by-node path (RayMarcher -> NGP.forward -> VolumeRenderer) up to the summation order of
+    the table gradient (tests/test_train_gpu.py::test_fused_render_node_matches_the_operator_chain)."""
+
+    @staticmethod
+    def forward(ctx, enc_params, rgb_params, model, rays_o, rays_d, hits_t, esf, T_threshold, bg):
+        from . import tcnn
+        n, dev = rays_o.shape[0], rays_o.device
+        enc, net = model.xyz_encoder, model.rgb_net
+        f32 = dict(dtype=torch.float32, device=dev); f16 = dict(dtype=torch.float16, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            sq = stream()
+            noise = torch.rand(n, **f32)                              # custom_functions.py:83
+            rays_a = torch.empty(n, 3, dtype=torch.int64, device=dev)
+            scratch = torch.empty(max(n, 1) * MAX_SAMPLES, **f32)
+            counter = _pinned_counter()
+            counter.np[0] = -1
+            call("ngp_raymarching_train_count", ptr(rays_o), ptr(rays_d), ptr(hits_t), ptr(model.density_bitfield), model.cascades,
+                 float(model.scale), float(esf), ptr(noise), model.grid_size, MAX_SAMPLES, n, ptr(rays_a), counter.ptr, ptr(scratch), sq)
+            eh, rh = enc._half.get(enc_params), net._half.get(rgb_params)      # the casts overlap the march on the device
+            done = torch.cuda.Event(); done.record()
+            while not done.query():                                   # the reference syncs here too (raymarching.cu:298: counter.item())
+                pass
+            S = int(counter.np[0])
+            xyzs = torch.empty(S, 3, **f32); dirs = torch.empty(S, 3, **f32); deltas = torch.empty(S, **f32); ts = torch.empty(S, **f32)
+            call("ngp_raymarching_train_write", ptr(rays_o), ptr(rays_d), ptr(rays_a), ptr(scratch), float(model.scale), float(esf),
+                 model.grid_size, MAX_SAMPLES, n, ptr(xyzs), ptr(dirs), ptr(deltas), ptr(ts), sq)
+            feats = torch.empty(16, S, 2, **f16); h = torch.empty(S, 16, **f16)
+            sigmas = torch.empty(S, **f32); rgbs = torch.empty(S, 3, **f32)
+            if S > 0:
+                call("ngp_hashgrid_fwd", ptr(xyzs), ptr(model.xyz_min), ptr(model.xyz_max), ptr(eh[enc.n_mlp:]), C.byref(enc.meta), S, ptr(feats), sq)
+                call("ngp_field_fwd", ptr(feats), ptr(dirs), ptr(eh), ptr(rh), S, ptr(sigmas), ptr(rgbs), ptr(h), sq)
+            total = torch.empty(n, dtype=torch.int64, device=dev)
+            opacity = torch.empty(n, **f32); depth = torch.empty(n, **f32); rgb = torch.empty(n, 3, **f32); ws = torch.empty(S, **f32)
+            ray_offs = torch.empty(n, **i32); n_active = torch.empty(1, **i32)
+            call("ngp_composite_train_fw", ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(ts), ptr(rays_a), float(T_threshold), n, S,
+                 ptr(total), ptr(opacity), ptr(depth), ptr(rgb), ptr(ws), ptr(ray_offs), sq)
+            call("ngp_active_scan", ptr(ray_offs), n, ptr(n_active), sq)
+        rgb_out = torch.addcmul(rgb, bg.view(1, 3), (1 - opacity).unsqueeze(1))      # rendering.py:161
+        ctx.model, ctx.S, ctx.T_threshold = model, S, T_threshold
+        ctx.save_for_backward(rays_a, xyzs, dirs, deltas, ts, feats, h, sigmas, rgbs, ws, opacity, depth, rgb, ray_offs, n_active, bg)
+        ctx.mark_non_differentiable(rays_a, deltas, ts)
+        vr_samples = total.sum()
+        rm_samples = torch.tensor(S, dtype=torch.int32)
+        ctx.mark_non_differentiable(vr_samples, rm_samples)
+        return vr_samples, opacity, depth, rgb_out, ws, rays_a, deltas, ts, rm_samples
+
+    @staticmethod
+    def backward(ctx, _g_vr, g_opacity, g_depth, g_rgb, g_ws, _g_rays_a, _g_deltas, _g_ts, _g_rm):
+        from . import tcnn
+        model, S = ctx.model, ctx.S
+        rays_a, xyzs, dirs, deltas, ts, feats, h, sigmas, rgbs, ws, opacity, depth, rgb, ray_offs, n_active, bg = ctx.saved_tensors
+        enc, net = model.xyz_encoder, model.rgb_net
+        n, dev = rays_a.shape[0], rays_a.device
+        none5 = (None,) * 7
+        if S == 0:
+            if model.native_grads:
+                return (None, None) + none5
+            return (torch.zeros_like(enc.params), torch.zeros_like(net.params)) + none5
+        f32 = dict(dtype=torch.float32, device=dev); f16 = dict(dtype=torch.float16, device=dev)
+        g_rgb = torch.zeros(n, 3, **f32) if g_rgb is None else g_rgb.float().contiguous()
+        g_opacity = torch.zeros(n, **f32) if g_opacity is None else g_opacity.float()
+        g_opacity = (g_opacity - (g_rgb * bg.view(1, 3)).sum(1)).contiguous()         # through rgb + bg (1 - opacity)
+        g_depth = torch.zeros(n, **f32) if g_depth is None else g_depth.float().contiguous()
+        g_ws = None if g_ws is None else g_ws.float().contiguous()
+        scale = tcnn.LOSS_SCALE
+        lib = _lib.lib()
+        with torch.cuda.device(dev):
+            sq = stream()
+            eh, rh = enc._half.get(enc.params), net._half.get(net.params)
+            nbytes = lib.ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(enc.meta), S) if tcnn.binned_enabled() else 0
+            dL_dsigmas = torch.empty(S, **f32); dL_drgbs = torch.empty(S, 3, **f32)
+            active = torch.empty(S, dtype=torch.int32, device=dev)
+            x_act = torch.empty(S, 3, **f32) if nbytes else None
+            call("ngp_composite_train_bw", ptr(g_opacity), ptr(g_depth), ptr(g_rgb), ptr(g_ws), ptr(sigmas), ptr(rgbs), ptr(ws), ptr(deltas),
+                 ptr(ts), ptr(rays_a), ptr(opacity), ptr(depth), ptr(rgb), float(ctx.T_threshold), n, S, ptr(dL_dsigmas), ptr(dL_drgbs),
+                 ptr(ray_offs), ptr(active), ptr(xyzs) if nbytes else None, ptr(x_act), sq)
+            n_part = call("ngp_field_bwd_partials", S)
+            partials = torch.empty(n_part * (enc.n_mlp + net.params.numel()), **f32)
+            dh = torch.empty(S, 16, **f16); dfeats = torch.empty(16, S, 2, **f16)
+            call("ngp_field_bwd", ptr(feats), ptr(dirs), ptr(h), ptr(eh), ptr(rh), ptr(dL_dsigmas), ptr(dL_drgbs), scale, S,
+                 ptr(active), ptr(n_active), ptr(dh), ptr(dfeats), ptr(partials), sq)
+            g16 = model._grid_grad16(dev)
+            if nbytes:
+                bin_ws = tcnn.binned_workspace(dev, nbytes)
+                call("ngp_hashgrid_bwd_binned", ptr(x_act), ptr(model.xyz_min), ptr(model.xyz_max), ptr(dfeats), C.byref(enc.meta), S,
+                     None, ptr(n_active), ptr(bin_ws), bin_ws.numel(), ptr(g16), sq)
+            else:
+                call("ngp_hashgrid_bwd_sliced", ptr(xyzs), ptr(model.xyz_min), ptr(model.xyz_max), ptr(dfeats), C.byref(enc.meta), S,
+                     ptr(active), ptr(n_active), ptr(g16), sq)
+            p_density = partials[:n_part * enc.n_mlp]; p_rgb = partials[n_part * enc.n_mlp:]
+            if model.native_grads:
+                model.hand_over_native(dict(grid16=g16, density_partials=p_density, rgb_partials=p_rgb, n_partials=n_part, scale=scale))
+                return (None, None) + none5
+            g_enc = torch.empty_like(enc.params)
+            g_enc[:enc.n_mlp] = tcnn.reduce_partials(p_density, n_part, enc.n_mlp) / scale
+            call("ngp_cast_f16_to_f32", ptr(g16), enc.n_grid, 1.0 / scale, ptr(g_enc[enc.n_mlp:]), sq)
+            g_rgbw = tcnn.reduce_partials(p_rgb, n_part, net.params.numel()) / scale
+        return (g_enc, g_rgbw) + none5
+
+
+class _PinnedCounter:
+    def __init__(self):
+        self.t = torch.zeros(2, dtype=torch.int32).pin_memory()
+        self.np = self.t.numpy()
+        self.ptr = self.t.data_ptr()
+
+
+_COUNTER = None
+
+
+def _pinned_counter():
+    """{S, R} of the march lands in pinned (device-mapped) host memory: no copy kernel between the march and the host read."""
+    global _COUNTER
+    if _COUNTER is None:
+        _COUNTER = _PinnedCounter()
+    return _COUNTER
+
+
 def _render_train(model, rays_o, rays_d, hits_t, **kwargs):
     """march -> field -> composite (rendering.py:121-163)."""
     esf = kwargs.get("exp_step_factor", 0.)
     results = {}
+    fused = getattr(model, "fused", False) and getattr(model, "fused_render", True) and model.rgb_act == "Sigmoid" and rays_o.is_cuda and \
+        not (torch.is_grad_enabled() and (rays_o.requires_grad or rays_d.requires_grad)) and \
+        not any(isinstance(v, torch.Tensor) for v in kwargs.values())
+    if fused:
+        bg = _background(esf, rays_o.device, kwargs.get("random_bg", False))
+        (results["vr_samples"], results["opacity"], results["depth"], results["rgb"], results["ws"], results["rays_a"],
+         results["deltas"], results["ts"], results["rm_samples"]) = _FusedTrainRender.apply(
+            model.xyz_encoder.params, model.rgb_net.params, model, rays_o.float(), rays_d.float(), hits_t[:, 0].contiguous(), esf,
+            kwargs.get("T_threshold", 1e-4), bg)
+        return results
     rays_a, xyzs, dirs, results["deltas"], results["ts"], results["rm_samples"] = RayMarcher.apply(
         rays_o, rays_d, hits_t[:, 0], model.density_bitfield, model.cascades, model.scale, esf,
         model.grid_size, MAX_SAMPLES)

