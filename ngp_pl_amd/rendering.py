@@ -218,10 +218,9 @@ class _FusedTrainRender(torch.autograd.Function):
         rgb_out = torch.addcmul(rgb, bg.view(1, 3), (1 - opacity).unsqueeze(1))      # rendering.py:161
         ctx.model, ctx.S, ctx.T_threshold = model, S, T_threshold
         ctx.save_for_backward(rays_a, xyzs, dirs, deltas, ts, feats, h, sigmas, rgbs, ws, opacity, depth, rgb, ray_offs, n_active, bg)
-        ctx.mark_non_differentiable(rays_a, deltas, ts)
         vr_samples = total.sum()
         rm_samples = torch.tensor(S, dtype=torch.int32)
-        ctx.mark_non_differentiable(vr_samples, rm_samples)
+        ctx.mark_non_differentiable(rays_a, deltas, ts, vr_samples, rm_samples)
         return vr_samples, opacity, depth, rgb_out, ws, rays_a, deltas, ts, rm_samples
 
     @staticmethod
