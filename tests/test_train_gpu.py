@@ -635,7 +635,7 @@ def test_fused_render_node_matches_the_operator_chain(lambda_distortion):
     m = make_model(seed=21)
     tr = Trainer(m)
     bs = [batch(4096, seed=500 + i) for i in range(4)]
-    for it in range(80):                                    # a partly trained field: early stops, real occupancy
+    for it in range(300):                                   # a trained field: early stops, real occupancy
         tr.step(*bs[it % 4])
     m.native_grads = False                                  # f32 .grad tensors for the comparison
     ro, rd, gt = batch(4096, seed=77)
@@ -665,7 +665,7 @@ def test_fused_render_node_matches_the_operator_chain(lambda_distortion):
     m._native = None
     res = render(m, ro, rd)
     ((res["rgb"] - gt) ** 2).mean().backward()
-    assert m._native is not None and m.xyz_encoder.params.grad is gea or True
+    assert m._native is not None
     res = render(m, ro, rd)
     with pytest.raises(RuntimeError, match="has not been consumed"):
         ((res["rgb"] - gt) ** 2).mean().backward()
