@@ -29,15 +29,30 @@ using namespace ngp_grid;
 
 namespace {
 
-constexpr uint32_t SLICE2 = 6912;            // entries per task: 2 x int64 each -> 108 KiB of LDS
-constexpr int MAX_SLICES = 80;               // ceil(2^19 / SLICE2) = 76
+#ifndef NGP_SLICE2
+#define NGP_SLICE2 6912
+#endif
+#ifndef NGP_APPLY_WGS
+#define NGP_APPLY_WGS 256
+#endif
+constexpr uint32_t SLICE2 = NGP_SLICE2;      // entries per task: 2 x int64 each -> 108 KiB of LDS at 6912
+constexpr int MAX_SLICES = ((1 << 19) + SLICE2 - 1) / SLICE2 + 4;   // 2^19 / SLICE2 slices per hashed level (76 at 6912)
 constexpr float FIX_SCALE = 16777216.0f;     // 2^24 units per 1.0 (f16 subnormal spacing is 2^-24)
 constexpr int BIN_THREADS = 512;             // binning workgroup: 4 of them are resident per CU (the pass is latency-bound)
 constexpr int BIN_SPT = 2;                   // samples per thread
 constexpr int CHUNK = BIN_THREADS * BIN_SPT; // samples per binning workgroup ("chunk")
 constexpr int CHUNK_SLOTS = CHUNK * 8;       // list entries a chunk can produce for one level (<= 8 slices per sample)
 constexpr int MAX_CHUNKS = 1024;             // the slice owners scan the chunk directory in one pass
-constexpr int APPLY_THREADS = 1024;
+#ifndef NGP_APPLY_THREADS
+#define NGP_APPLY_THREADS 1024
+#endif
+#ifndef NGP_APPLY_WAVES_PER_EU
+#define NGP_APPLY_WAVES_PER_EU 1
+#endif
+#ifndef NGP_APPLY_B
+#define NGP_APPLY_B 11
+#endif
+constexpr int APPLY_THREADS = NGP_APPLY_THREADS;
 
 struct BinPlan {
     int32_t n_levels;
@@ -293,7 +308,7 @@ __device__ __forceinline__ void apply_segments_dense(long long* lds, uint32_t lo
     }
 }
 
-__global__ void __launch_bounds__(APPLY_THREADS)
+__global__ void __launch_bounds__(APPLY_THREADS, NGP_APPLY_WAVES_PER_EU)
 apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const float* __restrict__ xyz_max,
              const half2_t* __restrict__ dfeats, GridMeta meta, BinPlan plan, BinWs ws, int n_samples,
              const int32_t* __restrict__ active, half2_t* __restrict__ grad_table) {
@@ -332,7 +347,7 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
 #endif
         const half2_t* __restrict__ g_level = dfeats + (size_t)level * n_samples;
         const int32_t* __restrict__ pool_level = ws.pool + (size_t)level * n_chunks * CHUNK_SLOTS;
-        if (level_is_hashed(res, size)) apply_segments_hashed<11>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
+        if (level_is_hashed(res, size)) apply_segments_hashed<NGP_APPLY_B>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
         else apply_segments_dense<4>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
         __syncthreads();
 #ifdef NGP_BIN_TIMING
@@ -470,7 +485,7 @@ int ngp_hashgrid_bwd_binned(const float* x, const float* xyz_min, const float* x
         if (e != hipSuccess) return (int)e;
         attr_set[dev] = true;
     }
-    const int n_wg = P.n_tasks < 256 ? P.n_tasks : 256;
+    const int n_wg = P.n_tasks < NGP_APPLY_WGS ? P.n_tasks : NGP_APPLY_WGS;
     apply_kernel<<<dim3(n_wg), dim3(APPLY_THREADS), smem, st>>>(
         x, xyz_min, xyz_max, (const half2_t*)dfeats, dm, P, ws, n_samples, active_idx, (half2_t*)grad_table);
     if (L.merge_entries > 0)

@@ -321,6 +321,46 @@ march_train_count_kernel(const float* __restrict__ rays_o, const float* __restri
     rays_a[3 * (size_t)r + 2] = n;
 }
 
+
+// T[j] = fl(T[j-1] + dt), j = 1..64, for a CONSTANT step (the Synthetic-NeRF setting), in closed form instead of a chain of
+// 64 dependent adds: inside one binade [2^e, 2^(e+1)) every element is a multiple of u = 2^(e-23) and dt / u = q + r with a
+// fraction r that is the same for every element, so round-to-nearest adds the SAME integer number of ulps each step:
+// delta = q + (r > 1/2).  Lane i of a binade segment starting at mantissa m0 therefore holds m0 + i * delta exactly as long as
+// that stays below 2^24; the element that crosses into the next binade is formed by a real float add from its predecessor
+// (its rounding follows the new binade's ulp) and starts the next segment.  Returns false where the closed form does not
+// hold bit for bit (r == 1/2: ties round to even and the increment depends on the mantissa's parity; t below dt; zero /
+// subnormal t): the caller then runs the chain.  Wave-uniform t_start, dt; lane j receives T[j], every lane T[64] in t_end.
+__device__ __forceinline__ bool lattice_tile_const_dt(float t_start, float dt, int lane, float& mine, float& t_end) {
+    const uint32_t db = __float_as_uint(dt);
+    const int ed = (int)((db >> 23) & 0xffu) - 127;
+    const uint32_t md = (db & 0x7fffffu) | 0x800000u;
+    if (((db >> 23) & 0xffu) == 0u) return false;
+    uint32_t seg_bits = __builtin_amdgcn_readfirstlane(__float_as_uint(t_start));
+    int seg_j = 0;
+    mine = t_start;
+    while (seg_j < 64) {
+        const int be = (int)((seg_bits >> 23) & 0xffu);
+        const int s = (be - 127) - ed;
+        if (be == 0 || be == 255 || (seg_bits >> 31) != 0u || s < 1 || s > 23) return false;
+        const uint32_t rem = md & ((1u << s) - 1u), half = 1u << (s - 1);
+        if (rem == half) return false;
+        const uint32_t delta = (md >> s) + (rem > half ? 1u : 0u);
+        const uint32_t m0 = (seg_bits & 0x7fffffu) | 0x800000u;
+        const uint32_t mj = m0 + (uint32_t)(lane - seg_j) * delta;           // < 2^24 + 63 * 2^23: no wrap
+        const bool in = lane >= seg_j && mj < 0x1000000u;
+        if (in) mine = __uint_as_float(((uint32_t)be << 23) | (mj & 0x7fffffu));
+        const int n_in = (int)__popcll(__ballot(in));                           // >= 1: the segment's first element is in its own binade
+        const int jc = seg_j + n_in;
+        // the element behind the segment: a real add from the segment's last element (T[64] when the tile is complete)
+        const float last = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(mine), jc - 1));
+        const float nxt = last + dt;
+        if (jc >= 64) { t_end = nxt; return true; }
+        seg_bits = __builtin_amdgcn_readfirstlane(__float_as_uint(nxt));
+        seg_j = jc;
+    }
+    return true;
+}
+
 // The same pass with ONE WAVE PER RAY, bit-identical to the serial loop above.  The loop visits a subsequence of one
 // fixed sequence per ray, T[0] = t1, T[j+1] = T[j] + calc_dt(T[j]): an occupied cell advances by one element, an empty
 // cell by k >= 1 elements (the do-while of the skip).  Per tile of 64 elements the wave
@@ -354,14 +394,18 @@ march_train_count_wave_kernel(const float* __restrict__ rays_o, const float* __r
     float pending = -1.0f;                              // landing value of a skip that left the previous tile (< 0: none)
     bool done = !(t1 >= 0);
     while (!done) {
-        // 1. the tile's elements
-        float tt = t_start, mine = t_start;
+        // 1. the tile's elements: closed form for the constant step (lattice_tile_const_dt), else the chain of 64 adds
+        float mine = t_start, t_end = t_start;
+        if (!(SIMPLE && lattice_tile_const_dt(t_start, p.dt_lo, lane, mine, t_end))) {
+            float tt = t_start;
+            mine = t_start;
 #pragma unroll 8
-        for (int j = 0; j < 64; ++j) {
-            mine = (lane == j) ? tt : mine;
-            tt += SIMPLE ? p.dt_lo : calc_dt(tt, p);
+            for (int j = 0; j < 64; ++j) {
+                mine = (lane == j) ? tt : mine;
+                tt += SIMPLE ? p.dt_lo : calc_dt(tt, p);
+            }
+            t_end = tt;                                 // T[64]: first element of the next tile
         }
-        const float t_end = tt;                         // T[64]: first element of the next tile
         const int nvalid = __popcll(__ballot(0 <= mine && mine < t2));        // the sequence increases: valid lanes are a prefix
         const int entry = pending >= 0 ? __popcll(__ballot(mine < pending)) : 0;
         if (entry >= 64) {                              // the carried skip jumps over the whole tile

@@ -96,6 +96,46 @@ def march_ray(o, d, t1, t2, noise, bf, cascades, G, scale, esf, max_samples, nai
         start, pending = T[TILE], carry
 
 
+
+def tile_closed_form(t_start, dt):
+    """numpy restatement of lattice_tile_const_dt (csrc/march.hip): the 64 elements T[j] = fl(T[j-1] + dt) of a tile of the
+    constant-step lattice and T[64], WITHOUT the chain of adds -- inside a binade every step adds the same integer number of
+    ulps.  Returns None where the kernel falls back to the chain (ties, t below dt, zero/subnormal t)."""
+    f32 = np.float32
+    db = int(np.array(dt, f32).view(np.uint32)); ed = ((db >> 23) & 0xff) - 127; md = (db & 0x7fffff) | 0x800000
+    if ((db >> 23) & 0xff) == 0:
+        return None
+    seg_bits = int(np.array(t_start, f32).view(np.uint32)); seg_j = 0
+    mine = np.full(64, t_start, f32)
+    lane = np.arange(64)
+    while seg_j < 64:
+        be = (seg_bits >> 23) & 0xff; s = (be - 127) - ed
+        if be == 0 or be == 255 or (seg_bits >> 31) or s < 1 or s > 23:
+            return None
+        rem = md & ((1 << s) - 1); half = 1 << (s - 1)
+        if rem == half:
+            return None
+        delta = (md >> s) + (1 if rem > half else 0)
+        m0 = (seg_bits & 0x7fffff) | 0x800000
+        mj = m0 + (lane - seg_j) * delta
+        inn = (lane >= seg_j) & (mj < 0x1000000)
+        vals = (((be << 23) | (mj & 0x7fffff)).astype(np.uint32)).view(f32)
+        mine = np.where(inn, vals, mine)
+        jc = seg_j + int(inn.sum())
+        nxt = f32(mine[jc - 1] + f32(dt))
+        if jc >= 64:
+            return mine, nxt
+        seg_bits = int(np.array(nxt, f32).view(np.uint32)); seg_j = jc
+
+
+def tile_chain(t_start, dt):
+    f32 = np.float32
+    out = np.empty(65, f32); t = f32(t_start)
+    for j in range(65):
+        out[j] = t; t = f32(t + f32(dt))
+    return out[:64], out[64]
+
+
 def main(n_rays=1500):
     o = Oracle(fma=False)
     for cascades, scale, esf, fill in ((1, 0.5, 0.0, 0.1), (3, 2.0, 1 / 256, 0.2)):
