@@ -367,8 +367,10 @@ __device__ __forceinline__ bool lattice_tile_const_dt(float t_start, float dt, i
 //   1. generates the 64 elements (a chain of adds, no memory) -- lane j keeps T[j];
 //   2. probes all 64 candidates in parallel (march_probe, the serial kernel's own arithmetic): occupancy bit and, for
 //      empty cells, the skip length k, i.e. the successor index j + k;
-//   3. follows the orbit of the tile's entry index under `successor` with wave-uniform scalar code: runs of occupied
-//      lanes are taken at once from the ballot mask, each visited empty lane costs one cross-lane read.  Candidates the
+//   3. follows the orbit of the tile's entry index under `successor`: chains of consecutive skips are closed on the vector
+//      unit by pointer doubling (lane -> landing lane of the whole chain), then wave-uniform scalar code walks the orbit --
+//      runs of occupied lanes are taken at once from the ballot mask, a chain of skips costs one cross-lane read (the
+//      scalar unit is shared by the CU's four SIMDs: one read per skipped cell made the kernel SALU-bound).  Candidates the
 //      serial loop jumps over are never emitted, whatever their own bit says (next to a voxel face the computed skip
 //      target can reach a rounding error into the neighbour cell);
 //   4. writes the visited occupied candidates' t to the ray's scratch row (coalesced, ranked by popcount).
@@ -418,30 +420,48 @@ march_train_count_wave_kernel(const float* __restrict__ rays_o, const float* __r
         int k = 1;
         const bool occ = march_probe<SIMPLE>(ray, p, mine, x, y, z, dt, t_next, &k);
         const unsigned long long occ_mask = __ballot(occ);
-        const int succ = lane + k;
-        // 3. the orbit of `entry` (wave-uniform)
+        const unsigned long long empty_mask = ~occ_mask;
+        // 3a. empty lanes: where does the chain of skips that starts here end?  Pointer doubling on the vector unit over
+        //     packed (last empty lane of the chain << 8 | landing lane): after r rounds a lane knows the end of a chain of 2^r
+        //     skips, so 6 rounds close every chain of a 64-lane tile (a skip advances by >= 1); rounds stop as soon as no lane's
+        //     landing lane is empty any more (typically after 3-4).  The landing lane is occupied, or >= 64 (the chain leaves the tile).
+        int chain = occ ? ((lane << 8) | 64) : ((lane << 8) | (lane + k > 64 ? 64 : lane + k));
+#pragma unroll 1
+        for (int round = 0; round < 6; ++round) {
+            const int h = chain & 0xff;
+            const bool go = h < 64 && ((empty_mask >> h) & 1ull);
+            const int via = __builtin_amdgcn_ds_bpermute((h & 63) << 2, chain);       // the chain that starts at the landing lane
+            if (go) chain = via;
+            if (!__ballot(go)) break;
+        }
+        // 3b. the orbit of `entry` (wave-uniform, on the scalar unit): occupied runs come from the ballot mask, a whole chain of
+        //     skips costs one cross-lane read
         unsigned long long emit = 0ull;
         float next_pending = -1.0f;
         bool finished = false;
         int v = entry;
         while (v < 64) {
             if (v >= nvalid) { finished = true; break; }
-            const unsigned long long un = (~occ_mask) >> v;
-            const int u = un ? v + (int)__builtin_ctzll(un) : 64;            // lanes v .. u-1 are occupied
+            if ((empty_mask >> v) & 1ull) {
+                const int pk = __builtin_amdgcn_readlane(chain, v);                 // v is wave-uniform
+                const int h = pk & 0xff;
+                if (h >= 64) {                                                        // the chain's last skip leaves the tile: carry its landing value
+                    next_pending = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t_next), pk >> 8));
+                    v = 64;
+                    break;
+                }
+                v = h;
+                continue;
+            }
+            const unsigned long long un = empty_mask >> v;
+            const int u = un ? v + (int)__builtin_ctzll(un) : 64;                   // lanes v .. u-1 are occupied
             const int hi = u < nvalid ? u : nvalid;
             if (hi > v) {
                 const int len = hi - v;
                 emit |= (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << v;
             }
-            if (nvalid < 64 && u >= nvalid) { finished = true; break; }     // the run (or the empty lane behind it) reaches the far hit
-            if (u >= 64) { v = 64; break; }
-            const int s_u = __builtin_amdgcn_readlane(succ, u);             // u is wave-uniform: the walk stays on the scalar unit
-            if (s_u >= 64) {
-                next_pending = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t_next), u));
-                v = s_u;
-                break;
-            }
-            v = s_u;
+            if (nvalid < 64 && u >= nvalid) { finished = true; break; }             // the run (or the empty lane behind it) reaches the far hit
+            v = u;                                                                    // 64: the tile ends inside a run; else the empty lane behind the run
         }
         // 4. write out, capped at max_samples like the serial loop's N_samples < max_samples
         const int room = max_samples - n;
