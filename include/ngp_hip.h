@@ -439,6 +439,17 @@ int ngp_nerf_loss(const float* rgb, const float* opacity, const float* gt_rgb, c
                   float* loss, float* sq_err, float* dL_drgb, float* dL_dopacity,
                   ngp_stream_t stream);
 
+/* NeRFLoss.forward as the reference shapes it (losses.py:47-60): UNREDUCED terms
+ *   sq_err (R,3) = (rgb - gt)^2,   entropy (R) = lambda_o * -(o + 1e-10) log(o + 1e-10)
+ * (train.py:173 sums their means) and the backward through them: g_rgb = g_sq_err * 2 (rgb - gt),
+ * g_opacity = g_entropy * lambda_o * -(log(o + 1e-10) + 1).  One launch each. */
+int ngp_nerf_loss_terms_fw(const float* rgb, const float* opacity, const float* gt_rgb,
+                           float lambda_opacity, int n_rays, float* sq_err, float* entropy,
+                           ngp_stream_t stream);
+int ngp_nerf_loss_terms_bw(const float* g_sq_err, const float* g_entropy, const float* rgb,
+                           const float* opacity, const float* gt_rgb, float lambda_opacity,
+                           int n_rays, float* g_rgb, float* g_opacity, ngp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * batch sampling (datasets/base.py:22-35 'all_images' + train.py:78-91 + ray_utils.py:46-70)
  * ------------------------------------------------------------------------------------------ */

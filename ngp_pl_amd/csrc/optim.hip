@@ -226,6 +226,33 @@ nerf_loss_kernel(const float* __restrict__ rgb, const float* __restrict__ opacit
     }
 }
 
+
+// NeRFLoss's per-element terms (losses.py:47-60: the module returns a dictionary of UNREDUCED terms, train.py:173 takes their
+// means) and their backward, one launch each instead of ~6 + ~10 elementwise torch kernels.
+__global__ void __launch_bounds__(256)
+nerf_loss_terms_fw_kernel(const float* __restrict__ rgb, const float* __restrict__ opacity, const float* __restrict__ gt,
+                          float lambda_o, int n_rays, float* __restrict__ sq, float* __restrict__ ent) {
+#pragma clang fp contract(off)
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const float d = rgb[3 * r + k] - gt[3 * r + k]; sq[3 * r + k] = d * d; }
+    const float o = opacity[r] + 1e-10f;
+    ent[r] = lambda_o * (-o * logf(o));
+}
+__global__ void __launch_bounds__(256)
+nerf_loss_terms_bw_kernel(const float* __restrict__ g_sq, const float* __restrict__ g_ent, const float* __restrict__ rgb,
+                          const float* __restrict__ opacity, const float* __restrict__ gt, float lambda_o, int n_rays,
+                          float* __restrict__ g_rgb, float* __restrict__ g_opacity) {
+#pragma clang fp contract(off)
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g_rgb[3 * r + k] = g_sq[3 * r + k] * (2.0f * (rgb[3 * r + k] - gt[3 * r + k]));
+    const float o = opacity[r] + 1e-10f;
+    g_opacity[r] = g_ent[r] * (lambda_o * (-(logf(o) + 1.0f)));
+}
+
 // GPU-resident batch sampler: the reference draws img/pix indices with np.random.choice in 16
 // dataloader workers, gathers rays[img, pix] from a CPU tensor and ships the batch over PCIe
 // (datasets/base.py:22-35, train.py:141-146), then forms rays on the GPU (train.py:78-91,
@@ -407,6 +434,27 @@ int ngp_nerf_loss(const float* rgb, const float* opacity, const float* gt_rgb, c
         hipLaunchKernelGGL(nerf_loss_kernel<false>, dim3(ngp_div_up(n_rays, 256)), dim3(256), 0, ngp_stream(stream),
                            rgb, opacity, gt_rgb, bg, lambda_opacity, grad_scale, n_rays, loss, sq_err, dL_drgb, dL_dopacity);
     }
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_nerf_loss_terms_fw(const float* rgb, const float* opacity, const float* gt_rgb, float lambda_opacity, int n_rays,
+                           float* sq_err, float* entropy, ngp_stream_t stream) {
+    if (n_rays < 0) return NGP_EINVAL;
+    if (n_rays == 0) return 0;
+    NGP_CHECK_PTR(rgb); NGP_CHECK_PTR(opacity); NGP_CHECK_PTR(gt_rgb); NGP_CHECK_PTR(sq_err); NGP_CHECK_PTR(entropy);
+    hipLaunchKernelGGL(nerf_loss_terms_fw_kernel, dim3(ngp_div_up(n_rays, 256)), dim3(256), 0, ngp_stream(stream), rgb, opacity, gt_rgb,
+                       lambda_opacity, n_rays, sq_err, entropy);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_nerf_loss_terms_bw(const float* g_sq_err, const float* g_entropy, const float* rgb, const float* opacity, const float* gt_rgb,
+                           float lambda_opacity, int n_rays, float* g_rgb, float* g_opacity, ngp_stream_t stream) {
+    if (n_rays < 0) return NGP_EINVAL;
+    if (n_rays == 0) return 0;
+    NGP_CHECK_PTR(g_sq_err); NGP_CHECK_PTR(g_entropy); NGP_CHECK_PTR(rgb); NGP_CHECK_PTR(opacity); NGP_CHECK_PTR(gt_rgb);
+    NGP_CHECK_PTR(g_rgb); NGP_CHECK_PTR(g_opacity);
+    hipLaunchKernelGGL(nerf_loss_terms_bw_kernel, dim3(ngp_div_up(n_rays, 256)), dim3(256), 0, ngp_stream(stream), g_sq_err, g_entropy,
+                       rgb, opacity, gt_rgb, lambda_opacity, n_rays, g_rgb, g_opacity);
     return NGP_LAUNCH_RESULT();
 }
 

@@ -68,16 +68,49 @@ class DistortionLoss(torch.autograd.Function):
         return g, None, None, None
 
 
+class _LossTerms(torch.autograd.Function):
+    """rgb (R,3), opacity (R), gt (R,3) -> (rgb - gt)^2 (R,3), lambda * -(o + eps) log(o + eps) (R): the two unreduced terms of
+    losses.py:47-56 in one launch forward and one backward (ngp_nerf_loss_terms_fw/_bw)."""
+
+    @staticmethod
+    def forward(ctx, rgb, opacity, gt, lambda_opacity):
+        from ._lib import call, ptr, stream
+        rgb = rgb.float().contiguous(); opacity = opacity.float().contiguous(); gt = gt.float().contiguous()
+        n = rgb.shape[0]
+        sq = torch.empty_like(rgb); ent = torch.empty_like(opacity)
+        with torch.cuda.device(rgb.device):
+            call("ngp_nerf_loss_terms_fw", ptr(rgb), ptr(opacity), ptr(gt), float(lambda_opacity), n, ptr(sq), ptr(ent), stream())
+        ctx.save_for_backward(rgb, opacity, gt)
+        ctx.lambda_opacity = float(lambda_opacity)
+        return sq, ent
+
+    @staticmethod
+    def backward(ctx, g_sq, g_ent):
+        from ._lib import call, ptr, stream
+        rgb, opacity, gt = ctx.saved_tensors
+        n = rgb.shape[0]
+        g_sq = g_sq.float().contiguous(); g_ent = g_ent.float().contiguous()      # `.mean()` hands back expanded (stride-0) views
+        g_rgb = torch.empty_like(rgb); g_op = torch.empty_like(opacity)
+        with torch.cuda.device(rgb.device):
+            call("ngp_nerf_loss_terms_bw", ptr(g_sq), ptr(g_ent), ptr(rgb), ptr(opacity), ptr(gt), ctx.lambda_opacity, n, ptr(g_rgb), ptr(g_op), stream())
+        return g_rgb, g_op, None, None
+
+
 class NeRFLoss(nn.Module):
     def __init__(self, lambda_opacity=1e-3, lambda_distortion=1e-3):
         super().__init__()
         self.lambda_opacity, self.lambda_distortion = lambda_opacity, lambda_distortion
 
     def forward(self, results, target, **kwargs):
-        terms = {
-            "rgb": squared_error(results["rgb"], target["rgb"]),
-            "opacity": opacity_entropy(results["opacity"], self.lambda_opacity),
-        }
+        rgb, opacity, gt = results["rgb"], results["opacity"], target["rgb"]
+        if rgb.is_cuda and rgb.dim() == 2 and rgb.shape[1] == 3 and gt.shape == rgb.shape and not gt.requires_grad:
+            sq, ent = _LossTerms.apply(rgb, opacity, gt, self.lambda_opacity)
+            terms = {"rgb": sq, "opacity": ent}
+        else:
+            terms = {
+                "rgb": squared_error(rgb, gt),
+                "opacity": opacity_entropy(opacity, self.lambda_opacity),
+            }
         if self.lambda_distortion > 0:
             per_ray = DistortionLoss.apply(results["ws"], results["deltas"], results["ts"], results["rays_a"])
             terms["distortion"] = self.lambda_distortion * per_ray

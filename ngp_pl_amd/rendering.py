@@ -27,18 +27,28 @@ def render(model, rays_o, rays_d, **kwargs):
     """rays (R,3)/(R,3) -> dict with rgb (R,3), depth (R), opacity (R) and, in training, ws, deltas,
     ts, rays_a, rm_samples, vr_samples; at test time total_samples (rendering.py:11-43)."""
     rays_o = rays_o.contiguous(); rays_d = rays_d.contiguous()
-    _, hits_t, _ = RayAABBIntersector.apply(rays_o, rays_d, model.center, model.half_size, 1)
-    t1 = hits_t[:, 0, 0]
-    hits_t[(t1 >= 0) & (t1 < NEAR_DISTANCE), 0, 0] = NEAR_DISTANCE
-    if kwargs.get("test_time", False):
-        native = getattr(model, "fused", False) and model.rgb_act == "Sigmoid" and rays_o.is_cuda and \
-            not any(isinstance(v, torch.Tensor) for v in kwargs.values())
-        if native:
-            fn = _render_test_native if kwargs.get("host_loop", False) else _render_test_device
-        else:
-            fn = _render_test
-    else:
+    test_time = kwargs.get("test_time", False)
+    if not test_time and _fused_train(model, rays_o, rays_d, kwargs):
+        # rendering.py:27-29 (one box, one hit, near clamp) as ONE launch; (R,1,2) like the operator's output
+        rays_o, rays_d = rays_o.float(), rays_d.float()
+        hits_t = torch.empty(rays_o.shape[0], 1, 2, dtype=torch.float32, device=rays_o.device)
+        with torch.cuda.device(rays_o.device):
+            call("ngp_ray_aabb_near", ptr(rays_o), ptr(rays_d), ptr(model.center), ptr(model.half_size), NEAR_DISTANCE,
+                 rays_o.shape[0], ptr(hits_t), stream())
         fn = _render_train
+    else:
+        _, hits_t, _ = RayAABBIntersector.apply(rays_o, rays_d, model.center, model.half_size, 1)
+        t1 = hits_t[:, 0, 0]
+        hits_t[(t1 >= 0) & (t1 < NEAR_DISTANCE), 0, 0] = NEAR_DISTANCE
+        if test_time:
+            native = getattr(model, "fused", False) and model.rgb_act == "Sigmoid" and rays_o.is_cuda and \
+                not any(isinstance(v, torch.Tensor) for v in kwargs.values())
+            if native:
+                fn = _render_test_native if kwargs.get("host_loop", False) else _render_test_device
+            else:
+                fn = _render_test
+        else:
+            fn = _render_train
     results = fn(model, rays_o, rays_d, hits_t, **kwargs)
     if kwargs.get("to_cpu", False):
         for k, v in results.items():
@@ -295,14 +305,19 @@ def _pinned_counter():
     return _COUNTER
 
 
+def _fused_train(model, rays_o, rays_d, kwargs):
+    """The training branch runs as one autograd node when the model is in its fused configuration, the rays carry no gradient
+    (no pose optimisation) and no per-ray tensor kwargs (exposure) have to be expanded per sample."""
+    return getattr(model, "fused", False) and getattr(model, "fused_render", True) and model.rgb_act == "Sigmoid" and rays_o.is_cuda and \
+        not (torch.is_grad_enabled() and (rays_o.requires_grad or rays_d.requires_grad)) and \
+        not any(isinstance(v, torch.Tensor) for v in kwargs.values())
+
+
 def _render_train(model, rays_o, rays_d, hits_t, **kwargs):
     """march -> field -> composite (rendering.py:121-163)."""
     esf = kwargs.get("exp_step_factor", 0.)
     results = {}
-    fused = getattr(model, "fused", False) and getattr(model, "fused_render", True) and model.rgb_act == "Sigmoid" and rays_o.is_cuda and \
-        not (torch.is_grad_enabled() and (rays_o.requires_grad or rays_d.requires_grad)) and \
-        not any(isinstance(v, torch.Tensor) for v in kwargs.values())
-    if fused:
+    if _fused_train(model, rays_o, rays_d, kwargs):
         bg = _background(esf, rays_o.device, kwargs.get("random_bg", False))
         (results["vr_samples"], results["opacity"], results["depth"], results["rgb"], results["ws"], results["rays_a"],
          results["deltas"], results["ts"], results["rm_samples"]) = _FusedTrainRender.apply(
