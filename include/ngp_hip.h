@@ -280,6 +280,19 @@ int ngp_hashgrid_bwd_binned(const float* x, const float* xyz_min, const float* x
                             void* workspace, size_t workspace_bytes,
                             ngp_half* grad_table, ngp_stream_t stream);
 
+/* The same backward in n_groups (<= 16) launches that each COMPLETE one contiguous range of table entries (group 0: the
+ * coarse dense levels + the first hashed levels, binning pass included; the other groups: the remaining hashed levels, evenly):
+ * a multi-GPU caller hands the finished range [entry_begin, entry_end) x 2 features of grad_table to its gradient
+ * collective while the next group's kernel runs (ngp_pl_amd/ddp.py; the reference's DDP buckets, train.py:270-272).
+ * Groups must be launched in order 0 .. n_groups-1 on one stream; n_groups = 1 is ngp_hashgrid_bwd_binned. */
+int ngp_hashgrid_bwd_binned_group(const float* x, const float* xyz_min, const float* xyz_max,
+                                  const ngp_half* dfeats, const ngp_grid_meta* meta, int n_samples,
+                                  const int32_t* active_idx, const int32_t* n_active,
+                                  void* workspace, size_t workspace_bytes, ngp_half* grad_table,
+                                  int n_groups, int group, ngp_stream_t stream);
+int ngp_hashgrid_bwd_binned_group_entries(const ngp_grid_meta* meta, int n_samples, int n_groups, int group,
+                                          int64_t* entry_begin, int64_t* entry_end);
+
 /* The samples that can carry gradient after compositing: the first min(N, total_samples+1) of
  * every ray (later ones have w = 0 exactly, volumerendering.cu:41).  Writes their ids in ray
  * order to active_idx (capacity S) and the count to n_active (device i32); ray_offsets (R) i32

@@ -83,6 +83,8 @@ _PROTOS = {
     "ngp_field_fwd_n": [P, P, P, P, I, P, P, P, P, P],
     "ngp_gather_xyz": [P, P, P, I, P, P],
     "ngp_hashgrid_bwd_binned": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P, C.c_size_t, P, P],
+    "ngp_hashgrid_bwd_binned_group": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P, C.c_size_t, P, I, I, P],
+    "ngp_hashgrid_bwd_binned_group_entries": [C.POINTER(GridMeta), I, I, I, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     "ngp_hashgrid_bwd_input": [P, P, P, P, P, C.POINTER(GridMeta), I, F, P, P],
     "ngp_sh4_bwd": [P, P, I, F, P, P],
     "ngp_density_fwd_scatter": [P, P, I, P, P, P],

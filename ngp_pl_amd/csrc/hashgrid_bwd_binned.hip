@@ -88,7 +88,7 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const
     const int chunk = (int)blockIdx.x - level * n_chunks;
     const int n = n_active ? min(*n_active, n_samples) : n_samples;
     const int ns = plan.n_slices[level];
-    if (blockIdx.x == 0 && threadIdx.x == 0) ws.queue[0] = 0;       // the slice owners' task counter (they start after this kernel)
+    if (blockIdx.x == 0 && threadIdx.x < 16) ws.queue[threadIdx.x] = 0;   // the slice owners' task counters, one per launch group (they start after this kernel)
     int32_t* __restrict__ dir = ws.dir + (size_t)level * MAX_SLICES * n_chunks + chunk;     // + s * n_chunks
     if (chunk * CHUNK >= n) {                                      // nothing here: empty segments
         for (int i = threadIdx.x; i < ns; i += BIN_THREADS) dir[(size_t)i * n_chunks] = 0;
@@ -311,20 +311,25 @@ __device__ __forceinline__ void apply_segments_dense(long long* lds, uint32_t lo
 __global__ void __launch_bounds__(APPLY_THREADS, NGP_APPLY_WAVES_PER_EU)
 apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const float* __restrict__ xyz_max,
              const half2_t* __restrict__ dfeats, GridMeta meta, BinPlan plan, BinWs ws, int n_samples,
-             const int32_t* __restrict__ active, half2_t* __restrict__ grad_table) {
+             const int32_t* __restrict__ active, half2_t* __restrict__ grad_table, int group, int task_begin, int task_end) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     long long* lds = reinterpret_cast<long long*>(smem_raw);
-    __shared__ int s_task;
+    __shared__ int s_task[2];                                          // s_task[k & 1]: id of the workgroup's k-th task
     __shared__ int s_dir[MAX_CHUNKS];
     const Box box = load_box(xyz_min, xyz_max);
     const int n_chunks = plan.n_chunks;
     const int tid = threadIdx.x;
-    for (;;) {
-        __syncthreads();                                           // previous task's LDS reads are done
-        if (tid == 0) s_task = atomicAdd(&ws.queue[0], 1);
-        __syncthreads();
-        const int task = s_task;
-        if (task >= plan.n_tasks) return;
+    // Three barriers per task, none of them behind a global round trip: the id of task k+1 is requested from the queue at the
+    // top of task k and parked in LDS at its end; the accumulators are cleared by the write-out pass that reads them (the
+    // first task finds them cleared by the prologue).
+    if (tid == 0) s_task[0] = task_begin + atomicAdd(&ws.queue[group], 1);
+    for (uint32_t k = tid; k < 2 * SLICE2; k += APPLY_THREADS) lds[k] = 0;
+    __syncthreads();
+    for (int it = 0;; ++it) {
+        const int task = s_task[it & 1];
+        if (task >= task_end) return;
+        int next_task = 0;
+        if (tid == 0) next_task = task_begin + atomicAdd(&ws.queue[group], 1);   // consumed at the end of this task
 #ifdef NGP_BIN_TIMING
         if (tid == 0) ws.timing[4 * task + 0] = (long long)wall_clock64();
 #endif
@@ -340,7 +345,6 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
         const uint32_t len = min(SLICE2, size - lo);
         const int32_t* __restrict__ dir = ws.dir + ((size_t)level * MAX_SLICES + slice) * n_chunks;
         for (int c = tid; c < n_chunks; c += APPLY_THREADS) s_dir[c] = dir[c];
-        for (uint32_t k = tid; k < 2 * len; k += APPLY_THREADS) lds[k] = 0;
         __syncthreads();
 #ifdef NGP_BIN_TIMING
         if (tid == 0) ws.timing[4 * task + 1] = (long long)wall_clock64();
@@ -356,13 +360,14 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
         half2_t* __restrict__ out = grad_table + meta.offset[level] + lo;
         const float inv = 1.0f / FIX_SCALE;
         for (uint32_t k = tid; k < len; k += APPLY_THREADS) {
-            half2_t v;
-            v[0] = (_Float16)((float)lds[2 * k] * inv); v[1] = (_Float16)((float)lds[2 * k + 1] * inv);
-            if (K == 1) out[k] = v;
-            else ws.partial[plan.part_off[level] + (size_t)part * size + lo + k] = make_float2((float)lds[2 * k] * inv, (float)lds[2 * k + 1] * inv);
+            const float a0 = (float)lds[2 * k] * inv, a1 = (float)lds[2 * k + 1] * inv;
+            lds[2 * k] = 0; lds[2 * k + 1] = 0;                        // ready for the next task
+            if (K == 1) { half2_t v; v[0] = (_Float16)a0; v[1] = (_Float16)a1; out[k] = v; }
+            else ws.partial[plan.part_off[level] + (size_t)part * size + lo + k] = make_float2(a0, a1);
         }
+        if (tid == 0) s_task[(it + 1) & 1] = next_task;
+        __syncthreads();                                               // accumulators clear, s_dir free, next id visible
 #ifdef NGP_BIN_TIMING
-        __syncthreads();
         if (tid == 0) ws.timing[4 * task + 3] = (long long)wall_clock64();
 #endif
     }
@@ -447,11 +452,39 @@ size_t ngp_hashgrid_bwd_binned_workspace_bytes(const ngp_grid_meta* meta, int n_
     return L.bytes;
 }
 
-int ngp_hashgrid_bwd_binned(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* dfeats,
-                            const ngp_grid_meta* meta, int n_samples, const int32_t* active_idx,
-                            const int32_t* n_active, void* workspace, size_t workspace_bytes,
-                            ngp_half* grad_table, ngp_stream_t stream) {
+// Launch groups for a table backward whose result is handed on piecewise (multi-GPU: the gradient exchange of a finished
+// piece runs underneath the slice owners of the next): group 0 = the K-split (dense, coarse) levels + the first hashed
+// levels, the remaining hashed levels are spread evenly over the other groups.  Levels are contiguous in the table, so
+// every group completes one contiguous range of entries.
+static void group_bounds(const ngp_grid_meta* meta, const BinPlan& P, int n_groups, int group, int& order_begin, int& order_end) {
+    int n_dense = 0;
+    while (n_dense < meta->n_levels && P.k_split[P.order[n_dense]] > 1) ++n_dense;
+    const int n_hashed = meta->n_levels - n_dense;
+    // hashed levels per group: as even as possible, group 0 takes the remainder together with the dense levels' (cheap) tables
+    auto first_hashed = [&](int g) { return g <= 0 ? 0 : (int)(((long long)n_hashed * g + n_groups - 1) / n_groups); };
+    order_begin = group == 0 ? 0 : n_dense + first_hashed(group);
+    order_end = n_dense + (group + 1 >= n_groups ? n_hashed : first_hashed(group + 1));
+}
+
+int ngp_hashgrid_bwd_binned_group_entries(const ngp_grid_meta* meta, int n_samples, int n_groups, int group,
+                                          int64_t* entry_begin, int64_t* entry_end) {
+    if (!meta || n_groups < 1 || n_groups > 16 || group < 0 || group >= n_groups || !entry_begin || !entry_end) return NGP_EINVAL;
+    BinPlan P; BinLayout L;
+    if (!make_plan(meta, n_samples > 0 ? n_samples : 1, P, L)) return NGP_EUNSUP;
+    int a, b;
+    group_bounds(meta, P, n_groups, group, a, b);
+    for (int i = 0; i + 1 < meta->n_levels; ++i) if (P.order[i] > P.order[i + 1]) return NGP_EUNSUP;     // levels in table order (coarse = dense first)
+    *entry_begin = a < meta->n_levels ? meta->offset[P.order[a]] : meta->offset[meta->n_levels];
+    *entry_end = b < meta->n_levels ? meta->offset[P.order[b]] : meta->offset[meta->n_levels];
+    return 0;
+}
+
+int ngp_hashgrid_bwd_binned_group(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* dfeats,
+                                  const ngp_grid_meta* meta, int n_samples, const int32_t* active_idx,
+                                  const int32_t* n_active, void* workspace, size_t workspace_bytes,
+                                  ngp_half* grad_table, int n_groups, int group, ngp_stream_t stream) {
     if (n_samples < 0 || !meta || meta->n_features != 2 || meta->n_levels < 1 || meta->n_levels > NGP_MAX_LEVELS) return NGP_EINVAL;
+    if (n_groups < 1 || n_groups > 16 || group < 0 || group >= n_groups) return NGP_EINVAL;
     NGP_CHECK_PTR(grad_table); NGP_CHECK_PTR(workspace);
     if (n_samples > 0) { NGP_CHECK_PTR(x); NGP_CHECK_PTR(xyz_min); NGP_CHECK_PTR(xyz_max); NGP_CHECK_PTR(dfeats); }
     if (active_idx != nullptr && n_active == nullptr) return NGP_EINVAL;      // n_active alone: x and dfeats both in compact order
@@ -473,8 +506,9 @@ int ngp_hashgrid_bwd_binned(const float* x, const float* xyz_min, const float* x
     ws.partial = reinterpret_cast<float2*>(wsb + L.partial);
     hipError_t e = hipSuccess;
     const GridMeta dm = to_dev_meta(meta);
-    bin_kernel<<<dim3(meta->n_levels * P.n_chunks), dim3(BIN_THREADS), 0, st>>>(
-        x, xyz_min, xyz_max, (const half2_t*)dfeats, dm, P, ws, n_samples, active_idx, n_active);
+    if (group == 0)
+        bin_kernel<<<dim3(meta->n_levels * P.n_chunks), dim3(BIN_THREADS), 0, st>>>(
+            x, xyz_min, xyz_max, (const half2_t*)dfeats, dm, P, ws, n_samples, active_idx, n_active);
     constexpr int smem = (int)(SLICE2 * 2 * sizeof(long long));
     static bool attr_set[64] = {};              // per device: the attribute belongs to the device's code object
     int dev = 0;
@@ -485,12 +519,26 @@ int ngp_hashgrid_bwd_binned(const float* x, const float* xyz_min, const float* x
         if (e != hipSuccess) return (int)e;
         attr_set[dev] = true;
     }
-    const int n_wg = P.n_tasks < NGP_APPLY_WGS ? P.n_tasks : NGP_APPLY_WGS;
-    apply_kernel<<<dim3(n_wg), dim3(APPLY_THREADS), smem, st>>>(
-        x, xyz_min, xyz_max, (const half2_t*)dfeats, dm, P, ws, n_samples, active_idx, (half2_t*)grad_table);
-    if (L.merge_entries > 0)
+    int a, b;
+    group_bounds(meta, P, n_groups, group, a, b);
+    const int task_begin = P.first_task[a], task_end = P.first_task[b];
+    const int n_tasks = task_end - task_begin;
+    if (n_tasks > 0) {
+        const int n_wg = n_tasks < NGP_APPLY_WGS ? n_tasks : NGP_APPLY_WGS;
+        apply_kernel<<<dim3(n_wg), dim3(APPLY_THREADS), smem, st>>>(
+            x, xyz_min, xyz_max, (const half2_t*)dfeats, dm, P, ws, n_samples, active_idx, (half2_t*)grad_table, group, task_begin, task_end);
+    }
+    if (group == 0 && L.merge_entries > 0)      // the K-split levels all sit in group 0
         merge_kernel<<<dim3(ngp_div_up(L.merge_entries, 256)), dim3(256), 0, st>>>(dm, P, ws, (half2_t*)grad_table);
     return NGP_LAUNCH_RESULT();
+}
+
+int ngp_hashgrid_bwd_binned(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* dfeats,
+                            const ngp_grid_meta* meta, int n_samples, const int32_t* active_idx,
+                            const int32_t* n_active, void* workspace, size_t workspace_bytes,
+                            ngp_half* grad_table, ngp_stream_t stream) {
+    return ngp_hashgrid_bwd_binned_group(x, xyz_min, xyz_max, dfeats, meta, n_samples, active_idx, n_active, workspace, workspace_bytes,
+                                         grad_table, 1, 0, stream);
 }
 
 #pragma GCC visibility pop

@@ -12,6 +12,11 @@ all-reduce every step), applied to the native gradient buffers the fused backwar
     size.  The table backward accumulates in 64-bit fixed point and rounds to f16 once, so each rank's
     addend carries one f16 rounding; the ring adds world - 1 more (tiny-cuda-nn's own f16 atomics round
     after EVERY corner update);
+  * the table backward runs in `n_groups` launch groups (ngp_hashgrid_bwd_binned_group) that each complete one contiguous
+    range of the gradient table; the all-reduce of a finished range is issued asynchronously right behind its group, i.e.
+    it runs on RCCL's stream while the slice owners of the next group still occupy the main stream (DDP's bucketed overlap,
+    with the buckets aligned to what the backward finishes when); the last range and whatever is still in flight are
+    waited for in front of the optimizer;
   * GradScaler's non-finite check runs on the reduced buffers (`ngp_found_inf`) and feeds the fused Adam's
     skip flag: a sum that overflowed on any rank is seen by all ranks alike (they hold the same sum), so the
     ranks stay in lock step without a second collective.
@@ -25,12 +30,35 @@ from . import tcnn
 
 
 class GradientExchange:
-    def __init__(self, model, dist, world, group=None):
+    def __init__(self, model, dist, world, group=None, n_groups=3, ranges=None):
+        """`n_groups`: launch groups of the table backward = pieces of the grid-gradient exchange (1: one all-reduce behind
+        the whole backward).  `ranges`: their table-entry ranges [(begin, end), ...]; taken from the library's plan for the
+        model's grid when not given.  EVERY rank issues the same sequence of collectives every step -- MLP block, then the
+        ranges in order -- whichever path its own step took (binned groups, the one-pass fallback for oversized batches, or
+        no samples at all): ranges a rank's backward did not hand over piecewise are issued in front of the optimizer."""
         self.model, self.dist, self.world, self.group = model, dist, world, group
         self.loss_scale = tcnn.LOSS_SCALE / world
+        if ranges is None:
+            ranges = self._plan_ranges(model, n_groups) if n_groups > 1 else []
+        self.ranges = [tuple(r) for r in ranges]
+        self.n_groups = max(len(self.ranges), 1)
         self._small = None
         self._flag = None
         self._work = None
+        self._issued = 0           # ranges of this step already in flight
+        self._works = []
+
+    @staticmethod
+    def _plan_ranges(model, n_groups):
+        import ctypes as C
+        from ._lib import call
+        meta = model.xyz_encoder.meta
+        out = []
+        for g in range(n_groups):
+            a, b = C.c_int64(), C.c_int64()
+            call("ngp_hashgrid_bwd_binned_group_entries", C.byref(meta), 1, n_groups, g, C.byref(a), C.byref(b))
+            out.append((a.value, b.value))
+        return out
 
     def install(self, trainer):
         """Hooks into Trainer.step: MLP collective behind the MLP backward, grid collective + inf check behind the
@@ -38,6 +66,9 @@ class GradientExchange:
         trainer.loss_scale = self.loss_scale
         trainer.mlp_grad_hook = self.reduce_mlp
         trainer.grad_hook = self.reduce_grid
+        if len(self.ranges) > 1:
+            trainer.bwd_groups = len(self.ranges)
+            trainer.group_hook = self.reduce_piece
         return self
 
     def broadcast_parameters(self):
@@ -66,6 +97,22 @@ class GradientExchange:
             small[:n_d] = dp.view(n_part, n_d).sum(0); small[n_d:] = rp.view(n_part, n_r).sum(0)
         self._work = self.dist.all_reduce(small, group=self.group, async_op=True)
 
+    def reduce_piece(self, group, n_groups, entry_begin, entry_end):
+        """Behind launch group `group` of the table backward: all-reduce the table range it completed (2 features per entry)."""
+        nat = self.model._native
+        if nat is None:
+            return
+        if n_groups != len(self.ranges) or group != self._issued or (entry_begin, entry_end) != self.ranges[group]:
+            raise RuntimeError("table backward group %d/%d [%d, %d) does not match the exchange plan %r" % (
+                group, n_groups, entry_begin, entry_end, self.ranges))
+        self._issue_next(nat["grid16"])
+
+    def _issue_next(self, g16):
+        a, b = self.ranges[self._issued]
+        self._issued += 1
+        if b > a:
+            self._works.append(self.dist.all_reduce(g16[2 * a:2 * b], group=self.group, async_op=True))
+
     def reduce_grid(self):
         """Returns the device int32 found_inf flag (None on CPU tensors when everything is finite)."""
         nat = self.model._native
@@ -75,7 +122,16 @@ class GradientExchange:
         if self._work is None:
             self.reduce_mlp()
         g16 = nat["grid16"]
-        self.dist.all_reduce(g16, group=self.group)
+        if self.ranges:
+            if self.ranges[0][0] != 0 or self.ranges[-1][1] * 2 != g16.numel():
+                raise RuntimeError("exchange plan %r does not cover the gradient table (%d entries)" % (self.ranges, g16.numel() // 2))
+            while self._issued < len(self.ranges):        # ranges this rank's backward did not hand over piecewise
+                self._issue_next(g16)
+            for work in self._works:
+                work.wait()
+            self._works, self._issued = [], 0
+        else:
+            self.dist.all_reduce(g16, group=self.group)
         self._work.wait(); self._work = None
         small = self._small
         nat["density_partials"] = small[:enc.n_mlp]

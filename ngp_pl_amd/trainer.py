@@ -159,6 +159,9 @@ class Trainer:
         self.last = {}
         self.grad_hook = None    # called between backward and optimizer (multi-GPU gradient all-reduce)
         self.mlp_grad_hook = None  # called once the MLP gradients exist, before the hash-grid backward is enqueued
+        self.group_hook = None     # called behind each launch group of the table backward: (group, n_groups, entry_begin, entry_end)
+        self.bwd_groups = 1        # launch groups of the table backward when a group_hook is installed
+        self._group_cache = {}
         self.events = None       # list of (stage, event) when stage timing is on (bench.py roofline)
         self.march_ms = None
 
@@ -349,8 +352,14 @@ class Trainer:
 
                 def table_backward():
                     if binned:
-                        call("ngp_hashgrid_bwd_binned", P["x_act"], ptr(m.xyz_min), ptr(m.xyz_max), P["dfeats"], C.byref(enc.meta), S,
-                             None, P["n_active"], P["bin_ws"], B.bin_bytes, ptr(g16), mq)
+                        # one launch group per piece of the table that is handed on separately (multi-GPU: the exchange of a finished
+                        # piece runs underneath the next group's slice owners); a single group otherwise
+                        ng = self.bwd_groups if self.group_hook is not None else 1
+                        for g in range(ng):
+                            call("ngp_hashgrid_bwd_binned_group", P["x_act"], ptr(m.xyz_min), ptr(m.xyz_max), P["dfeats"], C.byref(enc.meta), S,
+                                 None, P["n_active"], P["bin_ws"], B.bin_bytes, ptr(g16), ng, g, mq)
+                            if ng > 1:
+                                self.group_hook(g, ng, *self._group_entries(enc.meta, S, ng, g))
                     else:
                         call("ngp_hashgrid_bwd_sliced", P["xyzs"], ptr(m.xyz_min), ptr(m.xyz_max), P["dfeats"], C.byref(enc.meta), S,
                              P["active"], P["n_active"], ptr(g16), mq)
@@ -372,6 +381,15 @@ class Trainer:
                 self._mark("grid_update")
                 self._pending = self._march(next_batch[0], next_batch[1])
         return self.last
+
+    def _group_entries(self, meta, S, n_groups, group):
+        """Table-entry range [begin, end) that launch group `group` of `n_groups` completes (host-side plan, cached)."""
+        key = (n_groups, group)
+        if key not in self._group_cache:
+            a, b = C.c_int64(), C.c_int64()
+            call("ngp_hashgrid_bwd_binned_group_entries", C.byref(meta), 1, n_groups, group, C.byref(a), C.byref(b))
+            self._group_cache[key] = (a.value, b.value)
+        return self._group_cache[key]
 
     def zero_native(self, dev):
         """The native gradient record of a rank whose batch produced no samples: zeros, at this trainer's loss scale."""

@@ -85,6 +85,9 @@ class _CapturingAdam:
         self.model._native = None
 
 
+RANGES = [(0, 1000), (1000, 2600), (2600, N_TABLE)]     # stand-in for the library's launch-group plan (ngp_hashgrid_bwd_binned_group_entries)
+
+
 def _make_trainer(model, world):
     from ngp_pl_amd.ddp import GradientExchange
     from ngp_pl_amd.trainer import Trainer
@@ -92,9 +95,11 @@ def _make_trainer(model, world):
     tr.model, tr.opt = model, _CapturingAdam(model)
     tr.global_step, tr.steps_per_epoch, tr.base_lr, tr.num_epochs = 0, 1000, 1e-2, 30
     tr.grad_scale, tr.loss_scale = 1.0, 128.0
-    tr.grad_hook = tr.mlp_grad_hook = None
-    ex = GradientExchange(model, dist, world).install(tr)
+    tr.grad_hook = tr.mlp_grad_hook = tr.group_hook = None
+    tr.bwd_groups = 1
+    ex = GradientExchange(model, dist, world, ranges=RANGES).install(tr)
     assert tr.loss_scale == 128.0 / world and tr.grad_hook is not None and tr.mlp_grad_hook is not None
+    assert tr.bwd_groups == 3 and tr.group_hook is not None
     return tr, ex
 
 
@@ -125,12 +130,20 @@ def _worker(rank, world, port, q, empty_rank):
         native = dict(grid16=model._g16, density_partials=(split * mine[0][None] * ls).reshape(-1).contiguous(),
                       rgb_partials=(split * mine[1][None] * ls).reshape(-1).contiguous(), n_partials=n_part, scale=ls)
 
-        def table_backward():                               # the table backward overwrites the packed-f16 gradient
-            order.append("table_bwd")
-            model._g16.copy_((mine[2].reshape(-1)[:n_grid] * ls).half())
+        def table_backward():                               # the table backward overwrites the packed-f16 gradient, group by group
+            full = (mine[2].reshape(-1)[:n_grid] * ls).half()
+            if rank == 0:                                   # rank 0: piecewise, as Trainer.step's binned backward hands it over
+                for g, (a, b) in enumerate(RANGES):
+                    order.append("table_bwd[%d]" % g)
+                    model._g16[2 * a:2 * b] = full[2 * a:2 * b]
+                    tr.group_hook(g, len(RANGES), a, b)
+            else:                                           # rank 1: in one piece (the one-pass fallback for oversized batches) --
+                order.append("table_bwd")                   # the ranks' collective sequences must still match
+                model._g16.copy_(full)
         tr._exchange_and_update(native, table_backward, None)
     seen = tr.opt.seen
-    ok = order == (["mlp", "grid"] if rank == empty_rank else ["mlp", "table_bwd", "grid"])
+    want_order = ["mlp", "grid"] if rank == empty_rank else (["mlp", "table_bwd[0]", "table_bwd[1]", "table_bwd[2]", "grid"] if rank == 0 else ["mlp", "table_bwd", "grid"])
+    ok = order == want_order
     ok &= seen["found_inf"] is None and model._native is None and seen["lr"] == pytest.approx(1e-2)
     errs = {}
     for key, w in (("density", want[0]), ("rgb", want[1]), ("grid", want[2].reshape(-1)[:n_grid])):
