@@ -388,8 +388,7 @@ def main():
         "ms_per_step_hip_events": r["ms_per_step_hip_events"], "cold_start": r["cold_start"],
     }
     if dist is not None:      # what follows runs on rank 0 only: no collectives from here on
-        loop.trainer.grad_hook = loop.trainer.mlp_grad_hook = None
-        loop.trainer.loss_scale = 128.0
+        loop.exchange.uninstall(loop.trainer)
     if rank == 0 and args.timed_only:
         print(json.dumps(out))
     elif rank == 0:

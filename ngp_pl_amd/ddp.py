@@ -71,6 +71,13 @@ class GradientExchange:
             trainer.group_hook = self.reduce_piece
         return self
 
+    def uninstall(self, trainer):
+        """Back to a single-process step (bench.py: the rank-0-only legs behind the timed region issue no collectives)."""
+        trainer.loss_scale = tcnn.LOSS_SCALE
+        trainer.mlp_grad_hook = trainer.grad_hook = trainer.group_hook = None
+        trainer.bwd_groups = 1
+        self._works, self._issued, self._work = [], 0, None
+
     def broadcast_parameters(self):
         """DDP's constructor broadcast: every rank starts from rank 0's parameters."""
         for p in self.model.parameters():

@@ -354,7 +354,7 @@ class Trainer:
                     if binned:
                         # one launch group per piece of the table that is handed on separately (multi-GPU: the exchange of a finished
                         # piece runs underneath the next group's slice owners); a single group otherwise
-                        ng = self.bwd_groups if self.group_hook is not None else 1
+                        ng = self.bwd_groups if (self.group_hook is not None and self.grad_hook is not None) else 1
                         for g in range(ng):
                             call("ngp_hashgrid_bwd_binned_group", P["x_act"], ptr(m.xyz_min), ptr(m.xyz_max), P["dfeats"], C.byref(enc.meta), S,
                                  None, P["n_active"], P["bin_ws"], B.bin_bytes, ptr(g16), ng, g, mq)
