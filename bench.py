@@ -142,21 +142,23 @@ class Loop:
             self.exchange = GradientExchange(self.model, dist, world).install(self.trainer)
             self.exchange.broadcast_parameters()
         self.draws = 0
-        self.main_stream = torch.cuda.current_stream()
+        # three batch buffers in rotation (the batch being stepped, the one being marched, the one being drawn): nothing is
+        # allocated per draw and no allocator bookkeeping across the two streams is needed
+        self.ring = [tuple(torch.empty(self.rays, 3, device=dev) for _ in range(3)) for _ in range(3)]
         self.cur = self.draw()
 
     def draw(self, on_side=True):
-        # the batch sampler runs on the trainer's marching stream, in front of the march that consumes its rays (the
-        # main stream picks the batch up behind that march's event); record_stream: the main stream reads them too
+        """Next batch (ngp_sample_rays).  It is drawn on the trainer's marching stream, in front of the march that consumes its
+        rays: the main stream picks the batch up behind that march's event."""
         self.draws += 1
         tr = self.trainer
-        if tr.side is None or not on_side:
-            return self.data.sample_native(self.rays, self.draws, seed=1234 + self.rank)     # per-rank independent batches (base.py:25-29)
-        with torch.cuda.stream(tr.side):
-            batch = self.data.sample_native(self.rays, self.draws, seed=1234 + self.rank)
-        for t in batch:
-            t.record_stream(self.main_stream)
-        return batch
+        out = self.ring[self.draws % 3]
+        side = tr.side is not None and on_side
+        # No extra ordering needed for the buffer reuse: the marching stream last waited on the main stream when the march of
+        # the previous batch was enqueued (inside the step before this one), i.e. behind every kernel of the step that consumed
+        # this buffer's previous batch, three draws back.
+        return self.data.sample_native(self.rays, self.draws, seed=1234 + self.rank, out=out,      # per-rank independent batches (base.py:25-29)
+                                       stream_handle=tr.side.cuda_stream if side else None)
 
     def steps(self, n):
         for _ in range(n):

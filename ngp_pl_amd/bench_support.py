@@ -84,17 +84,22 @@ class GpuDataset:
             self.rgb[i] = surface_ground_truth(ro, rd, boxes, spheres, white_bg=(scene == "lego"))
         self.device = device
 
-    def sample_native(self, n, step, seed=0, want_indices=False):
+    def sample_native(self, n, step, seed=0, want_indices=False, out=None, stream_handle=None):
         """Same draw as `sample` in ONE kernel (ngp_sample_rays): indices from a counter-based RNG
-        keyed by (seed, step), colour gather, pose rotation.  Returns rays_o, rays_d, rgb[, img, pix]."""
+        keyed by (seed, step), colour gather, pose rotation.  Returns rays_o, rays_d, rgb[, img, pix].
+        `out` = (rays_o, rays_d, rgb) buffers to fill instead of allocating; `stream_handle` = raw stream to launch on."""
         from ._lib import call, ptr, stream
         dev = self.device
-        ro = torch.empty(n, 3, device=dev); rd = torch.empty(n, 3, device=dev); rgb = torch.empty(n, 3, device=dev)
+        if out is None:
+            ro = torch.empty(n, 3, device=dev); rd = torch.empty(n, 3, device=dev); rgb = torch.empty(n, 3, device=dev)
+        else:
+            ro, rd, rgb = out
         img = pix = None
         if want_indices:
             img = torch.empty(n, dtype=torch.int32, device=dev); pix = torch.empty(n, dtype=torch.int32, device=dev)
         call("ngp_sample_rays", ptr(self.poses), ptr(self.directions), ptr(self.rgb), self.poses.shape[0], self.W * self.H, n,
-             (int(seed) << 32) | (int(step) & 0xFFFFFFFF), ptr(ro), ptr(rd), ptr(rgb), None, ptr(img), ptr(pix), stream())
+             (int(seed) << 32) | (int(step) & 0xFFFFFFFF), ptr(ro), ptr(rd), ptr(rgb), None, ptr(img), ptr(pix),
+             stream_handle if stream_handle is not None else stream())
         return (ro, rd, rgb, img, pix) if want_indices else (ro, rd, rgb)
 
     def sample(self, n, gen):

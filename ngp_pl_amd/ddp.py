@@ -30,7 +30,7 @@ from . import tcnn
 
 
 class GradientExchange:
-    def __init__(self, model, dist, world, group=None, n_groups=3, ranges=None):
+    def __init__(self, model, dist, world, group=None, n_groups=2, ranges=None):
         """`n_groups`: launch groups of the table backward = pieces of the grid-gradient exchange (1: one all-reduce behind
         the whole backward).  `ranges`: their table-entry ranges [(begin, end), ...]; taken from the library's plan for the
         model's grid when not given.  EVERY rank issues the same sequence of collectives every step -- MLP block, then the

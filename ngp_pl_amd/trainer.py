@@ -13,6 +13,7 @@ Two implementations of the same step:
   * `step_autograd()` -- the same maths through render() + NeRFLoss + torch autograd, i.e. what
                          the reference's train.py drives; used to check the hot path (tests).
 """
+import contextlib
 import ctypes as C
 import math
 import os
@@ -25,6 +26,12 @@ from ._lib import call, ptr, stream
 from .losses import NeRFLoss
 from .optim import FusedAdam, cosine_lr
 from .rendering import MAX_SAMPLES, NEAR_DISTANCE, render
+
+
+def _set_current_stream(st):
+    """torch.cuda.set_stream without its bookkeeping (the context manager costs ~20 us of host time per use: two
+    current_stream() queries and two switches; this is one switch)."""
+    torch._C._cuda_setStream(stream_id=st.stream_id, device_index=st.device_index, device_type=st.device_type)
 
 
 def _align(x, a=256):
@@ -104,6 +111,8 @@ class StepBuffers:
         self.counter_np = [t.numpy() for t in self.counter_host]
         self.counter_p = [t.data_ptr() for t in self.counter_host]
         self.next_set = 0
+        self.ready = [torch.cuda.Event() for _ in (0, 1)]
+        self.done = [torch.cuda.Event() for _ in (0, 1)]
 
     def sample_views(self, S):
         """Tensor views of the last step's packed samples (debugging / tests; the step itself uses raw pointers)."""
@@ -162,6 +171,7 @@ class Trainer:
         self.group_hook = None     # called behind each launch group of the table backward: (group, n_groups, entry_begin, entry_end)
         self.bwd_groups = 1        # launch groups of the table backward when a group_hook is installed
         self._group_cache = {}
+        self._main = None        # torch's current stream while a step is being enqueued (cached: the query costs ~8 us)
         self.events = None       # list of (stage, event) when stage timing is on (bench.py roofline)
         self.march_ms = None
 
@@ -182,6 +192,13 @@ class Trainer:
         return out
 
     # -- pieces --------------------------------------------------------------------------------
+    def _device_guard(self, dev):
+        """`with torch.cuda.device(dev)` only when dev is not the current device already (one process per GPU sets its device
+        once; the guard's bookkeeping is ~10 us of host time per step otherwise)."""
+        if dev.index is None or torch.cuda.current_device() == dev.index:
+            return contextlib.nullcontext()
+        return torch.cuda.device(dev)
+
     def _maybe_update_grid(self):
         if self.global_step % self.update_interval == 0:                  # train.py:160-163
             self.model.update_density_grid(0.01 * MAX_SAMPLES / 3 ** 0.5, warmup=self.global_step < self.warmup_steps,
@@ -207,25 +224,31 @@ class Trainer:
         B = self.buffers(n)
         k = B.next_set; B.next_set ^= 1
         P = B.p
-        main = torch.cuda.current_stream()
+        main = self._main if self._main is not None else torch.cuda.current_stream()
         st = self.side if self.side is not None else main
+        ready, done = B.ready[k], B.done[k]                 # reusable events of this record set
         if st is not main:
-            ready = torch.cuda.Event(); ready.record(main)
+            ready.record(main)
             st.wait_event(ready)
         sq = st.cuda_stream                      # raw handle once: torch.cuda.current_stream() costs ~8 us per call
         B.counter_np[k][0] = -1
-        with torch.cuda.stream(st):
+        if st is not main:
+            _set_current_stream(st)
+        try:
             t0 = t1 = None
             if self.events is not None:
-                t0 = torch.cuda.Event(enable_timing=True); t0.record()
+                t0 = torch.cuda.Event(enable_timing=True); t0.record(st)
             B.noise[k].uniform_()                # jitter of the first sample (custom_functions.py:83: torch.rand_like); drawn on the marching stream
             call("ngp_ray_aabb_near", ptr(rays_o), ptr(rays_d), ptr(m.center), ptr(m.half_size), NEAR_DISTANCE, n, P["hits_t%d" % k], sq)
             call(self._march_count, ptr(rays_o), ptr(rays_d), P["hits_t%d" % k], ptr(m.density_bitfield), m.cascades,
                  float(m.scale), self.exp_step_factor, P["noise%d" % k], m.grid_size, MAX_SAMPLES, n, P["rays_a%d" % k], B.counter_p[k],
                  P["scratch%d" % k], sq)
             if self.events is not None:
-                t1 = torch.cuda.Event(enable_timing=True); t1.record()
-            done = torch.cuda.Event(); done.record()
+                t1 = torch.cuda.Event(enable_timing=True); t1.record(st)
+            done.record(st)
+        finally:
+            if st is not main:
+                _set_current_stream(main)
         return dict(rays_o=rays_o, rays_d=rays_d, set=k, done=done, timing=(t0, t1) if t0 is not None else None)
 
     def _drop_pending(self):
@@ -245,8 +268,8 @@ class Trainer:
         m = self.model
         dev = rays_o.device
         enc, net = m.xyz_encoder, m.rgb_net
-        with torch.cuda.device(dev):
-            main = torch.cuda.current_stream()
+        with self._device_guard(dev):
+            main = self._main = torch.cuda.current_stream()
             mq = main.cuda_stream
             n = rays_o.shape[0]
             if self._pending is not None and self._pending["rays_o"] is rays_o:
