@@ -429,9 +429,17 @@ int ngp_adam_step_field(float* grid_param, ngp_half* grid_param_h, ngp_half* gri
  * sum can overflow where no single rank's gradient did; feed the flag to ngp_adam_step*'s found_inf. */
 int ngp_found_inf(const void* grad, int grad_is_f32, int64_t n, int32_t* flag, int reset,
                   ngp_stream_t stream);
+/* The same check over two buffers in one launch (byte sizes multiples of 16); flag_clear (may be NULL) is zeroed on the side:
+ * a caller alternating between two flags needs no memset launch per step. */
+int ngp_found_inf2(const void* grad_a, int a_is_f32, int64_t n_a, const void* grad_b, int b_is_f32, int64_t n_b,
+                   int32_t* flag, int32_t* flag_clear, ngp_stream_t stream);
 /* Sum n_partials rows of (n) f32 into out (n) f32 (out = sum, not accumulated). */
 int ngp_reduce_partials(const float* partials, int n_partials, int n, float* out,
                         ngp_stream_t stream);
+/* Both MLP blocks in one launch: out[0:n_a] and out[n_a:n_a+n_b] = column sums of partials_a (n_partials, n_a) and
+ * partials_b (n_partials, n_b). */
+int ngp_reduce_partials2(const float* partials_a, int n_a, const float* partials_b, int n_b,
+                         int n_partials, float* out, ngp_stream_t stream);
 /* f32 -> f16 cast (tiny-cuda-nn casts the master params every forward). */
 int ngp_cast_f32_to_f16(const float* in, int64_t n, ngp_half* out, ngp_stream_t stream);
 int ngp_cast_f16_to_f32(const ngp_half* in, int64_t n, float scale, float* out,

@@ -71,6 +71,8 @@ _PROTOS = {
     "ngp_adam_step_field": [P, P, P, P, P, L, P, P, P, P, P, I, P, P, P, P, P, I, I, F, F, F, F, F, I, F, P, P],
     "ngp_reduce_partials": [P, I, I, P, P],
     "ngp_found_inf": [P, I, L, P, I, P],
+    "ngp_found_inf2": [P, I, L, P, I, L, P, P, P],
+    "ngp_reduce_partials2": [P, I, P, I, I, P, P],
     "ngp_cast_f32_to_f16": [P, L, P, P],
     "ngp_cast_f16_to_f32": [P, L, F, P, P],
     "ngp_nerf_loss": [P, P, P, P, F, F, I, P, P, P, P, P],

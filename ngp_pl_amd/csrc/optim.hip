@@ -310,6 +310,58 @@ found_inf_kernel(const u32x4* __restrict__ g, long long n16, const unsigned shor
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
+// The same check over TWO buffers in one launch (the reduced grid gradient and the reduced MLP sums), with the flag of the
+// NEXT step cleared on the side: callers alternate between two flags, so no memset launch is needed in steady state.
+__global__ void __launch_bounds__(256)
+found_inf2_kernel(const u32x4* __restrict__ a, long long a16, int a_half, const u32x4* __restrict__ b, long long b16, int b_half,
+                  int32_t* __restrict__ flag, int32_t* __restrict__ flag_clear) {
+    bool bad = false;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < a16 + b16; q += stride) {
+        const bool in_a = q < a16;
+        const u32x4 w = in_a ? __builtin_nontemporal_load(a + q) : __builtin_nontemporal_load(b + (q - a16));
+        const int is_half = in_a ? a_half : b_half;
+        const uint32_t x[4] = {w[0], w[1], w[2], w[3]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (is_half) bad |= ((x[k] & 0x7c00u) == 0x7c00u) | ((x[k] & 0x7c000000u) == 0x7c000000u);
+            else bad |= (x[k] & 0x7f800000u) == 0x7f800000u;
+        }
+    }
+    if (flag_clear && blockIdx.x == 0 && threadIdx.x == 0) *flag_clear = 0;
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+// out[0:n_a] = column sums of partials_a (n_partials, n_a), out[n_a:n_a+n_b] = column sums of partials_b (n_partials, n_b): both MLP
+// blocks' per-workgroup partial sums in one launch (reduce_partials_kernel's scheme).
+__global__ void __launch_bounds__(256)
+reduce_partials2_kernel(const float* __restrict__ pa, int n_a, const float* __restrict__ pb, int n_b, int n_partials, float* __restrict__ out) {
+    __shared__ float s_acc[8][32];
+    const int c = threadIdx.x & 31, lane_row = threadIdx.x >> 5;
+    const int blocks_a = (n_a + 31) / 32;
+    const bool first = (int)blockIdx.x < blocks_a;
+    const float* __restrict__ partials = first ? pa : pb;
+    const int n = first ? n_a : n_b;
+    const int col = (first ? blockIdx.x : blockIdx.x - blocks_a) * 32 + c;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (col < n) {
+        int p = lane_row;
+        for (; p + 24 < n_partials; p += 32) {
+            a0 += partials[(size_t)p * n + col]; a1 += partials[(size_t)(p + 8) * n + col];
+            a2 += partials[(size_t)(p + 16) * n + col]; a3 += partials[(size_t)(p + 24) * n + col];
+        }
+        for (; p < n_partials; p += 8) a0 += partials[(size_t)p * n + col];
+    }
+    s_acc[lane_row][c] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (lane_row == 0 && col < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += s_acc[r][c];
+        out[(first ? 0 : n_a) + col] = t;
+    }
+}
+
 AdamHyper adam_hyper(float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale, const int32_t* found_inf) {
     AdamHyper hp;
     hp.lr = lr; hp.beta1 = beta1; hp.beta2 = beta2; hp.eps = eps; hp.wd = wd;
@@ -388,6 +440,31 @@ int ngp_found_inf(const void* grad, int grad_is_f32, int64_t n, int32_t* flag, i
     const int blocks = (int)((n16 + 255) / 256 < 2048 ? ((n16 + 255) / 256 > 0 ? (n16 + 255) / 256 : 1) : 2048);
     hipLaunchKernelGGL(found_inf_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const u32x4*>(grad), n16,
                        reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(grad) + n16 * 16), n_tail, grad_is_f32 ? 0 : 1, flag);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_found_inf2(const void* grad_a, int a_is_f32, int64_t n_a, const void* grad_b, int b_is_f32, int64_t n_b, int32_t* flag,
+                   int32_t* flag_clear, ngp_stream_t stream) {
+    if (n_a < 0 || n_b < 0) return NGP_EINVAL;
+    NGP_CHECK_PTR(flag);
+    if (n_a > 0) NGP_CHECK_PTR(grad_a);
+    if (n_b > 0) NGP_CHECK_PTR(grad_b);
+    const long long bytes_a = (long long)n_a * (a_is_f32 ? 4 : 2), bytes_b = (long long)n_b * (b_is_f32 ? 4 : 2);
+    if ((reinterpret_cast<uintptr_t>(grad_a) & 15) || (reinterpret_cast<uintptr_t>(grad_b) & 15) || (bytes_a & 15) || (bytes_b & 15)) return NGP_EINVAL;
+    const long long n16 = (bytes_a + bytes_b) / 16;
+    const int blocks = (int)((n16 + 255) / 256 < 2048 ? ((n16 + 255) / 256 > 0 ? (n16 + 255) / 256 : 1) : 2048);
+    hipLaunchKernelGGL(found_inf2_kernel, dim3(blocks), dim3(256), 0, ngp_stream(stream), reinterpret_cast<const u32x4*>(grad_a), bytes_a / 16,
+                       a_is_f32 ? 0 : 1, reinterpret_cast<const u32x4*>(grad_b), bytes_b / 16, b_is_f32 ? 0 : 1, flag, flag_clear);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_reduce_partials2(const float* partials_a, int n_a, const float* partials_b, int n_b, int n_partials, float* out, ngp_stream_t stream) {
+    if (n_partials < 0 || n_a < 0 || n_b < 0) return NGP_EINVAL;
+    if (n_a + n_b == 0) return 0;
+    NGP_CHECK_PTR(out);
+    if (n_partials > 0) { NGP_CHECK_PTR(partials_a); NGP_CHECK_PTR(partials_b); }
+    hipLaunchKernelGGL(reduce_partials2_kernel, dim3(ngp_div_up(n_a, 32) + ngp_div_up(n_b, 32)), dim3(256), 0, ngp_stream(stream),
+                       partials_a, n_a, partials_b, n_b, n_partials, out);
     return NGP_LAUNCH_RESULT();
 }
 

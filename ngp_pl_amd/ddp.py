@@ -30,9 +30,11 @@ from . import tcnn
 
 
 class GradientExchange:
-    def __init__(self, model, dist, world, group=None, n_groups=2, ranges=None):
-        """`n_groups`: launch groups of the table backward = pieces of the grid-gradient exchange (1: one all-reduce behind
-        the whole backward).  `ranges`: their table-entry ranges [(begin, end), ...]; taken from the library's plan for the
+    def __init__(self, model, dist, world, group=None, n_groups=1, ranges=None):
+        """`n_groups`: launch groups of the table backward = pieces of the grid-gradient exchange (1, the default: one
+        all-reduce behind the whole backward.  Measured on MI355X with a 1-rank process group (profiles/r02_pg1_timeline.txt):
+        every cross-stream hand-over -- the event the collective's stream waits on, the event the main stream waits on --
+        idles the main stream for ~20 us, so a piece only pays where the transfer it hides is much longer than that).  `ranges`: their table-entry ranges [(begin, end), ...]; taken from the library's plan for the
         model's grid when not given.  EVERY rank issues the same sequence of collectives every step -- MLP block, then the
         ranges in order -- whichever path its own step took (binned groups, the one-pass fallback for oversized batches, or
         no samples at all): ranges a rank's backward did not hand over piecewise are issued in front of the optimizer."""
@@ -96,10 +98,9 @@ class GradientExchange:
         if self._small is None or self._small.device != dp.device:
             self._small = torch.empty(n_d + n_r, dtype=torch.float32, device=dp.device)
         small = self._small
-        if dp.is_cuda:                          # two launches into one buffer (torch sum/sum/cat costs ~40 us of GPU time)
+        if dp.is_cuda:                          # one launch into one buffer (the torch sum/sum/cat costs ~40 us of GPU time)
             from ._lib import call, ptr, stream
-            call("ngp_reduce_partials", ptr(dp), n_part, n_d, ptr(small), stream())
-            call("ngp_reduce_partials", ptr(rp), n_part, n_r, ptr(small[n_d:]), stream())
+            call("ngp_reduce_partials2", ptr(dp), n_d, ptr(rp), n_r, n_part, ptr(small), stream())
         else:
             small[:n_d] = dp.view(n_part, n_d).sum(0); small[n_d:] = rp.view(n_part, n_r).sum(0)
         self._work = self.dist.all_reduce(small, group=self.group, async_op=True)
@@ -148,9 +149,11 @@ class GradientExchange:
         if g16.is_cuda:
             from ._lib import call, ptr, stream
             if self._flag is None or self._flag.device != g16.device:
-                self._flag = torch.zeros(1, dtype=torch.int32, device=g16.device)
-            call("ngp_found_inf", ptr(g16), 0, g16.numel(), ptr(self._flag), 1, stream())
-            call("ngp_found_inf", ptr(small), 1, small.numel(), ptr(self._flag), 0, stream())
-            return self._flag
+                self._flag = torch.zeros(8, dtype=torch.int32, device=g16.device)     # two flags (16 bytes apart), used alternately
+                self._flag_step = 0
+            cur, nxt = self._flag[4 * (self._flag_step & 1):], self._flag[4 * ((self._flag_step + 1) & 1):]
+            self._flag_step += 1
+            call("ngp_found_inf2", ptr(g16), 0, g16.numel(), ptr(small), 1, small.numel(), ptr(cur), ptr(nxt), stream())
+            return cur
         bad = not (bool(torch.isfinite(g16.float()).all()) and bool(torch.isfinite(small).all()))
         return torch.ones(1, dtype=torch.int32) if bad else None

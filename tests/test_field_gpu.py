@@ -515,3 +515,68 @@ def test_exact_level_table_option(lib):
              lib.ptr(ws), nbytes, lib.ptr(grad), lib.stream())
     err = (grad.float().cpu() - tb.grad).abs().max().item() / tb.grad.abs().max().item()
     assert err < 1e-3, err
+
+
+def test_binned_backward_in_launch_groups(lib, field):
+    """ngp_hashgrid_bwd_binned_group: n launch groups that each complete a contiguous table range == the single launch, bit
+    for bit; a group's range is final as soon as its launch is done (what the multi-GPU exchange hands on piecewise)."""
+    meta = native_meta(lib)
+    n = 40000
+    x, _ = sample_points(n, seed=51)
+    g = torch.Generator().manual_seed(52)
+    dfe = (torch.randn(n, 32, generator=g) * 0.3).half()
+    dfl = dfe.view(n, 16, 2).permute(1, 0, 2).contiguous().cuda()
+    xs = x.cuda().contiguous()
+    mnt = torch.full((3,), -0.5, device="cuda"); mxt = torch.full((3,), 0.5, device="cuda")
+    nbytes = lib.lib().ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(meta), n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    ref = torch.full((field.meta.total, 2), float("nan"), dtype=torch.float16, device="cuda")
+    lib.call("ngp_hashgrid_bwd_binned", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), n, None, None,
+             lib.ptr(ws), nbytes, lib.ptr(ref), lib.stream())
+    for ng in (2, 3, 5):
+        out = torch.full_like(ref, float("nan"))
+        covered = 0
+        for grp in range(ng):
+            a, b = C.c_int64(), C.c_int64()
+            lib.call("ngp_hashgrid_bwd_binned_group_entries", C.byref(meta), n, ng, grp, C.byref(a), C.byref(b))
+            assert a.value == covered and b.value > a.value
+            lib.call("ngp_hashgrid_bwd_binned_group", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), n, None, None,
+                     lib.ptr(ws), nbytes, lib.ptr(out), ng, grp, lib.stream())
+            torch.cuda.synchronize()
+            assert torch.equal(out[a.value:b.value], ref[a.value:b.value]), (ng, grp)        # final right behind its own launch
+            if grp + 1 < ng:
+                assert torch.isnan(out[b.value:].float()).all()                                # later ranges untouched so far
+            covered = b.value
+        assert covered == field.meta.total and torch.equal(out, ref)
+
+
+def test_exchange_helper_kernels(lib):
+    """ngp_reduce_partials2 (both MLP blocks' partial rows in one launch) and ngp_found_inf2 (non-finite check over two
+    buffers, alternating flags)."""
+    g = torch.Generator(device="cuda").manual_seed(61)
+    n_part = 37
+    pa = torch.randn(n_part, 3072, device="cuda", generator=g); pb = torch.randn(n_part, 7168, device="cuda", generator=g)
+    out = torch.empty(10240, device="cuda")
+    lib.call("ngp_reduce_partials2", lib.ptr(pa), 3072, lib.ptr(pb), 7168, n_part, lib.ptr(out), lib.stream())
+    one = torch.empty(3072, device="cuda")
+    lib.call("ngp_reduce_partials", lib.ptr(pa), n_part, 3072, lib.ptr(one), lib.stream())
+    assert torch.equal(out[:3072], one)
+    np.testing.assert_allclose(out.cpu().numpy(), torch.cat([pa.sum(0), pb.sum(0)]).cpu().numpy(), rtol=1e-5, atol=1e-5)
+    flags = torch.zeros(8, dtype=torch.int32, device="cuda")
+    g16 = torch.randn(11445040, device="cuda", generator=g).half(); small = torch.randn(10240, device="cuda", generator=g)
+    cur, nxt = flags[0:], flags[4:]
+    nxt.fill_(7)
+    lib.call("ngp_found_inf2", lib.ptr(g16), 0, g16.numel(), lib.ptr(small), 1, small.numel(), lib.ptr(cur), lib.ptr(nxt), lib.stream())
+    assert int(flags[0]) == 0 and int(flags[4]) == 0                       # finite; the other flag was cleared
+    for buf, idx, val in ((g16, 11445039, float("inf")), (g16, 5, float("nan")), (small, 10239, float("-inf")), (small, 0, float("nan"))):
+        keep = buf[idx].clone(); buf[idx] = val
+        flags.zero_()
+        lib.call("ngp_found_inf2", lib.ptr(g16), 0, g16.numel(), lib.ptr(small), 1, small.numel(), lib.ptr(cur), lib.ptr(nxt), lib.stream())
+        assert int(flags[0]) == 1, (idx, val)
+        buf[idx] = keep
+    f1 = torch.zeros(1, dtype=torch.int32, device="cuda")
+    g16[77] = float("inf")
+    lib.call("ngp_found_inf", lib.ptr(g16), 0, g16.numel(), lib.ptr(f1), 1, lib.stream())
+    assert int(f1) == 1
+    lib.call("ngp_found_inf", lib.ptr(small), 1, small.numel(), lib.ptr(f1), 1, lib.stream())
+    assert int(f1) == 0

@@ -33,4 +33,4 @@ for i in range(200):
 pr.disable()
 torch.cuda.synchronize()
 print("ms/step %.3f" % ((time.perf_counter() - t0) / 200 * 1e3))
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(14); print(s.getvalue()[:3500])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(30); print(s.getvalue()[:6000])
