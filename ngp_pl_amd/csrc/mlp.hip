@@ -449,6 +449,81 @@ __device__ __forceinline__ void wgrad_flush(float* part, int ld, int n_rows, int
             }
 }
 
+
+// Everything a backward tile reads from global memory, as RAW register values: the loads of tile t+1 are issued before tile t
+// is computed (the kernel runs ONE wave per SIMD -- 164 VGPRs, 100 KB of LDS -- so nothing else hides a global round trip;
+// before this, every tile paid two dependent ones: active index -> inputs/seeds).
+template <int N_IN>
+struct BwdRaw {
+    long long s, j;
+    bool valid;
+    half8_t in[N_IN / 16];   // IN_ROWMAJOR / IN_LEVELMAJOR: the input B fragments; IN_SH_H: in[1] = h, in[0] unused
+    float dir[3];            // IN_SH_H
+    float seed[3];           // OUT_RGB: dL_drgbs; OUT_DENSITY: seed[0] = dL_dsigmas
+    h1 dout[8];              // OUT_PLAIN / OUT_DENSITY: dL_dout16 at units 4hh + (r&3) + 8(r>>2)
+};
+
+template <int N_IN, int IN_MODE, int OUT_MODE>
+__device__ __forceinline__ void bwd_fetch(const MlpBwdIO& io, long long j, long long s, bool valid, int n_samples, int hh, BwdRaw<N_IN>& r) {
+    const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+    r.s = s; r.j = j; r.valid = valid;
+#pragma unroll
+    for (int c = 0; c < N_IN / 16; ++c) r.in[c] = z;
+    r.dir[0] = r.dir[1] = r.dir[2] = 1.0f;
+    r.seed[0] = r.seed[1] = r.seed[2] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) r.dout[q] = (h1)0;
+    if (!valid) return;
+    if (IN_MODE == IN_ROWMAJOR) {
+#pragma unroll
+        for (int c = 0; c < N_IN / 16; ++c) r.in[c] = *reinterpret_cast<const half8_t*>(io.fwd.in + s * N_IN + 16 * c + 8 * hh);
+    } else if (IN_MODE == IN_LEVELMAJOR) {
+        const half2_t* f = reinterpret_cast<const half2_t*>(io.fwd.in);
+#pragma unroll
+        for (int c = 0; c < N_IN / 16; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const half2_t v = __builtin_nontemporal_load(f + (size_t)(8 * c + 4 * hh + q) * n_samples + s);
+                r.in[c][2 * q] = v[0]; r.in[c][2 * q + 1] = v[1];
+            }
+    } else {
+        r.dir[0] = io.fwd.dirs[3 * s]; r.dir[1] = io.fwd.dirs[3 * s + 1]; r.dir[2] = io.fwd.dirs[3 * s + 2];
+        r.in[1] = *reinterpret_cast<const half8_t*>(io.fwd.in + s * 16 + 8 * hh);
+    }
+    if (OUT_MODE == OUT_RGB) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) r.seed[c] = io.dL_drgbs[3 * s + c];
+    } else {
+        if (io.dL_dout16) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int u = 4 * hh + (q & 3) + 8 * (q >> 2);
+                if (u < io.fwd.n_out) r.dout[q] = io.dL_dout16[j * io.dout_ld + u];
+            }
+        }
+        if (OUT_MODE == OUT_DENSITY && io.dL_dsigmas) r.seed[0] = io.dL_dsigmas[s];
+    }
+}
+
+// raw tile -> input B fragments (natural K order), as load_input() forms them
+template <int N_IN, int IN_MODE>
+__device__ __forceinline__ void bwd_input(const BwdRaw<N_IN>& r, int hh, half8_t (&b)[N_IN / 16]) {
+#pragma unroll
+    for (int c = 0; c < N_IN / 16; ++c) b[c] = r.in[c];
+    if (IN_MODE == IN_SH_H) {
+        const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+        b[0] = z;
+        if (r.valid) {
+            const float dx = r.dir[0], dy = r.dir[1], dz = r.dir[2];
+            const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+            float sh[16];
+            sh4(dx * inv, dy * inv, dz * inv, sh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b[0][e] = (h1)(hh ? sh[8 + e] : sh[e]);
+        }
+    }
+}
+
 template <int N_IN, int N_HIDDEN, int IN_MODE, int OUT_MODE>
 __global__ void __launch_bounds__(64 * WAVES)
 mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
@@ -493,13 +568,33 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
     }
     gWo[0][0] = zero16(); gWo[0][1] = zero16();
 
-    for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
-        const long long j = (long long)tile * TILE + i;       // compact position
-        const bool valid = j < n_eff;
-        const long long s = (io.active && valid) ? (long long)io.active[j] : j;   // sample id
+    // two-deep software pipeline over the wave's tiles: sample id of tile t+2 and raw inputs of tile t+1 are in flight while
+    // tile t is computed
+    const int tile_stride = gridDim.x * WAVES;
+    auto sample_of = [&](int t, long long& jj, bool& vv) -> long long {
+        jj = (long long)t * TILE + i;                            // compact position
+        vv = t < n_tiles && jj < n_eff;
+        return (io.active && vv) ? (long long)io.active[jj] : jj;   // sample id
+    };
+    BwdRaw<N_IN> cur, nxt;
+    long long j_pre; bool v_pre;
+    long long s_pre;
+    {
+        const int t0 = blockIdx.x * WAVES + wave;
+        long long j0; bool v0;
+        const long long s0 = sample_of(t0, j0, v0);
+        bwd_fetch<N_IN, IN_MODE, OUT_MODE>(io, j0, s0, v0, n_samples, hh, cur);
+        s_pre = sample_of(t0 + tile_stride, j_pre, v_pre);
+    }
+    for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += tile_stride) {
+        bwd_fetch<N_IN, IN_MODE, OUT_MODE>(io, j_pre, s_pre, v_pre, n_samples, hh, nxt);          // tile + stride
+        s_pre = sample_of(tile + 2 * tile_stride, j_pre, v_pre);                                   // tile + 2 strides
+        const long long j = cur.j;
+        const bool valid = cur.valid;
+        const long long s = cur.s;
         // ---- forward recompute ----
         half8_t xb[N_IN / 16];
-        load_input<N_IN, IN_MODE>(io.fwd, s, valid, n_samples, hh, xb);
+        bwd_input<N_IN, IN_MODE>(cur, hh, xb);
         f32x16 acc[2];
         half8_t h0b[4], h1b[4];
         layer_in<N_IN>(lds + L::OFF_W0, xb, i, hh, acc);
@@ -527,21 +622,18 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
                             const float sg = sigmoidf(o[0][c]);
-                            dyb[0][c] = (h1)(io.dL_drgbs[3 * s + c] * io.loss_scale * sg * (1.0f - sg));
+                            dyb[0][c] = (h1)(cur.seed[c] * io.loss_scale * sg * (1.0f - sg));
                         }
                     }
                 } else {
                     float g[8];
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        const int u = 4 * hh + (r & 3) + 8 * (r >> 2);
-                        g[r] = (io.dL_dout16 && u < io.fwd.n_out) ? (float)io.dL_dout16[j * io.dout_ld + u] : 0.f;
-                    }
+                    for (int r = 0; r < 8; ++r) g[r] = (float)cur.dout[r];
                     if (OUT_MODE == OUT_DENSITY) {
                         if (hh == 0 && io.dL_dsigmas) {
                             // TruncExp backward (custom_functions.py:168-173) on the f16 h[0]
                             const float h0 = (float)(h1)o[0][0];
-                            g[0] += io.dL_dsigmas[s] * io.loss_scale * __expf(fminf(fmaxf(h0, -15.f), 15.f));
+                            g[0] += cur.seed[0] * io.loss_scale * __expf(fminf(fmaxf(h0, -15.f), 15.f));
                         }
                     } else if (io.fwd.out_act == 1) {
 #pragma unroll
@@ -659,6 +751,7 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
         wave_lds_sync();
         wgrad_tile<1, 2>(tdy, tx, i, hh, gWo);
         wave_lds_sync();
+        cur = nxt;
     }
     // ---- reduce the 4 waves' dW into LDS (one wave at a time), then one coalesced partial row per workgroup ----
     constexpr int NT0 = (N_IN / 32 > 0 ? N_IN / 32 : 1);

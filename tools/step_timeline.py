@@ -21,8 +21,13 @@ qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols
 rows = list(db.execute("select name, start, end%s from kernels order by start" % ((", " + qcol) if qcol else "")))
 marks = [i for i, r in enumerate(rows) if "adam_field_kernel" in r[0]]
 skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-last = marks[-1 - skip]
-first = marks[-1 - skip - n_steps] + 1
+if len(sys.argv) > 4:            # window around the last launch of a named kernel (e.g. occ_scan_kernel: an occupancy update)
+    hit = [i for i, r in enumerate(rows) if sys.argv[4] in r[0]][-1]
+    k = max(j for j in range(len(marks)) if marks[j] < hit)
+    first, last = marks[k - 1] + 1, marks[min(k + 1, len(marks) - 1)]
+else:
+    last = marks[-1 - skip]
+    first = marks[-1 - skip - n_steps] + 1
 t0 = rows[first][1]
 prev_end = t0
 for r in rows[first:last + 1]:
