@@ -233,6 +233,13 @@ int ngp_grid_meta_init(ngp_grid_meta* meta, int n_levels, int n_features, int lo
 int ngp_hashgrid_fwd(const float* x, const float* xyz_min, const float* xyz_max,
                      const ngp_half* table, const ngp_grid_meta* meta, int n_samples,
                      ngp_half* feats, ngp_stream_t stream);
+/* Measured alternative for the coarse levels (not used by the default path): the first n_lds_levels levels
+ * -- dense, together at most 150 KB of half2: levels 0-2 of the reference configuration -- are gathered from tables RESIDENT IN
+ * LDS (one persistent 1024-thread workgroup per CU stages them once).  Writes rows 0 .. n_lds_levels-1 of feats [L][S] half2,
+ * bit-identical to ngp_hashgrid_fwd's. */
+int ngp_hashgrid_fwd_lds(const float* x, const float* xyz_min, const float* xyz_max,
+                         const ngp_half* table, const ngp_grid_meta* meta, int n_lds_levels,
+                         int n_samples, ngp_half* feats, ngp_stream_t stream);
 /* Same with a DEVICE-side sample count (sync-free callers): the launch covers n_samples_max,
  * n_dev[0] (i32, <= n_samples_max) is the real count and the level stride of feats. */
 int ngp_hashgrid_fwd_n(const float* x, const float* xyz_min, const float* xyz_max,

@@ -50,6 +50,7 @@ _PROTOS = {
     "ngp_distortion_loss_bw": [P, P, P, P, P, P, P, I, I, P, P],
     "ngp_grid_meta_init": [C.POINTER(GridMeta), I, I, I, I, F],
     "ngp_hashgrid_fwd": [P, P, P, P, C.POINTER(GridMeta), I, P, P],
+    "ngp_hashgrid_fwd_lds": [P, P, P, P, C.POINTER(GridMeta), I, I, P, P],
     "ngp_hashgrid_bwd": [P, P, P, P, C.POINTER(GridMeta), I, P, I, P],
     "ngp_hashgrid_bwd_sliced": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P, P],
     "ngp_active_samples": [P, P, I, P, P, P, P],

@@ -119,6 +119,52 @@ hashgrid_fwd_kernel(const float* __restrict__ x, const float* __restrict__ xyz_m
     }
 }
 
+
+// ---- coarse levels with their tables RESIDENT IN LDS (north_star: "8-corner trilinear gather staged through LDS") ----------
+// Levels 0 .. n_lds-1 of the reference configuration are dense and small (16^3, 22^3, 28^3 entries: 16 + 43 + 88 = 147 KB of
+// half2, inside one CU's 160 KB): a persistent 1024-thread workgroup per CU copies them into LDS once and serves every gather
+// of those levels from there (ds_read_b32 instead of the texture addresser + L2).  Same arithmetic as hashgrid_fwd_kernel,
+// bit-identical features.  Measured against the L2 path in profiles/r02_hashgrid_fwd_lds_experiment.txt.
+__global__ void __launch_bounds__(1024)
+hashgrid_fwd_lds_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const float* __restrict__ xyz_max,
+                        const half2_t* __restrict__ table, GridMeta meta, int n_lds, int n_samples, int feat_stride,
+                        half2_t* __restrict__ feats) {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    half2_t* tab = reinterpret_cast<half2_t*>(lds_raw);
+    const uint32_t total = meta.offset[n_lds];
+    {   // 16-byte staging loads; the level tables are contiguous and 8-entry aligned
+        const uint4* src = reinterpret_cast<const uint4*>(table);
+        uint4* dst = reinterpret_cast<uint4*>(lds_raw);
+        for (uint32_t k = threadIdx.x; k < total / 4; k += blockDim.x) dst[k] = src[k];
+    }
+    __syncthreads();
+    const Box box = load_box(xyz_min, xyz_max);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_samples; i += gridDim.x * blockDim.x) {
+        const float xin[3] = {__builtin_nontemporal_load(x + 3 * (size_t)i), __builtin_nontemporal_load(x + 3 * (size_t)i + 1),
+                              __builtin_nontemporal_load(x + 3 * (size_t)i + 2)};
+        for (int level = 0; level < n_lds; ++level) {
+            const uint32_t res = meta.resolution[level];
+            const uint32_t size = meta.offset[level + 1] - meta.offset[level];
+            uint32_t p[3], idx[8]; float f[3];
+            cell_of_loaded(xin, box, meta.scale[level], p, f);
+            corner_indices<false>(p, res, size, idx);
+            const half2_t* __restrict__ t = tab + meta.offset[level];
+            half2_t v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = t[idx[c]];
+            float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float w = corner_weight(c, f);
+                o0 = fmaf(w, (float)v[c][0], o0);
+                o1 = fmaf(w, (float)v[c][1], o1);
+            }
+            half2_t out; out[0] = (_Float16)o0; out[1] = (_Float16)o1;
+            __builtin_nontemporal_store(out, feats + (size_t)level * feat_stride + i);
+        }
+    }
+}
+
 // ---- backward w.r.t. the input positions (pose optimisation, train.py:86-89,117-122) -------------
 // tiny-cuda-nn's grid backward-input for linear interpolation: d feat / d pos_k =
 // sum over corners of (+-1 along k) * (the other two weights) * value; chain: pos = x01*scale + 0.5,
@@ -498,6 +544,32 @@ int ngp_grid_meta_init(ngp_grid_meta* meta, int n_levels, int n_features, int lo
     }
     for (int l = n_levels; l <= NGP_MAX_LEVELS; ++l) meta->offset[l] = off;
     return 0;
+}
+
+int ngp_hashgrid_fwd_lds(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* table,
+                         const ngp_grid_meta* meta, int n_lds_levels, int n_samples, ngp_half* feats, ngp_stream_t stream) {
+    if (n_samples < 0 || !meta || meta->n_features != 2 || n_lds_levels < 1 || n_lds_levels > meta->n_levels) return NGP_EINVAL;
+    if (n_samples == 0) return 0;
+    NGP_CHECK_PTR(x); NGP_CHECK_PTR(xyz_min); NGP_CHECK_PTR(xyz_max); NGP_CHECK_PTR(table); NGP_CHECK_PTR(feats);
+    const size_t bytes = (size_t)meta->offset[n_lds_levels] * 4;
+    if (bytes > 150 * 1024 || (meta->offset[n_lds_levels] & 3)) return NGP_EUNSUP;                    // must fit one CU's LDS next to nothing else
+    for (int l = 0; l < n_lds_levels; ++l) {
+        const uint64_t res = meta->resolution[l];
+        if (res * res * res > meta->offset[l + 1] - meta->offset[l]) return NGP_EUNSUP;               // dense levels only
+    }
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hashgrid_fwd_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set[dev] = true;
+    }
+    const int blocks = ngp_div_up(n_samples, 1024) < 256 ? ngp_div_up(n_samples, 1024) : 256;
+    hipLaunchKernelGGL(hashgrid_fwd_lds_kernel, dim3(blocks), dim3(1024), bytes, ngp_stream(stream), x, xyz_min, xyz_max, (const half2_t*)table,
+                       to_dev_meta(meta), n_lds_levels, n_samples, n_samples, (half2_t*)feats);
+    return NGP_LAUNCH_RESULT();
 }
 
 int ngp_hashgrid_fwd(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* table,

@@ -665,7 +665,7 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool SIMPLE>
+template <bool SIMPLE, int NMAX>
 __global__ void __launch_bounds__(64)
 render_march_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                     float* __restrict__ hits, const int32_t* __restrict__ alive, int32_t* __restrict__ emitted,
@@ -673,7 +673,7 @@ render_march_kernel(const float* __restrict__ rays_o, const float* __restrict__ 
                     int max_samples_total, int probe_cap,
                     float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas,
                     float* __restrict__ ts, int32_t* __restrict__ n_eff, int32_t* __restrict__ offsets) {
-    __shared__ float s_t[64 * 64];          // [sample][lane]
+    __shared__ float s_t[NMAX * 64];        // [sample][lane]; 16 KiB at NMAX = 64 allows two of these waves per SIMD, 8 KiB four
     __shared__ float s_ray[6 * 64];
     __shared__ int s_incl[64];
     // rendering.py:65 `while samples < max_samples`: `samples` grows by N per iteration.  With a probe
@@ -682,7 +682,7 @@ render_march_kernel(const float* __restrict__ rays_o, const float* __restrict__ 
     const int done = (probe_cap <= 0) ? plan->samples_done : 0;
     const int n_alive = (done < max_samples_total) ? plan->n_alive_raw : 0;
     int N = 0;
-    if (n_alive > 0) N = max(min((int)(((long long)chunk_scale * n_rays) / n_alive), 64), min_samples);
+    if (n_alive > 0) N = max(min((int)(((long long)chunk_scale * n_rays) / n_alive), NMAX), min_samples);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         plan->n_alive = n_alive; plan->n_step = N;
         plan[1].samples_done = done + N;
@@ -1182,14 +1182,18 @@ int ngp_render_test_frame(const float* rays_o, const float* rays_d, const float*
         }
         RenderPlan* pl = plan + it;
         const dim3 mgrid(ngp_div_up(bound, 64));
-        if (p.simple)
-            hipLaunchKernelGGL(render_march_kernel<true>, mgrid, dim3(64), 0, st, rays_o, rays_d, hits, alive[it & 1], emitted, p, pl, n_rays,
-                               chunk_scale, min_samples, max_samples, probe_cap, xyzs, dirs, deltas, ts, n_eff, offsets);
-        else
-            hipLaunchKernelGGL(render_march_kernel<false>, mgrid, dim3(64), 0, st, rays_o, rays_d, hits, alive[it & 1], emitted, p, pl, n_rays,
-                               chunk_scale, min_samples, max_samples, probe_cap, xyzs, dirs, deltas, ts, n_eff, offsets);
+        // the reference's chunking (chunk_scale 1, no probe cap) takes up to 64 samples per ray and iteration (rendering.py:72); the
+        // regrouping modes cap a ray's samples per iteration at 32, which halves the marcher's LDS tile and doubles its waves per CU
+        static const bool nmax64 = [] { const char* e = getenv("NGP_RENDER_NMAX64"); return e && atoi(e) != 0; }();      // A/B switch
+        const bool regroup = (chunk_scale > 1 || probe_cap > 0) && !nmax64;
+#define NGP_RENDER_MARCH(S, NM) hipLaunchKernelGGL((render_march_kernel<S, NM>), mgrid, dim3(64), 0, st, rays_o, rays_d, hits, alive[it & 1], emitted, p, pl, \
+                                                   n_rays, chunk_scale, min_samples, max_samples, probe_cap, xyzs, dirs, deltas, ts, n_eff, offsets)
+        if (p.simple) { if (regroup) NGP_RENDER_MARCH(true, 32); else NGP_RENDER_MARCH(true, 64); }
+        else { if (regroup) NGP_RENDER_MARCH(false, 32); else NGP_RENDER_MARCH(false, 64); }
+#undef NGP_RENDER_MARCH
+        const int n_max = regroup ? 32 : 64;
         long long m_bound = (long long)chunk_scale * n_rays;
-        if (64 * bound < m_bound) m_bound = 64 * bound;
+        if (n_max * bound < m_bound) m_bound = n_max * bound;
         if ((long long)min_samples * bound > m_bound) m_bound = (long long)min_samples * bound;
         if (m_bound > L.m_cap) m_bound = L.m_cap;
         rc = ngp_hashgrid_fwd_n(xyzs, xyz_min, xyz_max, table, meta, (int)m_bound, &pl->m, feats, stream);

@@ -580,3 +580,20 @@ def test_exchange_helper_kernels(lib):
     assert int(f1) == 1
     lib.call("ngp_found_inf", lib.ptr(small), 1, small.numel(), lib.ptr(f1), 1, lib.stream())
     assert int(f1) == 0
+
+
+def test_lds_resident_coarse_levels_forward_is_bit_identical(lib, field):
+    """ngp_hashgrid_fwd_lds (levels 0-2 gathered from tables resident in LDS, the measured alternative of
+    profiles/r02_hashgrid_fwd_lds_experiment.txt) produces exactly ngp_hashgrid_fwd's features for those levels."""
+    meta = native_meta(lib)
+    for n in (1, 777, 200000):
+        x, _ = sample_points(n, seed=71)
+        table_h = field.table.half().cuda()
+        ref = run_hash_fwd(lib, meta, x, table_h)
+        out = torch.zeros_like(ref)
+        xs = x.cuda().contiguous()
+        mnt = torch.full((3,), -0.5, device="cuda"); mxt = torch.full((3,), 0.5, device="cuda")
+        lib.call("ngp_hashgrid_fwd_lds", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(table_h), C.byref(meta), 3, n, lib.ptr(out), lib.stream())
+        assert torch.equal(out[:3], ref[:3]) and (out[3:] == 0).all()
+    with pytest.raises(lib.NgpError):           # level 6 is hashed and the first 7 levels do not fit a CU's LDS
+        lib.call("ngp_hashgrid_fwd_lds", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(table_h), C.byref(meta), 7, n, lib.ptr(out), lib.stream())
