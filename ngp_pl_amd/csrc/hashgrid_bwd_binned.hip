@@ -410,7 +410,10 @@ bool make_plan(const ngp_grid_meta* meta, int n_samples, BinPlan& P, BinLayout& 
         const bool hashed = (uint64_t)res * res * res > size;
         const int ns = (int)((size + SLICE2 - 1) / SLICE2);
         P.n_slices[l] = ns;
-        P.k_split[l] = hashed ? 1 : (ns == 1 ? 16 : ns == 2 ? 8 : 4);      // dense: a z-slab can hold most of the scene's samples (64/ns tasks measured slower)
+#ifndef NGP_DENSE_K_BIG
+#define NGP_DENSE_K_BIG 4
+#endif
+        P.k_split[l] = hashed ? 1 : (ns == 1 ? 16 : ns == 2 ? 8 : NGP_DENSE_K_BIG);      // dense: a z-slab can hold most of the scene's samples (64/ns tasks measured slower)
         // relative cost of one task: a dense slice (a slab of the grid) gets all 8 corners of its samples, a hashed one ~2
         cost[l] = hashed ? 1.0 : 4.0;
     }
