@@ -419,7 +419,9 @@ int ngp_adam_step_partials(float* param, ngp_half* param_h, const float* partial
 /* The optimizer step of the whole field in ONE launch (train.py:131 hands every parameter of the
  * model to one FusedAdam): ngp_adam_step (f16 gradient) on the grid table and
  * ngp_adam_step_partials on the density and rgb MLP blocks, bit-identical to the three separate
- * calls.  The MLP workgroups are dispatched first and run underneath the HBM-bound grid pass. */
+ * calls.  The MLP workgroups are dispatched first and run underneath the HBM-bound grid pass.
+ * zero_grid_grad = 0 leaves grid_grad as it is (28 instead of 30 bytes per parameter): the sliced / binned table
+ * backwards OVERWRITE the whole gradient table every step, only accumulating producers (ngp_hashgrid_bwd) need it cleared. */
 int ngp_adam_step_field(float* grid_param, ngp_half* grid_param_h, ngp_half* grid_grad,
                         float* grid_m, float* grid_v, int64_t n_grid,
                         float* density_param, ngp_half* density_param_h,
@@ -428,8 +430,8 @@ int ngp_adam_step_field(float* grid_param, ngp_half* grid_param_h, ngp_half* gri
                         float* rgb_param, ngp_half* rgb_param_h, const float* rgb_partials,
                         float* rgb_m, float* rgb_v, int n_rgb,
                         int n_partials, float lr, float beta1, float beta2, float eps,
-                        float weight_decay, int step, float grad_scale, const int32_t* found_inf,
-                        ngp_stream_t stream);
+                        float weight_decay, int step, float grad_scale, int zero_grid_grad,
+                        const int32_t* found_inf, ngp_stream_t stream);
 /* GradScaler's non-finite check (train.py:274 precision=16 -> torch.amp.GradScaler.unscale_) on a native
  * gradient buffer of n elements (f16, or f32 if grad_is_f32; 16-byte aligned): flag[0] (device i32) |= 1 if any
  * element is inf or NaN; reset != 0 zeroes the flag first.  Used behind the multi-GPU all-reduce, whose f16

@@ -69,7 +69,7 @@ _PROTOS = {
     "ngp_feats_from_rowmajor": [P, I, I, P, P],
     "ngp_adam_step": [P, P, P, I, P, P, L, F, F, F, F, F, I, F, P, P],
     "ngp_adam_step_partials": [P, P, P, I, P, P, I, F, F, F, F, F, I, F, P, P],
-    "ngp_adam_step_field": [P, P, P, P, P, L, P, P, P, P, P, I, P, P, P, P, P, I, I, F, F, F, F, F, I, F, P, P],
+    "ngp_adam_step_field": [P, P, P, P, P, L, P, P, P, P, P, I, P, P, P, P, P, I, I, F, F, F, F, F, I, F, I, P, P],
     "ngp_reduce_partials": [P, I, I, P, P],
     "ngp_found_inf": [P, I, L, P, I, P],
     "ngp_found_inf2": [P, I, L, P, I, L, P, P, P],

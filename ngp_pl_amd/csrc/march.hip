@@ -942,7 +942,7 @@ thread_local RenderHost g_render_host;
 extern "C" {
 #pragma GCC visibility push(default)
 
-int ngp_abi_version(void) { return 1; }
+int ngp_abi_version(void) { return 2; }
 const char* ngp_build_arch(void) { return "gfx950"; }
 
 int ngp_ray_aabb_intersect(const float* rays_o, const float* rays_d, const float* centers,

@@ -16,7 +16,7 @@ typedef _Float16 h1;
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-struct AdamHyper { float lr, beta1, beta2, eps, wd, bc1, bc2, inv_scale; const int32_t* found_inf; };
+struct AdamHyper { float lr, beta1, beta2, eps, wd, bc1, bc2, inv_scale; const int32_t* found_inf; int zero_grad; };
 
 // Dense (streaming) update of n parameters by workgroups `block` of `n_blocks`, 4 parameters per thread and trip.
 template <bool GRAD_F32>
@@ -34,11 +34,11 @@ __device__ __forceinline__ void adam_dense(float* __restrict__ param, h1* __rest
             if (GRAD_F32) {
                 float4* gp = reinterpret_cast<float4*>(reinterpret_cast<float*>(grad) + base);
                 const float4 t = *gp; g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w;
-                *gp = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (hp.zero_grad) *gp = make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
                 half4_t* gp = reinterpret_cast<half4_t*>(reinterpret_cast<h1*>(grad) + base);
                 const half4_t t = *gp; g[0] = (float)t[0]; g[1] = (float)t[1]; g[2] = (float)t[2]; g[3] = (float)t[3];
-                const half4_t z = {0, 0, 0, 0}; *gp = z;
+                if (hp.zero_grad) { const half4_t z = {0, 0, 0, 0}; *gp = z; }
             }
             if (skip) continue;
             float4 p = *reinterpret_cast<float4*>(param + base);
@@ -63,8 +63,8 @@ __device__ __forceinline__ void adam_dense(float* __restrict__ param, h1* __rest
             for (int k = 0; k < cnt; ++k) {
                 const long long i = base + k;
                 float gk;
-                if (GRAD_F32) { float* gp = reinterpret_cast<float*>(grad) + i; gk = *gp; *gp = 0.f; }
-                else { h1* gp = reinterpret_cast<h1*>(grad) + i; gk = (float)*gp; *gp = (h1)0; }
+                if (GRAD_F32) { float* gp = reinterpret_cast<float*>(grad) + i; gk = *gp; if (hp.zero_grad) *gp = 0.f; }
+                else { h1* gp = reinterpret_cast<h1*>(grad) + i; gk = (float)*gp; if (hp.zero_grad) *gp = (h1)0; }
                 if (skip) continue;
                 gk *= inv_scale;
                 const float mk = beta1 * m[i] + (1.f - beta1) * gk;
@@ -366,7 +366,7 @@ AdamHyper adam_hyper(float lr, float beta1, float beta2, float eps, float wd, in
     AdamHyper hp;
     hp.lr = lr; hp.beta1 = beta1; hp.beta2 = beta2; hp.eps = eps; hp.wd = wd;
     hp.bc1 = 1.0f - powf(beta1, (float)step); hp.bc2 = 1.0f - powf(beta2, (float)step);
-    hp.inv_scale = 1.0f / grad_scale; hp.found_inf = found_inf;
+    hp.inv_scale = 1.0f / grad_scale; hp.found_inf = found_inf; hp.zero_grad = 1;
     return hp;
 }
 
@@ -410,13 +410,14 @@ int ngp_adam_step_field(float* grid_param, ngp_half* grid_param_h, ngp_half* gri
                         float* density_param, ngp_half* density_param_h, const float* density_partials, float* density_m,
                         float* density_v, int n_density, float* rgb_param, ngp_half* rgb_param_h, const float* rgb_partials,
                         float* rgb_m, float* rgb_v, int n_rgb, int n_partials, float lr, float beta1, float beta2, float eps,
-                        float weight_decay, int step, float grad_scale, const int32_t* found_inf, ngp_stream_t stream) {
+                        float weight_decay, int step, float grad_scale, int zero_grid_grad, const int32_t* found_inf, ngp_stream_t stream) {
     if (n_grid <= 0 || n_density <= 0 || n_rgb <= 0 || n_partials < 0 || step < 1 || grad_scale == 0.f) return NGP_EINVAL;
     NGP_CHECK_PTR(grid_param); NGP_CHECK_PTR(grid_grad); NGP_CHECK_PTR(grid_m); NGP_CHECK_PTR(grid_v);
     NGP_CHECK_PTR(density_param); NGP_CHECK_PTR(density_m); NGP_CHECK_PTR(density_v);
     NGP_CHECK_PTR(rgb_param); NGP_CHECK_PTR(rgb_m); NGP_CHECK_PTR(rgb_v);
     if (n_partials > 0) { NGP_CHECK_PTR(density_partials); NGP_CHECK_PTR(rgb_partials); }
-    const AdamHyper hp = adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale, found_inf);
+    AdamHyper hp = adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale, found_inf);
+    hp.zero_grad = zero_grid_grad != 0;
     const long long n4 = (n_grid + 3) / 4;
     const int dense_blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
     const AdamMlp a = {density_param, (h1*)density_param_h, density_partials, density_m, density_v, n_density, ngp_div_up(n_density, 32)};

@@ -55,7 +55,7 @@ class FusedAdam:
             call("ngp_adam_step_field", p_enc + 4 * ne, p_half + 2 * ne, ptr(nat["grid16"]), p_m + 4 * ne, p_v + 4 * ne, enc.n_grid,
                  p_enc, p_half, ptr(nat["density_partials"]), p_m, p_v, ne,
                  net.params.data_ptr(), net._half.t.data_ptr(), ptr(nat["rgb_partials"]), rm.data_ptr(), rv.data_ptr(), net.params.numel(),
-                 nat["n_partials"], lr, b1, b2, self.eps, self.weight_decay, self.t, total_scale, ptr(found_inf), sq)
+                 nat["n_partials"], lr, b1, b2, self.eps, self.weight_decay, self.t, total_scale, 0, ptr(found_inf), sq)      # 0: every table backward of this package overwrites the gradient
         model._native = None
 
 

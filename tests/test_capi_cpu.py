@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert set(names) <= exported, sorted(set(names) - exported)
     assert exported <= set(names), "exported but undeclared: %s" % sorted(exported - set(names))
     assert set(_lib.exported_symbols()) == set(names)          # the ctypes table covers the whole header
-    assert lib.ngp_abi_version() == 1 and lib.ngp_build_arch() == b"gfx950"
+    assert lib.ngp_abi_version() == 2 and lib.ngp_build_arch() == b"gfx950"
 
 
 def test_code_object_is_gfx950_only():
@@ -143,8 +143,8 @@ def test_workspace_queries_and_new_entry_points_validate_on_host():
     # whole-field Adam: all three blocks must exist, step is 1-based
     field = [0x1000] * 5 + [100] + [0x1000] * 5 + [64] + [0x1000] * 5 + [64, 4, 1e-2, 0.9, 0.999, 1e-15, 0.0]
     with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
-        _lib.call("ngp_adam_step_field", *(field + [0, 1.0, None, None]))
+        _lib.call("ngp_adam_step_field", *(field + [0, 1.0, 1, None, None]))
     with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
-        _lib.call("ngp_adam_step_field", *(field[:5] + [0] + field[6:] + [1, 1.0, None, None]))
+        _lib.call("ngp_adam_step_field", *(field[:5] + [0] + field[6:] + [1, 1.0, 1, None, None]))
     with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
-        _lib.call("ngp_adam_step_field", *([None] + field[1:] + [1, 1.0, None, None]))
+        _lib.call("ngp_adam_step_field", *([None] + field[1:] + [1, 1.0, 1, None, None]))

@@ -176,14 +176,27 @@ def test_adam_field_launch_is_bit_identical_to_the_three_separate_launches():
     call("ngp_adam_step_partials", ptr(d[0]), ptr(d[1]), ptr(pd), rows, ptr(d[2]), ptr(d[3]), n_d, *hyper)
     call("ngp_adam_step", ptr(g[0]), ptr(g[1]), ptr(ref_grad), 0, ptr(g[2]), ptr(g[3]), n_grid, *hyper)
     call("ngp_adam_step_partials", ptr(r[0]), ptr(r[1]), ptr(pr), rows, ptr(r[2]), ptr(r[3]), n_r, *hyper)
+    keep = [[t.clone() for t in s] for s in (grid, dens, rgb)]
+    grad_keep = grad.clone()
     call("ngp_adam_step_field", ptr(grid[0]), ptr(grid[1]), ptr(grad), ptr(grid[2]), ptr(grid[3]), n_grid,
          ptr(dens[0]), ptr(dens[1]), ptr(pd), ptr(dens[2]), ptr(dens[3]), n_d,
-         ptr(rgb[0]), ptr(rgb[1]), ptr(pr), ptr(rgb[2]), ptr(rgb[3]), n_r, rows, *hyper)
+         ptr(rgb[0]), ptr(rgb[1]), ptr(pr), ptr(rgb[2]), ptr(rgb[3]), n_r, rows, *hyper[:7], 1, *hyper[7:])
     torch.cuda.synchronize()
     for got, want in zip((grid, dens, rgb), ref):
         for a, b in zip(got, want):
             assert torch.equal(a, b)
     assert torch.equal(grad, ref_grad) and not grad.any()
+    # zero_grid_grad = 0 (what the trainer passes: its table backwards overwrite the gradient): same update, gradient left alone
+    g2, d2, r2 = keep
+    before = grad_keep.clone()
+    call("ngp_adam_step_field", ptr(g2[0]), ptr(g2[1]), ptr(grad_keep), ptr(g2[2]), ptr(g2[3]), n_grid,
+         ptr(d2[0]), ptr(d2[1]), ptr(pd), ptr(d2[2]), ptr(d2[3]), n_d,
+         ptr(r2[0]), ptr(r2[1]), ptr(pr), ptr(r2[2]), ptr(r2[3]), n_r, rows, *hyper[:7], 0, *hyper[7:])
+    torch.cuda.synchronize()
+    for got, want in zip(keep, ref):
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+    assert torch.equal(grad_keep, before) and bool(grad_keep.any())
     assert torch.equal(grid[1], grid[0].half()) and bool(grid[1].any())    # the update happened and refreshed the working copy
 
 
