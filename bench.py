@@ -238,7 +238,7 @@ def kernel_roofline(loop, n_steps=ROOFLINE_STEPS):
     algo = {   # bytes per launch
         "march_count(side stream)": 60.0 * R + 4.0 * S, "march_write": 32.0 * S, "hashgrid_fwd": 588.0 * S, "mlp_fwd": 210.0 * S,
         "composite_fw+loss": 28.0 * S + 52.0 * R, "composite_bw": 52.0 * S + 64.0 * R + 24.0 * A, "mlp_bwd": 300.0 * A,
-        "hashgrid_bwd": 1100.0 * A, "adam": 30.0 * n_params, "grid_update": 0.0,
+        "hashgrid_bwd": 1100.0 * A, "adam": 28.0 * n_params, "grid_update": 0.0,
     }
     stages = []
     for name, ms in acc.items():
