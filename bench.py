@@ -33,6 +33,7 @@ Without a GPU (`--dry-run`, implied when none is visible) only the launcher and 
 exercised (gloo): the product path has no CPU fallback.
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -174,8 +175,18 @@ class Loop:
 
     def timed(self, n):
         """n steps bracketed by barrier + synchronize; seconds, max over ranks.  Also the HIP-event time of the same
-        window on the main stream (the stream every kernel of the step but the march is launched on)."""
+        window on the main stream (the stream every kernel of the step but the march is launched on).  Python's cyclic
+        garbage collector is held off inside the window (a generation-2 pass was seen to stall the enqueueing thread for
+        35 ms, i.e. 70 steps' worth, at a fixed step of this script)."""
         self.fence()
+        gc.collect()
+        gc.disable()
+        try:
+            return self._timed(n)
+        finally:
+            gc.enable()
+
+    def _timed(self, n):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         e0.record()
@@ -227,13 +238,18 @@ def kernel_roofline(loop, n_steps=ROOFLINE_STEPS):
     n_params = trainer.model.xyz_encoder.params.numel() + trainer.model.rgb_net.params.numel()
     acc, S_acc, A_acc, R = {}, 0, 0, loop.rays
     trainer.events = []
+    gc.collect()
+    gc.disable()
     for _ in range(n_steps):
         loop.steps(1)
         for name, ms in trainer.stage_times_ms():
             acc[name] = acc.get(name, 0.0) + ms
+            if os.environ.get("NGP_BENCH_DEBUG") and name == "grid_update":
+                print("[debug] step %d grid_update %.3f ms" % (trainer.global_step, ms), file=sys.stderr)
         S_acc += trainer.last["rm_samples"]
         A_acc += int(trainer.last["n_active"].item())
     trainer.events = None
+    gc.enable()
     S, A = S_acc / n_steps, A_acc / n_steps
     algo = {   # bytes per launch
         "march_count(side stream)": 60.0 * R + 4.0 * S, "march_write": 32.0 * S, "hashgrid_fwd": 588.0 * S, "mlp_fwd": 210.0 * S,
