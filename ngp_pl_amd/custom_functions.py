@@ -39,12 +39,18 @@ RaySphereIntersector.__name__ = RaySphereIntersector.__qualname__ = "RaySphereIn
 
 def segment_sum(values, rays_a):
     """Per-ray sums of packed per-sample rows; replaces torch_scatter.segment_csr in
-    RayMarcher.backward (custom_functions.py:107-110).  Results are placed at ray_idx, so the
-    gradient lands on the right ray whatever the row order of rays_a (the reference returns them
-    in row order, which is only right when rows happen to be ray-ordered)."""
-    owner = torch.repeat_interleave(rays_a[:, 0], rays_a[:, 2])
-    acc = values.new_zeros((rays_a.shape[0],) + tuple(values.shape[1:]))
-    acc.index_add_(0, owner, values)
+    RayMarcher.backward (custom_functions.py:107-110).  Results are placed at ray_idx, and the owner of a
+    sample is derived from the rows' start_idx, so the gradient lands on the right ray whatever the row order
+    of rays_a (this package packs in ray order; the reference's atomics hand out ray_count and start_idx
+    independently, and its segment_csr over rays_a[:,1] is only right when the rows happen to be start-ordered)."""
+    n_rows, n_samples = rays_a.shape[0], values.shape[0]
+    acc = values.new_zeros((n_rows,) + tuple(values.shape[1:]))
+    if n_samples == 0 or n_rows == 0:
+        return acc
+    rows = torch.nonzero(rays_a[:, 2] > 0)[:, 0]                      # segments that hold samples
+    starts, order = torch.sort(rays_a[rows, 1])
+    seg = torch.searchsorted(starts, torch.arange(n_samples, device=values.device), right=True) - 1   # latest segment start <= sample
+    acc.index_add_(0, rays_a[rows[order], 0][seg], values)
     return acc
 
 

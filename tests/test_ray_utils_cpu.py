@@ -45,3 +45,24 @@ def test_pose_correction_is_differentiable_at_zero():
     eps = 1e-3
     d_eps = ru.get_rays(dirs[:1], ru.perturbed_poses(poses[:1], (w * eps)[None], torch.zeros(1, 3)))[1][0]
     assert torch.allclose((d_eps - base) / eps, torch.linalg.cross(w, base), atol=5e-3)
+
+
+def test_segment_sum_is_independent_of_the_row_order_of_rays_a():
+    """RayMarcher.backward's per-ray reduction (custom_functions.py:102-112): the reference's `segment_csr(.., rays_a[:, 1])`
+    is only right when the rows of rays_a are ordered by start_idx (its atomics do not guarantee it); segment_sum derives
+    a sample's owner from the start indices, so any row order and any packing order give the per-ray sums at ray_idx."""
+    import torch
+    from ngp_pl_amd.custom_functions import segment_sum
+    g = torch.Generator().manual_seed(0)
+    R = 60
+    counts = torch.randint(0, 9, (R,), generator=g); counts[3] = 0; counts[0] = 4
+    order = torch.randperm(R, generator=g)                       # segments laid out in an order unrelated to the ray index
+    start = torch.zeros(R, dtype=torch.long); pos = 0
+    for r in order.tolist():
+        start[r] = pos; pos += int(counts[r])
+    vals = torch.randn(pos, 3, generator=g)
+    want = torch.stack([vals[start[r]:start[r] + counts[r]].sum(0) for r in range(R)])
+    rays_a = torch.stack([torch.arange(R), start, counts], 1)
+    for rows in (rays_a, rays_a[torch.randperm(R, generator=g)]):
+        assert torch.allclose(segment_sum(vals, rows), want, atol=1e-6)
+    assert segment_sum(vals[:0], rays_a).abs().sum() == 0
