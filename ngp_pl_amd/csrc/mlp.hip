@@ -785,7 +785,10 @@ constexpr int bwd_smem_bytes() {
 int fwd_grid(int n_samples) {
     const int n_tiles = (n_samples + TILE - 1) / TILE;
     const int blocks = (n_tiles + WAVES - 1) / WAVES;
-    return blocks < 512 ? (blocks < 1 ? 1 : blocks) : 512;   // <= 2 workgroups per CU: the per-workgroup weight staging is amortised over more tiles
+    // workgroups per CU: the per-workgroup weight staging (24 KB) wants several tiles per wave, the latency of a tile's loads
+    // wants several waves per SIMD (2 workgroups = 2 waves per SIMD measured 75 us per 1.3 M samples in the frame loop)
+    static const int cap = [] { const char* e = getenv("NGP_FWD_GRID_CAP"); return e ? atoi(e) : 512; }();
+    return blocks < cap ? (blocks < 1 ? 1 : blocks) : cap;
 }
 int bwd_grid(int n_samples) {
     const int n_tiles = (n_samples + TILE - 1) / TILE;
