@@ -22,7 +22,7 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JS
                 stages run on the active samples only, read back per step) / its HIP-event time on the stream it
                 runs on, measured over ROOFLINE_STEPS steps right behind the timed windows; `traffic` = HBM bytes
                 from the PMC profile recorded at the same operating point (profiles/*_pmc_traffic.json, made by
-                tools/profile_bench.sh + tools/pmc_traffic.py), or null when the operating points differ by more than 5 %.
+                tools/profile_bench.sh + tools/pmc_traffic.py), or null when the operating points differ by more than 10 %.
   * cpu_baseline = the CPU oracle (reference kernels compiled for the host when available, our restatement
                 otherwise) timed on rank 0 on a bounded sample of the same workload.
 Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL).  `--gpus N` with no RANK in the
