@@ -98,7 +98,7 @@ def respawn_under_torchrun(args):
     return subprocess.call(cmd, env=env)
 
 
-def dry_run(args, rank, world):
+def dry_run(args, rank, world, out_stream):
     """No GPU: prove the launch path (N ranks, rendezvous on 127.0.0.1, a collective) and nothing else."""
     import torch.distributed as dist
     if world > 1 or "RANK" in os.environ:
@@ -112,7 +112,7 @@ def dry_run(args, rank, world):
     else:
         world_seen = 1
     if rank == 0:
-        print(json.dumps({"metric": "train rays/sec", "value": None, "unit": "rays/s", "n_gpus": world_seen, "steps": args.steps,
+        out_stream.emit(json.dumps({"metric": "train rays/sec", "value": None, "unit": "rays/s", "n_gpus": world_seen, "steps": args.steps,
                           "warmup": args.warmup, "dry_run": True, "note": "no GPU visible: launcher and process group only (gloo); "
                           "the product path has no CPU fallback"}))
 
@@ -373,13 +373,30 @@ def secondary_line(name, args, dev):
     return out
 
 
+class OnlyTheJsonLineOnStdout:
+    """Everything a library prints to file descriptor 1 while the bench runs (RCCL writes a five-line version banner there when the
+    first communicator is created) goes to stderr; `emit` writes the one JSON line to the real stdout."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self.real = os.dup(1)
+        os.dup2(2, 1)
+
+    def emit(self, line):
+        sys.stdout.flush()
+        os.dup2(self.real, 1)
+        print(line, flush=True)
+        os.dup2(2, 1)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(respawn_under_torchrun(args))
+    out_stream = OnlyTheJsonLineOnStdout()
     rank = int(os.environ.get("RANK", 0)); local = int(os.environ.get("LOCAL_RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
     if args.dry_run or not torch.cuda.is_available():
-        return dry_run(args, rank, world)
+        return dry_run(args, rank, world, out_stream)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -409,7 +426,7 @@ def main():
     if dist is not None:      # what follows runs on rank 0 only: no collectives from here on
         loop.exchange.uninstall(loop.trainer)
     if rank == 0 and args.timed_only:
-        print(json.dumps(out))
+        out_stream.emit(json.dumps(out))
     elif rank == 0:
         out["roofline"] = kernel_roofline(loop)
         if not args.no_render:
@@ -431,7 +448,7 @@ def main():
             del loop
             torch.cuda.empty_cache()
             out["secondary"] = [secondary_line("unbounded", args, dev), secondary_line("lego16k", args, dev)]
-        print(json.dumps(out))
+        out_stream.emit(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
