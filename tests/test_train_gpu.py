@@ -673,3 +673,65 @@ def test_fused_render_node_matches_the_operator_chain(lambda_distortion):
     with pytest.raises(RuntimeError, match="has not been consumed"):
         ((res["rgb"] - gt) ** 2).mean().backward()
     m._native = None
+
+
+def test_batch_size_change_reallocates_the_step_buffers():
+    """The step's buffers are allocated per batch size (trainer.StepBuffers): changing the number of rays between steps -- also with a
+    prefetched march of the old size pending -- rebuilds them and keeps training."""
+    from ngp_pl_amd.trainer import Trainer
+    m = make_model(seed=3)
+    tr = Trainer(m)
+    big = [batch(4096, seed=600 + i) for i in range(2)]
+    small = [batch(1024, seed=610 + i) for i in range(2)]
+    tr.step(*big[0], next_batch=(big[1][0], big[1][1]))
+    assert tr._buf.n == 4096 and tr._pending is not None
+    out = tr.step(*small[0])                                     # the pending 4096-ray march is dropped, buffers rebuilt
+    assert tr._buf.n == 1024 and out["n_rays"] == 1024 and out["rm_samples"] > 0
+    tr.step(*small[1], next_batch=(big[1][0], big[1][1]))         # a next batch of another size is not prefetched
+    assert tr._pending is None
+    out = tr.step(*big[1])
+    assert tr._buf.n == 4096 and math.isfinite(tr.metrics()["loss"]) and out["rm_samples"] > 0
+
+
+def test_gradient_exchange_at_world_size_one_is_the_identity():
+    """The multi-GPU hooks on a real RCCL process group of ONE rank (ngp_pl_amd/ddp.py: MLP collective, grid collective in 1 and in
+    3 launch groups, non-finite check, loss scale 128 / world): the parameters after a few steps equal those of the plain step bit for
+    bit, and a non-finite gradient makes every parameter block skip the update."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from ngp_pl_amd.ddp import GradientExchange
+    from ngp_pl_amd.trainer import Trainer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        bs = [batch(4096, seed=700 + i) for i in range(3)]
+        results = []
+        for groups in (0, 1, 3):
+            m = make_model(seed=9)
+            tr = Trainer(m)
+            if groups:
+                ex = GradientExchange(m, dist, 1, n_groups=groups).install(tr)
+                ex.broadcast_parameters()
+                assert tr.loss_scale == 128.0 and (tr.group_hook is not None) == (groups > 1)
+            torch.manual_seed(4)
+            for i in range(6):
+                tr.step(*bs[i % 3])
+            results.append((m.xyz_encoder.params.detach().clone(), m.rgb_net.params.detach().clone(), tr.metrics()["loss"]))
+        for other in results[1:]:
+            assert torch.equal(other[0], results[0][0]) and torch.equal(other[1], results[0][1]) and other[2] == results[0][2]
+        # non-finite reduced gradient -> the whole step is skipped (GradScaler semantics), on the real kernels
+        before = (m.xyz_encoder.params.detach().clone(), m.rgb_net.params.detach().clone())
+        hook = tr.grad_hook
+
+        def poisoned():
+            m._native["grid16"][12345] = float("inf")
+            return hook()
+        tr.grad_hook = poisoned
+        tr.step(*bs[0])
+        assert torch.equal(m.xyz_encoder.params.detach(), before[0]) and torch.equal(m.rgb_net.params.detach(), before[1])
+        tr.grad_hook = hook
+        tr.step(*bs[1])
+        assert not torch.equal(m.xyz_encoder.params.detach(), before[0])
+    finally:
+        dist.destroy_process_group()
