@@ -695,9 +695,9 @@ def test_batch_size_change_reallocates_the_step_buffers():
 
 def test_gradient_exchange_at_world_size_one_is_the_identity():
     """The multi-GPU hooks on a real RCCL process group of ONE rank (ngp_pl_amd/ddp.py: MLP collective, grid collective in 1 and in
-    3 launch groups, non-finite check, loss scale 128 / world): the parameters after a few steps equal those of the plain step bit for
-    bit, and a non-finite gradient makes every parameter block skip the update."""
-    import os
+    3 launch groups, non-finite check, loss scale 128 / world): the gradient that reaches the optimizer equals the plain step's
+    (grid: bit for bit -- the binned backward sums exactly; MLP blocks: to f32 summation order), and a non-finite reduced gradient
+    makes every parameter block skip the update on the real kernels."""
     import socket
     import torch.distributed as dist
     from ngp_pl_amd.ddp import GradientExchange
@@ -705,7 +705,7 @@ def test_gradient_exchange_at_world_size_one_is_the_identity():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        bs = [batch(4096, seed=700 + i) for i in range(3)]
+        ro, rd, gt = batch(2048, seed=700)                   # ~0.5 M samples on the untrained grid: the binned (deterministic) backward
         results = []
         for groups in (0, 1, 3):
             m = make_model(seed=9)
@@ -714,13 +714,32 @@ def test_gradient_exchange_at_world_size_one_is_the_identity():
                 ex = GradientExchange(m, dist, 1, n_groups=groups).install(tr)
                 ex.broadcast_parameters()
                 assert tr.loss_scale == 128.0 and (tr.group_hook is not None) == (groups > 1)
+            captured = {}
+
+            def capture(grad_scale=1.0, found_inf=None, stream_handle=None, m=m, captured=captured):
+                nat = m._native
+                enc, net = m.xyz_encoder, m.rgb_net
+                captured["grid"] = nat["grid16"].clone()
+                captured["density"] = nat["density_partials"].view(nat["n_partials"], enc.n_mlp).sum(0) / nat["scale"]
+                captured["rgb"] = nat["rgb_partials"].view(nat["n_partials"], net.params.numel()).sum(0) / nat["scale"]
+                captured["scale"], captured["found_inf"] = nat["scale"], found_inf
+                m._native = None
+            tr.opt.step = capture
             torch.manual_seed(4)
-            for i in range(6):
-                tr.step(*bs[i % 3])
-            results.append((m.xyz_encoder.params.detach().clone(), m.rgb_net.params.detach().clone(), tr.metrics()["loss"]))
+            out = tr.step(ro, rd, gt)
+            assert 0 < out["rm_samples"] <= tr._buf.bin_max
+            results.append(captured)
+        plain = results[0]
+        assert plain["found_inf"] is None and plain["scale"] == 128.0
         for other in results[1:]:
-            assert torch.equal(other[0], results[0][0]) and torch.equal(other[1], results[0][1]) and other[2] == results[0][2]
-        # non-finite reduced gradient -> the whole step is skipped (GradScaler semantics), on the real kernels
+            assert other["scale"] == 128.0 and int(other["found_inf"][0]) == 0
+            assert torch.equal(other["grid"], plain["grid"])
+            for k in ("density", "rgb"):
+                assert (other[k] - plain[k]).abs().max().item() <= 1e-5 * plain[k].abs().max().item(), k
+        # non-finite reduced gradient -> the whole step is skipped (GradScaler semantics)
+        m = make_model(seed=9)
+        tr = Trainer(m)
+        GradientExchange(m, dist, 1).install(tr)
         before = (m.xyz_encoder.params.detach().clone(), m.rgb_net.params.detach().clone())
         hook = tr.grad_hook
 
@@ -728,10 +747,11 @@ def test_gradient_exchange_at_world_size_one_is_the_identity():
             m._native["grid16"][12345] = float("inf")
             return hook()
         tr.grad_hook = poisoned
-        tr.step(*bs[0])
+        tr.step(ro, rd, gt)
         assert torch.equal(m.xyz_encoder.params.detach(), before[0]) and torch.equal(m.rgb_net.params.detach(), before[1])
         tr.grad_hook = hook
-        tr.step(*bs[1])
-        assert not torch.equal(m.xyz_encoder.params.detach(), before[0])
+        tr.step(ro, rd, gt)
+        assert not torch.equal(m.xyz_encoder.params.detach(), before[0]) and not torch.equal(m.rgb_net.params.detach(), before[1])
+        assert torch.isfinite(m.xyz_encoder.params).all()
     finally:
         dist.destroy_process_group()
