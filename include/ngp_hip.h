@@ -472,13 +472,20 @@ int ngp_nerf_loss(const float* rgb, const float* opacity, const float* gt_rgb, c
 /* NeRFLoss.forward as the reference shapes it (losses.py:47-60): UNREDUCED terms
  *   sq_err (R,3) = (rgb - gt)^2,   entropy (R) = lambda_o * -(o + 1e-10) log(o + 1e-10)
  * (train.py:173 sums their means) and the backward through them: g_rgb = g_sq_err * 2 (rgb - gt),
- * g_opacity = g_entropy * lambda_o * -(log(o + 1e-10) + 1).  One launch each. */
+ * g_opacity = g_entropy * lambda_o * -(log(o + 1e-10) + 1).  One launch each.
 int ngp_nerf_loss_terms_fw(const float* rgb, const float* opacity, const float* gt_rgb,
                            float lambda_opacity, int n_rays, float* sq_err, float* entropy,
                            ngp_stream_t stream);
-int ngp_nerf_loss_terms_bw(const float* g_sq_err, const float* g_entropy, const float* rgb,
-                           const float* opacity, const float* gt_rgb, float lambda_opacity,
-                           int n_rays, float* g_rgb, float* g_opacity, ngp_stream_t stream);
+ * `*_is_scalar`: the seed is ONE float broadcast over all elements (what `.mean().backward()` hands back as a stride-0 view). */
+int ngp_nerf_loss_terms_bw(const float* g_sq_err, int g_sq_err_is_scalar, const float* g_entropy,
+                           int g_entropy_is_scalar, const float* rgb, const float* opacity,
+                           const float* gt_rgb, float lambda_opacity, int n_rays, float* g_rgb,
+                           float* g_opacity, ngp_stream_t stream);
+/* render()'s background blend rgb_out = rgb + bg (1 - opacity) (rendering.py:153-161; bg 3 floats on the device) and its backward
+ * onto the opacity seed: g_opacity_out = g_opacity (NULL: 0) - sum_c g_rgb[.,c] bg[c]. */
+int ngp_bg_blend(const float* rgb, const float* opacity, const float* bg, int n_rays, float* rgb_out, ngp_stream_t stream);
+int ngp_bg_blend_bw(const float* g_rgb, const float* g_opacity, const float* bg, int n_rays, float* g_opacity_out,
+                    ngp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * batch sampling (datasets/base.py:22-35 'all_images' + train.py:78-91 + ray_utils.py:46-70)

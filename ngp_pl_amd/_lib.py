@@ -78,7 +78,9 @@ _PROTOS = {
     "ngp_cast_f16_to_f32": [P, L, F, P, P],
     "ngp_nerf_loss": [P, P, P, P, F, F, I, P, P, P, P, P],
     "ngp_nerf_loss_terms_fw": [P, P, P, F, I, P, P, P],
-    "ngp_nerf_loss_terms_bw": [P, P, P, P, P, F, I, P, P, P],
+    "ngp_nerf_loss_terms_bw": [P, I, P, I, P, P, P, F, I, P, P, P],
+    "ngp_bg_blend": [P, P, P, I, P, P],
+    "ngp_bg_blend_bw": [P, P, P, I, P, P],
     "ngp_compact_alive": [P, P, I, P, P, P, P],
     "ngp_sample_rays": [P, P, P, I, I, I, C.c_uint64, P, P, P, P, P, P, P],
     "ngp_abi_version": [],

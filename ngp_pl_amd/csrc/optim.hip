@@ -241,16 +241,37 @@ nerf_loss_terms_fw_kernel(const float* __restrict__ rgb, const float* __restrict
     ent[r] = lambda_o * (-o * logf(o));
 }
 __global__ void __launch_bounds__(256)
-nerf_loss_terms_bw_kernel(const float* __restrict__ g_sq, const float* __restrict__ g_ent, const float* __restrict__ rgb,
-                          const float* __restrict__ opacity, const float* __restrict__ gt, float lambda_o, int n_rays,
-                          float* __restrict__ g_rgb, float* __restrict__ g_opacity) {
+nerf_loss_terms_bw_kernel(const float* __restrict__ g_sq, int g_sq_bcast, const float* __restrict__ g_ent, int g_ent_bcast,
+                          const float* __restrict__ rgb, const float* __restrict__ opacity, const float* __restrict__ gt, float lambda_o,
+                          int n_rays, float* __restrict__ g_rgb, float* __restrict__ g_opacity) {
 #pragma clang fp contract(off)
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rays) return;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) g_rgb[3 * r + k] = g_sq[3 * r + k] * (2.0f * (rgb[3 * r + k] - gt[3 * r + k]));
+    for (int k = 0; k < 3; ++k) g_rgb[3 * r + k] = g_sq[g_sq_bcast ? 0 : 3 * r + k] * (2.0f * (rgb[3 * r + k] - gt[3 * r + k]));
     const float o = opacity[r] + 1e-10f;
-    g_opacity[r] = g_ent[r] * (lambda_o * (-(logf(o) + 1.0f)));
+    g_opacity[r] = g_ent[g_ent_bcast ? 0 : r] * (lambda_o * (-(logf(o) + 1.0f)));
+}
+
+// render()'s background blend (rendering.py:153-161, rgb + bg (1 - opacity)) and its backward onto the opacity seed, one launch each
+__global__ void __launch_bounds__(256)
+bg_blend_kernel(const float* __restrict__ rgb, const float* __restrict__ opacity, const float* __restrict__ bg, int n_rays,
+                float* __restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const float tr = 1.0f - opacity[r];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[3 * r + k] = fmaf(bg[k], tr, rgb[3 * r + k]);
+}
+__global__ void __launch_bounds__(256)
+bg_blend_bw_kernel(const float* __restrict__ g_rgb, const float* __restrict__ g_opacity, const float* __restrict__ bg, int n_rays,
+                   float* __restrict__ g_opacity_out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    float g = g_opacity ? g_opacity[r] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g -= g_rgb[3 * r + k] * bg[k];
+    g_opacity_out[r] = g;
 }
 
 // GPU-resident batch sampler: the reference draws img/pix indices with np.random.choice in 16
@@ -525,14 +546,32 @@ int ngp_nerf_loss_terms_fw(const float* rgb, const float* opacity, const float* 
     return NGP_LAUNCH_RESULT();
 }
 
-int ngp_nerf_loss_terms_bw(const float* g_sq_err, const float* g_entropy, const float* rgb, const float* opacity, const float* gt_rgb,
-                           float lambda_opacity, int n_rays, float* g_rgb, float* g_opacity, ngp_stream_t stream) {
+int ngp_nerf_loss_terms_bw(const float* g_sq_err, int g_sq_err_is_scalar, const float* g_entropy, int g_entropy_is_scalar, const float* rgb,
+                           const float* opacity, const float* gt_rgb, float lambda_opacity, int n_rays, float* g_rgb, float* g_opacity,
+                           ngp_stream_t stream) {
     if (n_rays < 0) return NGP_EINVAL;
     if (n_rays == 0) return 0;
     NGP_CHECK_PTR(g_sq_err); NGP_CHECK_PTR(g_entropy); NGP_CHECK_PTR(rgb); NGP_CHECK_PTR(opacity); NGP_CHECK_PTR(gt_rgb);
     NGP_CHECK_PTR(g_rgb); NGP_CHECK_PTR(g_opacity);
-    hipLaunchKernelGGL(nerf_loss_terms_bw_kernel, dim3(ngp_div_up(n_rays, 256)), dim3(256), 0, ngp_stream(stream), g_sq_err, g_entropy,
-                       rgb, opacity, gt_rgb, lambda_opacity, n_rays, g_rgb, g_opacity);
+    hipLaunchKernelGGL(nerf_loss_terms_bw_kernel, dim3(ngp_div_up(n_rays, 256)), dim3(256), 0, ngp_stream(stream), g_sq_err,
+                       g_sq_err_is_scalar, g_entropy, g_entropy_is_scalar, rgb, opacity, gt_rgb, lambda_opacity, n_rays, g_rgb, g_opacity);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_bg_blend(const float* rgb, const float* opacity, const float* bg, int n_rays, float* rgb_out, ngp_stream_t stream) {
+    if (n_rays < 0) return NGP_EINVAL;
+    if (n_rays == 0) return 0;
+    NGP_CHECK_PTR(rgb); NGP_CHECK_PTR(opacity); NGP_CHECK_PTR(bg); NGP_CHECK_PTR(rgb_out);
+    hipLaunchKernelGGL(bg_blend_kernel, dim3(ngp_div_up(n_rays, 256)), dim3(256), 0, ngp_stream(stream), rgb, opacity, bg, n_rays, rgb_out);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_bg_blend_bw(const float* g_rgb, const float* g_opacity, const float* bg, int n_rays, float* g_opacity_out, ngp_stream_t stream) {
+    if (n_rays < 0) return NGP_EINVAL;
+    if (n_rays == 0) return 0;
+    NGP_CHECK_PTR(g_rgb); NGP_CHECK_PTR(bg); NGP_CHECK_PTR(g_opacity_out);
+    hipLaunchKernelGGL(bg_blend_bw_kernel, dim3(ngp_div_up(n_rays, 256)), dim3(256), 0, ngp_stream(stream), g_rgb, g_opacity, bg, n_rays,
+                       g_opacity_out);
     return NGP_LAUNCH_RESULT();
 }
 

@@ -89,10 +89,16 @@ class _LossTerms(torch.autograd.Function):
         from ._lib import call, ptr, stream
         rgb, opacity, gt = ctx.saved_tensors
         n = rgb.shape[0]
-        g_sq = g_sq.float().contiguous(); g_ent = g_ent.float().contiguous()      # `.mean()` hands back expanded (stride-0) views
+        # `.mean().backward()` hands back expanded (stride-0) views of one scalar: pass the scalar, do not materialise it
+        def seed(g):
+            if g.dtype == torch.float32 and g.numel() > 0 and all(st == 0 for st in g.stride()):
+                return g, 1
+            return g.float().contiguous(), 0
+        (g_sq, sq_scalar), (g_ent, ent_scalar) = seed(g_sq), seed(g_ent)
         g_rgb = torch.empty_like(rgb); g_op = torch.empty_like(opacity)
         with torch.cuda.device(rgb.device):
-            call("ngp_nerf_loss_terms_bw", ptr(g_sq), ptr(g_ent), ptr(rgb), ptr(opacity), ptr(gt), ctx.lambda_opacity, n, ptr(g_rgb), ptr(g_op), stream())
+            call("ngp_nerf_loss_terms_bw", ptr(g_sq), sq_scalar, ptr(g_ent), ent_scalar, ptr(rgb), ptr(opacity), ptr(gt), ctx.lambda_opacity, n,
+                 ptr(g_rgb), ptr(g_op), stream())
         return g_rgb, g_op, None, None
 
 

@@ -14,12 +14,19 @@ MAX_SAMPLES = 1024
 NEAR_DISTANCE = 0.01
 
 
+_BG = {}
+
+
 def _background(exp_step_factor, device, random_bg=False):
-    if exp_step_factor == 0:                 # synthetic scenes: white (rendering.py:111-112,153-154)
-        return torch.ones(3, device=device)
-    if random_bg:
+    """white for synthetic scenes (rendering.py:111-112,153-154), random or black for real ones; the two constant colours are
+    cached per device (a torch.ones per call is a kernel launch)."""
+    if exp_step_factor != 0 and random_bg:
         return torch.rand(3, device=device)
-    return torch.zeros(3, device=device)
+    key = (exp_step_factor == 0, str(device))
+    bg = _BG.get(key)
+    if bg is None:
+        bg = _BG[key] = torch.ones(3, device=device) if exp_step_factor == 0 else torch.zeros(3, device=device)
+    return bg
 
 
 @torch.autocast("cuda")
@@ -225,7 +232,8 @@ class _FusedTrainRender(torch.autograd.Function):
             call("ngp_composite_train_fw", ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(ts), ptr(rays_a), float(T_threshold), n, S,
                  ptr(total), ptr(opacity), ptr(depth), ptr(rgb), ptr(ws), ptr(ray_offs), sq)
             call("ngp_active_scan", ptr(ray_offs), n, ptr(n_active), sq)
-        rgb_out = torch.addcmul(rgb, bg.view(1, 3), (1 - opacity).unsqueeze(1))      # rendering.py:161
+            rgb_out = torch.empty(n, 3, **f32)
+            call("ngp_bg_blend", ptr(rgb), ptr(opacity), ptr(bg), n, ptr(rgb_out), sq)       # rendering.py:161
         ctx.model, ctx.S, ctx.T_threshold = model, S, T_threshold
         ctx.save_for_backward(rays_a, xyzs, dirs, deltas, ts, feats, h, sigmas, rgbs, ws, opacity, depth, rgb, ray_offs, n_active, bg)
         vr_samples = total.sum()
@@ -247,9 +255,11 @@ class _FusedTrainRender(torch.autograd.Function):
             return (torch.zeros_like(enc.params), torch.zeros_like(net.params)) + none5
         f32 = dict(dtype=torch.float32, device=dev); f16 = dict(dtype=torch.float16, device=dev)
         g_rgb = torch.zeros(n, 3, **f32) if g_rgb is None else g_rgb.float().contiguous()
-        g_opacity = torch.zeros(n, **f32) if g_opacity is None else g_opacity.float()
-        g_opacity = (g_opacity - (g_rgb * bg.view(1, 3)).sum(1)).contiguous()         # through rgb + bg (1 - opacity)
-        g_depth = torch.zeros(n, **f32) if g_depth is None else g_depth.float().contiguous()
+        g_opacity_in = None if g_opacity is None else g_opacity.float().contiguous()
+        g_opacity = torch.empty(n, **f32)
+        with torch.cuda.device(dev):
+            call("ngp_bg_blend_bw", ptr(g_rgb), ptr(g_opacity_in), ptr(bg), n, ptr(g_opacity), stream())     # through rgb + bg (1 - opacity)
+        g_depth = _zeros(n, dev) if g_depth is None else g_depth.float().contiguous()
         g_ws = None if g_ws is None else g_ws.float().contiguous()
         scale = tcnn.LOSS_SCALE
         lib = _lib.lib()
@@ -285,6 +295,17 @@ class _FusedTrainRender(torch.autograd.Function):
             call("ngp_cast_f16_to_f32", ptr(g16), enc.n_grid, 1.0 / scale, ptr(g_enc[enc.n_mlp:]), sq)
             g_rgbw = tcnn.reduce_partials(p_rgb, n_part, net.params.numel()) / scale
         return (g_enc, g_rgbw) + none5
+
+
+_ZEROS = {}
+
+
+def _zeros(n, dev):
+    """A cached all-zero (n) f32 seed (dL/ddepth when the loss has no depth term): read-only by convention."""
+    z = _ZEROS.get((n, dev))
+    if z is None:
+        z = _ZEROS[(n, dev)] = torch.zeros(n, dtype=torch.float32, device=dev)
+    return z
 
 
 class _PinnedCounter:
