@@ -83,7 +83,8 @@ class GradientExchange:
     def broadcast_parameters(self):
         """DDP's constructor broadcast: every rank starts from rank 0's parameters."""
         for p in self.model.parameters():
-            self.dist.broadcast(p.data, 0, group=self.group)
+            if p.numel():                       # `dir_encoder.params` is empty (the SH encoding has no parameters)
+                self.dist.broadcast(p.data, 0, group=self.group)
         for mod in (self.model.xyz_encoder, self.model.rgb_net):
             mod._half.invalidate()              # the f16 working copies follow the broadcast
 
