@@ -1,0 +1,113 @@
+"""GPU: the multi-rank training step END TO END with real kernels -- two processes share the one GPU of the test box (RCCL refuses
+two ranks on one device, so the collectives go through gloo, which moves CUDA tensors through the host; everything else is the
+product path: Trainer.step, the native gradient buffers, ngp_pl_amd.ddp.GradientExchange, ngp_found_inf2, the fused Adam).
+Checks, per step: every rank's reduced gradient is the SUM of the ranks' local gradients (packed f16 grid, f32 MLP blocks), the
+parameters of the ranks stay bit-identical although their batches differ, and a rank whose batch produces no samples keeps up."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, n_groups, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import numpy as np
+        from ngp_pl_amd import synthetic as syn
+        from ngp_pl_amd.ddp import GradientExchange
+        from ngp_pl_amd.networks import NGP
+        from ngp_pl_amd.trainer import Trainer
+        torch.manual_seed(100 + rank)                     # different initial parameters per rank on purpose: the broadcast must fix that
+        m = NGP(scale=0.5).cuda()
+        m.register_training_buffers()
+        tr = Trainer(m)
+        ex = GradientExchange(m, dist, world, n_groups=n_groups).install(tr)
+        ex.broadcast_parameters()
+        assert tr.loss_scale == 128.0 / world
+
+        def batch(n, seed):
+            g = np.random.RandomState(seed)
+            W = 200
+            dirs = syn.get_ray_directions(W, W, syn.intrinsics(W))
+            poses = syn.hemisphere_poses(16, seed=1)
+            ro, rd = syn.get_rays(dirs[torch.from_numpy(g.randint(0, W * W, n))], poses[torch.from_numpy(g.randint(0, 16, n))])
+            ro, rd = ro.cuda(), rd.cuda()
+            gt, _ = syn.render_ground_truth(ro, rd, n_steps=96)
+            return ro, rd, gt.contiguous()
+
+        ok, notes = True, []
+        pre = {}
+        reduce_grid = tr.grad_hook
+
+        def spy():                                         # local gradient right before the grid collective
+            nat = m._native
+            pre["grid"] = nat["grid16"].clone(); pre["scale"] = nat["scale"]
+            return reduce_grid()
+        tr.grad_hook = spy
+        adam = tr.opt.step
+
+        def spy_adam(grad_scale=1.0, found_inf=None, stream_handle=None):
+            nat = m._native
+            pre["grid_sum"] = nat["grid16"].clone(); pre["mlp_sum"] = torch.cat([nat["density_partials"], nat["rgb_partials"]]).clone()
+            pre["scale_after"] = nat["scale"]
+            return adam(grad_scale=grad_scale, found_inf=found_inf, stream_handle=stream_handle)
+        tr.opt.step = spy_adam
+        for step in range(4):
+            ro, rd, gt = batch(2048, seed=1000 + 10 * step + rank)           # per-rank batches
+            if step == 2 and rank == 1:
+                ro = ro + 10.0; rd = rd.abs() + 0.1                          # this rank's rays all miss the box: S = 0
+            out = tr.step(ro, rd, gt)
+            torch.cuda.synchronize()
+            if step == 2 and rank == 1:
+                ok &= out["rm_samples"] == 0
+            # (1) reduced grid gradient == f16 sum of the ranks' local gradients
+            mine = pre["grid"].float().cpu() if out["rm_samples"] > 0 else torch.zeros(m.xyz_encoder.n_grid)
+            parts = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            want = parts[0].half()
+            for p in parts[1:]:
+                want = (want.float() + p).half()
+            got = pre["grid_sum"].cpu()
+            err = (got.float() - want.float()).abs().max().item() / max(want.float().abs().max().item(), 1e-12)
+            ok &= err < 2e-3 and pre["scale_after"] == 128.0 and bool(torch.isfinite(got.float()).all())
+            notes.append("step %d grid err %.2e" % (step, err))
+            # (2) parameters bit-identical across ranks
+            for p in (m.xyz_encoder.params, m.rgb_net.params):
+                mine_p = p.detach().cpu()
+                all_p = [torch.zeros_like(mine_p) for _ in range(world)]
+                dist.all_gather(all_p, mine_p)
+                ok &= all(torch.equal(all_p[0], a) for a in all_p)
+            # (3) every rank holds the same reduced MLP sums
+            small = pre["mlp_sum"].cpu()
+            alls = [torch.zeros_like(small) for _ in range(world)]
+            dist.all_gather(alls, small)
+            ok &= all(torch.equal(alls[0], a) for a in alls) and float(small.abs().sum()) > 0
+        ok &= bool(torch.isfinite(m.xyz_encoder.params).all())
+        q.put((rank, bool(ok), notes))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:                                                  # surface the traceback in the parent
+        import traceback
+        q.put((rank, False, [traceback.format_exc()]))
+        raise
+
+
+@pytest.mark.parametrize("n_groups", [1, 2])
+def test_two_ranks_train_in_lock_step_on_one_gpu(n_groups):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_groups, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(120)
+    assert [(r, ok) for r, ok, _ in res] == [(0, True), (1, True)], res
