@@ -357,7 +357,7 @@ int ngp_field_fwd_n(const ngp_half* feats, const float* dirs,
  *                    h = forward's h_out, dh_scratch (S,16) f16 workspace.
  * active_idx / n_active (both NULL or both set) compact the backward as in
  * ngp_hashgrid_bwd_sliced: inputs and f32 seeds are addressed by sample id, dL_dh / dfeats by
- * compact position. */
+ * compact position.  wgrad_partial must be 16-byte aligned (NGP_EINVAL otherwise; also ngp_mlp_bwd). */
 int ngp_field_bwd_partials(int n_samples);
 int ngp_rgb_bwd(const ngp_half* h, const float* dirs, const ngp_half* rgb_w,
                 const float* dL_drgbs, float loss_scale, int n_samples,

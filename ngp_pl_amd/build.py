@@ -18,6 +18,10 @@ ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
           "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-result"]
+# per-source extras.  mlp.hip: MFMA results land in VGPRs -- every result of forward/dgrad is consumed by VALU code (convert to
+# f16, ReLU), and with the accumulator-register form the compiler chose under this register pressure each of those 16-register
+# results cost 16 v_accvgpr_read (208 of the 980 instructions of a backward tile)
+EXTRA = {"mlp.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _stale(target, deps):
@@ -41,8 +45,8 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
-            jobs.append([HIPCC] + CFLAGS + ["-c", s, "-o", o])
+        if force or _stale(o, [s, os.path.abspath(__file__)] + hdrs):
+            jobs.append([HIPCC] + CFLAGS + EXTRA.get(src, []) + ["-c", s, "-o", o])
     if jobs:
         if verbose:
             print("[ngp_pl_amd.build] compiling %d HIP sources for %s" % (len(jobs), ARCH))

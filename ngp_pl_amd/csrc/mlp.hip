@@ -35,6 +35,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int HID = 64;          // neurons
 constexpr int PAD = 8;           // halves of row padding in LDS
 constexpr int WAVES = 4;         // waves per workgroup
+#ifndef NGP_MLP_BWD_WAVES
+#define NGP_MLP_BWD_WAVES 4
+#endif
+constexpr int BWD_WAVES = NGP_MLP_BWD_WAVES;   // backward: waves per workgroup (one workgroup per CU: 128 accumulator registers per wave, 20 KB of LDS image per wave)
 constexpr int TILE = 32;         // samples per wave tile
 
 __device__ __forceinline__ f32x16 mfma(half8_t a, half8_t b, f32x16 c) {
@@ -58,32 +62,54 @@ __device__ __forceinline__ half8_t ldsA_dl(const h1* W, int ld, int row, bool va
     return r;
 }
 
-// D fragment (f32) -> B fragment (f16) for chunk half c2 (registers 8*c2 .. 8*c2+7)
+// D fragment (f32) -> B fragment (f16) for chunk half c2 (registers 8*c2 .. 8*c2+7).  ReLU is applied to the PACKED halves as
+// an INTEGER max of the bit patterns against 0 (4 v_pk_max_i16 where an f32 max of an MFMA result cost 2 x 16 VALU ops: the
+// compiler canonicalises first): positive halves are positive int16 and stay, everything with the sign bit -- negative values
+// and the -0 a tiny negative pre-activation rounds to -- becomes +0, exactly what (half)fmaxf(v, 0) gives.
 template <bool RELU>
 __device__ __forceinline__ half8_t d_to_b(const f32x16& d, int c2) {
     half8_t b;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        float v = d[8 * c2 + e];
-        if (RELU) v = fmaxf(v, 0.f);
-        b[e] = (h1)v;
+    for (int e = 0; e < 8; ++e) b[e] = (h1)d[8 * c2 + e];
+    if (RELU) {
+        typedef short short8_t __attribute__((ext_vector_type(8)));
+        const short8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+        b = __builtin_bit_cast(half8_t, __builtin_elementwise_max(__builtin_bit_cast(short8_t, b), z));
     }
     return b;
 }
 
+// ReLU backward on packed halves: d where h > 0, else 0.  h is a d_to_b<true>() result (positive or +0): per 16-bit half
+// min(bits, 1) is 0/1, its negation the AND mask -- 3 packed integer ops per pair instead of a compare + select per element.
+__device__ __forceinline__ half8_t relu_bwd(half8_t d, half8_t h) {
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t hb = __builtin_bit_cast(u32x4_t, h);
+    u32x4_t db = __builtin_bit_cast(u32x4_t, d);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        unsigned int m;
+        asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(m) : "v"(hb[k]));
+        asm("v_pk_sub_u16 %0, 0, %1 op_sel_hi:[0,1]" : "=v"(m) : "v"(m));
+        db[k] &= m;
+    }
+    return __builtin_bit_cast(half8_t, db);
+}
+
 // Stage a (rows, cols) row-major f16 matrix from global into LDS with padded pitch, optionally
-// transposed (LDS gets (cols, rows)).  Whole workgroup participates.
+// transposed (LDS gets (cols, rows)).  Whole workgroup participates; 16-byte global loads (cols is a multiple of 8, blobs are
+// 16 B aligned).  Transposed: consecutive lanes take consecutive ROWS, so the eight 2-byte stores of a lane's chunk land on
+// consecutive halves across the wave (lanes on consecutive columns put 16 lanes on one bank).
 __device__ __forceinline__ void stage_weights(const h1* __restrict__ g, h1* lds, int rows, int cols, bool transpose) {
-    // 16-byte global loads (cols is a multiple of 8, blobs are 16 B aligned)
-    const int n8 = rows * cols / 8;
+    const int n8 = rows * cols / 8, chunks = cols / 8;
     for (int t = threadIdx.x; t < n8; t += blockDim.x) {
-        const half8_t v = *reinterpret_cast<const half8_t*>(g + 8 * t);
-        const int r = (8 * t) / cols, c = 8 * t - r * cols;
         if (transpose) {
+            const int r = t % rows, c = 8 * (t / rows);
+            const half8_t v = *reinterpret_cast<const half8_t*>(g + r * cols + c);
 #pragma unroll
             for (int e = 0; e < 8; ++e) lds[(c + e) * (rows + PAD) + r] = v[e];
         } else {
-            *reinterpret_cast<half8_t*>(lds + r * (cols + PAD) + c) = v;
+            const int r = t / chunks, c = 8 * (t - r * chunks);
+            *reinterpret_cast<half8_t*>(lds + r * (cols + PAD) + c) = *reinterpret_cast<const half8_t*>(g + 8 * t);
         }
     }
 }
@@ -381,9 +407,6 @@ struct MlpBwdIO {
     const int32_t* n_active;
 };
 
-// wave-private transpose tile: [unit][sample], pitch 40 halves (80 B)
-constexpr int TP = TILE + PAD;
-
 // Lanes of one wave exchange data through LDS: DS operations of a wave execute in program
 // order, so only the COMPILER has to be kept from moving reads above other lanes' writes.
 __device__ __forceinline__ void wave_lds_sync() {
@@ -392,63 +415,116 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// write a natural-order B fragment set (units 16c+8hh+e) for N units
-template <int NCH>
-__device__ __forceinline__ void tr_write_nat(h1* t, const half8_t (&b)[NCH], int j, int hh) {
+// Weight gradient operands.  dW = dY^T X needs the SAMPLE on the MFMA K index, i.e. both operands transposed with respect
+// to how forward and dgrad hold them (lane = sample).  Every wave keeps its tile's activations and gradients in a private LDS
+// image in the layout it owns them in -- blocks of [32 samples][32 units] f16, 64-byte rows, written with 8-byte stores (4
+// consecutive units of one sample) -- and reads the operands back with gfx950's transposing LDS read (ds_read_b64_tr_b16: the 16
+// lanes of a group hand in 16 x 4 halves and receive them transposed, 4 samples of one unit per lane).  38 stores + 40 reads per
+// tile where element-wise transposition took 160 two-byte stores.
+// The 8-byte pieces of a row are XOR-swizzled by (sample >> 1) & 7 so that the 32 lanes of a store spread over all banks;
+// a read covers whole rows (4 samples x 64 B per half-wave), which no permutation inside a row can make conflict.
+constexpr int BLK_BYTES = 32 * 32 * 2;
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(8)));
+
+struct TrAddr {
+    int wD[4];    // store offset of piece hh + 2k of this lane's sample row (D-order fragments: units 4hh+{0..3} (+8) of a 16-unit chunk)
+    int wN[4];    // store offset of piece 2hh + 4(k>>1) + (k&1)            (natural-order fragments: units 8hh + {0..7} of a chunk)
+    int r[2];     // read offset of this lane's 8 bytes for samples 8hh + 4t + {0..3} of K chunk 0 (chunk 1: + 16 rows)
+};
+__device__ __forceinline__ TrAddr tr_addr(int lane) {
+    const int j = lane & 31, hh = lane >> 5, swz = (j >> 1) & 7;
+    TrAddr a;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c)
+    for (int k = 0; k < 4; ++k) {
+        a.wD[k] = j * 64 + (((hh + 2 * k) ^ swz) << 3);
+        a.wN[k] = j * 64 + (((2 * hh + 4 * (k >> 1) + (k & 1)) ^ swz) << 3);
+    }
+    const int q = lane & 15, blk16 = (lane >> 4) & 1;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) t[(16 * c + 8 * hh + e) * TP + j] = b[c][e];
+    for (int t = 0; t < 2; ++t) {
+        const int srow = 8 * hh + 4 * t + (q >> 2);
+        a.r[t] = srow * 64 + (((4 * blk16 + (q & 3)) ^ ((srow >> 1) & 7)) << 3);
+    }
+    return a;
 }
-// write D-order fragments hb[NCH] (units 16c + 4hh + (e&3) + 8(e>>2))
-template <int NCH>
-__device__ __forceinline__ void tr_write_dl(h1* t, const half8_t (&b)[NCH], int j, int hh) {
+__device__ __forceinline__ void tr_st(char* p, const half8_t& b, int lo_or_hi) {
+    half4_t v;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) t[(16 * c + 4 * hh + (e & 3) + 8 * (e >> 2)) * TP + j] = b[c][e];
+    for (int e = 0; e < 4; ++e) v[e] = b[4 * lo_or_hi + e];
+    *reinterpret_cast<half4_t*>(p) = v;
 }
-// fragment read for wgrad: rows = units, K = samples (natural order both operands)
-__device__ __forceinline__ half8_t tr_read(const h1* t, int unit, int c, int hh) {
-    return *reinterpret_cast<const half8_t*>(t + unit * TP + 16 * c + 8 * hh);
+// D-order fragments b[NCH] (unit 16c + 4hh + (e&3) + 8(e>>2)) -> blocks c>>1 of `arr`
+template <int NCH>
+__device__ __forceinline__ void tr_put_dl(char* arr, const half8_t (&b)[NCH], const TrAddr& a) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        tr_st(arr + (c >> 1) * BLK_BYTES + a.wD[2 * (c & 1)], b[c], 0);
+        tr_st(arr + (c >> 1) * BLK_BYTES + a.wD[2 * (c & 1) + 1], b[c], 1);
+    }
+}
+// natural-order fragments b[NCH] (unit 16c + 8hh + e)
+template <int NCH>
+__device__ __forceinline__ void tr_put_nat(char* arr, const half8_t (&b)[NCH], const TrAddr& a) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        tr_st(arr + (c >> 1) * BLK_BYTES + a.wN[2 * (c & 1)], b[c], 0);
+        tr_st(arr + (c >> 1) * BLK_BYTES + a.wN[2 * (c & 1) + 1], b[c], 1);
+    }
+}
+// MFMA operand of K chunk c (samples 16c .. 16c+15) for the 32 units of block `blk`: lane (i, hh) gets samples 16c + 8hh + e of unit i
+__device__ __forceinline__ half8_t tr_get(const char* blk, int c, const TrAddr& a) {
+    typedef __attribute__((address_space(3))) fp16x4_t* lds_p;
+    const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_p)(blk + c * 1024 + a.r[0]));
+    const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_p)(blk + c * 1024 + a.r[1]));
+    half8_t v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = (h1)lo[e]; v[4 + e] = (h1)hi[e]; }
+    return v;
 }
 // dW(MT*32 x NT*32) += dY^T (rows) * X (cols) over the 32 samples of the tile
 template <int MT, int NT>
-__device__ __forceinline__ void wgrad_tile(const h1* tdy, const h1* tx, int i, int hh, f32x16 (&acc)[MT][NT]) {
+__device__ __forceinline__ void wgrad_tile(const char* dy, const char* x, const TrAddr& ta, f32x16 (&acc)[MT][NT]) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         half8_t a[MT], b[NT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) a[m] = tr_read(tdy, 32 * m + i, c, hh);
+        for (int m = 0; m < MT; ++m) a[m] = tr_get(dy + m * BLK_BYTES, c, ta);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) b[n] = tr_read(tx, 32 * n + i, c, hh);
+        for (int n = 0; n < NT; ++n) b[n] = tr_get(x + n * BLK_BYTES, c, ta);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[m][n] = mfma(a[m], b[n], acc[m][n]);
     }
 }
-// Add a wave's dW accumulators into the workgroup's f32 LDS partial (row-major (rows, ld)).
-// Called by ONE wave at a time (the caller serialises the waves with barriers): plain
-// read-modify-write, no LDS float atomics (those cost ~3 cycles per lane on gfx950 and made this
-// epilogue 40 us per workgroup).  FIRST: store instead of accumulate (no zero-fill needed).
-template <int MT, int NT, bool FIRST>
-__device__ __forceinline__ void wgrad_flush(float* part, int ld, int n_rows, int n_cols, int j, int hh,
-                                            const f32x16 (&acc)[MT][NT]) {
+// Workgroup reduction of one layer's dW: every wave stores its accumulators into its own LDS slab (row-major (n_rows, n_cols)
+// f32, lanes on consecutive columns: conflict-free), one barrier, then all threads add the slabs 16 bytes at a time and store
+// the sums straight to the workgroup's partial row in global memory.  (Before: the waves took turns read-modify-writing one
+// LDS copy, 4 serial rounds with barriers -- 11 000 cycles of a 70 000-cycle kernel.)
+template <int MT, int NT>
+__device__ __forceinline__ void wgrad_reduce_layer(float* slabs, int n_rows, int n_cols, int wave, int j, int hh,
+                                                   const f32x16 (&acc)[MT][NT], float* __restrict__ out) {
+    const int n = n_rows * n_cols;                        // a multiple of 4 (n_cols is)
+    float* mine = slabs + wave * n;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+        for (int nn = 0; nn < NT; ++nn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * hh, col = 32 * n + j;
-                if (row < n_rows && col < n_cols) {
-                    float* q = part + row * ld + col;
-                    *q = FIRST ? acc[m][n][r] : *q + acc[m][n][r];
-                }
+                const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * hh, col = 32 * nn + j;
+                if (row < n_rows && col < n_cols) mine[row * n_cols + col] = acc[m][nn][r];
             }
+    __syncthreads();
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    for (int t = threadIdx.x * 4; t < n; t += blockDim.x * 4) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(slabs + t);
+#pragma unroll
+        for (int w = 1; w < BWD_WAVES; ++w) v += *reinterpret_cast<const f32x4*>(slabs + w * n + t);
+        *reinterpret_cast<f32x4*>(out + t) = v;
+    }
+    __syncthreads();                                      // the next layer reuses the slabs
 }
-
 
 // Everything a backward tile reads from global memory, as RAW register values: the loads of tile t+1 are issued before tile t
 // is computed (the kernel runs ONE wave per SIMD -- 164 VGPRs, 100 KB of LDS -- so nothing else hides a global round trip;
@@ -463,17 +539,17 @@ struct BwdRaw {
     h1 dout[8];              // OUT_PLAIN / OUT_DENSITY: dL_dout16 at units 4hh + (r&3) + 8(r>>2)
 };
 
+// Straight-line code: every lane loads, from positions the caller has clamped into range (lanes past the end re-read the last
+// sample; their output gradient is forced to zero, which zeroes everything they contribute).  Loads under per-lane conditions
+// come with zero-initialised destinations and branch merges, and the s_waitcnt pass answered those with vmcnt(0) in the middle
+// of the prefetch.
 template <int N_IN, int IN_MODE, int OUT_MODE>
 __device__ __forceinline__ void bwd_fetch(const MlpBwdIO& io, long long j, long long s, bool valid, int n_samples, int hh, BwdRaw<N_IN>& r) {
-    const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
     r.s = s; r.j = j; r.valid = valid;
-#pragma unroll
-    for (int c = 0; c < N_IN / 16; ++c) r.in[c] = z;
     r.dir[0] = r.dir[1] = r.dir[2] = 1.0f;
     r.seed[0] = r.seed[1] = r.seed[2] = 0.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) r.dout[q] = (h1)0;
-    if (!valid) return;
     if (IN_MODE == IN_ROWMAJOR) {
 #pragma unroll
         for (int c = 0; c < N_IN / 16; ++c) r.in[c] = *reinterpret_cast<const half8_t*>(io.fwd.in + s * N_IN + 16 * c + 8 * hh);
@@ -487,6 +563,8 @@ __device__ __forceinline__ void bwd_fetch(const MlpBwdIO& io, long long j, long 
                 r.in[c][2 * q] = v[0]; r.in[c][2 * q + 1] = v[1];
             }
     } else {
+        const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+        r.in[0] = z;
         r.dir[0] = io.fwd.dirs[3 * s]; r.dir[1] = io.fwd.dirs[3 * s + 1]; r.dir[2] = io.fwd.dirs[3 * s + 2];
         r.in[1] = *reinterpret_cast<const half8_t*>(io.fwd.in + s * 16 + 8 * hh);
     }
@@ -494,11 +572,19 @@ __device__ __forceinline__ void bwd_fetch(const MlpBwdIO& io, long long j, long 
 #pragma unroll
         for (int c = 0; c < 3; ++c) r.seed[c] = io.dL_drgbs[3 * s + c];
     } else {
-        if (io.dL_dout16) {
+        if (io.dL_dout16) {                                       // wave-uniform conditions from here on
+            if (io.dout_ld == 16 && io.fwd.n_out == 16) {        // (S,16) rows: units 4hh+{0..3} and 8+4hh+{0..3} as two 8-byte loads
+                const half4_t lo = *reinterpret_cast<const half4_t*>(io.dL_dout16 + j * 16 + 4 * hh);
+                const half4_t hi = *reinterpret_cast<const half4_t*>(io.dL_dout16 + j * 16 + 8 + 4 * hh);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int u = 4 * hh + (q & 3) + 8 * (q >> 2);
-                if (u < io.fwd.n_out) r.dout[q] = io.dL_dout16[j * io.dout_ld + u];
+                for (int q = 0; q < 4; ++q) { r.dout[q] = lo[q]; r.dout[4 + q] = hi[q]; }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int u = 4 * hh + (q & 3) + 8 * (q >> 2);
+                    const h1 v = io.dL_dout16[j * io.dout_ld + (u < io.fwd.n_out ? u : 0)];
+                    r.dout[q] = u < io.fwd.n_out ? v : (h1)0;
+                }
             }
         }
         if (OUT_MODE == OUT_DENSITY && io.dL_dsigmas) r.seed[0] = io.dL_dsigmas[s];
@@ -513,7 +599,7 @@ __device__ __forceinline__ void bwd_input(const BwdRaw<N_IN>& r, int hh, half8_t
     if (IN_MODE == IN_SH_H) {
         const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
         b[0] = z;
-        if (r.valid) {
+        {
             const float dx = r.dir[0], dy = r.dir[1], dz = r.dir[2];
             const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
             float sh[16];
@@ -524,36 +610,59 @@ __device__ __forceinline__ void bwd_input(const BwdRaw<N_IN>& r, int hh, half8_t
     }
 }
 
+#ifdef NGP_MLP_TIMING
+// A/B instrumentation (tools/build_variant.sh ... -DNGP_MLP_TIMING): core-clock cycles wave 0 of every workgroup spends per stage
+__device__ unsigned long long g_mlp_t[16];
+#define MLP_T(k) do { const long long now_ = clock64(); t_acc[k] += now_ - t_last; t_last = now_; } while (0)
+#define MLP_T0() long long t_acc[6] = {0, 0, 0, 0, 0, 0}; long long t_last = clock64()
+#define MLP_TEND() do { if (threadIdx.x == 0) for (int k_ = 0; k_ < 6; ++k_) atomicAdd(&g_mlp_t[k_], (unsigned long long)t_acc[k_]); } while (0)
+#else
+#define MLP_T(k) do { } while (0)
+#define MLP_T0() do { } while (0)
+#define MLP_TEND() do { } while (0)
+#endif
+
+template <int N_IN, int N_HIDDEN>
+struct BwdLds {
+    using L = LdsW<N_IN, N_HIDDEN>;
+    static constexpr int NXB = (N_IN + 31) / 32;                                   // input blocks
+    static constexpr int NB = NXB + 4 + (N_HIDDEN == 2 ? 4 : 0) + 1;               // blocks per wave
+    static constexpr int W_HALVES = L::SIZE + N_IN * (HID + PAD) + (N_HIDDEN == 2 ? HID * (HID + PAD) : 0) + HID * (16 + PAD);
+    static constexpr int OFF_TR = (W_HALVES + 127) / 128 * 128;
+    static constexpr int IMG_BYTES = BWD_WAVES * NB * BLK_BYTES;
+    static constexpr int PART_BYTES = BWD_WAVES * HID * (N_IN > HID ? N_IN : HID) * 4;   // one f32 slab per wave of the largest layer
+    static constexpr int BYTES = OFF_TR * 2 + (IMG_BYTES > PART_BYTES ? IMG_BYTES : PART_BYTES);
+};
+
 template <int N_IN, int N_HIDDEN, int IN_MODE, int OUT_MODE>
-__global__ void __launch_bounds__(64 * WAVES)
+__global__ void __launch_bounds__(64 * BWD_WAVES)
 mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
     using L = LdsW<N_IN, N_HIDDEN>;
     // LDS carve-up (halves unless noted):
     //   forward weights (L::SIZE) | transposed weights W0^T (N_IN, 64) W1^T (64,64) Wo^T (64,16)
-    //   | per-wave transpose tiles 2 x (64 x TP) | f32 partial dW (G_SIZE floats)
+    //   | per-wave weight-gradient operand images (B::NB blocks of 2 KB) -- reused for the dW reduction slabs at the end
     constexpr int LDT0 = HID + PAD;                 // W0^T rows = in units, cols = 64 hidden
     constexpr int OFF_T0 = L::SIZE;
     constexpr int OFF_T1 = OFF_T0 + N_IN * LDT0;    // W1^T (64,64)
     constexpr int OFF_TO = OFF_T1 + (N_HIDDEN == 2 ? HID * (HID + PAD) : 0);   // Wo^T (64,16)
     constexpr int LDTO = 16 + PAD;
-    constexpr int OFF_TR = OFF_TO + HID * LDTO;
-    constexpr int TR_PER_WAVE = 2 * 64 * TP;
-    constexpr int OFF_PART_H = OFF_TR + WAVES * TR_PER_WAVE;   // halves; f32 partial follows (16B aligned)
-    static_assert(OFF_PART_H % 8 == 0, "partial must be 16-byte aligned");
+    using B = BwdLds<N_IN, N_HIDDEN>;
+    constexpr int OFF_TR = B::OFF_TR;               // the waves' operand images (256-byte aligned); the dW reduction slabs reuse them
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     h1* lds = reinterpret_cast<h1*>(smem_raw);
-    float* part = reinterpret_cast<float*>(lds + OFF_PART_H);
+    float* part = reinterpret_cast<float*>(lds + OFF_TR);
 
-    stage_fwd_weights<N_IN, N_HIDDEN>(weights, lds);
-    stage_weights(weights, lds + OFF_T0, HID, N_IN, true);
-    if (N_HIDDEN == 2) stage_weights(weights + L::G_W1, lds + OFF_T1, HID, HID, true);
-    stage_weights(weights + L::G_WO, lds + OFF_TO, 16, HID, true);
-    __syncthreads();
-
+    MLP_T0();
     const int lane = threadIdx.x & 63, i = lane & 31, hh = lane >> 5;
     const int wave = threadIdx.x >> 6;
-    h1* tx = lds + OFF_TR + wave * TR_PER_WAVE;
-    h1* tdy = tx + 64 * TP;
+    char* img = reinterpret_cast<char*>(lds + OFF_TR) + wave * B::NB * BLK_BYTES;
+    char* img_x = img;                                        // network input            (NXB blocks)
+    char* img_dh0 = img_x + B::NXB * BLK_BYTES;               // dL/d hidden 0 (pre-ReLU)   (2)
+    char* img_h0 = img_dh0 + 2 * BLK_BYTES;                   // hidden 0                   (2)
+    char* img_dh1 = img_h0 + 2 * BLK_BYTES;                   // N_HIDDEN == 2 only         (2)
+    char* img_h1 = img_dh1 + 2 * BLK_BYTES;                   //                            (2)
+    char* img_dy = img_h0 + (N_HIDDEN == 2 ? 6 : 2) * BLK_BYTES;   // dL/d output (16 units; units 16..31 feed dW rows nobody stores)
+    const TrAddr ta = tr_addr(lane);
     const int n_eff = io.active ? min(*io.n_active, n_samples) : n_samples;
     const int n_tiles = (n_eff + TILE - 1) / TILE;
 
@@ -570,25 +679,38 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
 
     // two-deep software pipeline over the wave's tiles: sample id of tile t+2 and raw inputs of tile t+1 are in flight while
     // tile t is computed
-    const int tile_stride = gridDim.x * WAVES;
-    auto sample_of = [&](int t, long long& jj, bool& vv) -> long long {
-        jj = (long long)t * TILE + i;                            // compact position
-        vv = t < n_tiles && jj < n_eff;
-        return (io.active && vv) ? (long long)io.active[jj] : jj;   // sample id
+    const int tile_stride = gridDim.x * BWD_WAVES;
+    // Sample id of tile t for this lane, loaded unconditionally from a clamped position (without a list: a dummy word of the
+    // weight blob, ignored).  Lanes past the end get the last sample; a garbage id (n_eff == 0) is clamped into the arrays.
+    const bool has_list = io.active != nullptr;                      // wave-uniform
+    const long long j_last = n_eff > 0 ? n_eff - 1 : 0;
+    const int32_t* idx_src = has_list ? io.active : reinterpret_cast<const int32_t*>(weights);
+    auto raw_index = [&](int t) -> int {
+        const long long jj = (long long)t * TILE + i;
+        return idx_src[has_list ? (jj < j_last ? jj : j_last) : 0];
+    };
+    auto fetch = [&](int t, int raw, BwdRaw<N_IN>& r) {
+        const long long jj = (long long)t * TILE + i;                // compact position
+        const bool vv = t < n_tiles && jj < n_eff;
+        const long long jc = jj < j_last ? jj : j_last;
+        long long sc = has_list ? (long long)raw : jc;
+        sc = sc < 0 ? 0 : (sc < n_samples ? sc : (long long)n_samples - 1);
+        bwd_fetch<N_IN, IN_MODE, OUT_MODE>(io, jc, sc, vv, n_samples, hh, r);
     };
     BwdRaw<N_IN> cur, nxt;
-    long long j_pre; bool v_pre;
-    long long s_pre;
-    {
-        const int t0 = blockIdx.x * WAVES + wave;
-        long long j0; bool v0;
-        const long long s0 = sample_of(t0, j0, v0);
-        bwd_fetch<N_IN, IN_MODE, OUT_MODE>(io, j0, s0, v0, n_samples, hh, cur);
-        s_pre = sample_of(t0 + tile_stride, j_pre, v_pre);
-    }
-    for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += tile_stride) {
-        bwd_fetch<N_IN, IN_MODE, OUT_MODE>(io, j_pre, s_pre, v_pre, n_samples, hh, nxt);          // tile + stride
-        s_pre = sample_of(tile + 2 * tile_stride, j_pre, v_pre);                                   // tile + 2 strides
+    const int t0 = blockIdx.x * BWD_WAVES + wave;
+    const int raw0 = raw_index(t0);                    // in flight while the weights are staged
+    int raw_pre = raw_index(t0 + tile_stride);
+    stage_fwd_weights<N_IN, N_HIDDEN>(weights, lds);
+    stage_weights(weights, lds + OFF_T0, HID, N_IN, true);
+    if (N_HIDDEN == 2) stage_weights(weights + L::G_W1, lds + OFF_T1, HID, HID, true);
+    stage_weights(weights + L::G_WO, lds + OFF_TO, 16, HID, true);
+    fetch(t0, raw0, cur);
+    __syncthreads();
+    MLP_T(0);                                          // prologue: weights staged, first tile fetched
+    for (int tile = t0; tile < n_tiles; tile += tile_stride) {
+        fetch(tile + tile_stride, raw_pre, nxt);                     // raw inputs of the next tile ...
+        raw_pre = raw_index(tile + 2 * tile_stride);                 // ... and the sample ids of the one after it are in flight
         const long long j = cur.j;
         const bool valid = cur.valid;
         const long long s = cur.s;
@@ -644,6 +766,7 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
                 }
             }
         }
+        MLP_T(1);                                      // forward recompute + output gradient
         // ---- dgrad: output layer -> last hidden ----
         half8_t dh1b[4], dh0b[4];
         {
@@ -657,10 +780,7 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int c2 = 0; c2 < 2; ++c2) {
-                    half8_t b = d_to_b<false>(d[m], c2);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) if (!(hlast[2 * m + c2][e] > (h1)0)) b[e] = (h1)0;   // ReLU'
-                    dst[2 * m + c2] = b;
+                    dst[2 * m + c2] = relu_bwd(d_to_b<false>(d[m], c2), hlast[2 * m + c2]);
                 }
         }
         if (N_HIDDEN == 2) {
@@ -675,10 +795,7 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int c2 = 0; c2 < 2; ++c2) {
-                    half8_t b = d_to_b<false>(d[m], c2);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) if (!(h0b[2 * m + c2][e] > (h1)0)) b[e] = (h1)0;
-                    dh0b[2 * m + c2] = b;
+                    dh0b[2 * m + c2] = relu_bwd(d_to_b<false>(d[m], c2), h0b[2 * m + c2]);
                 }
         }
         // ---- dgrad into the network input ----
@@ -722,65 +839,40 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
                 }
             }
         }
-        // ---- wgrad (samples on K: transpose through the wave-private LDS tiles) ----
-        // layer 0: dW0 (64 x N_IN) = dH0^T * X
-        tr_write_nat<N_IN / 16>(tx, xb, i, hh);
-        if (N_IN < 32) {   // zero the unused rows of the 32-wide N tile
-            const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
-            half8_t zz[1] = {z};
-            tr_write_nat<1>(tx + 16 * TP, zz, i, hh);
+        MLP_T(2);                                      // dgrad + input-gradient store
+        // ---- wgrad (samples on K: through the wave-private LDS image, read back transposed) ----
+        wave_lds_sync();                                  // the previous tile's reads are behind us (DS ops of a wave run in order)
+        tr_put_nat<N_IN / 16>(img_x, xb, ta);             // N_IN == 16: units 16..31 of the block feed dW columns nobody stores
+        tr_put_dl<4>(img_dh0, dh0b, ta);
+        tr_put_dl<4>(img_h0, h0b, ta);
+        if (N_HIDDEN == 2) {
+            tr_put_dl<4>(img_dh1, dh1b, ta);
+            tr_put_dl<4>(img_h1, h1b, ta);
         }
-        tr_write_dl<4>(tdy, dh0b, i, hh);
+        tr_put_dl<1>(img_dy, dyb, ta);
         wave_lds_sync();
-        wgrad_tile<2, (N_IN / 32 > 0 ? N_IN / 32 : 1)>(tdy, tx, i, hh, gW0);
-        wave_lds_sync();
-        if (N_HIDDEN == 2) {   // layer 1: dW1 (64 x 64) = dH1^T * H0
-            tr_write_dl<4>(tx, h0b, i, hh);
-            tr_write_dl<4>(tdy, dh1b, i, hh);
-            wave_lds_sync();
-            wgrad_tile<2, 2>(tdy, tx, i, hh, gW1);
-            wave_lds_sync();
-        }
-        // output layer: dWo (16 x 64) = dY^T * Hlast   (dY rows 16..31 of the M tile are zero)
-        tr_write_dl<4>(tx, hlast, i, hh);
-        {
-            const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
-            half8_t two[2] = {dyb[0], z};
-            tr_write_dl<2>(tdy, two, i, hh);
-        }
-        wave_lds_sync();
-        wgrad_tile<1, 2>(tdy, tx, i, hh, gWo);
-        wave_lds_sync();
+        MLP_T(3);                                      // image stores
+        wgrad_tile<2, B::NXB>(img_dh0, img_x, ta, gW0);                                   // dW0 (64 x N_IN) = dH0^T X
+        if (N_HIDDEN == 2) wgrad_tile<2, 2>(img_dh1, img_h0, ta, gW1);                    // dW1 (64 x 64)   = dH1^T H0
+        wgrad_tile<1, 2>(img_dy, (N_HIDDEN == 2) ? img_h1 : img_h0, ta, gWo);             // dWo (16 x 64)   = dY^T Hlast
+        MLP_T(4);                                      // wgrad
         cur = nxt;
     }
-    // ---- reduce the 4 waves' dW into LDS (one wave at a time), then one coalesced partial row per workgroup ----
+    // ---- reduce the waves' dW layer by layer into the workgroup's partial row ----
+    __syncthreads();                                      // the slabs reuse the operand images: every wave is done with them
     constexpr int NT0 = (N_IN / 32 > 0 ? N_IN / 32 : 1);
-    for (int w = 0; w < WAVES; ++w) {
-        if (wave == w) {
-            if (w == 0) {
-                wgrad_flush<2, NT0, true>(part, N_IN, HID, N_IN, i, hh, gW0);
-                if (N_HIDDEN == 2) wgrad_flush<2, 2, true>(part + L::G_W1, HID, HID, HID, i, hh, gW1);
-                wgrad_flush<1, 2, true>(part + L::G_WO, HID, 16, HID, i, hh, gWo);
-            } else {
-                wgrad_flush<2, NT0, false>(part, N_IN, HID, N_IN, i, hh, gW0);
-                if (N_HIDDEN == 2) wgrad_flush<2, 2, false>(part + L::G_W1, HID, HID, HID, i, hh, gW1);
-                wgrad_flush<1, 2, false>(part + L::G_WO, HID, 16, HID, i, hh, gWo);
-            }
-        }
-        __syncthreads();
-    }
     float* out = io.wgrad_partial + (size_t)blockIdx.x * L::G_SIZE;
-    for (int t = threadIdx.x; t < L::G_SIZE; t += blockDim.x) out[t] = part[t];
+    wgrad_reduce_layer<2, NT0>(part, HID, N_IN, wave, i, hh, gW0, out);
+    if (N_HIDDEN == 2) wgrad_reduce_layer<2, 2>(part, HID, HID, wave, i, hh, gW1, out + L::G_W1);
+    wgrad_reduce_layer<1, 2>(part, 16, HID, wave, i, hh, gWo, out + L::G_WO);
+    MLP_T(5);                                          // epilogue
+    MLP_TEND();
 }
 
 template <int N_IN, int N_HIDDEN>
 constexpr int fwd_smem_bytes() { return LdsW<N_IN, N_HIDDEN>::SIZE * 2; }
 template <int N_IN, int N_HIDDEN>
-constexpr int bwd_smem_bytes() {
-    using L = LdsW<N_IN, N_HIDDEN>;
-    return (L::SIZE + N_IN * (HID + PAD) + (N_HIDDEN == 2 ? HID * (HID + PAD) : 0) + HID * (16 + PAD) +
-            WAVES * 2 * 64 * TP) * 2 + L::G_SIZE * 4;
-}
+constexpr int bwd_smem_bytes() { return BwdLds<N_IN, N_HIDDEN>::BYTES; }
 
 int fwd_grid(int n_samples) {
     const int n_tiles = (n_samples + TILE - 1) / TILE;
@@ -792,7 +884,7 @@ int fwd_grid(int n_samples) {
 }
 int bwd_grid(int n_samples) {
     const int n_tiles = (n_samples + TILE - 1) / TILE;
-    const int blocks = (n_tiles + WAVES - 1) / WAVES;
+    const int blocks = (n_tiles + BWD_WAVES - 1) / BWD_WAVES;
     return blocks < 256 ? (blocks < 1 ? 1 : blocks) : 256;   // one workgroup per CU; bounds the partial buffer
 }
 
@@ -806,12 +898,13 @@ template <int N_IN, int N_HIDDEN, int IN_MODE, int OUT_MODE>
 int launch_bwd(const MlpBwdIO& io, const h1* w, int n_samples, hipStream_t st) {
     constexpr int smem = bwd_smem_bytes<N_IN, N_HIDDEN>();
     static_assert(smem <= 160 * 1024, "LDS budget");
+    if (reinterpret_cast<uintptr_t>(io.wgrad_partial) & 15) return NGP_EINVAL;     // partial rows are stored 16 bytes at a time
     auto kern = mlp_bwd_kernel<N_IN, N_HIDDEN, IN_MODE, OUT_MODE>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
     }
-    kern<<<dim3(bwd_grid(n_samples)), dim3(64 * WAVES), smem, st>>>(io, w, n_samples);
+    kern<<<dim3(bwd_grid(n_samples)), dim3(64 * BWD_WAVES), smem, st>>>(io, w, n_samples);
     return NGP_LAUNCH_RESULT();
 }
 
@@ -919,6 +1012,14 @@ int ngp_field_fwd_n(const ngp_half* feats, const float* dirs, const ngp_half* de
         io, (const h1*)density_w, (const h1*)rgb_w, n_samples);
     return NGP_LAUNCH_RESULT();
 }
+
+#ifdef NGP_MLP_TIMING
+int ngp_debug_mlp_timing(unsigned long long* host_out, int reset) {
+    if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_mlp_t), sizeof(g_mlp_t)) != hipSuccess) return NGP_EINVAL;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_t), z, sizeof(z)) != hipSuccess) return NGP_EINVAL; }
+    return 0;
+}
+#endif
 
 int ngp_field_bwd_partials(int n_samples) { return n_samples <= 0 ? 0 : bwd_grid(n_samples); }
 

@@ -7,6 +7,7 @@ cd "$(dirname "$0")/../ngp_pl_amd/csrc"
 name=$1; src=$2; shift 2
 mkdir -p variants
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-result"
+if [ "$src" == "mlp.hip" ]; then FLAGS="$FLAGS -mllvm -amdgpu-mfma-vgpr-form"; fi
 /opt/rocm/bin/hipcc $FLAGS "$@" -c $src -o variants/${src%.hip}_$name.o
 objs=""
 for f in march composite hashgrid mlp optim occupancy hashgrid_bwd_binned; do
