@@ -68,9 +68,14 @@ __device__ __forceinline__ half8_t ldsA_dl(const h1* W, int ld, int row, bool va
 // and the -0 a tiny negative pre-activation rounds to -- becomes +0, exactly what (half)fmaxf(v, 0) gives.
 template <bool RELU>
 __device__ __forceinline__ half8_t d_to_b(const f32x16& d, int c2) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     half8_t b;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) b[e] = (h1)d[8 * c2 + e];
+    for (int e = 0; e < 8; e += 2) {                      // <2 x float> -> <2 x half>: one v_cvt_pk_f16_f32 (round to nearest even)
+        const f32x2 p = {d[8 * c2 + e], d[8 * c2 + e + 1]};
+        const half2_t q = __builtin_convertvector(p, half2_t);
+        b[e] = q[0]; b[e + 1] = q[1];
+    }
     if (RELU) {
         typedef short short8_t __attribute__((ext_vector_type(8)));
         const short8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -334,13 +339,31 @@ field_fwd_kernel(FieldIO io, const h1* __restrict__ density_w, const h1* __restr
     const int lane = threadIdx.x & 63, i = lane & 31, hh = lane >> 5;
     const int wave = threadIdx.x >> 6;
     const int n_tiles = (n_samples + TILE - 1) / TILE;
-    MlpIO din = {};
-    din.in = io.feats;
-    for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
+    // one tile of raw inputs ahead: the loads of tile t+1 are in flight while tile t runs through the networks (two waves per
+    // SIMD alone left every wave waiting a memory round trip per tile).  Straight-line loads from a clamped sample position.
+    const half2_t* fp = reinterpret_cast<const half2_t*>(io.feats);
+    const long long s_last = n_samples - 1;
+    half8_t x_nxt[2]; float d_nxt[3];
+    auto fetch = [&](int t) {
+        const long long sj = (long long)t * TILE + i;
+        const long long sc = sj < s_last ? sj : s_last;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const half2_t v = __builtin_nontemporal_load(fp + (size_t)(8 * c + 4 * hh + q) * n_samples + sc);
+                x_nxt[c][2 * q] = v[0]; x_nxt[c][2 * q + 1] = v[1];
+            }
+        d_nxt[0] = io.dirs[3 * sc]; d_nxt[1] = io.dirs[3 * sc + 1]; d_nxt[2] = io.dirs[3 * sc + 2];
+    };
+    const int tile_stride = gridDim.x * WAVES;
+    fetch(blockIdx.x * WAVES + wave);
+    for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += tile_stride) {
         const long long s = (long long)tile * TILE + i;
         const bool valid = s < n_samples;
-        half8_t xb[2];
-        load_input<32, IN_LEVELMAJOR>(din, s, valid, n_samples, hh, xb);
+        half8_t xb[2] = {x_nxt[0], x_nxt[1]};
+        const float dx = d_nxt[0], dy = d_nxt[1], dz = d_nxt[2];
+        fetch(tile + tile_stride);
         f32x16 acc[2];
         half8_t hb[4];
         layer_in<32>(ldsd + LD::OFF_W0, xb, i, hh, acc);
@@ -352,9 +375,8 @@ field_fwd_kernel(FieldIO io, const h1* __restrict__ density_w, const h1* __restr
 #pragma unroll
         for (int e = 0; e < 8; ++e) hfrag[e] = (h1)o[0][e];
         // colour net input chunk 0: SH(d/|d|), natural K order
-        half8_t shfrag = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (valid) {
-            const float dx = io.dirs[3 * s], dy = io.dirs[3 * s + 1], dz = io.dirs[3 * s + 2];
+        half8_t shfrag;
+        {
             const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
             float sh[16];
             sh4(dx * inv, dy * inv, dz * inv, sh);
