@@ -157,13 +157,13 @@ class Trainer:
         self.side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("NGP_MARCH_PRIORITY", "-1"))) if (overlap_march and dev.type == "cuda") else None
         self._pending = None     # marched-but-not-consumed batch
         # where in the step the next batch's march is enqueued (it starts behind whatever the main stream has queued by
-        # then): "top" = next to the hash forward (default), "hashgrid_fwd" / "mlp_fwd" / "mlp_bwd" / "hashgrid_bwd" = behind
-        # that stage.  NGP_MARCH_LATE=1 is "mlp_bwd" (next to the table backward's latency-bound slice owners).
-        # Measured in round 2 (gpurun_out/sweep_march_r2.txt -> profiles/r02_march_sweep.txt): with the wave-per-ray pass-1 kernel
-        # every placement up to "mlp_bwd" gives the same step time (0.495-0.51 ms); "mlp_fwd" keeps the march away from the hash forward
-        # (which it slows) and well ahead of the next step's host wait.
-        self.march_at = os.environ.get("NGP_MARCH_AT", "mlp_fwd")
-        if self.march_at not in ("top", "hashgrid_fwd", "mlp_fwd", "mlp_bwd", "hashgrid_bwd"):
+        # then): "top" = next to the hash forward, "hashgrid_fwd" / "mlp_fwd" / "composite_fw" (default) / "composite_bw" / "mlp_bwd" /
+        # "hashgrid_bwd" = behind that stage.
+        # Measured in round 2 (profiles/r02_march_sweep.txt): up to "mlp_bwd" the placements were within noise of each other while the
+        # MLP backward took 68 us; with the faster MLP kernels (45 us) the march behind the composite forward -- next to the composite
+        # and MLP backward instead of the hash / field forward it slows -- is 3.5 % ahead of "mlp_fwd" (0.447 vs 0.464 ms, 3 runs each).
+        self.march_at = os.environ.get("NGP_MARCH_AT", "composite_fw")
+        if self.march_at not in ("top", "hashgrid_fwd", "mlp_fwd", "composite_fw", "composite_bw", "mlp_bwd", "hashgrid_bwd"):
             raise ValueError("NGP_MARCH_AT: unknown stage %r" % self.march_at)
         self.last = {}
         self.grad_hook = None    # called between backward and optimizer (multi-GPU gradient all-reduce)
@@ -228,8 +228,8 @@ class Trainer:
         st = self.side if self.side is not None else main
         ready, done = B.ready[k], B.done[k]                 # reusable events of this record set
         if st is not main:
-            ready.record(main)
-            st.wait_event(ready)
+            ready.record(main)          # (event flags make no difference to the ~6 us the marker packet idles the main stream:
+            st.wait_event(ready)        #  hipEventDisableSystemFence / ReleaseToDevice measured the same)
         sq = st.cuda_stream                      # raw handle once: torch.cuda.current_stream() costs ~8 us per call
         B.counter_np[k][0] = -1
         if st is not main:
@@ -341,6 +341,8 @@ class Trainer:
                  self.lambda_opacity, self.grad_scale, P["stats"], P["stats"] + 4, P["dL_drgb"], P["dL_dopacity"],
                  P["fw_ws"], B.fw_bytes, mq)
             self._mark("composite_fw+loss")
+            if S > 0:
+                march_next_if_at("composite_fw")
             use_dist = self.lambda_distortion > 0
             if S > 0:
                 # backward only over the samples up to each ray's early stop (the rest have zero gradient):
@@ -361,6 +363,7 @@ class Trainer:
                      P["deltas"], P["ts"], rays_a, P["opacity"], P["depth"], P["rgb"], self.T_threshold, n, S,
                      P["dL_dsigmas"], P["dL_drgbs"], P["ray_offs"], P["active"], P["xyzs"] if binned else None, P["x_act"] if binned else None, mq)
                 self._mark("composite_bw")
+                march_next_if_at("composite_bw")
                 n_part = call("ngp_field_bwd_partials", S)
                 assert n_part <= B.MAX_PARTIALS
                 call("ngp_field_bwd", P["feats"], P["dirs"], P["h"], eh_p, rh_p, P["dL_dsigmas"], P["dL_drgbs"], self.loss_scale, S,
