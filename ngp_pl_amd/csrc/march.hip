@@ -156,7 +156,7 @@ packbits_kernel(const T* __restrict__ grid, int n_bytes, float thr, const float*
 // depend on the arrival order of atomics: workgroups park their partial sums in a library-owned
 // scratch and the last one to finish (self-resetting ticket) adds them in workgroup order.
 // Like ngp_nerf_loss: do not run two of these launches concurrently on different streams.
-constexpr int GRID_UPDATE_BLOCKS = 512;
+constexpr int GRID_UPDATE_BLOCKS = 256;      // every workgroup pays a fence + ticket at the end: 2048 of them took 73 us, 512 20 us
 __device__ unsigned int g_grid_ticket = 0;
 __device__ float g_grid_partial[2 * GRID_UPDATE_BLOCKS];
 
@@ -165,7 +165,24 @@ density_grid_update_kernel(float* __restrict__ grid, const float* __restrict__ t
                            const float* __restrict__ decay_grid, float decay, int n,
                            float* __restrict__ stats) {
     float sum = 0.f, cnt = 0.f;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    // 16 bytes per lane and stream (three streams, 24 MB for a 128^3 grid: 25 us with 4-byte accesses); the scalar loop takes the
+    // tail of a cell count that is not a multiple of 4
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int n4 = n >> 2;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+        const f32x4 g = reinterpret_cast<const f32x4*>(grid)[i];
+        const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tmp) + i);
+        f32x4 dk = {decay, decay, decay, decay};
+        if (decay_grid) dk = reinterpret_cast<const f32x4*>(decay_grid)[i];
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = (g[e] < 0) ? g[e] : fmaxf(g[e] * dk[e], t[e]);
+            if (v[e] > 0) { sum += v[e]; cnt += 1.f; }
+        }
+        reinterpret_cast<f32x4*>(grid)[i] = v;
+    }
+    for (int i = 4 * n4 + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float g = grid[i];
         const float dk = decay_grid ? decay_grid[i] : decay;
         const float v = (g < 0) ? g : fmaxf(g * dk, tmp[i]);
@@ -1026,7 +1043,9 @@ int ngp_density_grid_update(float* density_grid, const float* density_grid_tmp, 
     if (n_cells < 0) return NGP_EINVAL;
     if (n_cells == 0) return 0;
     NGP_CHECK_PTR(density_grid); NGP_CHECK_PTR(density_grid_tmp); NGP_CHECK_PTR(stats);
-    const int blocks = min(ngp_div_up(n_cells, 256), GRID_UPDATE_BLOCKS);
+    if ((reinterpret_cast<uintptr_t>(density_grid) | reinterpret_cast<uintptr_t>(density_grid_tmp) | reinterpret_cast<uintptr_t>(decay_grid)) & 15)
+        return NGP_EINVAL;                                   // 16-byte accesses
+    const int blocks = min(ngp_div_up(ngp_div_up(n_cells, 4), 256), GRID_UPDATE_BLOCKS);
     hipLaunchKernelGGL(density_grid_update_kernel, dim3(blocks), dim3(256), 0, ngp_stream(stream),
                        density_grid, density_grid_tmp, decay_grid, decay, n_cells, stats);
     return NGP_LAUNCH_RESULT();

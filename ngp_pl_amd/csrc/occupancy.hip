@@ -2,10 +2,10 @@
 // /root/reference/models/networks.py:155-195, 240-269; train.py:160-163 calls it every 16 steps).
 //
 // The reference does this with ~100 small torch launches and two host syncs (nonzero(), .item()).
-// Here one call enqueues, per cascade: occupancy words + prefix (2 launches), cell sampling with
-// jittered positions (1), the density-only field forward (hash grid + density MLP whose epilogue
-// scatters sigma straight into the scratch grid, 2), then the decay/max merge with the masked
-// mean (1) and the bit packing with the device-side threshold (1).
+// Here one call enqueues, per cascade: occupancy words + prefix (2 launches), the cell draws (1), their regrouping
+// by Morton block with the jittered positions (3; warm-up needs none: every cell once, in order), the density-only
+// field forward (hash grid + density MLP whose epilogue scatters sigma straight into the scratch grid, 2), then the
+// decay/max merge with the masked mean (1) and the bit packing with the device-side threshold (1).
 //
 // Sampling semantics (networks.py:169-195): per cascade M = G^3/4 cells uniform over the grid plus
 // M cells uniform over {cell : density_grid > density_threshold} (with replacement); warm-up: every
@@ -35,34 +35,48 @@ occ_words_kernel(const float* __restrict__ grid, float threshold, int n_words,
     if (lane == 0) { words[w] = m; counts[w] = __popcll(m); }
 }
 
-// exclusive scan of counts in one workgroup; prefix[n] = total.  Tiles of 1024 counts: coalesced
-// loads, wave shuffle scan, carry across tiles (32 tiles for G = 128).
+// exclusive scan of counts in one workgroup; prefix[n] = total.  Each of the 16 waves owns one contiguous run of the counts and
+// walks it 256 counts (64 lanes x 16 bytes, coalesced) at a time: pass 1 sums the run, the 16 run totals are exchanged through
+// LDS, pass 2 re-reads (L2) and writes the prefixes -- two barriers in all.  (Tile by tile with four barriers per 1024 counts it
+// took 36 us for the 32 768 words of a 128^3 grid.)
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
 __global__ void __launch_bounds__(1024)
 occ_scan_kernel(const int32_t* __restrict__ counts, int n, int32_t* __restrict__ prefix) {
     __shared__ int s_wave[16];
-    __shared__ int s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_carry = 0;
+    const int n4 = n >> 2;                                     // whole int4 groups; a tail of n & 3 counts goes to the last thread
+    const int run = ((n4 + 15) / 16 + 63) / 64 * 64;           // int4 groups per wave, a multiple of the 64 lanes
+    const int begin = min(wave * run, n4), end = min(begin + run, n4);
+    const int4* c4 = reinterpret_cast<const int4*>(counts);
+    int sum = 0;
+    for (int g = begin + lane; g < end; g += 64) { const int4 v = c4[g]; sum += (v.x + v.y) + (v.z + v.w); }
+    sum = wave_incl_scan(sum, lane);
+    if (lane == 63) s_wave[wave] = sum;
     __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + tid;
-        const int v = (i < n) ? counts[i] : 0;
-        int incl = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int u = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += u;
-        }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        int off = s_carry;
-        for (int w = 0; w < wave; ++w) off += s_wave[w];
-        if (i < n) prefix[i] = off + incl - v;
-        __syncthreads();
-        if (tid == 1023) s_carry = off + incl;
-        __syncthreads();
+    int carry = 0;
+    for (int w = 0; w < wave; ++w) carry += s_wave[w];
+    for (int g0 = begin; g0 < end; g0 += 64) {
+        const int g = g0 + lane;
+        int4 v = {0, 0, 0, 0};
+        if (g < end) v = c4[g];
+        const int local = (v.x + v.y) + (v.z + v.w);
+        const int incl = wave_incl_scan(local, lane);
+        int4 o; o.x = carry + incl - local; o.y = o.x + v.x; o.z = o.y + v.y; o.w = o.z + v.z;
+        if (g < end) reinterpret_cast<int4*>(prefix)[g] = o;
+        carry += __shfl(incl, 63, 64);
     }
-    if (tid == 0) prefix[n] = s_carry;
+    if (tid == 1023) {                                         // the last wave's carry is the total of the int4 part
+        int total = carry;
+        for (int i = 4 * n4; i < n; ++i) { prefix[i] = total; total += counts[i]; }
+        prefix[n] = total;
+    }
 }
 
 // position of the r-th (0-based) set bit of m
@@ -83,9 +97,10 @@ __device__ __forceinline__ int select_bit(unsigned long long m, int r) {
 __global__ void __launch_bounds__(256)
 occ_sample_kernel(int mode, int n, int M, int grid_size, int n_words, const unsigned long long* __restrict__ words,
                   const int32_t* __restrict__ prefix, float s_minus_hgs, float hgs, uint32_t seed_lo, uint32_t seed_hi,
-                  int32_t* __restrict__ cell_idx, float* __restrict__ xyzs) {
+                  int32_t* __restrict__ cell_idx, float* __restrict__ xyzs, float* __restrict__ zero_stats) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (i == 0 && zero_stats != nullptr) { zero_stats[0] = 0.f; zero_stats[1] = 0.f; }   // (an 8-byte hipMemsetAsync is a 7 us launch)
     const uint32_t base = occ_hash(seed_lo ^ occ_hash(seed_hi + 0x9E3779B9u)) + 7u * (uint32_t)i;
     uint32_t idx, cx, cy, cz;
     if (mode == 0) {
@@ -114,6 +129,7 @@ occ_sample_kernel(int mode, int n, int M, int grid_size, int n_words, const unsi
         cx = ngp_compact_bits(idx); cy = ngp_compact_bits(idx >> 1); cz = ngp_compact_bits(idx >> 2);
     }
     cell_idx[i] = (int32_t)idx;
+    if (xyzs == nullptr) return;                 // mode 1: positions are generated where the draws are put in evaluation order
     // (coords/(G-1)*2-1)*(s-hgs) + (rand*2-1)*hgs   (networks.py:253-255), torch op order
     const float gm1 = (float)(grid_size - 1);
     const uint32_t c[3] = {cx, cy, cz};
@@ -124,7 +140,81 @@ occ_sample_kernel(int mode, int n, int M, int grid_size, int n_words, const unsi
     }
 }
 
-struct OccLayout { size_t tmp, words, counts, prefix, idx, xyzs, feats, stats, bytes; };
+// ---- evaluation order of the 2M draws of an update ----
+// The order in which the update evaluates its draws is free (sigma is scattered by cell index), but the hash forward of a million
+// i.i.d. positions gathers incoherently (329 us; ~210 us for the same positions grouped by cell block).  The draws are therefore
+// regrouped by the top bits of their Morton index, each half of the update (uniform / occupied, networks.py:181-192) on its own:
+// a counting sort with workgroup-private LDS histograms -- no global atomics (a million returning global atomics cost 70 us on
+// this part) -- in three small launches: histogram per (workgroup, block), offsets, placement.  Jitter is keyed by the DRAW,
+// so the set of evaluated positions does not depend on the order.
+constexpr int OCC_BUCKETS = 1024;      // cell blocks per half
+constexpr int OCC_SORT_WGS = 64;       // workgroups per half (a multiple of 16).  32 / 64 / 128: histogram + offsets + placement 40 / 38 / 42 us
+
+__global__ void __launch_bounds__(1024)
+occ_hist_kernel(const int32_t* __restrict__ drawn, int M, int shift, int32_t* __restrict__ hist) {
+    __shared__ int s_hist[OCC_BUCKETS];
+    const int half = blockIdx.x / OCC_SORT_WGS, w = blockIdx.x % OCC_SORT_WGS;
+    const int chunk = (M + OCC_SORT_WGS - 1) / OCC_SORT_WGS;
+    const int begin = min(w * chunk, M), end = min(begin + chunk, M);
+    s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = begin + threadIdx.x; i < end; i += 1024) atomicAdd(&s_hist[((uint32_t)drawn[(size_t)half * M + i]) >> shift], 1);
+    __syncthreads();
+    hist[(size_t)blockIdx.x * OCC_BUCKETS + threadIdx.x] = s_hist[threadIdx.x];          // [half][workgroup][block]
+}
+
+// hist[half][w][b] -> first evaluation slot of workgroup w's draws of block b: half * M + (draws of blocks < b) + (block b draws of
+// workgroups < w).  One workgroup per half, thread b walks its column (coalesced across the wave; a row per thread is not: 53 us).
+__global__ void __launch_bounds__(1024)
+occ_hist_scan_kernel(int32_t* __restrict__ hist, int M) {
+    __shared__ int s_wave[16];
+    const int b = threadIdx.x, lane = b & 63, wave = b >> 6;
+    int32_t* h = hist + (size_t)blockIdx.x * OCC_SORT_WGS * OCC_BUCKETS;
+    int total = 0;
+#pragma unroll 16
+    for (int w = 0; w < OCC_SORT_WGS; ++w) total += h[w * OCC_BUCKETS + b];
+    const int incl = wave_incl_scan(total, lane);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int run = (int)blockIdx.x * M + incl - total;
+    for (int w = 0; w < wave; ++w) run += s_wave[w];
+    for (int w0 = 0; w0 < OCC_SORT_WGS; w0 += 16) {          // second walk of the column (L2), 16 loads in flight: counts -> first slots
+        int c[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) c[k] = h[(w0 + k) * OCC_BUCKETS + b];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { h[(w0 + k) * OCC_BUCKETS + b] = run; run += c[k]; }
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+occ_place_kernel(const int32_t* __restrict__ drawn, int M, int shift, const int32_t* __restrict__ offsets, int grid_size,
+                 float s_minus_hgs, float hgs, uint32_t seed_lo, uint32_t seed_hi, int32_t* __restrict__ cell_idx, float* __restrict__ xyzs) {
+    __shared__ int s_cursor[OCC_BUCKETS];
+    const int half = blockIdx.x / OCC_SORT_WGS, w = blockIdx.x % OCC_SORT_WGS;
+    const int chunk = (M + OCC_SORT_WGS - 1) / OCC_SORT_WGS;
+    const int begin = min(w * chunk, M), end = min(begin + chunk, M);
+    s_cursor[threadIdx.x] = offsets[(size_t)blockIdx.x * OCC_BUCKETS + threadIdx.x];
+    __syncthreads();
+    const uint32_t seed = occ_hash(seed_lo ^ occ_hash(seed_hi + 0x9E3779B9u));
+    const float gm1 = (float)(grid_size - 1);
+    for (int k = begin + threadIdx.x; k < end; k += 1024) {
+        const int i = half * M + k;                                    // the draw
+        const uint32_t idx = (uint32_t)drawn[i];
+        const int slot = atomicAdd(&s_cursor[idx >> shift], 1);
+        cell_idx[slot] = (int32_t)idx;
+        // (coords/(G-1)*2-1)*(s-hgs) + (rand*2-1)*hgs   (networks.py:253-255), torch op order; same jitter stream as occ_sample_kernel
+        const uint32_t base = seed + 7u * (uint32_t)i;
+        const uint32_t c[3] = {ngp_compact_bits(idx), ngp_compact_bits(idx >> 1), ngp_compact_bits(idx >> 2)};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float centre = ((float)c[a] / gm1 * 2.0f - 1.0f) * s_minus_hgs;
+            xyzs[3 * (size_t)slot + a] = centre + (u01(occ_hash(base + 4u + a)) * 2.0f - 1.0f) * hgs;
+        }
+    }
+}
+
+struct OccLayout { size_t tmp, words, counts, prefix, idx, xyzs, feats, stats, drawn, hist, bytes; };
 OccLayout occ_layout(int cascades, int grid_size) {
     OccLayout L;
     const size_t cells = (size_t)grid_size * grid_size * grid_size, n_words = cells / 64;
@@ -133,6 +223,8 @@ OccLayout occ_layout(int cascades, int grid_size) {
     L.tmp = take((size_t)cascades * cells * 4);
     L.words = take(n_words * 8); L.counts = take(n_words * 4); L.prefix = take((n_words + 1) * 4);
     L.idx = take(cells * 4); L.xyzs = take(cells * 12); L.feats = take(cells * 64); L.stats = take(8);
+    L.drawn = take(cells * 2);                                 // the 2M = cells / 2 draws in draw order (`idx`: in evaluation order)
+    L.hist = take((size_t)2 * OCC_SORT_WGS * OCC_BUCKETS * 4);
     L.bytes = off;
     return L;
 }
@@ -170,7 +262,6 @@ int ngp_occupancy_update(float* density_grid, uint8_t* density_bitfield, int cas
     const int M = cells / 4;                                   // networks.py:254
     const int n = warmup ? cells : 2 * M;
     hipError_t e = hipMemsetAsync(tmp, 0, (size_t)cascades * cells * 4, st);
-    if (e == hipSuccess) e = hipMemsetAsync(stats, 0, 8, st);
     if (e != hipSuccess) return (int)e;
     for (int c = 0; c < cascades; ++c) {
         float* grid_c = density_grid + (size_t)c * cells;
@@ -184,8 +275,22 @@ int ngp_occupancy_update(float* density_grid, uint8_t* density_bitfield, int cas
         if ((double)scale < s) s = (double)scale;
         const double hgs = s / grid_size;
         const uint64_t sd = seed * 0x9E3779B97F4A7C15ull + (uint64_t)c;
-        hipLaunchKernelGGL(occ_sample_kernel, dim3(ngp_div_up(n, 256)), dim3(256), 0, st, warmup ? 0 : 1, n, M, grid_size, n_words,
-                           words, prefix, (float)(s - hgs), (float)hgs, (uint32_t)sd, (uint32_t)(sd >> 32), idx, xyzs);
+        const uint32_t sd_lo = (uint32_t)sd, sd_hi = (uint32_t)(sd >> 32);
+        if (warmup) {
+            hipLaunchKernelGGL(occ_sample_kernel, dim3(ngp_div_up(n, 256)), dim3(256), 0, st, 0, n, M, grid_size, n_words,
+                               words, prefix, (float)(s - hgs), (float)hgs, sd_lo, sd_hi, idx, xyzs, c == 0 ? stats : (float*)nullptr);
+        } else {
+            int32_t* drawn = reinterpret_cast<int32_t*>(ws + L.drawn);
+            int32_t* hist = reinterpret_cast<int32_t*>(ws + L.hist);
+            int bits = 0; while ((1 << bits) < cells) ++bits;
+            const int shift = bits > 10 ? bits - 10 : 0;           // OCC_BUCKETS = 2^10 blocks of 2^shift cells
+            hipLaunchKernelGGL(occ_sample_kernel, dim3(ngp_div_up(n, 256)), dim3(256), 0, st, 1, n, M, grid_size, n_words,
+                               words, prefix, (float)(s - hgs), (float)hgs, sd_lo, sd_hi, drawn, (float*)nullptr, c == 0 ? stats : (float*)nullptr);
+            hipLaunchKernelGGL(occ_hist_kernel, dim3(2 * OCC_SORT_WGS), dim3(1024), 0, st, drawn, M, shift, hist);
+            hipLaunchKernelGGL(occ_hist_scan_kernel, dim3(2), dim3(1024), 0, st, hist, M);
+            hipLaunchKernelGGL(occ_place_kernel, dim3(2 * OCC_SORT_WGS), dim3(1024), 0, st, drawn, M, shift, hist, grid_size,
+                               (float)(s - hgs), (float)hgs, sd_lo, sd_hi, idx, xyzs);
+        }
         int rc = ngp_hashgrid_fwd(xyzs, xyz_min, xyz_max, table, meta, n, feats, stream);
         if (rc) return rc;
         rc = ngp_density_fwd_scatter(feats, density_w, n, idx, tmp + (size_t)c * cells, stream);

@@ -300,6 +300,8 @@ def test_native_occupancy_update_matches_reference_semantics():
             assert torch.equal(idx, torch.arange(cells, device="cuda"))
         else:
             uni, occ = idx[:M], idx[M:]
+            for half in (uni, occ):                                            # evaluation order: by block of 2^11 cells (Morton), per half
+                assert (torch.diff(half >> 11) >= 0).all()
             c1 = vren.morton3D_invert(uni.int())
             for k in range(3):                                                 # uniform coordinates per axis
                 hist = torch.bincount(c1[:, k].long(), minlength=G).float()
