@@ -35,10 +35,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int HID = 64;          // neurons
 constexpr int PAD = 8;           // halves of row padding in LDS
 constexpr int WAVES = 4;         // waves per workgroup
-#ifndef NGP_MLP_BWD_WAVES
-#define NGP_MLP_BWD_WAVES 4
+// backward: waves per workgroup, one workgroup per CU.  Two hidden layers: 128 accumulator registers and 20 KB of LDS image per
+// wave -> 4 waves, one per SIMD.  One hidden layer (the density net): 64 accumulators, 228 registers in all, 12 KB of image ->
+// 8 waves, two per SIMD, which hide each other's LDS / MFMA latencies.
+#ifndef NGP_MLP_BWD_WAVES_1HIDDEN
+#define NGP_MLP_BWD_WAVES_1HIDDEN 8
 #endif
-constexpr int BWD_WAVES = NGP_MLP_BWD_WAVES;   // backward: waves per workgroup (one workgroup per CU: 128 accumulator registers per wave, 20 KB of LDS image per wave)
+template <int N_IN, int N_HIDDEN>
+constexpr int bwd_waves() { return (N_HIDDEN == 1 && N_IN <= 32) ? NGP_MLP_BWD_WAVES_1HIDDEN : 4; }
 constexpr int TILE = 32;         // samples per wave tile
 
 __device__ __forceinline__ f32x16 mfma(half8_t a, half8_t b, f32x16 c) {
@@ -523,7 +527,7 @@ __device__ __forceinline__ void wgrad_tile(const char* dy, const char* x, const 
 // f32, lanes on consecutive columns: conflict-free), one barrier, then all threads add the slabs 16 bytes at a time and store
 // the sums straight to the workgroup's partial row in global memory.  (Before: the waves took turns read-modify-writing one
 // LDS copy, 4 serial rounds with barriers -- 11 000 cycles of a 70 000-cycle kernel.)
-template <int MT, int NT>
+template <int MT, int NT, int BWD_WAVES>
 __device__ __forceinline__ void wgrad_reduce_layer(float* slabs, int n_rows, int n_cols, int wave, int j, int hh,
                                                    const f32x16 (&acc)[MT][NT], float* __restrict__ out) {
     const int n = n_rows * n_cols;                        // a multiple of 4 (n_cols is)
@@ -647,6 +651,7 @@ __device__ unsigned long long g_mlp_t[16];
 template <int N_IN, int N_HIDDEN>
 struct BwdLds {
     using L = LdsW<N_IN, N_HIDDEN>;
+    static constexpr int BWD_WAVES = bwd_waves<N_IN, N_HIDDEN>();
     static constexpr int NXB = (N_IN + 31) / 32;                                   // input blocks
     static constexpr int NB = NXB + 4 + (N_HIDDEN == 2 ? 4 : 0) + 1;               // blocks per wave
     static constexpr int W_HALVES = L::SIZE + N_IN * (HID + PAD) + (N_HIDDEN == 2 ? HID * (HID + PAD) : 0) + HID * (16 + PAD);
@@ -657,9 +662,10 @@ struct BwdLds {
 };
 
 template <int N_IN, int N_HIDDEN, int IN_MODE, int OUT_MODE>
-__global__ void __launch_bounds__(64 * BWD_WAVES)
+__global__ void __launch_bounds__((64 * bwd_waves<N_IN, N_HIDDEN>()))
 mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
     using L = LdsW<N_IN, N_HIDDEN>;
+    constexpr int BWD_WAVES = bwd_waves<N_IN, N_HIDDEN>();
     // LDS carve-up (halves unless noted):
     //   forward weights (L::SIZE) | transposed weights W0^T (N_IN, 64) W1^T (64,64) Wo^T (64,16)
     //   | per-wave weight-gradient operand images (B::NB blocks of 2 KB) -- reused for the dW reduction slabs at the end
@@ -884,9 +890,9 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
     __syncthreads();                                      // the slabs reuse the operand images: every wave is done with them
     constexpr int NT0 = (N_IN / 32 > 0 ? N_IN / 32 : 1);
     float* out = io.wgrad_partial + (size_t)blockIdx.x * L::G_SIZE;
-    wgrad_reduce_layer<2, NT0>(part, HID, N_IN, wave, i, hh, gW0, out);
-    if (N_HIDDEN == 2) wgrad_reduce_layer<2, 2>(part, HID, HID, wave, i, hh, gW1, out + L::G_W1);
-    wgrad_reduce_layer<1, 2>(part, 16, HID, wave, i, hh, gWo, out + L::G_WO);
+    wgrad_reduce_layer<2, NT0, BWD_WAVES>(part, HID, N_IN, wave, i, hh, gW0, out);
+    if (N_HIDDEN == 2) wgrad_reduce_layer<2, 2, BWD_WAVES>(part, HID, HID, wave, i, hh, gW1, out + L::G_W1);
+    wgrad_reduce_layer<1, 2, BWD_WAVES>(part, 16, HID, wave, i, hh, gWo, out + L::G_WO);
     MLP_T(5);                                          // epilogue
     MLP_TEND();
 }
@@ -906,7 +912,7 @@ int fwd_grid(int n_samples) {
 }
 int bwd_grid(int n_samples) {
     const int n_tiles = (n_samples + TILE - 1) / TILE;
-    const int blocks = (n_tiles + BWD_WAVES - 1) / BWD_WAVES;
+    const int blocks = (n_tiles + 3) / 4;                    // (the same count for every network: the callers' partial rows)
     return blocks < 256 ? (blocks < 1 ? 1 : blocks) : 256;   // one workgroup per CU; bounds the partial buffer
 }
 
@@ -926,7 +932,7 @@ int launch_bwd(const MlpBwdIO& io, const h1* w, int n_samples, hipStream_t st) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
     }
-    kern<<<dim3(bwd_grid(n_samples)), dim3(64 * BWD_WAVES), smem, st>>>(io, w, n_samples);
+    kern<<<dim3(bwd_grid(n_samples)), dim3(64 * bwd_waves<N_IN, N_HIDDEN>()), smem, st>>>(io, w, n_samples);
     return NGP_LAUNCH_RESULT();
 }
 
