@@ -307,63 +307,117 @@ def api_path_rate(loop, n_steps=40):
     return {"rays_per_s": loop.rays / dt, "ms_per_step": dt * 1e3, "what": "render()+NeRFLoss+autograd+FusedAdam, same kernels"}
 
 
-def cpu_baseline(model, data, budget_s=20.0):
+def usable_cpus():
+    """Cores this process may actually use: affinity mask and cgroup quota, not the machine's core count (32 OpenMP threads
+    spinning on a 4-core quota turn the 20 s sample into many minutes)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(model, data, budget_s=20.0, timeout_s=150.0):
     """The CPU oracle timed on the host cores on BASELINE.json configs[0] (256 rays/batch): full
     step = AABB + march + composite fwd/bwd with the reference's own kernels compiled for the CPU
     (oracle/_ref, falls back to our C restatement) + hash grid / MLPs / SH / Adam as fp32 torch-CPU
     (the tiny-cuda-nn restatement, which is why kind = "port").  Checker code only: this is the one
-    place outside tests/ and smoke() that touches oracle/."""
+    place outside tests/ and smoke() that touches oracle/.
+    Runs in a child process under a wall-clock limit: whatever the host does to the CPU leg (on one box it did not come back
+    within the 25 minutes of the call, with every GPU leg done in 3 s), the bench line is printed; the leg then reports
+    value null and says so."""
+    import tempfile
+    cores = min(usable_cpus(), 32)     # tiny tensors: more threads only add synchronisation cost
+    enc = model.xyz_encoder
+    gen = torch.Generator(device=data.device); gen.manual_seed(7)
+    R, n_batches = 256, 101
+    batches = [tuple(t.cpu() for t in data.sample(R, gen)) for _ in range(n_batches)]
+    blob = {"density_w": enc.params.detach()[:enc.n_mlp].cpu().clone(), "table": enc.params.detach()[enc.n_mlp:].cpu().view(-1, 2).clone(),
+            "rgb_w": model.rgb_net.params.detach().cpu().clone(), "bitfield": model.density_bitfield.cpu(),
+            "ro": torch.stack([b[0] for b in batches]), "rd": torch.stack([b[1] for b in batches]), "gt": torch.stack([b[2] for b in batches]),
+            "cores": cores, "budget_s": budget_s}
+    fd, path = tempfile.mkstemp(suffix=".pt", prefix="ngp_cpu_baseline_")
+    os.close(fd)
+    failed = None
+    try:
+        torch.save(blob, path)
+        env = dict(os.environ, OMP_NUM_THREADS=str(cores), MKL_NUM_THREADS=str(cores))
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", path], stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, text=True, timeout=timeout_s, env=env)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and lines:
+                return json.loads(lines[-1])
+            failed = "worker exited with code %d: %s" % (r.returncode, r.stderr.strip()[-300:])
+        except subprocess.TimeoutExpired:
+            failed = "worker did not finish %.0f s of CPU work within %.0f s on this host (%d usable cores)" % (budget_s, timeout_s, cores)
+    finally:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    return {"value": None, "unit": "rays/s", "cores": cores, "kind": "port", "sample": "not measured in this run: " + failed}
+
+
+def cpu_baseline_worker(path):
+    """Child process of cpu_baseline(): no GPU, inputs from the file, one JSON line on stdout."""
     import numpy as np
     from oracle import tcnn_oracle as T
     from oracle.vren_oracle import Oracle, Reference
-    cores = min(os.cpu_count(), 32)     # tiny tensors: more threads only add synchronisation cost
+    blob = torch.load(path)
+    cores, budget_s = int(blob["cores"]), float(blob["budget_s"])
     torch.set_num_threads(cores)
     vr = Reference(True) if Reference.available(True) else Oracle(True)
     field = T.Field(scale=0.5)
-    enc = model.xyz_encoder
-    field.density_w = enc.params.detach()[:enc.n_mlp].cpu().clone().requires_grad_(True)
-    field.table = enc.params.detach()[enc.n_mlp:].cpu().view(-1, 2).clone().requires_grad_(True)
-    field.rgb_w = model.rgb_net.params.detach().cpu().clone().requires_grad_(True)
+    field.density_w = blob["density_w"].requires_grad_(True)
+    field.table = blob["table"].requires_grad_(True)
+    field.rgb_w = blob["rgb_w"].requires_grad_(True)
     opt = torch.optim.Adam([field.density_w, field.table, field.rgb_w], lr=1e-2, eps=1e-15)
-    bitfield = model.density_bitfield.cpu().numpy()
-    gen = torch.Generator(device=data.device); gen.manual_seed(7)
-    R = 256
+    bitfield = blob["bitfield"].numpy()
+    R = blob["ro"].shape[1]
     c = np.zeros((1, 3), np.float32); hs = np.full((1, 3), 0.5, np.float32)
     n_done, S_tot, t0 = -1, 0, time.perf_counter()      # step -1 is an untimed warm-up (lazy inits)
-    while n_done < 0 or (time.perf_counter() - t0 < budget_s and n_done < 100):
-        ro, rd, gt = (t.cpu() for t in data.sample(R, gen))
+    while n_done < 0 or (time.perf_counter() - t0 < budget_s and n_done < blob["ro"].shape[0] - 1):
+        ro, rd, gt = blob["ro"][n_done + 1], blob["rd"][n_done + 1], blob["gt"][n_done + 1]
         _, hits_t, _ = vr.ray_aabb_intersect(ro.numpy(), rd.numpy(), c, hs, 1)
         ht = hits_t[:, 0].copy(); m = (ht[:, 0] >= 0) & (ht[:, 0] < 0.01); ht[m, 0] = 0.01
         noise = np.random.rand(R).astype(np.float32)
         rays_a, xyzs, dirs, deltas, ts, _ = vr.raymarching_train(ro.numpy(), rd.numpy(), ht, bitfield, 1, 0.5, 0.0, noise, 128, 1024)
-        sig, rgb, _ = field.forward(torch.from_numpy(xyzs), torch.from_numpy(dirs))
-        total, opacity, depth, crgb, ws = vr.composite_train_fw(sig.detach().numpy(), rgb.detach().numpy(), deltas, ts, rays_a, 1e-4)
-        o = torch.from_numpy(opacity); col = torch.from_numpy(crgb) + (1 - o)[:, None]
-        dcol = 2 * (col - gt) / (3 * R)
-        oe = o + 1e-10
-        do = -(dcol.sum(1)) + 1e-3 * (-(torch.log(oe) + 1)) / R
-        dsig, drgbs = vr.composite_train_bw(do.numpy(), np.zeros(R, np.float32), dcol.numpy(), np.zeros_like(ws), sig.detach().numpy(),
-                                            rgb.detach().numpy(), ws, deltas, ts, rays_a, opacity, depth, crgb, 1e-4)
-        opt.zero_grad(set_to_none=True)
-        torch.autograd.backward([sig, rgb], [torch.from_numpy(dsig), torch.from_numpy(drgbs)])
-        opt.step()
+        if ts.shape[0] > 0:                              # (an empty occupancy grid gives no samples: nothing to evaluate or to update)
+            sig, rgb, _ = field.forward(torch.from_numpy(xyzs), torch.from_numpy(dirs))
+            total, opacity, depth, crgb, ws = vr.composite_train_fw(sig.detach().numpy(), rgb.detach().numpy(), deltas, ts, rays_a, 1e-4)
+            o = torch.from_numpy(opacity); col = torch.from_numpy(crgb) + (1 - o)[:, None]
+            dcol = 2 * (col - gt) / (3 * R)
+            oe = o + 1e-10
+            do = -(dcol.sum(1)) + 1e-3 * (-(torch.log(oe) + 1)) / R
+            dsig, drgbs = vr.composite_train_bw(do.numpy(), np.zeros(R, np.float32), dcol.numpy(), np.zeros_like(ws), sig.detach().numpy(),
+                                                rgb.detach().numpy(), ws, deltas, ts, rays_a, opacity, depth, crgb, 1e-4)
+            opt.zero_grad(set_to_none=True)
+            torch.autograd.backward([sig, rgb], [torch.from_numpy(dsig), torch.from_numpy(drgbs)])
+            opt.step()
         n_done += 1
         if n_done == 0:
             t0 = time.perf_counter()
         else:
             S_tot += ts.shape[0]
     dt = time.perf_counter() - t0
-    return {"value": R * n_done / dt, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": "%d full training steps of 256 rays (BASELINE configs[0] batch) on the same scene/occupancy grid, %.1f samples/ray, %.1f s; "
-                      "vren kernels = %s, tiny-cuda-nn parts = fp32 torch-CPU restatement with autograd + torch Adam" % (
-                          n_done, S_tot / max(n_done, 1) / R, dt,
-                          "reference .cu compiled for CPU (oracle/_ref)" if isinstance(vr, Reference) else "oracle/ngp_oracle.c")}
+    print(json.dumps({"value": R * n_done / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+                      "sample": "%d full training steps of 256 rays (BASELINE configs[0] batch) on the same scene/occupancy grid, %.1f samples/ray, %.1f s; "
+                                "vren kernels = %s, tiny-cuda-nn parts = fp32 torch-CPU restatement with autograd + torch Adam" % (
+                                    n_done, S_tot / max(n_done, 1) / R, dt,
+                                    "reference .cu compiled for CPU (oracle/_ref)" if isinstance(vr, Reference) else "oracle/ngp_oracle.c")}), flush=True)
 
 
 def secondary_line(name, args, dev):
     """A short run of one of the other recipes (single GPU, rank 0): 320 setup steps, 100 timed."""
+    progress("secondary %s: building" % name)
     loop = Loop(name, args, dev, 0, 1, None)
+    progress("secondary %s: running" % name)
     r = loop.run(setup_steps=args.setup_steps, warmup=10, steps=100, min_timed=100)
+    progress("secondary %s: done" % name)
     met = r["metrics"]
     out = {"workload": loop.description, "rays_per_s": r["rays_per_s"], "ms_per_step": r["ms_per_step"], "rays_per_batch": loop.rays,
            "samples_per_ray_marched": met["rm_s"], "samples_per_ray_composited": met["vr_s"], "train_psnr": met["psnr"],
@@ -389,7 +443,18 @@ class OnlyTheJsonLineOnStdout:
         os.dup2(2, 1)
 
 
+def progress(what):
+    """NGP_BENCH_PROGRESS=1: leg-by-leg progress on stderr (where a run that does not finish got to)."""
+    if os.environ.get("NGP_BENCH_PROGRESS"):
+        print("[bench %8.2f s] %s" % (time.perf_counter() - _T0, what), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--cpu-baseline-worker":
+        return cpu_baseline_worker(sys.argv[2])
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(respawn_under_torchrun(args))
@@ -407,7 +472,9 @@ def main():
     from ngp_pl_amd.bench_support import render_fps
 
     loop = Loop(args.workload, args, dev, rank, world, dist)
+    progress("loop built")
     r = loop.run(args.setup_steps, args.warmup, args.steps)
+    progress("timed windows done")
     met = r["metrics"]
     out = {
         "metric": "train rays/sec (800x800 Lego-like, 8192 rays/batch/GPU, full step incl. optimizer)",
@@ -429,25 +496,46 @@ def main():
         out_stream.emit(json.dumps(out))
     elif rank == 0:
         out["roofline"] = kernel_roofline(loop)
+        progress("roofline done")
+        def leg(name, fn):     # the legs below are reported next to `value`, never part of it: whatever happens in one, the line is printed
+            try:
+                out[name] = fn()
+            except Exception as e:                       # noqa: BLE001 -- recorded in the line, the run goes on
+                out[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            progress(name + " done")
+
         if not args.no_render:
             # device-driven frame loop; chunk_scale/probe_cap only regroup the SAME per-ray samples into fewer
             # iterations (tests/test_train_gpu.py::test_device_frame_loop_matches_host_loop)
             state = "after %d training steps of %d rays" % (loop.trainer.global_step, loop.rays)
-            fast = render_fps(loop.model, loop.data, n_frames=5, chunk_scale=4, probe_cap=64)
-            fast["loop"] = "ngp_render_test_frame chunk_scale=4 probe_cap=64 (same samples per ray, regrouped: <= 1e-5 from the reference chunking)"
-            ref = render_fps(loop.model, loop.data, n_frames=3)
-            ref["loop"] = "ngp_render_test_frame chunk_scale=1 probe_cap=0 (the reference's chunking, bit-identical to its host loop)"
-            fast["field_state"] = ref["field_state"] = state
-            out["render_fps_800x800"] = fast
-            out["render_fps_800x800_reference_chunking"] = ref
+
+            def fast_frames():
+                fast = render_fps(loop.model, loop.data, n_frames=5, chunk_scale=4, probe_cap=64)
+                fast["loop"] = "ngp_render_test_frame chunk_scale=4 probe_cap=64 (same samples per ray, regrouped: <= 1e-5 from the reference chunking)"
+                fast["field_state"] = state
+                return fast
+
+            def reference_frames():
+                ref = render_fps(loop.model, loop.data, n_frames=3)
+                ref["loop"] = "ngp_render_test_frame chunk_scale=1 probe_cap=0 (the reference's chunking, bit-identical to its host loop)"
+                ref["field_state"] = state
+                return ref
+            leg("render_fps_800x800", fast_frames)
+            leg("render_fps_800x800_reference_chunking", reference_frames)
         if not args.no_api:
-            out["api_path"] = api_path_rate(loop)
+            leg("api_path", lambda: api_path_rate(loop))
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(loop.model, loop.data)
+            # (the driver's contract asks for this object; it runs in a child process under a wall-clock limit)
+            leg("cpu_baseline", lambda: cpu_baseline(loop.model, loop.data))
         if not args.no_secondary and world == 1 and args.workload == "lego":
             del loop
             torch.cuda.empty_cache()
-            out["secondary"] = [secondary_line("unbounded", args, dev), secondary_line("lego16k", args, dev)]
+            out["secondary"] = []
+            for name in ("unbounded", "lego16k"):
+                try:
+                    out["secondary"].append(secondary_line(name, args, dev))
+                except Exception as e:                   # noqa: BLE001
+                    out["secondary"].append({"workload": name, "error": "%s: %s" % (type(e).__name__, str(e)[:300])})
         out_stream.emit(json.dumps(out))
     if dist is not None:
         dist.barrier()
