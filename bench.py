@@ -275,8 +275,9 @@ def kernel_roofline(loop, n_steps=ROOFLINE_STEPS):
 def pmc_traffic(stage, S, A):
     """HBM bytes per launch of `stage` from the newest PMC profile under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     separate passes over `bench.py --timed-only`, summarised by tools/pmc_traffic.py).  Not measurable from inside this process;
-    only reported when that profile's operating point (marched and active samples per step) is within 10 % of this run's (the
-    active count of step ~540 differs by +-5 % from run to run: the first steps of the occupancy warm-up use f16 atomics)."""
+    only reported when that profile's operating point is close to this run's: marched samples per step within 10 %, active
+    samples within 20 % (the active count of step ~540 was seen between 145 k and 169 k from run to run: the first steps of the
+    occupancy warm-up add f16 atomics in arrival order); the profile's own operating point is quoted next to the number."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
@@ -288,8 +289,8 @@ def pmc_traffic(stage, S, A):
     if rec is None:
         return None, "%s has no entry for %s" % (rel, stage)
     pS, pA = prof["samples_marched_per_step"], prof["samples_active_per_step"]
-    if abs(pS - S) > 0.10 * S or abs(pA - A) > 0.10 * A:
-        return None, "%s was recorded at %.0f marched / %.0f active samples per step, this run has %.0f / %.0f (> 10 %% apart)" % (rel, pS, pA, S, A)
+    if abs(pS - S) > 0.10 * S or abs(pA - A) > 0.20 * A:
+        return None, "%s was recorded at %.0f marched / %.0f active samples per step, this run has %.0f / %.0f (too far apart)" % (rel, pS, pA, S, A)
     return rec["hbm_bytes_per_launch"], "%s, recorded at %.0f marched / %.0f active samples per step (%s)" % (rel, pS, pA, rec.get("how", "FETCH_SIZE x2 + WRITE_SIZE"))
 
 
