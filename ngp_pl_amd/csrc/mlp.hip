@@ -15,7 +15,9 @@
 // changes which weight columns the A fragment loads.  Activations therefore never leave
 // registers in forward/dgrad; no LDS round trip, no barrier (tiny-cuda-nn goes through shared
 // memory between layers because wmma keeps samples on M).  Only the weight gradient needs the
-// sample on K, i.e. a transpose, which goes through a small wave-private LDS tile.
+// sample on K, i.e. both operands transposed: each wave parks its tile's activations and gradients
+// in a private LDS image in the layout it holds them in and reads them back through gfx950's
+// transposing LDS read (ds_read_b64_tr_b16; see TrAddr below).
 //
 // K-slot renaming: MFMA element e (0..7) of lane-half hh (lane>>5) in K-chunk c is
 //   natural order : unit 16c + 8hh + e                      (operand loaded from memory)
@@ -414,8 +416,8 @@ field_fwd_kernel(FieldIO io, const h1* __restrict__ density_w, const h1* __restr
 }
 
 // ------------------------------------------------------------------------------------------
-// backward kernel: recompute forward, dgrad in registers, wgrad through a wave-private LDS
-// transpose, per-workgroup partial weight gradients.
+// backward kernel: recompute forward, dgrad in registers, wgrad operands through a wave-private
+// LDS image read back transposed, per-workgroup partial weight gradients.
 // ------------------------------------------------------------------------------------------
 struct MlpBwdIO {
     MlpIO fwd;               // inputs as in forward (outputs unused)
