@@ -31,14 +31,25 @@ torchrun it takes RANK/LOCAL_RANK/WORLD_SIZE from the environment.  Per-rank ind
 gradient exchange per step (ngp_pl_amd/ddp.py) -- the reference's only collective (DDP, train.py:270-272).
 Without a GPU (`--dry-run`, implied when none is visible) only the launcher and the process group are
 exercised (gloo): the product path has no CPU fallback.
+
+Robustness (round 2's driver run was killed at 1800 s with nothing on stdout): the ONE line is owned by a watchdog thread
+(`LineKeeper`).  The headline record is handed to it the moment the timed windows are done; every further object
+(`roofline`, `cpu_baseline`, the FPS legs, `api_path`) is a leg with its own wall-clock budget, run in
+order of importance.  A leg that exceeds its budget, or the global deadline (NGP_BENCH_DEADLINE_S, default 270 s from
+process start), gets `{"error": "timeout ..."}`, the stacks of all Python threads go to stderr (faulthandler), the line is
+printed with what is complete and the process leaves through os._exit -- the line is never printed later than the deadline,
+and never twice.  Progress goes to stderr unconditionally, one line per leg.
 """
 import argparse
+import faulthandler
 import gc
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import torch
@@ -71,7 +82,11 @@ def parse():
     p.add_argument("--setup-steps", type=int, default=SETUP_STEPS)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-render", action="store_true")
-    p.add_argument("--no-secondary", action="store_true", help="skip the short unbounded / 16k-ray secondary lines")
+    p.add_argument("--secondary", action="store_true", help="also run the short unbounded / 16k-ray secondary recipes (each rebuilds a "
+                   "100x800x800 dataset and runs 320 setup steps: off by default, they are parity-test configurations, not bench lines)")
+    p.add_argument("--no-secondary", action="store_true", help="(default; kept for older command lines)")
+    p.add_argument("--deadline", type=float, default=float(os.environ.get("NGP_BENCH_DEADLINE_S", "270")),
+                   help="seconds from process start after which the line is printed with whatever is complete")
     p.add_argument("--no-api", action="store_true", help="skip the api_path leg")
     p.add_argument("--timed-only", action="store_true", help="stop after the timed windows (for rocprofv3 runs: the trace then ends with the timed steps)")
     p.add_argument("--dry-run", action="store_true", help="launcher + process group only (gloo, no GPU work)")
@@ -230,7 +245,7 @@ class Loop:
                 "global_step_at_end": tr.global_step}
 
 
-def kernel_roofline(loop, n_steps=ROOFLINE_STEPS):
+def kernel_roofline(loop, ms_per_step=None, n_steps=ROOFLINE_STEPS):
     """Stage times of real training steps from HIP events on the stream the kernels run on (torch's current
     stream), then the roofline of the dominant stage.  Algorithmic bytes per unit are SURVEY.md section 8(d)'s
     (restated in DESIGN.md); the backward stages are priced by the samples they process (the active list)."""
@@ -264,11 +279,20 @@ def kernel_roofline(loop, n_steps=ROOFLINE_STEPS):
     main = [d for d in stages if d["stage"] not in ("grid_update", "march_count(side stream)")]      # the march overlaps the main stream
     top = main[0]
     achieved = top["GB/s"]
-    traffic, source = pmc_traffic(top["stage"], S, A)
+    traffic, source, prof = pmc_traffic(top["stage"], S, A)
+    # every algorithmic byte the step processes (all stages, the march included) over the step time of the timed windows
+    step_bytes = sum(algo.get(d["stage"], 0.0) for d in stages)
+    whole = None
+    if ms_per_step:
+        gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
+        whole = {"bytes_per_step": step_bytes, "ms_per_step": ms_per_step, "achieved": round(gbs, 1), "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                 "what": "sum of the stages' algorithmic bytes (SURVEY.md 8(d) per-unit figures x the units this run processed) / ms_per_step of the timed windows"}
     return {"bound": "hbm", "kernel": top["stage"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
             "avg_ms": top["ms"], "samples_marched_per_launch": S, "samples_active_per_launch": A,
             "units_priced": "active samples (the backward runs on the samples up to each ray's early stop)" if top["stage"] in ("hashgrid_bwd", "mlp_bwd") else "marched samples",
+            "whole_step": whole, "issue_bound": (prof or {}).get("issue_bound", {}).get(top["stage"]),
+            "profile_kernel_sum_ms": (prof or {}).get("kernel_sum_ms", {}).get(top["stage"]),
             "main_stream_stage_sum_ms": round(sum(d["ms"] for d in main), 4), "stages": stages}
 
 
@@ -281,17 +305,17 @@ def pmc_traffic(stage, S, A):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
-        return None, "no profiles/r*_pmc_traffic.json"
+        return None, "no profiles/r*_pmc_traffic.json", None
     with open(files[-1]) as f:
         prof = json.load(f)
     rel = os.path.relpath(files[-1], ROOT)
     rec = prof.get("stages", {}).get(stage)
     if rec is None:
-        return None, "%s has no entry for %s" % (rel, stage)
+        return None, "%s has no entry for %s" % (rel, stage), prof
     pS, pA = prof["samples_marched_per_step"], prof["samples_active_per_step"]
     if abs(pS - S) > 0.10 * S or abs(pA - A) > 0.20 * A:
-        return None, "%s was recorded at %.0f marched / %.0f active samples per step, this run has %.0f / %.0f (too far apart)" % (rel, pS, pA, S, A)
-    return rec["hbm_bytes_per_launch"], "%s, recorded at %.0f marched / %.0f active samples per step (%s)" % (rel, pS, pA, rec.get("how", "FETCH_SIZE x2 + WRITE_SIZE"))
+        return None, "%s was recorded at %.0f marched / %.0f active samples per step, this run has %.0f / %.0f (too far apart)" % (rel, pS, pA, S, A), prof
+    return rec["hbm_bytes_per_launch"], "%s, recorded at %.0f marched / %.0f active samples per step (%s)" % (rel, pS, pA, rec.get("how", "FETCH_SIZE x2 + WRITE_SIZE")), prof
 
 
 def api_path_rate(loop, n_steps=40):
@@ -321,15 +345,14 @@ def usable_cpus():
     return max(1, n)
 
 
-def cpu_baseline(model, data, budget_s=20.0, timeout_s=150.0):
+def cpu_baseline(model, data, budget_s=20.0, timeout_s=75.0):
     """The CPU oracle timed on the host cores on BASELINE.json configs[0] (256 rays/batch): full
     step = AABB + march + composite fwd/bwd with the reference's own kernels compiled for the CPU
     (oracle/_ref, falls back to our C restatement) + hash grid / MLPs / SH / Adam as fp32 torch-CPU
     (the tiny-cuda-nn restatement, which is why kind = "port").  Checker code only: this is the one
     place outside tests/ and smoke() that touches oracle/.
-    Runs in a child process under a wall-clock limit: whatever the host does to the CPU leg (on one box it did not come back
-    within the 25 minutes of the call, with every GPU leg done in 3 s), the bench line is printed; the leg then reports
-    value null and says so."""
+    Runs in a child process in its OWN session, result through a file (no pipe a grandchild could hold open); the parent
+    polls with a deadline and kills the child's process group when it is exceeded: this leg cannot outlive timeout_s."""
     import tempfile
     cores = min(usable_cpus(), 32)     # tiny tensors: more threads only add synchronisation cost
     enc = model.xyz_encoder
@@ -340,26 +363,36 @@ def cpu_baseline(model, data, budget_s=20.0, timeout_s=150.0):
             "rgb_w": model.rgb_net.params.detach().cpu().clone(), "bitfield": model.density_bitfield.cpu(),
             "ro": torch.stack([b[0] for b in batches]), "rd": torch.stack([b[1] for b in batches]), "gt": torch.stack([b[2] for b in batches]),
             "cores": cores, "budget_s": budget_s}
-    fd, path = tempfile.mkstemp(suffix=".pt", prefix="ngp_cpu_baseline_")
-    os.close(fd)
+    tmp = tempfile.mkdtemp(prefix="ngp_cpu_baseline_")
+    path, out_path, err_path = os.path.join(tmp, "in.pt"), os.path.join(tmp, "out.json"), os.path.join(tmp, "err.txt")
     failed = None
     try:
         torch.save(blob, path)
-        env = dict(os.environ, OMP_NUM_THREADS=str(cores), MKL_NUM_THREADS=str(cores))
-        try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", path], stdout=subprocess.PIPE,
-                               stderr=subprocess.PIPE, text=True, timeout=timeout_s, env=env)
-            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-            if r.returncode == 0 and lines:
-                return json.loads(lines[-1])
-            failed = "worker exited with code %d: %s" % (r.returncode, r.stderr.strip()[-300:])
-        except subprocess.TimeoutExpired:
+        env = dict(os.environ, OMP_NUM_THREADS=str(cores), MKL_NUM_THREADS=str(cores), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        t0 = time.perf_counter()
+        with open(out_path, "w") as fo, open(err_path, "w") as fe:
+            child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", path], stdout=fo, stderr=fe,
+                                     stdin=subprocess.DEVNULL, env=env, start_new_session=True)
+        while child.poll() is None and time.perf_counter() - t0 < timeout_s:
+            time.sleep(0.2)
+        if child.poll() is None:
+            try:
+                os.killpg(child.pid, signal.SIGKILL)          # the child's own process group, nothing else
+            except OSError:
+                pass
+            try:
+                child.wait(timeout=5)
+            except subprocess.TimeoutExpired:
+                pass
             failed = "worker did not finish %.0f s of CPU work within %.0f s on this host (%d usable cores)" % (budget_s, timeout_s, cores)
+        else:
+            lines = [ln for ln in open(out_path).read().splitlines() if ln.startswith("{")]
+            if child.returncode == 0 and lines:
+                return json.loads(lines[-1])
+            failed = "worker exited with code %s: %s" % (child.returncode, open(err_path).read().strip()[-300:])
     finally:
-        try:
-            os.unlink(path)
-        except OSError:
-            pass
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
     return {"value": None, "unit": "rays/s", "cores": cores, "kind": "port", "sample": "not measured in this run: " + failed}
 
 
@@ -438,19 +471,118 @@ class OnlyTheJsonLineOnStdout:
         os.dup2(2, 1)
 
     def emit(self, line):
-        sys.stdout.flush()
-        os.dup2(self.real, 1)
-        print(line, flush=True)
-        os.dup2(2, 1)
+        os.write(self.real, (line + "\n").encode())        # straight to the descriptor: no Python-level buffer or lock in the way
 
 
 def progress(what):
-    """NGP_BENCH_PROGRESS=1: leg-by-leg progress on stderr (where a run that does not finish got to)."""
-    if os.environ.get("NGP_BENCH_PROGRESS"):
-        print("[bench %8.2f s] %s" % (time.perf_counter() - _T0, what), file=sys.stderr, flush=True)
+    """Leg-by-leg progress on stderr, always (a run that is killed from outside then says where it was)."""
+    print("[bench %8.2f s] %s" % (time.perf_counter() - _T0, what), file=sys.stderr, flush=True)
 
 
 _T0 = time.perf_counter()
+
+
+class LineKeeper:
+    """Owns the one JSON line.  `headline(record)` hands over the record the moment the timed windows are done;
+    `leg(name, fn, budget_s)` runs one optional leg on the calling thread under a wall-clock budget; `finish()` prints.
+    A daemon thread watches the running leg's budget and the global deadline: on expiry it writes the stacks of all threads
+    to stderr, records the timeout in the line, prints the line (once) and ends the process with os._exit -- a hung kernel or
+    a host spin cannot be interrupted from Python, it can only be left behind.  Exit status 0 when the headline was complete."""
+
+    def __init__(self, out_stream, deadline_s, rank=0, required=("roofline", "cpu_baseline")):
+        self.out_stream, self.rank, self.required = out_stream, rank, required
+        self.deadline = _T0 + deadline_s
+        self.deadline_s = deadline_s
+        self.lock = threading.Lock()
+        self.record = None
+        self.partial = {}                 # what to print if the headline itself never completes
+        self.emitted = False
+        self.current = ("startup", _T0, self.deadline)       # (leg, started, leg deadline)
+        self.pending = []                 # legs announced but not run yet (named in the line if the process has to leave early)
+        self._stop = threading.Event()
+        self.thread = threading.Thread(target=self._watch, name="bench-watchdog", daemon=True)
+        self.thread.start()
+
+    # -- main-thread side ------------------------------------------------------------------------
+    def phase(self, name, budget_s):
+        now = time.perf_counter()
+        self.current = (name, now, min(now + budget_s, self.deadline))
+        progress("%s ..." % name)
+
+    def headline(self, record):
+        with self.lock:
+            self.record = record
+        progress("headline complete: %.3g %s, %.4f ms/step" % (record.get("value") or float("nan"), record.get("unit"), record.get("ms_per_step") or float("nan")))
+
+    def announce(self, names):
+        self.pending = list(names)
+
+    def remaining(self):
+        return self.deadline - time.perf_counter()
+
+    def leg(self, name, fn, budget_s, reserve_s=3.0):
+        """Runs fn() and stores its result under `name`; exceptions are recorded, not raised.  Skipped (with a note) when less
+        than the leg's budget is left before the global deadline."""
+        if name in self.pending:
+            self.pending.remove(name)
+        left = self.remaining() - reserve_s
+        if left < min(budget_s, 5.0):
+            self.record[name] = {"error": "skipped: %.0f s left before the %.0f s deadline" % (max(left, 0.0), self.deadline_s)}
+            progress("%s skipped (deadline)" % name)
+            return
+        self.phase(name, min(budget_s, left))
+        t = time.perf_counter()
+        try:
+            res = fn()
+        except Exception as e:                       # noqa: BLE001 -- recorded in the line, the run goes on
+            res = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        with self.lock:
+            if not self.emitted:
+                self.record[name] = res
+        progress("%s done in %.2f s" % (name, time.perf_counter() - t))
+
+    def finish(self):
+        """Prints the line (once).  The watchdog stays: what follows (process-group teardown) is still under the deadline."""
+        self._emit()
+
+    # -- watchdog side ---------------------------------------------------------------------------
+    def _emit(self):
+        with self.lock:
+            if self.emitted:
+                return
+            self.emitted = True
+            rec = self.record if self.record is not None else dict(self.partial)
+            if self.rank == 0:
+                self.out_stream.emit(json.dumps(rec))
+
+    def _watch(self):
+        while not self._stop.wait(0.25):
+            name, started, leg_deadline = self.current
+            now = time.perf_counter()
+            if now < leg_deadline and now < self.deadline:
+                continue
+            why = "timeout in %s: %.0f s (budget %.0f s, global deadline %.0f s)" % (name, now - started, leg_deadline - started, self.deadline_s)
+            print("[bench %8.2f s] %s -- stacks of all threads follow; printing the line and leaving" % (now - _T0, why), file=sys.stderr, flush=True)
+            try:
+                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+            except Exception:                        # noqa: BLE001
+                pass
+            with self.lock:
+                if self.record is not None:
+                    self.record[name] = {"error": why}
+                    for later in self.pending:
+                        if later != name:
+                            self.record.setdefault(later, {"error": "not run: " + why})
+                    self.record["error"] = why
+                else:
+                    self.partial.update({"value": None, "error": why})
+            ok = self.record is not None
+            self._emit()
+            sys.stderr.flush()
+            os._exit(0 if ok else 1)
+
+    def stop(self):
+        self._stop.set()
 
 
 def main():
@@ -463,6 +595,10 @@ def main():
     rank = int(os.environ.get("RANK", 0)); local = int(os.environ.get("LOCAL_RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
     if args.dry_run or not torch.cuda.is_available():
         return dry_run(args, rank, world, out_stream)
+    keeper = LineKeeper(out_stream, args.deadline, rank)
+    keeper.partial = {"metric": "train rays/sec (800x800 Lego-like, 8192 rays/batch/GPU, full step incl. optimizer)", "value": None, "unit": "rays/s",
+                      "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True}
+    keeper.phase("device + process group", 90.0)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -472,10 +608,10 @@ def main():
         world = dist.get_world_size()
     from ngp_pl_amd.bench_support import render_fps
 
+    keeper.phase("dataset + model (%s)" % args.workload, 90.0)
     loop = Loop(args.workload, args, dev, rank, world, dist)
-    progress("loop built")
+    keeper.phase("setup %d steps + warm-up %d + timed windows of %d" % (args.setup_steps, args.warmup, args.steps), 120.0)
     r = loop.run(args.setup_steps, args.warmup, args.steps)
-    progress("timed windows done")
     met = r["metrics"]
     out = {
         "metric": "train rays/sec (800x800 Lego-like, 8192 rays/batch/GPU, full step incl. optimizer)",
@@ -491,20 +627,27 @@ def main():
         "timed_windows": r["timed_windows"], "timed_steps_total": r["timed_steps_total"], "window_ms_per_step_min_max": r["window_ms_per_step_min_max"],
         "ms_per_step_hip_events": r["ms_per_step_hip_events"], "cold_start": r["cold_start"],
     }
+    if "exchange_ms" in r:
+        out["exchange_ms"] = r["exchange_ms"]
+    keeper.headline(out)
     if dist is not None:      # what follows runs on rank 0 only: no collectives from here on
         loop.exchange.uninstall(loop.trainer)
-    if rank == 0 and args.timed_only:
-        out_stream.emit(json.dumps(out))
-    elif rank == 0:
-        out["roofline"] = kernel_roofline(loop)
-        progress("roofline done")
-        def leg(name, fn):     # the legs below are reported next to `value`, never part of it: whatever happens in one, the line is printed
-            try:
-                out[name] = fn()
-            except Exception as e:                       # noqa: BLE001 -- recorded in the line, the run goes on
-                out[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-            progress(name + " done")
-
+    if rank == 0 and not args.timed_only:
+        legs = ["roofline"]
+        if not args.no_cpu_baseline and world == 1:
+            legs.append("cpu_baseline")
+        if not args.no_render:
+            legs += ["render_fps_800x800", "render_fps_800x800_reference_chunking"]
+        if not args.no_api:
+            legs.append("api_path")
+        secondary = args.secondary and world == 1 and args.workload == "lego"
+        if secondary:
+            legs.append("secondary")
+        keeper.announce(legs)
+        keeper.leg("roofline", lambda: kernel_roofline(loop, r["ms_per_step"]), 30.0)
+        if "cpu_baseline" in legs:
+            # (the driver's contract asks for this object: second in line, in a child process the parent can kill)
+            keeper.leg("cpu_baseline", lambda: cpu_baseline(loop.model, loop.data), 90.0)
         if not args.no_render:
             # device-driven frame loop; chunk_scale/probe_cap only regroup the SAME per-ray samples into fewer
             # iterations (tests/test_train_gpu.py::test_device_frame_loop_matches_host_loop)
@@ -521,26 +664,31 @@ def main():
                 ref["loop"] = "ngp_render_test_frame chunk_scale=1 probe_cap=0 (the reference's chunking, bit-identical to its host loop)"
                 ref["field_state"] = state
                 return ref
-            leg("render_fps_800x800", fast_frames)
-            leg("render_fps_800x800_reference_chunking", reference_frames)
+            keeper.leg("render_fps_800x800", fast_frames, 30.0)
+            keeper.leg("render_fps_800x800_reference_chunking", reference_frames, 30.0)
         if not args.no_api:
-            leg("api_path", lambda: api_path_rate(loop))
-        if not args.no_cpu_baseline and world == 1:
-            # (the driver's contract asks for this object; it runs in a child process under a wall-clock limit)
-            leg("cpu_baseline", lambda: cpu_baseline(loop.model, loop.data))
-        if not args.no_secondary and world == 1 and args.workload == "lego":
+            keeper.leg("api_path", lambda: api_path_rate(loop), 30.0)
+        if secondary:
             del loop
             torch.cuda.empty_cache()
-            out["secondary"] = []
-            for name in ("unbounded", "lego16k"):
-                try:
-                    out["secondary"].append(secondary_line(name, args, dev))
-                except Exception as e:                   # noqa: BLE001
-                    out["secondary"].append({"workload": name, "error": "%s: %s" % (type(e).__name__, str(e)[:300])})
-        out_stream.emit(json.dumps(out))
+
+            def both():
+                res = []
+                for name in ("unbounded", "lego16k"):
+                    try:
+                        res.append(secondary_line(name, args, dev))
+                    except Exception as e:                   # noqa: BLE001
+                        res.append({"workload": name, "error": "%s: %s" % (type(e).__name__, str(e)[:300])})
+                return res
+            keeper.leg("secondary", both, 90.0)
+    if rank == 0:
+        keeper.finish()
+    keeper.phase("leaving" if rank == 0 else "waiting for rank 0's legs", 30.0 if rank == 0 else max(keeper.remaining(), 1.0))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    keeper.finish()
+    keeper.stop()
 
 
 if __name__ == "__main__":

@@ -29,6 +29,7 @@ typedef uint16_t ngp_half;    /* IEEE binary16 bits */
 
 #define NGP_EINVAL   (-1)  /* bad argument (null pointer, size out of range) */
 #define NGP_EUNSUP   (-2)  /* configuration not supported by the native kernels */
+#define NGP_ETIMEOUT (-3)  /* a bounded host wait on a device result ran out (NGP_SPIN_TIMEOUT_S, default 30 s) */
 
 #define NGP_MAX_LEVELS 16
 
@@ -36,6 +37,12 @@ typedef uint16_t ngp_half;    /* IEEE binary16 bits */
 int ngp_abi_version(void);
 /* Name of the GPU arch the library was built for ("gfx950"). */
 const char* ngp_build_arch(void);
+
+/* Termination guards of the marching kernels (no reference counterpart: raymarching.cu:225-232 loops for ever on a ray
+ * whose far hit is infinite or whose step is absorbed by rounding).  A tripped guard ends that ray only and is counted on
+ * the device: counts4[0] = skips whose smallest step would not move t, [1] = wave-per-ray tile cap, [2] = serial loop
+ * iteration cap, [3] = reserved.  Synchronous (hipMemcpyFromSymbol); reset != 0 clears the counts. */
+int ngp_march_guard_read(uint32_t* counts4, int reset);
 
 /* ------------------------------------------------------------------------------------------
  * vren: intersection            (reference: models/csrc/intersection.cu)

@@ -84,6 +84,7 @@ _PROTOS = {
     "ngp_compact_alive": [P, P, I, P, P, P, P],
     "ngp_sample_rays": [P, P, P, I, I, I, C.c_uint64, P, P, P, P, P, P, P],
     "ngp_abi_version": [],
+    "ngp_march_guard_read": [P, I],
     "ngp_hashgrid_fwd_n": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P],
     "ngp_field_fwd_n": [P, P, P, P, I, P, P, P, P, P],
     "ngp_gather_xyz": [P, P, P, I, P, P],
@@ -143,9 +144,56 @@ def call(name, *args):
     if name in _COUNT_QUERIES:
         return rc
     if rc != 0:
-        kind = {-1: "NGP_EINVAL (bad argument)", -2: "NGP_EUNSUP (unsupported configuration)"}.get(rc, "hipError_t %d" % rc)
+        kind = {-1: "NGP_EINVAL (bad argument)", -2: "NGP_EUNSUP (unsupported configuration)",
+                -3: "NGP_ETIMEOUT (a device result did not arrive within NGP_SPIN_TIMEOUT_S)"}.get(rc, "hipError_t %d" % rc)
         raise NgpError("%s failed: %s" % (name, kind))
     return 0
+
+
+SPIN_TIMEOUT_S = float(os.environ.get("NGP_SPIN_TIMEOUT_S", "30"))
+
+
+class DeviceTimeout(NgpError):
+    """A host poll on a device result ran out of time: the kernel named in the message did not finish."""
+
+
+def poll_event(event, what, word=None, timeout_s=None):
+    """Busy-polls `event` (a torch.cuda.Event) -- and, first, the pinned count word `word` (a numpy view that holds -1 until the
+    kernel writes it) -- like the loops it replaces (no interrupt-driven sleep: those wake tens of microseconds late), but
+    with a deadline: after `timeout_s` (NGP_SPIN_TIMEOUT_S, default 30 s) it raises DeviceTimeout naming the kernel instead
+    of spinning for ever on a march that does not come back."""
+    import time
+    spins, t_end = 0, None
+    limit = SPIN_TIMEOUT_S if timeout_s is None else timeout_s
+    if word is not None:
+        while word[0] < 0:
+            spins += 1
+            if spins & 1023 == 0:
+                if event.query():
+                    break
+                if spins > 50000:
+                    time.sleep(0)                    # a long wait: offer the core to other threads
+                now = time.perf_counter()
+                if t_end is None:
+                    t_end = now + limit
+                elif now > t_end:
+                    raise DeviceTimeout("%s: no result after %.0f s (the kernel is still running or the device is gone)" % (what, limit))
+    while not event.query():
+        spins += 1
+        if spins & 1023 == 0:
+            now = time.perf_counter()
+            if t_end is None:
+                t_end = now + limit
+            elif now > t_end:
+                raise DeviceTimeout("%s: event not reached after %.0f s (the kernel is still running or the device is gone)" % (what, limit))
+
+
+def march_guard_counts(reset=False):
+    """Counts of tripped termination guards in the marching kernels since the last reset (synchronises): all zero for rays
+    that come from an AABB / sphere intersection."""
+    buf = (C.c_uint32 * 4)()
+    call("ngp_march_guard_read", C.cast(buf, P), 1 if reset else 0)
+    return list(buf)
 
 
 def ptr(t):

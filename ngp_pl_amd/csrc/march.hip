@@ -15,6 +15,7 @@
 #pragma clang fp contract(off)
 
 #include <cstdlib>
+#include <chrono>
 #include "ngp_common.h"
 
 #define NGP_SQRT3 1.73205080757f
@@ -243,6 +244,16 @@ __device__ __forceinline__ float calc_dt(float t, const MarchParams& p) {
     return fmaxf(p.dt_lo, fminf(t * p.esf, p.dt_hi));
 }
 
+// Termination guards.  Every marching loop below ends because t strictly increases; that only holds while a step is not
+// absorbed by rounding (t + dt == t once ulp(t) > 2 dt, i.e. t >~ 3e4 for the smallest step) and the far hit is finite --
+// true for every ray an AABB / sphere intersection produces, not for arbitrary caller input (the reference's loops,
+// raymarching.cu:225-232, spin for ever there).  A tripped guard ends the RAY (never the kernel's other rays), and counts
+// itself in g_march_guard, which ngp_march_guard_read() hands to the host: [0] a skip whose step would be absorbed,
+// [1] the wave-per-ray tile cap, [2] a serial loop's iteration cap (train / test / frame loop).
+__device__ unsigned int g_march_guard[4];
+constexpr int MARCH_TILE_CAP = 1 << 14;          // 2^20 lattice points per ray; the longest legitimate ray (scale 64) has 2^17
+constexpr int MARCH_ITER_CAP = 1 << 20;
+
 struct Ray {
     float ox, oy, oz, dx, dy, dz, ix, iy, iz;
 };
@@ -287,7 +298,10 @@ __device__ __forceinline__ bool march_probe(const Ray& ray, const MarchParams& p
         const float t_target = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
         float tt = t;
         int k = 0;                                   // elements of the ray's t sequence the skip advances by (>= 1)
-        if (SIMPLE) { do { tt += p.dt_lo; ++k; } while (tt < t_target); }
+        if (t_target + p.dt_lo == t_target) {        // the smallest step no longer moves t anywhere up to the target (false for NaN): end the ray
+            atomicAdd(&g_march_guard[0], 1u);
+            tt = __builtin_inff(); k = 1 << 20;
+        } else if (SIMPLE) { do { tt += p.dt_lo; ++k; } while (tt < t_target); }
         else { do { tt += calc_dt(tt, p); ++k; } while (tt < t_target); }
         t_next = tt;
         if (steps) *steps = k;
@@ -324,8 +338,9 @@ march_train_count_kernel(const float* __restrict__ rays_o, const float* __restri
     if (t1 >= 0) t1 = fmaf(calc_dt(t1, p), noise[r], t1);   // general formula also on the SIMPLE path (== dt_lo there)
     float* __restrict__ row = t_scratch + (size_t)r * max_samples;
     float t = t1;
-    int n = 0;
+    int n = 0, iters = 0;
     while (0 <= t && t < t2 && n < max_samples) {
+        if (++iters > MARCH_ITER_CAP) { atomicAdd(&g_march_guard[2], 1u); break; }
         float x, y, z, dt, t_next;
         if (march_probe<SIMPLE>(ray, p, t, x, y, z, dt, t_next)) {
             row[n] = t;
@@ -412,7 +427,9 @@ march_train_count_wave_kernel(const float* __restrict__ rays_o, const float* __r
     float t_start = t1;
     float pending = -1.0f;                              // landing value of a skip that left the previous tile (< 0: none)
     bool done = !(t1 >= 0);
+    int tiles = 0;
     while (!done) {
+        if (++tiles > MARCH_TILE_CAP) { if (lane == 0) atomicAdd(&g_march_guard[1], 1u); break; }
         // 1. the tile's elements: closed form for the constant step (lattice_tile_const_dt), else the chain of 64 adds
         float mine = t_start, t_end = t_start;
         if (!(SIMPLE && lattice_tile_const_dt(t_start, p.dt_lo, lane, mine, t_end))) {
@@ -566,9 +583,10 @@ march_test_kernel(const float* __restrict__ rays_o, const float* __restrict__ ra
     float t = hits_t[2 * r];
     const float t2 = hits_t[2 * r + 1];
     const size_t base = (size_t)n * n_samples;
-    int s = 0;
+    int s = 0, iters = 0;
     float t_resume = t;
     while (t < t2 && s < n_samples) {
+        if (++iters > MARCH_ITER_CAP) { atomicAdd(&g_march_guard[2], 1u); t_resume = t2; break; }
         float x, y, z, dt, t_next;
         if (march_probe<SIMPLE>(ray, p, t, x, y, z, dt, t_next)) {
             const size_t o = base + s;
@@ -718,7 +736,9 @@ render_march_kernel(const float* __restrict__ rays_o, const float* __restrict__ 
         const float t2 = hits[2 * r + 1];
         if (probe_cap <= 0) {
             float t_resume = t;
+            int iters = 0;
             while (t < t2 && s < N) {
+                if (++iters > MARCH_ITER_CAP) { atomicAdd(&g_march_guard[2], 1u); t_resume = t2; break; }
                 float x, y, z, dt, t_next;
                 if (march_probe<SIMPLE>(ray, p, t, x, y, z, dt, t_next)) {
                     s_t[s * 64 + lane] = t;
@@ -951,6 +971,11 @@ struct RenderHost {
 };
 thread_local RenderHost g_render_host;
 
+double render_wait_limit_s() {
+    static const double v = [] { const char* e = getenv("NGP_SPIN_TIMEOUT_S"); const double x = e ? atof(e) : 30.0; return x > 0 ? x : 30.0; }();
+    return v;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -959,7 +984,18 @@ thread_local RenderHost g_render_host;
 extern "C" {
 #pragma GCC visibility push(default)
 
-int ngp_abi_version(void) { return 2; }
+int ngp_abi_version(void) { return 3; }
+
+int ngp_march_guard_read(uint32_t* counts4, int reset) {
+    NGP_CHECK_PTR(counts4);
+    hipError_t e = hipMemcpyFromSymbol(counts4, HIP_SYMBOL(g_march_guard), 4 * sizeof(uint32_t), 0, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return (int)e;
+    if (reset) {
+        const uint32_t z[4] = {0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_march_guard), z, sizeof(z), 0, hipMemcpyHostToDevice);
+    }
+    return (int)e;
+}
 const char* ngp_build_arch(void) { return "gfx950"; }
 
 int ngp_ray_aabb_intersect(const float* rays_o, const float* rays_d, const float* centers,
@@ -1194,7 +1230,16 @@ int ngp_render_test_frame(const float* rays_o, const float* rays_d, const float*
     for (; it < RENDER_MAX_ITERS; ++it) {
         if (it >= LAG) {
             const int j = (it - LAG) % RENDER_RING;
-            hipError_t e = hipEventSynchronize(H.ev[j]);
+            // bounded wait: a first quick poll (the event is two iterations old and usually reached), then the blocking wait is
+            // replaced by polling with a deadline, so a kernel that never finishes turns into NGP_ETIMEOUT instead of a hung caller
+            hipError_t e = hipEventQuery(H.ev[j]);
+            if (e == hipErrorNotReady) {
+                const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(render_wait_limit_s());
+                int polls = 0;
+                while ((e = hipEventQuery(H.ev[j])) == hipErrorNotReady) {
+                    if ((++polls & 255) == 0 && std::chrono::steady_clock::now() > t_end) return NGP_ETIMEOUT;
+                }
+            }
             if (e != hipSuccess) return (int)e;
             bound = H.counts[j];               // survivors after iteration it-LAG >= alive rays now
             if (bound <= 0) break;

@@ -215,8 +215,8 @@ class _FusedTrainRender(torch.autograd.Function):
                  float(model.scale), float(esf), ptr(noise), model.grid_size, MAX_SAMPLES, n, ptr(rays_a), counter.ptr, ptr(scratch), sq)
             eh, rh = enc._half.get(enc_params), net._half.get(rgb_params)      # the casts overlap the march on the device
             done = torch.cuda.Event(); done.record()
-            while not done.query():                                   # the reference syncs here too (raymarching.cu:298: counter.item())
-                pass
+            # the reference syncs here too (raymarching.cu:298: counter.item()); bounded poll
+            _lib.poll_event(done, "ngp_raymarching_train_count inside render() (%d rays)" % n)
             S = int(counter.np[0])
             xyzs = torch.empty(S, 3, **f32); dirs = torch.empty(S, 3, **f32); deltas = torch.empty(S, **f32); ts = torch.empty(S, **f32)
             call("ngp_raymarching_train_write", ptr(rays_o), ptr(rays_d), ptr(rays_a), ptr(scratch), float(model.scale), float(esf),

@@ -301,14 +301,7 @@ class Trainer:
             # then): no HIP call in that loop, and the core is offered to other threads once the wait gets long.  The event
             # query that follows is what orders the main stream's kernels behind the march (kernel-end release of its L2)
             cnt = B.counter_np[k]
-            done = rec["done"]
-            spins = 0
-            while cnt[0] < 0 and not (spins & 1023 == 1023 and done.query()):
-                spins += 1
-                if spins > 50000:
-                    time.sleep(0)
-            while not done.query():
-                pass
+            _lib.poll_event(rec["done"], "ngp_raymarching_train_count (record set %d, %d rays, step %d)" % (k, n, self.global_step), word=cnt)
             if cnt[0] < 0:
                 raise RuntimeError("ngp_raymarching_train_count finished without writing its sample count")
             S = int(cnt[0])

@@ -35,14 +35,14 @@ class _FakeLoop:
 def test_the_line_is_printed_whatever_the_side_legs_do(monkeypatch, capfd):
     b = _load_bench()
     import ngp_pl_amd.bench_support as support
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5"])
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--secondary"])
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
     monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
     monkeypatch.setattr(torch.cuda, "empty_cache", lambda: None)
     monkeypatch.setattr(b, "Loop", _FakeLoop)
-    monkeypatch.setattr(b, "kernel_roofline", lambda loop: {"bound": "hbm", "achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": 1.25e-4, "traffic": None})
+    monkeypatch.setattr(b, "kernel_roofline", lambda loop, ms=None: {"bound": "hbm", "achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": 1.25e-4, "traffic": None})
     calls = []
 
     def fps(model, data, n_frames, chunk_scale=1, probe_cap=0):
@@ -77,6 +77,78 @@ def test_the_line_is_printed_whatever_the_side_legs_do(monkeypatch, capfd):
     assert d["api_path"]["error"].startswith("ValueError")
     assert d["cpu_baseline"]["value"] is None and d["cpu_baseline"]["kind"] == "port"
     assert "out of memory" in d["secondary"][0]["error"] and d["secondary"][1]["rays_per_s"] == 2.0e7
+
+
+def _run_bench_with_fakes(tmp_path, body, deadline):
+    """bench.py's main() in a child process with the measured pieces replaced by `body` (python source defining the fakes)."""
+    import subprocess
+    script = tmp_path / "drive.py"
+    script.write_text("""
+import importlib.util, os, sys, time, types, torch
+ROOT = %r
+sys.path.insert(0, ROOT)
+spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+import ngp_pl_amd.bench_support as support
+torch.cuda.is_available = lambda: True
+torch.cuda.set_device = lambda d: None
+torch.cuda.empty_cache = lambda: None
+class FakeLoop:
+    description, rays, exchange = "fake workload", 8192, None
+    def __init__(self, workload, args, dev, rank, world, dist):
+        self.model, self.data = object(), object()
+        self.trainer = types.SimpleNamespace(global_step=545)
+    def run(self, setup_steps, warmup, steps, min_timed=200):
+        return dict(rays_per_s=1.0e7, ms_per_step=0.8192, timed_windows=10, timed_steps_total=10 * steps, window_ms_per_step_min_max=[0.8, 0.83],
+                    ms_per_step_hip_events=0.81, cold_start=None, metrics=dict(rm_s=40.0, vr_s=20.0, psnr=25.0, loss=0.01))
+b.Loop = FakeLoop
+b.kernel_roofline = lambda loop, ms=None: {"bound": "hbm", "frac": 0.1}
+b.cpu_baseline = lambda model, data: {"value": 100.0, "unit": "rays/s", "cores": 8, "kind": "port", "sample": "fake"}
+support.render_fps = lambda model, data, n_frames, **kw: {"fps": 200.0}
+b.api_path_rate = lambda loop: {"rays_per_s": 1.0}
+%s
+sys.argv = ["bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--deadline", "%g"]
+b.main()
+""" % (ROOT, body, deadline))
+    return subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+
+
+def test_a_leg_that_never_returns_costs_its_budget_not_the_line(tmp_path):
+    """A leg that spins for ever (a hung kernel under a host poll): the watchdog prints the line with the headline, the legs that
+    were complete and the timeout recorded for the hung one, dumps the stacks to stderr, and the process ends with status 0."""
+    body = """
+def spin(model, data, n_frames, **kw):
+    if kw.get("chunk_scale", 1) == 1:
+        while True:
+            pass
+    return {"fps": 200.0}
+support.render_fps = spin
+"""
+    import time
+    t = time.perf_counter()
+    r = _run_bench_with_fakes(tmp_path, body, deadline=25.0)
+    assert time.perf_counter() - t < 60
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout, r.stderr)
+    d = json.loads(lines[0])
+    assert d["value"] == 1.0e7 and d["roofline"]["frac"] == 0.1 and d["cpu_baseline"]["value"] == 100.0 and d["render_fps_800x800"]["fps"] == 200.0
+    assert "timeout in render_fps_800x800_reference_chunking" in d["render_fps_800x800_reference_chunking"]["error"]
+    assert d["api_path"]["error"].startswith("not run: timeout") and "timeout" in d["error"]
+    assert "stacks of all threads" in r.stderr and "in spin" in r.stderr           # faulthandler names the spinning frame
+
+
+def test_a_hang_before_the_headline_still_prints_one_line_and_fails(tmp_path):
+    body = """
+def never(self, setup_steps, warmup, steps, min_timed=200):
+    while True:
+        pass
+FakeLoop.run = never
+"""
+    r = _run_bench_with_fakes(tmp_path, body, deadline=12.0)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 1 and len(lines) == 1, (r.stdout, r.stderr)
+    d = json.loads(lines[0])
+    assert d["value"] is None and "timeout in setup" in d["error"] and d["steps"] == 20
 
 
 def test_cpu_baseline_runs_in_a_child_process_and_is_bounded():

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_prints_one_json_line_with_roofline_and_cold_start():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3", "--setup-steps", "48",
-                        "--images", "8", "--res", "200", "--no-cpu-baseline", "--no-secondary", "--no-render"],
+                        "--images", "8", "--res", "200", "--no-cpu-baseline", "--no-render"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -32,3 +32,26 @@ def test_bench_prints_one_json_line_with_roofline_and_cold_start():
     assert roof["samples_active_per_launch"] <= roof["samples_marched_per_launch"]
     cold = d["cold_start"]
     assert cold["ms_per_step"] > 0 and cold["window"].startswith("steps [3, 13)")
+
+
+def test_driver_command_verbatim():
+    """The driver's literal command, no skip flags: ONE line on stdout within the time the driver allows, carrying `roofline`
+    and `cpu_baseline`, exit status 0.  (Round 2's driver run of this command was killed at 1800 s with an empty stdout.)"""
+    import time
+    t = time.perf_counter()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    wall = time.perf_counter() - t
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert "error" not in d, (d["error"], r.stderr[-3000:])
+    assert d["value"] > 3e6 and d["steps"] == 20 and d["warmup"] == 5 and d["n_gpus"] == 1
+    roof, cpu = d["roofline"], d["cpu_baseline"]
+    assert 0 < roof["frac"] < 1 and roof["bound"] == "hbm" and roof["whole_step"]["frac"] > 0
+    assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and (cpu["value"] is None or cpu["value"] > 0)
+    for leg in ("render_fps_800x800", "render_fps_800x800_reference_chunking", "api_path"):
+        assert "error" not in d[leg], (leg, d[leg])
+    assert wall < 200, wall
+    assert "[bench" in r.stderr and "headline complete" in r.stderr              # leg-by-leg progress is on by default

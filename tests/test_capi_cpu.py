@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert set(names) <= exported, sorted(set(names) - exported)
     assert exported <= set(names), "exported but undeclared: %s" % sorted(exported - set(names))
     assert set(_lib.exported_symbols()) == set(names)          # the ctypes table covers the whole header
-    assert lib.ngp_abi_version() == 2 and lib.ngp_build_arch() == b"gfx950"
+    assert lib.ngp_abi_version() == 3 and lib.ngp_build_arch() == b"gfx950"
 
 
 def test_code_object_is_gfx950_only():

@@ -237,3 +237,49 @@ def test_serial_chain_march_is_bit_identical_too():
                         "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"], cwd=root, env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "9 passed" in r.stdout, r.stdout[-2000:]
+
+
+def test_marching_guards_end_rays_that_would_never_end(vren):
+    """Rays whose far hit is infinite (or whose t is so large that a step is absorbed by rounding) make the reference's loops
+    (raymarching.cu:225-232) spin for ever.  Here every marching kernel ends such a ray, leaves the other rays of the
+    launch untouched (bit-identical to a launch without the bad rays), and counts the event (ngp_march_guard_read).  Rays from
+    an AABB intersection never trip a guard."""
+    from ngp_pl_amd import _lib
+    n = 512
+    ro, rd = make_rays(n, seed=11)
+    o = Oracle(fma=True)
+    ht = aabb_hits(o, ro, rd, 0.5)
+    noise = np.random.RandomState(2).rand(n).astype(np.float32)
+    bf = syn.random_blob_bitfield(1, 128, 0.08, seed=4)
+    _lib.march_guard_counts(reset=True)
+    good = vren.raymarching_train(dev(ro), dev(rd), dev(ht), dev(bf), 1, 0.5, 0.0, dev(noise), 128, 1024)
+    torch.cuda.synchronize()
+    assert _lib.march_guard_counts() == [0, 0, 0, 0]
+    bad = ht.copy()
+    hit = np.nonzero(ht[:, 0] >= 0)[0]
+    worst = hit[:7]
+    bad[worst[:4], 1] = np.inf                                   # no far hit: t runs until a step is absorbed
+    bad[worst[4:], 0] = 3.0e7; bad[worst[4:], 1] = 4.0e7         # t so large that t + dt == t from the start
+    empty = np.zeros_like(bf)
+    got = vren.raymarching_train(dev(ro), dev(rd), dev(bad), dev(empty), 1, 0.5, 0.0, dev(noise), 128, 1024)
+    torch.cuda.synchronize()
+    assert int(got[5][0]) == 0                                   # empty grid: no samples, and the launch came back
+    c = _lib.march_guard_counts(reset=True)
+    assert c[0] + c[1] >= 7 and c[2] == 0, c
+    got = vren.raymarching_train(dev(ro), dev(rd), dev(bad), dev(bf), 1, 0.5, 0.0, dev(noise), 128, 1024)
+    torch.cuda.synchronize()
+    keep = np.ones(n, bool); keep[worst] = False
+    ga, wa = got[0].cpu().numpy(), good[0].cpu().numpy()
+    assert np.array_equal(ga[keep][:, 2], wa[keep][:, 2])        # the other rays' sample counts are untouched
+    # their samples too: compare ray by ray through the start offsets
+    gt, wt = got[4].cpu().numpy(), good[4].cpu().numpy()
+    for r in np.nonzero(keep)[0][::17]:
+        a, b = ga[r], wa[r]
+        assert np.array_equal(gt[a[1]:a[1] + a[2]].view(np.uint32), wt[b[1]:b[1] + b[2]].view(np.uint32))
+    # test-time kernel: same bad rays, bounded
+    alive = torch.arange(n, device="cuda")
+    hits = dev(bad.copy())
+    out = vren.raymarching_test(dev(ro), dev(rd), hits, alive, dev(np.zeros_like(bf)), 1, 0.5, 0.0, 128, 1024, 4)
+    torch.cuda.synchronize()
+    assert int(out[4].sum()) == 0
+    _lib.march_guard_counts(reset=True)
