@@ -41,7 +41,7 @@ const char* ngp_build_arch(void);
 /* Termination guards of the marching kernels (no reference counterpart: raymarching.cu:225-232 loops for ever on a ray
  * whose far hit is infinite or whose step is absorbed by rounding).  A tripped guard ends that ray only and is counted on
  * the device: counts4[0] = skips whose smallest step would not move t, [1] = wave-per-ray tile cap, [2] = serial loop
- * iteration cap, [3] = reserved.  Synchronous (hipMemcpyFromSymbol); reset != 0 clears the counts. */
+ * iteration cap, [3] = 1 + index of the last ray that ran into [1].  Synchronous (hipMemcpyFromSymbol); reset != 0 clears the counts. */
 int ngp_march_guard_read(uint32_t* counts4, int reset);
 
 /* ------------------------------------------------------------------------------------------
@@ -71,6 +71,11 @@ int ngp_ray_sphere_intersect(const float* rays_o, const float* rays_d,
 int ngp_ray_aabb_near(const float* rays_o, const float* rays_d,
                       const float* center, const float* half_size, float near_distance,
                       int n_rays, float* hits_t, ngp_stream_t stream);
+/* The same launch also draws the marcher's per-ray jitter (custom_functions.py:83: torch.rand_like(rays_o[:, 0])):
+ * noise (R) f32 in [0,1) from a counter-based generator keyed by (seed, ray). */
+int ngp_ray_aabb_near_noise(const float* rays_o, const float* rays_d,
+                            const float* center, const float* half_size, float near_distance,
+                            int n_rays, uint64_t seed, float* hits_t, float* noise, ngp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * vren: occupancy grid helpers  (reference: models/csrc/raymarching.cu:35-161)
@@ -566,6 +571,96 @@ int ngp_render_test_frame(const float* rays_o, const float* rays_d, const float*
                           void* workspace, size_t workspace_bytes,
                           float* opacity, float* depth, float* rgb, int64_t* total_samples,
                           int32_t* n_iterations, ngp_stream_t stream);
+
+
+/* ------------------------------------------------------------------------------------------
+ * native driver of one optimisation step   (reference: NeRFSystem.training_step, train.py:159-185, with
+ * configure_optimizers :112-139; the kernels are the entry points above)
+ * ------------------------------------------------------------------------------------------
+ * One object per model and batch size.  The caller owns every buffer (device pointers below; nothing here allocates device
+ * memory) and keeps them alive while the stepper exists.  A step is three calls, so that a multi-GPU caller can place its
+ * gradient collectives between them (ngp_pl_amd/ddp.py):
+ *     ngp_stepper_front          march hand-over -> sample expansion -> hash grid -> field -> composite + loss seeds ->
+ *                                composite backward -> field backward (per-workgroup weight-gradient partials)
+ *     ngp_stepper_table_backward the hash-table gradient (binned; one-pass kernel for batches beyond the bin workspace)
+ *     ngp_stepper_update         fused Adam on the native gradient buffers
+ * and ngp_stepper_march enqueues AABB + jitter + pass 1 of the march of a batch on the marching stream (front() does it
+ * for the NEXT batch behind the composite forward when it is handed one: the march then overlaps this step's backward).
+ * The only host wait of a step is front()'s poll of the pinned sample count of its own batch's march, bounded by
+ * NGP_SPIN_TIMEOUT_S (NGP_ETIMEOUT).  The occupancy-grid update stays with the caller (ngp_occupancy_update between
+ * update() and march() every `update_interval` steps, train.py:160-163). */
+typedef struct ngp_stepper_config {
+    /* scene + occupancy grid */
+    const float* center; const float* half_size; const float* xyz_min; const float* xyz_max;
+    const uint8_t* density_bitfield;
+    int32_t cascades, grid_size;
+    float scale, exp_step_factor;
+    ngp_grid_meta meta;
+    /* parameters: f32 masters, f16 working copies, Adam moments.  enc = [density MLP (n_density) | grid table (n_grid)] */
+    float* enc_param; ngp_half* enc_half; float* enc_m; float* enc_v;
+    float* rgb_param; ngp_half* rgb_half; float* rgb_m; float* rgb_v;
+    int64_t n_grid; int32_t n_density, n_rgb;
+    ngp_half* grid_grad16;                         /* (n_grid) packed f16, overwritten by every table backward */
+    /* recipe */
+    int32_t max_samples;                           /* rendering.py:7 MAX_SAMPLES */
+    float near_distance, T_threshold, lambda_opacity, lambda_distortion;
+    const float* bg;                               /* 3 floats on the device, or NULL (black) */
+    float beta1, beta2, eps, weight_decay;
+    uint64_t noise_seed;
+} ngp_stepper_config;
+
+typedef struct ngp_step_buffers {
+    int32_t n_rays; int32_t distortion;            /* distortion != 0: ws_incl, wts_incl, dL_dws, dist, dist_seed are used */
+    int64_t cap;                                   /* sample slots of the per-sample buffers (n_rays * max_samples) */
+    /* per sample */
+    float* xyzs; float* dirs; float* deltas; float* ts; ngp_half* feats; ngp_half* h; float* sigmas; float* rgbs; float* ws;
+    float* dL_dsigmas; float* dL_drgbs; int32_t* active; float* x_act; ngp_half* dh; ngp_half* dfeats;
+    float* ws_incl; float* wts_incl; float* dL_dws;
+    /* per ray */
+    int64_t* total; float* opacity; float* depth; float* rgb; float* dL_drgb; float* dL_dopacity; int32_t* ray_offs;
+    float* dist; const float* zeros; const float* dist_seed;
+    /* two sets of march records (the march of batch k+1 runs while step k reads its own) */
+    float* hits_t[2]; int64_t* rays_a[2]; float* noise[2]; float* scratch[2];
+    int32_t* counter[2];                           /* pinned, device-mapped host memory: {S, R} of a march */
+    /* scalars and workspaces */
+    int32_t* n_active; float* stats;               /* stats[0] = loss, stats[1] = sum of squared errors */
+    float* partials; int32_t max_partials;         /* [max_partials x (n_density + n_rgb)] f32 */
+    void* fw_ws; size_t fw_bytes;                  /* ngp_composite_train_fw_loss_workspace_bytes(n_rays) */
+    void* bin_ws; size_t bin_bytes; int32_t bin_max; /* binned table backward: workspace for up to bin_max samples (0: always one-pass) */
+} ngp_step_buffers;
+
+typedef struct ngp_stepper ngp_stepper;
+int ngp_stepper_create(const ngp_stepper_config* config, const ngp_step_buffers* buffers, ngp_stepper** out);
+int ngp_stepper_destroy(ngp_stepper* s);
+/* New buffers (another batch size).  Any prefetched march is waited for and dropped first. */
+int ngp_stepper_set_buffers(ngp_stepper* s, const ngp_step_buffers* buffers);
+/* AABB + near clamp + jitter + pass 1 of the march of (rays_o, rays_d) on `march_stream`, behind everything `main_stream`
+ * has queued so far.  One march can be pending; NGP_EINVAL if one already is. */
+int ngp_stepper_march(ngp_stepper* s, const float* rays_o, const float* rays_d, ngp_stream_t main_stream, ngp_stream_t march_stream);
+/* Is a march of exactly these buffers pending?  (1 / 0) */
+int ngp_stepper_pending(const ngp_stepper* s, const float* rays_o, const float* rays_d);
+/* Waits for a pending march and forgets it (the batch it was made for is not going to be stepped). */
+int ngp_stepper_drop_pending(ngp_stepper* s);
+/* The step up to the field backward, on main_stream.  The pending march must be the one of (rays_o, rays_d).
+ * next_o / next_d (may be NULL): the following batch, marched behind the composite forward.  loss_scale: factor on the
+ * f16 backward (128, or 128 / world under data parallelism); grad_scale: GradScaler-style factor on the loss seeds.
+ * out (host): n_samples = S of this batch, n_partials = rows of weight-gradient partials the field backward wrote. */
+int ngp_stepper_front(ngp_stepper* s, const float* rays_o, const float* rays_d, const float* rgb_gt,
+                      const float* next_o, const float* next_d, float loss_scale, float grad_scale,
+                      ngp_stream_t main_stream, ngp_stream_t march_stream, int32_t* n_samples, int32_t* n_partials);
+int ngp_stepper_table_backward(ngp_stepper* s, int n_groups, int group, ngp_stream_t main_stream);
+/* Fused Adam (ngp_adam_step_field).  density_partials / rgb_partials NULL: the partial rows front() wrote (n_partials rows);
+ * a caller that reduced them across ranks passes its own buffers with n_partials = 1.  grad_scale = the total factor the
+ * gradients carry (loss_scale x grad_scale x world).  step is 1-based (bias correction). */
+int ngp_stepper_update(ngp_stepper* s, float lr, int32_t step, float grad_scale, const float* density_partials,
+                       const float* rgb_partials, int32_t n_partials, const int32_t* found_inf, ngp_stream_t main_stream);
+/* Stage timing (HIP events on the streams the kernels run on).  enable != 0: the following steps record events;
+ * ngp_stepper_stage_times synchronises and writes the last step's times in ms:
+ *   [0] march_write [1] hashgrid_fwd [2] mlp_fwd [3] composite_fw+loss [4] composite_bw [5] mlp_bwd [6] hashgrid_bwd [7] adam
+ *   [8] march_count (marching stream; of the batch the last front() consumed).  Negative = not recorded. */
+#define NGP_STEPPER_STAGES 9
+int ngp_stepper_timing(ngp_stepper* s, int enable);
+int ngp_stepper_stage_times(ngp_stepper* s, float* ms);
 
 #ifdef __cplusplus
 }

@@ -27,11 +27,34 @@ class GridMeta(C.Structure):
                 ("scale", C.c_float * NGP_MAX_LEVELS)]
 
 
+class StepperConfig(C.Structure):
+    """ngp_stepper_config (include/ngp_hip.h)."""
+    _fields_ = [("center", P), ("half_size", P), ("xyz_min", P), ("xyz_max", P), ("density_bitfield", P),
+                ("cascades", C.c_int32), ("grid_size", C.c_int32), ("scale", F), ("exp_step_factor", F), ("meta", GridMeta),
+                ("enc_param", P), ("enc_half", P), ("enc_m", P), ("enc_v", P),
+                ("rgb_param", P), ("rgb_half", P), ("rgb_m", P), ("rgb_v", P),
+                ("n_grid", C.c_int64), ("n_density", C.c_int32), ("n_rgb", C.c_int32), ("grid_grad16", P),
+                ("max_samples", C.c_int32), ("near_distance", F), ("T_threshold", F), ("lambda_opacity", F), ("lambda_distortion", F),
+                ("bg", P), ("beta1", F), ("beta2", F), ("eps", F), ("weight_decay", F), ("noise_seed", C.c_uint64)]
+
+
+class StepBuffersC(C.Structure):
+    """ngp_step_buffers (include/ngp_hip.h)."""
+    _fields_ = [("n_rays", C.c_int32), ("distortion", C.c_int32), ("cap", C.c_int64)] + \
+        [(k, P) for k in ("xyzs", "dirs", "deltas", "ts", "feats", "h", "sigmas", "rgbs", "ws", "dL_dsigmas", "dL_drgbs", "active", "x_act",
+                          "dh", "dfeats", "ws_incl", "wts_incl", "dL_dws",
+                          "total", "opacity", "depth", "rgb", "dL_drgb", "dL_dopacity", "ray_offs", "dist", "zeros", "dist_seed")] + \
+        [("hits_t", P * 2), ("rays_a", P * 2), ("noise", P * 2), ("scratch", P * 2), ("counter", P * 2),
+         ("n_active", P), ("stats", P), ("partials", P), ("max_partials", C.c_int32),
+         ("fw_ws", P), ("fw_bytes", C.c_size_t), ("bin_ws", P), ("bin_bytes", C.c_size_t), ("bin_max", C.c_int32)]
+
+
 # name -> argtypes (every function returns int, except the two queries noted below)
 _PROTOS = {
     "ngp_ray_aabb_intersect": [P, P, P, P, I, I, I, P, P, P, P],
     "ngp_ray_sphere_intersect": [P, P, P, P, I, I, I, P, P, P, P],
     "ngp_ray_aabb_near": [P, P, P, P, F, I, P, P],
+    "ngp_ray_aabb_near_noise": [P, P, P, P, F, I, C.c_uint64, P, P, P],
     "ngp_morton3D": [P, I, P, P],
     "ngp_morton3D_invert": [P, I, P, P],
     "ngp_packbits": [P, I, I, F, P, P],
@@ -85,6 +108,17 @@ _PROTOS = {
     "ngp_sample_rays": [P, P, P, I, I, I, C.c_uint64, P, P, P, P, P, P, P],
     "ngp_abi_version": [],
     "ngp_march_guard_read": [P, I],
+    "ngp_stepper_create": [C.POINTER(StepperConfig), C.POINTER(StepBuffersC), C.POINTER(P)],
+    "ngp_stepper_destroy": [P],
+    "ngp_stepper_set_buffers": [P, C.POINTER(StepBuffersC)],
+    "ngp_stepper_march": [P, P, P, P, P],
+    "ngp_stepper_pending": [P, P, P],
+    "ngp_stepper_drop_pending": [P],
+    "ngp_stepper_front": [P, P, P, P, P, P, F, F, P, P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
+    "ngp_stepper_table_backward": [P, I, I, P],
+    "ngp_stepper_update": [P, F, I, F, P, P, I, P, P],
+    "ngp_stepper_timing": [P, I],
+    "ngp_stepper_stage_times": [P, C.POINTER(C.c_float)],
     "ngp_hashgrid_fwd_n": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P],
     "ngp_field_fwd_n": [P, P, P, P, I, P, P, P, P, P],
     "ngp_gather_xyz": [P, P, P, I, P, P],
@@ -98,7 +132,7 @@ _PROTOS = {
     "ngp_render_test_frame": [P, P, P, P, I, F, F, I, I, F, P, P, P, C.POINTER(GridMeta), P, P, I, I, I,
                               C.POINTER(C.c_float), P, C.c_size_t, P, P, P, P, C.POINTER(C.c_int32), P],
 }
-_COUNT_QUERIES = ("ngp_field_bwd_partials", "ngp_mlp_bwd_partials", "ngp_abi_version")
+_COUNT_QUERIES = ("ngp_field_bwd_partials", "ngp_mlp_bwd_partials", "ngp_abi_version", "ngp_stepper_pending")
 
 _lib = None
 

@@ -43,6 +43,19 @@ constexpr int BIN_SPT = 2;                   // samples per thread
 constexpr int CHUNK = BIN_THREADS * BIN_SPT; // samples per binning workgroup ("chunk")
 constexpr int CHUNK_SLOTS = CHUNK * 8;       // list entries a chunk can produce for one level (<= 8 slices per sample)
 constexpr int MAX_CHUNKS = 1024;             // the slice owners scan the chunk directory in one pass
+// Hashed levels hand the slice owner everything it needs in the list entry itself (12 bytes, NGP_BIN_PAYLOAD, default on):
+//   word 0: l0 | l1 << 13      slice-local indices of the pair's two corners (x, .) and (x+1, .); PAY_INVALID = not in this slice
+//   word 1: the sample's gradient for this level (half2 bits)
+//   word 2: w0 | w1 << 16      the two trilinear weights in 16-bit fixed point (units of 2^-16; tiny-cuda-nn rounds every
+//                              w * g product to f16, i.e. to 11 bits)
+// so that an owner's trip is three coalesced stream loads, four multiplies and four LDS adds per entry: no position /
+// gradient gathers (they ran at the texture addressers' one-lane-address-per-clock rate: 29 M gathers per step), no cell,
+// hash or weight arithmetic repeated by each of a sample's four pair entries (round 2: 80 VALU per row of 64 entries).
+#ifndef NGP_BIN_PAYLOAD
+#define NGP_BIN_PAYLOAD 1
+#endif
+constexpr uint32_t PAY_INVALID = 0x1fffu;    // >= SLICE2: fails the in-slice test
+static_assert(SLICE2 < PAY_INVALID, "slice-local indices are stored in 13 bits");
 #ifndef NGP_APPLY_THREADS
 #define NGP_APPLY_THREADS 1024
 #endif
@@ -51,6 +64,9 @@ constexpr int MAX_CHUNKS = 1024;             // the slice owners scan the chunk 
 #endif
 #ifndef NGP_APPLY_B
 #define NGP_APPLY_B 11
+#endif
+#ifndef NGP_APPLY_PB
+#define NGP_APPLY_PB 8                        // payload entries: segments per trip (3 words per segment and lane in flight)
 #endif
 constexpr int APPLY_THREADS = NGP_APPLY_THREADS;
 
@@ -61,6 +77,8 @@ struct BinPlan {
     int32_t first_task[NGP_MAX_LEVELS + 1];  // tasks are numbered level by level in `order`
     int32_t order[NGP_MAX_LEVELS];           // levels, most expensive tasks first
     int64_t part_off[NGP_MAX_LEVELS];        // K-split levels: entry offset of the level's K partial tables in ws.partial
+    int64_t pool_off[NGP_MAX_LEVELS];        // the level's list slots in ws.pool, in 4-byte words
+    int32_t entry_words[NGP_MAX_LEVELS];     // words per list entry: 1 = sample id (dense levels), 3 = payload entry (hashed levels)
     int32_t n_tasks, n_chunks;
 };
 
@@ -101,6 +119,7 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const
     const bool hashed = level_is_hashed(res, size);
     const Box box = load_box(xyz_min, xyz_max);
     int jj[BIN_SPT], sid[BIN_SPT][8], loc[BIN_SPT][8], tag[BIN_SPT][8], n_mine[BIN_SPT];
+    int32_t pay0[BIN_SPT][8], pay2[BIN_SPT][4];       // payload words 0 (per entry) and 2 (per corner pair)
     half2_t gg[BIN_SPT]; int src[BIN_SPT]; float xin[BIN_SPT][3];
 #pragma unroll
     for (int t = 0; t < BIN_SPT; ++t) {               // all loads of the thread's samples before any use
@@ -130,6 +149,16 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const
                     const int s0 = (int)(idx[2 * k] / SLICE2), s1 = (int)(idx[2 * k + 1] / SLICE2);
                     sid[t][2 * k] = s0; tag[t][2 * k] = k;
                     sid[t][2 * k + 1] = (s1 != s0) ? s1 : -1; tag[t][2 * k + 1] = k;
+                    if (NGP_BIN_PAYLOAD) {
+                        const uint32_t l0 = idx[2 * k] - (uint32_t)s0 * SLICE2, l1 = idx[2 * k + 1] - (uint32_t)s1 * SLICE2;
+                        // the pair in one slice: both corners in one entry; straddling two slices: one entry each, the other corner invalid
+                        pay0[t][2 * k] = (int32_t)(l0 | ((s1 == s0 ? l1 : PAY_INVALID) << 13));
+                        pay0[t][2 * k + 1] = (int32_t)(PAY_INVALID | (l1 << 13));
+                        const float wy = (k & 1) ? f[1] : 1.f - f[1], wz = (k >> 1) ? f[2] : 1.f - f[2];
+                        const float w0 = ((1.f - f[0]) * wy) * wz, w1 = (f[0] * wy) * wz;              // corner_weight()'s order
+                        const uint32_t q0 = min((uint32_t)__float2int_rn(w0 * 65536.0f), 65535u), q1 = min((uint32_t)__float2int_rn(w1 * 65536.0f), 65535u);
+                        pay2[t][k] = (int32_t)(q0 | (q1 << 16));
+                    }
                 }
                 n_mine[t] = 8;
             } else {
@@ -168,14 +197,26 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const
         if (threadIdx.x == 0) s_pre[ns] = run;
     }
     __syncthreads();
+    int32_t* __restrict__ slot = ws.pool + plan.pool_off[level] + (size_t)chunk * CHUNK_SLOTS * plan.entry_words[level];
+    if (NGP_BIN_PAYLOAD && hashed) {
+        // payload entries go straight to their place in the chunk's slot (12-byte stores; a slice's segment is written by the
+        // threads that found entries for it and merges in L2)
 #pragma unroll
-    for (int t = 0; t < BIN_SPT; ++t)
+        for (int t = 0; t < BIN_SPT; ++t)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) if (q < n_mine[t] && sid[t][q] >= 0) s_stage[s_pre[sid[t][q]] + loc[t][q]] = (jj[t] << 2) | tag[t][q];
-    __syncthreads();
-    const int total = s_pre[ns];
-    int32_t* __restrict__ slot = ws.pool + (size_t)blockIdx.x * CHUNK_SLOTS;
-    for (int i = threadIdx.x; i < total; i += BIN_THREADS) slot[i] = s_stage[i];
+            for (int q = 0; q < 8; ++q) if (q < n_mine[t] && sid[t][q] >= 0) {
+                int32_t* __restrict__ e = slot + 3 * (size_t)(s_pre[sid[t][q]] + loc[t][q]);
+                e[0] = pay0[t][q]; e[1] = __builtin_bit_cast(int32_t, gg[t]); e[2] = pay2[t][q >> 1];
+            }
+    } else {
+#pragma unroll
+        for (int t = 0; t < BIN_SPT; ++t)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (q < n_mine[t] && sid[t][q] >= 0) s_stage[s_pre[sid[t][q]] + loc[t][q]] = (jj[t] << 2) | tag[t][q];
+        __syncthreads();
+        const int total = s_pre[ns];
+        for (int i = threadIdx.x; i < total; i += BIN_THREADS) slot[i] = s_stage[i];
+    }
     for (int i = threadIdx.x; i < ns; i += BIN_THREADS) dir[(size_t)i * n_chunks] = (s_pre[i] << 16) | s_cnt[i];
 }
 
@@ -183,6 +224,11 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const
 __device__ __forceinline__ void lds_add_fixed(long long* acc, float v) {
     const int q = __float2int_rn(v * FIX_SCALE);                   // saturates; |w*g| < 128 by a wide margin
     atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)(long long)q);   // ds_add_u64
+}
+
+__device__ __forceinline__ void lds_add_q(long long* acc, float v_fixed) {        // v_fixed already in 2^-24 units
+    const int q = __float2int_rn(v_fixed);
+    atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)(long long)q);
 }
 
 // One pass for the lanes of a wave over whole-sample entries (dense levels): all 8 corners, in-slice test each.
@@ -278,6 +324,44 @@ __device__ __forceinline__ void apply_segments_hashed(long long* lds, uint32_t l
     }
 }
 
+// Hashed levels with payload entries (NGP_BIN_PAYLOAD): lane = entry, three coalesced words per entry, no gathers.
+template <int B>
+__device__ __forceinline__ void apply_segments_payload(long long* lds, uint32_t len, const int32_t* __restrict__ pool_level,
+                                                       const int* s_dir, int n_chunks, int part, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = APPLY_THREADS / 64;
+    for (int c0 = part + K * wave; c0 < n_chunks; c0 += K * NW * B) {
+        int cnt[B], maxcnt = 0; size_t start[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const int c = c0 + b * K * NW;
+            const int d = (c < n_chunks) ? s_dir[c] : 0;
+            start[b] = (size_t)c * CHUNK_SLOTS + (d >> 16); cnt[b] = d & 0xffff;
+            maxcnt = max(maxcnt, cnt[b]);
+        }
+        for (int off = 0; off < maxcnt; off += 64) {               // one pass unless a segment has more than 64 entries
+            uint32_t e0[B], e1[B], e2[B];
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                const bool ok = off + lane < cnt[b];
+                const int32_t* __restrict__ e = pool_level + 3 * (start[b] + (size_t)(ok ? off + lane : 0));
+                e0[b] = ok ? (uint32_t)__builtin_nontemporal_load(e) : ~0u;             // not ok: both corners invalid
+                e1[b] = (uint32_t)__builtin_nontemporal_load(e + 1); e2[b] = (uint32_t)__builtin_nontemporal_load(e + 2);
+            }
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                const uint32_t l0 = e0[b] & 0x1fffu, l1 = (e0[b] >> 13) & 0x1fffu;
+                const half2_t g = __builtin_bit_cast(half2_t, e1[b]);
+                // w * g * 2^24 with w in units of 2^-16: one f32 rounding of a 16 x 11 bit product, then exact
+                const float g0 = (float)g[0] * (FIX_SCALE / 65536.0f), g1 = (float)g[1] * (FIX_SCALE / 65536.0f);
+                const float w0 = (float)(e2[b] & 0xffffu), w1 = (float)(e2[b] >> 16);
+                if (l0 < len) { lds_add_q(lds + 2 * l0, w0 * g0); lds_add_q(lds + 2 * l0 + 1, w0 * g1); }
+                if (l1 < len) { lds_add_q(lds + 2 * l1, w1 * g0); lds_add_q(lds + 2 * l1 + 1, w1 * g1); }
+            }
+        }
+    }
+}
+
 // Dense (coarse) levels: a segment holds up to every sample of its chunk, and dozens of consecutive
 // samples of a ray sit in the same cell, i.e. consecutive entries hit the same 8 accumulators
 // (measured: an LDS add_u64 with 8 lanes per address costs 64 cycles instead of 11.5).  Lane L
@@ -350,8 +434,11 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
         if (tid == 0) ws.timing[4 * task + 1] = (long long)wall_clock64();
 #endif
         const half2_t* __restrict__ g_level = dfeats + (size_t)level * n_samples;
-        const int32_t* __restrict__ pool_level = ws.pool + (size_t)level * n_chunks * CHUNK_SLOTS;
-        if (level_is_hashed(res, size)) apply_segments_hashed<NGP_APPLY_B>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
+        const int32_t* __restrict__ pool_level = ws.pool + plan.pool_off[level];
+        if (level_is_hashed(res, size)) {
+            if (NGP_BIN_PAYLOAD) apply_segments_payload<NGP_APPLY_PB>(lds, len, pool_level, s_dir, n_chunks, part, K);
+            else apply_segments_hashed<NGP_APPLY_B>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
+        }
         else apply_segments_dense<4>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
         __syncthreads();
 #ifdef NGP_BIN_TIMING
@@ -433,12 +520,20 @@ bool make_plan(const ngp_grid_meta* meta, int n_samples, BinPlan& P, BinLayout& 
         part_entries += size * P.k_split[l];
         L.merge_entries += size;
     }
-    const size_t rows = (size_t)meta->n_levels * P.n_chunks;
+    long long pool_words = 0;
+    for (int l = 0; l < NGP_MAX_LEVELS; ++l) { P.pool_off[l] = 0; P.entry_words[l] = 1; }
+    for (int l = 0; l < meta->n_levels; ++l) {
+        const uint32_t size = meta->offset[l + 1] - meta->offset[l], res = meta->resolution[l];
+        const bool hashed = (uint64_t)res * res * res > size;
+        P.entry_words[l] = (NGP_BIN_PAYLOAD && hashed) ? 3 : 1;
+        P.pool_off[l] = pool_words;
+        pool_words += (long long)P.n_chunks * CHUNK_SLOTS * P.entry_words[l];
+    }
     L.queue = 0;
     L.timing = 256;                               // 2048 tasks x 4 x 8 B (NGP_BIN_TIMING builds)
     L.dir = 256 + 65536;
     L.pool = L.dir + ((size_t)meta->n_levels * MAX_SLICES * P.n_chunks * 4 + 255) / 256 * 256;
-    L.partial = L.pool + rows * CHUNK_SLOTS * 4;
+    L.partial = L.pool + ((size_t)pool_words * 4 + 255) / 256 * 256;
     L.bytes = L.partial + (size_t)part_entries * sizeof(float2);
     return P.n_chunks <= MAX_CHUNKS;
 }

@@ -101,9 +101,14 @@ ray_prim_intersect_kernel(const float* __restrict__ rays_o, const float* __restr
 __global__ void __launch_bounds__(256)
 ray_aabb_near_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                      const float* __restrict__ center, const float* __restrict__ half_size,
-                     float near_distance, int n_rays, float* __restrict__ hits_t) {
+                     float near_distance, int n_rays, float* __restrict__ hits_t,
+                     float* __restrict__ noise, uint32_t seed_lo, uint32_t seed_hi) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rays) return;
+    if (noise) {          // the marcher's jitter (custom_functions.py:83 torch.rand_like): counter-based, keyed by (seed, ray)
+        const uint32_t base = ngp_pcg_hash(seed_lo ^ ngp_pcg_hash(seed_hi + 0x9E3779B9u)) + (uint32_t)r;
+        noise[r] = (float)(ngp_pcg_hash(base) >> 8) * (1.0f / 16777216.0f);      // [0,1), 24 bits like torch.rand
+    }
     const float ox = rays_o[3 * r], oy = rays_o[3 * r + 1], oz = rays_o[3 * r + 2];
     const float ix = 1.0f / rays_d[3 * r], iy = 1.0f / rays_d[3 * r + 1], iz = 1.0f / rays_d[3 * r + 2];
     const float2 t = aabb_hit(ox, oy, oz, ix, iy, iz, center[0], center[1], center[2],
@@ -249,7 +254,8 @@ __device__ __forceinline__ float calc_dt(float t, const MarchParams& p) {
 // true for every ray an AABB / sphere intersection produces, not for arbitrary caller input (the reference's loops,
 // raymarching.cu:225-232, spin for ever there).  A tripped guard ends the RAY (never the kernel's other rays), and counts
 // itself in g_march_guard, which ngp_march_guard_read() hands to the host: [0] a skip whose step would be absorbed,
-// [1] the wave-per-ray tile cap, [2] a serial loop's iteration cap (train / test / frame loop).
+// [1] the wave-per-ray tile cap, [2] a serial loop's iteration cap (train / test / frame loop), [3] 1 + index of the last ray
+// that ran into [1] (diagnostics).
 __device__ unsigned int g_march_guard[4];
 constexpr int MARCH_TILE_CAP = 1 << 14;          // 2^20 lattice points per ray; the longest legitimate ray (scale 64) has 2^17
 constexpr int MARCH_ITER_CAP = 1 << 20;
@@ -429,7 +435,7 @@ march_train_count_wave_kernel(const float* __restrict__ rays_o, const float* __r
     bool done = !(t1 >= 0);
     int tiles = 0;
     while (!done) {
-        if (++tiles > MARCH_TILE_CAP) { if (lane == 0) atomicAdd(&g_march_guard[1], 1u); break; }
+        if (++tiles > MARCH_TILE_CAP) { if (lane == 0) { atomicAdd(&g_march_guard[1], 1u); g_march_guard[3] = (unsigned)r + 1u; } break; }
         // 1. the tile's elements: closed form for the constant step (lattice_tile_const_dt), else the chain of 64 adds
         float mine = t_start, t_end = t_start;
         if (!(SIMPLE && lattice_tile_const_dt(t_start, p.dt_lo, lane, mine, t_end))) {
@@ -1029,7 +1035,18 @@ int ngp_ray_aabb_near(const float* rays_o, const float* rays_d, const float* cen
     if (n_rays == 0) return 0;
     NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d); NGP_CHECK_PTR(center); NGP_CHECK_PTR(half_size); NGP_CHECK_PTR(hits_t);
     hipLaunchKernelGGL(ray_aabb_near_kernel, dim3(ngp_div_up(n_rays, 256)), dim3(256), 0, ngp_stream(stream),
-                       rays_o, rays_d, center, half_size, near_distance, n_rays, hits_t);
+                       rays_o, rays_d, center, half_size, near_distance, n_rays, hits_t, (float*)nullptr, 0u, 0u);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_ray_aabb_near_noise(const float* rays_o, const float* rays_d, const float* center,
+                            const float* half_size, float near_distance, int n_rays, uint64_t seed,
+                            float* hits_t, float* noise, ngp_stream_t stream) {
+    if (n_rays < 0) return NGP_EINVAL;
+    if (n_rays == 0) return 0;
+    NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d); NGP_CHECK_PTR(center); NGP_CHECK_PTR(half_size); NGP_CHECK_PTR(hits_t); NGP_CHECK_PTR(noise);
+    hipLaunchKernelGGL(ray_aabb_near_kernel, dim3(ngp_div_up(n_rays, 256)), dim3(256), 0, ngp_stream(stream),
+                       rays_o, rays_d, center, half_size, near_distance, n_rays, hits_t, noise, (uint32_t)seed, (uint32_t)(seed >> 32));
     return NGP_LAUNCH_RESULT();
 }
 

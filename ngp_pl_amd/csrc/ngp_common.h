@@ -32,6 +32,13 @@ __device__ __forceinline__ uint32_t ngp_compact_bits(uint32_t x) {
     return x;
 }
 
+// ---- counter-based RNG (PCG output function on a Weyl-style counter) ----
+__device__ __forceinline__ uint32_t ngp_pcg_hash(uint32_t v) {
+    uint32_t state = v * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+
 // ---- wave64 helpers ----
 __device__ __forceinline__ float ngp_wave_sum(float v) {
 #pragma unroll

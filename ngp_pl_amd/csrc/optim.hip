@@ -279,11 +279,7 @@ bg_blend_bw_kernel(const float* __restrict__ g_rgb, const float* __restrict__ g_
 // (datasets/base.py:22-35, train.py:141-146), then forms rays on the GPU (train.py:78-91,
 // ray_utils.py:46-70).  Here one kernel draws the indices (counter-based hash RNG), gathers the
 // ground-truth colour and rotates the pixel direction by the camera pose.
-__device__ __forceinline__ uint32_t pcg_hash(uint32_t v) {
-    uint32_t state = v * 747796405u + 2891336453u;
-    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
-    return (word >> 22u) ^ word;
-}
+__device__ __forceinline__ uint32_t pcg_hash(uint32_t v) { return ngp_pcg_hash(v); }
 __global__ void __launch_bounds__(256)
 sample_rays_kernel(const float* __restrict__ poses, const float* __restrict__ directions, const float* __restrict__ images,
                    int n_images, int n_pixels, int n, uint32_t seed_lo, uint32_t seed_hi,

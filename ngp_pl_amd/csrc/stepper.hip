@@ -1,0 +1,314 @@
+// Native driver of one optimisation step (reference: NeRFSystem.training_step, /root/reference/train.py:159-185).
+//
+// Why this exists: the step is 12-14 kernel launches of 8-100 us each.  Enqueued from Python through ctypes they cost
+// ~0.3 ms of host time per step against ~0.37 ms of device time (tools/profile_host.py, round 2), so every further kernel
+// gain would have been eaten by the host.  Here the whole sequence is enqueued by three C calls (~50 us of host time), on
+// the caller's two HIP streams (main + marching), with reusable events and the one host wait of a step -- the packed
+// sample count of the batch's march, written by the scan kernel into pinned host memory -- polled with a deadline.
+// No device memory is allocated here; all buffers are the caller's (ngp_step_buffers).
+#include "ngp_common.h"
+#include <chrono>
+#include <cstdlib>
+#include <new>
+
+namespace {
+
+constexpr int N_MARKS = 9;       // start + 8 main-stream stages
+
+double spin_limit_s() {
+    static const double v = [] { const char* e = getenv("NGP_SPIN_TIMEOUT_S"); const double x = e ? atof(e) : 30.0; return x > 0 ? x : 30.0; }();
+    return v;
+}
+
+}  // namespace
+
+struct ngp_stepper {
+    ngp_stepper_config c;
+    ngp_step_buffers b;
+    hipEvent_t ready[2] = {}, done[2] = {};
+    hipEvent_t mark[N_MARKS] = {}, march_t[2][2] = {};       // stage marks (timing); march_t[set][begin/end]
+    bool mark_set[N_MARKS] = {}, march_t_set[2] = {};
+    int timing = 0;
+    int next_set = 0;
+    // the marched-but-not-consumed batch
+    bool has_pending = false;
+    const float* pend_o = nullptr; const float* pend_d = nullptr;
+    int pend_set = 0;
+    uint64_t marches = 0;
+    // state of the step between front() and update()
+    int32_t S = 0, n_part = 0, last_set = 0;
+    bool binned = false;
+    int device = 0;
+};
+
+namespace {
+
+#define STEP_TRY(expr) do { const int rc_ = (expr); if (rc_ != 0) return rc_; } while (0)
+#define STEP_HIP(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+int check_buffers(const ngp_stepper_config& c, const ngp_step_buffers& b) {
+    if (b.n_rays < 1 || b.cap < b.n_rays || b.max_partials < 1) return NGP_EINVAL;
+    const void* need[] = {b.xyzs, b.dirs, b.deltas, b.ts, b.feats, b.h, b.sigmas, b.rgbs, b.ws, b.dL_dsigmas, b.dL_drgbs, b.active, b.dh,
+                          b.dfeats, b.total, b.opacity, b.depth, b.rgb, b.dL_drgb, b.dL_dopacity, b.ray_offs, b.zeros, b.n_active, b.stats,
+                          b.partials, b.fw_ws, b.hits_t[0], b.hits_t[1], b.rays_a[0], b.rays_a[1], b.noise[0], b.noise[1], b.scratch[0],
+                          b.scratch[1], b.counter[0], b.counter[1]};
+    for (const void* p : need) if (p == nullptr) return NGP_EINVAL;
+    if (b.bin_max > 0 && (b.bin_ws == nullptr || b.x_act == nullptr)) return NGP_EINVAL;
+    if (b.distortion && (!b.ws_incl || !b.wts_incl || !b.dL_dws || !b.dist || !b.dist_seed)) return NGP_EINVAL;
+    if (c.lambda_distortion > 0 && !b.distortion) return NGP_EINVAL;
+    return 0;
+}
+
+inline void mark(ngp_stepper* s, int i, hipStream_t st) {
+    if (!s->timing) return;
+    if (hipEventRecord(s->mark[i], st) == hipSuccess) s->mark_set[i] = true;
+}
+
+// Bounded host wait for the march of record set k: first the pinned count word (no HIP call in that loop), then the
+// event, which is what orders the caller's following launches behind the march.
+int wait_march(ngp_stepper* s, int k) {
+    volatile int32_t* cnt = s->b.counter[k];
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(spin_limit_s());
+    unsigned spins = 0;
+    while (cnt[0] < 0) {
+        if ((++spins & 1023u) == 0) {
+            if (hipEventQuery(s->done[k]) == hipSuccess) break;
+            if (std::chrono::steady_clock::now() > t_end) return NGP_ETIMEOUT;
+        }
+    }
+    hipError_t e;
+    while ((e = hipEventQuery(s->done[k])) == hipErrorNotReady) {
+        if ((++spins & 255u) == 0 && std::chrono::steady_clock::now() > t_end) return NGP_ETIMEOUT;
+    }
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int do_march(ngp_stepper* s, const float* rays_o, const float* rays_d, hipStream_t main, hipStream_t side) {
+    if (s->has_pending) return NGP_EINVAL;
+    NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d);
+    const ngp_stepper_config& c = s->c;
+    const ngp_step_buffers& b = s->b;
+    const int k = s->next_set; s->next_set ^= 1;
+    if (side != main) {
+        STEP_HIP(hipEventRecord(s->ready[k], main));
+        STEP_HIP(hipStreamWaitEvent(side, s->ready[k], 0));
+    }
+    b.counter[k][0] = -1;
+    s->march_t_set[k] = false;
+    if (s->timing) STEP_HIP(hipEventRecord(s->march_t[k][0], side));
+    STEP_TRY(ngp_ray_aabb_near_noise(rays_o, rays_d, c.center, c.half_size, c.near_distance, b.n_rays, c.noise_seed + 0x9E3779B97F4A7C15ull * (++s->marches),
+                                     b.hits_t[k], b.noise[k], (ngp_stream_t)side));
+    STEP_TRY(ngp_raymarching_train_count(rays_o, rays_d, b.hits_t[k], c.density_bitfield, c.cascades, c.scale, c.exp_step_factor, b.noise[k],
+                                         c.grid_size, c.max_samples, b.n_rays, b.rays_a[k], b.counter[k], b.scratch[k], (ngp_stream_t)side));
+    if (s->timing) { STEP_HIP(hipEventRecord(s->march_t[k][1], side)); s->march_t_set[k] = true; }
+    STEP_HIP(hipEventRecord(s->done[k], side));
+    s->has_pending = true; s->pend_o = rays_o; s->pend_d = rays_d; s->pend_set = k;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+int ngp_stepper_create(const ngp_stepper_config* config, const ngp_step_buffers* buffers, ngp_stepper** out) {
+    if (!config || !buffers || !out) return NGP_EINVAL;
+    *out = nullptr;
+    const ngp_stepper_config& c = *config;
+    const void* need[] = {c.center, c.half_size, c.xyz_min, c.xyz_max, c.density_bitfield, c.enc_param, c.enc_half, c.enc_m, c.enc_v,
+                          c.rgb_param, c.rgb_half, c.rgb_m, c.rgb_v, c.grid_grad16};
+    for (const void* p : need) if (p == nullptr) return NGP_EINVAL;
+    if (c.cascades < 1 || c.grid_size < 1 || c.max_samples < 1 || c.n_grid < 1 || c.n_density != NGP_DENSITY_NET_PARAMS || c.n_rgb != NGP_RGB_NET_PARAMS)
+        return NGP_EINVAL;
+    if (c.meta.n_features != 2 || c.meta.n_levels != 16) return NGP_EUNSUP;          // the fused field kernels' configuration
+    const int rc = check_buffers(c, *buffers);
+    if (rc) return rc;
+    ngp_stepper* s = new (std::nothrow) ngp_stepper();
+    if (!s) return NGP_EINVAL;
+    s->c = c; s->b = *buffers;
+    (void)hipGetDevice(&s->device);
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+        e = hipEventCreateWithFlags(&s->ready[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->done[k], hipEventDisableTiming);
+        for (int j = 0; j < 2 && e == hipSuccess; ++j) e = hipEventCreate(&s->march_t[k][j]);
+    }
+    for (int i = 0; i < N_MARKS && e == hipSuccess; ++i) e = hipEventCreate(&s->mark[i]);
+    if (e != hipSuccess) { ngp_stepper_destroy(s); return (int)e; }
+    *out = s;
+    return 0;
+}
+
+int ngp_stepper_destroy(ngp_stepper* s) {
+    if (!s) return 0;
+    if (s->has_pending) (void)wait_march(s, s->pend_set);          // bounded: a march that never ends must not hang the teardown
+    for (int k = 0; k < 2; ++k) {
+        if (s->ready[k]) (void)hipEventDestroy(s->ready[k]);
+        if (s->done[k]) (void)hipEventDestroy(s->done[k]);
+        for (int j = 0; j < 2; ++j) if (s->march_t[k][j]) (void)hipEventDestroy(s->march_t[k][j]);
+    }
+    for (int i = 0; i < N_MARKS; ++i) if (s->mark[i]) (void)hipEventDestroy(s->mark[i]);
+    delete s;
+    return 0;
+}
+
+int ngp_stepper_drop_pending(ngp_stepper* s) {
+    if (!s) return NGP_EINVAL;
+    if (!s->has_pending) return 0;
+    // its kernels may still be running on the marching stream and they write the record's buffers
+    const int rc = wait_march(s, s->pend_set);
+    s->next_set = s->pend_set;          // hand the set back
+    s->has_pending = false;
+    return rc;
+}
+
+int ngp_stepper_set_buffers(ngp_stepper* s, const ngp_step_buffers* buffers) {
+    if (!s || !buffers) return NGP_EINVAL;
+    STEP_TRY(ngp_stepper_drop_pending(s));
+    STEP_TRY(check_buffers(s->c, *buffers));
+    s->b = *buffers;
+    s->S = 0; s->n_part = 0;
+    return 0;
+}
+
+int ngp_stepper_pending(const ngp_stepper* s, const float* rays_o, const float* rays_d) {
+    return (s && s->has_pending && s->pend_o == rays_o && s->pend_d == rays_d) ? 1 : 0;
+}
+
+int ngp_stepper_march(ngp_stepper* s, const float* rays_o, const float* rays_d, ngp_stream_t main_stream, ngp_stream_t march_stream) {
+    if (!s) return NGP_EINVAL;
+    return do_march(s, rays_o, rays_d, ngp_stream(main_stream), ngp_stream(march_stream));
+}
+
+int ngp_stepper_front(ngp_stepper* s, const float* rays_o, const float* rays_d, const float* rgb_gt,
+                      const float* next_o, const float* next_d, float loss_scale, float grad_scale,
+                      ngp_stream_t main_stream, ngp_stream_t march_stream, int32_t* n_samples, int32_t* n_partials) {
+    if (!s || !n_samples || !n_partials) return NGP_EINVAL;
+    NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d); NGP_CHECK_PTR(rgb_gt);
+    if (!s->has_pending || s->pend_o != rays_o || s->pend_d != rays_d) return NGP_EINVAL;     // march() this batch first
+    if ((next_o == nullptr) != (next_d == nullptr)) return NGP_EINVAL;
+    const ngp_stepper_config& c = s->c;
+    const ngp_step_buffers& b = s->b;
+    hipStream_t main = ngp_stream(main_stream), side = ngp_stream(march_stream);
+    const int k = s->pend_set;
+    s->has_pending = false;
+    // the step's only host wait.  No hipStreamWaitEvent on the main stream: the host has observed the event, so everything
+    // enqueued from here on is ordered behind the march (the barrier packet measured ~20 us of idle main stream per step)
+    STEP_TRY(wait_march(s, k));
+    const int32_t S = b.counter[k][0];
+    if (S < 0 || (int64_t)S > b.cap) return NGP_EINVAL;
+    s->S = S; s->last_set = k; s->n_part = 0;
+    *n_samples = S; *n_partials = 0;
+    const int n = b.n_rays;
+    for (int i = 0; i < N_MARKS; ++i) s->mark_set[i] = false;
+    mark(s, 0, main);
+    STEP_TRY(ngp_raymarching_train_write(rays_o, rays_d, b.rays_a[k], b.scratch[k], c.scale, c.exp_step_factor, c.grid_size, c.max_samples, n,
+                                         b.xyzs, b.dirs, b.deltas, b.ts, main_stream));
+    mark(s, 1, main);
+    const ngp_half* table = c.enc_half + c.n_density;
+    if (S > 0) {
+        STEP_TRY(ngp_hashgrid_fwd(b.xyzs, c.xyz_min, c.xyz_max, table, &c.meta, S, b.feats, main_stream));
+        mark(s, 2, main);
+        STEP_TRY(ngp_field_fwd(b.feats, b.dirs, c.enc_half, c.rgb_half, S, b.sigmas, b.rgbs, b.h, main_stream));
+        mark(s, 3, main);
+    }
+    // composite + per-ray loss seeds, then one small kernel: offsets of the live samples and the loss sums
+    STEP_TRY(ngp_composite_train_fw_loss(b.sigmas, b.rgbs, b.deltas, b.ts, b.rays_a[k], c.T_threshold, n, S, b.total, b.opacity, b.depth, b.rgb,
+                                         b.ws, b.ray_offs, b.n_active, rgb_gt, c.bg, c.lambda_opacity, grad_scale, b.stats, b.stats + 1,
+                                         b.dL_drgb, b.dL_dopacity, b.fw_ws, b.fw_bytes, main_stream));
+    mark(s, 4, main);
+    // the next batch's march: behind the composite forward, next to the composite / field backward (round-2 placement sweep)
+    if (next_o) STEP_TRY(do_march(s, next_o, next_d, main, side));
+    if (S > 0) {
+        const float* dL_dws = nullptr;
+        if (c.lambda_distortion > 0) {
+            // losses.py:6-37,58-59: lambda * distortion per ray, mean over rays; its gradient enters the composite as dL/dws
+            STEP_TRY(ngp_distortion_loss_fw(b.ws, b.deltas, b.ts, b.rays_a[k], n, S, b.dist, b.ws_incl, b.wts_incl, main_stream));
+            STEP_TRY(ngp_distortion_loss_bw(b.dist_seed, b.ws_incl, b.wts_incl, b.ws, b.deltas, b.ts, b.rays_a[k], n, S, b.dL_dws, main_stream));
+            dL_dws = b.dL_dws;
+        }
+        // backward only over the samples up to each ray's early stop (the rest have zero gradient); the binned table backward
+        // reads the live samples' positions as a stream: composite_bw copies them in list order
+        s->binned = S <= b.bin_max;
+        STEP_TRY(ngp_composite_train_bw(b.dL_dopacity, b.zeros, b.dL_drgb, dL_dws, b.sigmas, b.rgbs, b.ws, b.deltas, b.ts, b.rays_a[k], b.opacity,
+                                        b.depth, b.rgb, c.T_threshold, n, S, b.dL_dsigmas, b.dL_drgbs, b.ray_offs, b.active,
+                                        s->binned ? b.xyzs : nullptr, s->binned ? b.x_act : nullptr, main_stream));
+        mark(s, 5, main);
+        const int n_part = ngp_field_bwd_partials(S);
+        if (n_part < 1 || n_part > b.max_partials) return NGP_EINVAL;
+        STEP_TRY(ngp_field_bwd(b.feats, b.dirs, b.h, c.enc_half, c.rgb_half, b.dL_dsigmas, b.dL_drgbs, loss_scale, S, b.active, b.n_active,
+                               b.dh, b.dfeats, b.partials, main_stream));
+        mark(s, 6, main);
+        s->n_part = n_part;
+        *n_partials = n_part;
+    }
+    return 0;
+}
+
+int ngp_stepper_table_backward(ngp_stepper* s, int n_groups, int group, ngp_stream_t main_stream) {
+    if (!s || n_groups < 1 || group < 0 || group >= n_groups) return NGP_EINVAL;
+    if (s->S <= 0) return 0;
+    const ngp_stepper_config& c = s->c;
+    const ngp_step_buffers& b = s->b;
+    if (s->binned) {
+        STEP_TRY(ngp_hashgrid_bwd_binned_group(b.x_act, c.xyz_min, c.xyz_max, b.dfeats, &c.meta, s->S, nullptr, b.n_active, b.bin_ws, b.bin_bytes,
+                                               c.grid_grad16, n_groups, group, main_stream));
+    } else if (group == 0) {
+        STEP_TRY(ngp_hashgrid_bwd_sliced(b.xyzs, c.xyz_min, c.xyz_max, b.dfeats, &c.meta, s->S, b.active, b.n_active, c.grid_grad16, main_stream));
+    }
+    if (group == n_groups - 1) mark(s, 7, ngp_stream(main_stream));
+    return 0;
+}
+
+int ngp_stepper_update(ngp_stepper* s, float lr, int32_t step, float grad_scale, const float* density_partials,
+                       const float* rgb_partials, int32_t n_partials, const int32_t* found_inf, ngp_stream_t main_stream) {
+    if (!s || step < 1 || (density_partials == nullptr) != (rgb_partials == nullptr)) return NGP_EINVAL;
+    const ngp_stepper_config& c = s->c;
+    const ngp_step_buffers& b = s->b;
+    if (density_partials == nullptr) {
+        if (s->n_part < 1) return NGP_EINVAL;            // no backward ran (S == 0): nothing to apply
+        density_partials = b.partials;
+        rgb_partials = b.partials + (size_t)s->n_part * c.n_density;
+        n_partials = s->n_part;
+    }
+    if (n_partials < 1) return NGP_EINVAL;
+    STEP_TRY(ngp_adam_step_field(c.enc_param + c.n_density, c.enc_half + c.n_density, c.grid_grad16, c.enc_m + c.n_density, c.enc_v + c.n_density, c.n_grid,
+                                 c.enc_param, c.enc_half, density_partials, c.enc_m, c.enc_v, c.n_density,
+                                 c.rgb_param, c.rgb_half, rgb_partials, c.rgb_m, c.rgb_v, c.n_rgb,
+                                 n_partials, lr, c.beta1, c.beta2, c.eps, c.weight_decay, step, grad_scale, 0, found_inf, main_stream));
+    mark(s, 8, ngp_stream(main_stream));
+    return 0;
+}
+
+int ngp_stepper_timing(ngp_stepper* s, int enable) {
+    if (!s) return NGP_EINVAL;
+    s->timing = enable ? 1 : 0;
+    return 0;
+}
+
+int ngp_stepper_stage_times(ngp_stepper* s, float* ms) {
+    if (!s || !ms) return NGP_EINVAL;
+    for (int i = 0; i < NGP_STEPPER_STAGES; ++i) ms[i] = -1.0f;
+    int prev = -1;
+    for (int i = 0; i < N_MARKS; ++i) {
+        if (!s->mark_set[i]) continue;
+        STEP_HIP(hipEventSynchronize(s->mark[i]));
+        if (prev >= 0 && i >= 1) {
+            float t = 0.f;
+            STEP_HIP(hipEventElapsedTime(&t, s->mark[prev], s->mark[i]));
+            ms[i - 1] = t;
+        }
+        prev = i;
+    }
+    const int k = s->last_set;
+    if (s->march_t_set[k]) {
+        STEP_HIP(hipEventSynchronize(s->march_t[k][1]));
+        float t = 0.f;
+        STEP_HIP(hipEventElapsedTime(&t, s->march_t[k][0], s->march_t[k][1]));
+        ms[8] = t;
+    }
+    return 0;
+}
+
+#pragma GCC visibility pop
+}  // extern "C"

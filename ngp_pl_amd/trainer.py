@@ -114,6 +114,24 @@ class StepBuffers:
         self.ready = [torch.cuda.Event() for _ in (0, 1)]
         self.done = [torch.cuda.Event() for _ in (0, 1)]
 
+    def c_struct(self, distortion):
+        """The same buffers as an ngp_step_buffers record for the native stepper."""
+        P = self.p
+        c = _lib.StepBuffersC()
+        c.n_rays, c.distortion, c.cap = self.n, 1 if distortion else 0, self.cap
+        for name in ("xyzs", "dirs", "deltas", "ts", "feats", "h", "sigmas", "rgbs", "ws", "dL_dsigmas", "dL_drgbs", "active", "x_act", "dh",
+                     "dfeats", "total", "opacity", "depth", "rgb", "dL_drgb", "dL_dopacity", "ray_offs", "dist", "zeros", "dist_seed",
+                     "n_active", "stats", "partials", "fw_ws"):
+            setattr(c, name, P[name])
+        if distortion:
+            c.ws_incl, c.wts_incl, c.dL_dws = P["ws_incl"], P["wts_incl"], P["dL_dws"]
+        for k in (0, 1):
+            c.hits_t[k], c.rays_a[k], c.noise[k], c.scratch[k] = P["hits_t%d" % k], P["rays_a%d" % k], P["noise%d" % k], P["scratch%d" % k]
+            c.counter[k] = self.counter_p[k]
+        c.max_partials, c.fw_bytes = self.MAX_PARTIALS, self.fw_bytes
+        c.bin_ws, c.bin_bytes, c.bin_max = (P["bin_ws"] if self.bin_max else None), self.bin_bytes, self.bin_max
+        return c
+
     def sample_views(self, S):
         """Tensor views of the last step's packed samples (debugging / tests; the step itself uses raw pointers)."""
         f32 = torch.float32
@@ -125,7 +143,7 @@ class StepBuffers:
 class Trainer:
     def __init__(self, model, lr=1e-2, num_epochs=30, steps_per_epoch=1000, T_threshold=1e-4,
                  lambda_opacity=1e-3, grad_scale=1.0, warmup_steps=256, update_interval=16, overlap_march=True,
-                 lambda_distortion=0.0, binned_backward=None, erode=False):
+                 lambda_distortion=0.0, binned_backward=None, erode=False, native_step=None):
         self.model = model
         if not hasattr(model, "density_grid"):
             model.register_training_buffers()
@@ -156,6 +174,7 @@ class Trainer:
         # queue_id, step 0.52 -> 0.89 ms).  High-priority streams are served from a separate queue.
         self.side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("NGP_MARCH_PRIORITY", "-1"))) if (overlap_march and dev.type == "cuda") else None
         self._pending = None     # marched-but-not-consumed batch
+        self._marches = 0        # marches enqueued so far (keys the jitter draw)
         # where in the step the next batch's march is enqueued (it starts behind whatever the main stream has queued by
         # then): "top" = next to the hash forward, "hashgrid_fwd" / "mlp_fwd" / "composite_fw" (default) / "composite_bw" / "mlp_bwd" /
         # "hashgrid_bwd" = behind that stage.
@@ -174,6 +193,14 @@ class Trainer:
         self._main = None        # torch's current stream while a step is being enqueued (cached: the query costs ~8 us)
         self.events = None       # list of (stage, event) when stage timing is on (bench.py roofline)
         self.march_ms = None
+        # the step is enqueued by the native stepper (csrc/stepper.hip: three C calls per step) unless NGP_NATIVE_STEP=0 /
+        # native_step=False selects the Python enqueue path (the same launches through ctypes, ~0.3 ms of host time per step)
+        self.native_step = bool(int(os.environ.get("NGP_NATIVE_STEP", "1"))) if native_step is None else native_step
+        self._stepper = None         # ngp_stepper handle
+        self._stepper_key = None     # what it was built for (pointers, recipe)
+        self._pending_key = None     # (rays_o ptr, rays_d ptr) of the batch whose march the native stepper holds
+        self._pending_keep = None    # ... and the tensors themselves (alive until consumed)
+        self._timing_on = False
 
     # -- stage timing ----------------------------------------------------------------------------
     def _mark(self, name):
@@ -182,8 +209,15 @@ class Trainer:
             e.record()           # torch's current stream == the stream every kernel here is launched on
             self.events.append((name, e))
 
+    STAGES = ("march_write", "hashgrid_fwd", "mlp_fwd", "composite_fw+loss", "composite_bw", "mlp_bwd", "hashgrid_bwd", "adam",
+              "march_count(side stream)")
+
     def stage_times_ms(self):
         """Elapsed time between consecutive stage marks of the last profiled step (syncs)."""
+        if self.native_step and self._stepper is not None:
+            ms = (C.c_float * len(self.STAGES))()
+            call("ngp_stepper_stage_times", self._stepper, ms)
+            return [(name, float(t)) for name, t in zip(self.STAGES, ms) if t >= 0]
         torch.cuda.synchronize()
         ev = self.events
         out = [(ev[i + 1][0], ev[i][1].elapsed_time(ev[i + 1][1])) for i in range(len(ev) - 1)]
@@ -210,10 +244,157 @@ class Trainer:
             if self._pending is not None:
                 self._pending["done"].synchronize()
                 self._pending = None
+            if self._stepper is not None:
+                call("ngp_stepper_drop_pending", self._stepper)
+                self._pending_key = self._pending_keep = None
             torch.cuda.synchronize()
             self._buf = None                                   # release the old arena before the new one is requested
             self._buf = StepBuffers(self.model, n_rays, self.lambda_distortion > 0, self.binned_backward)
+            if self._stepper is not None:
+                bc = self._buf.c_struct(self.lambda_distortion > 0)
+                call("ngp_stepper_set_buffers", self._stepper, C.byref(bc))
         return self._buf
+
+    @property
+    def has_pending(self):
+        """A march of the next batch has been enqueued ahead of its step."""
+        return self._pending is not None or self._pending_key is not None
+
+    # -- the native stepper ----------------------------------------------------------------------
+    def _native_stepper(self, B):
+        """The ngp_stepper for the model's current buffers (created on first use; rebuilt when a pointer it holds moved)."""
+        m = self.model
+        enc, net = m.xyz_encoder, m.rgb_net
+        eh, rh = enc._half.get(enc.params), net._half.get(net.params)
+        (em, ev), (rm, rv) = self.opt.state["enc"], self.opt.state["rgb"]
+        g16 = m._grid_grad16(enc.params.device)
+        key = (enc.params.data_ptr(), eh.data_ptr(), em.data_ptr(), ev.data_ptr(), net.params.data_ptr(), rh.data_ptr(), rm.data_ptr(),
+               rv.data_ptr(), g16.data_ptr(), m.density_bitfield.data_ptr(), m.center.data_ptr(), self.lambda_distortion)
+        if self._stepper is not None and key == self._stepper_key:
+            return self._stepper
+        self._destroy_stepper()
+        c = _lib.StepperConfig()
+        c.center, c.half_size, c.xyz_min, c.xyz_max = ptr(m.center), ptr(m.half_size), ptr(m.xyz_min), ptr(m.xyz_max)
+        c.density_bitfield = ptr(m.density_bitfield)
+        c.cascades, c.grid_size, c.scale, c.exp_step_factor = m.cascades, m.grid_size, float(m.scale), float(self.exp_step_factor)
+        c.meta = enc.meta
+        c.enc_param, c.enc_half, c.enc_m, c.enc_v = ptr(enc.params), ptr(eh), ptr(em), ptr(ev)
+        c.rgb_param, c.rgb_half, c.rgb_m, c.rgb_v = ptr(net.params), ptr(rh), ptr(rm), ptr(rv)
+        c.n_grid, c.n_density, c.n_rgb, c.grid_grad16 = enc.n_grid, enc.n_mlp, net.params.numel(), ptr(g16)
+        c.max_samples, c.near_distance, c.T_threshold = MAX_SAMPLES, NEAR_DISTANCE, self.T_threshold
+        c.lambda_opacity, c.lambda_distortion, c.bg = self.lambda_opacity, self.lambda_distortion, ptr(self.bg)
+        b1, b2 = self.opt.betas
+        c.beta1, c.beta2, c.eps, c.weight_decay = b1, b2, self.opt.eps, self.opt.weight_decay
+        c.noise_seed = int(os.environ.get("NGP_NOISE_SEED", "20240924"))
+        bc = B.c_struct(self.lambda_distortion > 0)
+        h = C.c_void_p()
+        call("ngp_stepper_create", C.byref(c), C.byref(bc), C.byref(h))
+        self._stepper, self._stepper_key = h, key
+        self._pending_key = self._pending_keep = None
+        self._timing_on = False
+        return h
+
+    def _destroy_stepper(self):
+        if self._stepper is not None:
+            _lib.lib().ngp_stepper_destroy(self._stepper)
+            self._stepper = self._stepper_key = None
+            self._pending_key = self._pending_keep = None
+
+    def __del__(self):
+        try:
+            self._destroy_stepper()
+        except Exception:            # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    @torch.no_grad()
+    def _step_native(self, rays_o, rays_d, rgb_gt, next_batch):
+        """`step` through the native stepper: march hand-over, front, [MLP-gradient hook], table backward, [grid-gradient hook],
+        Adam -- three library calls without hooks."""
+        m = self.model
+        dev = rays_o.device
+        enc, net = m.xyz_encoder, m.rgb_net
+        with self._device_guard(dev):
+            main = self._main = torch.cuda.current_stream()
+            mq = main.cuda_stream
+            sq = self.side.cuda_stream if self.side is not None else mq
+            n = rays_o.shape[0]
+            if not (rays_o.is_contiguous() and rays_d.is_contiguous() and rgb_gt.is_contiguous()):
+                rays_o, rays_d, rgb_gt = rays_o.contiguous(), rays_d.contiguous(), rgb_gt.contiguous()
+            had_pending = self._pending_key is not None
+            B = self.buffers(n)                      # (a batch-size change drops the pending march)
+            h = self._native_stepper(B)
+            timing = self.events is not None
+            if timing != self._timing_on:
+                call("ngp_stepper_timing", h, 1 if timing else 0); self._timing_on = timing
+            ro_p, rd_p = rays_o.data_ptr(), rays_d.data_ptr()
+            if self._pending_key != (ro_p, rd_p):
+                if self._pending_key is not None:
+                    call("ngp_stepper_drop_pending", h)
+                if not had_pending or self._grid_step != self.global_step:
+                    self._maybe_update_grid(); self._grid_step = self.global_step
+                call("ngp_stepper_march", h, ro_p, rd_p, mq, sq)
+            self._pending_key = self._pending_keep = None
+            # march of the next batch: concurrent with this step unless the occupancy grid is due for an update first
+            # (that needs this step's optimizer result)
+            next_needs_update = (self.global_step + 1) % self.update_interval == 0
+            prefetch = next_batch is not None and not next_needs_update and next_batch[0].shape[0] == n
+            no_p = nd_p = None
+            if next_batch is not None:
+                if not (next_batch[0].is_contiguous() and next_batch[1].is_contiguous()):
+                    next_batch = (next_batch[0].contiguous(), next_batch[1].contiguous())
+                no_p, nd_p = next_batch[0].data_ptr(), next_batch[1].data_ptr()
+            use_dist = self.lambda_distortion > 0
+            if use_dist:
+                seed_val = self.lambda_distortion / n * self.grad_scale
+                if B.dist_seed_val != seed_val:
+                    B.view("dist_seed", torch.float32, n).fill_(seed_val); B.dist_seed_val = seed_val
+            S_c, np_c = C.c_int32(0), C.c_int32(0)
+            call("ngp_stepper_front", h, ro_p, rd_p, rgb_gt.data_ptr(), no_p if prefetch else None, nd_p if prefetch else None,
+                 self.loss_scale, self.grad_scale, mq, sq, C.byref(S_c), C.byref(np_c))
+            if prefetch:
+                self._pending_key, self._pending_keep = (no_p, nd_p), next_batch
+            S, n_part = S_c.value, np_c.value
+            hooks = self.grad_hook is not None or self.mlp_grad_hook is not None
+            if S > 0:
+                epoch = self.global_step // self.steps_per_epoch
+                lr = self.opt.param_groups[0]["lr"] = cosine_lr(self.base_lr, epoch, self.num_epochs)
+                if not hooks:
+                    call("ngp_stepper_table_backward", h, 1, 0, mq)
+                    self.opt.t += 1
+                    call("ngp_stepper_update", h, lr, self.opt.t, self.loss_scale * self.grad_scale, None, None, 0, None, mq)
+                    enc._half.mark_fresh(enc.params); net._half.mark_fresh(net.params)
+                else:
+                    g16 = m._grid_grad16(dev)
+                    native = dict(grid16=g16, density_partials=B.view("partials", torch.float32, n_part * enc.n_mlp),
+                                  rgb_partials=B.arena[B.off["partials"] + 4 * n_part * enc.n_mlp:
+                                                       B.off["partials"] + 4 * n_part * B.n_mlp_params].view(torch.float32),
+                                  n_partials=n_part, scale=self.loss_scale)
+                    m._native = native
+                    if self.mlp_grad_hook is not None:
+                        self.mlp_grad_hook()
+                    ng = self.bwd_groups if (self.group_hook is not None and self.grad_hook is not None and 0 < S <= B.bin_max) else 1
+                    for g in range(ng):
+                        call("ngp_stepper_table_backward", h, ng, g, mq)
+                        if ng > 1:
+                            self.group_hook(g, ng, *self._group_entries(enc.meta, S, ng, g))
+                    found_inf = self.grad_hook() if self.grad_hook is not None else None
+                    nat = m._native
+                    self.opt.t += 1
+                    call("ngp_stepper_update", h, lr, self.opt.t, nat["scale"] * self.grad_scale, ptr(nat["density_partials"]),
+                         ptr(nat["rgb_partials"]), nat["n_partials"], ptr(found_inf), mq)
+                    enc._half.mark_fresh(enc.params); net._half.mark_fresh(net.params)
+                    m._native = None
+            elif hooks:
+                # no samples on THIS rank: the other ranks still expect it in the gradient collectives
+                self._exchange_and_update(self.zero_native(dev), None, mq)
+            self.global_step += 1
+            self.last = dict(stats=B.stats, rm_samples=S, total=B.total, n_rays=n, rgb=B.rgb, opacity=B.opacity,
+                             distortion=B.dist if (S > 0 and use_dist) else None, n_active=B.n_active)
+            if next_batch is not None and next_needs_update and next_batch[0].shape[0] == n:
+                self._maybe_update_grid(); self._grid_step = self.global_step
+                call("ngp_stepper_march", h, no_p, nd_p, mq, sq)
+                self._pending_key, self._pending_keep = (no_p, nd_p), next_batch
+        return self.last
 
     def _march(self, rays_o, rays_d):
         """AABB + near clamp + pass 1 of the march (+ ray-ordered scan).  Enqueued on the side
@@ -238,8 +419,12 @@ class Trainer:
             t0 = t1 = None
             if self.events is not None:
                 t0 = torch.cuda.Event(enable_timing=True); t0.record(st)
-            B.noise[k].uniform_()                # jitter of the first sample (custom_functions.py:83: torch.rand_like); drawn on the marching stream
-            call("ngp_ray_aabb_near", ptr(rays_o), ptr(rays_d), ptr(m.center), ptr(m.half_size), NEAR_DISTANCE, n, P["hits_t%d" % k], sq)
+            # AABB + near clamp + the jitter of the first sample (custom_functions.py:83: torch.rand_like) in one launch; the same
+            # counter-based draw as the native stepper's (csrc/stepper.hip), so the two enqueue paths produce the same steps
+            self._marches += 1
+            seed = (int(os.environ.get("NGP_NOISE_SEED", "20240924")) + 0x9E3779B97F4A7C15 * self._marches) & 0xFFFFFFFFFFFFFFFF
+            call("ngp_ray_aabb_near_noise", ptr(rays_o), ptr(rays_d), ptr(m.center), ptr(m.half_size), NEAR_DISTANCE, n, seed,
+                 P["hits_t%d" % k], P["noise%d" % k], sq)
             call(self._march_count, ptr(rays_o), ptr(rays_d), P["hits_t%d" % k], ptr(m.density_bitfield), m.cascades,
                  float(m.scale), self.exp_step_factor, P["noise%d" % k], m.grid_size, MAX_SAMPLES, n, P["rays_a%d" % k], B.counter_p[k],
                  P["scratch%d" % k], sq)
@@ -265,6 +450,8 @@ class Trainer:
         """One optimisation step on a batch of rays.  `next_batch` = (rays_o, rays_d) of the
         following step, if known: its march overlaps this step's kernels.  The tensors in the returned
         record are views of the step's preallocated buffers: valid until the next step."""
+        if self.native_step and rays_o.is_cuda:
+            return self._step_native(rays_o, rays_d, rgb_gt, next_batch)
         m = self.model
         dev = rays_o.device
         enc, net = m.xyz_encoder, m.rgb_net

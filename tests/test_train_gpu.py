@@ -686,11 +686,11 @@ def test_batch_size_change_reallocates_the_step_buffers():
     big = [batch(4096, seed=600 + i) for i in range(2)]
     small = [batch(1024, seed=610 + i) for i in range(2)]
     tr.step(*big[0], next_batch=(big[1][0], big[1][1]))
-    assert tr._buf.n == 4096 and tr._pending is not None
+    assert tr._buf.n == 4096 and tr.has_pending
     out = tr.step(*small[0])                                     # the pending 4096-ray march is dropped, buffers rebuilt
     assert tr._buf.n == 1024 and out["n_rays"] == 1024 and out["rm_samples"] > 0
     tr.step(*small[1], next_batch=(big[1][0], big[1][1]))         # a next batch of another size is not prefetched
-    assert tr._pending is None
+    assert not tr.has_pending
     out = tr.step(*big[1])
     assert tr._buf.n == 4096 and math.isfinite(tr.metrics()["loss"]) and out["rm_samples"] > 0
 
@@ -757,3 +757,56 @@ def test_gradient_exchange_at_world_size_one_is_the_identity():
         assert torch.isfinite(m.xyz_encoder.params).all()
     finally:
         dist.destroy_process_group()
+
+
+def test_native_stepper_equals_the_python_enqueue_path():
+    """Trainer.step through the native stepper (csrc/stepper.hip: three library calls per step) and through the Python enqueue
+    path (NGP_NATIVE_STEP=0: the same launches through ctypes) from the same initialisation on the same batches, with the
+    occupancy update every 16 steps, the prefetched march on the second stream and the distortion loss: sample counts, loss
+    and EVERY parameter bit for bit after 40 steps (the jitter is the same counter-based draw in both, the table backward is
+    the exact fixed-point one, every reduction has a fixed order)."""
+    from ngp_pl_amd.trainer import Trainer
+    batches = [batch(1024, seed=900 + i) for i in range(8)]
+
+    def run(native, lambda_distortion):
+        m = make_model(seed=11)
+        tr = Trainer(m, native_step=native, lambda_distortion=lambda_distortion)
+        log = []
+        for i in range(40):
+            b, nb = batches[i % 8], batches[(i + 1) % 8]
+            out = tr.step(*b, next_batch=(nb[0], nb[1]))
+            log.append((out["rm_samples"], tr.last["stats"].tolist(), int(tr.last["n_active"].item())))
+        torch.cuda.synchronize()
+        return m, tr, log
+
+    for lam in (0.0, 1e-3):
+        ma, ta, la = run(True, lam)
+        mb, tb, lb = run(False, lam)
+        assert ta._stepper is not None and tb._stepper is None
+        assert [x[0] for x in la] == [x[0] for x in lb]
+        assert la == lb, [i for i in range(40) if la[i] != lb[i]][:5]
+        for (ka, pa), (kb, pb) in zip(ma.state_dict().items(), mb.state_dict().items()):
+            assert ka == kb and torch.equal(pa, pb), ka
+        assert la[-1][0] > 0 and la[-1][2] > 0 and la[0][0] > 20 * 1024          # full grid at first, pruned later
+
+
+def test_native_stepper_stage_times_and_timeout_code():
+    """Stage timing of the native stepper (what bench.py's roofline reads): every main-stream stage and the march report a
+    positive time once timing is on; a stepper asked to step a batch it has not marched refuses (NGP_EINVAL), it does not wait."""
+    from ngp_pl_amd import _lib
+    from ngp_pl_amd.trainer import Trainer
+    m = make_model(seed=12)
+    tr = Trainer(m)
+    a, b = batch(2048, seed=950), batch(2048, seed=951)
+    tr.step(*a, next_batch=(b[0], b[1]))
+    tr.events = []
+    tr.step(*b, next_batch=(a[0], a[1]))
+    st = dict(tr.stage_times_ms())
+    assert set(st) == set(Trainer.STAGES), st
+    assert all(0 < v < 50 for v in st.values()), st
+    tr.events = None
+    import ctypes as C
+    s_c, n_c = C.c_int32(), C.c_int32()
+    with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
+        _lib.call("ngp_stepper_front", tr._stepper, b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr(), None, None, 128.0, 1.0,
+                  torch.cuda.current_stream().cuda_stream, tr.side.cuda_stream, C.byref(s_c), C.byref(n_c))
