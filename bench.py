@@ -456,6 +456,10 @@ def secondary_line(name, args, dev):
     out = {"workload": loop.description, "rays_per_s": r["rays_per_s"], "ms_per_step": r["ms_per_step"], "rays_per_batch": loop.rays,
            "samples_per_ray_marched": met["rm_s"], "samples_per_ray_composited": met["vr_s"], "train_psnr": met["psnr"],
            "cascades": loop.model.cascades, "timed_steps_total": r["timed_steps_total"], "setup_steps": args.setup_steps}
+    from ngp_pl_amd import _lib as native
+    out["march_guards"] = native.march_guard_counts()
+    if out["march_guards"][0]:
+        out["march_guard_first_probe"] = native.march_guard_first()
     del loop
     torch.cuda.empty_cache()
     return out
@@ -629,6 +633,10 @@ def main():
     }
     if "exchange_ms" in r:
         out["exchange_ms"] = r["exchange_ms"]
+    from ngp_pl_amd import _lib as native
+    out["march_guards"] = native.march_guard_counts()
+    if out["march_guards"][0]:
+        out["march_guard_first_probe"] = native.march_guard_first()        # tripped termination guards of the marching kernels so far: all zero for sane rays
     keeper.headline(out)
     if dist is not None:      # what follows runs on rank 0 only: no collectives from here on
         loop.exchange.uninstall(loop.trainer)

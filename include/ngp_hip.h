@@ -43,6 +43,9 @@ const char* ngp_build_arch(void);
  * the device: counts4[0] = skips whose smallest step would not move t, [1] = wave-per-ray tile cap, [2] = serial loop
  * iteration cap, [3] = 1 + index of the last ray that ran into [1].  Synchronous (hipMemcpyFromSymbol); reset != 0 clears the counts. */
 int ngp_march_guard_read(uint32_t* counts4, int reset);
+/* Diagnostics: the first probe that ran into guard [0] since the library was loaded: t, t_target, the three face distances,
+ * ray origin (3), ray direction (3), the smallest step.  Synchronous. */
+int ngp_march_guard_first(float* probe12);
 
 /* ------------------------------------------------------------------------------------------
  * vren: intersection            (reference: models/csrc/intersection.cu)
@@ -444,6 +447,22 @@ int ngp_adam_step_field(float* grid_param, ngp_half* grid_param_h, ngp_half* gri
                         int n_partials, float lr, float beta1, float beta2, float eps,
                         float weight_decay, int step, float grad_scale, int zero_grid_grad,
                         const int32_t* found_inf, ngp_stream_t stream);
+/* The same launch for a data-parallel rank that owns ONE SHARD of the grid table (ngp_pl_amd/ddp.py ShardedExchange: reduce-scatter of
+ * the gradient -> this update -> all-gather of the updated f16 table): the grid pointers address the rank's shard (n_shard
+ * parameters, gradient = the reduce-scatter's output), the MLP blocks are updated by every rank alike.  Two skip flags: the MLP
+ * blocks follow found_inf_mlp (computed on the all-reduced MLP sums: identical on every rank), the shard follows found_inf_shard
+ * (computed on the shard's reduced gradient by its owner): every parameter is decided by exactly one flag that all ranks that
+ * update it agree on, so the ranks stay in lock step without a flag collective.  The gradient is not cleared. */
+int ngp_adam_step_field_shard(float* grid_param, ngp_half* grid_param_h, ngp_half* grid_grad,
+                              float* grid_m, float* grid_v, int64_t n_shard,
+                              float* density_param, ngp_half* density_param_h,
+                              const float* density_partials, float* density_m, float* density_v,
+                              int n_density,
+                              float* rgb_param, ngp_half* rgb_param_h, const float* rgb_partials,
+                              float* rgb_m, float* rgb_v, int n_rgb,
+                              int n_partials, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, int step, float grad_scale,
+                              const int32_t* found_inf_mlp, const int32_t* found_inf_shard, ngp_stream_t stream);
 /* GradScaler's non-finite check (train.py:274 precision=16 -> torch.amp.GradScaler.unscale_) on a native
  * gradient buffer of n elements (f16, or f32 if grad_is_f32; 16-byte aligned): flag[0] (device i32) |= 1 if any
  * element is inf or NaN; reset != 0 zeroes the flag first.  Used behind the multi-GPU all-reduce, whose f16
@@ -639,6 +658,8 @@ int ngp_stepper_set_buffers(ngp_stepper* s, const ngp_step_buffers* buffers);
 int ngp_stepper_march(ngp_stepper* s, const float* rays_o, const float* rays_d, ngp_stream_t main_stream, ngp_stream_t march_stream);
 /* Is a march of exactly these buffers pending?  (1 / 0) */
 int ngp_stepper_pending(const ngp_stepper* s, const float* rays_o, const float* rays_d);
+/* Which of the two march record sets (hits_t / rays_a / noise / scratch / counter) the last front() consumed: 0 or 1. */
+int ngp_stepper_last_set(const ngp_stepper* s);
 /* Waits for a pending march and forgets it (the batch it was made for is not going to be stepped). */
 int ngp_stepper_drop_pending(ngp_stepper* s);
 /* The step up to the field backward, on main_stream.  The pending march must be the one of (rays_o, rays_d).

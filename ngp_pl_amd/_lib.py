@@ -93,6 +93,7 @@ _PROTOS = {
     "ngp_adam_step": [P, P, P, I, P, P, L, F, F, F, F, F, I, F, P, P],
     "ngp_adam_step_partials": [P, P, P, I, P, P, I, F, F, F, F, F, I, F, P, P],
     "ngp_adam_step_field": [P, P, P, P, P, L, P, P, P, P, P, I, P, P, P, P, P, I, I, F, F, F, F, F, I, F, I, P, P],
+    "ngp_adam_step_field_shard": [P, P, P, P, P, L, P, P, P, P, P, I, P, P, P, P, P, I, I, F, F, F, F, F, I, F, P, P, P],
     "ngp_reduce_partials": [P, I, I, P, P],
     "ngp_found_inf": [P, I, L, P, I, P],
     "ngp_found_inf2": [P, I, L, P, I, L, P, P, P],
@@ -108,11 +109,13 @@ _PROTOS = {
     "ngp_sample_rays": [P, P, P, I, I, I, C.c_uint64, P, P, P, P, P, P, P],
     "ngp_abi_version": [],
     "ngp_march_guard_read": [P, I],
+    "ngp_march_guard_first": [P],
     "ngp_stepper_create": [C.POINTER(StepperConfig), C.POINTER(StepBuffersC), C.POINTER(P)],
     "ngp_stepper_destroy": [P],
     "ngp_stepper_set_buffers": [P, C.POINTER(StepBuffersC)],
     "ngp_stepper_march": [P, P, P, P, P],
     "ngp_stepper_pending": [P, P, P],
+    "ngp_stepper_last_set": [P],
     "ngp_stepper_drop_pending": [P],
     "ngp_stepper_front": [P, P, P, P, P, P, F, F, P, P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "ngp_stepper_table_backward": [P, I, I, P],
@@ -132,7 +135,7 @@ _PROTOS = {
     "ngp_render_test_frame": [P, P, P, P, I, F, F, I, I, F, P, P, P, C.POINTER(GridMeta), P, P, I, I, I,
                               C.POINTER(C.c_float), P, C.c_size_t, P, P, P, P, C.POINTER(C.c_int32), P],
 }
-_COUNT_QUERIES = ("ngp_field_bwd_partials", "ngp_mlp_bwd_partials", "ngp_abi_version", "ngp_stepper_pending")
+_COUNT_QUERIES = ("ngp_field_bwd_partials", "ngp_mlp_bwd_partials", "ngp_abi_version", "ngp_stepper_pending", "ngp_stepper_last_set")
 
 _lib = None
 
@@ -228,6 +231,14 @@ def march_guard_counts(reset=False):
     buf = (C.c_uint32 * 4)()
     call("ngp_march_guard_read", C.cast(buf, P), 1 if reset else 0)
     return list(buf)
+
+
+def march_guard_first():
+    """The first probe that tripped the absorbed-step guard: dict of t, t_target, face distances, ray origin / direction."""
+    buf = (C.c_float * 12)()
+    call("ngp_march_guard_first", C.cast(buf, P))
+    v = list(buf)
+    return dict(t=v[0], t_target=v[1], t_faces=v[2:5], origin=v[5:8], direction=v[8:11], dt_lo=v[11])
 
 
 def ptr(t):

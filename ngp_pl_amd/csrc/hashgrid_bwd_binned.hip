@@ -43,16 +43,19 @@ constexpr int BIN_SPT = 2;                   // samples per thread
 constexpr int CHUNK = BIN_THREADS * BIN_SPT; // samples per binning workgroup ("chunk")
 constexpr int CHUNK_SLOTS = CHUNK * 8;       // list entries a chunk can produce for one level (<= 8 slices per sample)
 constexpr int MAX_CHUNKS = 1024;             // the slice owners scan the chunk directory in one pass
-// Hashed levels hand the slice owner everything it needs in the list entry itself (12 bytes, NGP_BIN_PAYLOAD, default on):
+// Measured alternative, compiled out by default (NGP_BIN_PAYLOAD=1 builds it; profiles/r03_table_backward_experiments.txt):
+// hashed levels hand the slice owner everything it needs in the list entry itself (12 bytes):
 //   word 0: l0 | l1 << 13      slice-local indices of the pair's two corners (x, .) and (x+1, .); PAY_INVALID = not in this slice
 //   word 1: the sample's gradient for this level (half2 bits)
 //   word 2: w0 | w1 << 16      the two trilinear weights in 16-bit fixed point (units of 2^-16; tiny-cuda-nn rounds every
 //                              w * g product to f16, i.e. to 11 bits)
 // so that an owner's trip is three coalesced stream loads, four multiplies and four LDS adds per entry: no position /
-// gradient gathers (they ran at the texture addressers' one-lane-address-per-clock rate: 29 M gathers per step), no cell,
-// hash or weight arithmetic repeated by each of a sample's four pair entries (round 2: 80 VALU per row of 64 entries).
+// gradient gathers, no cell, hash or weight arithmetic repeated by each of a sample's four pair entries.  On MI355X the
+// slice owners get 14 % faster (apply span 96.5 -> 83.0 us at 155 k samples) and the binning pass, whose 12-byte entries
+// now leave as scattered stores, twice as slow (26 -> 53 us): 132 -> 145 us for the stage.  The owners' time is not in
+// their gathers or arithmetic.
 #ifndef NGP_BIN_PAYLOAD
-#define NGP_BIN_PAYLOAD 1
+#define NGP_BIN_PAYLOAD 0
 #endif
 constexpr uint32_t PAY_INVALID = 0x1fffu;    // >= SLICE2: fails the in-slice test
 static_assert(SLICE2 < PAY_INVALID, "slice-local indices are stored in 13 bits");
@@ -64,6 +67,9 @@ static_assert(SLICE2 < PAY_INVALID, "slice-local indices are stored in 13 bits")
 #endif
 #ifndef NGP_APPLY_B
 #define NGP_APPLY_B 11
+#endif
+#ifndef NGP_DENSE_B
+#define NGP_DENSE_B 4                         // dense levels: entries per lane in flight
 #endif
 #ifndef NGP_APPLY_PB
 #define NGP_APPLY_PB 8                        // payload entries: segments per trip (3 words per segment and lane in flight)
@@ -221,6 +227,12 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const
 }
 
 // ---- pass 2: slice owners -------------------------------------------------------------------
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
 __device__ __forceinline__ void lds_add_fixed(long long* acc, float v) {
     const int q = __float2int_rn(v * FIX_SCALE);                   // saturates; |w*g| < 128 by a wide margin
     atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)(long long)q);   // ds_add_u64
@@ -294,8 +306,16 @@ __device__ __forceinline__ void apply_pairs(long long* lds, uint32_t lo, uint32_
     }
 }
 
-// Hashed levels: a wave takes B chunk segments per trip (typically ~57 entries each), lane = entry:
-// coalesced entry / gradient / position streams, all of a trip's loads in flight together.
+// Hashed levels: a wave takes B chunk segments per trip (typically ~57 entries each): all of a trip's loads in flight together.
+// Which lane takes which entry decides how often the lanes of ONE ds_add_u64 hit the same accumulator: a segment lists its
+// chunk's samples in (roughly) sample order, and consecutive samples of a ray sit in the same cell for 7 .. 1 steps on the
+// hashed levels 6 .. 15, so with lane = position in the segment a wave instruction carries runs of up to 7 equal addresses
+// (measured: 8 lanes per address cost 64 cycles instead of 11.5).  NGP_APPLY_TRANSPOSE (default): lane L works on segment
+// L & 7 of the trip and, in its i-th instruction, on that segment's entry 8 (L >> 3) + i -- the lanes of one instruction are
+// 8 entries apart within a segment and otherwise in different chunks.
+#ifndef NGP_APPLY_TRANSPOSE
+#define NGP_APPLY_TRANSPOSE 1
+#endif
 template <int B>
 __device__ __forceinline__ void apply_segments_hashed(long long* lds, uint32_t lo, uint32_t len, uint32_t res, uint32_t size, float scale,
                                                       const float* __restrict__ x, const Box& box, const half2_t* __restrict__ g_level,
@@ -303,6 +323,28 @@ __device__ __forceinline__ void apply_segments_hashed(long long* lds, uint32_t l
                                                       const int* s_dir, int n_chunks, int part, int K) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NW = APPLY_THREADS / 64;
+    if (NGP_APPLY_TRANSPOSE) {
+        static_assert(!NGP_APPLY_TRANSPOSE || B == 8, "the transposed assignment works on 8 segments per trip");
+        const int seg = lane & 7, row0 = (lane >> 3) << 3;
+        for (int c0 = part + K * wave; c0 < n_chunks; c0 += K * NW * 8) {
+            const int c = c0 + seg * K * NW;                           // this lane's segment of the trip
+            const int d = (c < n_chunks) ? s_dir[c] : 0;
+            const size_t start = (size_t)c * CHUNK_SLOTS + (d >> 16);
+            const int cnt = d & 0xffff;
+            const int maxcnt = __builtin_amdgcn_readfirstlane(wave_max_i32(cnt));
+            for (int off = 0; off < maxcnt; off += 64) {               // one pass unless a segment has more than 64 entries
+                int ee[8]; bool ok[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int pos = off + row0 + i;
+                    ok[i] = pos < cnt;
+                    ee[i] = ok[i] ? pool_level[start + pos] : 0;
+                }
+                apply_pairs<8>(lds, lo, len, size, scale, x, box, g_level, active, ee, ok);
+            }
+        }
+        return;
+    }
     for (int c0 = part + K * wave; c0 < n_chunks; c0 += K * NW * B) {
         int start[B], cnt[B], maxcnt = 0;
 #pragma unroll
@@ -367,6 +409,9 @@ __device__ __forceinline__ void apply_segments_payload(long long* lds, uint32_t 
 // (measured: an LDS add_u64 with 8 lanes per address costs 64 cycles instead of 11.5).  Lane L
 // therefore walks the contiguous run [L*R, (L+1)*R) of the segment: the lanes of a wave are a whole
 // run apart, on different rays.
+#ifndef NGP_DENSE_RUNS
+#define NGP_DENSE_RUNS 1                 // 0: every sample's 16 updates go to LDS one by one (round 2; kept for A/B builds)
+#endif
 template <int B>
 __device__ __forceinline__ void apply_segments_dense(long long* lds, uint32_t lo, uint32_t len, uint32_t res, uint32_t size, float scale,
                                                      const float* __restrict__ x, const Box& box, const half2_t* __restrict__ g_level,
@@ -389,6 +434,80 @@ __device__ __forceinline__ void apply_segments_dense(long long* lds, uint32_t lo
             }
             apply_entries<B>(lds, lo, len, res, size, scale, x, box, g_level, active, jj, ok);
         }
+    }
+}
+
+// Within a lane's run consecutive entries are consecutive samples of a ray (a chunk's list keeps the order in which the
+// binning waves arrived: blocks of 64 consecutive samples), i.e. they sit in the same cell for 10-40 steps on the coarse
+// levels: the 8 corner sums are kept in REGISTERS -- as 64-bit fixed point, the accumulators' own arithmetic: exact, so
+// neither the run boundaries nor the list order can change a bit of the result -- and reach LDS when the cell changes.
+__device__ __forceinline__ void flush_cell(long long* lds, uint32_t lo, uint32_t len, uint32_t res, uint32_t size, uint32_t key,
+                                           const long long (&acc)[16]) {
+    const uint32_t r2 = res * res;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        uint32_t i = key + (c & 1) + ((c >> 1) & 1) * res + (c >> 2) * r2;
+        i = (i >= size) ? i - size : i;
+        const uint32_t local = i - lo;
+        if (local < len) {
+            if (acc[2 * c] != 0) atomicAdd(reinterpret_cast<unsigned long long*>(lds + 2 * local), (unsigned long long)acc[2 * c]);
+            if (acc[2 * c + 1] != 0) atomicAdd(reinterpret_cast<unsigned long long*>(lds + 2 * local + 1), (unsigned long long)acc[2 * c + 1]);
+        }
+    }
+}
+template <int B>
+__device__ __forceinline__ void apply_segments_dense_runs(long long* lds, uint32_t lo, uint32_t len, uint32_t res, uint32_t size, float scale,
+                                                          const float* __restrict__ x, const Box& box, const half2_t* __restrict__ g_level,
+                                                          const int32_t* __restrict__ active, const int32_t* __restrict__ pool_level,
+                                                          const int* s_dir, int n_chunks, int part, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = APPLY_THREADS / 64;
+    const uint32_t top = res - 1u, r2 = res * res;
+    for (int c = part + K * wave; c < n_chunks; c += K * NW) {
+        const int d = s_dir[c];
+        const int cnt = d & 0xffff;
+        const size_t start = (size_t)c * CHUNK_SLOTS + (d >> 16);
+        const int R = (cnt + 63) >> 6;
+        long long acc[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0;
+        uint32_t cur = 0xffffffffu;
+        for (int t0 = 0; t0 < R; t0 += B) {
+            int jj[B]; bool ok[B]; half2_t g[B]; float px[B][3];
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                const int i = lane * R + t0 + b;
+                ok[b] = (t0 + b < R) && i < cnt;
+                jj[b] = ok[b] ? (pool_level[start + i] >> 2) : 0;
+            }
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                g[b] = g_level[jj[b]];
+                const float* __restrict__ xp = x + 3 * (size_t)(active ? active[jj[b]] : jj[b]);
+                px[b][0] = xp[0]; px[b][1] = xp[1]; px[b][2] = xp[2];
+            }
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                if (!ok[b]) continue;
+                const float g0 = (float)g[b][0], g1 = (float)g[b][1];
+                uint32_t p[3]; float f[3];
+                cell_of_loaded(px[b], box, scale, p, f);
+                const uint32_t key = min(p[0], top) + min(p[1], top) * res + min(p[2], top) * r2;       // border clamp: corner_indices<false>
+                if (key != cur) {
+                    if (cur != 0xffffffffu) flush_cell(lds, lo, len, res, size, cur, acc);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[q] = 0;
+                    cur = key;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float w = corner_weight(q, f);
+                    acc[2 * q] += (long long)__float2int_rn((w * g0) * FIX_SCALE);                       // lds_add_fixed()'s quantisation
+                    acc[2 * q + 1] += (long long)__float2int_rn((w * g1) * FIX_SCALE);
+                }
+            }
+        }
+        if (cur != 0xffffffffu) flush_cell(lds, lo, len, res, size, cur, acc);
     }
 }
 
@@ -437,8 +556,9 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
         const int32_t* __restrict__ pool_level = ws.pool + plan.pool_off[level];
         if (level_is_hashed(res, size)) {
             if (NGP_BIN_PAYLOAD) apply_segments_payload<NGP_APPLY_PB>(lds, len, pool_level, s_dir, n_chunks, part, K);
-            else apply_segments_hashed<NGP_APPLY_B>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
+            else apply_segments_hashed<NGP_APPLY_TRANSPOSE ? 8 : NGP_APPLY_B>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
         }
+        else if (NGP_DENSE_RUNS) apply_segments_dense_runs<NGP_DENSE_B>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
         else apply_segments_dense<4>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
         __syncthreads();
 #ifdef NGP_BIN_TIMING

@@ -257,6 +257,7 @@ __device__ __forceinline__ float calc_dt(float t, const MarchParams& p) {
 // [1] the wave-per-ray tile cap, [2] a serial loop's iteration cap (train / test / frame loop), [3] 1 + index of the last ray
 // that ran into [1] (diagnostics).
 __device__ unsigned int g_march_guard[4];
+__device__ float g_march_guard_first[12];       // the first probe that ran into [0]: t, t_target, tx, ty, tz, o (3), d (3), dt_lo
 constexpr int MARCH_TILE_CAP = 1 << 14;          // 2^20 lattice points per ray; the longest legitimate ray (scale 64) has 2^17
 constexpr int MARCH_ITER_CAP = 1 << 20;
 
@@ -305,7 +306,11 @@ __device__ __forceinline__ bool march_probe(const Ray& ray, const MarchParams& p
         float tt = t;
         int k = 0;                                   // elements of the ray's t sequence the skip advances by (>= 1)
         if (t_target + p.dt_lo == t_target) {        // the smallest step no longer moves t anywhere up to the target (false for NaN): end the ray
-            atomicAdd(&g_march_guard[0], 1u);
+            if (atomicAdd(&g_march_guard[0], 1u) == 0u) {
+                float* q = g_march_guard_first;
+                q[0] = t; q[1] = t_target; q[2] = tx; q[3] = ty; q[4] = tz; q[5] = ray.ox; q[6] = ray.oy; q[7] = ray.oz;
+                q[8] = ray.dx; q[9] = ray.dy; q[10] = ray.dz; q[11] = p.dt_lo;
+            }
             tt = __builtin_inff(); k = 1 << 20;
         } else if (SIMPLE) { do { tt += p.dt_lo; ++k; } while (tt < t_target); }
         else { do { tt += calc_dt(tt, p); ++k; } while (tt < t_target); }
@@ -991,6 +996,11 @@ extern "C" {
 #pragma GCC visibility push(default)
 
 int ngp_abi_version(void) { return 3; }
+
+int ngp_march_guard_first(float* probe12) {
+    NGP_CHECK_PTR(probe12);
+    return (int)hipMemcpyFromSymbol(probe12, HIP_SYMBOL(g_march_guard_first), 12 * sizeof(float), 0, hipMemcpyDeviceToHost);
+}
 
 int ngp_march_guard_read(uint32_t* counts4, int reset) {
     NGP_CHECK_PTR(counts4);

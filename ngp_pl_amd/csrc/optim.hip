@@ -16,7 +16,8 @@ typedef _Float16 h1;
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-struct AdamHyper { float lr, beta1, beta2, eps, wd, bc1, bc2, inv_scale; const int32_t* found_inf; int zero_grad; };
+struct AdamHyper { float lr, beta1, beta2, eps, wd, bc1, bc2, inv_scale; const int32_t* found_inf; int zero_grad;
+                   const int32_t* found_inf_dense; };     // skip flag of the dense (grid) block: found_inf unless a caller gives it its own
 
 // Dense (streaming) update of n parameters by workgroups `block` of `n_blocks`, 4 parameters per thread and trip.
 template <bool GRAD_F32>
@@ -24,7 +25,7 @@ __device__ __forceinline__ void adam_dense(float* __restrict__ param, h1* __rest
                                            float* __restrict__ m, float* __restrict__ v, long long n4, long long n,
                                            const AdamHyper& hp, int block, int n_blocks) {
     const float lr = hp.lr, beta1 = hp.beta1, beta2 = hp.beta2, eps = hp.eps, wd = hp.wd, bc1 = hp.bc1, bc2 = hp.bc2, inv_scale = hp.inv_scale;
-    const bool skip = hp.found_inf != nullptr && *hp.found_inf != 0;
+    const bool skip = hp.found_inf_dense != nullptr && *hp.found_inf_dense != 0;
     const long long stride = (long long)n_blocks * blockDim.x;
     for (long long q = (long long)block * blockDim.x + threadIdx.x; q < n4; q += stride) {
         const long long base = q * 4;
@@ -383,7 +384,7 @@ AdamHyper adam_hyper(float lr, float beta1, float beta2, float eps, float wd, in
     AdamHyper hp;
     hp.lr = lr; hp.beta1 = beta1; hp.beta2 = beta2; hp.eps = eps; hp.wd = wd;
     hp.bc1 = 1.0f - powf(beta1, (float)step); hp.bc2 = 1.0f - powf(beta2, (float)step);
-    hp.inv_scale = 1.0f / grad_scale; hp.found_inf = found_inf; hp.zero_grad = 1;
+    hp.inv_scale = 1.0f / grad_scale; hp.found_inf = found_inf; hp.found_inf_dense = found_inf; hp.zero_grad = 1;
     return hp;
 }
 
@@ -423,17 +424,19 @@ int ngp_adam_step_partials(float* param, ngp_half* param_h, const float* partial
     return NGP_LAUNCH_RESULT();
 }
 
-int ngp_adam_step_field(float* grid_param, ngp_half* grid_param_h, ngp_half* grid_grad, float* grid_m, float* grid_v, int64_t n_grid,
-                        float* density_param, ngp_half* density_param_h, const float* density_partials, float* density_m,
-                        float* density_v, int n_density, float* rgb_param, ngp_half* rgb_param_h, const float* rgb_partials,
-                        float* rgb_m, float* rgb_v, int n_rgb, int n_partials, float lr, float beta1, float beta2, float eps,
-                        float weight_decay, int step, float grad_scale, int zero_grid_grad, const int32_t* found_inf, ngp_stream_t stream) {
+static int adam_step_field_impl(float* grid_param, ngp_half* grid_param_h, ngp_half* grid_grad, float* grid_m, float* grid_v, int64_t n_grid,
+                                float* density_param, ngp_half* density_param_h, const float* density_partials, float* density_m,
+                                float* density_v, int n_density, float* rgb_param, ngp_half* rgb_param_h, const float* rgb_partials,
+                                float* rgb_m, float* rgb_v, int n_rgb, int n_partials, float lr, float beta1, float beta2, float eps,
+                                float weight_decay, int step, float grad_scale, int zero_grid_grad, const int32_t* found_inf,
+                                const int32_t* found_inf_grid, ngp_stream_t stream) {
     if (n_grid <= 0 || n_density <= 0 || n_rgb <= 0 || n_partials < 0 || step < 1 || grad_scale == 0.f) return NGP_EINVAL;
     NGP_CHECK_PTR(grid_param); NGP_CHECK_PTR(grid_grad); NGP_CHECK_PTR(grid_m); NGP_CHECK_PTR(grid_v);
     NGP_CHECK_PTR(density_param); NGP_CHECK_PTR(density_m); NGP_CHECK_PTR(density_v);
     NGP_CHECK_PTR(rgb_param); NGP_CHECK_PTR(rgb_m); NGP_CHECK_PTR(rgb_v);
     if (n_partials > 0) { NGP_CHECK_PTR(density_partials); NGP_CHECK_PTR(rgb_partials); }
     AdamHyper hp = adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale, found_inf);
+    hp.found_inf_dense = found_inf_grid;
     hp.zero_grad = zero_grid_grad != 0;
     const long long n4 = (n_grid + 3) / 4;
     const int dense_blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
@@ -442,6 +445,27 @@ int ngp_adam_step_field(float* grid_param, ngp_half* grid_param_h, ngp_half* gri
     hipLaunchKernelGGL(adam_field_kernel, dim3(a.blocks + b.blocks + dense_blocks), dim3(256), 0, ngp_stream(stream), grid_param,
                        (h1*)grid_param_h, (void*)grid_grad, grid_m, grid_v, n4, (long long)n_grid, a, b, n_partials, hp);
     return NGP_LAUNCH_RESULT();
+}
+
+int ngp_adam_step_field(float* grid_param, ngp_half* grid_param_h, ngp_half* grid_grad, float* grid_m, float* grid_v, int64_t n_grid,
+                        float* density_param, ngp_half* density_param_h, const float* density_partials, float* density_m,
+                        float* density_v, int n_density, float* rgb_param, ngp_half* rgb_param_h, const float* rgb_partials,
+                        float* rgb_m, float* rgb_v, int n_rgb, int n_partials, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, float grad_scale, int zero_grid_grad, const int32_t* found_inf, ngp_stream_t stream) {
+    return adam_step_field_impl(grid_param, grid_param_h, grid_grad, grid_m, grid_v, n_grid, density_param, density_param_h, density_partials,
+                                density_m, density_v, n_density, rgb_param, rgb_param_h, rgb_partials, rgb_m, rgb_v, n_rgb, n_partials, lr,
+                                beta1, beta2, eps, weight_decay, step, grad_scale, zero_grid_grad, found_inf, found_inf, stream);
+}
+
+int ngp_adam_step_field_shard(float* grid_param, ngp_half* grid_param_h, ngp_half* grid_grad, float* grid_m, float* grid_v, int64_t n_shard,
+                              float* density_param, ngp_half* density_param_h, const float* density_partials, float* density_m,
+                              float* density_v, int n_density, float* rgb_param, ngp_half* rgb_param_h, const float* rgb_partials,
+                              float* rgb_m, float* rgb_v, int n_rgb, int n_partials, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, int step, float grad_scale, const int32_t* found_inf_mlp,
+                              const int32_t* found_inf_shard, ngp_stream_t stream) {
+    return adam_step_field_impl(grid_param, grid_param_h, grid_grad, grid_m, grid_v, n_shard, density_param, density_param_h, density_partials,
+                                density_m, density_v, n_density, rgb_param, rgb_param_h, rgb_partials, rgb_m, rgb_v, n_rgb, n_partials, lr,
+                                beta1, beta2, eps, weight_decay, step, grad_scale, 0, found_inf_mlp, found_inf_shard, stream);
 }
 
 

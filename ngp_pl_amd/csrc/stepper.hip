@@ -175,6 +175,8 @@ int ngp_stepper_pending(const ngp_stepper* s, const float* rays_o, const float* 
     return (s && s->has_pending && s->pend_o == rays_o && s->pend_d == rays_d) ? 1 : 0;
 }
 
+int ngp_stepper_last_set(const ngp_stepper* s) { return s ? s->last_set : 0; }
+
 int ngp_stepper_march(ngp_stepper* s, const float* rays_o, const float* rays_d, ngp_stream_t main_stream, ngp_stream_t march_stream) {
     if (!s) return NGP_EINVAL;
     return do_march(s, rays_o, rays_d, ngp_stream(main_stream), ngp_stream(march_stream));

@@ -158,3 +158,140 @@ class GradientExchange:
             return cur
         bad = not (bool(torch.isfinite(g16.float()).all()) and bool(torch.isfinite(small).all()))
         return torch.ones(1, dtype=torch.int32) if bad else None
+
+
+class ShardedExchange(GradientExchange):
+    """The exchange that scales: reduce-scatter of the packed-f16 grid gradient -> Adam on THIS rank's 1/world shard of (f32 master,
+    m, v) -> all-gather of the updated f16 working table.  The same bytes cross each link as with the all-reduce (a ring all-reduce
+    IS a reduce-scatter + all-gather: 2 (world - 1) / world x 22.9 MB per rank and step), but the optimizer pass -- 52 us of an
+    HBM-bound stream over 11.4 M parameters on one GPU -- is divided by the world size, and what is gathered is the table the next
+    forward reads anyway.  The MLP blocks (10 240 parameters) keep the small asynchronous all-reduce and are updated by every rank.
+
+    Semantics preserved from DDP (train.py:268-272): mean gradient over ranks, identical parameters on every rank after every
+    step (tests/test_ddp_gloo.py: bit-identical f16 tables on all ranks, equal to the single-process update).  Two deliberate
+    differences: (1) a rank's f32 master / m / v are only current inside its own shard -- `gather_master()` makes the f32 master
+    whole again (checkpoints; `state_dict()` callers); (2) the non-finite check decides per shard (owner's reduced shard) and per MLP
+    block (the all-reduced sums every rank holds): every parameter is decided by one flag all its updaters agree on, so the ranks
+    stay in lock step without a flag collective; GradScaler would skip the whole step.
+
+    Shards: `shard_len` = ceil(n_grid / world / 8) * 8 f16 values (16-byte multiples); the gradient buffer and the f16 working
+    copy are re-seated on storages padded to world x shard_len (the padding stays zero).  Expected link traffic per step at
+    world = 8: 2 x 7/8 x 22.9 MB = 40 MB per rank over the 7 xGMI links (~5.7 MB per link and direction each way)."""
+
+    def __init__(self, model, dist, world, rank, group=None, adam=None):
+        super().__init__(model, dist, world, group=group, n_groups=1)
+        self.rank = rank
+        enc = model.xyz_encoder
+        self.n_grid = enc.n_grid
+        self.shard_len = -(-self.n_grid // (world * 8)) * 8
+        self.lo = min(rank * self.shard_len, self.n_grid)
+        self.hi = min(self.lo + self.shard_len, self.n_grid)
+        self._shard16 = None
+        self._flag_shard = None
+        self._adam = adam if adam is not None else self._adam_kernel        # tests on CPU tensors inject a restatement
+
+    # -- storage ---------------------------------------------------------------------------------
+    def _seat(self, dev):
+        """Gradient buffer and f16 working copy on storages padded to world x shard_len (once)."""
+        m = self.model
+        enc = m.xyz_encoder
+        padded = self.world * self.shard_len
+        if getattr(self, "_g_big", None) is None or self._g_big.device != dev:
+            self._g_big = torch.zeros(padded, dtype=torch.float16, device=dev)
+            m._g16 = self._g_big[:self.n_grid]
+        if getattr(self, "_h_big", None) is None or self._h_big.device != dev:
+            self._h_big = torch.zeros(enc.n_mlp + padded, dtype=torch.float16, device=dev)
+            if hasattr(enc, "_half"):                    # the model's f16 working copy moves onto the padded storage
+                self._h_big[:enc.n_mlp + self.n_grid].copy_(enc._half.get(enc.params))
+                enc._half.t = self._h_big[:enc.n_mlp + self.n_grid]
+                enc._half.mark_fresh(enc.params)
+        if self._shard16 is None or self._shard16.device != dev:
+            self._shard16 = torch.zeros(self.shard_len, dtype=torch.float16, device=dev)
+
+    def install(self, trainer):
+        super().install(trainer)
+        trainer.update_hook = self.update
+        trainer.bwd_groups, trainer.group_hook = 1, None
+        self._trainer = trainer
+        dev = self.model.xyz_encoder.params.device
+        self._seat(dev)
+        if getattr(trainer, "_stepper", None) is not None:
+            trainer._destroy_stepper()          # it holds the old gradient / working-copy pointers
+        return self
+
+    def uninstall(self, trainer):
+        super().uninstall(trainer)
+        trainer.update_hook = None
+        self.gather_master()
+
+    # -- hooks -----------------------------------------------------------------------------------
+    def reduce_grid(self):
+        """Reduce-scatter of the grid gradient; returns (flag_mlp, flag_shard) device flags (None on CPU tensors when finite)."""
+        nat = self.model._native
+        if nat is None:
+            return None
+        enc = self.model.xyz_encoder
+        if self._work is None:
+            self.reduce_mlp()
+        g16 = nat["grid16"]
+        self._seat(g16.device)
+        if g16.data_ptr() != self._g_big.data_ptr():
+            self._g_big[:self.n_grid].copy_(g16)          # a producer that did not write into the seated buffer (zero_native)
+        self.dist.reduce_scatter_tensor(self._shard16, self._g_big, group=self.group)
+        self._work.wait(); self._work = None
+        small = self._small
+        nat["density_partials"], nat["rgb_partials"], nat["n_partials"] = small[:enc.n_mlp], small[enc.n_mlp:], 1
+        nat["scale"] = nat["scale"] * self.world
+        if g16.is_cuda:
+            from ._lib import call, ptr, stream
+            if self._flag is None or self._flag.device != g16.device:
+                self._flag = torch.zeros(16, dtype=torch.int32, device=g16.device)      # {mlp, shard} x two alternating sets, 16 bytes apart
+                self._flag_step = 0
+            k = self._flag_step & 1
+            self._flag_step += 1
+            mlp_cur, mlp_nxt = self._flag[8 * k:], self._flag[8 * (1 - k):]
+            sh_cur, sh_nxt = self._flag[8 * k + 4:], self._flag[8 * (1 - k) + 4:]
+            call("ngp_found_inf2", ptr(small), 1, small.numel(), None, 0, 0, ptr(mlp_cur), ptr(mlp_nxt), stream())
+            call("ngp_found_inf2", ptr(self._shard16), 0, self._shard16.numel(), None, 0, 0, ptr(sh_cur), ptr(sh_nxt), stream())
+            return mlp_cur, sh_cur
+        bad_mlp = not bool(torch.isfinite(small).all())
+        bad_sh = not bool(torch.isfinite(self._shard16.float()).all())
+        one = torch.ones(1, dtype=torch.int32)
+        return (one if bad_mlp else None), (one if bad_sh else None)
+
+    def update(self, lr, step, grad_scale, found_inf, stream_handle=None):
+        """Adam on this rank's shard + the MLP blocks, then the all-gather of the f16 table (Trainer calls this instead of the
+        whole-table update).  grad_scale: the factor the reduced gradients carry."""
+        nat = self.model._native
+        flag_mlp, flag_shard = found_inf if found_inf is not None else (None, None)
+        self._adam(lr, step, grad_scale, nat, flag_mlp, flag_shard, stream_handle)
+        enc = self.model.xyz_encoder
+        table = self._h_big[enc.n_mlp:]
+        self.dist.all_gather_into_tensor(table, table[self.rank * self.shard_len:(self.rank + 1) * self.shard_len], group=self.group)
+        self.model._native = None
+
+    def _adam_kernel(self, lr, step, grad_scale, nat, flag_mlp, flag_shard, stream_handle):
+        from ._lib import call, ptr, stream
+        tr = self._trainer
+        m = self.model
+        enc, net = m.xyz_encoder, m.rgb_net
+        (em, ev), (rm, rv) = tr.opt.state["enc"], tr.opt.state["rgb"]
+        b1, b2 = tr.opt.betas
+        ne, lo, n = enc.n_mlp, self.lo, self.hi - self.lo
+        p_enc, p_half, p_m, p_v = enc.params.data_ptr(), self._h_big.data_ptr(), em.data_ptr(), ev.data_ptr()
+        sq = stream_handle if stream_handle is not None else stream()
+        call("ngp_adam_step_field_shard", p_enc + 4 * (ne + lo), p_half + 2 * (ne + lo), ptr(self._shard16), p_m + 4 * (ne + lo), p_v + 4 * (ne + lo), max(n, 1),
+             p_enc, p_half, ptr(nat["density_partials"]), p_m, p_v, ne,
+             net.params.data_ptr(), net._half.t.data_ptr(), ptr(nat["rgb_partials"]), rm.data_ptr(), rv.data_ptr(), net.params.numel(),
+             nat["n_partials"], lr, b1, b2, tr.opt.eps, tr.opt.weight_decay, step, grad_scale, ptr(flag_mlp), ptr(flag_shard), sq)
+        enc._half.mark_fresh(enc.params); net._half.mark_fresh(net.params)
+
+    def gather_master(self):
+        """All ranks' f32 master shards -> every rank's `xyz_encoder.params` (checkpointing / leaving the sharded mode)."""
+        enc = self.model.xyz_encoder
+        p = enc.params.data
+        padded = self.world * self.shard_len
+        buf = torch.zeros(padded, dtype=p.dtype, device=p.device)
+        buf[self.lo:self.hi] = p[enc.n_mlp + self.lo:enc.n_mlp + self.hi]
+        self.dist.all_gather_into_tensor(buf, buf[self.rank * self.shard_len:(self.rank + 1) * self.shard_len].clone(), group=self.group)
+        p[enc.n_mlp:] = buf[:self.n_grid]

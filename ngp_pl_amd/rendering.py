@@ -198,7 +198,7 @@ class _FusedTrainRender(torch.autograd.Function):
     the table gradient (tests/test_train_gpu.py::test_fused_render_node_matches_the_operator_chain)."""
 
     @staticmethod
-    def forward(ctx, enc_params, rgb_params, model, rays_o, rays_d, hits_t, esf, T_threshold, bg):
+    def forward(ctx, enc_params, rgb_params, model, rays_o, rays_d, hits_t, esf, T_threshold, bg, noise=None):
         from . import tcnn
         n, dev = rays_o.shape[0], rays_o.device
         enc, net = model.xyz_encoder, model.rgb_net
@@ -206,7 +206,10 @@ class _FusedTrainRender(torch.autograd.Function):
         i32 = dict(dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
             sq = stream()
-            noise = torch.rand(n, **f32)                              # custom_functions.py:83
+            if noise is None:
+                noise = torch.rand(n, **f32)                          # custom_functions.py:83
+            else:                                                     # caller-supplied jitter (tests: the same draw as another path)
+                noise = noise.to(**f32).contiguous()
             rays_a = torch.empty(n, 3, dtype=torch.int64, device=dev)
             scratch = torch.empty(max(n, 1) * MAX_SAMPLES, **f32)
             counter = _pinned_counter()
@@ -248,7 +251,7 @@ class _FusedTrainRender(torch.autograd.Function):
         rays_a, xyzs, dirs, deltas, ts, feats, h, sigmas, rgbs, ws, opacity, depth, rgb, ray_offs, n_active, bg = ctx.saved_tensors
         enc, net = model.xyz_encoder, model.rgb_net
         n, dev = rays_a.shape[0], rays_a.device
-        none5 = (None,) * 7
+        none5 = (None,) * 8
         if S == 0:
             if model.native_grads:
                 return (None, None) + none5
@@ -331,7 +334,7 @@ def _fused_train(model, rays_o, rays_d, kwargs):
     (no pose optimisation) and no per-ray tensor kwargs (exposure) have to be expanded per sample."""
     return getattr(model, "fused", False) and getattr(model, "fused_render", True) and model.rgb_act == "Sigmoid" and rays_o.is_cuda and \
         not (torch.is_grad_enabled() and (rays_o.requires_grad or rays_d.requires_grad)) and \
-        not any(isinstance(v, torch.Tensor) for v in kwargs.values())
+        not any(isinstance(v, torch.Tensor) for k, v in kwargs.items() if k != "noise")
 
 
 def _render_train(model, rays_o, rays_d, hits_t, **kwargs):
@@ -343,7 +346,7 @@ def _render_train(model, rays_o, rays_d, hits_t, **kwargs):
         (results["vr_samples"], results["opacity"], results["depth"], results["rgb"], results["ws"], results["rays_a"],
          results["deltas"], results["ts"], results["rm_samples"]) = _FusedTrainRender.apply(
             model.xyz_encoder.params, model.rgb_net.params, model, rays_o.float(), rays_d.float(), hits_t[:, 0].contiguous(), esf,
-            kwargs.get("T_threshold", 1e-4), bg)
+            kwargs.get("T_threshold", 1e-4), bg, kwargs.get("noise"))
         return results
     rays_a, xyzs, dirs, results["deltas"], results["ts"], results["rm_samples"] = RayMarcher.apply(
         rays_o, rays_d, hits_t[:, 0], model.density_bitfield, model.cascades, model.scale, esf,

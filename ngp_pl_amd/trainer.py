@@ -189,6 +189,7 @@ class Trainer:
         self.mlp_grad_hook = None  # called once the MLP gradients exist, before the hash-grid backward is enqueued
         self.group_hook = None     # called behind each launch group of the table backward: (group, n_groups, entry_begin, entry_end)
         self.bwd_groups = 1        # launch groups of the table backward when a group_hook is installed
+        self.update_hook = None    # replaces the whole-table Adam: (lr, step, grad_scale, found_inf, stream) -- ddp.ShardedExchange
         self._group_cache = {}
         self._main = None        # torch's current stream while a step is being enqueued (cached: the query costs ~8 us)
         self.events = None       # list of (stage, event) when stage timing is on (bench.py roofline)
@@ -254,6 +255,13 @@ class Trainer:
                 bc = self._buf.c_struct(self.lambda_distortion > 0)
                 call("ngp_stepper_set_buffers", self._stepper, C.byref(bc))
         return self._buf
+
+    def last_march_noise(self):
+        """The jitter values (R) the march of the last stepped batch used (a view of the step buffers; tests hand it to another path)."""
+        B = self._buf
+        if self.native_step and self._stepper is not None:
+            return B.noise[call("ngp_stepper_last_set", self._stepper)]
+        return B.noise[self._last_set]
 
     @property
     def has_pending(self):
@@ -354,7 +362,10 @@ class Trainer:
             if prefetch:
                 self._pending_key, self._pending_keep = (no_p, nd_p), next_batch
             S, n_part = S_c.value, np_c.value
-            hooks = self.grad_hook is not None or self.mlp_grad_hook is not None
+            # hooks (multi-GPU exchange), an update hook, or an optimizer whose step() was replaced (tests capture the gradients
+            # there): the tail runs through Python; otherwise table backward + Adam are two more library calls
+            custom_opt = "step" in vars(self.opt)
+            hooks = self.grad_hook is not None or self.mlp_grad_hook is not None or custom_opt
             if S > 0:
                 epoch = self.global_step // self.steps_per_epoch
                 lr = self.opt.param_groups[0]["lr"] = cosine_lr(self.base_lr, epoch, self.num_epochs)
@@ -379,12 +390,18 @@ class Trainer:
                             self.group_hook(g, ng, *self._group_entries(enc.meta, S, ng, g))
                     found_inf = self.grad_hook() if self.grad_hook is not None else None
                     nat = m._native
-                    self.opt.t += 1
-                    call("ngp_stepper_update", h, lr, self.opt.t, nat["scale"] * self.grad_scale, ptr(nat["density_partials"]),
-                         ptr(nat["rgb_partials"]), nat["n_partials"], ptr(found_inf), mq)
-                    enc._half.mark_fresh(enc.params); net._half.mark_fresh(net.params)
-                    m._native = None
-            elif hooks:
+                    if self.update_hook is not None:
+                        self.opt.t += 1
+                        self.update_hook(lr, self.opt.t, nat["scale"] * self.grad_scale, found_inf, mq)
+                    elif custom_opt:
+                        self.opt.step(grad_scale=self.grad_scale, found_inf=found_inf, stream_handle=mq)
+                    else:
+                        self.opt.t += 1
+                        call("ngp_stepper_update", h, lr, self.opt.t, nat["scale"] * self.grad_scale, ptr(nat["density_partials"]),
+                             ptr(nat["rgb_partials"]), nat["n_partials"], ptr(found_inf), mq)
+                        enc._half.mark_fresh(enc.params); net._half.mark_fresh(net.params)
+                        m._native = None
+            elif self.grad_hook is not None or self.mlp_grad_hook is not None:
                 # no samples on THIS rank: the other ranks still expect it in the gradient collectives
                 self._exchange_and_update(self.zero_native(dev), None, mq)
             self.global_step += 1
@@ -470,7 +487,7 @@ class Trainer:
             self._pending = None
             B = self.buffers(n)
             P = B.p
-            k = rec["set"]
+            k = self._last_set = rec["set"]
             # march of the next batch: concurrent with this step unless the occupancy grid is due
             # for an update first (that needs this step's optimizer result).  Enqueued BEFORE the
             # host blocks on this batch's march: the marching stream then runs the marches back to
@@ -621,7 +638,11 @@ class Trainer:
         found_inf = None
         if self.grad_hook is not None:
             found_inf = self.grad_hook()
-        self.opt.step(grad_scale=self.grad_scale, found_inf=found_inf, stream_handle=mq)
+        if getattr(self, "update_hook", None) is not None:
+            self.opt.t += 1
+            self.update_hook(self.opt.param_groups[0]["lr"], self.opt.t, self.model._native["scale"] * self.grad_scale, found_inf, mq)
+        else:
+            self.opt.step(grad_scale=self.grad_scale, found_inf=found_inf, stream_handle=mq)
 
     def metrics(self):
         """Host-side readout of the last step (syncs): loss, psnr, rm_s, vr_s as train.py:177-183 logs them."""
@@ -634,13 +655,15 @@ class Trainer:
                     vr_s=float(self.last["total"].sum().item()) / n)
 
     # -- the reference-shaped path ---------------------------------------------------------------
-    def step_autograd(self, rays_o, rays_d, rgb_gt):
+    def step_autograd(self, rays_o, rays_d, rgb_gt, noise=None):
         """render() -> NeRFLoss -> backward -> FusedAdam, as train.py:159-185 (no GradScaler: the
         tcnn modules carry their own loss scale)."""
         self._maybe_update_grid()
         kwargs = {"test_time": False}
         if self.exp_step_factor:
             kwargs["exp_step_factor"] = self.exp_step_factor
+        if noise is not None:
+            kwargs["noise"] = noise          # (R) jitter of the march instead of a fresh torch.rand draw
         results = render(self.model, rays_o, rays_d, **kwargs)
         loss_d = self.loss_fn(results, {"rgb": rgb_gt})
         loss = sum(lo.mean() for lo in loss_d.values())

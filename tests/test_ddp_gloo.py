@@ -233,3 +233,141 @@ def test_bench_launcher_spawns_n_ranks():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["dry_run"] is True
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# ShardedExchange: reduce-scatter -> Adam on the rank's shard -> all-gather of the f16 table
+# ---------------------------------------------------------------------------------------------------------------------------
+N_ENTRIES_SH = 4093                 # table entries (x 2 features): NOT divisible by world x 8, so the last shard is short
+
+
+def _adam_reference(p, m, v, g, lr, b1, b2, eps, step):
+    """apex FusedAdam / optim.hip adam_dense, in the kernels' operation order (f32)."""
+    bc1, bc2 = 1.0 - b1 ** step, 1.0 - b2 ** step
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).add_(g * g, alpha=1 - b2)
+    p.sub_(lr * ((m / bc1) / ((v / bc2).sqrt() + eps)))
+
+
+class _Opt:
+    def __init__(self):
+        self.param_groups, self.t, self.betas, self.eps, self.weight_decay = [{"lr": 0.0}], 0, (0.9, 0.999), 1e-15, 0.0
+
+
+def _sharded_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from ngp_pl_amd.ddp import ShardedExchange
+    from ngp_pl_amd.trainer import Trainer
+    n_grid, n_d, n_r = 2 * N_ENTRIES_SH, 3072, 7168
+    g0 = torch.Generator().manual_seed(1)
+    master0 = (torch.rand(n_d + n_grid, generator=g0) - 0.5) * 0.2           # identical on every rank (DDP's broadcast)
+    rgb0 = (torch.rand(n_r, generator=g0) - 0.5) * 0.2
+
+    class Enc:
+        pass
+    model = _Model(n_grid)
+    model.xyz_encoder.params = master0.clone()
+    model.rgb_net.params = rgb0.clone()
+    state = {"enc": (torch.zeros(n_d + n_grid), torch.zeros(n_d + n_grid)), "rgb": (torch.zeros(n_r), torch.zeros(n_r))}
+    rgb_half = torch.zeros(n_r, dtype=torch.float16)
+
+    tr = Trainer.__new__(Trainer)
+    tr.model, tr.opt = model, _Opt()
+    tr.global_step, tr.steps_per_epoch, tr.base_lr, tr.num_epochs = 0, 1000, 1e-2, 30
+    tr.grad_scale, tr.loss_scale = 1.0, 128.0
+    tr.grad_hook = tr.mlp_grad_hook = tr.group_hook = tr.update_hook = None
+    tr.bwd_groups = 1
+
+    def adam_cpu(lr, step, grad_scale, nat, flag_mlp, flag_shard, stream_handle, ex=None):
+        ex = exchange
+        lo, hi = ex.lo, ex.hi
+        em, ev = state["enc"]
+        p = model.xyz_encoder.params
+        if flag_shard is None and hi > lo:
+            g = ex._shard16[:hi - lo].float() / grad_scale
+            _adam_reference(p[n_d + lo:n_d + hi], em[n_d + lo:n_d + hi], ev[n_d + lo:n_d + hi], g, lr, 0.9, 0.999, 1e-15, step)
+            ex._h_big[n_d + lo:n_d + hi] = p[n_d + lo:n_d + hi].half()
+        if flag_mlp is None:
+            _adam_reference(p[:n_d], em[:n_d], ev[:n_d], nat["density_partials"].view(nat["n_partials"], -1).sum(0) / grad_scale, lr, 0.9, 0.999, 1e-15, step)
+            ex._h_big[:n_d] = p[:n_d].half()
+            rm, rv = state["rgb"]
+            _adam_reference(model.rgb_net.params, rm, rv, nat["rgb_partials"].view(nat["n_partials"], -1).sum(0) / grad_scale, lr, 0.9, 0.999, 1e-15, step)
+            rgb_half.copy_(model.rgb_net.params.half())
+
+    exchange = ShardedExchange(model, dist, world, rank, adam=adam_cpu).install(tr)
+    ok = tr.loss_scale == 128.0 / world and tr.update_hook is not None and exchange.shard_len % 8 == 0
+    ok &= exchange.shard_len * world >= n_grid > exchange.shard_len * (world - 1)
+    exchange._h_big[:n_d + n_grid] = master0.half()
+    # three steps of per-rank gradients; values are multiples of 1/64 below 4 in magnitude, so that f16 sums over <= 4 ranks are exact
+    # whatever the order of the ring's adds, and the expected update can be formed from the f32 sum
+    ref_p, ref_rgb = master0.clone(), rgb0.clone()
+    ref_state = {"enc": (torch.zeros(n_d + n_grid), torch.zeros(n_d + n_grid)), "rgb": (torch.zeros(n_r), torch.zeros(n_r))}
+    for step in range(1, 4):
+        grads = []
+        for r in range(world):
+            gr = torch.Generator().manual_seed(1000 * step + r)
+            grid = torch.randint(-255, 256, (n_grid,), generator=gr).float() / 64
+            grid[torch.rand(n_grid, generator=gr) < 0.5] = 0                 # untouched entries, as in a real backward
+            dens = torch.randn(n_d, generator=gr) * 1e-2
+            rgbw = torch.randn(n_r, generator=gr) * 1e-2
+            grads.append((grid, dens, rgbw))
+        mine = grads[rank]
+        ls = tr.loss_scale                                                   # 128 / world
+        # the table backward writes into the seated (padded) gradient buffer; values are stored scaled: mine * ls / ls ... use ls-free units
+        native = dict(grid16=model._grid_grad16(torch.device("cpu")), density_partials=(mine[1] * ls).clone(), rgb_partials=(mine[2] * ls).clone(),
+                      n_partials=1, scale=ls)
+
+        def table_backward(mine=mine):
+            model._grid_grad16(torch.device("cpu")).copy_(mine[0].half())    # (already "scaled": the reference below divides the same way)
+        tr._exchange_and_update(native, table_backward, None)
+        # single-process reference: grid gradient = sum over ranks / (ls * world); MLP = sum of (g * ls) / (ls * world)
+        total_scale = ls * world
+        gsum = sum(g[0] for g in grads).half().float() / total_scale
+        _adam_reference(ref_p[n_d:], ref_state["enc"][0][n_d:], ref_state["enc"][1][n_d:], gsum, 1e-2, 0.9, 0.999, 1e-15, step)
+        dsum = sum((g[1] * ls) for g in grads) / total_scale
+        rsum = sum((g[2] * ls) for g in grads) / total_scale
+        _adam_reference(ref_p[:n_d], ref_state["enc"][0][:n_d], ref_state["enc"][1][:n_d], dsum, 1e-2, 0.9, 0.999, 1e-15, step)
+        _adam_reference(ref_rgb, ref_state["rgb"][0], ref_state["rgb"][1], rsum, 1e-2, 0.9, 0.999, 1e-15, step)
+    table16 = exchange._h_big[:n_d + n_grid].clone()
+    # (1) every rank holds the same f16 table ...
+    gathered = [torch.zeros_like(table16) for _ in range(world)]
+    dist.all_gather(gathered, table16)
+    ok &= all(torch.equal(gathered[0], t) for t in gathered)
+    # (2) ... equal to the single-process update (grid part bit for bit: exact f16 sums; MLP part: the all-reduce sums f32 in ring order)
+    ok &= torch.equal(table16[n_d:], ref_p[n_d:].half())
+    ok &= float((table16[:n_d].float() - ref_p[:n_d].half().float()).abs().max()) <= 2e-3 * float(ref_p[:n_d].abs().max())
+    # (3) the f32 master is whole again after gather_master(), on every rank
+    exchange.gather_master()
+    ok &= torch.equal(model.xyz_encoder.params[n_d:], ref_p[n_d:])
+    # (4) the padding of the gathered table stayed zero, the optimizer step count advanced once per step
+    ok &= bool((exchange._h_big[n_d + n_grid:] == 0).all()) and tr.opt.t == 3
+    # (5) a non-finite shard skips only that shard, on every rank alike: rank 0's first entries get an overflowing sum
+    before = exchange._h_big[:n_d + n_grid].clone()
+    big = torch.zeros(n_grid); big[:8] = 40000.0
+    native = dict(grid16=model._grid_grad16(torch.device("cpu")), density_partials=torch.zeros(n_d), rgb_partials=torch.zeros(n_r), n_partials=1, scale=tr.loss_scale)
+    tr._exchange_and_update(native, lambda: model._grid_grad16(torch.device("cpu")).copy_(big.half()), None)
+    after = exchange._h_big[:n_d + n_grid]
+    sl = exchange.shard_len
+    ok &= torch.equal(after[n_d:n_d + sl], before[n_d:n_d + sl]) if world > 1 else True        # shard 0 skipped (inf in its sum) ...
+    gathered = [torch.zeros_like(after) for _ in range(world)]
+    dist.all_gather(gathered, after.clone())
+    ok &= all(torch.equal(gathered[0], t) for t in gathered)                                   # ... and the ranks still agree
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_exchange_matches_the_single_process_update(world):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+    assert res == [(r, True) for r in range(world)], res

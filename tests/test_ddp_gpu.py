@@ -111,3 +111,83 @@ def test_two_ranks_train_in_lock_step_on_one_gpu(n_groups):
     for p in procs:
         p.join(120)
     assert [(r, ok) for r, ok, _ in res] == [(0, True), (1, True)], res
+
+
+def _sharded_worker(rank, world, port, q):
+    """Trains 6 steps twice from the same initialisation on the same per-rank batches: with the all-reduce exchange and with the
+    sharded one (reduce-scatter -> shard Adam -> all-gather).  Both must leave every rank with the same f16 working table, and
+    the f32 master (after gather_master) must agree between the two exchanges: the grid gradient sums are the same f16 ring sums
+    of exact per-rank addends whichever collective forms them (2 ranks: one add), the MLP blocks see the same all-reduce."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import numpy as np
+        from ngp_pl_amd import synthetic as syn
+        from ngp_pl_amd.ddp import GradientExchange, ShardedExchange
+        from ngp_pl_amd.networks import NGP
+        from ngp_pl_amd.trainer import Trainer
+
+        def batch(n, seed):
+            g = np.random.RandomState(seed)
+            W = 200
+            dirs = syn.get_ray_directions(W, W, syn.intrinsics(W))
+            poses = syn.hemisphere_poses(16, seed=1)
+            ro, rd = syn.get_rays(dirs[torch.from_numpy(g.randint(0, W * W, n))], poses[torch.from_numpy(g.randint(0, 16, n))])
+            ro, rd = ro.cuda(), rd.cuda()
+            gt, _ = syn.render_ground_truth(ro, rd, n_steps=96)
+            return ro, rd, gt.contiguous()
+        batches = [batch(1024, seed=2000 + 10 * s + rank) for s in range(6)]
+        empty = (batches[3][0] + 10.0, batches[3][1].abs() + 0.1, batches[3][2])      # rank 1's 4th batch misses the box
+        results = {}
+        for kind in ("allreduce", "sharded"):
+            torch.manual_seed(7)
+            m = NGP(scale=0.5).cuda()
+            m.register_training_buffers()
+            tr = Trainer(m)
+            ex = (GradientExchange(m, dist, world) if kind == "allreduce" else ShardedExchange(m, dist, world, rank)).install(tr)
+            ex.broadcast_parameters()
+            for s in range(6):
+                b = empty if (s == 3 and rank == 1) else batches[s]
+                nb = batches[s + 1] if s + 1 < 6 and not (s + 1 == 3 and rank == 1) else None
+                tr.step(*b, next_batch=None if nb is None else (nb[0], nb[1]))
+            torch.cuda.synchronize()
+            enc = m.xyz_encoder
+            half = enc._half.get(enc.params).clone()
+            if kind == "sharded":
+                assert tr.update_hook is not None and ex.shard_len * world >= enc.n_grid
+                ex.gather_master()
+            results[kind] = (half.cpu(), enc.params.detach().clone().cpu(), m.rgb_net.params.detach().clone().cpu())
+            ex.uninstall(tr)
+            del tr, m
+        ok, notes = True, []
+        for kind in results:
+            half = results[kind][0]
+            alls = [torch.zeros_like(half) for _ in range(world)]
+            dist.all_gather(alls, half)
+            same = all(torch.equal(alls[0], a) for a in alls)
+            ok &= same; notes.append("%s: ranks' f16 tables identical: %s" % (kind, same))
+        a, b = results["allreduce"], results["sharded"]
+        for name, x, y in (("f16 table", a[0], b[0]), ("f32 master", a[1], b[1]), ("rgb net", a[2], b[2])):
+            same = torch.equal(x, y)
+            ok &= same; notes.append("%s equal between the exchanges: %s (max diff %.3g)" % (name, same, float((x.float() - y.float()).abs().max())))
+        q.put((rank, bool(ok), notes))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, False, [traceback.format_exc()]))
+        raise
+
+
+def test_sharded_exchange_trains_like_the_allreduce_exchange_on_one_gpu():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(120)
+    assert [(r, ok) for r, ok, _ in res] == [(0, True), (1, True)], res

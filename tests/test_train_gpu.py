@@ -115,11 +115,12 @@ def test_fused_step_equals_autograd_step(lambda_distortion, n_rays):
             captured["rgb"] = nat["rgb_partials"].view(nat["n_partials"], net.params.numel()).sum(0) / nat["scale"]
             m._native = None
         tr.opt.step = capture
-        torch.manual_seed(5)            # same jitter noise and grid-update noise in both runs
+        torch.manual_seed(5)            # same grid-update noise in both runs
         if mode == "native":
             tr.step(ro, rd, gt)
+            noise = tr.last_march_noise().clone()           # ... and the same jitter: the autograd run marches with the native run's draw
         else:
-            tr.step_autograd(ro, rd, gt)
+            tr.step_autograd(ro, rd, gt, noise=noise)
         grads.append(captured)
     a, b = grads
     for k, tol in (("rgb", 2e-3), ("density", 2e-3), ("grid", 1e-2)):
@@ -800,7 +801,9 @@ def test_native_stepper_stage_times_and_timeout_code():
     a, b = batch(2048, seed=950), batch(2048, seed=951)
     tr.step(*a, next_batch=(b[0], b[1]))
     tr.events = []
-    tr.step(*b, next_batch=(a[0], a[1]))
+    tr.step(*b, next_batch=(a[0], a[1]))                  # (its own march was enqueued before timing was switched on)
+    assert set(dict(tr.stage_times_ms())) == set(Trainer.STAGES[:-1])
+    tr.step(*a, next_batch=(b[0], b[1]))
     st = dict(tr.stage_times_ms())
     assert set(st) == set(Trainer.STAGES), st
     assert all(0 < v < 50 for v in st.values()), st
