@@ -161,6 +161,13 @@ class Loop:
         # three batch buffers in rotation (the batch being stepped, the one being marched, the one being drawn): nothing is
         # allocated per draw and no allocator bookkeeping across the two streams is needed
         self.ring = [tuple(torch.empty(self.rays, 3, device=dev) for _ in range(3)) for _ in range(3)]
+        # The ring is allocated by torch's caching allocator in the MAIN stream's context and written by the sampler on the
+        # MARCHING stream: the allocator may hand out a block that a main-stream kernel still queued (a zero-fill of a temporary of
+        # the dataset / occupancy set-up above, already freed on the host) is going to write.  Without this hand-over the first batch
+        # of a loop built behind bench.py's api leg came back (partly) zeroed -- rays with origin = direction = 0, whose march never
+        # ended in round 2's kernels (t_target = inf): the 1800 s stall of BENCH_r02 (profiles/r03_round2_stall_root_cause.txt).
+        if self.trainer.side is not None:
+            self.trainer.side.wait_stream(torch.cuda.current_stream())
         self.cur = self.draw()
 
     def draw(self, on_side=True):

@@ -227,11 +227,6 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const
 }
 
 // ---- pass 2: slice owners -------------------------------------------------------------------
-__device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-    return v;
-}
 
 __device__ __forceinline__ void lds_add_fixed(long long* acc, float v) {
     const int q = __float2int_rn(v * FIX_SCALE);                   // saturates; |w*g| < 128 by a wide margin
@@ -306,16 +301,11 @@ __device__ __forceinline__ void apply_pairs(long long* lds, uint32_t lo, uint32_
     }
 }
 
-// Hashed levels: a wave takes B chunk segments per trip (typically ~57 entries each): all of a trip's loads in flight together.
-// Which lane takes which entry decides how often the lanes of ONE ds_add_u64 hit the same accumulator: a segment lists its
-// chunk's samples in (roughly) sample order, and consecutive samples of a ray sit in the same cell for 7 .. 1 steps on the
-// hashed levels 6 .. 15, so with lane = position in the segment a wave instruction carries runs of up to 7 equal addresses
-// (measured: 8 lanes per address cost 64 cycles instead of 11.5).  NGP_APPLY_TRANSPOSE (default): lane L works on segment
-// L & 7 of the trip and, in its i-th instruction, on that segment's entry 8 (L >> 3) + i -- the lanes of one instruction are
-// 8 entries apart within a segment and otherwise in different chunks.
-#ifndef NGP_APPLY_TRANSPOSE
-#define NGP_APPLY_TRANSPOSE 1
-#endif
+// Hashed levels: a wave takes B chunk segments per trip (typically ~57 entries each), lane = entry:
+// coalesced entry / gradient / position streams, all of a trip's loads in flight together.
+// (Measured and not kept, profiles/r03_table_backward_experiments.txt: lanes of one instruction taken 8 entries apart and from 8
+// different chunks, so that runs of consecutive samples in one cell never meet in one ds_add_u64 -- hashed tasks 16.4 -> 23.3 us:
+// same-address adds are not what they wait for, the strided entry loads cost more than the conflicts.)
 template <int B>
 __device__ __forceinline__ void apply_segments_hashed(long long* lds, uint32_t lo, uint32_t len, uint32_t res, uint32_t size, float scale,
                                                       const float* __restrict__ x, const Box& box, const half2_t* __restrict__ g_level,
@@ -323,28 +313,6 @@ __device__ __forceinline__ void apply_segments_hashed(long long* lds, uint32_t l
                                                       const int* s_dir, int n_chunks, int part, int K) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NW = APPLY_THREADS / 64;
-    if (NGP_APPLY_TRANSPOSE) {
-        static_assert(!NGP_APPLY_TRANSPOSE || B == 8, "the transposed assignment works on 8 segments per trip");
-        const int seg = lane & 7, row0 = (lane >> 3) << 3;
-        for (int c0 = part + K * wave; c0 < n_chunks; c0 += K * NW * 8) {
-            const int c = c0 + seg * K * NW;                           // this lane's segment of the trip
-            const int d = (c < n_chunks) ? s_dir[c] : 0;
-            const size_t start = (size_t)c * CHUNK_SLOTS + (d >> 16);
-            const int cnt = d & 0xffff;
-            const int maxcnt = __builtin_amdgcn_readfirstlane(wave_max_i32(cnt));
-            for (int off = 0; off < maxcnt; off += 64) {               // one pass unless a segment has more than 64 entries
-                int ee[8]; bool ok[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int pos = off + row0 + i;
-                    ok[i] = pos < cnt;
-                    ee[i] = ok[i] ? pool_level[start + pos] : 0;
-                }
-                apply_pairs<8>(lds, lo, len, size, scale, x, box, g_level, active, ee, ok);
-            }
-        }
-        return;
-    }
     for (int c0 = part + K * wave; c0 < n_chunks; c0 += K * NW * B) {
         int start[B], cnt[B], maxcnt = 0;
 #pragma unroll
@@ -556,7 +524,7 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
         const int32_t* __restrict__ pool_level = ws.pool + plan.pool_off[level];
         if (level_is_hashed(res, size)) {
             if (NGP_BIN_PAYLOAD) apply_segments_payload<NGP_APPLY_PB>(lds, len, pool_level, s_dir, n_chunks, part, K);
-            else apply_segments_hashed<NGP_APPLY_TRANSPOSE ? 8 : NGP_APPLY_B>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
+            else apply_segments_hashed<NGP_APPLY_B>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
         }
         else if (NGP_DENSE_RUNS) apply_segments_dense_runs<NGP_DENSE_B>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
         else apply_segments_dense<4>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);

@@ -810,6 +810,7 @@ def test_native_stepper_stage_times_and_timeout_code():
     tr.events = None
     import ctypes as C
     s_c, n_c = C.c_int32(), C.c_int32()
+    c = batch(2048, seed=952)                                   # the pending march is batch b's: c has not been marched
     with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
-        _lib.call("ngp_stepper_front", tr._stepper, b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr(), None, None, 128.0, 1.0,
+        _lib.call("ngp_stepper_front", tr._stepper, c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), None, None, 128.0, 1.0,
                   torch.cuda.current_stream().cuda_stream, tr.side.cuda_stream, C.byref(s_c), C.byref(n_c))
