@@ -154,8 +154,14 @@ class Loop:
         self.trainer = Trainer(self.model, lr=lr, num_epochs=30 if workload != "lego16k" else 20, erode=erode)
         self.exchange = None
         if dist is not None:       # also with a 1-rank process group (torchrun --nproc-per-node 1): exercises the collective path
-            from ngp_pl_amd.ddp import GradientExchange
-            self.exchange = GradientExchange(self.model, dist, world).install(self.trainer)
+            # NGP_DDP_EXCHANGE: "sharded" (default: reduce-scatter -> Adam on the rank's shard -> all-gather of the f16 table) or
+            # "allreduce" (one all-reduce of the f16 gradient, whole-table Adam on every rank)
+            from ngp_pl_amd.ddp import GradientExchange, ShardedExchange
+            self.exchange_kind = os.environ.get("NGP_DDP_EXCHANGE", "sharded")
+            if self.exchange_kind == "sharded":
+                self.exchange = ShardedExchange(self.model, dist, world, rank).install(self.trainer)
+            else:
+                self.exchange = GradientExchange(self.model, dist, world).install(self.trainer)
             self.exchange.broadcast_parameters()
         self.draws = 0
         # three batch buffers in rotation (the batch being stepped, the one being marched, the one being drawn): nothing is
@@ -246,7 +252,13 @@ class Loop:
             wins.append(dt); ev.append(dte)
         total = sum(wins)
         met = tr.metrics()
-        return {"ms_per_step": total / (n_win * steps) * 1e3, "rays_per_s": self.rays * self.world * n_win * steps / total,
+        extra = {}
+        if self.exchange is not None:          # the exchange stage on its own: 20 more steps with device events around it (all ranks alike)
+            self.exchange.timing = True
+            self.steps(20)
+            self.exchange.timing = False
+            extra = {"exchange_ms": self.exchange.exchange_ms(), "exchange": self.exchange_kind}
+        return {**extra, "ms_per_step": total / (n_win * steps) * 1e3, "rays_per_s": self.rays * self.world * n_win * steps / total,
                 "timed_windows": n_win, "timed_steps_total": n_win * steps, "window_ms_per_step_min_max": [min(wins) / steps * 1e3, max(wins) / steps * 1e3],
                 "ms_per_step_hip_events": sum(ev) / (n_win * steps) * 1e3, "cold_start": cold, "metrics": met,
                 "global_step_at_end": tr.global_step}
@@ -639,7 +651,7 @@ def main():
         "ms_per_step_hip_events": r["ms_per_step_hip_events"], "cold_start": r["cold_start"],
     }
     if "exchange_ms" in r:
-        out["exchange_ms"] = r["exchange_ms"]
+        out["exchange_ms"], out["exchange"] = r["exchange_ms"], r["exchange"]
     from ngp_pl_amd import _lib as native
     out["march_guards"] = native.march_guard_counts()
     if out["march_guards"][0]:

@@ -39,7 +39,10 @@ constexpr uint32_t SLICE2 = NGP_SLICE2;      // entries per task: 2 x int64 each
 constexpr int MAX_SLICES = ((1 << 19) + SLICE2 - 1) / SLICE2 + 4;   // 2^19 / SLICE2 slices per hashed level (76 at 6912)
 constexpr float FIX_SCALE = 16777216.0f;     // 2^24 units per 1.0 (f16 subnormal spacing is 2^-24)
 constexpr int BIN_THREADS = 512;             // binning workgroup: 4 of them are resident per CU (the pass is latency-bound)
-constexpr int BIN_SPT = 2;                   // samples per thread
+#ifndef NGP_BIN_SPT
+#define NGP_BIN_SPT 2
+#endif
+constexpr int BIN_SPT = NGP_BIN_SPT;         // samples per thread
 constexpr int CHUNK = BIN_THREADS * BIN_SPT; // samples per binning workgroup ("chunk")
 constexpr int CHUNK_SLOTS = CHUNK * 8;       // list entries a chunk can produce for one level (<= 8 slices per sample)
 constexpr int MAX_CHUNKS = 1024;             // the slice owners scan the chunk directory in one pass

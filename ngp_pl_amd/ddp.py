@@ -49,6 +49,8 @@ class GradientExchange:
         self._work = None
         self._issued = 0           # ranges of this step already in flight
         self._works = []
+        self.timing = False        # record device events around the exchange (bench.py's exchange_ms)
+        self._t_events = []
 
     @staticmethod
     def _plan_ranges(model, n_groups):
@@ -87,6 +89,27 @@ class GradientExchange:
                 self.dist.broadcast(p.data, 0, group=self.group)
         for mod in (self.model.xyz_encoder, self.model.rgb_net):
             mod._half.invalidate()              # the f16 working copies follow the broadcast
+
+    # -- timing --------------------------------------------------------------------------------
+    def _t_begin(self, tensor):
+        if self.timing and tensor.is_cuda:
+            e = torch.cuda.Event(enable_timing=True); e.record()
+            self._t_open = e
+
+    def _t_end(self, tensor):
+        if self.timing and tensor.is_cuda and getattr(self, "_t_open", None) is not None:
+            e = torch.cuda.Event(enable_timing=True); e.record()
+            self._t_events.append((self._t_open, e)); self._t_open = None
+
+    def exchange_ms(self):
+        """Mean device time per step between the start of the grid-gradient collective and the point where the optimizer may run
+        (all-reduce exchange) or has run and the table is gathered (sharded exchange), over the steps recorded while `timing`."""
+        if not self._t_events:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._t_events]
+        self._t_events = []
+        return sum(ms) / len(ms)
 
     # -- hooks ---------------------------------------------------------------------------------
     def reduce_mlp(self):
@@ -131,6 +154,7 @@ class GradientExchange:
         if self._work is None:
             self.reduce_mlp()
         g16 = nat["grid16"]
+        self._t_begin(g16)
         if self.ranges:
             if self.ranges[0][0] != 0 or self.ranges[-1][1] * 2 != g16.numel():
                 raise RuntimeError("exchange plan %r does not cover the gradient table (%d entries)" % (self.ranges, g16.numel() // 2))
@@ -155,6 +179,7 @@ class GradientExchange:
             cur, nxt = self._flag[4 * (self._flag_step & 1):], self._flag[4 * ((self._flag_step + 1) & 1):]
             self._flag_step += 1
             call("ngp_found_inf2", ptr(g16), 0, g16.numel(), ptr(small), 1, small.numel(), ptr(cur), ptr(nxt), stream())
+            self._t_end(g16)
             return cur
         bad = not (bool(torch.isfinite(g16.float()).all()) and bool(torch.isfinite(small).all()))
         return torch.ones(1, dtype=torch.int32) if bad else None
@@ -235,6 +260,7 @@ class ShardedExchange(GradientExchange):
             self.reduce_mlp()
         g16 = nat["grid16"]
         self._seat(g16.device)
+        self._t_begin(g16)
         if g16.data_ptr() != self._g_big.data_ptr():
             self._g_big[:self.n_grid].copy_(g16)          # a producer that did not write into the seated buffer (zero_native)
         self.dist.reduce_scatter_tensor(self._shard16, self._g_big, group=self.group)
@@ -268,6 +294,7 @@ class ShardedExchange(GradientExchange):
         enc = self.model.xyz_encoder
         table = self._h_big[enc.n_mlp:]
         self.dist.all_gather_into_tensor(table, table[self.rank * self.shard_len:(self.rank + 1) * self.shard_len], group=self.group)
+        self._t_end(table)
         self.model._native = None
 
     def _adam_kernel(self, lr, step, grad_scale, nat, flag_mlp, flag_shard, stream_handle):

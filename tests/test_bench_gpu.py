@@ -55,3 +55,24 @@ def test_driver_command_verbatim():
         assert "error" not in d[leg], (leg, d[leg])
     assert wall < 200, wall
     assert "[bench" in r.stderr and "headline complete" in r.stderr              # leg-by-leg progress is on by default
+
+
+@pytest.mark.parametrize("exchange", ["sharded", "allreduce"])
+def test_bench_under_a_one_rank_rccl_group(exchange):
+    """The multi-GPU path of bench.py on a real RCCL process group of ONE rank (what `torchrun --nproc-per-node 1 bench.py` runs):
+    process group, parameter broadcast, the gradient exchange installed on the trainer (sharded: reduce-scatter -> shard Adam ->
+    all-gather; or the all-reduce), the timed windows, the exchange stage timed on its own, teardown."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               NGP_DDP_EXCHANGE=exchange, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3", "--setup-steps", "48",
+                        "--images", "8", "--res", "200", "--no-cpu-baseline", "--no-render", "--no-api"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert "error" not in d, d.get("error")
+    assert d["n_gpus"] == 1 and d["exchange"] == exchange and d["exchange_ms"] > 0 and d["value"] > 1e6
+    assert d["config"]["train_psnr"] > 10 and d["march_guards"] == [0, 0, 0, 0]
