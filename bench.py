@@ -339,16 +339,19 @@ def pmc_traffic(stage, S, A):
 
 def api_path_rate(loop, n_steps=40):
     """The same step driven through the reference-shaped surface: render() -> NeRFLoss -> torch autograd -> FusedAdam
-    (Trainer.step_autograd), i.e. what train.py would exercise.  Secondary number, not `value`."""
+    (Trainer.step_autograd), i.e. what train.py would exercise; the loop hands render() its next batch (`next_rays`), as a
+    dataloader that is one batch ahead can.  Secondary number, not `value`."""
     tr = loop.trainer
+    cur = loop.draw(on_side=False)
     for _ in range(8):
-        b = loop.draw(on_side=False); tr.step_autograd(b[0], b[1], b[2])
+        nxt = loop.draw(on_side=False); tr.step_autograd(cur[0], cur[1], cur[2], next_batch=nxt); cur = nxt
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(n_steps):
-        b = loop.draw(on_side=False); tr.step_autograd(b[0], b[1], b[2])
+        nxt = loop.draw(on_side=False); tr.step_autograd(cur[0], cur[1], cur[2], next_batch=nxt); cur = nxt
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / n_steps
-    return {"rays_per_s": loop.rays / dt, "ms_per_step": dt * 1e3, "what": "render()+NeRFLoss+autograd+FusedAdam, same kernels"}
+    return {"rays_per_s": loop.rays / dt, "ms_per_step": dt * 1e3,
+            "what": "render(next_rays=...) + NeRFLoss + autograd + FusedAdam: the native stepper's forward / backward halves around torch's loss"}
 
 
 def usable_cpus():

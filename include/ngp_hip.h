@@ -670,6 +670,17 @@ int ngp_stepper_front(ngp_stepper* s, const float* rays_o, const float* rays_d, 
                       const float* next_o, const float* next_d, float loss_scale, float grad_scale,
                       ngp_stream_t main_stream, ngp_stream_t march_stream, int32_t* n_samples, int32_t* n_partials);
 int ngp_stepper_table_backward(ngp_stepper* s, int n_groups, int group, ngp_stream_t main_stream);
+/* The same step split where the reference's API splits it (render() -> NeRFLoss -> autograd, rendering.py:121-163, losses.py:47-60):
+ * render_forward = front() up to the composite WITHOUT the loss (plain ngp_composite_train_fw + ngp_active_scan), the
+ * background blend into rgb_out (R,3; may be NULL) and the next batch's march; the per-ray / per-sample results stay in the
+ * step buffers (opacity, depth, rgb, ws, total, deltas, ts, rays_a of set ngp_stepper_last_set()).
+ * render_backward = the rest of front() from the caller's seeds: g_rgb (R,3) w.r.t. the BLENDED colour, g_opacity, g_depth (R),
+ * g_ws (S) w.r.t. the composited values (the last three may be NULL = zero).  A stepper used only this way may be created
+ * without f32 masters / Adam moments (NULL): ngp_stepper_update then returns NGP_EINVAL. */
+int ngp_stepper_render_forward(ngp_stepper* s, const float* rays_o, const float* rays_d, const float* next_o, const float* next_d,
+                               float* rgb_out, ngp_stream_t main_stream, ngp_stream_t march_stream, int32_t* n_samples);
+int ngp_stepper_render_backward(ngp_stepper* s, const float* g_rgb, const float* g_opacity, const float* g_depth, const float* g_ws,
+                                float loss_scale, ngp_stream_t main_stream, int32_t* n_partials);
 /* Fused Adam (ngp_adam_step_field).  density_partials / rgb_partials NULL: the partial rows front() wrote (n_partials rows);
  * a caller that reduced them across ranks passes its own buffers with n_partials = 1.  grad_scale = the total factor the
  * gradients carry (loss_scale x grad_scale x world).  step is 1-based (bias correction). */

@@ -119,6 +119,8 @@ _PROTOS = {
     "ngp_stepper_drop_pending": [P],
     "ngp_stepper_front": [P, P, P, P, P, P, F, F, P, P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "ngp_stepper_table_backward": [P, I, I, P],
+    "ngp_stepper_render_forward": [P, P, P, P, P, P, P, P, C.POINTER(C.c_int32)],
+    "ngp_stepper_render_backward": [P, P, P, P, P, F, P, C.POINTER(C.c_int32)],
     "ngp_stepper_update": [P, F, I, F, P, P, I, P, P],
     "ngp_stepper_timing": [P, I],
     "ngp_stepper_stage_times": [P, C.POINTER(C.c_float)],

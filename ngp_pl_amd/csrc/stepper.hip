@@ -115,8 +115,8 @@ int ngp_stepper_create(const ngp_stepper_config* config, const ngp_step_buffers*
     if (!config || !buffers || !out) return NGP_EINVAL;
     *out = nullptr;
     const ngp_stepper_config& c = *config;
-    const void* need[] = {c.center, c.half_size, c.xyz_min, c.xyz_max, c.density_bitfield, c.enc_param, c.enc_half, c.enc_m, c.enc_v,
-                          c.rgb_param, c.rgb_half, c.rgb_m, c.rgb_v, c.grid_grad16};
+    // (the f32 masters and Adam moments may be NULL for a stepper that only runs the render-shaped halves: update() then refuses)
+    const void* need[] = {c.center, c.half_size, c.xyz_min, c.xyz_max, c.density_bitfield, c.enc_half, c.rgb_half, c.grid_grad16};
     for (const void* p : need) if (p == nullptr) return NGP_EINVAL;
     if (c.cascades < 1 || c.grid_size < 1 || c.max_samples < 1 || c.n_grid < 1 || c.n_density != NGP_DENSITY_NET_PARAMS || c.n_rgb != NGP_RGB_NET_PARAMS)
         return NGP_EINVAL;
@@ -182,16 +182,11 @@ int ngp_stepper_march(ngp_stepper* s, const float* rays_o, const float* rays_d, 
     return do_march(s, rays_o, rays_d, ngp_stream(main_stream), ngp_stream(march_stream));
 }
 
-int ngp_stepper_front(ngp_stepper* s, const float* rays_o, const float* rays_d, const float* rgb_gt,
-                      const float* next_o, const float* next_d, float loss_scale, float grad_scale,
-                      ngp_stream_t main_stream, ngp_stream_t march_stream, int32_t* n_samples, int32_t* n_partials) {
-    if (!s || !n_samples || !n_partials) return NGP_EINVAL;
-    NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d); NGP_CHECK_PTR(rgb_gt);
+// march hand-over -> sample expansion -> hash grid -> field: the part both step shapes share.  Leaves S in s->S.
+static int forward_field(ngp_stepper* s, const float* rays_o, const float* rays_d, hipStream_t main, ngp_stream_t main_stream, int* k_out) {
     if (!s->has_pending || s->pend_o != rays_o || s->pend_d != rays_d) return NGP_EINVAL;     // march() this batch first
-    if ((next_o == nullptr) != (next_d == nullptr)) return NGP_EINVAL;
     const ngp_stepper_config& c = s->c;
     const ngp_step_buffers& b = s->b;
-    hipStream_t main = ngp_stream(main_stream), side = ngp_stream(march_stream);
     const int k = s->pend_set;
     s->has_pending = false;
     // the step's only host wait.  No hipStreamWaitEvent on the main stream: the host has observed the event, so everything
@@ -200,7 +195,7 @@ int ngp_stepper_front(ngp_stepper* s, const float* rays_o, const float* rays_d, 
     const int32_t S = b.counter[k][0];
     if (S < 0 || (int64_t)S > b.cap) return NGP_EINVAL;
     s->S = S; s->last_set = k; s->n_part = 0;
-    *n_samples = S; *n_partials = 0;
+    *k_out = k;
     const int n = b.n_rays;
     for (int i = 0; i < N_MARKS; ++i) s->mark_set[i] = false;
     mark(s, 0, main);
@@ -214,6 +209,58 @@ int ngp_stepper_front(ngp_stepper* s, const float* rays_o, const float* rays_d, 
         STEP_TRY(ngp_field_fwd(b.feats, b.dirs, c.enc_half, c.rgb_half, S, b.sigmas, b.rgbs, b.h, main_stream));
         mark(s, 3, main);
     }
+    return 0;
+}
+
+// composite backward (+ distortion) -> field backward on the live samples, from seeds w.r.t. the composited per-ray values
+static int backward_field(ngp_stepper* s, const float* dL_dopacity, const float* dL_ddepth, const float* dL_drgb, const float* dL_dws_in,
+                          float loss_scale, hipStream_t main, ngp_stream_t main_stream, int32_t* n_partials) {
+    const ngp_stepper_config& c = s->c;
+    const ngp_step_buffers& b = s->b;
+    const int k = s->last_set, n = b.n_rays;
+    const int32_t S = s->S;
+    *n_partials = 0;
+    if (S <= 0) return 0;
+    const float* dL_dws = dL_dws_in;
+    if (c.lambda_distortion > 0) {
+        // losses.py:6-37,58-59: lambda * distortion per ray, mean over rays; its gradient enters the composite as dL/dws
+        if (dL_dws_in != nullptr) return NGP_EINVAL;                      // (one source of dL/dws)
+        STEP_TRY(ngp_distortion_loss_fw(b.ws, b.deltas, b.ts, b.rays_a[k], n, S, b.dist, b.ws_incl, b.wts_incl, main_stream));
+        STEP_TRY(ngp_distortion_loss_bw(b.dist_seed, b.ws_incl, b.wts_incl, b.ws, b.deltas, b.ts, b.rays_a[k], n, S, b.dL_dws, main_stream));
+        dL_dws = b.dL_dws;
+    }
+    // backward only over the samples up to each ray's early stop (the rest have zero gradient); the binned table backward
+    // reads the live samples' positions as a stream: composite_bw copies them in list order
+    s->binned = S <= b.bin_max;
+    STEP_TRY(ngp_composite_train_bw(dL_dopacity, dL_ddepth, dL_drgb, dL_dws, b.sigmas, b.rgbs, b.ws, b.deltas, b.ts, b.rays_a[k], b.opacity,
+                                    b.depth, b.rgb, c.T_threshold, n, S, b.dL_dsigmas, b.dL_drgbs, b.ray_offs, b.active,
+                                    s->binned ? b.xyzs : nullptr, s->binned ? b.x_act : nullptr, main_stream));
+    mark(s, 5, main);
+    const int n_part = ngp_field_bwd_partials(S);
+    if (n_part < 1 || n_part > b.max_partials) return NGP_EINVAL;
+    STEP_TRY(ngp_field_bwd(b.feats, b.dirs, b.h, c.enc_half, c.rgb_half, b.dL_dsigmas, b.dL_drgbs, loss_scale, S, b.active, b.n_active,
+                           b.dh, b.dfeats, b.partials, main_stream));
+    mark(s, 6, main);
+    s->n_part = n_part;
+    *n_partials = n_part;
+    return 0;
+}
+
+int ngp_stepper_front(ngp_stepper* s, const float* rays_o, const float* rays_d, const float* rgb_gt,
+                      const float* next_o, const float* next_d, float loss_scale, float grad_scale,
+                      ngp_stream_t main_stream, ngp_stream_t march_stream, int32_t* n_samples, int32_t* n_partials) {
+    if (!s || !n_samples || !n_partials) return NGP_EINVAL;
+    NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d); NGP_CHECK_PTR(rgb_gt);
+    if ((next_o == nullptr) != (next_d == nullptr)) return NGP_EINVAL;
+    const ngp_stepper_config& c = s->c;
+    const ngp_step_buffers& b = s->b;
+    hipStream_t main = ngp_stream(main_stream), side = ngp_stream(march_stream);
+    int k = 0;
+    *n_samples = 0; *n_partials = 0;
+    STEP_TRY(forward_field(s, rays_o, rays_d, main, main_stream, &k));
+    const int32_t S = s->S;
+    *n_samples = S;
+    const int n = b.n_rays;
     // composite + per-ray loss seeds, then one small kernel: offsets of the live samples and the loss sums
     STEP_TRY(ngp_composite_train_fw_loss(b.sigmas, b.rgbs, b.deltas, b.ts, b.rays_a[k], c.T_threshold, n, S, b.total, b.opacity, b.depth, b.rgb,
                                          b.ws, b.ray_offs, b.n_active, rgb_gt, c.bg, c.lambda_opacity, grad_scale, b.stats, b.stats + 1,
@@ -221,30 +268,56 @@ int ngp_stepper_front(ngp_stepper* s, const float* rays_o, const float* rays_d, 
     mark(s, 4, main);
     // the next batch's march: behind the composite forward, next to the composite / field backward (round-2 placement sweep)
     if (next_o) STEP_TRY(do_march(s, next_o, next_d, main, side));
-    if (S > 0) {
-        const float* dL_dws = nullptr;
-        if (c.lambda_distortion > 0) {
-            // losses.py:6-37,58-59: lambda * distortion per ray, mean over rays; its gradient enters the composite as dL/dws
-            STEP_TRY(ngp_distortion_loss_fw(b.ws, b.deltas, b.ts, b.rays_a[k], n, S, b.dist, b.ws_incl, b.wts_incl, main_stream));
-            STEP_TRY(ngp_distortion_loss_bw(b.dist_seed, b.ws_incl, b.wts_incl, b.ws, b.deltas, b.ts, b.rays_a[k], n, S, b.dL_dws, main_stream));
-            dL_dws = b.dL_dws;
-        }
-        // backward only over the samples up to each ray's early stop (the rest have zero gradient); the binned table backward
-        // reads the live samples' positions as a stream: composite_bw copies them in list order
-        s->binned = S <= b.bin_max;
-        STEP_TRY(ngp_composite_train_bw(b.dL_dopacity, b.zeros, b.dL_drgb, dL_dws, b.sigmas, b.rgbs, b.ws, b.deltas, b.ts, b.rays_a[k], b.opacity,
-                                        b.depth, b.rgb, c.T_threshold, n, S, b.dL_dsigmas, b.dL_drgbs, b.ray_offs, b.active,
-                                        s->binned ? b.xyzs : nullptr, s->binned ? b.x_act : nullptr, main_stream));
-        mark(s, 5, main);
-        const int n_part = ngp_field_bwd_partials(S);
-        if (n_part < 1 || n_part > b.max_partials) return NGP_EINVAL;
-        STEP_TRY(ngp_field_bwd(b.feats, b.dirs, b.h, c.enc_half, c.rgb_half, b.dL_dsigmas, b.dL_drgbs, loss_scale, S, b.active, b.n_active,
-                               b.dh, b.dfeats, b.partials, main_stream));
-        mark(s, 6, main);
-        s->n_part = n_part;
-        *n_partials = n_part;
+    return backward_field(s, b.dL_dopacity, b.zeros, b.dL_drgb, nullptr, loss_scale, main, main_stream, n_partials);
+}
+
+// The same step for a caller that forms the loss itself (render()'s training branch, rendering.py:121-163, followed by
+// NeRFLoss and autograd): forward half ...
+int ngp_stepper_render_forward(ngp_stepper* s, const float* rays_o, const float* rays_d, const float* next_o, const float* next_d,
+                               float* rgb_out, ngp_stream_t main_stream, ngp_stream_t march_stream, int32_t* n_samples) {
+    if (!s || !n_samples) return NGP_EINVAL;
+    NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d);
+    if ((next_o == nullptr) != (next_d == nullptr)) return NGP_EINVAL;
+    const ngp_stepper_config& c = s->c;
+    const ngp_step_buffers& b = s->b;
+    hipStream_t main = ngp_stream(main_stream), side = ngp_stream(march_stream);
+    int k = 0;
+    *n_samples = 0;
+    STEP_TRY(forward_field(s, rays_o, rays_d, main, main_stream, &k));
+    *n_samples = s->S;
+    const int n = b.n_rays;
+    STEP_TRY(ngp_composite_train_fw(b.sigmas, b.rgbs, b.deltas, b.ts, b.rays_a[k], c.T_threshold, n, s->S, b.total, b.opacity, b.depth, b.rgb,
+                                    b.ws, b.ray_offs, main_stream));
+    STEP_TRY(ngp_active_scan(b.ray_offs, n, b.n_active, main_stream));
+    if (rgb_out) {                                           // rendering.py:153-161: rgb + bg (1 - opacity); bg NULL = black: a copy
+        if (c.bg) STEP_TRY(ngp_bg_blend(b.rgb, b.opacity, c.bg, n, rgb_out, main_stream));
+        else STEP_HIP(hipMemcpyAsync(rgb_out, b.rgb, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, main));
     }
+    mark(s, 4, main);
+    if (next_o) STEP_TRY(do_march(s, next_o, next_d, main, side));
     return 0;
+}
+
+// ... and backward half: g_rgb (R,3) w.r.t. the BLENDED colour, g_opacity / g_depth (R) and g_ws (S) w.r.t. the composited values
+// (any of the last three may be NULL = zero).  Leaves the per-workgroup weight-gradient partials like front(); the table
+// backward and the update follow as separate calls.
+int ngp_stepper_render_backward(ngp_stepper* s, const float* g_rgb, const float* g_opacity, const float* g_depth, const float* g_ws,
+                                float loss_scale, ngp_stream_t main_stream, int32_t* n_partials) {
+    if (!s || !n_partials) return NGP_EINVAL;
+    NGP_CHECK_PTR(g_rgb);
+    const ngp_stepper_config& c = s->c;
+    const ngp_step_buffers& b = s->b;
+    *n_partials = 0;
+    if (s->S <= 0) return 0;
+    const int n = b.n_rays;
+    const float* g_o = g_opacity;
+    if (c.bg) {                                              // through rgb + bg (1 - opacity): dL/do -= sum_c g_rgb[c] bg[c]
+        STEP_TRY(ngp_bg_blend_bw(g_rgb, g_opacity, c.bg, n, b.dL_dopacity, main_stream));
+        g_o = b.dL_dopacity;
+    } else if (g_o == nullptr) {
+        g_o = b.zeros;
+    }
+    return backward_field(s, g_o, g_depth ? g_depth : b.zeros, g_rgb, g_ws, loss_scale, ngp_stream(main_stream), main_stream, n_partials);
 }
 
 int ngp_stepper_table_backward(ngp_stepper* s, int n_groups, int group, ngp_stream_t main_stream) {
@@ -266,6 +339,7 @@ int ngp_stepper_update(ngp_stepper* s, float lr, int32_t step, float grad_scale,
                        const float* rgb_partials, int32_t n_partials, const int32_t* found_inf, ngp_stream_t main_stream) {
     if (!s || step < 1 || (density_partials == nullptr) != (rgb_partials == nullptr)) return NGP_EINVAL;
     const ngp_stepper_config& c = s->c;
+    if (!c.enc_param || !c.enc_m || !c.enc_v || !c.rgb_param || !c.rgb_m || !c.rgb_v) return NGP_EINVAL;      // built without an optimizer state
     const ngp_step_buffers& b = s->b;
     if (density_partials == nullptr) {
         if (s->n_part < 1) return NGP_EINVAL;            // no backward ran (S == 0): nothing to apply

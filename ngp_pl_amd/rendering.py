@@ -10,7 +10,7 @@ from . import _lib, vren
 from ._lib import call, ptr, stream
 from .custom_functions import RayAABBIntersector, RayMarcher, VolumeRenderer
 
-MAX_SAMPLES = 1024
+from .stepper import MAX_SAMPLES        # noqa: E402  (1024, rendering.py:7)
 NEAR_DISTANCE = 0.01
 
 
@@ -36,12 +36,14 @@ def render(model, rays_o, rays_d, **kwargs):
     rays_o = rays_o.contiguous(); rays_d = rays_d.contiguous()
     test_time = kwargs.get("test_time", False)
     if not test_time and _fused_train(model, rays_o, rays_d, kwargs):
-        # rendering.py:27-29 (one box, one hit, near clamp) as ONE launch; (R,1,2) like the operator's output
         rays_o, rays_d = rays_o.float(), rays_d.float()
-        hits_t = torch.empty(rays_o.shape[0], 1, 2, dtype=torch.float32, device=rays_o.device)
-        with torch.cuda.device(rays_o.device):
-            call("ngp_ray_aabb_near", ptr(rays_o), ptr(rays_d), ptr(model.center), ptr(model.half_size), NEAR_DISTANCE,
-                 rays_o.shape[0], ptr(hits_t), stream())
+        hits_t = None
+        if not _native_train(model, kwargs):       # (the native stepper's march starts with this prologue itself)
+            # rendering.py:27-29 (one box, one hit, near clamp) as ONE launch; (R,1,2) like the operator's output
+            hits_t = torch.empty(rays_o.shape[0], 1, 2, dtype=torch.float32, device=rays_o.device)
+            with torch.cuda.device(rays_o.device):
+                call("ngp_ray_aabb_near", ptr(rays_o), ptr(rays_d), ptr(model.center), ptr(model.half_size), NEAR_DISTANCE,
+                     rays_o.shape[0], ptr(hits_t), stream())
         fn = _render_train
     else:
         _, hits_t, _ = RayAABBIntersector.apply(rays_o, rays_d, model.center, model.half_size, 1)
@@ -300,6 +302,88 @@ class _FusedTrainRender(torch.autograd.Function):
         return (g_enc, g_rgbw) + none5
 
 
+class _NativeTrainRender(torch.autograd.Function):
+    """`__render_rays_train` (rendering.py:121-163) through the native stepper (csrc/stepper.hip): the forward half of the step
+    is ONE library call (AABB + jitter + march, sample expansion, hash grid, field, composite, live-sample offsets, background
+    blend), the backward half two (composite + field backward on the live samples; table backward) -- the launch sequence of
+    `Trainer.step`, split where the reference's API splits it.  Used when the model is in its fused configuration AND leaves its
+    gradients in native buffers for optim.FusedAdam (model.native_grads: one backward per forward).  The returned per-ray /
+    per-sample tensors are views of the model's step buffers: valid until its next training-branch render()."""
+
+    @staticmethod
+    def forward(ctx, enc_params, rgb_params, model, rays_o, rays_d, esf, T_threshold, bg, next_rays):
+        from .stepper import RenderStepper
+        n, dev = rays_o.shape[0], rays_o.device
+        rs = getattr(model, "_render_stepper", None)
+        if rs is None:
+            rs = model._render_stepper = RenderStepper(model)
+        with torch.cuda.device(dev):
+            B, h = rs.prepare(n, esf, T_threshold, bg)
+            mq = stream()
+            sq = mq
+            ro_p, rd_p = rays_o.data_ptr(), rays_d.data_ptr()
+            if rs.pending is None or rs.pending[:2] != (ro_p, rd_p):
+                if rs.pending is not None:
+                    call("ngp_stepper_drop_pending", h)
+                call("ngp_stepper_march", h, ro_p, rd_p, mq, mq)
+            rs.pending = None
+            no_p = nd_p = None
+            if next_rays is not None and next_rays[0].shape[0] == n:       # the caller knows its next batch: march it under this step
+                if rs.side is None:
+                    rs.side = torch.cuda.Stream(device=dev, priority=-1)
+                sq = rs.side.cuda_stream
+                nxt = (next_rays[0].float().contiguous(), next_rays[1].float().contiguous())
+                no_p, nd_p = nxt[0].data_ptr(), nxt[1].data_ptr()
+            S_c = C.c_int32(0)
+            call("ngp_stepper_render_forward", h, ro_p, rd_p, no_p, nd_p, B.p["rgb_out"], mq, sq, C.byref(S_c))
+            if no_p is not None:
+                rs.pending = (no_p, nd_p, nxt)
+            S = S_c.value
+            k = call("ngp_stepper_last_set", h)
+        rs.generation += 1
+        ctx.model, ctx.rs, ctx.generation, ctx.S = model, rs, rs.generation, S
+        f32 = torch.float32
+        opacity, depth = B.opacity, B.depth
+        rgb_out = B.view("rgb_out", f32, n, 3)
+        ws, deltas, ts = B.view("ws", f32, S), B.view("deltas", f32, S), B.view("ts", f32, S)
+        rays_a = B.view("rays_a%d" % k, torch.int64, n, 3)
+        vr_samples = B.total.sum()
+        rm_samples = torch.tensor(S, dtype=torch.int32)
+        ctx.mark_non_differentiable(rays_a, deltas, ts, vr_samples, rm_samples)
+        return vr_samples, opacity, depth, rgb_out, ws, rays_a, deltas, ts, rm_samples
+
+    @staticmethod
+    def backward(ctx, _g_vr, g_opacity, g_depth, g_rgb, g_ws, _g_rays_a, _g_deltas, _g_ts, _g_rm):
+        from . import tcnn
+        model, rs, S = ctx.model, ctx.rs, ctx.S
+        none7 = (None,) * 7
+        if ctx.generation != rs.generation:
+            raise RuntimeError("backward of a render() whose step buffers have been reused by a later training-branch render() of the "
+                               "same model: with model.native_grads every forward needs its backward before the next one "
+                               "(set model.native_grads = False for several forwards per backward)")
+        enc, net = model.xyz_encoder, model.rgb_net
+        if S == 0:
+            return (None, None) + none7
+        B, h = rs.buf, rs.handle
+        n, dev = B.n, B.arena.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        g_rgb = torch.zeros(n, 3, **f32) if g_rgb is None else g_rgb.float().contiguous()
+        g_opacity = None if g_opacity is None else g_opacity.float().contiguous()
+        g_depth = None if g_depth is None else g_depth.float().contiguous()
+        g_ws = None if g_ws is None else g_ws.float().contiguous()
+        np_c = C.c_int32(0)
+        with torch.cuda.device(dev):
+            mq = stream()
+            call("ngp_stepper_render_backward", h, ptr(g_rgb), ptr(g_opacity), ptr(g_depth), ptr(g_ws), tcnn.LOSS_SCALE, mq, C.byref(np_c))
+            call("ngp_stepper_table_backward", h, 1, 0, mq)
+        n_part = np_c.value
+        g16 = model._grid_grad16(dev)
+        p_density = B.view("partials", torch.float32, n_part * enc.n_mlp)
+        p_rgb = B.arena[B.off["partials"] + 4 * n_part * enc.n_mlp:B.off["partials"] + 4 * n_part * B.n_mlp_params].view(torch.float32)
+        model.hand_over_native(dict(grid16=g16, density_partials=p_density, rgb_partials=p_rgb, n_partials=n_part, scale=tcnn.LOSS_SCALE))
+        return (None, None) + none7
+
+
 _ZEROS = {}
 
 
@@ -337,12 +421,27 @@ def _fused_train(model, rays_o, rays_d, kwargs):
         not any(isinstance(v, torch.Tensor) for k, v in kwargs.items() if k != "noise")
 
 
+def _native_train(model, kwargs):
+    """The training branch goes through the native stepper when the gradients stay in native buffers for optim.FusedAdam (one
+    backward per forward, see _NativeTrainRender), autograd is recording, and the caller supplies no jitter of its own.
+    NGP_NATIVE_RENDER=0 keeps the launch-by-launch node."""
+    import os
+    return getattr(model, "native_grads", False) and torch.is_grad_enabled() and "noise" not in kwargs and \
+        os.environ.get("NGP_NATIVE_RENDER", "1") != "0"
+
+
 def _render_train(model, rays_o, rays_d, hits_t, **kwargs):
     """march -> field -> composite (rendering.py:121-163)."""
     esf = kwargs.get("exp_step_factor", 0.)
     results = {}
     if _fused_train(model, rays_o, rays_d, kwargs):
         bg = _background(esf, rays_o.device, kwargs.get("random_bg", False))
+        if _native_train(model, kwargs):
+            (results["vr_samples"], results["opacity"], results["depth"], results["rgb"], results["ws"], results["rays_a"],
+             results["deltas"], results["ts"], results["rm_samples"]) = _NativeTrainRender.apply(
+                model.xyz_encoder.params, model.rgb_net.params, model, rays_o.float().contiguous(), rays_d.float().contiguous(), esf,
+                kwargs.get("T_threshold", 1e-4), bg, kwargs.get("next_rays"))
+            return results
         (results["vr_samples"], results["opacity"], results["depth"], results["rgb"], results["ws"], results["rays_a"],
          results["deltas"], results["ts"], results["rm_samples"]) = _FusedTrainRender.apply(
             model.xyz_encoder.params, model.rgb_net.params, model, rays_o.float(), rays_d.float(), hits_t[:, 0].contiguous(), esf,

@@ -34,110 +34,7 @@ def _set_current_stream(st):
     torch._C._cuda_setStream(stream_id=st.stream_id, device_index=st.device_index, device_type=st.device_type)
 
 
-def _align(x, a=256):
-    return (x + a - 1) // a * a
-
-
-class StepBuffers:
-    """Every buffer a step touches, allocated ONCE per batch size: the sample-proportional ones at the worst
-    case S = R * MAX_SAMPLES (276 B per sample slot: 2.3 GB for 8192 rays -- under 1 % of the 288 GB of HBM; only
-    the first S rows of each are ever touched), two sets of march records (the march of batch k+1 runs while
-    step k still reads its own), pinned count words, the table-backward workspace.  After construction a step
-    performs no hipMalloc / hipHostMalloc / hipFuncSetAttribute: the first timed step costs what the 10 000th does."""
-
-    PER_SAMPLE = (("xyzs", 12), ("dirs", 12), ("deltas", 4), ("ts", 4), ("feats", 64), ("h", 32), ("sigmas", 4), ("rgbs", 12),
-                  ("ws", 4), ("dL_dsigmas", 4), ("dL_drgbs", 12), ("active", 4), ("x_act", 12), ("dh", 32), ("dfeats", 64))
-    DISTORTION = (("ws_incl", 4), ("wts_incl", 4), ("dL_dws", 4))
-    PER_RAY = (("total", 8), ("opacity", 4), ("depth", 4), ("rgb", 12), ("dL_drgb", 12), ("dL_dopacity", 4), ("ray_offs", 4),
-               ("dist", 4), ("zeros", 4), ("dist_seed", 4))
-    MARCH = (("hits_t", 8), ("rays_a", 24), ("noise", 4), ("scratch", 4 * MAX_SAMPLES))
-    MAX_PARTIALS = 256
-
-    def __init__(self, model, n_rays, distortion, binned):
-        enc, net = model.xyz_encoder, model.rgb_net
-        dev = model.center.device
-        self.n, self.cap = n_rays, n_rays * MAX_SAMPLES
-        lib = _lib.lib()
-        self.n_mlp_params = enc.n_mlp + net.params.numel()
-        off, total = {}, 0
-
-        def add(name, nbytes):
-            nonlocal total
-            off[name] = total
-            total += _align(nbytes)
-        for name, b in self.PER_SAMPLE + (self.DISTORTION if distortion else ()):
-            add(name, b * self.cap)
-        for name, b in self.PER_RAY:
-            add(name, b * n_rays)
-        for k in (0, 1):
-            for name, b in self.MARCH:
-                add("%s%d" % (name, k), b * n_rays)
-        add("n_active", 4); add("stats", 8)
-        add("partials", self.MAX_PARTIALS * self.n_mlp_params * 4)
-        self.fw_bytes = int(lib.ngp_composite_train_fw_loss_workspace_bytes(n_rays))
-        add("fw_ws", self.fw_bytes)
-        # the binned table backward takes batches up to its chunk directory (1 M samples); larger ones (only the first
-        # steps of the occupancy warm-up) go to the one-pass sliced kernel, which needs no workspace
-        self.bin_max, self.bin_bytes = 0, 0
-        if binned:
-            s = min(self.cap, 1 << 20)
-            while s > 0 and not lib.ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(enc.meta), s):
-                s -= 1024
-            self.bin_max = max(s, 0)
-            self.bin_bytes = int(lib.ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(enc.meta), self.bin_max)) if self.bin_max else 0
-            add("bin_ws", self.bin_bytes)
-        self.arena = torch.empty(total, dtype=torch.uint8, device=dev)
-        base = self.arena.data_ptr()
-        assert base % 256 == 0
-        self.p = {k: base + v for k, v in off.items()}
-        self.off = off
-
-        def view(name, dtype, *shape):
-            n = 1
-            for d in shape:
-                n *= d
-            return self.arena[off[name]:off[name] + n * torch.empty(0, dtype=dtype).element_size()].view(dtype).view(*shape)
-        self.view = view
-        f32 = torch.float32
-        self.total = view("total", torch.int64, n_rays); self.opacity = view("opacity", f32, n_rays)
-        self.depth = view("depth", f32, n_rays); self.rgb = view("rgb", f32, n_rays, 3)
-        self.stats = view("stats", f32, 2); self.dist = view("dist", f32, n_rays)
-        self.n_active = view("n_active", torch.int32, 1)
-        view("zeros", f32, n_rays).zero_()               # dL/ddepth: the loss has no depth term
-        self.dist_seed_val = None
-        self.noise = [view("noise%d" % k, f32, n_rays) for k in (0, 1)]
-        # {S, R} of a march is written by its scan kernel straight into pinned (device-mapped) host memory
-        self.counter_host = [torch.zeros(2, dtype=torch.int32).pin_memory() for _ in (0, 1)]
-        self.counter_np = [t.numpy() for t in self.counter_host]
-        self.counter_p = [t.data_ptr() for t in self.counter_host]
-        self.next_set = 0
-        self.ready = [torch.cuda.Event() for _ in (0, 1)]
-        self.done = [torch.cuda.Event() for _ in (0, 1)]
-
-    def c_struct(self, distortion):
-        """The same buffers as an ngp_step_buffers record for the native stepper."""
-        P = self.p
-        c = _lib.StepBuffersC()
-        c.n_rays, c.distortion, c.cap = self.n, 1 if distortion else 0, self.cap
-        for name in ("xyzs", "dirs", "deltas", "ts", "feats", "h", "sigmas", "rgbs", "ws", "dL_dsigmas", "dL_drgbs", "active", "x_act", "dh",
-                     "dfeats", "total", "opacity", "depth", "rgb", "dL_drgb", "dL_dopacity", "ray_offs", "dist", "zeros", "dist_seed",
-                     "n_active", "stats", "partials", "fw_ws"):
-            setattr(c, name, P[name])
-        if distortion:
-            c.ws_incl, c.wts_incl, c.dL_dws = P["ws_incl"], P["wts_incl"], P["dL_dws"]
-        for k in (0, 1):
-            c.hits_t[k], c.rays_a[k], c.noise[k], c.scratch[k] = P["hits_t%d" % k], P["rays_a%d" % k], P["noise%d" % k], P["scratch%d" % k]
-            c.counter[k] = self.counter_p[k]
-        c.max_partials, c.fw_bytes = self.MAX_PARTIALS, self.fw_bytes
-        c.bin_ws, c.bin_bytes, c.bin_max = (P["bin_ws"] if self.bin_max else None), self.bin_bytes, self.bin_max
-        return c
-
-    def sample_views(self, S):
-        """Tensor views of the last step's packed samples (debugging / tests; the step itself uses raw pointers)."""
-        f32 = torch.float32
-        return dict(xyzs=self.view("xyzs", f32, S, 3), dirs=self.view("dirs", f32, S, 3), deltas=self.view("deltas", f32, S),
-                    ts=self.view("ts", f32, S), sigmas=self.view("sigmas", f32, S), rgbs=self.view("rgbs", f32, S, 3),
-                    ws=self.view("ws", f32, S))
+from .stepper import StepBuffers, _align        # noqa: E402,F401  (the step's buffers: shared with rendering.py's native render node)
 
 
 class Trainer:
@@ -655,7 +552,7 @@ class Trainer:
                     vr_s=float(self.last["total"].sum().item()) / n)
 
     # -- the reference-shaped path ---------------------------------------------------------------
-    def step_autograd(self, rays_o, rays_d, rgb_gt, noise=None):
+    def step_autograd(self, rays_o, rays_d, rgb_gt, noise=None, next_batch=None):
         """render() -> NeRFLoss -> backward -> FusedAdam, as train.py:159-185 (no GradScaler: the
         tcnn modules carry their own loss scale)."""
         self._maybe_update_grid()
@@ -664,6 +561,8 @@ class Trainer:
             kwargs["exp_step_factor"] = self.exp_step_factor
         if noise is not None:
             kwargs["noise"] = noise          # (R) jitter of the march instead of a fresh torch.rand draw
+        if next_batch is not None and (self.global_step + 1) % self.update_interval != 0:
+            kwargs["next_rays"] = (next_batch[0], next_batch[1])     # marched under this step (not across an occupancy update)
         results = render(self.model, rays_o, rays_d, **kwargs)
         loss_d = self.loss_fn(results, {"rgb": rgb_gt})
         loss = sum(lo.mean() for lo in loss_d.values())

@@ -435,11 +435,13 @@ def test_render_matches_the_cpu_oracle_end_to_end():
         err = (a.cpu().numpy() - b)
         err = np.abs(err).reshape(len(b), -1).max(1)
         assert err.mean() < 2e-3 and np.quantile(err, 0.99) < 2e-2, (name, err.mean(), np.quantile(err, 0.99))
-    # training branch, same jitter on both sides
-    torch.manual_seed(123)
+    # training branch (through the native stepper: the model has a FusedAdam), same jitter on both sides: the oracle marches
+    # with the draw the stepper made
+    from ngp_pl_amd import _lib
     res = render(m, ro, rd, test_time=False)
-    torch.manual_seed(123)
-    noise = torch.rand_like(ro[:, 0]).cpu().numpy()
+    assert type(res["rgb"].grad_fn).__name__.startswith("_NativeTrainRender")
+    rs = m._render_stepper
+    noise = rs.buf.noise[_lib.call("ngp_stepper_last_set", rs.handle)].cpu().numpy().copy()
     want = RO.render_rays_train(vr, f, ron, rdn, bits, noise)
     assert int(res["rm_samples"]) == want["rm_samples"]            # marching: exact
     assert torch.equal(res["rays_a"].cpu(), torch.from_numpy(want["rays_a"]))
@@ -894,3 +896,63 @@ def test_step_gradients_at_the_bench_batch_match_the_cpu_oracle():
     got_nz = captured["grid"].cpu() != 0
     assert float((got_nz & ~nz).float().mean()) < 1e-5 and float((~got_nz & (want["grid"].abs() > 5e-8)).float().mean()) < 1e-5
     print("S", S, "active", n_active, "gradient errors vs the CPU oracle (max, median, max |g|):", report)
+
+
+def test_native_render_node_matches_the_launch_by_launch_node():
+    """render()'s training branch through the native stepper (_NativeTrainRender: one library call forward, two backward) against
+    the launch-by-launch node (_FusedTrainRender) on the same rays and the same jitter: every result and every native gradient
+    buffer bit for bit; a next batch handed over as `next_rays` is marched ahead and picked up; a backward whose buffers a later
+    forward has reused is refused."""
+    import ctypes as C
+    from ngp_pl_amd import _lib
+    from ngp_pl_amd.rendering import render
+    from ngp_pl_amd.trainer import Trainer
+    m = make_model(seed=31)
+    tr = Trainer(m)                                               # FusedAdam: model.native_grads = True
+    bs = [batch(4096, seed=1200 + i) for i in range(3)]
+    for it in range(120):
+        tr.step(*bs[it % 3])
+    ro, rd, gt = batch(4096, seed=1290)
+    nxt = batch(4096, seed=1291)
+
+    def loss_of(res):
+        return ((res["rgb"] - gt) ** 2).mean() + 1e-3 * (-(res["opacity"] + 1e-10) * torch.log(res["opacity"] + 1e-10)).mean() + \
+            1e-3 * (res["ws"] ** 2).sum() + 1e-4 * res["depth"].mean()
+
+    def grab():
+        nat = m._native
+        out = {k: nat[k].clone() for k in ("grid16", "density_partials", "rgb_partials")}
+        out["n_partials"] = nat["n_partials"]
+        m._native = None
+        return out
+    res = render(m, ro, rd, next_rays=(nxt[0], nxt[1]))
+    assert type(res["rgb"].grad_fn).__name__.startswith("_NativeTrainRender")
+    rs = m._render_stepper
+    assert rs.pending is not None                                  # the next batch has been marched ahead
+    keep = {k: res[k].detach().clone() for k in ("rgb", "opacity", "depth", "ws", "deltas", "ts", "rays_a")}
+    keep["vr"], keep["rm"] = int(res["vr_samples"]), int(res["rm_samples"])
+    noise = rs.buf.noise[_lib.call("ngp_stepper_last_set", rs.handle)].clone()
+    loss_of(res).backward()
+    ga = grab()
+    res2 = render(m, ro, rd, noise=noise)                          # a caller-supplied jitter selects the launch-by-launch node
+    assert type(res2["rgb"].grad_fn).__name__.startswith("_FusedTrainRender")
+    assert int(res2["vr_samples"]) == keep["vr"] and int(res2["rm_samples"]) == keep["rm"] > 0
+    for k in ("rgb", "opacity", "depth", "ws", "deltas", "ts", "rays_a"):
+        assert torch.equal(res2[k].detach(), keep[k]), k
+    loss_of(res2).backward()
+    gb = grab()
+    assert ga["n_partials"] == gb["n_partials"]
+    for k in ("grid16", "density_partials", "rgb_partials"):
+        assert torch.equal(ga[k], gb[k]), k
+    # the prefetched batch is picked up (no second march), and its results equal a render of the same rays with the same jitter
+    res3 = render(m, nxt[0], nxt[1])
+    noise3 = rs.buf.noise[_lib.call("ngp_stepper_last_set", rs.handle)].clone()
+    rgb3 = res3["rgb"].detach().clone()
+    res4 = render(m, nxt[0], nxt[1], noise=noise3)
+    assert torch.equal(res4["rgb"].detach(), rgb3)
+    # one backward per forward: res3's buffers were not reused by a NATIVE forward (res4 ran launch by launch), so this works ...
+    loss_a = ((res3["rgb"] - nxt[2]) ** 2).mean()
+    res5 = render(m, ro, rd)                                       # ... but now they are
+    with pytest.raises(RuntimeError, match="step buffers have been reused"):
+        loss_a.backward()
+    m._native = None
