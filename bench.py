@@ -467,6 +467,18 @@ def cpu_baseline_worker(path):
                                     "reference .cu compiled for CPU (oracle/_ref)" if isinstance(vr, Reference) else "oracle/ngp_oracle.c")}), flush=True)
 
 
+def march_guard_record():
+    """Tripped termination guards of the marching kernels so far (all zero for sane rays) and, if any, the first tripping probe."""
+    from ngp_pl_amd import _lib as native
+    try:
+        rec = {"march_guards": native.march_guard_counts()}
+        if rec["march_guards"][0]:
+            rec["march_guard_first_probe"] = native.march_guard_first()
+        return rec
+    except native.NgpError as e:
+        return {"march_guards": None, "march_guards_error": str(e)[:200]}
+
+
 def secondary_line(name, args, dev):
     """A short run of one of the other recipes (single GPU, rank 0): 320 setup steps, 100 timed."""
     progress("secondary %s: building" % name)
@@ -478,10 +490,7 @@ def secondary_line(name, args, dev):
     out = {"workload": loop.description, "rays_per_s": r["rays_per_s"], "ms_per_step": r["ms_per_step"], "rays_per_batch": loop.rays,
            "samples_per_ray_marched": met["rm_s"], "samples_per_ray_composited": met["vr_s"], "train_psnr": met["psnr"],
            "cascades": loop.model.cascades, "timed_steps_total": r["timed_steps_total"], "setup_steps": args.setup_steps}
-    from ngp_pl_amd import _lib as native
-    out["march_guards"] = native.march_guard_counts()
-    if out["march_guards"][0]:
-        out["march_guard_first_probe"] = native.march_guard_first()
+    out.update(march_guard_record())
     del loop
     torch.cuda.empty_cache()
     return out
@@ -655,10 +664,7 @@ def main():
     }
     if "exchange_ms" in r:
         out["exchange_ms"], out["exchange"] = r["exchange_ms"], r["exchange"]
-    from ngp_pl_amd import _lib as native
-    out["march_guards"] = native.march_guard_counts()
-    if out["march_guards"][0]:
-        out["march_guard_first_probe"] = native.march_guard_first()        # tripped termination guards of the marching kernels so far: all zero for sane rays
+    out.update(march_guard_record())
     keeper.headline(out)
     if dist is not None:      # what follows runs on rank 0 only: no collectives from here on
         loop.exchange.uninstall(loop.trainer)
