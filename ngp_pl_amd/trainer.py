@@ -31,7 +31,10 @@ from .rendering import MAX_SAMPLES, NEAR_DISTANCE, render
 def _set_current_stream(st):
     """torch.cuda.set_stream without its bookkeeping (the context manager costs ~20 us of host time per use: two
     current_stream() queries and two switches; this is one switch)."""
-    torch._C._cuda_setStream(stream_id=st.stream_id, device_index=st.device_index, device_type=st.device_type)
+    try:
+        torch._C._cuda_setStream(stream_id=st.stream_id, device_index=st.device_index, device_type=st.device_type)
+    except (AttributeError, TypeError):          # another torch build: the public call does the same with more bookkeeping
+        torch.cuda.set_stream(st)
 
 
 from .stepper import StepBuffers, _align        # noqa: E402,F401  (the step's buffers: shared with rendering.py's native render node)
@@ -555,6 +558,11 @@ class Trainer:
     def step_autograd(self, rays_o, rays_d, rgb_gt, noise=None, next_batch=None):
         """render() -> NeRFLoss -> backward -> FusedAdam, as train.py:159-185 (no GradScaler: the
         tcnn modules carry their own loss scale)."""
+        if self.grad_hook is not None or self.mlp_grad_hook is not None or self.update_hook is not None:
+            # the autograd surface issues no collectives: under an installed exchange the ranks would train independently and
+            # silently diverge (Trainer.step is the data-parallel path; uninstall() the exchange for single-process use)
+            raise RuntimeError("step_autograd() with a gradient exchange installed: the reference-shaped path is single-process; "
+                               "use Trainer.step under data parallelism or exchange.uninstall(trainer) first")
         self._maybe_update_grid()
         kwargs = {"test_time": False}
         if self.exp_step_factor:
