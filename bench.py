@@ -245,6 +245,8 @@ class Loop:
         else:
             self.steps(setup_steps)
         self.steps(warmup)
+        if hasattr(tr, "host_times"):
+            tr.host_times(reset=True)              # host accounting of the native stepper: the timed windows only
         n_win = max(1, -(-min_timed // steps))
         wins, ev = [], []
         for _ in range(n_win):
@@ -253,6 +255,9 @@ class Loop:
         total = sum(wins)
         met = tr.metrics()
         extra = {}
+        host = tr.host_times(reset=True) if hasattr(tr, "host_times") else None
+        if host:                       # native stepper only: polling for the march's count (device-bound) vs launches / events / checks
+            extra["host_ms_per_step"] = host
         if self.exchange is not None:          # the exchange stage on its own: 20 more steps with device events around it (all ranks alike)
             self.exchange.timing = True
             self.steps(20)
@@ -664,6 +669,8 @@ def main():
     }
     if "exchange_ms" in r:
         out["exchange_ms"], out["exchange"] = r["exchange_ms"], r["exchange"]
+    if "host_ms_per_step" in r:
+        out["host_ms_per_step"] = r["host_ms_per_step"]
     out.update(march_guard_record())
     keeper.headline(out)
     if dist is not None:      # what follows runs on rank 0 only: no collectives from here on

@@ -690,6 +690,9 @@ int ngp_stepper_update(ngp_stepper* s, float lr, int32_t step, float grad_scale,
  * ngp_stepper_stage_times synchronises and writes the last step's times in ms:
  *   [0] march_write [1] hashgrid_fwd [2] mlp_fwd [3] composite_fw+loss [4] composite_bw [5] mlp_bwd [6] hashgrid_bwd [7] adam
  *   [8] march_count (marching stream; of the batch the last front() consumed).  Negative = not recorded. */
+/* Host-side accounting since the last reset: seconds the entry points spent polling for a march's sample count (device-bound
+ * wait) and in everything else (argument checks, launches, event records), and the number of front() calls. */
+int ngp_stepper_host_times(ngp_stepper* s, double* wait_s, double* enqueue_s, long long* n_steps, int reset);
 #define NGP_STEPPER_STAGES 9
 int ngp_stepper_timing(ngp_stepper* s, int enable);
 int ngp_stepper_stage_times(ngp_stepper* s, float* ms);

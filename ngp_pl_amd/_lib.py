@@ -122,6 +122,7 @@ _PROTOS = {
     "ngp_stepper_render_forward": [P, P, P, P, P, P, P, P, C.POINTER(C.c_int32)],
     "ngp_stepper_render_backward": [P, P, P, P, P, F, P, C.POINTER(C.c_int32)],
     "ngp_stepper_update": [P, F, I, F, P, P, I, P, P],
+    "ngp_stepper_host_times": [P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong), I],
     "ngp_stepper_timing": [P, I],
     "ngp_stepper_stage_times": [P, C.POINTER(C.c_float)],
     "ngp_hashgrid_fwd_n": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P],

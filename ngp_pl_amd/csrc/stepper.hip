@@ -39,9 +39,18 @@ struct ngp_stepper {
     int32_t S = 0, n_part = 0, last_set = 0;
     bool binned = false;
     int device = 0;
+    // host-side accounting: seconds spent waiting for a march's count (device-bound) and in everything else the entry points do
+    double t_wait = 0.0, t_enqueue = 0.0;
+    long long n_fronts = 0;
 };
 
 namespace {
+
+struct HostTimer {          // accumulates the lifetime of a scope into *acc
+    double* acc; std::chrono::steady_clock::time_point t0;
+    explicit HostTimer(double* a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~HostTimer() { *acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 #define STEP_TRY(expr) do { const int rc_ = (expr); if (rc_ != 0) return rc_; } while (0)
 #define STEP_HIP(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
@@ -68,7 +77,10 @@ inline void mark(ngp_stepper* s, int i, hipStream_t st) {
 // event, which is what orders the caller's following launches behind the march.
 int wait_march(ngp_stepper* s, int k) {
     volatile int32_t* cnt = s->b.counter[k];
-    const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(spin_limit_s());
+    const auto t_begin = std::chrono::steady_clock::now();
+    struct Account { ngp_stepper* s; std::chrono::steady_clock::time_point t0;
+                     ~Account() { const double d = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); s->t_wait += d; s->t_enqueue -= d; } } account{s, t_begin};
+    const auto t_end = t_begin + std::chrono::duration<double>(spin_limit_s());
     unsigned spins = 0;
     while (cnt[0] < 0) {
         if ((++spins & 1023u) == 0) {
@@ -179,6 +191,7 @@ int ngp_stepper_last_set(const ngp_stepper* s) { return s ? s->last_set : 0; }
 
 int ngp_stepper_march(ngp_stepper* s, const float* rays_o, const float* rays_d, ngp_stream_t main_stream, ngp_stream_t march_stream) {
     if (!s) return NGP_EINVAL;
+    HostTimer host_timer(&s->t_enqueue);
     return do_march(s, rays_o, rays_d, ngp_stream(main_stream), ngp_stream(march_stream));
 }
 
@@ -251,12 +264,14 @@ int ngp_stepper_front(ngp_stepper* s, const float* rays_o, const float* rays_d, 
                       ngp_stream_t main_stream, ngp_stream_t march_stream, int32_t* n_samples, int32_t* n_partials) {
     if (!s || !n_samples || !n_partials) return NGP_EINVAL;
     NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d); NGP_CHECK_PTR(rgb_gt);
+    HostTimer host_timer(&s->t_enqueue);
     if ((next_o == nullptr) != (next_d == nullptr)) return NGP_EINVAL;
     const ngp_stepper_config& c = s->c;
     const ngp_step_buffers& b = s->b;
     hipStream_t main = ngp_stream(main_stream), side = ngp_stream(march_stream);
     int k = 0;
     *n_samples = 0; *n_partials = 0;
+    ++s->n_fronts;
     STEP_TRY(forward_field(s, rays_o, rays_d, main, main_stream, &k));
     const int32_t S = s->S;
     *n_samples = S;
@@ -277,6 +292,7 @@ int ngp_stepper_render_forward(ngp_stepper* s, const float* rays_o, const float*
                                float* rgb_out, ngp_stream_t main_stream, ngp_stream_t march_stream, int32_t* n_samples) {
     if (!s || !n_samples) return NGP_EINVAL;
     NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d);
+    HostTimer host_timer(&s->t_enqueue);
     if ((next_o == nullptr) != (next_d == nullptr)) return NGP_EINVAL;
     const ngp_stepper_config& c = s->c;
     const ngp_step_buffers& b = s->b;
@@ -305,6 +321,7 @@ int ngp_stepper_render_backward(ngp_stepper* s, const float* g_rgb, const float*
                                 float loss_scale, ngp_stream_t main_stream, int32_t* n_partials) {
     if (!s || !n_partials) return NGP_EINVAL;
     NGP_CHECK_PTR(g_rgb);
+    HostTimer host_timer(&s->t_enqueue);
     const ngp_stepper_config& c = s->c;
     const ngp_step_buffers& b = s->b;
     *n_partials = 0;
@@ -322,6 +339,7 @@ int ngp_stepper_render_backward(ngp_stepper* s, const float* g_rgb, const float*
 
 int ngp_stepper_table_backward(ngp_stepper* s, int n_groups, int group, ngp_stream_t main_stream) {
     if (!s || n_groups < 1 || group < 0 || group >= n_groups) return NGP_EINVAL;
+    HostTimer host_timer(&s->t_enqueue);
     if (s->S <= 0) return 0;
     const ngp_stepper_config& c = s->c;
     const ngp_step_buffers& b = s->b;
@@ -338,6 +356,7 @@ int ngp_stepper_table_backward(ngp_stepper* s, int n_groups, int group, ngp_stre
 int ngp_stepper_update(ngp_stepper* s, float lr, int32_t step, float grad_scale, const float* density_partials,
                        const float* rgb_partials, int32_t n_partials, const int32_t* found_inf, ngp_stream_t main_stream) {
     if (!s || step < 1 || (density_partials == nullptr) != (rgb_partials == nullptr)) return NGP_EINVAL;
+    HostTimer host_timer(&s->t_enqueue);
     const ngp_stepper_config& c = s->c;
     if (!c.enc_param || !c.enc_m || !c.enc_v || !c.rgb_param || !c.rgb_m || !c.rgb_v) return NGP_EINVAL;      // built without an optimizer state
     const ngp_step_buffers& b = s->b;
@@ -353,6 +372,13 @@ int ngp_stepper_update(ngp_stepper* s, float lr, int32_t step, float grad_scale,
                                  c.rgb_param, c.rgb_half, rgb_partials, c.rgb_m, c.rgb_v, c.n_rgb,
                                  n_partials, lr, c.beta1, c.beta2, c.eps, c.weight_decay, step, grad_scale, 0, found_inf, main_stream));
     mark(s, 8, ngp_stream(main_stream));
+    return 0;
+}
+
+int ngp_stepper_host_times(ngp_stepper* s, double* wait_s, double* enqueue_s, long long* n_steps, int reset) {
+    if (!s || !wait_s || !enqueue_s || !n_steps) return NGP_EINVAL;
+    *wait_s = s->t_wait; *enqueue_s = s->t_enqueue; *n_steps = s->n_fronts;
+    if (reset) { s->t_wait = s->t_enqueue = 0.0; s->n_fronts = 0; }
     return 0;
 }
 

@@ -156,6 +156,16 @@ class Trainer:
                 call("ngp_stepper_set_buffers", self._stepper, C.byref(bc))
         return self._buf
 
+    def host_times(self, reset=True):
+        """(wait_ms, enqueue_ms) per step the native stepper's entry points spent on the host since the last reset: polling for the
+        march's sample count (device-bound) / everything else (launches, events, checks)."""
+        if self._stepper is None:
+            return None
+        w, e, n = C.c_double(), C.c_double(), C.c_longlong()
+        call("ngp_stepper_host_times", self._stepper, C.byref(w), C.byref(e), C.byref(n), 1 if reset else 0)
+        k = max(n.value, 1)
+        return {"wait_ms_per_step": w.value / k * 1e3, "enqueue_ms_per_step": e.value / k * 1e3, "steps": n.value}
+
     def last_march_noise(self):
         """The jitter values (R) the march of the last stepped batch used (a view of the step buffers; tests hand it to another path)."""
         B = self._buf

@@ -38,16 +38,38 @@ def table(path):
     return out
 
 
+def trace_table(path):
+    """kernel_trace_summary.txt (tools/rocprof_summary.py): kernel -> (calls, avg_us)."""
+    out = {}
+    if not os.path.exists(path):
+        return out
+    with open(path) as f:
+        for line in f:
+            m = re.match(r"(\S+)\s+(\d+)\s+([\d.]+)\s+[\d.]+\s+[\d.]+\s", line)
+            if m:
+                out[m.group(1)] = (int(m.group(2)), float(m.group(3)))
+    return out
+
+
+N_SIMD, CLOCK_MHZ = 1024, 2400.0          # 256 CUs x 4 SIMDs; MI355X peak engine clock (MI355X_MICROARCH.md)
+
+
 def main():
     d = sys.argv[1]
     fetch, write = table(os.path.join(d, "pmc_fetch.txt")), table(os.path.join(d, "pmc_write.txt"))
+    sq = table(os.path.join(d, "pmc_sqwait.txt")) if os.path.exists(os.path.join(d, "pmc_sqwait.txt")) else {}
+    trace = trace_table(os.path.join(d, "kernel_trace_summary.txt"))
     with open(os.path.join(d, "bench_pmc_fetch.json")) as f:
         bench = json.loads([ln for ln in f.read().splitlines() if ln.startswith("{")][-1])
     roof = bench["roofline"]
     out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 20 --warmup 5 "
                      "--no-render --no-cpu-baseline --no-secondary --no-api`; means over the launches of the last 20 (stage-timed) steps",
            "samples_marched_per_step": roof["samples_marched_per_launch"], "samples_active_per_step": roof["samples_active_per_launch"],
-           "stages": {}}
+           "stages": {}, "kernel_sum_ms": {}, "issue_bound": {},
+           "kernel_sum_ms_how": "sum over the stage's kernels of the average duration in kernel_trace_summary.txt (rocprofv3 --kernel-trace of "
+                                "`bench.py --timed-only`, the 200 timed steps, marching stream running next to them)",
+           "issue_bound_how": "SQ_ACTIVE_INST_ANY (quad-cycles: x4) / (1024 SIMDs x kernel duration in the same PMC pass x 2400 MHz), the "
+                              "stage's longest kernel"}
     for stage, kernels in STAGES.items():
         fb = wb = 0.0
         found = []
@@ -60,6 +82,15 @@ def main():
             if any(name.startswith(k) or k in name for k in kernels):
                 per_step = max(1, round(rec["calls"] / max(write[next(n for n in write if "adam_field" in n)]["calls"], 1)))
                 wb += rec.get("WRITE_SIZE", 0.0) * 1024 * per_step
+        ks = [(name, rec) for name, rec in trace.items() if any(k.split("_kernel")[0] in name for k in kernels)]
+        if ks:
+            adam_calls = max([c for n, (c, a) in trace.items() if "adam_field" in n] + [1])
+            out["kernel_sum_ms"][stage] = round(sum(a * max(1, round(c / adam_calls)) for _n, (c, a) in ks) / 1e3, 4)
+        cand = [(rec["avg_us"], name, rec) for name, rec in sq.items() if any(name.startswith(k) or k in name for k in kernels) and rec.get("SQ_ACTIVE_INST_ANY")]
+        if cand:
+            avg_us, name, rec = max(cand)
+            out["issue_bound"][stage] = {"kernel": name, "avg_us_in_pmc_pass": avg_us, "SQ_ACTIVE_INST_ANY": rec["SQ_ACTIVE_INST_ANY"],
+                                         "frac": round(rec["SQ_ACTIVE_INST_ANY"] * 4.0 / (N_SIMD * avg_us * CLOCK_MHZ), 3)}
         if found:
             out["stages"][stage] = {"kernels": found, "fetch_bytes_raw": fb, "write_bytes": wb, "hbm_bytes_per_launch": 2 * fb + wb,
                                     "how": "2 x FETCH_SIZE (gfx950 halving, calibrated for 16 B/lane streams only) + WRITE_SIZE, KB x 1024"}
