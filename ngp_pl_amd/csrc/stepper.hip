@@ -9,6 +9,7 @@
 #include "ngp_common.h"
 #include <chrono>
 #include <cstdlib>
+#include <cstring>
 #include <new>
 
 namespace {
@@ -42,6 +43,10 @@ struct ngp_stepper {
     // host-side accounting: seconds spent waiting for a march's count (device-bound) and in everything else the entry points do
     double t_wait = 0.0, t_enqueue = 0.0;
     long long n_fronts = 0;
+    // the next batch handed to front(): marched behind the stage march_at names (NGP_MARCH_AT, default mlp_fwd)
+    const float* next_o = nullptr; const float* next_d = nullptr;
+    hipStream_t next_main = nullptr, next_side = nullptr;
+    int march_at = 2;
 };
 
 namespace {
@@ -95,6 +100,27 @@ int wait_march(ngp_stepper* s, int k) {
     return e == hipSuccess ? 0 : (int)e;
 }
 
+// where in the step the next batch's march is enqueued (it starts behind whatever the main stream has queued by then)
+enum { AT_TOP = 0, AT_HASHGRID_FWD, AT_MLP_FWD, AT_COMPOSITE_FW, AT_COMPOSITE_BW, AT_MLP_BWD, AT_HASHGRID_BWD, AT_ADAM };
+int march_at_from_env() {
+    static const int v = [] {
+        const char* e = getenv("NGP_MARCH_AT");
+        if (!e) return (int)AT_MLP_FWD;            // profiles/r03_march_sweep.txt: 0.417 ms per step against 0.424 behind the composite forward
+        const char* names[] = {"top", "hashgrid_fwd", "mlp_fwd", "composite_fw", "composite_bw", "mlp_bwd", "hashgrid_bwd", "adam"};
+        for (int i = 0; i < 8; ++i) if (strcmp(e, names[i]) == 0) return i;
+        return (int)AT_MLP_FWD;
+    }();
+    return v;
+}
+
+int do_march(ngp_stepper* s, const float* rays_o, const float* rays_d, hipStream_t main, hipStream_t side);
+inline int march_next_if_at(ngp_stepper* s, int stage) {
+    if (s->next_o == nullptr || s->march_at != stage) return 0;
+    const float* o = s->next_o; const float* d = s->next_d;
+    s->next_o = s->next_d = nullptr;
+    return do_march(s, o, d, s->next_main, s->next_side);
+}
+
 int do_march(ngp_stepper* s, const float* rays_o, const float* rays_d, hipStream_t main, hipStream_t side) {
     if (s->has_pending) return NGP_EINVAL;
     NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d);
@@ -138,6 +164,7 @@ int ngp_stepper_create(const ngp_stepper_config* config, const ngp_step_buffers*
     ngp_stepper* s = new (std::nothrow) ngp_stepper();
     if (!s) return NGP_EINVAL;
     s->c = c; s->b = *buffers;
+    s->march_at = march_at_from_env();
     (void)hipGetDevice(&s->device);
     hipError_t e = hipSuccess;
     for (int k = 0; k < 2 && e == hipSuccess; ++k) {
@@ -212,6 +239,7 @@ static int forward_field(ngp_stepper* s, const float* rays_o, const float* rays_
     const int n = b.n_rays;
     for (int i = 0; i < N_MARKS; ++i) s->mark_set[i] = false;
     mark(s, 0, main);
+    STEP_TRY(march_next_if_at(s, AT_TOP));
     STEP_TRY(ngp_raymarching_train_write(rays_o, rays_d, b.rays_a[k], b.scratch[k], c.scale, c.exp_step_factor, c.grid_size, c.max_samples, n,
                                          b.xyzs, b.dirs, b.deltas, b.ts, main_stream));
     mark(s, 1, main);
@@ -219,8 +247,10 @@ static int forward_field(ngp_stepper* s, const float* rays_o, const float* rays_
     if (S > 0) {
         STEP_TRY(ngp_hashgrid_fwd(b.xyzs, c.xyz_min, c.xyz_max, table, &c.meta, S, b.feats, main_stream));
         mark(s, 2, main);
+        STEP_TRY(march_next_if_at(s, AT_HASHGRID_FWD));
         STEP_TRY(ngp_field_fwd(b.feats, b.dirs, c.enc_half, c.rgb_half, S, b.sigmas, b.rgbs, b.h, main_stream));
         mark(s, 3, main);
+        STEP_TRY(march_next_if_at(s, AT_MLP_FWD));
     }
     return 0;
 }
@@ -249,11 +279,13 @@ static int backward_field(ngp_stepper* s, const float* dL_dopacity, const float*
                                     b.depth, b.rgb, c.T_threshold, n, S, b.dL_dsigmas, b.dL_drgbs, b.ray_offs, b.active,
                                     s->binned ? b.xyzs : nullptr, s->binned ? b.x_act : nullptr, main_stream));
     mark(s, 5, main);
+    STEP_TRY(march_next_if_at(s, AT_COMPOSITE_BW));
     const int n_part = ngp_field_bwd_partials(S);
     if (n_part < 1 || n_part > b.max_partials) return NGP_EINVAL;
     STEP_TRY(ngp_field_bwd(b.feats, b.dirs, b.h, c.enc_half, c.rgb_half, b.dL_dsigmas, b.dL_drgbs, loss_scale, S, b.active, b.n_active,
                            b.dh, b.dfeats, b.partials, main_stream));
     mark(s, 6, main);
+    STEP_TRY(march_next_if_at(s, AT_MLP_BWD));
     s->n_part = n_part;
     *n_partials = n_part;
     return 0;
@@ -272,6 +304,7 @@ int ngp_stepper_front(ngp_stepper* s, const float* rays_o, const float* rays_d, 
     int k = 0;
     *n_samples = 0; *n_partials = 0;
     ++s->n_fronts;
+    s->next_o = next_o; s->next_d = next_d; s->next_main = main; s->next_side = side;
     STEP_TRY(forward_field(s, rays_o, rays_d, main, main_stream, &k));
     const int32_t S = s->S;
     *n_samples = S;
@@ -281,9 +314,14 @@ int ngp_stepper_front(ngp_stepper* s, const float* rays_o, const float* rays_d, 
                                          b.ws, b.ray_offs, b.n_active, rgb_gt, c.bg, c.lambda_opacity, grad_scale, b.stats, b.stats + 1,
                                          b.dL_drgb, b.dL_dopacity, b.fw_ws, b.fw_bytes, main_stream));
     mark(s, 4, main);
-    // the next batch's march: behind the composite forward, next to the composite / field backward (round-2 placement sweep)
-    if (next_o) STEP_TRY(do_march(s, next_o, next_d, main, side));
-    return backward_field(s, b.dL_dopacity, b.zeros, b.dL_drgb, nullptr, loss_scale, main, main_stream, n_partials);
+    STEP_TRY(march_next_if_at(s, AT_COMPOSITE_FW));
+    STEP_TRY(backward_field(s, b.dL_dopacity, b.zeros, b.dL_drgb, nullptr, loss_scale, main, main_stream, n_partials));
+    if (s->next_o != nullptr && (S <= 0 || s->march_at < AT_HASHGRID_BWD)) {      // a batch without samples skips the stages a placement may name
+        const float* o = s->next_o; const float* d = s->next_d;
+        s->next_o = s->next_d = nullptr;
+        STEP_TRY(do_march(s, o, d, main, side));
+    }
+    return 0;
 }
 
 // The same step for a caller that forms the loss itself (render()'s training branch, rendering.py:121-163, followed by
@@ -310,7 +348,7 @@ int ngp_stepper_render_forward(ngp_stepper* s, const float* rays_o, const float*
         else STEP_HIP(hipMemcpyAsync(rgb_out, b.rgb, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, main));
     }
     mark(s, 4, main);
-    if (next_o) STEP_TRY(do_march(s, next_o, next_d, main, side));
+    if (next_o) STEP_TRY(do_march(s, next_o, next_d, main, side));      // (the render-shaped halves: always behind the composite forward)
     return 0;
 }
 
@@ -349,7 +387,10 @@ int ngp_stepper_table_backward(ngp_stepper* s, int n_groups, int group, ngp_stre
     } else if (group == 0) {
         STEP_TRY(ngp_hashgrid_bwd_sliced(b.xyzs, c.xyz_min, c.xyz_max, b.dfeats, &c.meta, s->S, b.active, b.n_active, c.grid_grad16, main_stream));
     }
-    if (group == n_groups - 1) mark(s, 7, ngp_stream(main_stream));
+    if (group == n_groups - 1) {
+        mark(s, 7, ngp_stream(main_stream));
+        STEP_TRY(march_next_if_at(s, AT_HASHGRID_BWD));
+    }
     return 0;
 }
 
@@ -372,6 +413,7 @@ int ngp_stepper_update(ngp_stepper* s, float lr, int32_t step, float grad_scale,
                                  c.rgb_param, c.rgb_half, rgb_partials, c.rgb_m, c.rgb_v, c.n_rgb,
                                  n_partials, lr, c.beta1, c.beta2, c.eps, c.weight_decay, step, grad_scale, 0, found_inf, main_stream));
     mark(s, 8, ngp_stream(main_stream));
+    STEP_TRY(march_next_if_at(s, AT_ADAM));
     return 0;
 }
 

@@ -81,8 +81,11 @@ class Trainer:
         # Measured in round 2 (profiles/r02_march_sweep.txt): up to "mlp_bwd" the placements were within noise of each other while the
         # MLP backward took 68 us; with the faster MLP kernels (45 us) the march behind the composite forward -- next to the composite
         # and MLP backward instead of the hash / field forward it slows -- is 3.5 % ahead of "mlp_fwd" (0.447 vs 0.464 ms, 3 runs each).
-        self.march_at = os.environ.get("NGP_MARCH_AT", "composite_fw")
-        if self.march_at not in ("top", "hashgrid_fwd", "mlp_fwd", "composite_fw", "composite_bw", "mlp_bwd", "hashgrid_bwd"):
+        # Round 3, native stepper (profiles/r03_march_sweep.txt, three runs each on one box): behind the field forward 0.417 ms per step,
+        # behind the hash forward 0.416-0.426, composite forward 0.424, composite backward 0.422-0.427, MLP backward 0.426, top 0.429,
+        # table backward 0.44, Adam 0.47: wherever it lands the march costs the kernels next to it 17-20 us.
+        self.march_at = os.environ.get("NGP_MARCH_AT", "mlp_fwd")
+        if self.march_at not in ("top", "hashgrid_fwd", "mlp_fwd", "composite_fw", "composite_bw", "mlp_bwd", "hashgrid_bwd", "adam"):
             raise ValueError("NGP_MARCH_AT: unknown stage %r" % self.march_at)
         self.last = {}
         self.grad_hook = None    # called between backward and optimizer (multi-GPU gradient all-reduce)
@@ -102,6 +105,7 @@ class Trainer:
         self._pending_key = None     # (rays_o ptr, rays_d ptr) of the batch whose march the native stepper holds
         self._pending_keep = None    # ... and the tensors themselves (alive until consumed)
         self._timing_on = False
+        self._late_march = self.march_at in ("hashgrid_bwd", "adam")
 
     # -- stage timing ----------------------------------------------------------------------------
     def _mark(self, name):
@@ -314,6 +318,8 @@ class Trainer:
             elif self.grad_hook is not None or self.mlp_grad_hook is not None:
                 # no samples on THIS rank: the other ranks still expect it in the gradient collectives
                 self._exchange_and_update(self.zero_native(dev), None, mq)
+            if prefetch and self._late_march and not call("ngp_stepper_pending", h, no_p, nd_p):
+                call("ngp_stepper_march", h, no_p, nd_p, mq, sq)       # a late placement (NGP_MARCH_AT=hashgrid_bwd / adam) whose stage did not run natively
             self.global_step += 1
             self.last = dict(stats=B.stats, rm_samples=S, total=B.total, n_rays=n, rgb=B.rgb, opacity=B.opacity,
                              distortion=B.dist if (S > 0 and use_dist) else None, n_active=B.n_active)
