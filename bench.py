@@ -316,8 +316,23 @@ def kernel_roofline(loop, ms_per_step=None, n_steps=ROOFLINE_STEPS):
             "avg_ms": top["ms"], "samples_marched_per_launch": S, "samples_active_per_launch": A,
             "units_priced": "active samples (the backward runs on the samples up to each ray's early stop)" if top["stage"] in ("hashgrid_bwd", "mlp_bwd") else "marched samples",
             "whole_step": whole, "issue_bound": (prof or {}).get("issue_bound", {}).get(top["stage"]),
-            "profile_kernel_sum_ms": (prof or {}).get("kernel_sum_ms", {}).get(top["stage"]),
+            "profile": profile_roofline(prof, top["stage"]),
             "main_stream_stage_sum_ms": round(sum(d["ms"] for d in main), 4), "stages": stages}
+
+
+def profile_roofline(prof, stage):
+    """The same roofline entry from the committed rocprofv3 profile alone (profiles/r*_pmc_traffic.json): the stage's kernel
+    durations summed from the kernel trace (marching stream running next to them, tracing on) at the PROFILE's operating point."""
+    if not prof or stage not in prof.get("kernel_sum_ms", {}):
+        return None
+    ms = prof["kernel_sum_ms"][stage]
+    units = prof["samples_active_per_step"] if stage in ("hashgrid_bwd", "mlp_bwd") else prof["samples_marched_per_step"]
+    per_unit = {"hashgrid_bwd": 1100.0, "mlp_bwd": 300.0, "hashgrid_fwd": 588.0, "mlp_fwd": 210.0}.get(stage)
+    if per_unit is None or not ms:
+        return {"kernel_sum_ms": ms}
+    gbs = per_unit * units / (ms * 1e-3) / 1e9
+    return {"kernel_sum_ms": ms, "units": units, "achieved": round(gbs, 1), "frac": gbs / HBM_PEAK_GBS,
+            "what": "algorithmic bytes at the profile's operating point / sum of the stage's kernel durations in profiles/r*_kernel_trace_summary.txt"}
 
 
 def pmc_traffic(stage, S, A):
