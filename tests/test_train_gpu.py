@@ -153,19 +153,53 @@ def test_training_converges():
     assert last["rm_s"] < first["rm_s"]
 
 
-def test_native_ray_sampler_matches_torch_path():
-    """ngp_sample_rays == GpuDataset.sample given the same (img, pix) draws; indices are uniform."""
+def test_native_ray_sampler_matches_the_reference_pinned_ray_construction():
+    """ngp_sample_rays against the reference's data path, piece by piece: the draw is `np.random.choice(n_images, B)` x
+    `np.random.choice(W * H, B)` of BaseDataset.__getitem__ ('all_images', datasets/base.py:22-35) -- uniform, with replacement,
+    checked by chi-square on both indices; the rays are `get_rays(directions[pix], poses[img])` of datasets/ray_utils.py:50-74 as
+    NeRFSystem.forward forms them (train.py:78-91) -- compared with ngp_pl_amd.ray_utils.get_rays, which
+    tests/test_ray_utils_cpu.py pins to vectors produced by the reference's own function (origins bit for bit, directions to
+    1e-6: the reference's batched matmul vs an elementwise sum) and, on the golden poses / directions themselves, with those
+    vectors; the colours are `rays[img, pix]`."""
+    import os
+    from ngp_pl_amd import ray_utils as ru
     from ngp_pl_amd.bench_support import GpuDataset
     data = GpuDataset(64, 5, torch.device("cuda"), seed=0)
-    ro, rd, rgb, img, pix = data.sample_native(20000, step=3, seed=9, want_indices=True)
+    n = 200000
+    ro, rd, rgb, img, pix = data.sample_native(n, step=3, seed=9, want_indices=True)
     assert int(img.min()) >= 0 and int(img.max()) == 4 and int(pix.max()) < 64 * 64 and int(pix.min()) >= 0
-    ro2, rd2 = syn.get_rays(data.directions[pix.long()], data.poses[img.long()])
+    ro2, rd2 = ru.get_rays(data.directions[pix.long()], data.poses[img.long()])
     assert torch.equal(ro, ro2) and torch.allclose(rd, rd2, rtol=0, atol=1e-6)
     assert torch.equal(rgb, data.rgb[img.long(), pix.long()])
-    counts = torch.bincount(img.long(), minlength=5).float()
-    assert (counts / 20000 - 0.2).abs().max() < 0.02
+    # uniform draws: chi-square against the flat distribution (5 images: 4 dof, 99.9 % quantile 18.5; 4096 pixels: 4095 dof,
+    # mean 4095, sd 90.5 -> 5 sd)
+    ci = torch.bincount(img.long(), minlength=5).double()
+    cp = torch.bincount(pix.long(), minlength=64 * 64).double()
+    chi_i = float(((ci - n / 5) ** 2 / (n / 5)).sum()); chi_p = float(((cp - n / 4096) ** 2 / (n / 4096)).sum())
+    assert chi_i < 18.5 and abs(chi_p - 4095) < 5 * 90.5, (chi_i, chi_p)
+    # independence of the two draws: the correlation of img and pix is that of independent samples
+    r = float(torch.corrcoef(torch.stack([img.double(), pix.double()]))[0, 1])
+    assert abs(r) < 5 / n ** 0.5, r
     a = data.sample_native(100, step=4, seed=9); b = data.sample_native(100, step=4, seed=9); c = data.sample_native(100, step=5, seed=9)
     assert torch.equal(a[1], b[1]) and not torch.equal(a[1], c[1])          # deterministic in (seed, step)
+    # the reference's own vectors: rays of golden poses / directions (tests/golden/make_ray_golden.py ran datasets/ray_utils.py)
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ray_golden.npz"))
+    dirs_g = torch.from_numpy(G["dirs"]).cuda().contiguous()              # (H*W, 3) from the reference's get_ray_directions
+    pose_g = torch.from_numpy(G["c2w"]).cuda().reshape(1, 3, 4).contiguous()
+    imgs = torch.zeros(1, dirs_g.shape[0], 3, device="cuda")
+    data_g = GpuDataset.__new__(GpuDataset)
+    data_g.poses, data_g.directions, data_g.rgb, data_g.W, data_g.H, data_g.device = pose_g, dirs_g, imgs, int(G["W"]), int(G["H"]), dirs_g.device
+    ro_g, rd_g, _, img_g, pix_g = data_g.sample_native(5000, step=1, seed=2, want_indices=True)
+    o1, d1 = torch.from_numpy(G["o1"]).cuda(), torch.from_numpy(G["d1"]).cuda()       # the reference's get_rays(dirs, c2w)
+    assert torch.equal(ro_g, o1[pix_g.long()]) and torch.allclose(rd_g, d1[pix_g.long()], rtol=0, atol=1e-6)
+    # ... and per-ray poses (the reference's vectors pair pose i with pixel i): the draws that happen to pair them
+    data_g.poses = torch.from_numpy(G["c2w_b"]).cuda().contiguous()
+    data_g.rgb = torch.zeros(data_g.poses.shape[0], dirs_g.shape[0], 3, device="cuda")
+    ro_b, rd_b, _, img_b, pix_b = data_g.sample_native(20000, step=1, seed=3, want_indices=True)
+    same = (img_b == pix_b).nonzero()[:, 0]
+    assert len(same) > 100
+    o2, d2 = torch.from_numpy(G["o2"]).cuda(), torch.from_numpy(G["d2"]).cuda()
+    assert torch.equal(ro_b[same], o2[pix_b[same].long()]) and torch.allclose(rd_b[same], d2[pix_b[same].long()], rtol=0, atol=1e-6)
 
 
 def test_native_test_renderer_matches_reference_loop():
