@@ -550,6 +550,10 @@ int ngp_density_fwd_scatter(const ngp_half* feats, const ngp_half* density_w, in
  * decay_grid (C, G^3) f32 per-cell decay or NULL (erode, networks.py:262-264); seed keys the
  * counter-based RNG (pass the step number).  workspace: ngp_occupancy_update_workspace_bytes. */
 size_t ngp_occupancy_update_workspace_bytes(int cascades, int grid_size);
+/* Where an update leaves what it evaluated, as byte offsets into the workspace (diagnostics / tests: which cells were drawn, at
+ * which jittered positions, with which density): tmp (C, G^3) f32 = sigma scattered by cell index; cell_idx (n) i32 and
+ * xyzs (n,3) f32 of the LAST cascade in evaluation order (n = G^3 in warm-up, G^3 / 2 otherwise). */
+int ngp_occupancy_update_workspace_layout(int cascades, int grid_size, size_t* tmp_off, size_t* cell_idx_off, size_t* xyzs_off);
 int ngp_occupancy_update(float* density_grid, uint8_t* density_bitfield, int cascades, int grid_size,
                          float scale, float density_threshold, float decay, const float* decay_grid,
                          int warmup, uint64_t seed,

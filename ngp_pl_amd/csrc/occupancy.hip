@@ -239,6 +239,14 @@ size_t ngp_occupancy_update_workspace_bytes(int cascades, int grid_size) {
     return occ_layout(cascades, grid_size).bytes;
 }
 
+int ngp_occupancy_update_workspace_layout(int cascades, int grid_size, size_t* tmp_off, size_t* cell_idx_off, size_t* xyzs_off) {
+    if (cascades < 1 || grid_size < 4 || grid_size > 256 || (grid_size & (grid_size - 1))) return NGP_EINVAL;
+    NGP_CHECK_PTR(tmp_off); NGP_CHECK_PTR(cell_idx_off); NGP_CHECK_PTR(xyzs_off);
+    const OccLayout L = occ_layout(cascades, grid_size);
+    *tmp_off = L.tmp; *cell_idx_off = L.idx; *xyzs_off = L.xyzs;
+    return 0;
+}
+
 int ngp_occupancy_update(float* density_grid, uint8_t* density_bitfield, int cascades, int grid_size, float scale,
                          float density_threshold, float decay, const float* decay_grid, int warmup, uint64_t seed,
                          const float* xyz_min, const float* xyz_max, const ngp_half* table, const ngp_grid_meta* meta,

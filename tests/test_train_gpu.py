@@ -281,23 +281,17 @@ def test_device_frame_loop_unbounded_scene():
 
 
 def _occ_workspace_views(m):
-    """Views into the ngp_occupancy_update workspace (layout of csrc/occupancy.hip: 256-byte aligned
-    tmp, words, counts, prefix, idx, xyzs, ...) for cascade-count 1."""
+    """What the last ngp_occupancy_update evaluated (cells, jittered positions, scattered sigma), located through the library's
+    own layout query."""
+    import ctypes as C
+    from ngp_pl_amd import _lib
     cells = m.grid_size ** 3
-    n_words = cells // 64
-    off = 0
-
-    def take(nbytes):
-        nonlocal off
-        o = off
-        off += (nbytes + 255) // 256 * 256
-        return o
-    o_tmp = take(m.cascades * cells * 4); take(n_words * 8); take(n_words * 4); take((n_words + 1) * 4)
-    o_idx = take(cells * 4); o_xyz = take(cells * 12)
+    o_tmp, o_idx, o_xyz = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    _lib.call("ngp_occupancy_update_workspace_layout", m.cascades, m.grid_size, C.byref(o_tmp), C.byref(o_idx), C.byref(o_xyz))
     ws = m._occ_ws
-    idx = ws[o_idx:o_idx + cells * 4].view(torch.int32)
-    xyz = ws[o_xyz:o_xyz + cells * 12].view(torch.float32).view(-1, 3)
-    tmp = ws[o_tmp:o_tmp + cells * 4].view(torch.float32)
+    idx = ws[o_idx.value:o_idx.value + cells * 4].view(torch.int32)
+    xyz = ws[o_xyz.value:o_xyz.value + cells * 12].view(torch.float32).view(-1, 3)
+    tmp = ws[o_tmp.value:o_tmp.value + cells * 4].view(torch.float32)
     return idx, xyz, tmp
 
 
