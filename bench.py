@@ -387,7 +387,7 @@ def usable_cpus():
     return max(1, n)
 
 
-def cpu_baseline(model, data, budget_s=20.0, timeout_s=75.0):
+def cpu_baseline(model, data, budget_s=20.0, timeout_s=110.0):
     """The CPU oracle timed on the host cores on BASELINE.json configs[0] (256 rays/batch): full
     step = AABB + march + composite fwd/bwd with the reference's own kernels compiled for the CPU
     (oracle/_ref, falls back to our C restatement) + hash grid / MLPs / SH / Adam as fp32 torch-CPU
@@ -705,7 +705,7 @@ def main():
         keeper.leg("roofline", lambda: kernel_roofline(loop, r["ms_per_step"]), 30.0)
         if "cpu_baseline" in legs:
             # (the driver's contract asks for this object: second in line, in a child process the parent can kill)
-            keeper.leg("cpu_baseline", lambda: cpu_baseline(loop.model, loop.data), 90.0)
+            keeper.leg("cpu_baseline", lambda: cpu_baseline(loop.model, loop.data), 125.0)
         if not args.no_render:
             # device-driven frame loop; chunk_scale/probe_cap only regroup the SAME per-ray samples into fewer
             # iterations (tests/test_train_gpu.py::test_device_frame_loop_matches_host_loop)
