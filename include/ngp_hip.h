@@ -137,6 +137,15 @@ int ngp_raymarching_train_write(const float* rays_o, const float* rays_d, const 
                                 float* xyzs, float* dirs, float* deltas, float* ts,
                                 ngp_stream_t stream);
 
+/* ngp_raymarching_train_write that also lists the ids of every ray's first min(N, first_k) samples (first_k in 1..64):
+ * list_k[ray * first_k + k] = start + k, or -1 where the ray has fewer (a padded list of n_rays * first_k entries), and clears
+ * *n_clear (may be NULL) on the side: the first round of the two-round forward (ngp_stepper, "two-round forward" below). */
+int ngp_raymarching_train_write_k(const float* rays_o, const float* rays_d, const int64_t* rays_a,
+                                  const float* t_scratch, float scale, float exp_step_factor,
+                                  int grid_size, int max_samples, int n_rays,
+                                  float* xyzs, float* dirs, float* deltas, float* ts,
+                                  int first_k, int32_t* list_k, int32_t* n_clear, ngp_stream_t stream);
+
 /* vren.raymarching_test (binding.cpp:84-106, raymarching.cu:335-454).  hits_t (R_total,2) is
  * advanced in place; alive_indices (N_alive) i64; outputs are dense (N_alive,N_samples,.) and
  * fully written (unused slots zero), N_eff_samples (N_alive) i32.  Keeps the reference's
@@ -169,6 +178,14 @@ int ngp_composite_train_fw(const float* sigmas, const float* rgbs, const float* 
                            float* ws, int32_t* n_active_per_ray /* optional (R) i32: min(N, total+1) per row */,
                            ngp_stream_t stream);
 
+/* Two-round forward: which rays are still transparent behind their first first_k (<= 64) samples?  For every ray with N > first_k
+ * whose transmittance after its first first_k samples is above T_threshold (the composite's own arithmetic on sigmas / deltas at
+ * those samples), the ids of its remaining samples are appended to list_rest (*n_rest += N - first_k; order unspecified).  The
+ * samples NOT listed lie behind their ray's early stop: volumerendering.cu:20-44 never reads them, so neither does the composite
+ * that follows -- the field need not be evaluated there. */
+int ngp_composite_probe(const float* sigmas, const float* deltas, const int64_t* rays_a, int first_k, float T_threshold,
+                        int n_rays, int32_t* list_rest, int32_t* n_rest, ngp_stream_t stream);
+
 /* ngp_composite_train_fw + ngp_active_scan + ngp_nerf_loss for the training step in two launches
  * instead of three (train.py:159-176: render -> NeRFLoss -> mean): every wave also forms its
  * ray's loss terms and backward seeds (dL_drgb (R,3), dL_dopacity (R), already multiplied by
@@ -178,6 +195,15 @@ int ngp_composite_train_fw(const float* sigmas, const float* rgbs, const float* 
  * ngp_raymarching_train_count writes it.  bg: 3 floats or NULL.  ray_offsets and workspace
  * (ngp_composite_train_fw_loss_workspace_bytes bytes, scratch) must be 16-byte aligned. */
 size_t ngp_composite_train_fw_loss_workspace_bytes(int n_rays);
+/* (_h: the same with the live-sample count also stored to n_active_host, pinned device-mapped host memory, may be NULL) */
+int ngp_composite_train_fw_loss_h(const float* sigmas, const float* rgbs, const float* deltas,
+                                  const float* ts, const int64_t* rays_a, float T_threshold,
+                                  int n_rays, int n_samples, int64_t* total_samples, float* opacity,
+                                  float* depth, float* rgb, float* ws, int32_t* ray_offsets,
+                                  int32_t* n_active, int32_t* n_active_host, const float* gt_rgb, const float* bg,
+                                  float lambda_opacity, float grad_scale, float* loss, float* sq_err,
+                                  float* dL_drgb, float* dL_dopacity, void* workspace,
+                                  size_t workspace_bytes, ngp_stream_t stream);
 int ngp_composite_train_fw_loss(const float* sigmas, const float* rgbs, const float* deltas,
                                 const float* ts, const int64_t* rays_a, float T_threshold,
                                 int n_rays, int n_samples, int64_t* total_samples, float* opacity,
@@ -260,6 +286,13 @@ int ngp_hashgrid_fwd_lds(const float* x, const float* xyz_min, const float* xyz_
 int ngp_hashgrid_fwd_n(const float* x, const float* xyz_min, const float* xyz_max,
                        const ngp_half* table, const ngp_grid_meta* meta, int n_samples_max,
                        const int32_t* n_dev, ngp_half* feats, ngp_stream_t stream);
+/* Encode forward over an explicit list of sample ids: work item j < n_list (n_list_max on the host; min(*n_list_dev, n_list_max) if
+ * n_list_dev is given) encodes sample list[j] and writes feats[level][list[j]] (level stride n_samples); entries outside
+ * [0, n_samples) are padding and skipped.  Per-sample results, independent of the list order. */
+int ngp_hashgrid_fwd_list(const float* x, const float* xyz_min, const float* xyz_max,
+                          const ngp_half* table, const ngp_grid_meta* meta, int n_samples,
+                          const int32_t* list, int n_list_max, const int32_t* n_list_dev,
+                          ngp_half* feats, ngp_stream_t stream);
 /* Encode backward w.r.t. the table: scatter-add of w*dL/dfeat into grad_table (total,2) f16
  * (packed f16 atomics, as tiny-cuda-nn) or f32 when grad_is_f32.  Accumulates (caller zeroes). */
 int ngp_hashgrid_bwd(const float* x, const float* xyz_min, const float* xyz_max,
@@ -359,6 +392,13 @@ int ngp_field_fwd_n(const ngp_half* feats, const float* dirs,
                     const ngp_half* density_w, const ngp_half* rgb_w, int n_samples_max,
                     const int32_t* n_dev, float* sigmas, float* rgbs, ngp_half* h_out,
                     ngp_stream_t stream);
+
+/* ngp_field_fwd over an explicit list of sample ids (see ngp_hashgrid_fwd_list): inputs are read and sigmas / rgbs / h_out written
+ * at the listed samples' own places; feats has level stride n_samples. */
+int ngp_field_fwd_list(const ngp_half* feats, const float* dirs,
+                       const ngp_half* density_w, const ngp_half* rgb_w, int n_samples,
+                       const int32_t* list, int n_list_max, const int32_t* n_list_dev,
+                       float* sigmas, float* rgbs, ngp_half* h_out, ngp_stream_t stream);
 
 /* Backward of the two halves.  Each recomputes its forward, runs dgrad in registers and emits
  * per-workgroup partial weight gradients (n_partials, n_params) f32, n_partials =
@@ -644,7 +684,12 @@ typedef struct ngp_step_buffers {
     float* dist; const float* zeros; const float* dist_seed;
     /* two sets of march records (the march of batch k+1 runs while step k reads its own) */
     float* hits_t[2]; int64_t* rays_a[2]; float* noise[2]; float* scratch[2];
-    int32_t* counter[2];                           /* pinned, device-mapped host memory: {S, R} of a march */
+    int32_t* counter[2];                           /* pinned, device-mapped host memory, 4 x i32 each: {S, R} of a march, [2] = the live-sample
+                                                      count of the step that consumed it (written by the composite's tail kernel) */
+    /* two-round forward (optional: all three NULL disables it) */
+    int32_t* list_k;                               /* (n_rays * 64) ids of the rays' first samples */
+    int32_t* list_rest;                            /* (cap) ids of the continuing rays' remaining samples */
+    int32_t* two_round_counts;                     /* 4 x i32 on the device, zeroed by the caller once */
     /* scalars and workspaces */
     int32_t* n_active; float* stats;               /* stats[0] = loss, stats[1] = sum of squared errors */
     float* partials; int32_t max_partials;         /* [max_partials x (n_density + n_rgb)] f32 */
@@ -652,6 +697,16 @@ typedef struct ngp_step_buffers {
     void* bin_ws; size_t bin_bytes; int32_t bin_max; /* binned table backward: workspace for up to bin_max samples (0: always one-pass) */
 } ngp_step_buffers;
 
+/* Two-round forward (NGP_TWO_ROUND = auto (default) | on | off; first K = NGP_TWO_ROUND_K, default 32).  Late in training a few per
+ * cent of the marched samples lie in front of their ray's early stop (measured: 5 % after 25 000 steps), yet hash grid and field
+ * were evaluated on all of them.  When the previous step's live fraction is below 0.15 (back above 0.25: off again) front() runs:
+ * sample expansion + padded list of every ray's first K samples -> hash grid + field on that list -> ngp_composite_probe lists
+ * the rest of the rays that are still transparent -> hash grid + field on that list -> the unchanged composite.  Exactly
+ * equivalent: the composite never reads a sample behind a ray's stop (volumerendering.cu:20-44), and every sample in front of it
+ * has been evaluated by the same per-sample kernels (tests/test_train_gpu.py::test_two_round_forward_is_bit_identical).  What it
+ * buys is modest because rays stop deep, not early (the occupied shell in front of a surface is ~20 samples thick): 0.304 -> 0.288
+ * ms per step after 8 000 steps, 0.302 -> 0.283 after 25 000 (profiles/r03_two_round_forward.txt); K = 8 loses.  Not used with
+ * the distortion loss (its kernels walk every sample's ws) and never at the bench's operating point (half of the samples live). */
 typedef struct ngp_stepper ngp_stepper;
 int ngp_stepper_create(const ngp_stepper_config* config, const ngp_step_buffers* buffers, ngp_stepper** out);
 int ngp_stepper_destroy(ngp_stepper* s);
@@ -664,6 +719,8 @@ int ngp_stepper_march(ngp_stepper* s, const float* rays_o, const float* rays_d, 
 int ngp_stepper_pending(const ngp_stepper* s, const float* rays_o, const float* rays_d);
 /* Which of the two march record sets (hits_t / rays_a / noise / scratch / counter) the last front() consumed: 0 or 1. */
 int ngp_stepper_last_set(const ngp_stepper* s);
+/* Did the last front() evaluate the field in two rounds? (1 / 0) */
+int ngp_stepper_two_rounds(const ngp_stepper* s);
 /* Waits for a pending march and forgets it (the batch it was made for is not going to be stepped). */
 int ngp_stepper_drop_pending(ngp_stepper* s);
 /* The step up to the field backward, on main_stream.  The pending march must be the one of (rays_o, rays_d).

@@ -45,6 +45,7 @@ class StepBuffersC(C.Structure):
                           "dh", "dfeats", "ws_incl", "wts_incl", "dL_dws",
                           "total", "opacity", "depth", "rgb", "dL_drgb", "dL_dopacity", "ray_offs", "dist", "zeros", "dist_seed")] + \
         [("hits_t", P * 2), ("rays_a", P * 2), ("noise", P * 2), ("scratch", P * 2), ("counter", P * 2),
+         ("list_k", P), ("list_rest", P), ("two_round_counts", P),
          ("n_active", P), ("stats", P), ("partials", P), ("max_partials", C.c_int32),
          ("fw_ws", P), ("fw_bytes", C.c_size_t), ("bin_ws", P), ("bin_bytes", C.c_size_t), ("bin_max", C.c_int32)]
 
@@ -63,16 +64,21 @@ _PROTOS = {
     "ngp_cells_to_xyz": [P, P, I, I, F, P, P],
     "ngp_raymarching_train_count": [P, P, P, P, I, F, F, P, I, I, I, P, P, P, P],
     "ngp_raymarching_train_write": [P, P, P, P, F, F, I, I, I, P, P, P, P, P],
+    "ngp_raymarching_train_write_k": [P, P, P, P, F, F, I, I, I, P, P, P, P, I, P, P, P],
     "ngp_raymarching_test": [P, P, P, P, P, I, F, F, I, I, I, I, P, P, P, P, P, P],
     "ngp_composite_train_fw": [P, P, P, P, P, F, I, I, P, P, P, P, P, P, P],
     "ngp_composite_train_bw": [P] * 13 + [F, I, I, P, P, P, P, P, P, P],
     "ngp_active_scan": [P, I, P, P],
     "ngp_composite_train_fw_loss": [P, P, P, P, P, F, I, I, P, P, P, P, P, P, P, P, P, F, F, P, P, P, P, P, C.c_size_t, P],
+    "ngp_composite_probe": [P, P, P, I, F, I, P, P, P],
+    "ngp_composite_train_fw_loss_h": [P, P, P, P, P, F, I, I, P, P, P, P, P, P, P, P, P, P, F, F, P, P, P, P, P, C.c_size_t, P],
     "ngp_composite_test_fw": [P, P, P, P, P, F, P, I, I, P, P, P, P],
     "ngp_distortion_loss_fw": [P, P, P, P, I, I, P, P, P, P],
     "ngp_distortion_loss_bw": [P, P, P, P, P, P, P, I, I, P, P],
     "ngp_grid_meta_init": [C.POINTER(GridMeta), I, I, I, I, F],
     "ngp_hashgrid_fwd": [P, P, P, P, C.POINTER(GridMeta), I, P, P],
+    "ngp_hashgrid_fwd_list": [P, P, P, P, C.POINTER(GridMeta), I, P, I, P, P, P],
+    "ngp_field_fwd_list": [P, P, P, P, I, P, I, P, P, P, P, P],
     "ngp_hashgrid_fwd_lds": [P, P, P, P, C.POINTER(GridMeta), I, I, P, P],
     "ngp_hashgrid_bwd": [P, P, P, P, C.POINTER(GridMeta), I, P, I, P],
     "ngp_hashgrid_bwd_sliced": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P, P],
@@ -116,6 +122,7 @@ _PROTOS = {
     "ngp_stepper_march": [P, P, P, P, P],
     "ngp_stepper_pending": [P, P, P],
     "ngp_stepper_last_set": [P],
+    "ngp_stepper_two_rounds": [P],
     "ngp_stepper_drop_pending": [P],
     "ngp_stepper_front": [P, P, P, P, P, P, F, F, P, P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "ngp_stepper_table_backward": [P, I, I, P],
@@ -139,7 +146,7 @@ _PROTOS = {
     "ngp_render_test_frame": [P, P, P, P, I, F, F, I, I, F, P, P, P, C.POINTER(GridMeta), P, P, I, I, I,
                               C.POINTER(C.c_float), P, C.c_size_t, P, P, P, P, C.POINTER(C.c_int32), P],
 }
-_COUNT_QUERIES = ("ngp_field_bwd_partials", "ngp_mlp_bwd_partials", "ngp_abi_version", "ngp_stepper_pending", "ngp_stepper_last_set")
+_COUNT_QUERIES = ("ngp_field_bwd_partials", "ngp_mlp_bwd_partials", "ngp_abi_version", "ngp_stepper_pending", "ngp_stepper_last_set", "ngp_stepper_two_rounds")
 
 _lib = None
 

@@ -55,6 +55,7 @@ struct FwTail {
     const float* gt; const float* bg; float lambda_o, grad_scale;
     float* loss; float* sq_err; float* dL_drgb; float* dL_dopacity;
     int32_t* n_active; float* row_loss; float* row_sq;
+    int32_t* n_active_host;          // optional: the same count into pinned host memory (the stepper's live-fraction estimate)
 };
 
 __device__ __forceinline__ void composite_fw_ray(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
@@ -156,9 +157,47 @@ composite_fw_tail_kernel(FwTail t, int32_t* __restrict__ n_act, int n_rays) {
 #pragma unroll
         for (int w = 0; w < 16; ++w) { tl += s_l[w]; te += s_e[w]; }
         *t.n_active = s_carry;
+        if (t.n_active_host) *t.n_active_host = s_carry;
         *t.loss = tl;
         if (t.sq_err) *t.sq_err = te;
     }
+}
+
+// Two-round forward (csrc/stepper.hip): after the field has been evaluated on every ray's first first_k samples, which rays are
+// still transparent there?  One wave per ray: the transmittance behind the first min(N, first_k) samples by the composite's own
+// arithmetic (chunk_transmittance; first_k <= 64: one chunk); a ray that has not stopped and has samples left appends the ids
+// of the rest to list_rest (one atomic per ray; the order of the list is irrelevant to the per-sample kernels it feeds).
+// Exactly the samples volumerendering.cu:20-44 would go on to read are evaluated in the second round: the composite that
+// follows never looks behind a ray's stop.
+__global__ void __launch_bounds__(256)
+composite_probe_kernel(const float* __restrict__ sigmas, const float* __restrict__ deltas, const int64_t* __restrict__ rays_a,
+                       int first_k, float T_threshold, int n_rays, int32_t* __restrict__ list_rest, int32_t* __restrict__ n_rest) {
+    __shared__ int s_rest[4], s_base;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + wave;
+    int rest = 0;
+    int64_t start = 0;
+    if (n < n_rays) {
+        start = rays_a[3 * (size_t)n + 1];
+        const int N = (int)rays_a[3 * (size_t)n + 2];
+        if (N > first_k) {
+            const bool valid = lane < first_k;
+            const size_t s = (size_t)start + (valid ? lane : 0);
+            const float sigma = valid ? sigmas[s] : 0.f, delta = valid ? deltas[s] : 0.f;
+            const ChunkT c = chunk_transmittance(sigma, delta, valid, 1.0f, T_threshold, lane);
+            if (__ballot(valid && c.T_after <= T_threshold) == 0ull) rest = N - first_k;      // still transparent behind its first samples
+        }
+    }
+    if (lane == 0) s_rest[wave] = rest;
+    __syncthreads();
+    if (threadIdx.x == 0) {                                    // one atomic per workgroup (4 rays), none if nothing continues
+        const int total = (s_rest[0] + s_rest[1]) + (s_rest[2] + s_rest[3]);
+        s_base = total ? atomicAdd(n_rest, total) : 0;
+    }
+    __syncthreads();
+    int base = s_base;
+    for (int w = 0; w < wave; ++w) base += s_rest[w];
+    for (int k = lane; k < rest; k += 64) list_rest[base + k] = (int32_t)(start + first_k + k);
 }
 
 template <bool LOSS>
@@ -346,6 +385,16 @@ int ngp_composite_train_fw(const float* sigmas, const float* rgbs, const float* 
     return NGP_LAUNCH_RESULT();
 }
 
+int ngp_composite_probe(const float* sigmas, const float* deltas, const int64_t* rays_a, int first_k, float T_threshold,
+                        int n_rays, int32_t* list_rest, int32_t* n_rest, ngp_stream_t stream) {
+    if (n_rays < 0 || first_k < 1 || first_k > 64) return NGP_EINVAL;
+    if (n_rays == 0) return 0;
+    NGP_CHECK_PTR(sigmas); NGP_CHECK_PTR(deltas); NGP_CHECK_PTR(rays_a); NGP_CHECK_PTR(list_rest); NGP_CHECK_PTR(n_rest);
+    hipLaunchKernelGGL(composite_probe_kernel, dim3(ngp_div_up((long long)n_rays * 64, 256)), dim3(256), 0, ngp_stream(stream),
+                       sigmas, deltas, rays_a, first_k, T_threshold, n_rays, list_rest, n_rest);
+    return NGP_LAUNCH_RESULT();
+}
+
 size_t ngp_composite_train_fw_loss_workspace_bytes(int n_rays) { return n_rays < 0 ? 0 : 8 * (((size_t)n_rays + 3) & ~(size_t)3); }
 
 int ngp_composite_train_fw_loss(const float* sigmas, const float* rgbs, const float* deltas, const float* ts,
@@ -354,6 +403,17 @@ int ngp_composite_train_fw_loss(const float* sigmas, const float* rgbs, const fl
                                 int32_t* ray_offsets, int32_t* n_active, const float* gt_rgb, const float* bg,
                                 float lambda_opacity, float grad_scale, float* loss, float* sq_err, float* dL_drgb,
                                 float* dL_dopacity, void* workspace, size_t workspace_bytes, ngp_stream_t stream) {
+    return ngp_composite_train_fw_loss_h(sigmas, rgbs, deltas, ts, rays_a, T_threshold, n_rays, n_samples, total_samples, opacity, depth, rgb,
+                                         ws, ray_offsets, n_active, nullptr, gt_rgb, bg, lambda_opacity, grad_scale, loss, sq_err, dL_drgb,
+                                         dL_dopacity, workspace, workspace_bytes, stream);
+}
+
+int ngp_composite_train_fw_loss_h(const float* sigmas, const float* rgbs, const float* deltas, const float* ts,
+                                  const int64_t* rays_a, float T_threshold, int n_rays, int n_samples,
+                                  int64_t* total_samples, float* opacity, float* depth, float* rgb, float* ws,
+                                  int32_t* ray_offsets, int32_t* n_active, int32_t* n_active_host, const float* gt_rgb, const float* bg,
+                                  float lambda_opacity, float grad_scale, float* loss, float* sq_err, float* dL_drgb,
+                                  float* dL_dopacity, void* workspace, size_t workspace_bytes, ngp_stream_t stream) {
     if (n_rays <= 0 || n_samples < 0) return NGP_EINVAL;
     NGP_CHECK_PTR(rays_a); NGP_CHECK_PTR(total_samples); NGP_CHECK_PTR(opacity); NGP_CHECK_PTR(depth); NGP_CHECK_PTR(rgb);
     NGP_CHECK_PTR(ray_offsets); NGP_CHECK_PTR(n_active); NGP_CHECK_PTR(gt_rgb); NGP_CHECK_PTR(loss); NGP_CHECK_PTR(dL_drgb);
@@ -363,6 +423,7 @@ int ngp_composite_train_fw_loss(const float* sigmas, const float* rgbs, const fl
     FwTail t;
     t.gt = gt_rgb; t.bg = bg; t.lambda_o = lambda_opacity; t.grad_scale = grad_scale;
     t.loss = loss; t.sq_err = sq_err; t.dL_drgb = dL_drgb; t.dL_dopacity = dL_dopacity; t.n_active = n_active;
+    t.n_active_host = n_active_host;
     t.row_loss = static_cast<float*>(workspace);
     t.row_sq = t.row_loss + ((n_rays + 3) & ~3);                          // keeps the float4 loads of the tail aligned
     hipLaunchKernelGGL(composite_train_fw_kernel<true>, dim3(ngp_div_up((long long)n_rays * 64, 256)), dim3(256), 0, ngp_stream(stream),

@@ -120,6 +120,48 @@ hashgrid_fwd_kernel(const float* __restrict__ x, const float* __restrict__ xyz_m
 }
 
 
+// The same forward over an explicit LIST of sample ids (the two-round forward of the training step, csrc/stepper.hip): work item j
+// of n_list (host bound; *n_list_dev on the device) encodes sample list[j] and writes its features at the sample's own place in the
+// level-major array (level stride = n_samples).  Ids come in runs of consecutive samples of a ray, so the streams stay mostly
+// coalesced; results are per-sample, i.e. independent of the list order.
+__global__ void __launch_bounds__(256)
+hashgrid_fwd_list_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const float* __restrict__ xyz_max,
+                         const half2_t* __restrict__ table, GridMeta meta, int n_samples, const int32_t* __restrict__ list,
+                         int n_list, int n_chunks, const int32_t* __restrict__ n_list_dev, half2_t* __restrict__ feats) {
+    int level, chunk;
+    if (!map_block(meta.n_levels, n_chunks, level, chunk)) return;
+    if (n_list_dev != nullptr) n_list = min(*n_list_dev, n_list);
+    const uint32_t res = meta.resolution[level];
+    const uint32_t size = meta.offset[level + 1] - meta.offset[level];
+    const half2_t* __restrict__ tab = table + meta.offset[level];
+    const Box box = load_box(xyz_min, xyz_max);
+    const bool hashed = level_is_hashed(res, size);
+    const float scale = meta.scale[level];
+    // the launch has a FIXED number of chunks per level (a list whose length only the device knows would otherwise be launched
+    // for its bound: 20 000 workgroups that look at the count and leave cost more than the work); chunks stride over the list
+    for (int j = chunk * 256 + threadIdx.x; j < n_list; j += n_chunks * 256) {
+        const int i = list[j];
+        if ((unsigned)i >= (unsigned)n_samples) continue;                // padding entries are -1
+        uint32_t p[3], idx[8]; float f[3];
+        cell_of(x, box, (size_t)i, scale, p, f);
+        if (hashed) corner_indices<true>(p, res, size, idx);
+        else corner_indices<false>(p, res, size, idx);
+        half2_t v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = tab[idx[c]];
+        float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float w = corner_weight(c, f);
+            o0 = fmaf(w, (float)v[c][0], o0);
+            o1 = fmaf(w, (float)v[c][1], o1);
+        }
+        half2_t out; out[0] = (_Float16)o0; out[1] = (_Float16)o1;
+        __builtin_nontemporal_store(out, feats + (size_t)level * n_samples + i);
+    }
+}
+
+
 // ---- coarse levels with their tables RESIDENT IN LDS (north_star: "8-corner trilinear gather staged through LDS") ----------
 // Levels 0 .. n_lds-1 of the reference configuration are dense and small (16^3, 22^3, 28^3 entries: 16 + 43 + 88 = 147 KB of
 // half2, inside one CU's 160 KB): a persistent 1024-thread workgroup per CU copies them into LDS once and serves every gather
@@ -588,6 +630,20 @@ int ngp_hashgrid_fwd_n(const float* x, const float* xyz_min, const float* xyz_ma
     const int n_chunks = ngp_div_up(n_samples, 256);
     hipLaunchKernelGGL(hashgrid_fwd_kernel<1>, dim3(n_blocks_for(meta->n_levels, n_chunks)), dim3(256), 0, ngp_stream(stream),
                        x, xyz_min, xyz_max, (const half2_t*)table, to_dev_meta(meta), n_samples, n_chunks, n_dev, (half2_t*)feats);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_hashgrid_fwd_list(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* table,
+                          const ngp_grid_meta* meta, int n_samples, const int32_t* list, int n_list_max,
+                          const int32_t* n_list_dev, ngp_half* feats, ngp_stream_t stream) {
+    if (n_samples < 0 || n_list_max < 0 || !meta || meta->n_features != 2) return NGP_EINVAL;
+    if (n_samples == 0 || n_list_max == 0) return 0;
+    NGP_CHECK_PTR(x); NGP_CHECK_PTR(xyz_min); NGP_CHECK_PTR(xyz_max); NGP_CHECK_PTR(table); NGP_CHECK_PTR(feats); NGP_CHECK_PTR(list);
+    int n_chunks = ngp_div_up(n_list_max, 256);
+    if (n_chunks > 128) n_chunks = 128;              // 2048 workgroups at most: 8 per CU, each striding over the list
+    hipLaunchKernelGGL(hashgrid_fwd_list_kernel, dim3(n_blocks_for(meta->n_levels, n_chunks)), dim3(256), 0, ngp_stream(stream),
+                       x, xyz_min, xyz_max, (const half2_t*)table, to_dev_meta(meta), n_samples, list, n_list_max, n_chunks, n_list_dev,
+                       (half2_t*)feats);
     return NGP_LAUNCH_RESULT();
 }
 

@@ -117,10 +117,8 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const
     const int ns = plan.n_slices[level];
     if (blockIdx.x == 0 && threadIdx.x < 16) ws.queue[threadIdx.x] = 0;   // the slice owners' task counters, one per launch group (they start after this kernel)
     int32_t* __restrict__ dir = ws.dir + (size_t)level * MAX_SLICES * n_chunks + chunk;     // + s * n_chunks
-    if (chunk * CHUNK >= n) {                                      // nothing here: empty segments
-        for (int i = threadIdx.x; i < ns; i += BIN_THREADS) dir[(size_t)i * n_chunks] = 0;
-        return;
-    }
+    if (chunk * CHUNK >= n) return;                                // nothing here, and no slice owner reads this chunk's directory column:
+                                                                   // they stop at the last chunk that holds live samples (apply_kernel)
     for (int i = threadIdx.x; i < ns; i += BIN_THREADS) s_cnt[i] = 0;
     __syncthreads();
     const uint32_t res = meta.resolution[level];
@@ -485,13 +483,18 @@ __device__ __forceinline__ void apply_segments_dense_runs(long long* lds, uint32
 __global__ void __launch_bounds__(APPLY_THREADS, NGP_APPLY_WAVES_PER_EU)
 apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const float* __restrict__ xyz_max,
              const half2_t* __restrict__ dfeats, GridMeta meta, BinPlan plan, BinWs ws, int n_samples,
-             const int32_t* __restrict__ active, half2_t* __restrict__ grad_table, int group, int task_begin, int task_end) {
+             const int32_t* __restrict__ active, const int32_t* __restrict__ n_active, half2_t* __restrict__ grad_table,
+             int group, int task_begin, int task_end) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     long long* lds = reinterpret_cast<long long*>(smem_raw);
     __shared__ int s_task[2];                                          // s_task[k & 1]: id of the workgroup's k-th task
     __shared__ int s_dir[MAX_CHUNKS];
     const Box box = load_box(xyz_min, xyz_max);
-    const int n_chunks = plan.n_chunks;
+    const int dir_pitch = plan.n_chunks;                               // the directory / slot layout is planned for n_samples ...
+    // ... the loops stop at the last chunk that holds live samples: late in training a few per cent of the marched samples are
+    // live, and a task's fixed cost was dominated by walking hundreds of empty directory entries
+    const int n_live = n_active ? min(*n_active, n_samples) : n_samples;
+    const int n_chunks = min(plan.n_chunks, (n_live + CHUNK - 1) / CHUNK);
     const int tid = threadIdx.x;
     // Three barriers per task, none of them behind a global round trip: the id of task k+1 is requested from the queue at the
     // top of task k and parked in LDS at its end; the accumulators are cleared by the write-out pass that reads them (the
@@ -517,7 +520,7 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
         const uint32_t size = meta.offset[level + 1] - meta.offset[level];
         const uint32_t lo = (uint32_t)slice * SLICE2;
         const uint32_t len = min(SLICE2, size - lo);
-        const int32_t* __restrict__ dir = ws.dir + ((size_t)level * MAX_SLICES + slice) * n_chunks;
+        const int32_t* __restrict__ dir = ws.dir + ((size_t)level * MAX_SLICES + slice) * dir_pitch;
         for (int c = tid; c < n_chunks; c += APPLY_THREADS) s_dir[c] = dir[c];
         __syncthreads();
 #ifdef NGP_BIN_TIMING
@@ -715,7 +718,7 @@ int ngp_hashgrid_bwd_binned_group(const float* x, const float* xyz_min, const fl
     if (n_tasks > 0) {
         const int n_wg = n_tasks < NGP_APPLY_WGS ? n_tasks : NGP_APPLY_WGS;
         apply_kernel<<<dim3(n_wg), dim3(APPLY_THREADS), smem, st>>>(
-            x, xyz_min, xyz_max, (const half2_t*)dfeats, dm, P, ws, n_samples, active_idx, (half2_t*)grad_table, group, task_begin, task_end);
+            x, xyz_min, xyz_max, (const half2_t*)dfeats, dm, P, ws, n_samples, active_idx, n_active, (half2_t*)grad_table, group, task_begin, task_end);
     }
     if (group == 0 && L.merge_entries > 0)      // the K-split levels all sit in group 0
         merge_kernel<<<dim3(ngp_div_up(L.merge_entries, 256)), dim3(256), 0, st>>>(dm, P, ws, (half2_t*)grad_table);

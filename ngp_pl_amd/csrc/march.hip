@@ -553,18 +553,24 @@ march_train_scan_kernel(int64_t* __restrict__ rays_a, int n_rays, int32_t* __res
 
 // Pass 2 of train marching: expand (ray, k) -> packed sample.  One wave per ray, lanes stride
 // the ray's samples: scratch reads and all four output streams are coalesced.
+// first_k > 0 (two-round forward, csrc/stepper.hip): the ids of every ray's first min(N, first_k) samples are also written to
+// list_k[ray * first_k + k] (-1 where the ray has fewer: a padded list of n_rays * first_k entries -- no counter, no atomics; 8192
+// atomics on one address cost 28 us), and *n_clear (the counter of the second round's list) is cleared on the side.
 __global__ void __launch_bounds__(256)
 march_train_write_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                          const int64_t* __restrict__ rays_a, const float* __restrict__ t_scratch,
                          MarchParams p, int max_samples, int n_rays,
                          float* __restrict__ xyzs, float* __restrict__ dirs,
-                         float* __restrict__ deltas, float* __restrict__ ts) {
+                         float* __restrict__ deltas, float* __restrict__ ts,
+                         int first_k, int32_t* __restrict__ list_k, int32_t* __restrict__ n_clear) {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
+    if (first_k > 0 && blockIdx.x == 0 && threadIdx.x == 0 && n_clear) *n_clear = 0;
     if (wave >= n_rays) return;
     const int64_t r = rays_a[3 * (size_t)wave];
     const int64_t start = rays_a[3 * (size_t)wave + 1];
     const int n = (int)rays_a[3 * (size_t)wave + 2];
+    if (first_k > 0 && lane < first_k) list_k[(size_t)wave * first_k + lane] = lane < n ? (int32_t)(start + lane) : -1;
     const float ox = rays_o[3 * r], oy = rays_o[3 * r + 1], oz = rays_o[3 * r + 2];
     const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz = rays_d[3 * r + 2];
     const float* __restrict__ row = t_scratch + (size_t)r * max_samples;
@@ -1170,7 +1176,22 @@ int ngp_raymarching_train_write(const float* rays_o, const float* rays_d, const 
     // xyzs..ts may be null only when S == 0, which the kernel never dereferences
     const MarchParams p = make_march_params(nullptr, 1, grid_size, scale, scale, exp_step_factor, max_samples);
     hipLaunchKernelGGL(march_train_write_kernel, dim3(ngp_div_up((long long)n_rays * 64, 256)), dim3(256), 0, ngp_stream(stream),
-                       rays_o, rays_d, rays_a, t_scratch, p, max_samples, n_rays, xyzs, dirs, deltas, ts);
+                       rays_o, rays_d, rays_a, t_scratch, p, max_samples, n_rays, xyzs, dirs, deltas, ts, 0, (int32_t*)nullptr,
+                       (int32_t*)nullptr);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_raymarching_train_write_k(const float* rays_o, const float* rays_d, const int64_t* rays_a,
+                                  const float* t_scratch, float scale, float exp_step_factor,
+                                  int grid_size, int max_samples, int n_rays,
+                                  float* xyzs, float* dirs, float* deltas, float* ts,
+                                  int first_k, int32_t* list_k, int32_t* n_clear, ngp_stream_t stream) {
+    if (n_rays < 0 || grid_size < 1 || max_samples < 1 || first_k < 1 || first_k > 64) return NGP_EINVAL;
+    if (n_rays == 0) return 0;
+    NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d); NGP_CHECK_PTR(rays_a); NGP_CHECK_PTR(t_scratch); NGP_CHECK_PTR(list_k);
+    const MarchParams p = make_march_params(nullptr, 1, grid_size, scale, scale, exp_step_factor, max_samples);
+    hipLaunchKernelGGL(march_train_write_kernel, dim3(ngp_div_up((long long)n_rays * 64, 256)), dim3(256), 0, ngp_stream(stream),
+                       rays_o, rays_d, rays_a, t_scratch, p, max_samples, n_rays, xyzs, dirs, deltas, ts, first_k, list_k, n_clear);
     return NGP_LAUNCH_RESULT();
 }
 

@@ -325,8 +325,11 @@ struct FieldIO {
     float* rgbs;           // (S,3)
     h1* h_out;             // (S,16), may be null (inference)
     const int32_t* n_dev;  // optional device-side sample count
+    const int32_t* list;   // LIST instantiation: work item j handles sample list[j]; n_samples is then the list length (bound) and
+    int stride;            //                     stride the level stride of feats / the bound of the ids
 };
 
+template <bool LIST>
 __global__ void __launch_bounds__(64 * WAVES)
 field_fwd_kernel(FieldIO io, const h1* __restrict__ density_w, const h1* __restrict__ rgb_w, int n_samples) {
     using LD = LdsW<32, 1>;
@@ -349,27 +352,41 @@ field_fwd_kernel(FieldIO io, const h1* __restrict__ density_w, const h1* __restr
     // SIMD alone left every wave waiting a memory round trip per tile).  Straight-line loads from a clamped sample position.
     const half2_t* fp = reinterpret_cast<const half2_t*>(io.feats);
     const long long s_last = n_samples - 1;
+    const long long stride = LIST ? (long long)io.stride : (long long)n_samples;
     half8_t x_nxt[2]; float d_nxt[3];
-    auto fetch = [&](int t) {
+    long long id_nxt = 0, id_pre = 0;                 // LIST: sample id of the tile being fetched / of the one after it (two ahead)
+    bool pad_nxt = false, pad_pre = false;            //       ... and whether that list entry is padding (-1): computed, never stored
+    auto list_id = [&](int t) -> long long {
         const long long sj = (long long)t * TILE + i;
-        const long long sc = sj < s_last ? sj : s_last;
+        const long long v = io.list[sj < s_last ? sj : s_last];
+        pad_pre = v < 0 || v >= stride;
+        return pad_pre ? 0 : v;
+    };
+    auto fetch = [&](int t, long long id) {
+        const long long sj = (long long)t * TILE + i;
+        const long long sc = LIST ? id : (sj < s_last ? sj : s_last);
+        id_nxt = sc; pad_nxt = pad_pre;
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const half2_t v = __builtin_nontemporal_load(fp + (size_t)(8 * c + 4 * hh + q) * n_samples + sc);
+                const half2_t v = __builtin_nontemporal_load(fp + (size_t)(8 * c + 4 * hh + q) * stride + sc);
                 x_nxt[c][2 * q] = v[0]; x_nxt[c][2 * q + 1] = v[1];
             }
         d_nxt[0] = io.dirs[3 * sc]; d_nxt[1] = io.dirs[3 * sc + 1]; d_nxt[2] = io.dirs[3 * sc + 2];
     };
     const int tile_stride = gridDim.x * WAVES;
-    fetch(blockIdx.x * WAVES + wave);
-    for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += tile_stride) {
-        const long long s = (long long)tile * TILE + i;
-        const bool valid = s < n_samples;
+    const int t_first = blockIdx.x * WAVES + wave;
+    fetch(t_first, LIST ? list_id(t_first) : 0);
+    if (LIST) id_pre = list_id(t_first + tile_stride);
+    for (int tile = t_first; tile < n_tiles; tile += tile_stride) {
+        const long long sj = (long long)tile * TILE + i;
+        const bool valid = sj < n_samples && !(LIST && pad_nxt);
+        const long long s = LIST ? id_nxt : sj;          // where this lane's sample lives
         half8_t xb[2] = {x_nxt[0], x_nxt[1]};
         const float dx = d_nxt[0], dy = d_nxt[1], dz = d_nxt[2];
-        fetch(tile + tile_stride);
+        fetch(tile + tile_stride, id_pre);
+        if (LIST) id_pre = list_id(tile + 2 * tile_stride);
         f32x16 acc[2];
         half8_t hb[4];
         layer_in<32>(ldsd + LD::OFF_W0, xb, i, hh, acc);
@@ -1038,8 +1055,24 @@ int ngp_field_fwd_n(const ngp_half* feats, const float* dirs, const ngp_half* de
     FieldIO io = {};
     io.feats = (const h1*)feats; io.dirs = dirs; io.sigmas = sigmas; io.rgbs = rgbs; io.h_out = (h1*)h_out; io.n_dev = n_dev;
     constexpr int smem = fwd_smem_bytes<32, 1>() + fwd_smem_bytes<32, 2>();
-    field_fwd_kernel<<<dim3(fwd_grid(n_samples)), dim3(64 * WAVES), smem, ngp_stream(stream)>>>(
+    field_fwd_kernel<false><<<dim3(fwd_grid(n_samples)), dim3(64 * WAVES), smem, ngp_stream(stream)>>>(
         io, (const h1*)density_w, (const h1*)rgb_w, n_samples);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_field_fwd_list(const ngp_half* feats, const float* dirs, const ngp_half* density_w, const ngp_half* rgb_w,
+                       int n_samples, const int32_t* list, int n_list_max, const int32_t* n_list_dev,
+                       float* sigmas, float* rgbs, ngp_half* h_out, ngp_stream_t stream) {
+    if (n_samples < 0 || n_list_max < 0) return NGP_EINVAL;
+    if (n_samples == 0 || n_list_max == 0) return 0;
+    NGP_CHECK_PTR(feats); NGP_CHECK_PTR(dirs); NGP_CHECK_PTR(density_w); NGP_CHECK_PTR(rgb_w);
+    NGP_CHECK_PTR(sigmas); NGP_CHECK_PTR(rgbs); NGP_CHECK_PTR(list);
+    FieldIO io = {};
+    io.feats = (const h1*)feats; io.dirs = dirs; io.sigmas = sigmas; io.rgbs = rgbs; io.h_out = (h1*)h_out; io.n_dev = n_list_dev;
+    io.list = list; io.stride = n_samples;
+    constexpr int smem = fwd_smem_bytes<32, 1>() + fwd_smem_bytes<32, 2>();
+    field_fwd_kernel<true><<<dim3(fwd_grid(n_list_max)), dim3(64 * WAVES), smem, ngp_stream(stream)>>>(
+        io, (const h1*)density_w, (const h1*)rgb_w, n_list_max);
     return NGP_LAUNCH_RESULT();
 }
 

@@ -47,6 +47,11 @@ struct ngp_stepper {
     const float* next_o = nullptr; const float* next_d = nullptr;
     hipStream_t next_main = nullptr, next_side = nullptr;
     int march_at = 2;
+    // two-round forward (include/ngp_hip.h): mode 0 off / 1 on / 2 auto, first K, the auto switch's state, steps run in two rounds
+    int two_round_mode = 2, two_round_k = 32;
+    bool two_round_active = false, two_rounds = false;
+    long long two_round_steps = 0;
+    int32_t prev_S = 0;
 };
 
 namespace {
@@ -165,6 +170,8 @@ int ngp_stepper_create(const ngp_stepper_config* config, const ngp_step_buffers*
     if (!s) return NGP_EINVAL;
     s->c = c; s->b = *buffers;
     s->march_at = march_at_from_env();
+    if (const char* e = getenv("NGP_TWO_ROUND")) s->two_round_mode = strcmp(e, "on") == 0 ? 1 : (strcmp(e, "off") == 0 ? 0 : 2);
+    if (const char* e = getenv("NGP_TWO_ROUND_K")) { const int k = atoi(e); if (k >= 1 && k <= 64) s->two_round_k = k; }
     (void)hipGetDevice(&s->device);
     hipError_t e = hipSuccess;
     for (int k = 0; k < 2 && e == hipSuccess; ++k) {
@@ -215,6 +222,7 @@ int ngp_stepper_pending(const ngp_stepper* s, const float* rays_o, const float* 
 }
 
 int ngp_stepper_last_set(const ngp_stepper* s) { return s ? s->last_set : 0; }
+int ngp_stepper_two_rounds(const ngp_stepper* s) { return (s && s->two_rounds) ? 1 : 0; }
 
 int ngp_stepper_march(ngp_stepper* s, const float* rays_o, const float* rays_d, ngp_stream_t main_stream, ngp_stream_t march_stream) {
     if (!s) return NGP_EINVAL;
@@ -240,18 +248,53 @@ static int forward_field(ngp_stepper* s, const float* rays_o, const float* rays_
     for (int i = 0; i < N_MARKS; ++i) s->mark_set[i] = false;
     mark(s, 0, main);
     STEP_TRY(march_next_if_at(s, AT_TOP));
-    STEP_TRY(ngp_raymarching_train_write(rays_o, rays_d, b.rays_a[k], b.scratch[k], c.scale, c.exp_step_factor, c.grid_size, c.max_samples, n,
-                                         b.xyzs, b.dirs, b.deltas, b.ts, main_stream));
-    mark(s, 1, main);
-    const ngp_half* table = c.enc_half + c.n_density;
-    if (S > 0) {
-        STEP_TRY(ngp_hashgrid_fwd(b.xyzs, c.xyz_min, c.xyz_max, table, &c.meta, S, b.feats, main_stream));
-        mark(s, 2, main);
-        STEP_TRY(march_next_if_at(s, AT_HASHGRID_FWD));
-        STEP_TRY(ngp_field_fwd(b.feats, b.dirs, c.enc_half, c.rgb_half, S, b.sigmas, b.rgbs, b.h, main_stream));
-        mark(s, 3, main);
-        STEP_TRY(march_next_if_at(s, AT_MLP_FWD));
+    // two rounds?  (auto: from the live fraction of the previous step, which its composite left in pinned memory)
+    bool two = false;
+    if (s->two_round_mode != 0 && b.list_k && b.list_rest && b.two_round_counts && c.lambda_distortion <= 0 && S > 0) {
+        if (s->two_round_mode == 1) two = true;
+        else {
+            const int32_t prev_live = b.counter[k ^ 1][2];
+            if (s->prev_S > 0 && prev_live >= 0) {
+                const float frac = (float)prev_live / (float)s->prev_S;
+                if (frac < 0.15f) s->two_round_active = true; else if (frac > 0.25f) s->two_round_active = false;
+            }
+            two = s->two_round_active;
+        }
     }
+    s->prev_S = S;
+    s->two_rounds = two;
+    const ngp_half* table = c.enc_half + c.n_density;
+    if (!two) {
+        STEP_TRY(ngp_raymarching_train_write(rays_o, rays_d, b.rays_a[k], b.scratch[k], c.scale, c.exp_step_factor, c.grid_size, c.max_samples, n,
+                                             b.xyzs, b.dirs, b.deltas, b.ts, main_stream));
+        mark(s, 1, main);
+        if (S > 0) {
+            STEP_TRY(ngp_hashgrid_fwd(b.xyzs, c.xyz_min, c.xyz_max, table, &c.meta, S, b.feats, main_stream));
+            mark(s, 2, main);
+            STEP_TRY(march_next_if_at(s, AT_HASHGRID_FWD));
+            STEP_TRY(ngp_field_fwd(b.feats, b.dirs, c.enc_half, c.rgb_half, S, b.sigmas, b.rgbs, b.h, main_stream));
+            mark(s, 3, main);
+            STEP_TRY(march_next_if_at(s, AT_MLP_FWD));
+        }
+        return 0;
+    }
+    // round 1: every ray's first K samples; round 2: the rest of the rays that are still transparent behind them
+    const int K = s->two_round_k;
+    ++s->two_round_steps;
+    int32_t* n2 = b.two_round_counts;
+    STEP_TRY(ngp_raymarching_train_write_k(rays_o, rays_d, b.rays_a[k], b.scratch[k], c.scale, c.exp_step_factor, c.grid_size, c.max_samples, n,
+                                           b.xyzs, b.dirs, b.deltas, b.ts, K, b.list_k, n2, main_stream));
+    mark(s, 1, main);
+    const int n1 = n * K;                                       // padded list: -1 where a ray has fewer than K samples
+    STEP_TRY(ngp_hashgrid_fwd_list(b.xyzs, c.xyz_min, c.xyz_max, table, &c.meta, S, b.list_k, n1, nullptr, b.feats, main_stream));
+    mark(s, 2, main);
+    STEP_TRY(march_next_if_at(s, AT_HASHGRID_FWD));
+    STEP_TRY(ngp_field_fwd_list(b.feats, b.dirs, c.enc_half, c.rgb_half, S, b.list_k, n1, nullptr, b.sigmas, b.rgbs, b.h, main_stream));
+    STEP_TRY(ngp_composite_probe(b.sigmas, b.deltas, b.rays_a[k], K, c.T_threshold, n, b.list_rest, n2, main_stream));
+    STEP_TRY(ngp_hashgrid_fwd_list(b.xyzs, c.xyz_min, c.xyz_max, table, &c.meta, S, b.list_rest, S, n2, b.feats, main_stream));
+    STEP_TRY(ngp_field_fwd_list(b.feats, b.dirs, c.enc_half, c.rgb_half, S, b.list_rest, S, n2, b.sigmas, b.rgbs, b.h, main_stream));
+    mark(s, 3, main);
+    STEP_TRY(march_next_if_at(s, AT_MLP_FWD));
     return 0;
 }
 
@@ -310,9 +353,10 @@ int ngp_stepper_front(ngp_stepper* s, const float* rays_o, const float* rays_d, 
     *n_samples = S;
     const int n = b.n_rays;
     // composite + per-ray loss seeds, then one small kernel: offsets of the live samples and the loss sums
-    STEP_TRY(ngp_composite_train_fw_loss(b.sigmas, b.rgbs, b.deltas, b.ts, b.rays_a[k], c.T_threshold, n, S, b.total, b.opacity, b.depth, b.rgb,
-                                         b.ws, b.ray_offs, b.n_active, rgb_gt, c.bg, c.lambda_opacity, grad_scale, b.stats, b.stats + 1,
-                                         b.dL_drgb, b.dL_dopacity, b.fw_ws, b.fw_bytes, main_stream));
+    b.counter[k][2] = -1;
+    STEP_TRY(ngp_composite_train_fw_loss_h(b.sigmas, b.rgbs, b.deltas, b.ts, b.rays_a[k], c.T_threshold, n, S, b.total, b.opacity, b.depth, b.rgb,
+                                           b.ws, b.ray_offs, b.n_active, b.counter[k] + 2, rgb_gt, c.bg, c.lambda_opacity, grad_scale, b.stats,
+                                           b.stats + 1, b.dL_drgb, b.dL_dopacity, b.fw_ws, b.fw_bytes, main_stream));
     mark(s, 4, main);
     STEP_TRY(march_next_if_at(s, AT_COMPOSITE_FW));
     STEP_TRY(backward_field(s, b.dL_dopacity, b.zeros, b.dL_drgb, nullptr, loss_scale, main, main_stream, n_partials));
@@ -340,6 +384,7 @@ int ngp_stepper_render_forward(ngp_stepper* s, const float* rays_o, const float*
     STEP_TRY(forward_field(s, rays_o, rays_d, main, main_stream, &k));
     *n_samples = s->S;
     const int n = b.n_rays;
+    b.counter[k][2] = -1;                                    // (no live-sample count from this composite: the auto switch stays where it is)
     STEP_TRY(ngp_composite_train_fw(b.sigmas, b.rgbs, b.deltas, b.ts, b.rays_a[k], c.T_threshold, n, s->S, b.total, b.opacity, b.depth, b.rgb,
                                     b.ws, b.ray_offs, main_stream));
     STEP_TRY(ngp_active_scan(b.ray_offs, n, b.n_active, main_stream));

@@ -52,6 +52,7 @@ class StepBuffers:
             for name, b in self.MARCH:
                 add("%s%d" % (name, k), b * n_rays)
         add("n_active", 4); add("stats", 8)
+        add("list_k", 4 * 64 * n_rays); add("list_rest", 4 * self.cap); add("two_round_counts", 16)
         add("partials", self.MAX_PARTIALS * self.n_mlp_params * 4)
         self.fw_bytes = int(lib.ngp_composite_train_fw_loss_workspace_bytes(n_rays))
         add("fw_ws", self.fw_bytes)
@@ -86,7 +87,9 @@ class StepBuffers:
         self.dist_seed_val = None
         self.noise = [view("noise%d" % k, f32, n_rays) for k in (0, 1)]
         # {S, R} of a march is written by its scan kernel straight into pinned (device-mapped) host memory
-        self.counter_host = [torch.zeros(2, dtype=torch.int32).pin_memory() for _ in (0, 1)]
+        view("two_round_counts", torch.int32, 4).zero_()
+        # {S, R, live samples of the step that consumed the march, -} per record set
+        self.counter_host = [torch.zeros(4, dtype=torch.int32).pin_memory() for _ in (0, 1)]
         self.counter_np = [t.numpy() for t in self.counter_host]
         self.counter_p = [t.data_ptr() for t in self.counter_host]
         self.next_set = 0
@@ -100,7 +103,7 @@ class StepBuffers:
         c.n_rays, c.distortion, c.cap = self.n, 1 if distortion else 0, self.cap
         for name in ("xyzs", "dirs", "deltas", "ts", "feats", "h", "sigmas", "rgbs", "ws", "dL_dsigmas", "dL_drgbs", "active", "x_act", "dh",
                      "dfeats", "total", "opacity", "depth", "rgb", "dL_drgb", "dL_dopacity", "ray_offs", "dist", "zeros", "dist_seed",
-                     "n_active", "stats", "partials", "fw_ws"):
+                     "n_active", "stats", "partials", "fw_ws", "list_k", "list_rest", "two_round_counts"):
             setattr(c, name, P[name])
         if distortion:
             c.ws_incl, c.wts_incl, c.dL_dws = P["ws_incl"], P["wts_incl"], P["dL_dws"]

@@ -984,3 +984,65 @@ def test_native_render_node_matches_the_launch_by_launch_node():
     with pytest.raises(RuntimeError, match="step buffers have been reused"):
         loss_a.backward()
     m._native = None
+
+
+def test_two_round_forward_is_bit_identical():
+    """The two-round forward of the native stepper (NGP_TWO_ROUND=on: hash grid + field on every ray's first K samples, then on the
+    rest of the rays that are still transparent behind them) against the one-round forward (off) from the same initialisation on
+    the same batches: the composite never reads a sample behind a ray's stop, every sample in front of it is evaluated by the same
+    per-sample kernels -- sample counts, loss, live-sample counts and EVERY parameter bit for bit after 60 steps, for K = 8 and for
+    K = 3 (many rays continue) and with the switch on `auto` (which stays off here: the field is young)."""
+    import os
+    from ngp_pl_amd import _lib
+    from ngp_pl_amd.trainer import Trainer
+    batches = [batch(2048, seed=1500 + i) for i in range(6)]
+
+    def run(mode, k):
+        os.environ["NGP_TWO_ROUND"] = mode
+        os.environ["NGP_TWO_ROUND_K"] = str(k)
+        try:
+            m = make_model(seed=41)
+            tr = Trainer(m)
+            log, rounds = [], 0
+            for i in range(60):
+                b, nb = batches[i % 6], batches[(i + 1) % 6]
+                out = tr.step(*b, next_batch=(nb[0], nb[1]))
+                rounds += _lib.call("ngp_stepper_two_rounds", tr._stepper)
+                log.append((out["rm_samples"], tr.last["stats"].tolist(), int(tr.last["n_active"].item())))
+            torch.cuda.synchronize()
+            return m, log, rounds
+        finally:
+            os.environ.pop("NGP_TWO_ROUND", None); os.environ.pop("NGP_TWO_ROUND_K", None)
+    ma, la, ra = run("off", 8)
+    assert ra == 0
+    for mode, k in (("on", 8), ("on", 3), ("auto", 8)):
+        mb, lb, rb = run(mode, k)
+        assert rb == (60 if mode == "on" else 0), (mode, rb)
+        assert la == lb, (mode, k, [i for i in range(60) if la[i] != lb[i]][:5])
+        for (ka, pa), (kb, pb) in zip(ma.state_dict().items(), mb.state_dict().items()):
+            assert ka == kb and torch.equal(pa, pb), (mode, k, ka)
+    assert la[-1][0] > 0 and la[-1][2] > 0
+
+
+def test_two_round_forward_switches_itself_on_late_in_training():
+    """`auto` (the default): on a scene of opaque surfaces the live fraction falls under 0.15 within a few thousand steps and the
+    stepper starts evaluating in two rounds; training goes on (finite loss, rising PSNR)."""
+    from ngp_pl_amd import _lib
+    from ngp_pl_amd.bench_support import GpuDataset
+    from ngp_pl_amd.networks import NGP
+    from ngp_pl_amd.trainer import Trainer
+    torch.manual_seed(5)
+    dev = torch.device("cuda")
+    m = NGP(0.5).to(dev); m.register_training_buffers()
+    tr = Trainer(m)
+    data = GpuDataset(800, 100, dev, seed=0)                  # the bench's workload: 0.09 live after 8 000 steps
+    cur = data.sample_native(8192, 0)
+    seen = []
+    for i in range(9000):
+        nxt = data.sample_native(8192, i + 1)
+        out = tr.step(cur[0], cur[1], cur[2], next_batch=(nxt[0], nxt[1])); cur = nxt
+        if i % 500 == 499:
+            seen.append((_lib.call("ngp_stepper_two_rounds", tr._stepper), int(tr.last["n_active"].item()) / max(out["rm_samples"], 1), tr.metrics()["psnr"]))
+    assert seen[0][0] == 0 and seen[0][1] > 0.25, seen
+    assert seen[-1][0] == 1 and seen[-1][1] < 0.15, seen
+    assert math.isfinite(tr.metrics()["loss"]) and seen[-1][2] > seen[0][2] + 3 and seen[-1][2] > 25, seen
