@@ -283,3 +283,70 @@ def test_marching_guards_end_rays_that_would_never_end(vren):
     torch.cuda.synchronize()
     assert int(out[4].sum()) == 0
     _lib.march_guard_counts(reset=True)
+
+
+@pytest.mark.parametrize("first_k", [1, 4, 8, 32, 64])
+def test_composite_probe_lists_what_the_reference_composite_goes_on_to_read(vren, oracle, first_k):
+    """ngp_composite_probe (two-round forward) against the oracle's composite_train_fw (bit-pinned to volumerendering.cu:20-44):
+    a ray's remaining samples are listed iff it has more than first_k samples and the reference loop is still running behind
+    the first first_k (its count of composited samples `total_samples` has reached first_k); rays whose transmittance sits within
+    rounding of the threshold at that point may fall either way (counted, must be rare).  Also the padded first-K list of
+    ngp_raymarching_train_write_k and the list variants of the hash / field forward against the full-range kernels."""
+    from ngp_pl_amd import _lib
+    from ngp_pl_amd._lib import call, ptr, stream
+    rays_a, sigmas, rgbs, deltas, ts = _packed(oracle)
+    R, S = rays_a.shape[0], sigmas.shape[0]
+    total = oracle.composite_train_fw(sigmas, rgbs, deltas, ts, rays_a, 1e-4)[0]
+    N = rays_a[:, 2]
+    want_cont = (N > first_k) & (total >= first_k)
+    lst = torch.full((S,), -7, dtype=torch.int32, device="cuda"); cnt = torch.zeros(4, dtype=torch.int32, device="cuda")
+    d_sig, d_del, d_rays = dev(sigmas), dev(deltas), dev(rays_a)              # (held: a temporary would be freed before the launch)
+    call("ngp_composite_probe", ptr(d_sig), ptr(d_del), ptr(d_rays), first_k, 1e-4, R, ptr(lst), ptr(cnt), stream())
+    torch.cuda.synchronize()
+    n = int(cnt[0])
+    got = np.sort(lst[:n].cpu().numpy())
+    assert (lst[n:] == -7).all() and len(np.unique(got)) == n                  # nothing written past the count, no sample twice
+    want_ids = np.concatenate([np.arange(rays_a[r, 1] + first_k, rays_a[r, 1] + N[r]) for r in np.nonzero(want_cont)[0]] + [np.zeros(0, np.int64)])
+    # threshold ties: rays whose membership differs
+    ray_of = np.repeat(np.arange(R), N)
+    diff_rays = np.unique(ray_of[np.setxor1d(got, want_ids).astype(np.int64)]) if len(np.setxor1d(got, want_ids)) else np.zeros(0)
+    assert len(diff_rays) <= max(1, R // 500), (first_k, len(diff_rays))
+    assert want_cont.sum() > 0 or first_k >= 32
+
+
+def test_list_forward_kernels_match_the_full_range_kernels():
+    """ngp_hashgrid_fwd_list / ngp_field_fwd_list write, for the listed samples, exactly what ngp_hashgrid_fwd / ngp_field_fwd write
+    for them (per-sample kernels), leave every other sample untouched, skip padding entries (-1), and honour a device-side count."""
+    import ctypes as C
+    import math
+    from ngp_pl_amd import _lib
+    from ngp_pl_amd._lib import GridMeta, call, ptr, stream
+    g = torch.Generator(device="cuda").manual_seed(3)
+    S = 50000
+    meta = GridMeta()
+    call("ngp_grid_meta_init", C.byref(meta), 16, 2, 19, 16, float(math.exp(math.log(2048 * 0.5 / 16) / 15)))
+    x = (torch.rand(S, 3, device="cuda", generator=g) - 0.5) * 0.98
+    d = torch.randn(S, 3, device="cuda", generator=g)
+    table = ((torch.rand(meta.offset[16], 2, device="cuda", generator=g) - 0.5) * 0.4).half()
+    dw = (torch.randn(3072, device="cuda", generator=g) * 0.2).half(); rw = (torch.randn(7168, device="cuda", generator=g) * 0.2).half()
+    mn = torch.full((3,), -0.5, device="cuda"); mx = torch.full((3,), 0.5, device="cuda")
+    feats = torch.empty(16, S, 2, dtype=torch.float16, device="cuda")
+    sig = torch.empty(S, device="cuda"); rgb = torch.empty(S, 3, device="cuda"); h = torch.empty(S, 16, dtype=torch.float16, device="cuda")
+    call("ngp_hashgrid_fwd", ptr(x), ptr(mn), ptr(mx), ptr(table), C.byref(meta), S, ptr(feats), stream())
+    call("ngp_field_fwd", ptr(feats), ptr(d), ptr(dw), ptr(rw), S, ptr(sig), ptr(rgb), ptr(h), stream())
+    # a list of runs with padding in between, in shuffled run order
+    ids = torch.cat([torch.arange(a * 8, a * 8 + 8) for a in torch.randperm(S // 8 - 1)[:2000].tolist()])        # 2000 runs of 8 consecutive samples
+    lst = torch.stack([ids.view(-1, 8), torch.full((2000, 8), -1, dtype=torch.long)], 1).reshape(-1)                 # run, padding, run, ...
+    lst = lst.int().cuda().contiguous()
+    n_dev = torch.tensor([lst.numel() - 16 * 5], dtype=torch.int32, device="cuda")                                  # the last 5 runs are beyond the count
+    f2 = torch.full_like(feats, 9.0); s2 = torch.full_like(sig, -3.0); c2 = torch.full_like(rgb, -3.0); h2 = torch.full_like(h, 9.0)
+    call("ngp_hashgrid_fwd_list", ptr(x), ptr(mn), ptr(mx), ptr(table), C.byref(meta), S, ptr(lst), lst.numel(), ptr(n_dev), ptr(f2), stream())
+    call("ngp_field_fwd_list", ptr(f2), ptr(d), ptr(dw), ptr(rw), S, ptr(lst), lst.numel(), ptr(n_dev), ptr(s2), ptr(c2), ptr(h2), stream())
+    torch.cuda.synchronize()
+    listed = lst[:int(n_dev[0])]
+    listed = listed[listed >= 0].long()
+    mask = torch.zeros(S, dtype=torch.bool, device="cuda"); mask[listed] = True
+    assert int(mask.sum()) == 1995 * 8
+    assert torch.equal(f2[:, mask], feats[:, mask]) and bool((f2[:, ~mask] == 9.0).all())
+    assert torch.equal(s2[mask], sig[mask]) and torch.equal(c2[mask], rgb[mask]) and torch.equal(h2[mask], h[mask])
+    assert bool((s2[~mask] == -3.0).all()) and bool((c2[~mask] == -3.0).all()) and bool((h2[~mask] == 9.0).all())
