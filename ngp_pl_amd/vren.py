@@ -169,7 +169,8 @@ def distortion_loss_bw(dL_dloss, ws_inclusive_scan, wts_inclusive_scan, ws, delt
     require_cuda(dL_dloss, ws_inclusive_scan, wts_inclusive_scan, ws, deltas, ts, rays_a)
     R, S = rays_a.shape[0], ws.shape[0]
     out = torch.zeros(S, dtype=torch.float32, device=ws.device)
+    dL_dloss = dL_dloss.contiguous()           # (require_cuda has checked it already; held by name for the duration of the launch)
     with torch.cuda.device(ws.device):
-        call("ngp_distortion_loss_bw", ptr(dL_dloss.contiguous()), ptr(ws_inclusive_scan), ptr(wts_inclusive_scan), ptr(ws),
+        call("ngp_distortion_loss_bw", ptr(dL_dloss), ptr(ws_inclusive_scan), ptr(wts_inclusive_scan), ptr(ws),
              ptr(deltas), ptr(ts), ptr(rays_a), R, S, ptr(out), stream())
     return out
