@@ -131,6 +131,15 @@ int ngp_raymarching_train_count(const float* rays_o, const float* rays_d, const 
                                 int max_samples, int n_rays,
                                 int64_t* rays_a, int32_t* counter, float* t_scratch,
                                 ngp_stream_t stream);
+
+/* ngp_raymarching_train_count that also prepares the compact first-round list of the two-round forward: offs_k (n_rays, i32) =
+ * exclusive scan of min(N, first_k) in ray order, counter[3] = its total (counter then holds 4 x i32).  offs_k NULL: exactly
+ * ngp_raymarching_train_count. */
+int ngp_raymarching_train_count_k(const float* rays_o, const float* rays_d, const float* hits_t,
+                                  const uint8_t* density_bitfield, int cascades, float scale,
+                                  float exp_step_factor, const float* noise, int grid_size,
+                                  int max_samples, int n_rays, int64_t* rays_a, int32_t* counter,
+                                  float* t_scratch, int first_k, int32_t* offs_k, ngp_stream_t stream);
 int ngp_raymarching_train_write(const float* rays_o, const float* rays_d, const int64_t* rays_a,
                                 const float* t_scratch, float scale, float exp_step_factor,
                                 int grid_size, int max_samples, int n_rays,
@@ -145,6 +154,15 @@ int ngp_raymarching_train_write_k(const float* rays_o, const float* rays_d, cons
                                   int grid_size, int max_samples, int n_rays,
                                   float* xyzs, float* dirs, float* deltas, float* ts,
                                   int first_k, int32_t* list_k, int32_t* n_clear, ngp_stream_t stream);
+
+/* The same with a COMPACT list in ray order: list_k[offs_k[ray] + k] = start + k for k < min(N, first_k), where offs_k is the
+ * exclusive scan of min(N, first_k) over the rays that ngp_raymarching_train_count_k wrote (its total is counter[3]: the list's
+ * length).  No padding entries: late in training most rays have no samples at all. */
+int ngp_raymarching_train_write_kc(const float* rays_o, const float* rays_d, const int64_t* rays_a,
+                                   const float* t_scratch, float scale, float exp_step_factor,
+                                   int grid_size, int max_samples, int n_rays,
+                                   float* xyzs, float* dirs, float* deltas, float* ts,
+                                   int first_k, const int32_t* offs_k, int32_t* list_k, int32_t* n_clear, ngp_stream_t stream);
 
 /* vren.raymarching_test (binding.cpp:84-106, raymarching.cu:335-454).  hits_t (R_total,2) is
  * advanced in place; alive_indices (N_alive) i64; outputs are dense (N_alive,N_samples,.) and
@@ -690,6 +708,8 @@ typedef struct ngp_step_buffers {
     int32_t* list_k;                               /* (n_rays * 64) ids of the rays' first samples */
     int32_t* list_rest;                            /* (cap) ids of the continuing rays' remaining samples */
     int32_t* two_round_counts;                     /* 4 x i32 on the device, zeroed by the caller once */
+    int32_t* offs_k[2];                            /* (n_rays) per march record set: where each ray's first samples go in the compact
+                                                      first-round list (NULL: the padded list is used); counter[.][3] = its length */
     /* scalars and workspaces */
     int32_t* n_active; float* stats;               /* stats[0] = loss, stats[1] = sum of squared errors */
     float* partials; int32_t max_partials;         /* [max_partials x (n_density + n_rgb)] f32 */
@@ -721,6 +741,9 @@ int ngp_stepper_pending(const ngp_stepper* s, const float* rays_o, const float* 
 int ngp_stepper_last_set(const ngp_stepper* s);
 /* Did the last front() evaluate the field in two rounds? (1 / 0) */
 int ngp_stepper_two_rounds(const ngp_stepper* s);
+/* sizeof(ngp_stepper_config) (which = 0) / sizeof(ngp_step_buffers) (which = 1) as this library was compiled: a binding that
+ * mirrors the records (ctypes, cgo ...) checks its own layout against them before it hands one over. */
+int ngp_stepper_record_bytes(int which);
 /* Waits for a pending march and forgets it (the batch it was made for is not going to be stepped). */
 int ngp_stepper_drop_pending(ngp_stepper* s);
 /* The step up to the field backward, on main_stream.  The pending march must be the one of (rays_o, rays_d).

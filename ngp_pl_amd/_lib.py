@@ -45,7 +45,7 @@ class StepBuffersC(C.Structure):
                           "dh", "dfeats", "ws_incl", "wts_incl", "dL_dws",
                           "total", "opacity", "depth", "rgb", "dL_drgb", "dL_dopacity", "ray_offs", "dist", "zeros", "dist_seed")] + \
         [("hits_t", P * 2), ("rays_a", P * 2), ("noise", P * 2), ("scratch", P * 2), ("counter", P * 2),
-         ("list_k", P), ("list_rest", P), ("two_round_counts", P),
+         ("list_k", P), ("list_rest", P), ("two_round_counts", P), ("offs_k", P * 2),
          ("n_active", P), ("stats", P), ("partials", P), ("max_partials", C.c_int32),
          ("fw_ws", P), ("fw_bytes", C.c_size_t), ("bin_ws", P), ("bin_bytes", C.c_size_t), ("bin_max", C.c_int32)]
 
@@ -65,6 +65,9 @@ _PROTOS = {
     "ngp_raymarching_train_count": [P, P, P, P, I, F, F, P, I, I, I, P, P, P, P],
     "ngp_raymarching_train_write": [P, P, P, P, F, F, I, I, I, P, P, P, P, P],
     "ngp_raymarching_train_write_k": [P, P, P, P, F, F, I, I, I, P, P, P, P, I, P, P, P],
+    "ngp_raymarching_train_write_kc": [P, P, P, P, F, F, I, I, I, P, P, P, P, I, P, P, P, P],
+    "ngp_raymarching_train_count_k": [P, P, P, P, I, F, F, P, I, I, I, P, P, P, I, P, P],
+    "ngp_stepper_record_bytes": [I],
     "ngp_raymarching_test": [P, P, P, P, P, I, F, F, I, I, I, I, P, P, P, P, P, P],
     "ngp_composite_train_fw": [P, P, P, P, P, F, I, I, P, P, P, P, P, P, P],
     "ngp_composite_train_bw": [P] * 13 + [F, I, I, P, P, P, P, P, P, P],
@@ -146,7 +149,8 @@ _PROTOS = {
     "ngp_render_test_frame": [P, P, P, P, I, F, F, I, I, F, P, P, P, C.POINTER(GridMeta), P, P, I, I, I,
                               C.POINTER(C.c_float), P, C.c_size_t, P, P, P, P, C.POINTER(C.c_int32), P],
 }
-_COUNT_QUERIES = ("ngp_field_bwd_partials", "ngp_mlp_bwd_partials", "ngp_abi_version", "ngp_stepper_pending", "ngp_stepper_last_set", "ngp_stepper_two_rounds")
+_COUNT_QUERIES = ("ngp_field_bwd_partials", "ngp_mlp_bwd_partials", "ngp_abi_version", "ngp_stepper_pending", "ngp_stepper_last_set", "ngp_stepper_two_rounds",
+                  "ngp_stepper_record_bytes")
 
 _lib = None
 
@@ -173,6 +177,10 @@ def lib():
         h.ngp_composite_train_fw_loss_workspace_bytes.restype = C.c_size_t
         h.ngp_occupancy_update_workspace_bytes.argtypes = [I, I]
         h.ngp_occupancy_update_workspace_bytes.restype = C.c_size_t
+        for which, rec in ((0, StepperConfig), (1, StepBuffersC)):      # the mirrored records must be the library's own layout
+            if h.ngp_stepper_record_bytes(which) != C.sizeof(rec):
+                raise RuntimeError("%s is %d bytes here, %d in %s: rebuild the library (python -m ngp_pl_amd.build)" % (
+                    rec.__name__, C.sizeof(rec), h.ngp_stepper_record_bytes(which), LIB_PATH))
         _lib = h
     return _lib
 

@@ -71,6 +71,9 @@ static_assert(SLICE2 < PAY_INVALID, "slice-local indices are stored in 13 bits")
 #ifndef NGP_APPLY_B
 #define NGP_APPLY_B 11
 #endif
+#ifndef NGP_APPLY_WRITEOUT_BATCHED
+#define NGP_APPLY_WRITEOUT_BATCHED 0          // accumulators per thread read together at write-out; 0: one at a time (round 2; A/B builds)
+#endif
 #ifndef NGP_DENSE_B
 #define NGP_DENSE_B 4                         // dense levels: entries per lane in flight
 #endif
@@ -540,12 +543,46 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
 #endif
         half2_t* __restrict__ out = grad_table + meta.offset[level] + lo;
         const float inv = 1.0f / FIX_SCALE;
+#if NGP_APPLY_WRITEOUT_BATCHED
+        {
+            // all of a thread's accumulators are read (16-byte LDS reads), then cleared, then converted and stored: the reads of one
+            // entry do not wait behind the clear of the previous one (same array: the compiler keeps them in program order)
+            typedef long long ll2 __attribute__((ext_vector_type(2)));
+            constexpr int WO = (int)((SLICE2 + APPLY_THREADS - 1) / APPLY_THREADS), WB = NGP_APPLY_WRITEOUT_BATCHED;
+            float2* __restrict__ pout = ws.partial + plan.part_off[level] + (size_t)part * size + lo;
+            const ll2 z2 = {0, 0};
+#pragma unroll
+            for (int q0 = 0; q0 < WO; q0 += WB) {
+                ll2 acc2[WB];
+#pragma unroll
+                for (int q = 0; q < WB; ++q) {
+                    const uint32_t k = tid + (q0 + q) * APPLY_THREADS;
+                    acc2[q] = *reinterpret_cast<const ll2*>(lds + 2 * (k < len ? k : 0));
+                }
+#pragma unroll
+                for (int q = 0; q < WB; ++q) {
+                    const uint32_t k = tid + (q0 + q) * APPLY_THREADS;
+                    if (k < len) *reinterpret_cast<ll2*>(lds + 2 * k) = z2;               // ready for the next task
+                }
+#pragma unroll
+                for (int q = 0; q < WB; ++q) {
+                    const uint32_t k = tid + (q0 + q) * APPLY_THREADS;
+                    if (k < len) {
+                        const float a0 = (float)acc2[q][0] * inv, a1 = (float)acc2[q][1] * inv;
+                        if (K == 1) { half2_t v; v[0] = (_Float16)a0; v[1] = (_Float16)a1; out[k] = v; }
+                        else pout[k] = make_float2(a0, a1);
+                    }
+                }
+            }
+        }
+#else
         for (uint32_t k = tid; k < len; k += APPLY_THREADS) {
             const float a0 = (float)lds[2 * k] * inv, a1 = (float)lds[2 * k + 1] * inv;
             lds[2 * k] = 0; lds[2 * k + 1] = 0;                        // ready for the next task
             if (K == 1) { half2_t v; v[0] = (_Float16)a0; v[1] = (_Float16)a1; out[k] = v; }
             else ws.partial[plan.part_off[level] + (size_t)part * size + lo + k] = make_float2(a0, a1);
         }
+#endif
         if (tid == 0) s_task[(it + 1) & 1] = next_task;
         __syncthreads();                                               // accumulators clear, s_dir free, next id visible
 #ifdef NGP_BIN_TIMING

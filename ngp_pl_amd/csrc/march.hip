@@ -528,12 +528,14 @@ march_train_count_wave_kernel(const float* __restrict__ rays_o, const float* __r
 
 // Exclusive scan of rays_a[:,2] into rays_a[:,1] in ray order; counter = {S, R}.
 // Single 1024-thread workgroup, tiles of 8192 rays (8 consecutive rays per thread, all loads first).
+// offs_k != nullptr (two-round forward): also the exclusive scan of min(N, first_k) into offs_k -- where every ray's first
+// samples go in the compact first-round list -- and its total into counter[3].
 __global__ void __launch_bounds__(1024)
-march_train_scan_kernel(int64_t* __restrict__ rays_a, int n_rays, int32_t* __restrict__ counter) {
-    __shared__ int s_wave[16];
-    __shared__ int s_carry;
+march_train_scan_kernel(int64_t* __restrict__ rays_a, int n_rays, int32_t* __restrict__ counter, int first_k, int32_t* __restrict__ offs_k) {
+    __shared__ int s_wave[16], s_wave_k[16];
+    __shared__ int s_carry, s_carry_k;
     const int tid = threadIdx.x;
-    if (tid == 0) s_carry = 0;
+    if (tid == 0) { s_carry = 0; s_carry_k = 0; }
     __syncthreads();
     for (int base = 0; base < n_rays; base += 8192) {
         const int r0 = base + 8 * tid;
@@ -546,31 +548,49 @@ march_train_scan_kernel(int64_t* __restrict__ rays_a, int n_rays, int32_t* __res
             if (r0 + k < n_rays) rays_a[3 * (size_t)(r0 + k) + 1] = run;
             run += v[k];
         }
+        if (offs_k) {                                   // (uniform)
+            int vk[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) vk[k] = min(v[k], first_k);
+            int run_k = ngp_block_scan_tile<8>(vk, s_wave_k, &s_carry_k);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (r0 + k < n_rays) offs_k[r0 + k] = run_k;
+                run_k += vk[k];
+            }
+        }
         __syncthreads();
     }
-    if (tid == 0) { counter[0] = s_carry; counter[1] = n_rays; }
+    if (tid == 0) { counter[0] = s_carry; counter[1] = n_rays; if (offs_k) counter[3] = s_carry_k; }
 }
 
 // Pass 2 of train marching: expand (ray, k) -> packed sample.  One wave per ray, lanes stride
 // the ray's samples: scratch reads and all four output streams are coalesced.
 // first_k > 0 (two-round forward, csrc/stepper.hip): the ids of every ray's first min(N, first_k) samples are also written to
 // list_k[ray * first_k + k] (-1 where the ray has fewer: a padded list of n_rays * first_k entries -- no counter, no atomics; 8192
-// atomics on one address cost 28 us), and *n_clear (the counter of the second round's list) is cleared on the side.
+// atomics on one address cost 28 us, one per 4-ray workgroup still 19 us), or, with the offsets offs_k the march's scan kernel
+// computed, to a COMPACT list in ray order (late in training 70 % of the rays have no samples: the padded list is mostly padding).
+// *n_clear (the counter of the second round's list) is cleared on the side.
 __global__ void __launch_bounds__(256)
 march_train_write_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                          const int64_t* __restrict__ rays_a, const float* __restrict__ t_scratch,
                          MarchParams p, int max_samples, int n_rays,
                          float* __restrict__ xyzs, float* __restrict__ dirs,
                          float* __restrict__ deltas, float* __restrict__ ts,
-                         int first_k, int32_t* __restrict__ list_k, int32_t* __restrict__ n_clear) {
+                         int first_k, int32_t* __restrict__ list_k, int32_t* __restrict__ n_clear,
+                         const int32_t* __restrict__ offs_k) {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (first_k > 0 && blockIdx.x == 0 && threadIdx.x == 0 && n_clear) *n_clear = 0;
-    if (wave >= n_rays) return;
-    const int64_t r = rays_a[3 * (size_t)wave];
-    const int64_t start = rays_a[3 * (size_t)wave + 1];
-    const int n = (int)rays_a[3 * (size_t)wave + 2];
-    if (first_k > 0 && lane < first_k) list_k[(size_t)wave * first_k + lane] = lane < n ? (int32_t)(start + lane) : -1;
+    const bool in = wave < n_rays;
+    const int64_t r = in ? rays_a[3 * (size_t)wave] : 0;
+    const int64_t start = in ? rays_a[3 * (size_t)wave + 1] : 0;
+    const int n = in ? (int)rays_a[3 * (size_t)wave + 2] : 0;
+    if (first_k > 0 && in) {
+        if (offs_k) { if (lane < min(n, first_k)) list_k[offs_k[wave] + lane] = (int32_t)(start + lane); }       // compact, in ray order
+        else if (lane < first_k) list_k[(size_t)wave * first_k + lane] = lane < n ? (int32_t)(start + lane) : -1;
+    }
+    if (!in) return;
     const float ox = rays_o[3 * r], oy = rays_o[3 * r + 1], oz = rays_o[3 * r + 2];
     const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz = rays_d[3 * r + 2];
     const float* __restrict__ row = t_scratch + (size_t)r * max_samples;
@@ -1136,7 +1156,17 @@ int ngp_raymarching_train_count(const float* rays_o, const float* rays_d, const 
                                 float exp_step_factor, const float* noise, int grid_size,
                                 int max_samples, int n_rays, int64_t* rays_a, int32_t* counter,
                                 float* t_scratch, ngp_stream_t stream) {
+    return ngp_raymarching_train_count_k(rays_o, rays_d, hits_t, density_bitfield, cascades, scale, exp_step_factor, noise, grid_size, max_samples,
+                                         n_rays, rays_a, counter, t_scratch, 0, nullptr, stream);
+}
+
+int ngp_raymarching_train_count_k(const float* rays_o, const float* rays_d, const float* hits_t,
+                                  const uint8_t* density_bitfield, int cascades, float scale,
+                                  float exp_step_factor, const float* noise, int grid_size,
+                                  int max_samples, int n_rays, int64_t* rays_a, int32_t* counter,
+                                  float* t_scratch, int first_k, int32_t* offs_k, ngp_stream_t stream) {
     if (n_rays < 0 || cascades < 1 || grid_size < 1 || grid_size > 1024 || max_samples < 1) return NGP_EINVAL;
+    if (offs_k != nullptr && (first_k < 1 || first_k > 64)) return NGP_EINVAL;
     NGP_CHECK_PTR(counter);
     if (n_rays > 0) {
         NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d); NGP_CHECK_PTR(hits_t); NGP_CHECK_PTR(density_bitfield);
@@ -1162,7 +1192,7 @@ int ngp_raymarching_train_count(const float* rays_o, const float* rays_d, const 
             hipLaunchKernelGGL(march_train_count_kernel<false>, dim3(ngp_div_up(n_rays, MARCH_RAYS_PER_WAVE)), dim3(64), 0, ngp_stream(stream),
                                rays_o, rays_d, hits_t, noise, p, max_samples, n_rays, rays_a, t_scratch);
     }
-    hipLaunchKernelGGL(march_train_scan_kernel, dim3(1), dim3(1024), 0, ngp_stream(stream), rays_a, n_rays, counter);
+    hipLaunchKernelGGL(march_train_scan_kernel, dim3(1), dim3(1024), 0, ngp_stream(stream), rays_a, n_rays, counter, first_k, offs_k);
     return NGP_LAUNCH_RESULT();
 }
 
@@ -1177,7 +1207,7 @@ int ngp_raymarching_train_write(const float* rays_o, const float* rays_d, const 
     const MarchParams p = make_march_params(nullptr, 1, grid_size, scale, scale, exp_step_factor, max_samples);
     hipLaunchKernelGGL(march_train_write_kernel, dim3(ngp_div_up((long long)n_rays * 64, 256)), dim3(256), 0, ngp_stream(stream),
                        rays_o, rays_d, rays_a, t_scratch, p, max_samples, n_rays, xyzs, dirs, deltas, ts, 0, (int32_t*)nullptr,
-                       (int32_t*)nullptr);
+                       (int32_t*)nullptr, (const int32_t*)nullptr);
     return NGP_LAUNCH_RESULT();
 }
 
@@ -1191,7 +1221,22 @@ int ngp_raymarching_train_write_k(const float* rays_o, const float* rays_d, cons
     NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d); NGP_CHECK_PTR(rays_a); NGP_CHECK_PTR(t_scratch); NGP_CHECK_PTR(list_k);
     const MarchParams p = make_march_params(nullptr, 1, grid_size, scale, scale, exp_step_factor, max_samples);
     hipLaunchKernelGGL(march_train_write_kernel, dim3(ngp_div_up((long long)n_rays * 64, 256)), dim3(256), 0, ngp_stream(stream),
-                       rays_o, rays_d, rays_a, t_scratch, p, max_samples, n_rays, xyzs, dirs, deltas, ts, first_k, list_k, n_clear);
+                       rays_o, rays_d, rays_a, t_scratch, p, max_samples, n_rays, xyzs, dirs, deltas, ts, first_k, list_k, n_clear,
+                       (const int32_t*)nullptr);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_raymarching_train_write_kc(const float* rays_o, const float* rays_d, const int64_t* rays_a,
+                                   const float* t_scratch, float scale, float exp_step_factor,
+                                   int grid_size, int max_samples, int n_rays,
+                                   float* xyzs, float* dirs, float* deltas, float* ts,
+                                   int first_k, const int32_t* offs_k, int32_t* list_k, int32_t* n_clear, ngp_stream_t stream) {
+    if (n_rays < 0 || grid_size < 1 || max_samples < 1 || first_k < 1 || first_k > 64) return NGP_EINVAL;
+    if (n_rays == 0) return 0;
+    NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d); NGP_CHECK_PTR(rays_a); NGP_CHECK_PTR(t_scratch); NGP_CHECK_PTR(list_k); NGP_CHECK_PTR(offs_k);
+    const MarchParams p = make_march_params(nullptr, 1, grid_size, scale, scale, exp_step_factor, max_samples);
+    hipLaunchKernelGGL(march_train_write_kernel, dim3(ngp_div_up((long long)n_rays * 64, 256)), dim3(256), 0, ngp_stream(stream),
+                       rays_o, rays_d, rays_a, t_scratch, p, max_samples, n_rays, xyzs, dirs, deltas, ts, first_k, list_k, n_clear, offs_k);
     return NGP_LAUNCH_RESULT();
 }
 

@@ -43,8 +43,17 @@ constexpr int WAVES = 4;         // waves per workgroup
 #ifndef NGP_MLP_BWD_WAVES_1HIDDEN
 #define NGP_MLP_BWD_WAVES_1HIDDEN 8
 #endif
+// Two hidden layers at 8 waves (round 3, NGP_MLP_BWD_WAVES_2HIDDEN=4 builds the round-2 kernel): the operand image shrinks to 7
+// blocks per wave (14 KB instead of 20: the first layer's operands go where the upper layers' have been read), the dW reduction
+// takes the 64-row layers in two 32-row passes (8 x 8 KB of slabs instead of 8 x 16 KB), and the register allocation is held to
+// 256 by the 512-thread launch bound.
+#ifndef NGP_MLP_BWD_WAVES_2HIDDEN
+#define NGP_MLP_BWD_WAVES_2HIDDEN 4
+#endif
 template <int N_IN, int N_HIDDEN>
-constexpr int bwd_waves() { return (N_HIDDEN == 1 && N_IN <= 32) ? NGP_MLP_BWD_WAVES_1HIDDEN : 4; }
+constexpr int bwd_waves() { return N_IN > 32 ? 4 : (N_HIDDEN == 1 ? NGP_MLP_BWD_WAVES_1HIDDEN : NGP_MLP_BWD_WAVES_2HIDDEN); }
+template <int N_IN, int N_HIDDEN>
+constexpr bool bwd_staged() { return N_HIDDEN == 2 && bwd_waves<N_IN, N_HIDDEN>() > 4; }
 constexpr int TILE = 32;         // samples per wave tile
 
 __device__ __forceinline__ f32x16 mfma(half8_t a, half8_t b, f32x16 c) {
@@ -546,29 +555,36 @@ __device__ __forceinline__ void wgrad_tile(const char* dy, const char* x, const 
 // f32, lanes on consecutive columns: conflict-free), one barrier, then all threads add the slabs 16 bytes at a time and store
 // the sums straight to the workgroup's partial row in global memory.  (Before: the waves took turns read-modify-writing one
 // LDS copy, 4 serial rounds with barriers -- 11 000 cycles of a 70 000-cycle kernel.)
-template <int MT, int NT, int BWD_WAVES>
+template <int MT, int NT, int BWD_WAVES, bool SPLIT>
 __device__ __forceinline__ void wgrad_reduce_layer(float* slabs, int n_rows, int n_cols, int wave, int j, int hh,
                                                    const f32x16 (&acc)[MT][NT], float* __restrict__ out) {
-    const int n = n_rows * n_cols;                        // a multiple of 4 (n_cols is)
-    float* mine = slabs + wave * n;
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int nn = 0; nn < NT; ++nn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * hh, col = 32 * nn + j;
-                if (row < n_rows && col < n_cols) mine[row * n_cols + col] = acc[m][nn][r];
-            }
-    __syncthreads();
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    for (int t = threadIdx.x * 4; t < n; t += blockDim.x * 4) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(slabs + t);
+    // SPLIT: one pass per 32-row block of the layer (slabs of 32 x n_cols floats), else the whole layer at once
+    constexpr int PASSES = SPLIT ? MT : 1, MP = SPLIT ? 1 : MT;
 #pragma unroll
-        for (int w = 1; w < BWD_WAVES; ++w) v += *reinterpret_cast<const f32x4*>(slabs + w * n + t);
-        *reinterpret_cast<f32x4*>(out + t) = v;
+    for (int p = 0; p < PASSES; ++p) {
+        const int rows_here = SPLIT ? min(32, n_rows - 32 * p) : n_rows;
+        const int n = rows_here * n_cols;                 // a multiple of 4 (n_cols is)
+        float* mine = slabs + wave * n;
+#pragma unroll
+        for (int mm = 0; mm < MP; ++mm)
+#pragma unroll
+            for (int nn = 0; nn < NT; ++nn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * mm + (r & 3) + 8 * (r >> 2) + 4 * hh, col = 32 * nn + j;
+                    if (row < rows_here && col < n_cols) mine[row * n_cols + col] = acc[SPLIT ? p : mm][nn][r];
+                }
+        __syncthreads();
+        float* __restrict__ o = out + (SPLIT ? 32 * p * n_cols : 0);
+        for (int t = threadIdx.x * 4; t < n; t += blockDim.x * 4) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(slabs + t);
+#pragma unroll
+            for (int w = 1; w < BWD_WAVES; ++w) v += *reinterpret_cast<const f32x4*>(slabs + w * n + t);
+            *reinterpret_cast<f32x4*>(o + t) = v;
+        }
+        __syncthreads();                                  // the next pass / layer reuses the slabs
     }
-    __syncthreads();                                      // the next layer reuses the slabs
 }
 
 // Everything a backward tile reads from global memory, as RAW register values: the loads of tile t+1 are issued before tile t
@@ -576,7 +592,6 @@ __device__ __forceinline__ void wgrad_reduce_layer(float* slabs, int n_rows, int
 // before this, every tile paid two dependent ones: active index -> inputs/seeds).
 template <int N_IN>
 struct BwdRaw {
-    long long s, j;
     bool valid;
     half8_t in[N_IN / 16];   // IN_ROWMAJOR / IN_LEVELMAJOR: the input B fragments; IN_SH_H: in[1] = h, in[0] unused
     float dir[3];            // IN_SH_H
@@ -590,7 +605,7 @@ struct BwdRaw {
 // of the prefetch.
 template <int N_IN, int IN_MODE, int OUT_MODE>
 __device__ __forceinline__ void bwd_fetch(const MlpBwdIO& io, long long j, long long s, bool valid, int n_samples, int hh, BwdRaw<N_IN>& r) {
-    r.s = s; r.j = j; r.valid = valid;
+    r.valid = valid;
     r.dir[0] = r.dir[1] = r.dir[2] = 1.0f;
     r.seed[0] = r.seed[1] = r.seed[2] = 0.f;
 #pragma unroll
@@ -672,11 +687,12 @@ struct BwdLds {
     using L = LdsW<N_IN, N_HIDDEN>;
     static constexpr int BWD_WAVES = bwd_waves<N_IN, N_HIDDEN>();
     static constexpr int NXB = (N_IN + 31) / 32;                                   // input blocks
-    static constexpr int NB = NXB + 4 + (N_HIDDEN == 2 ? 4 : 0) + 1;               // blocks per wave
+    static constexpr bool STAGED = bwd_staged<N_IN, N_HIDDEN>();                   // 7 blocks per wave, the first layer's operands reuse the upper layers'
+    static constexpr int NB = STAGED ? 7 : NXB + 4 + (N_HIDDEN == 2 ? 4 : 0) + 1;  // blocks per wave
     static constexpr int W_HALVES = L::SIZE + N_IN * (HID + PAD) + (N_HIDDEN == 2 ? HID * (HID + PAD) : 0) + HID * (16 + PAD);
     static constexpr int OFF_TR = (W_HALVES + 127) / 128 * 128;
     static constexpr int IMG_BYTES = BWD_WAVES * NB * BLK_BYTES;
-    static constexpr int PART_BYTES = BWD_WAVES * HID * (N_IN > HID ? N_IN : HID) * 4;   // one f32 slab per wave of the largest layer
+    static constexpr int PART_BYTES = BWD_WAVES * (STAGED ? 32 : HID) * (N_IN > HID ? N_IN : HID) * 4;   // one f32 slab per wave of the largest layer (STAGED: of its 32-row halves)
     static constexpr int BYTES = OFF_TR * 2 + (IMG_BYTES > PART_BYTES ? IMG_BYTES : PART_BYTES);
 };
 
@@ -758,9 +774,8 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
     for (int tile = t0; tile < n_tiles; tile += tile_stride) {
         fetch(tile + tile_stride, raw_pre, nxt);                     // raw inputs of the next tile ...
         raw_pre = raw_index(tile + 2 * tile_stride);                 // ... and the sample ids of the one after it are in flight
-        const long long j = cur.j;
+        const long long j = min((long long)tile * TILE + i, j_last);   // compact position (lanes past the end: the last sample, gradient forced to zero)
         const bool valid = cur.valid;
-        const long long s = cur.s;
         // ---- forward recompute ----
         half8_t xb[N_IN / 16];
         bwd_input<N_IN, IN_MODE>(cur, hh, xb);
@@ -888,20 +903,39 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
         }
         MLP_T(2);                                      // dgrad + input-gradient store
         // ---- wgrad (samples on K: through the wave-private LDS image, read back transposed) ----
-        wave_lds_sync();                                  // the previous tile's reads are behind us (DS ops of a wave run in order)
-        tr_put_nat<N_IN / 16>(img_x, xb, ta);             // N_IN == 16: units 16..31 of the block feed dW columns nobody stores
-        tr_put_dl<4>(img_dh0, dh0b, ta);
-        tr_put_dl<4>(img_h0, h0b, ta);
-        if (N_HIDDEN == 2) {
-            tr_put_dl<4>(img_dh1, dh1b, ta);
-            tr_put_dl<4>(img_h1, h1b, ta);
+        if (!B::STAGED) {
+            wave_lds_sync();                              // the previous tile's reads are behind us (DS ops of a wave run in order)
+            tr_put_nat<N_IN / 16>(img_x, xb, ta);         // N_IN == 16: units 16..31 of the block feed dW columns nobody stores
+            tr_put_dl<4>(img_dh0, dh0b, ta);
+            tr_put_dl<4>(img_h0, h0b, ta);
+            if (N_HIDDEN == 2) {
+                tr_put_dl<4>(img_dh1, dh1b, ta);
+                tr_put_dl<4>(img_h1, h1b, ta);
+            }
+            tr_put_dl<1>(img_dy, dyb, ta);
+            wave_lds_sync();
+            MLP_T(3);                                  // image stores
+            wgrad_tile<2, B::NXB>(img_dh0, img_x, ta, gW0);                               // dW0 (64 x N_IN) = dH0^T X
+            if (N_HIDDEN == 2) wgrad_tile<2, 2>(img_dh1, img_h0, ta, gW1);                // dW1 (64 x 64)   = dH1^T H0
+            wgrad_tile<1, 2>(img_dy, (N_HIDDEN == 2) ? img_h1 : img_h0, ta, gWo);         // dWo (16 x 64)   = dY^T Hlast
+        } else {
+            // 7 blocks: the two upper layers' operands at once, then the first layer's through the blocks they leave behind
+            char* img_b = img;
+            wave_lds_sync();
+            tr_put_dl<1>(img_b, dyb, ta);                                  // block 0 (units 16..31: dW rows nobody stores)
+            tr_put_dl<4>(img_b + 1 * BLK_BYTES, h1b, ta);                  // blocks 1-2
+            tr_put_dl<4>(img_b + 3 * BLK_BYTES, dh1b, ta);                 // blocks 3-4
+            tr_put_dl<4>(img_b + 5 * BLK_BYTES, h0b, ta);                  // blocks 5-6
+            wave_lds_sync();
+            MLP_T(3);
+            wgrad_tile<1, 2>(img_b, img_b + 1 * BLK_BYTES, ta, gWo);
+            wgrad_tile<2, 2>(img_b + 3 * BLK_BYTES, img_b + 5 * BLK_BYTES, ta, gW1);
+            wave_lds_sync();
+            tr_put_dl<4>(img_b, dh0b, ta);                                 // blocks 0-1
+            tr_put_nat<N_IN / 16>(img_b + 2 * BLK_BYTES, xb, ta);          // block 2
+            wave_lds_sync();
+            wgrad_tile<2, B::NXB>(img_b, img_b + 2 * BLK_BYTES, ta, gW0);
         }
-        tr_put_dl<1>(img_dy, dyb, ta);
-        wave_lds_sync();
-        MLP_T(3);                                      // image stores
-        wgrad_tile<2, B::NXB>(img_dh0, img_x, ta, gW0);                                   // dW0 (64 x N_IN) = dH0^T X
-        if (N_HIDDEN == 2) wgrad_tile<2, 2>(img_dh1, img_h0, ta, gW1);                    // dW1 (64 x 64)   = dH1^T H0
-        wgrad_tile<1, 2>(img_dy, (N_HIDDEN == 2) ? img_h1 : img_h0, ta, gWo);             // dWo (16 x 64)   = dY^T Hlast
         MLP_T(4);                                      // wgrad
         cur = nxt;
     }
@@ -909,9 +943,9 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
     __syncthreads();                                      // the slabs reuse the operand images: every wave is done with them
     constexpr int NT0 = (N_IN / 32 > 0 ? N_IN / 32 : 1);
     float* out = io.wgrad_partial + (size_t)blockIdx.x * L::G_SIZE;
-    wgrad_reduce_layer<2, NT0, BWD_WAVES>(part, HID, N_IN, wave, i, hh, gW0, out);
-    if (N_HIDDEN == 2) wgrad_reduce_layer<2, 2, BWD_WAVES>(part, HID, HID, wave, i, hh, gW1, out + L::G_W1);
-    wgrad_reduce_layer<1, 2, BWD_WAVES>(part, 16, HID, wave, i, hh, gWo, out + L::G_WO);
+    wgrad_reduce_layer<2, NT0, BWD_WAVES, B::STAGED>(part, HID, N_IN, wave, i, hh, gW0, out);
+    if (N_HIDDEN == 2) wgrad_reduce_layer<2, 2, BWD_WAVES, B::STAGED>(part, HID, HID, wave, i, hh, gW1, out + L::G_W1);
+    wgrad_reduce_layer<1, 2, BWD_WAVES, B::STAGED>(part, 16, HID, wave, i, hh, gWo, out + L::G_WO);
     MLP_T(5);                                          // epilogue
     MLP_TEND();
 }

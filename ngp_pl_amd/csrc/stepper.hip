@@ -7,6 +7,7 @@
 // sample count of the batch's march, written by the scan kernel into pinned host memory -- polled with a deadline.
 // No device memory is allocated here; all buffers are the caller's (ngp_step_buffers).
 #include "ngp_common.h"
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -50,6 +51,7 @@ struct ngp_stepper {
     // two-round forward (include/ngp_hip.h): mode 0 off / 1 on / 2 auto, first K, the auto switch's state, steps run in two rounds
     int two_round_mode = 2, two_round_k = 32;
     bool two_round_active = false, two_rounds = false;
+    int set_k[2] = {0, 0};                 // first K the scan of each march record set prepared a compact list for (0: none)
     long long two_round_steps = 0;
     int32_t prev_S = 0;
 };
@@ -141,8 +143,12 @@ int do_march(ngp_stepper* s, const float* rays_o, const float* rays_d, hipStream
     if (s->timing) STEP_HIP(hipEventRecord(s->march_t[k][0], side));
     STEP_TRY(ngp_ray_aabb_near_noise(rays_o, rays_d, c.center, c.half_size, c.near_distance, b.n_rays, c.noise_seed + 0x9E3779B97F4A7C15ull * (++s->marches),
                                      b.hits_t[k], b.noise[k], (ngp_stream_t)side));
-    STEP_TRY(ngp_raymarching_train_count(rays_o, rays_d, b.hits_t[k], c.density_bitfield, c.cascades, c.scale, c.exp_step_factor, b.noise[k],
-                                         c.grid_size, c.max_samples, b.n_rays, b.rays_a[k], b.counter[k], b.scratch[k], (ngp_stream_t)side));
+    // (two-round forward: the scan kernel also places every ray's first K samples in the compact first-round list)
+    const bool lists = s->two_round_mode != 0 && b.list_k && b.list_rest && b.two_round_counts && b.offs_k[k];
+    s->set_k[k] = lists ? s->two_round_k : 0;
+    STEP_TRY(ngp_raymarching_train_count_k(rays_o, rays_d, b.hits_t[k], c.density_bitfield, c.cascades, c.scale, c.exp_step_factor, b.noise[k],
+                                           c.grid_size, c.max_samples, b.n_rays, b.rays_a[k], b.counter[k], b.scratch[k], s->set_k[k],
+                                           lists ? b.offs_k[k] : nullptr, (ngp_stream_t)side));
     if (s->timing) { STEP_HIP(hipEventRecord(s->march_t[k][1], side)); s->march_t_set[k] = true; }
     STEP_HIP(hipEventRecord(s->done[k], side));
     s->has_pending = true; s->pend_o = rays_o; s->pend_d = rays_d; s->pend_set = k;
@@ -223,6 +229,7 @@ int ngp_stepper_pending(const ngp_stepper* s, const float* rays_o, const float* 
 
 int ngp_stepper_last_set(const ngp_stepper* s) { return s ? s->last_set : 0; }
 int ngp_stepper_two_rounds(const ngp_stepper* s) { return (s && s->two_rounds) ? 1 : 0; }
+int ngp_stepper_record_bytes(int which) { return which == 0 ? (int)sizeof(ngp_stepper_config) : (which == 1 ? (int)sizeof(ngp_step_buffers) : NGP_EINVAL); }
 
 int ngp_stepper_march(ngp_stepper* s, const float* rays_o, const float* rays_d, ngp_stream_t main_stream, ngp_stream_t march_stream) {
     if (!s) return NGP_EINVAL;
@@ -278,14 +285,23 @@ static int forward_field(ngp_stepper* s, const float* rays_o, const float* rays_
         }
         return 0;
     }
-    // round 1: every ray's first K samples; round 2: the rest of the rays that are still transparent behind them
+    // round 1: every ray's first K samples (a compact list in ray order where the march's scan prepared it, else a padded one);
+    // round 2: the rest of the rays that are still transparent behind them
     const int K = s->two_round_k;
     ++s->two_round_steps;
     int32_t* n2 = b.two_round_counts;
-    STEP_TRY(ngp_raymarching_train_write_k(rays_o, rays_d, b.rays_a[k], b.scratch[k], c.scale, c.exp_step_factor, c.grid_size, c.max_samples, n,
-                                           b.xyzs, b.dirs, b.deltas, b.ts, K, b.list_k, n2, main_stream));
+    const bool compact = s->set_k[k] == K && b.offs_k[k] != nullptr;       // this record set's scan placed the first K of every ray
+    int n1 = n * K;                                                        // padded list: -1 where a ray has fewer than K samples
+    if (compact) {
+        n1 = b.counter[k][3];
+        if (n1 < 0 || n1 > n * K || n1 > S) return NGP_EINVAL;
+        STEP_TRY(ngp_raymarching_train_write_kc(rays_o, rays_d, b.rays_a[k], b.scratch[k], c.scale, c.exp_step_factor, c.grid_size, c.max_samples, n,
+                                                b.xyzs, b.dirs, b.deltas, b.ts, K, b.offs_k[k], b.list_k, n2, main_stream));
+    } else {
+        STEP_TRY(ngp_raymarching_train_write_k(rays_o, rays_d, b.rays_a[k], b.scratch[k], c.scale, c.exp_step_factor, c.grid_size, c.max_samples, n,
+                                               b.xyzs, b.dirs, b.deltas, b.ts, K, b.list_k, n2, main_stream));
+    }
     mark(s, 1, main);
-    const int n1 = n * K;                                       // padded list: -1 where a ray has fewer than K samples
     STEP_TRY(ngp_hashgrid_fwd_list(b.xyzs, c.xyz_min, c.xyz_max, table, &c.meta, S, b.list_k, n1, nullptr, b.feats, main_stream));
     mark(s, 2, main);
     STEP_TRY(march_next_if_at(s, AT_HASHGRID_FWD));

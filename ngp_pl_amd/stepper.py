@@ -29,7 +29,7 @@ class StepBuffers:
     DISTORTION = (("ws_incl", 4), ("wts_incl", 4), ("dL_dws", 4))
     PER_RAY = (("total", 8), ("opacity", 4), ("depth", 4), ("rgb", 12), ("dL_drgb", 12), ("dL_dopacity", 4), ("ray_offs", 4),
                ("dist", 4), ("zeros", 4), ("dist_seed", 4), ("rgb_out", 12))
-    MARCH = (("hits_t", 8), ("rays_a", 24), ("noise", 4), ("scratch", 4 * MAX_SAMPLES))
+    MARCH = (("hits_t", 8), ("rays_a", 24), ("noise", 4), ("scratch", 4 * MAX_SAMPLES), ("offs_k", 4))
     MAX_PARTIALS = 256
 
     def __init__(self, model, n_rays, distortion, binned):
@@ -110,6 +110,7 @@ class StepBuffers:
         for k in (0, 1):
             c.hits_t[k], c.rays_a[k], c.noise[k], c.scratch[k] = P["hits_t%d" % k], P["rays_a%d" % k], P["noise%d" % k], P["scratch%d" % k]
             c.counter[k] = self.counter_p[k]
+            c.offs_k[k] = P["offs_k%d" % k]
         c.max_partials, c.fw_bytes = self.MAX_PARTIALS, self.fw_bytes
         c.bin_ws, c.bin_bytes, c.bin_max = (P["bin_ws"] if self.bin_max else None), self.bin_bytes, self.bin_max
         return c

@@ -148,3 +148,14 @@ def test_workspace_queries_and_new_entry_points_validate_on_host():
         _lib.call("ngp_adam_step_field", *(field[:5] + [0] + field[6:] + [1, 1.0, 1, None, None]))
     with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
         _lib.call("ngp_adam_step_field", *([None] + field[1:] + [1, 1.0, 1, None, None]))
+
+
+def test_mirrored_records_have_the_librarys_layout():
+    """The ctypes mirrors of ngp_stepper_config / ngp_step_buffers are checked against sizeof() as the library was compiled (the
+    loader refuses a mismatch: a stale .so would otherwise read pointers from the wrong offsets)."""
+    import ctypes as C
+    from ngp_pl_amd import _lib
+    h = _lib.lib()
+    assert h.ngp_stepper_record_bytes(0) == C.sizeof(_lib.StepperConfig)
+    assert h.ngp_stepper_record_bytes(1) == C.sizeof(_lib.StepBuffersC)
+    assert h.ngp_stepper_record_bytes(2) < 0

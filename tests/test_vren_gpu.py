@@ -350,3 +350,77 @@ def test_list_forward_kernels_match_the_full_range_kernels():
     assert torch.equal(f2[:, mask], feats[:, mask]) and bool((f2[:, ~mask] == 9.0).all())
     assert torch.equal(s2[mask], sig[mask]) and torch.equal(c2[mask], rgb[mask]) and torch.equal(h2[mask], h[mask])
     assert bool((s2[~mask] == -3.0).all()) and bool((c2[~mask] == -3.0).all()) and bool((h2[~mask] == 9.0).all())
+
+
+@pytest.mark.parametrize("first_k", [1, 8, 32, 64])
+def test_first_k_lists_of_the_train_write(first_k):
+    """ngp_raymarching_train_write_k / _kc write the same samples as ngp_raymarching_train_write and list every ray's first
+    min(N, first_k) sample ids: padded (ray-major, -1 where a ray has fewer) or compact in ray order at the offsets that
+    ngp_raymarching_train_count_k's scan left in offs_k (total in counter[3]); the side counter is cleared."""
+    from ngp_pl_amd._lib import call, ptr, stream
+    g = np.random.RandomState(5)
+    R, M = 1003, 128                                                           # not a multiple of the 4-ray workgroup
+    N = g.randint(0, M + 1, R); N[g.rand(R) < 0.6] = 0                        # most rays have no samples (late-training shape)
+    start = np.concatenate([[0], np.cumsum(N)[:-1]])
+    S = int(N.sum())
+    perm = g.permutation(R)                                                    # rays_a rows are in march order, r is the ray id
+    rays_a = np.stack([perm, start, N], 1).astype(np.int64)
+    scratch = np.sort(g.rand(R, M).astype(np.float32) * 2 + 0.1, axis=1)
+    ro = dev(g.randn(R, 3).astype(np.float32) * 0.1); rd = dev(g.randn(R, 3).astype(np.float32))
+    d_rays, d_scr = dev(rays_a), dev(scratch)
+    want_rows = np.full((R, first_k), -1, np.int64)
+    for r in range(R):
+        m = min(int(N[r]), first_k)
+        want_rows[r, :m] = start[r] + np.arange(m)
+    want_compact = want_rows[want_rows >= 0]                                   # ray order
+    offs = dev(np.concatenate([[0], np.cumsum(np.minimum(N, first_k))[:-1]]).astype(np.int32))
+
+    def outs():
+        return [torch.full((S, 3), 7.0, device="cuda"), torch.full((S, 3), 7.0, device="cuda"), torch.full((S,), 7.0, device="cuda"), torch.full((S,), 7.0, device="cuda")]
+    ref = outs()
+    call("ngp_raymarching_train_write", ptr(ro), ptr(rd), ptr(d_rays), ptr(d_scr), 0.5, 0.0, 128, M, R, *[ptr(o) for o in ref], stream())
+    pad = outs(); lst = torch.full((R * first_k,), -7, dtype=torch.int32, device="cuda"); side = torch.full((4,), 5, dtype=torch.int32, device="cuda")
+    call("ngp_raymarching_train_write_k", ptr(ro), ptr(rd), ptr(d_rays), ptr(d_scr), 0.5, 0.0, 128, M, R, *[ptr(o) for o in pad], first_k, ptr(lst), ptr(side), stream())
+    com = outs(); lst_c = torch.full((R * first_k,), -7, dtype=torch.int32, device="cuda"); side_c = torch.full((4,), 5, dtype=torch.int32, device="cuda")
+    call("ngp_raymarching_train_write_kc", ptr(ro), ptr(rd), ptr(d_rays), ptr(d_scr), 0.5, 0.0, 128, M, R, *[ptr(o) for o in com], first_k, ptr(offs), ptr(lst_c),
+         ptr(side_c), stream())
+    torch.cuda.synchronize()
+    for a, b, c in zip(ref, pad, com):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    assert np.array_equal(lst.cpu().numpy().reshape(R, first_k), want_rows) and side.tolist() == [0, 5, 5, 5]
+    n = len(want_compact)
+    assert np.array_equal(lst_c[:n].cpu().numpy(), want_compact) and bool((lst_c[n:] == -7).all()) and side_c.tolist() == [0, 5, 5, 5]
+
+
+@pytest.mark.parametrize("first_k", [4, 32])
+def test_train_count_k_scans_the_first_k_offsets(vren, first_k):
+    """ngp_raymarching_train_count_k = ngp_raymarching_train_count (same rays_a, scratch, {S, R}) + offs_k = exclusive scan of
+    min(N, first_k) in ray order and counter[3] = its total; more than one 8192-ray tile of the scan kernel."""
+    from ngp_pl_amd._lib import call, ptr, stream
+    g = np.random.RandomState(11)
+    R, G, M = 20000, 128, 256
+    ro = (g.rand(R, 3).astype(np.float32) - 0.5) * 3.0
+    rd = -ro / np.linalg.norm(ro, axis=1, keepdims=True) + g.randn(R, 3).astype(np.float32) * 0.2
+    rd = (rd / np.linalg.norm(rd, axis=1, keepdims=True)).astype(np.float32)
+    bits = np.packbits((g.rand(G ** 3) < 0.08).astype(np.uint8), bitorder="little")
+    d_o, d_d, d_bits = dev(ro), dev(rd), dev(bits)
+    center = torch.zeros(1, 3, device="cuda"); half = torch.full((1, 3), 0.5, device="cuda")
+    hits = torch.empty(R, 2, device="cuda"); noise = torch.rand(R, device="cuda")
+    call("ngp_ray_aabb_near", ptr(d_o), ptr(d_d), ptr(center), ptr(half), 0.05, R, ptr(hits), stream())
+    res = []
+    for with_k in (False, True):
+        rays_a = torch.full((R, 3), -1, dtype=torch.int64, device="cuda"); cnt = torch.full((4,), -9, dtype=torch.int32, device="cuda")
+        scr = torch.zeros(R, M, device="cuda"); offs = torch.full((R,), -9, dtype=torch.int32, device="cuda")
+        if with_k:
+            call("ngp_raymarching_train_count_k", ptr(d_o), ptr(d_d), ptr(hits), ptr(d_bits), 1, 0.5, 0.0, ptr(noise), G, M, R, ptr(rays_a), ptr(cnt), ptr(scr),
+                 first_k, ptr(offs), stream())
+        else:
+            call("ngp_raymarching_train_count", ptr(d_o), ptr(d_d), ptr(hits), ptr(d_bits), 1, 0.5, 0.0, ptr(noise), G, M, R, ptr(rays_a), ptr(cnt), ptr(scr), stream())
+        torch.cuda.synchronize()
+        res.append((rays_a.cpu(), cnt.cpu(), scr.cpu(), offs.cpu()))
+    (ra0, c0, s0, _), (ra1, c1, s1, offs) = res
+    assert torch.equal(ra0, ra1) and torch.equal(s0, s1) and c0[:2].tolist() == c1[:2].tolist() and c0[3] == -9
+    N = ra1[:, 2].numpy()
+    assert N.sum() == int(c1[0]) > 0 and (N > first_k).any() and (N == 0).any()
+    want = np.concatenate([[0], np.cumsum(np.minimum(N, first_k))[:-1]])
+    assert np.array_equal(offs.numpy(), want) and int(c1[3]) == int(np.minimum(N, first_k).sum())
