@@ -720,7 +720,8 @@ typedef struct ngp_step_buffers {
 /* Two-round forward (NGP_TWO_ROUND = auto (default) | on | off; first K = NGP_TWO_ROUND_K, default 32).  Late in training a few per
  * cent of the marched samples lie in front of their ray's early stop (measured: 5 % after 25 000 steps), yet hash grid and field
  * were evaluated on all of them.  When the previous step's live fraction is below 0.15 (back above 0.25: off again) front() runs:
- * sample expansion + padded list of every ray's first K samples -> hash grid + field on that list -> ngp_composite_probe lists
+ * sample expansion + list of every ray's first K samples (compact, at the offsets the march's scan prepared in offs_k; padded
+ * where it did not) -> hash grid + field on that list -> ngp_composite_probe lists
  * the rest of the rays that are still transparent -> hash grid + field on that list -> the unchanged composite.  Exactly
  * equivalent: the composite never reads a sample behind a ray's stop (volumerendering.cu:20-44), and every sample in front of it
  * has been evaluated by the same per-sample kernels (tests/test_train_gpu.py::test_two_round_forward_is_bit_identical).  What it
