@@ -11,9 +11,12 @@
 //   * work item = (sample, level); one thread gathers the 8 corners of one level (8 x 4 B
 //     half2 loads in flight per lane), so a workgroup only ever touches ONE level's table;
 //   * workgroups are mapped level-major and XCD-aware: workgroup b runs (observed, speed
-//     only) on XCD b%8, and each XCD is handed two whole levels {x, 15-x}, so the 2 MiB
-//     hashed table it is gathering from stays resident in that XCD's private 4 MiB L2
-//     instead of all 22.8 MB competing for every L2;
+//     only) on XCD b%8, and every level with a large table is handed whole to one XCD, so the
+//     2 MiB hashed table it is gathering from stays resident in that XCD's private 4 MiB L2
+//     instead of all 22.8 MB competing for every L2; the small dense levels fill the XCDs up
+//     to equal cost (FwdMap; launches sized for a device-side count pair levels {x, 15-x});
+//   * the lanes of a wave are consecutive samples of a ray: only the first lane of a run of
+//     lanes in one cell gathers, the rest take the corners from it (cell runs, below);
 //   * features are stored LEVEL-MAJOR [L][S] half2: every store/load of the stream is a
 //     contiguous 256 B per wave (the row-major (S,32) layout would be 4-byte writes at a
 //     64-byte stride);
@@ -24,6 +27,7 @@
 #include "hashgrid_common.h"
 #include <hip/hip_fp16.h>
 #include <cstdlib>
+#include <cstring>
 
 using namespace ngp_grid;
 
@@ -38,6 +42,44 @@ __device__ __forceinline__ bool map_block(int n_levels, int n_chunks, int& level
     if (n_levels == 16) level = (slot == 0) ? xcd : 15 - xcd;   // pair a small dense level with a hashed one
     else level = xcd + 8 * slot;
     return level < n_levels;
+}
+
+// Cost-balanced map of the forward (round 3).  The pair map above gives XCD 0 the cheapest and the most expensive level: measured
+// one level at a time (305 k ray-ordered samples, tools/profile_fwd_levels.py) a level costs 16 us (res 16) .. 38 us (res 1025),
+// the launch takes as long as its slowest pair (0 + 15: 54 us) while the sum over the levels is 340 us, 42 per XCD.  Here every
+// level's chunks are dealt out in 16 phases (chunk % 16) and an XCD takes a set of phases per level (make_fwd_map): any prefix of
+// the chunks (device-sized batches) is balanced the same way.
+struct FwdMap {
+    // per XCD up to 16 pieces = (level, set of phases), taken one after the other (a large table is in use by one piece at a
+    // time): end[k][j] = number of the XCD's workgroups up to and including piece j, piece[k][j] = level << 16 | phase mask,
+    // magic[k][j] = ceil(2^32 / phases of the piece) (division by multiplication).  The row arrives with three scalar loads;
+    // measured alternatives: a serial walk over per-level masks in kernel-argument memory (16 dependent loads per workgroup:
+    // 1.6x slower), period-major order (chunks in lockstep over all pieces: 47 instead of 45 us, two 2 MiB tables alternate
+    // in the L2 of the XCDs that own two).  Launches sized for a bound on a device-side sample count keep the pair map: a
+    // workgroup that finds its chunk beyond the count costs ~100 scalar instructions here (the scalar unit is shared by a CU's
+    // SIMDs), 5x what it costs there (bound = 2x count: 258 us against 234).
+    int32_t end[8][16];
+    uint32_t piece[8][16];
+    uint32_t magic[8][16];
+    int32_t blocks_per_xcd;             // 0: pair map
+};
+
+__device__ __forceinline__ bool map_block_weighted(const FwdMap& m, int n_chunks, int& level, int& chunk) {
+    const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
+    int e[16]; uint32_t pc[16], mg[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { e[j] = m.end[xcd][j]; pc[j] = m.piece[xcd][j]; mg[j] = m.magic[xcd][j]; }
+    if (q >= e[15]) return false;
+    int begin = 0; uint32_t mine = pc[0], mag = mg[0];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) if (q >= e[j - 1]) { begin = e[j - 1]; mine = pc[j]; mag = mg[j]; }
+    const uint32_t mk = mine & 0xFFFFu;
+    const int per = __builtin_popcount(mk), full = n_chunks >> 4, ql = q - begin;
+    const int period = min(per == 1 ? ql : (int)__umulhi((uint32_t)ql, mag), full), r = ql - period * per;    // ql / per, exact for ql < 2^28
+    uint32_t t = mk;
+    for (int k = 0; k < r; ++k) t &= t - 1u;
+    level = (int)(mine >> 16); chunk = period * 16 + (int)__builtin_ctz(t);
+    return true;
 }
 
 __device__ __forceinline__ void cell_of(const float* __restrict__ x, const Box& box, size_t i, float scale,
@@ -69,14 +111,24 @@ __device__ __forceinline__ void encode_one(const half2_t* __restrict__ tab, uint
     }
 }
 
+// Cell runs.  The lanes of a wave are consecutive samples of a ray, and on the coarse levels dozens of them sit in ONE cell (a
+// level-0 cell is 37 march steps across): 64 lanes then ask for the same 8 corners.  The vector memory path charges per lane
+// address whatever the addresses are (measured: the dense levels gather only ~2x faster than the hashed ones), so on levels up
+// to reuse_max_res only the FIRST lane of every run of equal cells gathers; the other lanes of the run take the 8 values from it
+// through the LDS crossbar (ds_bpermute: 8 per wave instead of 8 x 64 lane addresses).  Same values, same arithmetic: bit-identical.
+__device__ __forceinline__ half2_t lane_read(half2_t v, int src_lane) {
+    return __builtin_bit_cast(half2_t, __shfl(__builtin_bit_cast(int, v), src_lane, 64));
+}
+
 // SPT samples per thread: all 8*SPT gathers of a thread are issued before the first blend.
 template <int SPT>
 __global__ void __launch_bounds__(256)
 hashgrid_fwd_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const float* __restrict__ xyz_max,
                     const half2_t* __restrict__ table, GridMeta meta, int n_samples, int n_chunks,
-                    const int32_t* __restrict__ n_dev, half2_t* __restrict__ feats) {
+                    const int32_t* __restrict__ n_dev, half2_t* __restrict__ feats, uint32_t reuse_max_res, FwdMap fmap) {
     int level, chunk;
-    if (!map_block(meta.n_levels, n_chunks, level, chunk)) return;
+    if (fmap.blocks_per_xcd > 0) { if (!map_block_weighted(fmap, n_chunks, level, chunk)) return; }
+    else if (!map_block(meta.n_levels, n_chunks, level, chunk)) return;
     // device-sized batches (sync-free callers): the launch covers an upper bound, *n_dev is the
     // real sample count and also the level stride of `feats`
     if (n_dev != nullptr) {
@@ -89,6 +141,37 @@ hashgrid_fwd_kernel(const float* __restrict__ x, const float* __restrict__ xyz_m
     const Box box = load_box(xyz_min, xyz_max);
     const bool hashed = level_is_hashed(res, size);
     const float scale = meta.scale[level];
+    if (SPT == 1 && res <= reuse_max_res) {                                   // (wave-uniform)
+        const int i = chunk * 256 + threadIdx.x, lane = threadIdx.x & 63;
+        const bool ok = i < n_samples;
+        uint32_t p[3]; float f[3];
+        cell_of(x, box, (size_t)(ok ? i : n_samples - 1), scale, p, f);       // lanes past the end: the last sample's cell, no run of their own
+        const uint32_t q0 = __shfl_up(p[0], 1, 64), q1 = __shfl_up(p[1], 1, 64), q2 = __shfl_up(p[2], 1, 64);
+        const bool first = lane == 0 || p[0] != q0 || p[1] != q1 || p[2] != q2;
+        const unsigned long long firsts = __ballot(first);
+        const int src = 63 - __builtin_clzll(firsts & ((2ull << lane) - 1ull)); // the run's first lane (lane 0 always is one)
+        half2_t v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { v[c][0] = (_Float16)0; v[c][1] = (_Float16)0; }
+        if (first) {
+            uint32_t idx[8];
+            if (hashed) corner_indices<true>(p, res, size, idx);
+            else corner_indices<false>(p, res, size, idx);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = tab[idx[c]];
+        }
+        float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const half2_t u = lane_read(v[c], src);
+            const float w = corner_weight(c, f);
+            o0 = fmaf(w, (float)u[0], o0);
+            o1 = fmaf(w, (float)u[1], o1);
+        }
+        half2_t out; out[0] = (_Float16)o0; out[1] = (_Float16)o1;
+        if (ok) __builtin_nontemporal_store(out, feats + (size_t)level * n_samples + i);
+        return;
+    }
     uint32_t idx[SPT][8]; float f[SPT][3]; bool ok[SPT];
 #pragma unroll
     for (int k = 0; k < SPT; ++k) {
@@ -139,25 +222,41 @@ hashgrid_fwd_list_kernel(const float* __restrict__ x, const float* __restrict__ 
     const float scale = meta.scale[level];
     // the launch has a FIXED number of chunks per level (a list whose length only the device knows would otherwise be launched
     // for its bound: 20 000 workgroups that look at the count and leave cost more than the work); chunks stride over the list
-    for (int j = chunk * 256 + threadIdx.x; j < n_list; j += n_chunks * 256) {
-        const int i = list[j];
-        if ((unsigned)i >= (unsigned)n_samples) continue;                // padding entries are -1
-        uint32_t p[3], idx[8]; float f[3];
-        cell_of(x, box, (size_t)i, scale, p, f);
-        if (hashed) corner_indices<true>(p, res, size, idx);
-        else corner_indices<false>(p, res, size, idx);
+    // cell runs as in hashgrid_fwd_kernel: the list holds runs of consecutive samples of a ray; only the first lane of a run of
+    // equal cells gathers.  The loop is wave-uniform (whole waves step over the list) so that every lane takes part in the exchange.
+    const int lane = threadIdx.x & 63;
+    for (int jw = chunk * 256 + (int)(threadIdx.x & ~63u); jw < n_list; jw += n_chunks * 256) {
+        const int j = jw + lane;
+        const int i = j < n_list ? list[j] : -1;
+        const bool valid = (unsigned)i < (unsigned)n_samples;            // padding entries are -1
+        uint32_t p[3]; float f[3];
+        cell_of(x, box, (size_t)(valid ? i : 0), scale, p, f);
+        const uint32_t q0 = __shfl_up(p[0], 1, 64), q1 = __shfl_up(p[1], 1, 64), q2 = __shfl_up(p[2], 1, 64);
+        const bool prev_valid = __shfl_up((int)valid, 1, 64) != 0;
+        const bool first = valid && (lane == 0 || !prev_valid || p[0] != q0 || p[1] != q1 || p[2] != q2);
+        const unsigned long long firsts = __ballot(first);
+        const unsigned long long upto = firsts & ((2ull << lane) - 1ull);
+        const int src = upto ? 63 - __builtin_clzll(upto) : lane;        // (a valid lane always finds its run's first lane)
         half2_t v[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = tab[idx[c]];
+        for (int c = 0; c < 8; ++c) { v[c][0] = (_Float16)0; v[c][1] = (_Float16)0; }
+        if (first) {
+            uint32_t idx[8];
+            if (hashed) corner_indices<true>(p, res, size, idx);
+            else corner_indices<false>(p, res, size, idx);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = tab[idx[c]];
+        }
         float o0 = 0.f, o1 = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
+            const half2_t u = lane_read(v[c], src);
             const float w = corner_weight(c, f);
-            o0 = fmaf(w, (float)v[c][0], o0);
-            o1 = fmaf(w, (float)v[c][1], o1);
+            o0 = fmaf(w, (float)u[0], o0);
+            o1 = fmaf(w, (float)u[1], o1);
         }
         half2_t out; out[0] = (_Float16)o0; out[1] = (_Float16)o1;
-        __builtin_nontemporal_store(out, feats + (size_t)level * n_samples + i);
+        if (valid) __builtin_nontemporal_store(out, feats + (size_t)level * n_samples + i);
     }
 }
 
@@ -551,6 +650,63 @@ feats_from_rowmajor_kernel(const half2_t* __restrict__ in, int n_levels, int n_s
     feats[t] = in[(size_t)s * n_levels + l];
 }
 
+// see FwdMap.  Costs as measured one level at a time with cell runs on (us per 305 k samples on one XCD): 15 + 0.0225 x resolution
+// for a level with a large table, 16 for a dense one.  A large table (> 1 MiB) must stay in ONE XCD's 4 MiB L2 (cutting such levels
+// across XCDs by weight alone was measured: 54 -> 94..335 us, three 2 MiB tables per L2), so those levels go whole to the least
+// loaded XCD, most expensive first; the small dense levels, whose tables fit any L2 many times over, are dealt out in sixteenths
+// to fill the XCDs up to the same load.
+FwdMap make_fwd_map(const ngp_grid_meta* meta, int n_chunks, bool exact) {
+    FwdMap m;
+    uint16_t mask[8][NGP_MAX_LEVELS];
+    for (int k = 0; k < 8; ++k) for (int l = 0; l < NGP_MAX_LEVELS; ++l) mask[k][l] = 0;
+    for (int k = 0; k < 8; ++k) for (int j = 0; j < 16; ++j) { m.end[k][j] = 0; m.piece[k][j] = 1u; m.magic[k][j] = 0xFFFFFFFFu; }
+    m.blocks_per_xcd = 0;
+    static const int mode = [] { const char* e = getenv("NGP_FWD_MAP"); return (e && strcmp(e, "pairs") == 0) ? 0 : 1; }();
+    static const float small_cost = [] { const char* e = getenv("NGP_FWD_SMALL_COST"); return e ? (float)atof(e) : 16.0f; }();
+    if (mode == 0 || !exact || meta->n_levels < 8) return m;
+    float load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool big[NGP_MAX_LEVELS], done[NGP_MAX_LEVELS];
+    float cost[NGP_MAX_LEVELS];
+    for (int l = 0; l < meta->n_levels; ++l) {
+        const uint32_t size = meta->offset[l + 1] - meta->offset[l];
+        big[l] = (size_t)size * 4 > (1u << 20);
+        const float res = meta->resolution[l] < 2048u ? (float)meta->resolution[l] : 2048.f;
+        cost[l] = big[l] ? 15.0f + 0.0225f * res : small_cost;
+        done[l] = false;
+    }
+    auto least = [&] { int b = 0; for (int k = 1; k < 8; ++k) if (load[k] < load[b]) b = k; return b; };
+    for (;;) {                                                      // large tables: whole levels, most expensive first
+        int pick = -1;
+        for (int l = 0; l < meta->n_levels; ++l) if (big[l] && !done[l] && (pick < 0 || cost[l] > cost[pick])) pick = l;
+        if (pick < 0) break;
+        const int k = least();
+        mask[k][pick] = 0xFFFFu; load[k] += cost[pick]; done[pick] = true;
+    }
+    for (int l = meta->n_levels - 1; l >= 0; --l) {                 // small tables: by sixteenths
+        if (big[l]) continue;
+        for (int ph = 0; ph < 16; ++ph) {
+            const int k = least();
+            mask[k][l] |= (uint16_t)(1u << ph); load[k] += cost[l] / 16.f;
+        }
+    }
+    const int full = n_chunks >> 4;
+    const uint32_t low = (1u << (n_chunks & 15)) - 1u;
+    for (int k = 0; k < 8; ++k) {
+        int cnt = 0, j = 0;
+        for (int l = meta->n_levels - 1; l >= 0; --l) {
+            if (!mask[k][l]) continue;
+            const int per = __builtin_popcount(mask[k][l]);
+            cnt += full * per + __builtin_popcount(mask[k][l] & low);
+            m.end[k][j] = cnt; m.piece[k][j] = ((uint32_t)l << 16) | mask[k][l];
+            m.magic[k][j] = per == 1 ? 0xFFFFFFFFu : (uint32_t)(((1ull << 32) + per - 1) / per);
+            ++j;
+        }
+        for (; j < 16; ++j) m.end[k][j] = cnt;                      // (unused pieces: empty ranges)
+        if (cnt > m.blocks_per_xcd) m.blocks_per_xcd = cnt;
+    }
+    return m;
+}
+
 int n_blocks_for(int n_levels, int n_chunks) {
     const int slots = (n_levels == 16) ? 2 : (n_levels + 7) / 8;
     return 8 * slots * n_chunks;
@@ -628,8 +784,12 @@ int ngp_hashgrid_fwd_n(const float* x, const float* xyz_min, const float* xyz_ma
     // SPT = 1: measured on MI355X, 2 or 4 samples per thread change nothing (57 / 55 / 57 us at 303 k coherent samples):
     // the kernel is bound by L2 gather transactions, not by loads in flight per lane.
     const int n_chunks = ngp_div_up(n_samples, 256);
-    hipLaunchKernelGGL(hashgrid_fwd_kernel<1>, dim3(n_blocks_for(meta->n_levels, n_chunks)), dim3(256), 0, ngp_stream(stream),
-                       x, xyz_min, xyz_max, (const half2_t*)table, to_dev_meta(meta), n_samples, n_chunks, n_dev, (half2_t*)feats);
+    // cell runs (see hashgrid_fwd_kernel): levels up to this resolution gather once per run of lanes in one cell
+    static const uint32_t reuse_max_res = [] { const char* e = getenv("NGP_FWD_REUSE_MAX_RES"); return e ? (uint32_t)atoi(e) : 1u << 30; }();
+    const FwdMap fmap = make_fwd_map(meta, n_chunks, n_dev == nullptr);
+    const int n_blocks = fmap.blocks_per_xcd > 0 ? 8 * fmap.blocks_per_xcd : n_blocks_for(meta->n_levels, n_chunks);
+    hipLaunchKernelGGL(hashgrid_fwd_kernel<1>, dim3(n_blocks), dim3(256), 0, ngp_stream(stream),
+                       x, xyz_min, xyz_max, (const half2_t*)table, to_dev_meta(meta), n_samples, n_chunks, n_dev, (half2_t*)feats, reuse_max_res, fmap);
     return NGP_LAUNCH_RESULT();
 }
 

@@ -8,6 +8,7 @@ tiny-cuda-nn's published algorithm -- the reference does not pin it (see the ora
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import pytest
@@ -597,3 +598,48 @@ def test_lds_resident_coarse_levels_forward_is_bit_identical(lib, field):
         assert torch.equal(out[:3], ref[:3]) and (out[3:] == 0).all()
     with pytest.raises(lib.NgpError):           # level 6 is hashed and the first 7 levels do not fit a CU's LDS
         lib.call("ngp_hashgrid_fwd_lds", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(table_h), C.byref(meta), 7, n, lib.ptr(out), lib.stream())
+
+
+_FWD_VARIANT_SCRIPT = r"""
+import ctypes as C, hashlib, math, sys, torch
+from ngp_pl_amd._lib import GridMeta, call, ptr, stream
+torch.manual_seed(0)
+meta = GridMeta()
+call("ngp_grid_meta_init", C.byref(meta), 16, 2, 19, 16, float(math.exp(math.log(2048 * 0.5 / 16) / 15)))
+R, K = 700, 41                                   # ray-ordered samples: runs of lanes in one cell on the coarse levels
+o = torch.rand(R, 1, 3, device="cuda") - 0.5
+d = torch.randn(R, 1, 3, device="cuda"); d = d / d.norm(dim=-1, keepdim=True)
+x = (o * 0.7 + d * (torch.arange(K, device="cuda").view(1, K, 1) * 1.7e-3)).clamp(-0.5, 0.5).reshape(-1, 3).contiguous()
+x[1000:1100] = x[1000]                           # a run longer than a wave
+S = x.shape[0]
+table = ((torch.rand(meta.offset[16], 2, device="cuda") - 0.5) * 0.4).half()
+mn = torch.full((3,), -0.5, device="cuda"); mx = torch.full((3,), 0.5, device="cuda")
+f = torch.zeros(16, S, 2, dtype=torch.float16, device="cuda")
+call("ngp_hashgrid_fwd", ptr(x), ptr(mn), ptr(mx), ptr(table), C.byref(meta), S, ptr(f), stream())
+n_dev = torch.tensor([S - 777], dtype=torch.int32, device="cuda")
+g = torch.zeros(16, S, 2, dtype=torch.float16, device="cuda")                       # device-sized launch (level stride = the count)
+call("ngp_hashgrid_fwd_n", ptr(x), ptr(mn), ptr(mx), ptr(table), C.byref(meta), S, ptr(n_dev), ptr(g), stream())
+lst = torch.arange(S, device="cuda", dtype=torch.int32).view(-1, 7)[::2].reshape(-1).contiguous()   # runs of 7 samples, every other one
+h = torch.zeros(16, S, 2, dtype=torch.float16, device="cuda")
+call("ngp_hashgrid_fwd_list", ptr(x), ptr(mn), ptr(mx), ptr(table), C.byref(meta), S, ptr(lst), lst.numel(), None, ptr(h), stream())
+torch.cuda.synchronize()
+assert torch.equal(h[:, lst.long()], f[:, lst.long()])
+print("DIGEST", hashlib.sha256(f.cpu().numpy().tobytes() + g.cpu().numpy().tobytes() + h.cpu().numpy().tobytes()).hexdigest())
+"""
+
+
+def test_forward_variants_agree_bit_for_bit(lib):
+    """The hash forward's cell runs (one gather per run of lanes in a cell, NGP_FWD_REUSE_MAX_RES) and its two workgroup maps
+    (NGP_FWD_MAP = balanced | pairs) are scheduling only: the features of the plain, the device-sized and the list launch are the
+    same bits under every combination (the switches are read once per process, hence child processes)."""
+    import subprocess, sys
+    digests = {}
+    for name, env in (("default", {}), ("no runs, pair map", {"NGP_FWD_REUSE_MAX_RES": "0", "NGP_FWD_MAP": "pairs"}),
+                      ("runs on the dense levels only, pair map", {"NGP_FWD_REUSE_MAX_RES": "64", "NGP_FWD_MAP": "pairs"}),
+                      ("no runs, balanced map", {"NGP_FWD_REUSE_MAX_RES": "0"})):
+        e = dict(os.environ); e.update(env)
+        e["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + e.get("PYTHONPATH", "")
+        r = subprocess.run([sys.executable, "-c", _FWD_VARIANT_SCRIPT], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        digests[name] = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0]
+    assert len(set(digests.values())) == 1, digests
