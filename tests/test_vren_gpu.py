@@ -402,10 +402,10 @@ def test_train_count_k_scans_the_first_k_offsets(vren, first_k):
     ro = (g.rand(R, 3).astype(np.float32) - 0.5) * 3.0
     rd = -ro / np.linalg.norm(ro, axis=1, keepdims=True) + g.randn(R, 3).astype(np.float32) * 0.2
     rd = (rd / np.linalg.norm(rd, axis=1, keepdims=True)).astype(np.float32)
-    bits = np.packbits((g.rand(G ** 3) < 0.08).astype(np.uint8), bitorder="little")
+    bits = np.packbits((g.rand(G ** 3) < 0.4).astype(np.uint8), bitorder="little")       # dense enough for rays with more than first_k samples
     d_o, d_d, d_bits = dev(ro), dev(rd), dev(bits)
     center = torch.zeros(1, 3, device="cuda"); half = torch.full((1, 3), 0.5, device="cuda")
-    hits = torch.empty(R, 2, device="cuda"); noise = torch.rand(R, device="cuda")
+    hits = torch.empty(R, 2, device="cuda"); noise = dev(g.rand(R).astype(np.float32))
     call("ngp_ray_aabb_near", ptr(d_o), ptr(d_d), ptr(center), ptr(half), 0.05, R, ptr(hits), stream())
     res = []
     for with_k in (False, True):
