@@ -144,7 +144,10 @@ int do_march(ngp_stepper* s, const float* rays_o, const float* rays_d, hipStream
     STEP_TRY(ngp_ray_aabb_near_noise(rays_o, rays_d, c.center, c.half_size, c.near_distance, b.n_rays, c.noise_seed + 0x9E3779B97F4A7C15ull * (++s->marches),
                                      b.hits_t[k], b.noise[k], (ngp_stream_t)side));
     // (two-round forward: the scan kernel also places every ray's first K samples in the compact first-round list)
-    const bool lists = s->two_round_mode != 0 && b.list_k && b.list_rest && b.two_round_counts && b.offs_k[k];
+    // ... only while the two-round forward is in use: the second scan lengthens the march by ~6 us, which the benchmark's
+    // operating point (one round) would pay for nothing
+    const bool lists = (s->two_round_mode == 1 || (s->two_round_mode == 2 && s->two_round_active)) && b.list_k && b.list_rest &&
+                       b.two_round_counts && b.offs_k[k];
     s->set_k[k] = lists ? s->two_round_k : 0;
     STEP_TRY(ngp_raymarching_train_count_k(rays_o, rays_d, b.hits_t[k], c.density_bitfield, c.cascades, c.scale, c.exp_step_factor, b.noise[k],
                                            c.grid_size, c.max_samples, b.n_rays, b.rays_a[k], b.counter[k], b.scratch[k], s->set_k[k],
