@@ -304,6 +304,12 @@ int ngp_hashgrid_fwd_lds(const float* x, const float* xyz_min, const float* xyz_
 int ngp_hashgrid_fwd_n(const float* x, const float* xyz_min, const float* xyz_max,
                        const ngp_half* table, const ngp_grid_meta* meta, int n_samples_max,
                        const int32_t* n_dev, ngp_half* feats, ngp_stream_t stream);
+/* Diagnostics (host only, no launch): the workgroup map ngp_hashgrid_fwd uses for n_chunks = ceil(n_samples / 256) chunks per
+ * level -- every level with a table above 1 MiB whole on one XCD, the small ones in sixteenths (csrc/hashgrid.hip, FwdMap).
+ * Writes up to max_blocks triples (xcd, level, chunk), one per workgroup that has work, and returns their number (16 * n_chunks
+ * when every (level, chunk) is covered once); 0 when the table uses the pair map. */
+int ngp_debug_hashgrid_fwd_map(const ngp_grid_meta* meta, int n_chunks, int32_t* xcd_level_chunk, int max_blocks);
+
 /* Encode forward over an explicit list of sample ids: work item j < n_list (n_list_max on the host; min(*n_list_dev, n_list_max) if
  * n_list_dev is given) encodes sample list[j] and writes feats[level][list[j]] (level stride n_samples); entries outside
  * [0, n_samples) are padding and skipped.  Per-sample results, independent of the list order. */

@@ -68,6 +68,7 @@ _PROTOS = {
     "ngp_raymarching_train_write_kc": [P, P, P, P, F, F, I, I, I, P, P, P, P, I, P, P, P, P],
     "ngp_raymarching_train_count_k": [P, P, P, P, I, F, F, P, I, I, I, P, P, P, I, P, P],
     "ngp_stepper_record_bytes": [I],
+    "ngp_debug_hashgrid_fwd_map": [C.POINTER(GridMeta), I, P, I],
     "ngp_raymarching_test": [P, P, P, P, P, I, F, F, I, I, I, I, P, P, P, P, P, P],
     "ngp_composite_train_fw": [P, P, P, P, P, F, I, I, P, P, P, P, P, P, P],
     "ngp_composite_train_bw": [P] * 13 + [F, I, I, P, P, P, P, P, P, P],
@@ -150,7 +151,7 @@ _PROTOS = {
                               C.POINTER(C.c_float), P, C.c_size_t, P, P, P, P, C.POINTER(C.c_int32), P],
 }
 _COUNT_QUERIES = ("ngp_field_bwd_partials", "ngp_mlp_bwd_partials", "ngp_abi_version", "ngp_stepper_pending", "ngp_stepper_last_set", "ngp_stepper_two_rounds",
-                  "ngp_stepper_record_bytes")
+                  "ngp_stepper_record_bytes", "ngp_debug_hashgrid_fwd_map")
 
 _lib = None
 

@@ -64,8 +64,9 @@ struct FwdMap {
     int32_t blocks_per_xcd;             // 0: pair map
 };
 
-__device__ __forceinline__ bool map_block_weighted(const FwdMap& m, int n_chunks, int& level, int& chunk) {
-    const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
+// workgroup b -> (level, chunk) under a piece table (host and device: ngp_debug_hashgrid_fwd_map walks it on the CPU)
+__host__ __device__ __forceinline__ bool fwd_map_lookup(const FwdMap& m, int n_chunks, int b, int& level, int& chunk) {
+    const int xcd = b & 7, q = b >> 3;
     int e[16]; uint32_t pc[16], mg[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) { e[j] = m.end[xcd][j]; pc[j] = m.piece[xcd][j]; mg[j] = m.magic[xcd][j]; }
@@ -75,11 +76,15 @@ __device__ __forceinline__ bool map_block_weighted(const FwdMap& m, int n_chunks
     for (int j = 1; j < 16; ++j) if (q >= e[j - 1]) { begin = e[j - 1]; mine = pc[j]; mag = mg[j]; }
     const uint32_t mk = mine & 0xFFFFu;
     const int per = __builtin_popcount(mk), full = n_chunks >> 4, ql = q - begin;
-    const int period = min(per == 1 ? ql : (int)__umulhi((uint32_t)ql, mag), full), r = ql - period * per;    // ql / per, exact for ql < 2^28
+    const int quot = per == 1 ? ql : (int)(uint32_t)(((unsigned long long)(uint32_t)ql * mag) >> 32);     // ql / per, exact for ql < 2^28
+    const int period = quot < full ? quot : full, r = ql - period * per;
     uint32_t t = mk;
     for (int k = 0; k < r; ++k) t &= t - 1u;
     level = (int)(mine >> 16); chunk = period * 16 + (int)__builtin_ctz(t);
     return true;
+}
+__device__ __forceinline__ bool map_block_weighted(const FwdMap& m, int n_chunks, int& level, int& chunk) {
+    return fwd_map_lookup(m, n_chunks, (int)blockIdx.x, level, chunk);
 }
 
 __device__ __forceinline__ void cell_of(const float* __restrict__ x, const Box& box, size_t i, float scale,
@@ -791,6 +796,21 @@ int ngp_hashgrid_fwd_n(const float* x, const float* xyz_min, const float* xyz_ma
     hipLaunchKernelGGL(hashgrid_fwd_kernel<1>, dim3(n_blocks), dim3(256), 0, ngp_stream(stream),
                        x, xyz_min, xyz_max, (const half2_t*)table, to_dev_meta(meta), n_samples, n_chunks, n_dev, (half2_t*)feats, reuse_max_res, fmap);
     return NGP_LAUNCH_RESULT();
+}
+
+int ngp_debug_hashgrid_fwd_map(const ngp_grid_meta* meta, int n_chunks, int32_t* xcd_level_chunk, int max_blocks) {
+    if (!meta || n_chunks < 1 || max_blocks < 0 || (max_blocks > 0 && !xcd_level_chunk)) return NGP_EINVAL;
+    const FwdMap m = make_fwd_map(meta, n_chunks, true);
+    if (m.blocks_per_xcd <= 0) return 0;                            // the pair map is in use for this table (or NGP_FWD_MAP=pairs)
+    const int n_blocks = 8 * m.blocks_per_xcd;
+    int n = 0;
+    for (int b = 0; b < n_blocks; ++b) {
+        int level, chunk;
+        if (!fwd_map_lookup(m, n_chunks, b, level, chunk)) continue;
+        if (n < max_blocks) { xcd_level_chunk[3 * n] = b & 7; xcd_level_chunk[3 * n + 1] = level; xcd_level_chunk[3 * n + 2] = chunk; }
+        ++n;
+    }
+    return n;
 }
 
 int ngp_hashgrid_fwd_list(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* table,

@@ -159,3 +159,31 @@ def test_mirrored_records_have_the_librarys_layout():
     assert h.ngp_stepper_record_bytes(0) == C.sizeof(_lib.StepperConfig)
     assert h.ngp_stepper_record_bytes(1) == C.sizeof(_lib.StepBuffersC)
     assert h.ngp_stepper_record_bytes(2) < 0
+
+
+@pytest.mark.parametrize("scale", [0.5, 16.0])
+def test_forward_workgroup_map_covers_every_chunk_of_every_level_once(scale):
+    """The hash forward's cost-balanced workgroup map (csrc/hashgrid.hip, FwdMap), walked on the CPU by
+    ngp_debug_hashgrid_fwd_map: for any number of chunks every (level, chunk) is handed to exactly one workgroup, a level with a
+    table above 1 MiB is served by a single XCD, and the XCDs' workgroup counts are level within the granularity of the split."""
+    import ctypes as C
+    import math
+    import numpy as np
+    from ngp_pl_amd import _lib
+    meta = _lib.GridMeta()
+    _lib.call("ngp_grid_meta_init", C.byref(meta), 16, 2, 19, 16, float(math.exp(math.log(2048 * scale / 16) / 15)))
+    for n_chunks in list(range(1, 40)) + [255, 256, 257, 1192, 1259, 5078]:
+        buf = np.full((16 * n_chunks + 8, 3), -1, np.int32)
+        n = _lib.call("ngp_debug_hashgrid_fwd_map", C.byref(meta), n_chunks, buf.ctypes.data, buf.shape[0])
+        assert n == 16 * n_chunks, (n_chunks, n)
+        got = buf[:n]
+        keys = got[:, 1].astype(np.int64) * (1 << 20) + got[:, 2]
+        assert len(np.unique(keys)) == n and got[:, 2].max() == n_chunks - 1 and got[:, 1].min() == 0 and got[:, 1].max() == 15
+        for l in range(16):
+            size = meta.offset[l + 1] - meta.offset[l]
+            xcds = np.unique(got[got[:, 1] == l, 0])
+            if size * 4 > (1 << 20):
+                assert len(xcds) == 1, (l, xcds)
+        if n_chunks >= 256:
+            per_xcd = np.bincount(got[:, 0], minlength=8)
+            assert per_xcd.min() > 0 and per_xcd.max() <= 3 * n_chunks                    # at most two or three whole levels (cost-, not count-balanced)
