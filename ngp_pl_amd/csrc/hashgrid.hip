@@ -208,6 +208,80 @@ hashgrid_fwd_kernel(const float* __restrict__ x, const float* __restrict__ xyz_m
 }
 
 
+// Device-sized launches (the test-time frame loop: the sample count is device state, the launch is sized for a bound) as
+// PERSISTENT workgroups under the cost-balanced map: 8 x wgs_per_xcd workgroups, the ones of XCD k stride over that XCD's
+// (level, chunk) tasks, whose number they work out themselves from the real count -- no workgroup is launched just to find its
+// chunk beyond the count (under the per-chunk launch those cost the balanced map more than it gained, see FwdMap), and the map's
+// scalar arithmetic is paid once per workgroup instead of once per chunk.  Cell runs as in hashgrid_fwd_kernel; same bits.
+struct FwdPieces { uint32_t piece[8][16]; };            // level << 16 | phase mask, in the order an XCD takes them; 0 = unused
+
+__global__ void __launch_bounds__(256)
+hashgrid_fwd_persist_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const float* __restrict__ xyz_max,
+                            const half2_t* __restrict__ table, GridMeta meta, int n_bound, const int32_t* __restrict__ n_dev,
+                            half2_t* __restrict__ feats, FwdPieces fp, int wgs_per_xcd) {
+    const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
+    const int n_samples = n_dev != nullptr ? min(*n_dev, n_bound) : n_bound;
+    if (n_samples <= 0) return;
+    const int n_chunks = (n_samples + 255) >> 8, full = n_chunks >> 4;
+    const uint32_t low = (1u << (n_chunks & 15)) - 1u;
+    uint32_t pc[16]; int e[16];
+    int total = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        pc[j] = fp.piece[xcd][j];
+        const uint32_t mk = pc[j] & 0xFFFFu;
+        total += full * __builtin_popcount(mk) + __builtin_popcount(mk & low);
+        e[j] = total;
+    }
+    const Box box = load_box(xyz_min, xyz_max);
+    const int lane = threadIdx.x & 63;
+    for (int q = w; q < total; q += wgs_per_xcd) {
+        int begin = 0; uint32_t mine = pc[0];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) if (q >= e[j - 1]) { begin = e[j - 1]; mine = pc[j]; }
+        const uint32_t mk = mine & 0xFFFFu;
+        const int per = __builtin_popcount(mk), ql = q - begin;
+        const int quot = ql / per, period = quot < full ? quot : full, r = ql - period * per;
+        uint32_t t = mk;
+        for (int k = 0; k < r; ++k) t &= t - 1u;
+        const int level = (int)(mine >> 16), chunk = period * 16 + (int)__builtin_ctz(t);
+        const uint32_t res = meta.resolution[level];
+        const uint32_t size = meta.offset[level + 1] - meta.offset[level];
+        const half2_t* __restrict__ tab = table + meta.offset[level];
+        const bool hashed = level_is_hashed(res, size);
+        const float scale = meta.scale[level];
+        const int i = chunk * 256 + threadIdx.x;
+        const bool ok = i < n_samples;
+        uint32_t p[3]; float f[3];
+        cell_of(x, box, (size_t)(ok ? i : n_samples - 1), scale, p, f);
+        const uint32_t q0 = __shfl_up(p[0], 1, 64), q1 = __shfl_up(p[1], 1, 64), q2 = __shfl_up(p[2], 1, 64);
+        const bool first = lane == 0 || p[0] != q0 || p[1] != q1 || p[2] != q2;
+        const unsigned long long firsts = __ballot(first);
+        const int src = 63 - __builtin_clzll(firsts & ((2ull << lane) - 1ull));
+        half2_t v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { v[c][0] = (_Float16)0; v[c][1] = (_Float16)0; }
+        if (first) {
+            uint32_t idx[8];
+            if (hashed) corner_indices<true>(p, res, size, idx);
+            else corner_indices<false>(p, res, size, idx);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = tab[idx[c]];
+        }
+        float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const half2_t u = lane_read(v[c], src);
+            const float wgt = corner_weight(c, f);
+            o0 = fmaf(wgt, (float)u[0], o0);
+            o1 = fmaf(wgt, (float)u[1], o1);
+        }
+        half2_t out; out[0] = (_Float16)o0; out[1] = (_Float16)o1;
+        if (ok) __builtin_nontemporal_store(out, feats + (size_t)level * n_samples + i);
+    }
+}
+
+
 // The same forward over an explicit LIST of sample ids (the two-round forward of the training step, csrc/stepper.hip): work item j
 // of n_list (host bound; *n_list_dev on the device) encodes sample list[j] and writes its features at the sample's own place in the
 // level-major array (level stride = n_samples).  Ids come in runs of consecutive samples of a ray, so the streams stay mostly
@@ -660,8 +734,9 @@ feats_from_rowmajor_kernel(const half2_t* __restrict__ in, int n_levels, int n_s
 // across XCDs by weight alone was measured: 54 -> 94..335 us, three 2 MiB tables per L2), so those levels go whole to the least
 // loaded XCD, most expensive first; the small dense levels, whose tables fit any L2 many times over, are dealt out in sixteenths
 // to fill the XCDs up to the same load.
-FwdMap make_fwd_map(const ngp_grid_meta* meta, int n_chunks, bool exact) {
+FwdMap make_fwd_map(const ngp_grid_meta* meta, int n_chunks, bool exact, FwdPieces* pieces = nullptr) {
     FwdMap m;
+    if (pieces) for (int k = 0; k < 8; ++k) for (int j = 0; j < 16; ++j) pieces->piece[k][j] = 0u;
     uint16_t mask[8][NGP_MAX_LEVELS];
     for (int k = 0; k < 8; ++k) for (int l = 0; l < NGP_MAX_LEVELS; ++l) mask[k][l] = 0;
     for (int k = 0; k < 8; ++k) for (int j = 0; j < 16; ++j) { m.end[k][j] = 0; m.piece[k][j] = 1u; m.magic[k][j] = 0xFFFFFFFFu; }
@@ -703,6 +778,7 @@ FwdMap make_fwd_map(const ngp_grid_meta* meta, int n_chunks, bool exact) {
             const int per = __builtin_popcount(mask[k][l]);
             cnt += full * per + __builtin_popcount(mask[k][l] & low);
             m.end[k][j] = cnt; m.piece[k][j] = ((uint32_t)l << 16) | mask[k][l];
+            if (pieces) pieces->piece[k][j] = m.piece[k][j];
             m.magic[k][j] = per == 1 ? 0xFFFFFFFFu : (uint32_t)(((1ull << 32) + per - 1) / per);
             ++j;
         }
@@ -791,6 +867,18 @@ int ngp_hashgrid_fwd_n(const float* x, const float* xyz_min, const float* xyz_ma
     const int n_chunks = ngp_div_up(n_samples, 256);
     // cell runs (see hashgrid_fwd_kernel): levels up to this resolution gather once per run of lanes in one cell
     static const uint32_t reuse_max_res = [] { const char* e = getenv("NGP_FWD_REUSE_MAX_RES"); return e ? (uint32_t)atoi(e) : 1u << 30; }();
+    // device-sized launches: persistent workgroups under the balanced map (NGP_FWD_PERSIST=0: one workgroup per chunk, pair map)
+    static const int persist = [] { const char* e = getenv("NGP_FWD_PERSIST"); return e ? atoi(e) : 0; }();
+    if (n_dev != nullptr && persist > 0 && reuse_max_res >= (1u << 30)) {
+        FwdPieces fp;
+        const FwdMap pm = make_fwd_map(meta, n_chunks, true, &fp);
+        if (pm.blocks_per_xcd > 0) {
+            const int wgs = persist > 1 ? persist : 256;               // per XCD: 8 per CU
+            hipLaunchKernelGGL(hashgrid_fwd_persist_kernel, dim3(8 * wgs), dim3(256), 0, ngp_stream(stream),
+                               x, xyz_min, xyz_max, (const half2_t*)table, to_dev_meta(meta), n_samples, n_dev, (half2_t*)feats, fp, wgs);
+            return NGP_LAUNCH_RESULT();
+        }
+    }
     const FwdMap fmap = make_fwd_map(meta, n_chunks, n_dev == nullptr);
     const int n_blocks = fmap.blocks_per_xcd > 0 ? 8 * fmap.blocks_per_xcd : n_blocks_for(meta->n_levels, n_chunks);
     hipLaunchKernelGGL(hashgrid_fwd_kernel<1>, dim3(n_blocks), dim3(256), 0, ngp_stream(stream),

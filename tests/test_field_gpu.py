@@ -636,7 +636,8 @@ def test_forward_variants_agree_bit_for_bit(lib):
     digests = {}
     for name, env in (("default", {}), ("no runs, pair map", {"NGP_FWD_REUSE_MAX_RES": "0", "NGP_FWD_MAP": "pairs"}),
                       ("runs on the dense levels only, pair map", {"NGP_FWD_REUSE_MAX_RES": "64", "NGP_FWD_MAP": "pairs"}),
-                      ("no runs, balanced map", {"NGP_FWD_REUSE_MAX_RES": "0"})):
+                      ("no runs, balanced map", {"NGP_FWD_REUSE_MAX_RES": "0"}),
+                      ("device-sized launch by persistent workgroups", {"NGP_FWD_PERSIST": "1"})):
         e = dict(os.environ); e.update(env)
         e["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + e.get("PYTHONPATH", "")
         r = subprocess.run([sys.executable, "-c", _FWD_VARIANT_SCRIPT], env=e, capture_output=True, text=True, timeout=300)
