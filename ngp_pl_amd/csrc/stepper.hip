@@ -223,6 +223,7 @@ int ngp_stepper_set_buffers(ngp_stepper* s, const ngp_step_buffers* buffers) {
     STEP_TRY(check_buffers(s->c, *buffers));
     s->b = *buffers;
     s->S = 0; s->n_part = 0;
+    s->set_k[0] = s->set_k[1] = 0;                       // (no march of the new record sets has prepared a first-round list)
     return 0;
 }
 
