@@ -300,7 +300,7 @@ def _sharded_worker(rank, world, port, q):
     ok = tr.loss_scale == 128.0 / world and tr.update_hook is not None and exchange.shard_len % 8 == 0
     ok &= exchange.shard_len * world >= n_grid > exchange.shard_len * (world - 1)
     exchange._h_big[:n_d + n_grid] = master0.half()
-    # three steps of per-rank gradients; values are multiples of 1/64 below 4 in magnitude, so that f16 sums over <= 4 ranks are exact
+    # three steps of per-rank gradients; values are multiples of 1/64 below 4 in magnitude, so that f16 sums over <= 8 ranks are exact (below 32 in magnitude: f16 spacing 1/64)
     # whatever the order of the ring's adds, and the expected update can be formed from the f32 sum
     ref_p, ref_rgb = master0.clone(), rgb0.clone()
     ref_state = {"enc": (torch.zeros(n_d + n_grid), torch.zeros(n_d + n_grid)), "rgb": (torch.zeros(n_r), torch.zeros(n_r))}
@@ -359,7 +359,7 @@ def _sharded_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_sharded_exchange_matches_the_single_process_update(world):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
