@@ -568,10 +568,10 @@ int ngp_nerf_loss(const float* rgb, const float* opacity, const float* gt_rgb, c
  *   sq_err (R,3) = (rgb - gt)^2,   entropy (R) = lambda_o * -(o + 1e-10) log(o + 1e-10)
  * (train.py:173 sums their means) and the backward through them: g_rgb = g_sq_err * 2 (rgb - gt),
  * g_opacity = g_entropy * lambda_o * -(log(o + 1e-10) + 1).  One launch each.
+ * `*_is_scalar`: the seed is ONE float broadcast over all elements (what `.mean().backward()` hands back as a stride-0 view). */
 int ngp_nerf_loss_terms_fw(const float* rgb, const float* opacity, const float* gt_rgb,
                            float lambda_opacity, int n_rays, float* sq_err, float* entropy,
                            ngp_stream_t stream);
- * `*_is_scalar`: the seed is ONE float broadcast over all elements (what `.mean().backward()` hands back as a stride-0 view). */
 int ngp_nerf_loss_terms_bw(const float* g_sq_err, int g_sq_err_is_scalar, const float* g_entropy,
                            int g_entropy_is_scalar, const float* rgb, const float* opacity,
                            const float* gt_rgb, float lambda_opacity, int n_rays, float* g_rgb,
@@ -777,13 +777,13 @@ int ngp_stepper_render_backward(ngp_stepper* s, const float* g_rgb, const float*
  * gradients carry (loss_scale x grad_scale x world).  step is 1-based (bias correction). */
 int ngp_stepper_update(ngp_stepper* s, float lr, int32_t step, float grad_scale, const float* density_partials,
                        const float* rgb_partials, int32_t n_partials, const int32_t* found_inf, ngp_stream_t main_stream);
+/* Host-side accounting since the last reset: seconds the entry points spent polling for a march's sample count (device-bound
+ * wait) and in everything else (argument checks, launches, event records), and the number of front() calls. */
+int ngp_stepper_host_times(ngp_stepper* s, double* wait_s, double* enqueue_s, long long* n_steps, int reset);
 /* Stage timing (HIP events on the streams the kernels run on).  enable != 0: the following steps record events;
  * ngp_stepper_stage_times synchronises and writes the last step's times in ms:
  *   [0] march_write [1] hashgrid_fwd [2] mlp_fwd [3] composite_fw+loss [4] composite_bw [5] mlp_bwd [6] hashgrid_bwd [7] adam
  *   [8] march_count (marching stream; of the batch the last front() consumed).  Negative = not recorded. */
-/* Host-side accounting since the last reset: seconds the entry points spent polling for a march's sample count (device-bound
- * wait) and in everything else (argument checks, launches, event records), and the number of front() calls. */
-int ngp_stepper_host_times(ngp_stepper* s, double* wait_s, double* enqueue_s, long long* n_steps, int reset);
 #define NGP_STEPPER_STAGES 9
 int ngp_stepper_timing(ngp_stepper* s, int enable);
 int ngp_stepper_stage_times(ngp_stepper* s, float* ms);

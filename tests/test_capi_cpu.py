@@ -12,8 +12,74 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def header_symbols():
-    hdr = open(os.path.join(ROOT, "include", "ngp_hip.h")).read()
-    return sorted(set(re.findall(r"^(?:int|size_t|const char\*) (ngp_\w+)\(", hdr, re.M)))
+    """The entry points a C COMPILER sees in the header (comments stripped first: round 3's header had one declaration inside a
+    comment, which a regular expression over the raw text happily matched)."""
+    from ngp_pl_amd import _abi
+    return sorted(_abi.parse())
+
+
+def test_header_compiles_as_c99():
+    """The boundary is a C ABI: a C99 translation unit that includes nothing but the header must compile without a warning."""
+    src = '#include "ngp_hip.h"\nint main(void) { return 0; }\n'
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-x", "c", "-"],
+                       input=src, text=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout
+
+
+def test_c_program_links_every_declared_symbol(tmp_path):
+    """A generated C program takes the address of EVERY declared entry point through a function pointer of the header's own
+    prototype (a mismatch between declaration and pointer type is a compile error under -Werror), links against libngp_hip.so and
+    runs: ngp_abi_version() / ngp_build_arch() through the C ABI, no Python in between."""
+    from ngp_pl_amd import _abi, _lib
+    protos = _abi.parse()
+    lines = ['#include "ngp_hip.h"', "#include <stdio.h>", "#include <string.h>", "int main(void) {", "    int n = 0;"]
+    for i, (name, pr) in enumerate(sorted(protos.items())):
+        lines.append("    { %s = &%s; n += (p%d != 0); }" % (pr.c_pointer_decl("p%d" % i), name, i))
+    lines += ['    printf("%d %d %s\\n", n, ngp_abi_version(), ngp_build_arch());', "    return 0;", "}"]
+    c = tmp_path / "link_all.c"
+    c.write_text("\n".join(lines) + "\n")
+    exe = tmp_path / "link_all"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe),
+                        "-L", libdir, "-lngp_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout
+    assert r.stdout.split() == [str(len(protos)), "3", "gfx950"], r.stdout
+
+
+def test_ctypes_table_agrees_with_the_header():
+    """Every hand-written argtypes list of ngp_pl_amd/_lib.py against the header's prototype: same arity, pointer where the header
+    has a pointer, a scalar of the same size and kind (integer / floating) where it has a scalar."""
+    from ngp_pl_amd import _abi, _lib
+    protos = _abi.parse()
+    problems = [m for m in (_abi.ctypes_agrees(a, protos[n]) for n, a in _lib._PROTOS.items() if n in protos) if m]
+    assert not problems, "\n".join(problems)
+    lib = _lib.lib()
+    for name, pr in protos.items():                      # ... and what lib() set on the loaded functions, return types included
+        f = getattr(lib, name)
+        assert f.argtypes is not None and _abi.ctypes_agrees(list(f.argtypes), pr) is None, name
+        want = {"int": C.c_int, "size_t": C.c_size_t, "const char*": C.c_char_p}[pr.ret]
+        assert f.restype is want, (name, pr.ret, f.restype)
+
+
+def test_a_declaration_inside_a_comment_is_not_a_declaration(tmp_path):
+    """Round 3's defect, re-created: the prototype of ngp_nerf_loss_terms_fw moved back inside the preceding comment.  The reader
+    must lose the symbol (so that test_library_exports_every_declared_symbol fails) and the C link test's translation unit must
+    not compile."""
+    from ngp_pl_amd import _abi
+    hdr = open(_abi.HEADER).read()
+    m = re.search(r"(hands back as a stride-0 view\)\. \*/\n)(int ngp_nerf_loss_terms_fw\(.*?\);\n)", hdr, re.S)
+    assert m, "the header no longer has the passage this test re-breaks"
+    broken = hdr[:m.start()] + "hands back as a stride-0 view).\n" + m.group(2) + " */\n" + hdr[m.end():]
+    bad = tmp_path / "ngp_hip.h"
+    bad.write_text(broken)
+    assert "ngp_nerf_loss_terms_fw" in _abi.parse() and "ngp_nerf_loss_terms_fw" not in _abi.parse(str(bad))
+    src = '#include "ngp_hip.h"\nint main(void) { return ngp_nerf_loss_terms_fw(0, 0, 0, 0.f, 0, 0, 0, 0); }\n'
+    r = subprocess.run(["gcc", "-std=c99", "-Werror", "-fsyntax-only", "-I", str(tmp_path), "-x", "c", "-"], input=src, text=True,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode != 0 and "implicit declaration" in r.stdout
 
 
 def test_library_exports_every_declared_symbol():
