@@ -87,7 +87,8 @@ def parse():
     p.add_argument("--no-secondary", action="store_true", help="(default; kept for older command lines)")
     p.add_argument("--deadline", type=float, default=float(os.environ.get("NGP_BENCH_DEADLINE_S", "270")),
                    help="seconds from process start after which the line is printed with whatever is complete")
-    p.add_argument("--no-api", action="store_true", help="skip the api_path leg")
+    p.add_argument("--no-api", action="store_true", help="skip the api_path legs")
+    p.add_argument("--no-full-run", action="store_true", help="skip the literal configs[1] run (30 000 steps from scratch + evaluation over 200 held-out poses, ~15 s)")
     p.add_argument("--timed-only", action="store_true", help="stop after the timed windows (for rocprofv3 runs: the trace then ends with the timed steps)")
     p.add_argument("--dry-run", action="store_true", help="launcher + process group only (gloo, no GPU work)")
     return p.parse_args()
@@ -138,7 +139,7 @@ def dry_run(args, rank, world, out_stream):
 class Loop:
     """The training loop of one workload: model, trainer, HBM-resident data, batch sampler on the marching stream."""
 
-    def __init__(self, workload, args, dev, rank, world, dist):
+    def __init__(self, workload, args, dev, rank, world, dist, data=None):
         from ngp_pl_amd.bench_support import GpuDataset
         from ngp_pl_amd.networks import NGP
         from ngp_pl_amd.trainer import Trainer
@@ -148,7 +149,7 @@ class Loop:
         torch.manual_seed(1337)
         self.model = NGP(scale=scale).to(dev)
         self.model.register_training_buffers()
-        self.data = GpuDataset(args.res, args.images, dev, seed=0, scene=scene)     # ground truth resident in HBM
+        self.data = data if data is not None else GpuDataset(args.res, args.images, dev, seed=0, scene=scene)     # ground truth resident in HBM
         if erode:      # train.py:73-76,160-163: the colmap recipe marks the cells no camera sees and erodes by visibility
             self.model.mark_invisible_cells(self.data.K.to(dev), self.data.poses, (self.data.W, self.data.H))
         self.trainer = Trainer(self.model, lr=lr, num_epochs=30 if workload != "lego16k" else 20, erode=erode)
@@ -262,7 +263,7 @@ class Loop:
             self.exchange.timing = True
             self.steps(20)
             self.exchange.timing = False
-            extra = {"exchange_ms": self.exchange.exchange_ms(), "exchange": self.exchange_kind}
+            extra.update({"exchange_ms": self.exchange.exchange_ms(), "exchange": self.exchange_kind})
         return {**extra, "ms_per_step": total / (n_win * steps) * 1e3, "rays_per_s": self.rays * self.world * n_win * steps / total,
                 "timed_windows": n_win, "timed_steps_total": n_win * steps, "window_ms_per_step_min_max": [min(wins) / steps * 1e3, max(wins) / steps * 1e3],
                 "ms_per_step_hip_events": sum(ev) / (n_win * steps) * 1e3, "cold_start": cold, "metrics": met,
@@ -372,6 +373,105 @@ def api_path_rate(loop, n_steps=40):
     dt = (time.perf_counter() - t) / n_steps
     return {"rays_per_s": loop.rays / dt, "ms_per_step": dt * 1e3,
             "what": "render(next_rays=...) + NeRFLoss + autograd + FusedAdam: the native stepper's forward / backward halves around torch's loss"}
+
+
+def api_path_plain_rate(loop, n_steps=40):
+    """What an UNCHANGED training_step gets (train.py:159-185): `render(model, rays_o, rays_d)` with no `next_rays` -- the reference's
+    render() has no such argument -- then NeRFLoss, autograd, FusedAdam.  The batch's march runs synchronously inside render()
+    (the API hands it the rays only then, and the result shapes depend on the sample count: one host round trip per step)."""
+    tr = loop.trainer
+    for _ in range(8):
+        cur = loop.draw(on_side=False); tr.step_autograd(cur[0], cur[1], cur[2])
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n_steps):
+        cur = loop.draw(on_side=False); tr.step_autograd(cur[0], cur[1], cur[2])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / n_steps
+    return {"rays_per_s": loop.rays / dt, "ms_per_step": dt * 1e3,
+            "what": "render(model, rays_o, rays_d) exactly as train.py:159-185 calls it (no next_rays: synchronous march) + NeRFLoss + autograd + FusedAdam"}
+
+
+FULL_RUN_STEPS = 30000          # BASELINE.json configs[1]: 30 epochs x 1000 steps (opt.py:40, datasets/base.py:17-19)
+FULL_RUN_TEST_POSES = 200       # the Synthetic-NeRF test split (README.md:118-121 reports mean PSNR / FPS over it)
+
+
+def frame_bytes(n_rays, samples_per_ray):
+    """Algorithmic bytes of one rendered frame by SURVEY.md 8(d)'s per-unit figures: AABB 32 B/ray + test-time march (24 B of ray in,
+    32 B/sample out) + hash encode 588 + MLPs 210 + composite 28 B/sample and 52 B/ray."""
+    return n_rays * (32.0 + 24.0 + 52.0) + n_rays * samples_per_ray * (32.0 + 588.0 + 210.0 + 28.0)
+
+
+def render_profile():
+    """The committed rocprofv3 kernel trace of the frame loop on the trained field (profiles/r*_render_trace.json, written by
+    tools/profile_render.py): per-kernel share of a frame, dominant kernel."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_render_trace.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        rec = json.load(f)
+    rec["source"] = os.path.relpath(files[-1], ROOT)
+    return rec
+
+
+def full_run(base_loop, args, dev, budget_s):
+    """BASELINE.json configs[1] run literally: FULL_RUN_STEPS optimisation steps of 8192 rays from the random initialisation
+    (cosine schedule over 30 epochs, occupancy warm-up, every step timed: one wall-clock bracket around the whole run), then the
+    reference's evaluation protocol on the TRAINED field (train.py:193-237, test.ipynb cell 2): PSNR and render time of
+    `render(test_time=True)` incl. ray generation over FULL_RUN_TEST_POSES held-out poses, with both chunkings of the frame loop."""
+    from ngp_pl_amd import synthetic as syn
+    from ngp_pl_amd.bench_support import render_eval
+    t_leg = time.perf_counter()
+    loop = Loop("lego", args, dev, 0, 1, None, data=base_loop.data)       # fresh model (seed 1337), the same HBM-resident dataset
+    tr = loop.trainer
+    steps = int(os.environ.get("NGP_FULL_RUN_STEPS", FULL_RUN_STEPS))
+    tr.steps_per_epoch = max(steps // tr.num_epochs, 1)
+    log = []
+    torch.cuda.synchronize()
+    gc.collect(); gc.disable()
+    try:
+        t0 = time.perf_counter()
+        done = 0
+        while done < steps:
+            n = min(2500, steps - done)
+            loop.steps(n); done += n
+            if done % 5000 == 0 or done == steps:          # (reads two scalars back: ~12 syncs in the whole run, inside the bracket)
+                m = tr.metrics()
+                log.append({"step": done, "elapsed_s": round(time.perf_counter() - t0, 3), "train_psnr": round(m["psnr"], 2),
+                            "samples_per_ray_marched": round(m["rm_s"], 2), "samples_per_ray_composited": round(m["vr_s"], 2)})
+            if time.perf_counter() - t_leg > 0.6 * budget_s:
+                break
+        torch.cuda.synchronize()
+        train_s = time.perf_counter() - t0
+    finally:
+        gc.enable()
+    out = {"workload": "BASELINE configs[1] literal: %d steps x %d rays from the random initialisation, 800x800 Lego-like, scale 0.5" % (done, loop.rays),
+           "steps": done, "train_s": train_s, "rays_per_s": done * loop.rays / train_s, "ms_per_step_mean": train_s / done * 1e3,
+           "log": log, "complete": done == steps}
+    progress("full_run: %d steps in %.2f s" % (done, train_s))
+    poses = syn.hemisphere_poses(FULL_RUN_TEST_POSES, seed=999).to(dev)       # held-out: the training set is seed 0
+    fast = render_eval(loop.model, loop.data, poses, psnr=True, chunk_scale=4, probe_cap=64)
+    ref = render_eval(loop.model, loop.data, poses, psnr=False)
+    out["psnr"] = fast.pop("psnr")
+    out["psnr_min_max"] = fast.pop("psnr_min_max")
+    out["fps_200"], out["fps_200_reference_chunking"] = fast["fps"], ref["fps"]
+    fast["loop"] = "ngp_render_test_frame chunk_scale=4 probe_cap=64 (same samples per ray, regrouped: <= 1e-5 from the reference chunking)"
+    ref["loop"] = "ngp_render_test_frame chunk_scale=1 probe_cap=0 (the reference's chunking, bit-identical to its host loop)"
+    out["render"], out["render_reference_chunking"] = fast, ref
+    n_rays = loop.data.W * loop.data.H
+    rr = {}
+    for key, rec in (("regrouped", fast), ("reference_chunking", ref)):
+        b = frame_bytes(n_rays, rec["samples_per_ray"])
+        gbs = b / (rec["ms_per_frame"] * 1e-3) / 1e9
+        rr[key] = {"bytes_per_frame": b, "ms_per_frame": rec["ms_per_frame"], "achieved": round(gbs, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                   "frac": gbs / HBM_PEAK_GBS}
+    prof = render_profile()
+    out["roofline_render"] = {"bound": "hbm", "kernel": (prof or {}).get("dominant_kernel"), **rr["regrouped"], "reference_chunking": rr["reference_chunking"],
+                              "samples_per_ray": fast["samples_per_ray"], "profile": prof,
+                              "what": "algorithmic bytes of a frame (SURVEY.md 8(d) per-unit figures x the rays and samples of the frame) / mean frame time over the held-out poses"}
+    del loop
+    torch.cuda.empty_cache()
+    return out
 
 
 def usable_cpus():
@@ -694,10 +794,13 @@ def main():
         legs = ["roofline"]
         if not args.no_cpu_baseline and world == 1:
             legs.append("cpu_baseline")
+        do_full = not args.no_full_run and world == 1 and args.workload == "lego"
+        if do_full:
+            legs.append("full_run")
         if not args.no_render:
             legs += ["render_fps_800x800", "render_fps_800x800_reference_chunking"]
         if not args.no_api:
-            legs.append("api_path")
+            legs += ["api_path", "api_path_plain"]
         secondary = args.secondary and world == 1 and args.workload == "lego"
         if secondary:
             legs.append("secondary")
@@ -706,7 +809,17 @@ def main():
         if "cpu_baseline" in legs:
             # (the driver's contract asks for this object: second in line, in a child process the parent can kill)
             keeper.leg("cpu_baseline", lambda: cpu_baseline(loop.model, loop.data), 125.0)
-        if not args.no_render:
+        if do_full:
+            # the literal configs[1] run + the reference's evaluation protocol on the trained field; when it completes, the FPS
+            # legs below are taken from it (200 held-out poses on the trained field) instead of 5 frames on the young one
+            keeper.leg("full_run", lambda: full_run(loop, args, dev, 60.0), 60.0)
+        fr = keeper.record.get("full_run") if do_full else None
+        if isinstance(fr, dict) and fr.get("complete") and "render" in fr and not args.no_render:
+            for name, key in (("render_fps_800x800", "render"), ("render_fps_800x800_reference_chunking", "render_reference_chunking")):
+                if name in keeper.pending:
+                    keeper.pending.remove(name)
+                keeper.record[name] = dict(fr[key], field_state="trained: after %d steps of %d rays (full_run)" % (fr["steps"], loop.rays))
+        elif not args.no_render:
             # device-driven frame loop; chunk_scale/probe_cap only regroup the SAME per-ray samples into fewer
             # iterations (tests/test_train_gpu.py::test_device_frame_loop_matches_host_loop)
             state = "after %d training steps of %d rays" % (loop.trainer.global_step, loop.rays)
@@ -726,6 +839,7 @@ def main():
             keeper.leg("render_fps_800x800_reference_chunking", reference_frames, 30.0)
         if not args.no_api:
             keeper.leg("api_path", lambda: api_path_rate(loop), 30.0)
+            keeper.leg("api_path_plain", lambda: api_path_plain_rate(loop), 30.0)
         if secondary:
             del loop
             torch.cuda.empty_cache()

@@ -510,13 +510,19 @@ int ngp_adam_step_field(float* grid_param, ngp_half* grid_param_h, ngp_half* gri
                         float* rgb_m, float* rgb_v, int n_rgb,
                         int n_partials, float lr, float beta1, float beta2, float eps,
                         float weight_decay, int step, float grad_scale, int zero_grid_grad,
-                        const int32_t* found_inf, ngp_stream_t stream);
+                        const int32_t* found_inf, int32_t* step_state, ngp_stream_t stream);
+/* step_state (may be NULL: `step` is the bias-correction step, as everywhere else): 4 x i32 on the device holding the number of
+ * APPLIED steps -- {MLP blocks: slot 0, slot 1; grid block: slot 0, slot 1}, zeroed (or set to the steps already taken) by the
+ * caller once.  With it `step` is the 1-based number of this CALL: the launch reads slot (step - 1) & 1, corrects the bias for
+ * applied + 1, and writes slot step & 1 = applied + (skipped by its found_inf flag ? 0 : 1).  apex / GradScaler leave the
+ * optimizer's step count unchanged on a skipped step; the flag lives on the device, so the count has to as well. */
 /* The same launch for a data-parallel rank that owns ONE SHARD of the grid table (ngp_pl_amd/ddp.py ShardedExchange: reduce-scatter of
  * the gradient -> this update -> all-gather of the updated f16 table): the grid pointers address the rank's shard (n_shard
  * parameters, gradient = the reduce-scatter's output), the MLP blocks are updated by every rank alike.  Two skip flags: the MLP
  * blocks follow found_inf_mlp (computed on the all-reduced MLP sums: identical on every rank), the shard follows found_inf_shard
  * (computed on the shard's reduced gradient by its owner): every parameter is decided by exactly one flag that all ranks that
- * update it agree on, so the ranks stay in lock step without a flag collective.  The gradient is not cleared. */
+ * update it agree on, so the ranks stay in lock step without a flag collective.  The gradient is not cleared.  n_shard may be 0
+ * (a rank whose shard is empty: the MLP blocks only).  step_state: as above, one count per flag. */
 int ngp_adam_step_field_shard(float* grid_param, ngp_half* grid_param_h, ngp_half* grid_grad,
                               float* grid_m, float* grid_v, int64_t n_shard,
                               float* density_param, ngp_half* density_param_h,
@@ -526,7 +532,8 @@ int ngp_adam_step_field_shard(float* grid_param, ngp_half* grid_param_h, ngp_hal
                               float* rgb_m, float* rgb_v, int n_rgb,
                               int n_partials, float lr, float beta1, float beta2, float eps,
                               float weight_decay, int step, float grad_scale,
-                              const int32_t* found_inf_mlp, const int32_t* found_inf_shard, ngp_stream_t stream);
+                              const int32_t* found_inf_mlp, const int32_t* found_inf_shard, int32_t* step_state,
+                              ngp_stream_t stream);
 /* GradScaler's non-finite check (train.py:274 precision=16 -> torch.amp.GradScaler.unscale_) on a native
  * gradient buffer of n elements (f16, or f32 if grad_is_f32; 16-byte aligned): flag[0] (device i32) |= 1 if any
  * element is inf or NaN; reset != 0 zeroes the flag first.  Used behind the multi-GPU all-reduce, whose f16
@@ -774,9 +781,11 @@ int ngp_stepper_render_backward(ngp_stepper* s, const float* g_rgb, const float*
                                 float loss_scale, ngp_stream_t main_stream, int32_t* n_partials);
 /* Fused Adam (ngp_adam_step_field).  density_partials / rgb_partials NULL: the partial rows front() wrote (n_partials rows);
  * a caller that reduced them across ranks passes its own buffers with n_partials = 1.  grad_scale = the total factor the
- * gradients carry (loss_scale x grad_scale x world).  step is 1-based (bias correction). */
+ * gradients carry (loss_scale x grad_scale x world).  step is 1-based (bias correction; with step_state -- see
+ * ngp_adam_step_field -- the number of this call, the applied-step count then lives on the device next to found_inf). */
 int ngp_stepper_update(ngp_stepper* s, float lr, int32_t step, float grad_scale, const float* density_partials,
-                       const float* rgb_partials, int32_t n_partials, const int32_t* found_inf, ngp_stream_t main_stream);
+                       const float* rgb_partials, int32_t n_partials, const int32_t* found_inf, int32_t* step_state,
+                       ngp_stream_t main_stream);
 /* Host-side accounting since the last reset: seconds the entry points spent polling for a march's sample count (device-bound
  * wait) and in everything else (argument checks, launches, event records), and the number of front() calls. */
 int ngp_stepper_host_times(ngp_stepper* s, double* wait_s, double* enqueue_s, long long* n_steps, int reset);

@@ -102,8 +102,8 @@ _PROTOS = {
     "ngp_feats_from_rowmajor": [P, I, I, P, P],
     "ngp_adam_step": [P, P, P, I, P, P, L, F, F, F, F, F, I, F, P, P],
     "ngp_adam_step_partials": [P, P, P, I, P, P, I, F, F, F, F, F, I, F, P, P],
-    "ngp_adam_step_field": [P, P, P, P, P, L, P, P, P, P, P, I, P, P, P, P, P, I, I, F, F, F, F, F, I, F, I, P, P],
-    "ngp_adam_step_field_shard": [P, P, P, P, P, L, P, P, P, P, P, I, P, P, P, P, P, I, I, F, F, F, F, F, I, F, P, P, P],
+    "ngp_adam_step_field": [P, P, P, P, P, L, P, P, P, P, P, I, P, P, P, P, P, I, I, F, F, F, F, F, I, F, I, P, P, P],
+    "ngp_adam_step_field_shard": [P, P, P, P, P, L, P, P, P, P, P, I, P, P, P, P, P, I, I, F, F, F, F, F, I, F, P, P, P, P],
     "ngp_reduce_partials": [P, I, I, P, P],
     "ngp_found_inf": [P, I, L, P, I, P],
     "ngp_found_inf2": [P, I, L, P, I, L, P, P, P],
@@ -132,7 +132,7 @@ _PROTOS = {
     "ngp_stepper_table_backward": [P, I, I, P],
     "ngp_stepper_render_forward": [P, P, P, P, P, P, P, P, C.POINTER(C.c_int32)],
     "ngp_stepper_render_backward": [P, P, P, P, P, F, P, C.POINTER(C.c_int32)],
-    "ngp_stepper_update": [P, F, I, F, P, P, I, P, P],
+    "ngp_stepper_update": [P, F, I, F, P, P, I, P, P, P],
     "ngp_stepper_host_times": [P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong), I],
     "ngp_stepper_timing": [P, I],
     "ngp_stepper_stage_times": [P, C.POINTER(C.c_float)],

@@ -129,3 +129,41 @@ def render_fps(model, data, n_frames=5, **render_kwargs):
     if "n_iterations" in out:
         res["iterations"] = out["n_iterations"]
     return res
+
+
+@torch.no_grad()
+def render_eval(model, data, poses, psnr=True, **render_kwargs):
+    """The reference's evaluation loop (train.py:193-237 `validation_step`, test.ipynb cell 2) over `poses` (N,3,4): per pose,
+    wall-clock of ray generation + `render(test_time=True)` bracketed by synchronize (what `fps = 1 / mean(t)` is quoted on), and --
+    outside the timed bracket -- the PSNR of the frame against the analytic scene's ground truth (`psnr=True`).  One untimed frame
+    first (allocator, workspaces)."""
+    import math
+    n_pix = data.W * data.H
+    ro, rd = syn.get_rays(data.directions, poses[0])
+    render(model, ro, rd, test_time=True, **render_kwargs)
+    times, psnrs, n_samples, iters = [], [], 0.0, []
+    for i in range(poses.shape[0]):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        ro, rd = syn.get_rays(data.directions, poses[i])
+        out = render(model, ro, rd, test_time=True, **render_kwargs)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t)
+        n_samples += float(out["total_samples"])
+        if "n_iterations" in out:
+            iters.append(int(out["n_iterations"]))
+        if psnr:
+            gt = surface_ground_truth(ro, rd)
+            mse = float(((out["rgb"] - gt) ** 2).mean())
+            psnrs.append(-10.0 * math.log10(max(mse, 1e-12)))
+    mean = sum(times) / len(times)
+    srt = sorted(times)
+    res = {"fps": 1.0 / mean, "ms_per_frame": mean * 1e3, "ms_per_frame_median": srt[len(srt) // 2] * 1e3, "ms_per_frame_max": srt[-1] * 1e3,
+           "n_frames": len(times), "poses": "held-out (hemisphere_poses seed 999; training cameras: seed 0)",
+           "samples_per_ray": n_samples / len(times) / n_pix, "protocol": "1 / mean(wall of get_rays + render(test_time=True) per pose), test.ipynb cell 2"}
+    if iters:
+        res["iterations_mean"] = sum(iters) / len(iters)
+    if psnr:
+        res["psnr"] = sum(psnrs) / len(psnrs)
+        res["psnr_min_max"] = [min(psnrs), max(psnrs)]
+    return res

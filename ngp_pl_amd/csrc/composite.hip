@@ -30,7 +30,14 @@ __device__ __forceinline__ float wave_incl_sum(float v, int lane) {
 // T_before/T_after of every sample by an inclusive product scan of (1 - alpha) across the wave,
 // carried from chunk to chunk.  A sample is composited iff the transmittance BEFORE it is still
 // above the threshold (the sample that crosses it is composited, then the ray stops).
-struct ChunkT { float a, T_before, T_after; bool live; };
+//
+// `live` is decided by POSITION relative to the chunk's first stop lane, not by each lane's own T_before: with the two-round
+// forward (csrc/stepper.hip) the samples behind a ray's stop were never evaluated, so their sigma slots hold whatever an
+// earlier step or the allocator left there.  For sane values the two rules agree (T is non-increasing: every lane up to the
+// first one with T_after <= thr has T_before > thr, every later one does not), but a stale NEGATIVE sigma has 1 - a > 1 and
+// could lift a later lane's T_before back above the threshold -- garbage weights, and gradients, for a ray that had stopped.
+// Lanes up to the stop only look back (prefix scans), so nothing behind the stop can reach them.
+struct ChunkT { float a, T_before, T_after; bool live; uint64_t stop; };
 __device__ __forceinline__ ChunkT chunk_transmittance(float sigma, float delta, bool valid, float T_carry, float thr, int lane) {
     ChunkT c;
     c.a = valid ? 1.0f - __expf(-sigma * delta) : 0.0f;
@@ -38,7 +45,9 @@ __device__ __forceinline__ ChunkT chunk_transmittance(float sigma, float delta, 
     const float excl = __shfl_up(incl, 1, 64);
     c.T_before = T_carry * (lane == 0 ? 1.0f : excl);
     c.T_after = T_carry * incl;
-    c.live = valid && (c.T_before > thr);
+    c.stop = __ballot(valid && c.T_after <= thr);
+    const int first_stop = c.stop ? __ffsll((long long)c.stop) - 1 : 64;
+    c.live = valid && lane <= first_stop && (c.T_before > thr);
     return c;
 }
 
@@ -84,7 +93,7 @@ __device__ __forceinline__ void composite_fw_ray(const float* __restrict__ sigma
             D += w * ts[s]; O += w;
         }
         samples += __popcll(__ballot(c.live && c.T_after > T_threshold));
-        stopped = __ballot(valid && c.T_after <= T_threshold) != 0ull;
+        stopped = c.stop != 0ull;
         T_carry = __shfl(c.T_after, 63, 64);
     }
     for (int k = base + lane; k < N; k += 64) ws[(size_t)start + k] = 0.0f;   // chunks past the stop
@@ -185,7 +194,7 @@ composite_probe_kernel(const float* __restrict__ sigmas, const float* __restrict
             const size_t s = (size_t)start + (valid ? lane : 0);
             const float sigma = valid ? sigmas[s] : 0.f, delta = valid ? deltas[s] : 0.f;
             const ChunkT c = chunk_transmittance(sigma, delta, valid, 1.0f, T_threshold, lane);
-            if (__ballot(valid && c.T_after <= T_threshold) == 0ull) rest = N - first_k;      // still transparent behind its first samples
+            if (c.stop == 0ull) rest = N - first_k;      // still transparent behind its first samples
         }
     }
     if (lane == 0) s_rest[wave] = rest;
@@ -277,7 +286,7 @@ composite_train_bw_kernel(const float* __restrict__ dL_dopacity, const float* __
                 }
             }
         }
-        stopped = __ballot(valid && c.T_after <= T_threshold) != 0ull;
+        stopped = c.stop != 0ull;
         T_carry = __shfl(c.T_after, 63, 64);
         r0 = __shfl(r, 63, 64); g0 = __shfl(g, 63, 64); b0 = __shfl(b, 63, 64); d0 = __shfl(d, 63, 64); P0 = __shfl(P, 63, 64);
     }

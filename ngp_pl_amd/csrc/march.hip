@@ -106,8 +106,7 @@ ray_aabb_near_kernel(const float* __restrict__ rays_o, const float* __restrict__
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rays) return;
     if (noise) {          // the marcher's jitter (custom_functions.py:83 torch.rand_like): counter-based, keyed by (seed, ray)
-        const uint32_t base = ngp_pcg_hash(seed_lo ^ ngp_pcg_hash(seed_hi + 0x9E3779B9u)) + (uint32_t)r;
-        noise[r] = (float)(ngp_pcg_hash(base) >> 8) * (1.0f / 16777216.0f);      // [0,1), 24 bits like torch.rand
+        noise[r] = (float)(ngp_pcg_hash(ngp_rng_key(seed_lo, seed_hi, (uint32_t)r)) >> 8) * (1.0f / 16777216.0f);      // [0,1), 24 bits like torch.rand
     }
     const float ox = rays_o[3 * r], oy = rays_o[3 * r + 1], oz = rays_o[3 * r + 2];
     const float ix = 1.0f / rays_d[3 * r], iy = 1.0f / rays_d[3 * r + 1], iz = 1.0f / rays_d[3 * r + 2];
@@ -1021,7 +1020,7 @@ double render_wait_limit_s() {
 extern "C" {
 #pragma GCC visibility push(default)
 
-int ngp_abi_version(void) { return 3; }
+int ngp_abi_version(void) { return 4; }
 
 int ngp_march_guard_first(float* probe12) {
     NGP_CHECK_PTR(probe12);

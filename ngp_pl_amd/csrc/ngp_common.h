@@ -38,6 +38,12 @@ __device__ __forceinline__ uint32_t ngp_pcg_hash(uint32_t v) {
     uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
     return (word >> 22u) ^ word;
 }
+// Key of item i under a 64-bit seed: the three words are hashed in turn, NOT folded into one 32-bit base that the item index is
+// added to -- with `hash(seed) + i` two launches whose bases land within n of each other draw shifted copies of one sequence
+// (about 10^3 such pairs over a 30 000-step run of 8192-ray marches).  Draw j of item i = ngp_pcg_hash(key + j).
+__device__ __forceinline__ uint32_t ngp_rng_key(uint32_t seed_lo, uint32_t seed_hi, uint32_t i) {
+    return ngp_pcg_hash(ngp_pcg_hash(seed_lo ^ ngp_pcg_hash(i)) + seed_hi);
+}
 
 // ---- wave64 helpers ----
 __device__ __forceinline__ float ngp_wave_sum(float v) {

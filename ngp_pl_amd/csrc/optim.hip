@@ -17,7 +17,25 @@ typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct AdamHyper { float lr, beta1, beta2, eps, wd, bc1, bc2, inv_scale; const int32_t* found_inf; int zero_grad;
-                   const int32_t* found_inf_dense; };     // skip flag of the dense (grid) block: found_inf unless a caller gives it its own
+                   const int32_t* found_inf_dense;        // skip flag of the dense (grid) block: found_inf unless a caller gives it its own
+                   int32_t* step_state; int slot; };      // device-side counts of APPLIED steps (below), or NULL: bc1 / bc2 as given
+
+// Bias correction under a skip flag.  apex / GradScaler leave the optimizer's step count unchanged when a step is skipped; the host
+// cannot know whether the device-side flag was raised without a sync, so the count of APPLIED steps lives next to the flag:
+// step_state = 4 x i32 on the device, {MLP blocks: slot 0, slot 1, grid block: slot 0, slot 1} (the two flags of the sharded
+// exchange decide their blocks separately, so each has its own count).  Launch number c (1-based) reads slot (c - 1) & 1 and its
+// first workgroup of each kind writes slot c & 1 = applied + (skipped ? 0 : 1): readers and the writer never share an address
+// inside a launch, launches are ordered by the stream.
+__device__ __forceinline__ void adam_bias_from_state(AdamHyper& h, bool dense, bool writer) {
+    if (h.step_state == nullptr) return;
+    int32_t* st = h.step_state + (dense ? 2 : 0);
+    const int32_t applied = st[h.slot];
+    const int32_t* flag = dense ? h.found_inf_dense : h.found_inf;
+    const bool skip = flag != nullptr && *flag != 0;
+    const float t = (float)(applied + 1);
+    h.bc1 = 1.0f - powf(h.beta1, t); h.bc2 = 1.0f - powf(h.beta2, t);
+    if (writer && threadIdx.x == 0) st[h.slot ^ 1] = skip ? applied : applied + 1;
+}
 
 // Dense (streaming) update of n parameters by workgroups `block` of `n_blocks`, 4 parameters per thread and trip.
 template <bool GRAD_F32>
@@ -156,8 +174,10 @@ adam_field_kernel(float* __restrict__ param, h1* __restrict__ param_h, void* __r
                   float* __restrict__ v, long long n4, long long n, AdamMlp a, AdamMlp b, int n_partials, AdamHyper hp) {
     __shared__ float s_acc[8][32];
     const int blk = blockIdx.x;
+    const bool dense = blk >= a.blocks + b.blocks;
+    adam_bias_from_state(hp, dense, blk == 0 || blk == a.blocks + b.blocks);
     if (blk < a.blocks) adam_from_partials(a.param, a.param_h, a.partials, n_partials, a.m, a.v, a.n, hp, blk, s_acc);
-    else if (blk < a.blocks + b.blocks) adam_from_partials(b.param, b.param_h, b.partials, n_partials, b.m, b.v, b.n, hp, blk - a.blocks, s_acc);
+    else if (!dense) adam_from_partials(b.param, b.param_h, b.partials, n_partials, b.m, b.v, b.n, hp, blk - a.blocks, s_acc);
     else adam_dense<false>(param, param_h, grad16, m, v, n4, n, hp, blk - a.blocks - b.blocks, (int)gridDim.x - a.blocks - b.blocks);
 }
 
@@ -288,7 +308,7 @@ sample_rays_kernel(const float* __restrict__ poses, const float* __restrict__ di
                    float* __restrict__ noise, int32_t* __restrict__ img_idx, int32_t* __restrict__ pix_idx) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t base = pcg_hash(seed_lo ^ pcg_hash(seed_hi + 0x9E3779B9u)) + 3u * (uint32_t)i;
+    const uint32_t base = ngp_rng_key(seed_lo, seed_hi, (uint32_t)i);
     const uint32_t r0 = pcg_hash(base), r1 = pcg_hash(base + 1u), r2 = pcg_hash(base + 2u);
     const int img = (int)(((uint64_t)r0 * (uint64_t)n_images) >> 32);     // uniform in [0, n_images)
     const int pix = (int)(((uint64_t)r1 * (uint64_t)n_pixels) >> 32);
@@ -385,6 +405,7 @@ AdamHyper adam_hyper(float lr, float beta1, float beta2, float eps, float wd, in
     hp.lr = lr; hp.beta1 = beta1; hp.beta2 = beta2; hp.eps = eps; hp.wd = wd;
     hp.bc1 = 1.0f - powf(beta1, (float)step); hp.bc2 = 1.0f - powf(beta2, (float)step);
     hp.inv_scale = 1.0f / grad_scale; hp.found_inf = found_inf; hp.found_inf_dense = found_inf; hp.zero_grad = 1;
+    hp.step_state = nullptr; hp.slot = 0;
     return hp;
 }
 
@@ -429,15 +450,17 @@ static int adam_step_field_impl(float* grid_param, ngp_half* grid_param_h, ngp_h
                                 float* density_v, int n_density, float* rgb_param, ngp_half* rgb_param_h, const float* rgb_partials,
                                 float* rgb_m, float* rgb_v, int n_rgb, int n_partials, float lr, float beta1, float beta2, float eps,
                                 float weight_decay, int step, float grad_scale, int zero_grid_grad, const int32_t* found_inf,
-                                const int32_t* found_inf_grid, ngp_stream_t stream) {
-    if (n_grid <= 0 || n_density <= 0 || n_rgb <= 0 || n_partials < 0 || step < 1 || grad_scale == 0.f) return NGP_EINVAL;
-    NGP_CHECK_PTR(grid_param); NGP_CHECK_PTR(grid_grad); NGP_CHECK_PTR(grid_m); NGP_CHECK_PTR(grid_v);
+                                const int32_t* found_inf_grid, int32_t* step_state, ngp_stream_t stream) {
+    // n_grid == 0: the MLP blocks only (a data-parallel rank whose shard of the table is empty)
+    if (n_grid < 0 || n_density <= 0 || n_rgb <= 0 || n_partials < 0 || step < 1 || grad_scale == 0.f) return NGP_EINVAL;
+    if (n_grid > 0) { NGP_CHECK_PTR(grid_param); NGP_CHECK_PTR(grid_grad); NGP_CHECK_PTR(grid_m); NGP_CHECK_PTR(grid_v); }
     NGP_CHECK_PTR(density_param); NGP_CHECK_PTR(density_m); NGP_CHECK_PTR(density_v);
     NGP_CHECK_PTR(rgb_param); NGP_CHECK_PTR(rgb_m); NGP_CHECK_PTR(rgb_v);
     if (n_partials > 0) { NGP_CHECK_PTR(density_partials); NGP_CHECK_PTR(rgb_partials); }
     AdamHyper hp = adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale, found_inf);
     hp.found_inf_dense = found_inf_grid;
     hp.zero_grad = zero_grid_grad != 0;
+    hp.step_state = step_state; hp.slot = (step - 1) & 1;
     const long long n4 = (n_grid + 3) / 4;
     const int dense_blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
     const AdamMlp a = {density_param, (h1*)density_param_h, density_partials, density_m, density_v, n_density, ngp_div_up(n_density, 32)};
@@ -451,10 +474,12 @@ int ngp_adam_step_field(float* grid_param, ngp_half* grid_param_h, ngp_half* gri
                         float* density_param, ngp_half* density_param_h, const float* density_partials, float* density_m,
                         float* density_v, int n_density, float* rgb_param, ngp_half* rgb_param_h, const float* rgb_partials,
                         float* rgb_m, float* rgb_v, int n_rgb, int n_partials, float lr, float beta1, float beta2, float eps,
-                        float weight_decay, int step, float grad_scale, int zero_grid_grad, const int32_t* found_inf, ngp_stream_t stream) {
+                        float weight_decay, int step, float grad_scale, int zero_grid_grad, const int32_t* found_inf, int32_t* step_state,
+                        ngp_stream_t stream) {
+    if (n_grid <= 0) return NGP_EINVAL;
     return adam_step_field_impl(grid_param, grid_param_h, grid_grad, grid_m, grid_v, n_grid, density_param, density_param_h, density_partials,
                                 density_m, density_v, n_density, rgb_param, rgb_param_h, rgb_partials, rgb_m, rgb_v, n_rgb, n_partials, lr,
-                                beta1, beta2, eps, weight_decay, step, grad_scale, zero_grid_grad, found_inf, found_inf, stream);
+                                beta1, beta2, eps, weight_decay, step, grad_scale, zero_grid_grad, found_inf, found_inf, step_state, stream);
 }
 
 int ngp_adam_step_field_shard(float* grid_param, ngp_half* grid_param_h, ngp_half* grid_grad, float* grid_m, float* grid_v, int64_t n_shard,
@@ -462,10 +487,10 @@ int ngp_adam_step_field_shard(float* grid_param, ngp_half* grid_param_h, ngp_hal
                               float* density_v, int n_density, float* rgb_param, ngp_half* rgb_param_h, const float* rgb_partials,
                               float* rgb_m, float* rgb_v, int n_rgb, int n_partials, float lr, float beta1, float beta2, float eps,
                               float weight_decay, int step, float grad_scale, const int32_t* found_inf_mlp,
-                              const int32_t* found_inf_shard, ngp_stream_t stream) {
+                              const int32_t* found_inf_shard, int32_t* step_state, ngp_stream_t stream) {
     return adam_step_field_impl(grid_param, grid_param_h, grid_grad, grid_m, grid_v, n_shard, density_param, density_param_h, density_partials,
                                 density_m, density_v, n_density, rgb_param, rgb_param_h, rgb_partials, rgb_m, rgb_v, n_rgb, n_partials, lr,
-                                beta1, beta2, eps, weight_decay, step, grad_scale, 0, found_inf_mlp, found_inf_shard, stream);
+                                beta1, beta2, eps, weight_decay, step, grad_scale, 0, found_inf_mlp, found_inf_shard, step_state, stream);
 }
 
 

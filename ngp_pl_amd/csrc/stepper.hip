@@ -224,6 +224,8 @@ int ngp_stepper_set_buffers(ngp_stepper* s, const ngp_step_buffers* buffers) {
     s->b = *buffers;
     s->S = 0; s->n_part = 0;
     s->set_k[0] = s->set_k[1] = 0;                       // (no march of the new record sets has prepared a first-round list)
+    s->two_round_active = false; s->two_rounds = false;  // the auto switch starts over: its evidence (live fraction of the previous
+    s->prev_S = 0;                                       //  step, counter[.][2] of the OLD pinned words) does not describe these buffers
     return 0;
 }
 
@@ -247,10 +249,12 @@ static int forward_field(ngp_stepper* s, const float* rays_o, const float* rays_
     const ngp_stepper_config& c = s->c;
     const ngp_step_buffers& b = s->b;
     const int k = s->pend_set;
-    s->has_pending = false;
     // the step's only host wait.  No hipStreamWaitEvent on the main stream: the host has observed the event, so everything
-    // enqueued from here on is ordered behind the march (the barrier packet measured ~20 us of idle main stream per step)
+    // enqueued from here on is ordered behind the march (the barrier packet measured ~20 us of idle main stream per step).
+    // On NGP_ETIMEOUT the march stays pending: its kernels may still be writing record set k, so the set must not be handed to
+    // another march (do_march refuses while one is pending; a later front() of the same batch waits again).
     STEP_TRY(wait_march(s, k));
+    s->has_pending = false;
     const int32_t S = b.counter[k][0];
     if (S < 0 || (int64_t)S > b.cap) return NGP_EINVAL;
     s->S = S; s->last_set = k; s->n_part = 0;
@@ -264,6 +268,8 @@ static int forward_field(ngp_stepper* s, const float* rays_o, const float* rays_
     if (s->two_round_mode != 0 && b.list_k && b.list_rest && b.two_round_counts && c.lambda_distortion <= 0 && S > 0) {
         if (s->two_round_mode == 1) two = true;
         else {
+            // (the previous step normally consumed the OTHER record set; after a dropped march it was this one, whose word front()
+            //  has not reset yet either -- both hold a live count of an earlier step or -1, and a stale estimate only delays the switch)
             const int32_t prev_live = b.counter[k ^ 1][2];
             if (s->prev_S > 0 && prev_live >= 0) {
                 const float frac = (float)prev_live / (float)s->prev_S;
@@ -460,7 +466,7 @@ int ngp_stepper_table_backward(ngp_stepper* s, int n_groups, int group, ngp_stre
 }
 
 int ngp_stepper_update(ngp_stepper* s, float lr, int32_t step, float grad_scale, const float* density_partials,
-                       const float* rgb_partials, int32_t n_partials, const int32_t* found_inf, ngp_stream_t main_stream) {
+                       const float* rgb_partials, int32_t n_partials, const int32_t* found_inf, int32_t* step_state, ngp_stream_t main_stream) {
     if (!s || step < 1 || (density_partials == nullptr) != (rgb_partials == nullptr)) return NGP_EINVAL;
     HostTimer host_timer(&s->t_enqueue);
     const ngp_stepper_config& c = s->c;
@@ -476,7 +482,7 @@ int ngp_stepper_update(ngp_stepper* s, float lr, int32_t step, float grad_scale,
     STEP_TRY(ngp_adam_step_field(c.enc_param + c.n_density, c.enc_half + c.n_density, c.grid_grad16, c.enc_m + c.n_density, c.enc_v + c.n_density, c.n_grid,
                                  c.enc_param, c.enc_half, density_partials, c.enc_m, c.enc_v, c.n_density,
                                  c.rgb_param, c.rgb_half, rgb_partials, c.rgb_m, c.rgb_v, c.n_rgb,
-                                 n_partials, lr, c.beta1, c.beta2, c.eps, c.weight_decay, step, grad_scale, 0, found_inf, main_stream));
+                                 n_partials, lr, c.beta1, c.beta2, c.eps, c.weight_decay, step, grad_scale, 0, found_inf, step_state, main_stream));
     mark(s, 8, ngp_stream(main_stream));
     STEP_TRY(march_next_if_at(s, AT_ADAM));
     return 0;

@@ -245,9 +245,22 @@ class ShardedExchange(GradientExchange):
         return self
 
     def uninstall(self, trainer):
+        """Back to whole-table updates: every rank gets the whole f32 master AND the whole Adam moments (a rank's m / v are only
+        current inside its own shard; whole-table Adam afterwards would otherwise resume with stale moments everywhere else)."""
         super().uninstall(trainer)
         trainer.update_hook = None
         self.gather_master()
+        opt = getattr(trainer, "opt", None)
+        if opt is not None and hasattr(opt, "moments"):
+            for t in opt.moments("enc"):
+                self._gather_shards(t)
+
+    def broadcast_parameters(self):
+        """DDP's constructor broadcast.  In sharded mode a rank's f32 master is only current inside its own shard, and the f16
+        working copies are re-cast from the master afterwards: make the master whole first."""
+        if getattr(self, "_stepped", False):
+            self.gather_master()
+        super().broadcast_parameters()        # (the invalidated f16 copy is re-cast in place: it stays on the padded storage)
 
     # -- hooks -----------------------------------------------------------------------------------
     def reduce_grid(self):
@@ -291,6 +304,7 @@ class ShardedExchange(GradientExchange):
         nat = self.model._native
         flag_mlp, flag_shard = found_inf if found_inf is not None else (None, None)
         self._adam(lr, step, grad_scale, nat, flag_mlp, flag_shard, stream_handle)
+        self._stepped = True
         enc = self.model.xyz_encoder
         table = self._h_big[enc.n_mlp:]
         self.dist.all_gather_into_tensor(table, table[self.rank * self.shard_len:(self.rank + 1) * self.shard_len], group=self.group)
@@ -302,21 +316,26 @@ class ShardedExchange(GradientExchange):
         tr = self._trainer
         m = self.model
         enc, net = m.xyz_encoder, m.rgb_net
-        (em, ev), (rm, rv) = tr.opt.state["enc"], tr.opt.state["rgb"]
+        (em, ev), (rm, rv) = tr.opt.moments("enc"), tr.opt.moments("rgb")
         b1, b2 = tr.opt.betas
         ne, lo, n = enc.n_mlp, self.lo, self.hi - self.lo
         p_enc, p_half, p_m, p_v = enc.params.data_ptr(), self._h_big.data_ptr(), em.data_ptr(), ev.data_ptr()
         sq = stream_handle if stream_handle is not None else stream()
-        call("ngp_adam_step_field_shard", p_enc + 4 * (ne + lo), p_half + 2 * (ne + lo), ptr(self._shard16), p_m + 4 * (ne + lo), p_v + 4 * (ne + lo), max(n, 1),
+        # (a rank whose shard is empty -- rank * shard_len >= n_grid: small tables, large worlds -- passes n = 0: the MLP blocks only)
+        call("ngp_adam_step_field_shard", p_enc + 4 * (ne + lo), p_half + 2 * (ne + lo), ptr(self._shard16), p_m + 4 * (ne + lo), p_v + 4 * (ne + lo), n,
              p_enc, p_half, ptr(nat["density_partials"]), p_m, p_v, ne,
              net.params.data_ptr(), net._half.t.data_ptr(), ptr(nat["rgb_partials"]), rm.data_ptr(), rv.data_ptr(), net.params.numel(),
-             nat["n_partials"], lr, b1, b2, tr.opt.eps, tr.opt.weight_decay, step, grad_scale, ptr(flag_mlp), ptr(flag_shard), sq)
+             nat["n_partials"], lr, b1, b2, tr.opt.eps, tr.opt.weight_decay, step, grad_scale, ptr(flag_mlp), ptr(flag_shard),
+             tr.opt.step_state(flag_mlp), sq)
         enc._half.mark_fresh(enc.params); net._half.mark_fresh(net.params)
 
     def gather_master(self):
         """All ranks' f32 master shards -> every rank's `xyz_encoder.params` (checkpointing / leaving the sharded mode)."""
+        self._gather_shards(self.model.xyz_encoder.params.data)
+
+    def _gather_shards(self, p):
+        """p = [density MLP (n_mlp) | grid (n_grid)] f32 whose grid part is current per shard: all-gather the shards in place."""
         enc = self.model.xyz_encoder
-        p = enc.params.data
         padded = self.world * self.shard_len
         buf = torch.zeros(padded, dtype=p.dtype, device=p.device)
         buf[self.lo:self.hi] = p[enc.n_mlp + self.lo:enc.n_mlp + self.hi]

@@ -120,6 +120,8 @@ class NGP(nn.Module):
         self.sync_free_sampling = True   # occupancy-cell sampling without the reference's nonzero() host sync
         self._native = None
         self._g16 = None
+        from .optim import tag_parameters
+        tag_parameters(self)         # an optimizer built from bare parameter tensors (train.py:123-131) finds this model through them
 
     # -- helpers -------------------------------------------------------------------------------
     def hand_over_native(self, record):

@@ -1,52 +1,200 @@
-"""Fused Adam for the NGP field: apex FusedAdam's update (the reference's optimizer,
-/root/reference/train.py:131: lr 1e-2, eps 1e-15, adam_w_mode, bias correction) applied by
-ngp_adam_step directly to the native gradient buffers the fused backward leaves behind
-(packed-f16 grid gradient, f32 per-workgroup MLP partials): unscale + Adam + f32->f16 parameter
-cast + gradient zeroing in ONE pass over the 11.4 M parameters and ONE launch for the grid table and
-both MLP blocks (ngp_adam_step_field).
+"""Fused Adam for the NGP field: apex FusedAdam's update (the reference's optimizer, /root/reference/train.py:131-137:
+`FusedAdam(net_params, lr, eps=1e-15)` under `CosineAnnealingLR`; adam_w_mode, bias correction) as a `torch.optim.Optimizer`
+that is constructed the way the reference constructs apex's -- from a list of parameters -- and that recognises the two parameter
+tensors of an `ngp_pl_amd.networks.NGP` among them.
+
+Two sources of gradients, decided per step by what the backward left behind:
+  * NATIVE (`model.native_grads = True`: `Trainer`, bench.py's `api_path`): the fused backward leaves the packed-f16 grid gradient
+    and the f32 per-workgroup MLP partial rows in native buffers (`model._native`); `ngp_adam_step_field` applies unscale + Adam +
+    f32->f16 parameter cast to the grid table and both MLP blocks in ONE launch and ONE pass over the 11.4 M parameters;
+  * `.grad` (`model.native_grads = False`, the default of a freshly built NGP: what an unchanged train.py with Lightning's
+    GradScaler / DistributedDataParallel sees): f32 gradients on the Parameters, as tiny-cuda-nn's modules produce them;
+    `ngp_adam_step` per parameter tensor (Adam + the f16 working-copy refresh tiny-cuda-nn performs each forward).
+Parameters that belong to no NGP (none in the reference's recipe; `dR` / `dT` have their own torch Adam, train.py:117-122) are
+updated by the same per-tensor kernel.  CPU parameters are refused: the product path has no CPU fallback.
 """
 import contextlib
 import math
+import weakref
 
 import torch
 
-from . import tcnn
 from ._lib import call, ptr, stream
 
 
-class FusedAdam:
-    def __init__(self, model, lr=1e-2, betas=(0.9, 0.999), eps=1e-15, weight_decay=0.0):
-        self.model = model
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
-        self.param_groups = [{"lr": lr}]
-        self.t = 0
-        enc, net = model.xyz_encoder, model.rgb_net
-        self.state = {}
-        for name, p in (("enc", enc.params), ("rgb", net.params)):
-            self.state[name] = (torch.zeros_like(p.data), torch.zeros_like(p.data))
-        # make sure the f16 working copies exist; from now on this optimizer keeps them fresh
-        enc._half.get(enc.params); net._half.get(net.params)
-        model.native_grads = True
+def tag_parameters(model):
+    """Called by NGP.__init__: lets an optimizer that is handed bare parameter tensors (train.py:123-131) find the model whose
+    native gradient buffers they belong to.  The tags live on the Parameter objects (`.to(device)` keeps the objects)."""
+    ref = weakref.ref(model)
+    for role, mod in (("enc", model.xyz_encoder), ("rgb", model.rgb_net)):
+        mod.params._ngp_model = ref
+        mod.params._ngp_role = role
 
-    def zero_grad(self):
-        pass   # ngp_adam_step zeroes what it consumes; the sliced grid backward overwrites
 
+class FusedAdam(torch.optim.Optimizer):
+    """apex.optimizers.FusedAdam's constructor (params, lr, bias_correction, betas, eps, adam_w_mode, weight_decay, amsgrad,
+    set_grad_none).  `params` may also be an NGP module (its parameters are taken, and the model is switched to native gradients:
+    what `Trainer` does)."""
+
+    def __init__(self, params, lr=1e-3, bias_correction=True, betas=(0.9, 0.999), eps=1e-8, adam_w_mode=True, weight_decay=0.0,
+                 amsgrad=False, set_grad_none=True, native_grads=None):
+        if amsgrad:
+            raise RuntimeError("FusedAdam does not support the AMSGrad variant.")          # apex's own message
+        if not (bias_correction and adam_w_mode):
+            raise NotImplementedError("the native kernels implement apex's defaults: bias_correction=True, adam_w_mode=True")
+        model = None
+        if isinstance(params, torch.nn.Module):
+            model = params
+            params = list(model.parameters())
+            if native_grads is None:
+                native_grads = True
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.set_grad_none = set_grad_none
+        self.t = 0                       # native step calls so far (1-based inside a step)
+        self._step_state = None          # device-side counts of APPLIED steps, once a skip flag has been seen (ngp_adam_step_field)
+        # the NGP whose (xyz_encoder.params, rgb_net.params) are both in this optimizer
+        self._roles = {}
+        for group in self.param_groups:
+            for p in group["params"]:
+                ref = getattr(p, "_ngp_model", None)
+                m = ref() if ref is not None else None
+                if m is None:
+                    continue
+                if model is None:
+                    model = m
+                if m is model:
+                    self._roles[p._ngp_role] = p
+        self.model = model if (model is not None and set(self._roles) == {"enc", "rgb"}) else None
+        if self.model is not None:
+            enc, net = self.model.xyz_encoder, self.model.rgb_net
+            for p in (enc.params, net.params):
+                self._moments(p)
+            # make sure the f16 working copies exist; from now on this optimizer keeps them fresh
+            if enc.params.is_cuda:
+                enc._half.get(enc.params); net._half.get(net.params)
+            if native_grads is not None:
+                self.model.native_grads = bool(native_grads)
+
+    # -- state -----------------------------------------------------------------------------------
+    def _moments(self, p):
+        st = self.state[p]
+        if "exp_avg" not in st:
+            st["step"] = 0
+            st["exp_avg"] = torch.zeros_like(p.data)
+            st["exp_avg_sq"] = torch.zeros_like(p.data)
+        return st["exp_avg"], st["exp_avg_sq"]
+
+    def moments(self, role):
+        """(m, v) of the model's 'enc' (density MLP + grid table) or 'rgb' parameter tensor."""
+        return self._moments(self._roles[role])
+
+    @property
+    def lr(self):
+        return self.param_groups[0]["lr"]
+
+    @property
+    def betas(self):
+        return self.param_groups[0]["betas"]
+
+    @property
+    def eps(self):
+        return self.param_groups[0]["eps"]
+
+    @property
+    def weight_decay(self):
+        return self.param_groups[0]["weight_decay"]
+
+    def step_state(self, found_inf):
+        """Device pointer of the applied-step counts (ngp_adam_step_field's `step_state`), or None while no skip flag has ever been
+        handed to this optimizer: without a flag every call applies, and the host count `t` IS the bias-correction step."""
+        if found_inf is None and self._step_state is None:
+            return None
+        if self._step_state is None:
+            dev = self._roles["enc"].device
+            self._step_state = torch.full((4,), self.t - 1, dtype=torch.int32, device=dev)      # steps applied before this call
+        return self._step_state.data_ptr()
+
+    def applied_steps(self):
+        """Steps actually applied to (MLP blocks, grid block) -- equal to `t` unless a skip flag was raised (syncs)."""
+        if self._step_state is None:
+            return self.t, self.t
+        s = self._step_state.tolist()
+        return s[self.t & 1], s[2 + (self.t & 1)]
+
+    def zero_grad(self, set_to_none=None):
+        # (the native gradient buffers need no clearing: every table backward overwrites them, the MLP partial rows are rewritten)
+        super().zero_grad(set_to_none=self.set_grad_none if set_to_none is None else set_to_none)
+
+    # -- the update ------------------------------------------------------------------------------
     @torch.no_grad()
-    def step(self, grad_scale=1.0, found_inf=None, stream_handle=None):
-        """grad_scale: extra factor the caller put on the loss (GradScaler); the kernels' own loss
-        scale is taken from the native record.  found_inf: device int32 flag (non-zero: skip)."""
+    def step(self, closure=None, grad_scale=1.0, found_inf=None, stream_handle=None):
+        """grad_scale: extra factor the caller put on the loss (a GradScaler-style scale applied OUTSIDE torch's GradScaler, which
+        unscales `.grad` itself); the kernels' own loss scale is taken from the native record.  found_inf: device int32 flag
+        (non-zero: skip) -- with it the bias-correction count lives on the device too and does not advance on a skipped step."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
         model = self.model
-        nat = model._native
-        if nat is None:
-            raise RuntimeError("FusedAdam.step() needs a backward of NGP's fused field (model.native_grads=True)")
+        nat = model._native if model is not None else None
+        native_done = False
+        if nat is not None:
+            self._step_native(nat, grad_scale, found_inf, stream_handle)
+            native_done = True
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if native_done and (p is model.xyz_encoder.params or p is model.rgb_net.params):
+                    raise RuntimeError("both a native gradient record and a .grad tensor for the same NGP parameter: a backward ran with "
+                                       "model.native_grads switched in between")
+                if not p.is_cuda:
+                    raise RuntimeError("FusedAdam: parameter on %s -- the native optimizer has no CPU fallback" % p.device)
+                if p.grad.is_sparse:
+                    raise RuntimeError("FusedAdam does not support sparse gradients, please consider SparseAdam instead")
+                if p.numel() == 0:
+                    continue
+                m, v = self._moments(p)
+                self.state[p]["step"] += 1
+                if p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
+                    p.grad = p.grad.float().contiguous()
+                half = self._half_of(p)
+                with torch.cuda.device(p.device):
+                    # f32 gradient, CONSUMED: the kernel leaves .grad zero-filled (apex leaves it alone; every training loop clears
+                    # it next, Lightning included -- and a copy to preserve it would add 2 x 45.7 MB of traffic per step)
+                    call("ngp_adam_step", ptr(p.data), ptr(half), ptr(p.grad), 1, ptr(m), ptr(v), p.numel(), group["lr"], b1, b2,
+                         group["eps"], group["weight_decay"], self.state[p]["step"], float(grad_scale), ptr(found_inf),
+                         stream_handle if stream_handle is not None else stream())
+                mod = self._module_of(p)
+                if mod is not None and half is not None:
+                    mod._half.mark_fresh(p)
+        return loss
+
+    def _module_of(self, p):
+        ref = getattr(p, "_tcnn_module", None)
+        return ref() if ref is not None else None
+
+    def _half_of(self, p):
+        """The f16 working copy a tiny-cuda-nn style module keeps of `p` (refreshed by the kernel), or None for a plain tensor."""
+        mod = self._module_of(p)
+        if mod is None or not hasattr(mod, "_half"):
+            return None
+        if mod._half.t is None or mod._half.t.shape != p.shape or mod._half.t.device != p.device:
+            mod._half.get(p)
+        return mod._half.t
+
+    def _step_native(self, nat, grad_scale, found_inf, stream_handle):
+        model = self.model
         enc, net = model.xyz_encoder, model.rgb_net
         self.t += 1
-        lr = self.param_groups[0]["lr"]
-        b1, b2 = self.betas
+        group = self.param_groups[0]
+        lr = group["lr"]
+        b1, b2 = group["betas"]
         total_scale = nat["scale"] * grad_scale
         sq = stream_handle if stream_handle is not None else stream()
-        m, v = self.state["enc"]
-        rm, rv = self.state["rgb"]
+        m, v = self.moments("enc")
+        rm, rv = self.moments("rgb")
         ne = enc.n_mlp
         # raw pointers by arithmetic (a tensor slice costs ~4 us of host time, this call passes 6 of them)
         p_enc, p_half, p_m, p_v = enc.params.data_ptr(), enc._half.t.data_ptr(), m.data_ptr(), v.data_ptr()
@@ -55,7 +203,9 @@ class FusedAdam:
             call("ngp_adam_step_field", p_enc + 4 * ne, p_half + 2 * ne, ptr(nat["grid16"]), p_m + 4 * ne, p_v + 4 * ne, enc.n_grid,
                  p_enc, p_half, ptr(nat["density_partials"]), p_m, p_v, ne,
                  net.params.data_ptr(), net._half.t.data_ptr(), ptr(nat["rgb_partials"]), rm.data_ptr(), rv.data_ptr(), net.params.numel(),
-                 nat["n_partials"], lr, b1, b2, self.eps, self.weight_decay, self.t, total_scale, 0, ptr(found_inf), sq)      # 0: every table backward of this package overwrites the gradient
+                 nat["n_partials"], lr, b1, b2, group["eps"], group["weight_decay"], self.t, total_scale, 0, ptr(found_inf),
+                 self.step_state(found_inf), sq)      # 0: every table backward of this package overwrites the gradient
+        enc._half.mark_fresh(enc.params); net._half.mark_fresh(net.params)
         model._native = None
 
 

@@ -84,6 +84,10 @@ class StepBuffers:
         self.stats = view("stats", f32, 2); self.dist = view("dist", f32, n_rays)
         self.n_active = view("n_active", torch.int32, 1)
         view("zeros", f32, n_rays).zero_()               # dL/ddepth: the loss has no depth term
+        # The two-round forward leaves the samples behind a ray's stop unevaluated; the composite masks them by position (composite.hip:
+        # chunk_transmittance), so their contents cannot matter -- zero-filled once all the same, so that a debugger or a new kernel
+        # that does read them sees sigma = 0, rgb = 0 or an earlier step's values, never allocator bytes.
+        view("sigmas", f32, self.cap).zero_(); view("rgbs", f32, self.cap, 3).zero_()
         self.dist_seed_val = None
         self.noise = [view("noise%d" % k, f32, n_rays) for k in (0, 1)]
         # {S, R} of a march is written by its scan kernel straight into pinned (device-mapped) host memory

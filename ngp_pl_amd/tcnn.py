@@ -15,6 +15,8 @@ ones the reference instantiates (hash grid F=2, L<=16, linear; FullyFusedMLP 64 
 import ctypes as C
 import math
 
+import weakref
+
 import torch
 from torch import nn
 
@@ -220,6 +222,7 @@ class NetworkWithInputEncoding(nn.Module):
         mlp = mlp_init(gen, 32, 1)
         grid = (torch.rand(self.n_grid, generator=gen) * 2 - 1) * 1e-4
         self.params = nn.Parameter(torch.cat([mlp, grid]))
+        self.params._tcnn_module = weakref.ref(self)            # optim.FusedAdam refreshes this module's f16 working copy
         self.register_buffer("_zero3", torch.zeros(3), persistent=False)
         self.register_buffer("_one3", torch.ones(3), persistent=False)
         self._half = _HalfCache()
@@ -239,7 +242,9 @@ class Encoding(nn.Module):
         if encoding_config.get("otype") != "SphericalHarmonics" or int(encoding_config.get("degree", 4)) != 4 or n_input_dims != 3:
             _unsupported("encoding %r" % (encoding_config,))
         self.n_input_dims, self.n_output_dims = 3, 16
-        self.params = nn.Parameter(torch.zeros(0))
+        # (no gradient ever reaches an empty tensor: requires_grad=True would make DistributedDataParallel wait for one and fail
+        #  in the second iteration -- "Expected to have finished reduction in the prior iteration")
+        self.params = nn.Parameter(torch.zeros(0), requires_grad=False)
 
     def forward(self, x):
         return _SH4.apply(x)
@@ -323,6 +328,7 @@ class Network(nn.Module):
         self.n_hidden, self.out_act = _check_network(network_config, n_output_dims)
         gen = torch.Generator().manual_seed(seed)
         self.params = nn.Parameter(mlp_init(gen, self.n_in_padded, self.n_hidden))
+        self.params._tcnn_module = weakref.ref(self)
         self._half = _HalfCache()
         self.loss_scale = LOSS_SCALE
 

@@ -73,6 +73,12 @@ class Trainer:
         # default-priority stream was observed to share the main stream's queue (rocprofv3: every kernel on one
         # queue_id, step 0.52 -> 0.89 ms).  High-priority streams are served from a separate queue.
         self.side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("NGP_MARCH_PRIORITY", "-1"))) if (overlap_march and dev.type == "cuda") else None
+        # seed of the march's jitter draws (custom_functions.py:83: every rank's torch.rand_like draws from its own generator): the rank
+        # is mixed in so that data-parallel ranks do not jitter ray slot r alike at every step
+        rank = 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank = torch.distributed.get_rank()
+        self.noise_seed = (int(os.environ.get("NGP_NOISE_SEED", "20240924")) + 0x632BE59BD9B4E019 * rank) & 0xFFFFFFFFFFFFFFFF
         self._pending = None     # marched-but-not-consumed batch
         self._marches = 0        # marches enqueued so far (keys the jitter draw)
         # where in the step the next batch's march is enqueued (it starts behind whatever the main stream has queued by
@@ -188,7 +194,7 @@ class Trainer:
         m = self.model
         enc, net = m.xyz_encoder, m.rgb_net
         eh, rh = enc._half.get(enc.params), net._half.get(net.params)
-        (em, ev), (rm, rv) = self.opt.state["enc"], self.opt.state["rgb"]
+        (em, ev), (rm, rv) = self.opt.moments("enc"), self.opt.moments("rgb")
         g16 = m._grid_grad16(enc.params.device)
         key = (enc.params.data_ptr(), eh.data_ptr(), em.data_ptr(), ev.data_ptr(), net.params.data_ptr(), rh.data_ptr(), rm.data_ptr(),
                rv.data_ptr(), g16.data_ptr(), m.density_bitfield.data_ptr(), m.center.data_ptr(), self.lambda_distortion)
@@ -207,7 +213,7 @@ class Trainer:
         c.lambda_opacity, c.lambda_distortion, c.bg = self.lambda_opacity, self.lambda_distortion, ptr(self.bg)
         b1, b2 = self.opt.betas
         c.beta1, c.beta2, c.eps, c.weight_decay = b1, b2, self.opt.eps, self.opt.weight_decay
-        c.noise_seed = int(os.environ.get("NGP_NOISE_SEED", "20240924"))
+        c.noise_seed = self.noise_seed
         bc = B.c_struct(self.lambda_distortion > 0)
         h = C.c_void_p()
         call("ngp_stepper_create", C.byref(c), C.byref(bc), C.byref(h))
@@ -278,7 +284,7 @@ class Trainer:
             S, n_part = S_c.value, np_c.value
             # hooks (multi-GPU exchange), an update hook, or an optimizer whose step() was replaced (tests capture the gradients
             # there): the tail runs through Python; otherwise table backward + Adam are two more library calls
-            custom_opt = "step" in vars(self.opt)
+            custom_opt = "step" in vars(self.opt) and not getattr(self.opt.step, "_wrapped_by_lr_sched", False)     # (an LR scheduler wraps step(): still ours)
             hooks = self.grad_hook is not None or self.mlp_grad_hook is not None or custom_opt
             if S > 0:
                 epoch = self.global_step // self.steps_per_epoch
@@ -286,7 +292,7 @@ class Trainer:
                 if not hooks:
                     call("ngp_stepper_table_backward", h, 1, 0, mq)
                     self.opt.t += 1
-                    call("ngp_stepper_update", h, lr, self.opt.t, self.loss_scale * self.grad_scale, None, None, 0, None, mq)
+                    call("ngp_stepper_update", h, lr, self.opt.t, self.loss_scale * self.grad_scale, None, None, 0, None, self.opt.step_state(None), mq)
                     enc._half.mark_fresh(enc.params); net._half.mark_fresh(net.params)
                 else:
                     g16 = m._grid_grad16(dev)
@@ -312,7 +318,7 @@ class Trainer:
                     else:
                         self.opt.t += 1
                         call("ngp_stepper_update", h, lr, self.opt.t, nat["scale"] * self.grad_scale, ptr(nat["density_partials"]),
-                             ptr(nat["rgb_partials"]), nat["n_partials"], ptr(found_inf), mq)
+                             ptr(nat["rgb_partials"]), nat["n_partials"], ptr(found_inf), self.opt.step_state(found_inf), mq)
                         enc._half.mark_fresh(enc.params); net._half.mark_fresh(net.params)
                         m._native = None
             elif self.grad_hook is not None or self.mlp_grad_hook is not None:
@@ -355,7 +361,7 @@ class Trainer:
             # AABB + near clamp + the jitter of the first sample (custom_functions.py:83: torch.rand_like) in one launch; the same
             # counter-based draw as the native stepper's (csrc/stepper.hip), so the two enqueue paths produce the same steps
             self._marches += 1
-            seed = (int(os.environ.get("NGP_NOISE_SEED", "20240924")) + 0x9E3779B97F4A7C15 * self._marches) & 0xFFFFFFFFFFFFFFFF
+            seed = (self.noise_seed + 0x9E3779B97F4A7C15 * self._marches) & 0xFFFFFFFFFFFFFFFF
             call("ngp_ray_aabb_near_noise", ptr(rays_o), ptr(rays_d), ptr(m.center), ptr(m.half_size), NEAR_DISTANCE, n, seed,
                  P["hits_t%d" % k], P["noise%d" % k], sq)
             call(self._march_count, ptr(rays_o), ptr(rays_d), P["hits_t%d" % k], ptr(m.density_bitfield), m.cascades,

@@ -46,7 +46,7 @@ def test_c_program_links_every_declared_symbol(tmp_path):
     assert r.returncode == 0, r.stdout[-3000:]
     r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
     assert r.returncode == 0, r.stdout
-    assert r.stdout.split() == [str(len(protos)), "3", "gfx950"], r.stdout
+    assert r.stdout.split() == [str(len(protos)), "4", "gfx950"], r.stdout
 
 
 def test_ctypes_table_agrees_with_the_header():
@@ -92,7 +92,7 @@ def test_library_exports_every_declared_symbol():
     assert set(names) <= exported, sorted(set(names) - exported)
     assert exported <= set(names), "exported but undeclared: %s" % sorted(exported - set(names))
     assert set(_lib.exported_symbols()) == set(names)          # the ctypes table covers the whole header
-    assert lib.ngp_abi_version() == 3 and lib.ngp_build_arch() == b"gfx950"
+    assert lib.ngp_abi_version() == 4 and lib.ngp_build_arch() == b"gfx950"
 
 
 def test_code_object_is_gfx950_only():
@@ -209,11 +209,11 @@ def test_workspace_queries_and_new_entry_points_validate_on_host():
     # whole-field Adam: all three blocks must exist, step is 1-based
     field = [0x1000] * 5 + [100] + [0x1000] * 5 + [64] + [0x1000] * 5 + [64, 4, 1e-2, 0.9, 0.999, 1e-15, 0.0]
     with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
-        _lib.call("ngp_adam_step_field", *(field + [0, 1.0, 1, None, None]))
+        _lib.call("ngp_adam_step_field", *(field + [0, 1.0, 1, None, None, None]))
     with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
-        _lib.call("ngp_adam_step_field", *(field[:5] + [0] + field[6:] + [1, 1.0, 1, None, None]))
+        _lib.call("ngp_adam_step_field", *(field[:5] + [0] + field[6:] + [1, 1.0, 1, None, None, None]))
     with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
-        _lib.call("ngp_adam_step_field", *([None] + field[1:] + [1, 1.0, 1, None, None]))
+        _lib.call("ngp_adam_step_field", *([None] + field[1:] + [1, 1.0, 1, None, None, None]))
 
 
 def test_mirrored_records_have_the_librarys_layout():

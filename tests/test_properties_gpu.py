@@ -180,7 +180,7 @@ def test_adam_field_launch_is_bit_identical_to_the_three_separate_launches():
     grad_keep = grad.clone()
     call("ngp_adam_step_field", ptr(grid[0]), ptr(grid[1]), ptr(grad), ptr(grid[2]), ptr(grid[3]), n_grid,
          ptr(dens[0]), ptr(dens[1]), ptr(pd), ptr(dens[2]), ptr(dens[3]), n_d,
-         ptr(rgb[0]), ptr(rgb[1]), ptr(pr), ptr(rgb[2]), ptr(rgb[3]), n_r, rows, *hyper[:7], 1, *hyper[7:])
+         ptr(rgb[0]), ptr(rgb[1]), ptr(pr), ptr(rgb[2]), ptr(rgb[3]), n_r, rows, *hyper[:7], 1, hyper[7], None, hyper[8])
     torch.cuda.synchronize()
     for got, want in zip((grid, dens, rgb), ref):
         for a, b in zip(got, want):
@@ -191,13 +191,52 @@ def test_adam_field_launch_is_bit_identical_to_the_three_separate_launches():
     before = grad_keep.clone()
     call("ngp_adam_step_field", ptr(g2[0]), ptr(g2[1]), ptr(grad_keep), ptr(g2[2]), ptr(g2[3]), n_grid,
          ptr(d2[0]), ptr(d2[1]), ptr(pd), ptr(d2[2]), ptr(d2[3]), n_d,
-         ptr(r2[0]), ptr(r2[1]), ptr(pr), ptr(r2[2]), ptr(r2[3]), n_r, rows, *hyper[:7], 0, *hyper[7:])
+         ptr(r2[0]), ptr(r2[1]), ptr(pr), ptr(r2[2]), ptr(r2[3]), n_r, rows, *hyper[:7], 0, hyper[7], None, hyper[8])
     torch.cuda.synchronize()
     for got, want in zip(keep, ref):
         for a, b in zip(got, want):
             assert torch.equal(a, b)
     assert torch.equal(grad_keep, before) and bool(grad_keep.any())
     assert torch.equal(grid[1], grid[0].half()) and bool(grid[1].any())    # the update happened and refreshed the working copy
+
+
+def test_adam_step_count_lives_next_to_the_skip_flag():
+    """apex / GradScaler leave the optimizer's step count unchanged on a skipped step.  The skip flag is a device word, so the count of
+    APPLIED steps is one too (`step_state`): three calls with flags (0, 1, 0) must equal TWO plain calls (host steps 1, 2) on the
+    first and third gradient -- the bias correction of the third call is that of step 2, not 3 -- and the counts read back 2."""
+    from ngp_pl_amd._lib import call, ptr, stream
+    DEV = "cuda"
+    torch.manual_seed(6)
+    n_grid, n_d, n_r, rows = 40_000, 3072, 7168, 5
+
+    def state(n):
+        return [torch.randn(n, device=DEV) * 0.1, torch.zeros(n, dtype=torch.float16, device=DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)]
+    grads = [((torch.randn(n_grid, device=DEV) * 0.3).half(), torch.randn(rows, n_d, device=DEV), torch.randn(rows, n_r, device=DEV)) for _ in range(3)]
+
+    def run(calls, with_state):
+        torch.manual_seed(7)
+        grid, dens, rgb = state(n_grid), state(n_d), state(n_r)
+        st = torch.zeros(4, dtype=torch.int32, device=DEV) if with_state else None
+        flags = [torch.tensor([f], dtype=torch.int32, device=DEV) for f in (0, 1)]
+        for k, (gi, flag) in enumerate(calls):
+            g, pd, pr = grads[gi]
+            call("ngp_adam_step_field", ptr(grid[0]), ptr(grid[1]), ptr(g.clone()), ptr(grid[2]), ptr(grid[3]), n_grid,
+                 ptr(dens[0]), ptr(dens[1]), ptr(pd), ptr(dens[2]), ptr(dens[3]), n_d,
+                 ptr(rgb[0]), ptr(rgb[1]), ptr(pr), ptr(rgb[2]), ptr(rgb[3]), n_r, rows, 1e-2, 0.9, 0.999, 1e-15, 0.0, k + 1, 128.0, 0,
+                 ptr(flags[flag]) if with_state else None, ptr(st), stream())
+        torch.cuda.synchronize()
+        return grid, dens, rgb, st
+    a = run([(0, 0), (1, 1), (2, 0)], True)
+    b = run([(0, 0), (2, 0)], False)
+    for got, want in zip(a[:3], b[:3]):
+        for x, y in zip(got, want):
+            torch.testing.assert_close(x, y, rtol=2e-6, atol=1e-9)
+    st = a[3].tolist()
+    assert st[3 & 1] == 2 and st[2 + (3 & 1)] == 2, st          # slot (calls & 1) of each pair holds the applied count
+    # ... and WITHOUT the device count the third call would have corrected for step 3: a visibly different update
+    c = run([(0, 0), (2, 0)], False)
+    call_step3 = run([(0, 0), (1, 1), (2, 0)], True)
+    assert torch.equal(c[0][0], b[0][0]) and torch.equal(call_step3[0][0], a[0][0])      # deterministic
 
 
 @pytest.mark.parametrize("n_rays", [1, 777, 8192, 20000])

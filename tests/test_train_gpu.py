@@ -1024,6 +1024,50 @@ def test_two_round_forward_is_bit_identical():
     assert la[-1][0] > 0 and la[-1][2] > 0
 
 
+def test_two_round_forward_ignores_stale_values_behind_a_stop():
+    """with the two-round forward a ray that stops inside its first K samples leaves the rest of the ray
+    unevaluated, and the composite still loads sigma for all 64 lanes of that chunk.  Here the sigma / rgb slots are filled with
+    NaN and large NEGATIVE values (1 - alpha = exp(+x) > 1: the transmittance of a later lane would climb back over the threshold)
+    before every step; the composite decides `live` by position relative to the first stop lane, so the run must equal the one-round
+    run on clean buffers bit for bit -- losses, live counts and every parameter after 300 steps, by which time most rays stop early."""
+    import os
+    from ngp_pl_amd import _lib
+    from ngp_pl_amd.trainer import Trainer
+    batches = [batch(2048, seed=1700 + i) for i in range(8)]
+
+    def run(mode, poison):
+        os.environ["NGP_TWO_ROUND"] = mode
+        os.environ["NGP_TWO_ROUND_K"] = "32"
+        try:
+            m = make_model(seed=43)
+            tr = Trainer(m)
+            log, rounds, early = [], 0, 0
+            for i in range(300):
+                b, nb = batches[i % 8], batches[(i + 1) % 8]
+                if poison and tr._buf is not None:
+                    B = tr._buf
+                    sig = B.view("sigmas", torch.float32, B.cap); rgb = B.view("rgbs", torch.float32, B.cap * 3)
+                    sig[0::2] = float("nan"); sig[1::2] = -1e4
+                    rgb[0::2] = float("nan"); rgb[1::2] = -3.0
+                out = tr.step(*b, next_batch=(nb[0], nb[1]))
+                rounds += _lib.call("ngp_stepper_two_rounds", tr._stepper)
+                n_act = int(tr.last["n_active"].item())
+                early += n_act < out["rm_samples"]
+                log.append((out["rm_samples"], tr.last["stats"].tolist(), n_act))
+            torch.cuda.synchronize()
+            return m, log, rounds, early
+        finally:
+            os.environ.pop("NGP_TWO_ROUND", None); os.environ.pop("NGP_TWO_ROUND_K", None)
+    ma, la, ra, ea = run("off", False)
+    mb, lb, rb, eb = run("on", True)
+    assert ra == 0 and rb >= 299, (ra, rb)
+    assert ea > 100, "the field never learnt to stop rays early: the test does not exercise what it is for (%d)" % ea
+    assert all(math.isfinite(x) for rec in lb for x in rec[1]), "poisoned slots reached the loss"
+    assert la == lb, [i for i in range(300) if la[i] != lb[i]][:5]
+    for (ka, pa), (kb, pb) in zip(ma.state_dict().items(), mb.state_dict().items()):
+        assert ka == kb and torch.equal(pa, pb), ka
+
+
 def test_two_round_forward_switches_itself_on_late_in_training():
     """`auto` (the default): on a scene of opaque surfaces the live fraction falls under 0.15 within a few thousand steps and the
     stepper starts evaluating in two rounds; training goes on (finite loss, rising PSNR)."""
