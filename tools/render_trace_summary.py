@@ -29,4 +29,4 @@ kern = [{"kernel": k, "launches_per_frame": a[0] / frames, "avg_us": a[1] / a[0]
         for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]]
 print(json.dumps({"config": cfg, "frames": frames, "gpu_busy_ms_per_frame": busy / frames / 1e6, "span_ms_per_frame": span / frames / 1e6,
                   "dominant_kernel": kern[0]["kernel"], "kernels": kern, "run": run,
-                  "what": "rocprofv3 --kernel-trace of tools/render_trained.py; span includes the untimed PSNR ground-truth generation between frames"}))
+                  "what": "rocprofv3 --kernel-trace of tools/render_trained.py: every kernel between the first timed frame's render_begin and the end of the last frame (ray generation by torch included, as in the FPS protocol)"}))

@@ -19,6 +19,6 @@ loop.steps(steps)
 torch.cuda.synchronize(); train_s = time.perf_counter() - t0
 kw = {"k4_cap64": dict(chunk_scale=4, probe_cap=64), "device_exact": dict()}[config]
 poses = syn.hemisphere_poses(frames, seed=999).to(dev)
-res = render_eval(loop.model, loop.data, poses, psnr=True, **kw)
+res = render_eval(loop.model, loop.data, poses, psnr=bool(int(os.environ.get("PSNR", "0"))), **kw)      # (PSNR needs ground-truth kernels between the frames: off under a trace)
 res.update(config=config, train_steps=steps, train_s=train_s, frames=frames)
 print(json.dumps(res), flush=True)
