@@ -157,12 +157,33 @@ class Loop:
         if dist is not None:       # also with a 1-rank process group (torchrun --nproc-per-node 1): exercises the collective path
             # NGP_DDP_EXCHANGE: "sharded" (default: reduce-scatter -> Adam on the rank's shard -> all-gather of the f16 table) or
             # "allreduce" (one all-reduce of the f16 gradient, whole-table Adam on every rank)
-            from ngp_pl_amd.ddp import GradientExchange, ShardedExchange
+            # NGP_DDP_NATIVE (default 1): the exchange is enqueued by the library on its own RCCL communicator and stream
+            # (ddp.NativeExchange, csrc/comm.hip + ngp_stepper_tail); 0: the torch.distributed classes (the host-side mirrors the gloo
+            # tests drive).  NGP_DDP_CHUNKS / NGP_DDP_GROUPS: pieces of the grid exchange / launch groups of the table backward.
+            from ngp_pl_amd.ddp import GradientExchange, NativeExchange, ShardedExchange
             self.exchange_kind = os.environ.get("NGP_DDP_EXCHANGE", "sharded")
-            if self.exchange_kind == "sharded":
-                self.exchange = ShardedExchange(self.model, dist, world, rank).install(self.trainer)
-            else:
-                self.exchange = GradientExchange(self.model, dist, world).install(self.trainer)
+            self.exchange_impl = "native" if os.environ.get("NGP_DDP_NATIVE", "1") != "0" else "torch.distributed"
+            n_chunks = int(os.environ.get("NGP_DDP_CHUNKS", "2" if world > 1 else "1"))
+            if self.exchange_impl == "native":
+                try:
+                    self.exchange = NativeExchange(self.model, dist, world, rank, mode=self.exchange_kind, n_chunks=n_chunks,
+                                                   n_groups=int(os.environ.get("NGP_DDP_GROUPS", n_chunks))).install(self.trainer)
+                except Exception as e:                 # noqa: BLE001 -- RCCL could not be loaded / initialised: say so and use torch's communicator
+                    progress("native exchange unavailable (%s: %s): falling back to torch.distributed collectives" % (type(e).__name__, str(e)[:200]))
+                    self.exchange_impl = "torch.distributed (native exchange failed: %s)" % str(e)[:120]
+                    self.exchange = None
+                    self.trainer.native_exchange = None
+                # all ranks take the same path: one that could not build its communicator takes the others with it
+                agree = torch.tensor([1 if self.exchange is not None else 0], device=dev, dtype=torch.int32)
+                dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+                if int(agree.item()) == 0 and self.exchange is not None:
+                    self.exchange.uninstall(self.trainer); self.exchange.close(); self.exchange = None
+                    self.exchange_impl = "torch.distributed (native exchange failed on another rank)"
+            if self.exchange is None:
+                if self.exchange_kind == "sharded":
+                    self.exchange = ShardedExchange(self.model, dist, world, rank).install(self.trainer)
+                else:
+                    self.exchange = GradientExchange(self.model, dist, world).install(self.trainer)
             self.exchange.broadcast_parameters()
         self.draws = 0
         # three batch buffers in rotation (the batch being stepped, the one being marched, the one being drawn): nothing is
@@ -229,6 +250,23 @@ class Loop:
             dt = float(t.item())
         return dt, e0.elapsed_time(e1) * 1e-3
 
+    def time_exchange(self, n=20):
+        """n more steps with device events around the grid exchange: `exchange_ms` = first grid collective -> table ready for the
+        next forward; `exposed_exchange_ms` (native exchange) = the part of it behind the end of the table backward, i.e. what
+        nothing on the main stream hides."""
+        ex, tr = self.exchange, self.trainer
+        if hasattr(ex, "sample_times"):
+            tr.events = []
+            for _ in range(n):
+                self.steps(1)
+                ex.sample_times()
+            tr.events = None
+            return {"exchange_ms": ex.exchange_ms(), "exposed_exchange_ms": ex.exposed_ms()}
+        ex.timing = True
+        self.steps(n)
+        ex.timing = False
+        return {"exchange_ms": ex.exchange_ms()}
+
     def run(self, setup_steps, warmup, steps, min_timed=MIN_TIMED_STEPS):
         """setup (with the cold-start window inside) -> warm-up -> timed windows.  Returns the result record."""
         tr = self.trainer
@@ -260,10 +298,22 @@ class Loop:
         if host:                       # native stepper only: polling for the march's count (device-bound) vs launches / events / checks
             extra["host_ms_per_step"] = host
         if self.exchange is not None:          # the exchange stage on its own: 20 more steps with device events around it (all ranks alike)
-            self.exchange.timing = True
-            self.steps(20)
-            self.exchange.timing = False
-            extra.update({"exchange_ms": self.exchange.exchange_ms(), "exchange": self.exchange_kind})
+            extra.update({"exchange": self.exchange_kind, "exchange_impl": self.exchange_impl})
+            extra.update(self.time_exchange())
+            if hasattr(self.exchange, "switch_mode") and self.world > 1:
+                # the other mode on the same communicator and buffers ("sharded": reduce-scatter -> Adam on the rank's pieces ->
+                # all-gather; "allreduce": gradient all-reduce only, the reference's semantics literally): both exchange times in the line
+                other = "allreduce" if self.exchange_kind == "sharded" else "sharded"
+                modes = {self.exchange_kind: {k: extra[k] for k in ("exchange_ms", "exposed_exchange_ms") if k in extra}}
+                try:
+                    self.exchange.switch_mode(other)
+                    self.steps(5)
+                    t = self.timed(20)[0]
+                    modes[other] = dict(self.time_exchange(), ms_per_step=t / 20 * 1e3)
+                    self.exchange.switch_mode(self.exchange_kind)
+                except Exception as e:             # noqa: BLE001
+                    modes[other] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+                extra["exchange_modes"] = modes
         return {**extra, "ms_per_step": total / (n_win * steps) * 1e3, "rays_per_s": self.rays * self.world * n_win * steps / total,
                 "timed_windows": n_win, "timed_steps_total": n_win * steps, "window_ms_per_step_min_max": [min(wins) / steps * 1e3, max(wins) / steps * 1e3],
                 "ms_per_step_hip_events": sum(ev) / (n_win * steps) * 1e3, "cold_start": cold, "metrics": met,
@@ -782,12 +832,14 @@ def main():
         "timed_windows": r["timed_windows"], "timed_steps_total": r["timed_steps_total"], "window_ms_per_step_min_max": r["window_ms_per_step_min_max"],
         "ms_per_step_hip_events": r["ms_per_step_hip_events"], "cold_start": r["cold_start"],
     }
-    if "exchange_ms" in r:
-        out["exchange_ms"], out["exchange"] = r["exchange_ms"], r["exchange"]
+    for k in ("exchange", "exchange_impl", "exchange_ms", "exposed_exchange_ms", "exchange_modes"):
+        if k in r:
+            out[k] = r[k]
     if "host_ms_per_step" in r:
         out["host_ms_per_step"] = r["host_ms_per_step"]
     out.update(march_guard_record())
     keeper.headline(out)
+    exchange = loop.exchange
     if dist is not None:      # what follows runs on rank 0 only: no collectives from here on
         loop.exchange.uninstall(loop.trainer)
     if rank == 0 and not args.timed_only:
@@ -857,6 +909,8 @@ def main():
         keeper.finish()
     keeper.phase("leaving" if rank == 0 else "waiting for rank 0's legs", 30.0 if rank == 0 else max(keeper.remaining(), 1.0))
     if dist is not None:
+        if hasattr(exchange, "close"):
+            exchange.close()                   # the library's own RCCL communicator
         dist.barrier()
         dist.destroy_process_group()
     keeper.finish()

@@ -30,6 +30,7 @@ typedef uint16_t ngp_half;    /* IEEE binary16 bits */
 #define NGP_EINVAL   (-1)  /* bad argument (null pointer, size out of range) */
 #define NGP_EUNSUP   (-2)  /* configuration not supported by the native kernels */
 #define NGP_ETIMEOUT (-3)  /* a bounded host wait on a device result ran out (NGP_SPIN_TIMEOUT_S, default 30 s) */
+#define NGP_ECOMM    (-4)  /* an RCCL call failed or RCCL could not be loaded: ngp_comm_last_error() has the text */
 
 #define NGP_MAX_LEVELS 16
 
@@ -534,6 +535,22 @@ int ngp_adam_step_field_shard(float* grid_param, ngp_half* grid_param_h, ngp_hal
                               float weight_decay, int step, float grad_scale,
                               const int32_t* found_inf_mlp, const int32_t* found_inf_shard, int32_t* step_state,
                               ngp_stream_t stream);
+/* The same launch for the CHUNKED exchange of the native data-parallel step (ngp_stepper_tail below): the table gradient is
+ * reduce-scattered in n_chunks chunks of world x piece f16 values (piece a multiple of 8; n_chunks x world x piece >= n_grid, the
+ * buffers are padded to that); this rank owns values [c * world * piece + rank * piece, + piece) of every chunk c.  grid_* address
+ * the WHOLE table (n_grid parameters), shard_grad holds the rank's n_chunks pieces back to back (the reduce-scatters' outputs). */
+int ngp_adam_step_field_pieces(float* grid_param, ngp_half* grid_param_h, const ngp_half* shard_grad,
+                               float* grid_m, float* grid_v, int64_t n_grid, int64_t piece,
+                               int32_t n_chunks, int32_t world, int32_t rank,
+                               float* density_param, ngp_half* density_param_h,
+                               const float* density_partials, float* density_m, float* density_v,
+                               int n_density,
+                               float* rgb_param, ngp_half* rgb_param_h, const float* rgb_partials,
+                               float* rgb_m, float* rgb_v, int n_rgb,
+                               int n_partials, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, int step, float grad_scale,
+                               const int32_t* found_inf_mlp, const int32_t* found_inf_shard, int32_t* step_state,
+                               ngp_stream_t stream);
 /* GradScaler's non-finite check (train.py:274 precision=16 -> torch.amp.GradScaler.unscale_) on a native
  * gradient buffer of n elements (f16, or f32 if grad_is_f32; 16-byte aligned): flag[0] (device i32) |= 1 if any
  * element is inf or NaN; reset != 0 zeroes the flag first.  Used behind the multi-GPU all-reduce, whose f16
@@ -796,6 +813,64 @@ int ngp_stepper_host_times(ngp_stepper* s, double* wait_s, double* enqueue_s, lo
 #define NGP_STEPPER_STAGES 9
 int ngp_stepper_timing(ngp_stepper* s, int enable);
 int ngp_stepper_stage_times(ngp_stepper* s, float* ms);
+
+
+/* ------------------------------------------------------------------------------------------
+ * data-parallel exchange   (reference: Lightning DDPPlugin, train.py:268-272, opt.py:42: one process per GPU, the gradients of
+ * every step averaged over the ranks; here on the native gradient buffers, over RCCL / xGMI)
+ * ------------------------------------------------------------------------------------------
+ * ngp_comm = an RCCL communicator + its own high-priority HIP stream.  RCCL is resolved at run time (dlopen librccl.so.1): the
+ * library does not link against it.  One rank creates the id, the caller carries its 128 bytes to the other ranks (bench.py:
+ * a torch.distributed broadcast), every rank calls ngp_comm_create on ITS device (hipSetDevice first).  The collectives below
+ * enqueue on `stream` (NULL: the communicator's stream); in-place where there is one buffer.  dtype: NGP_COMM_F32 / NGP_COMM_F16. */
+#define NGP_COMM_ID_BYTES 128
+#define NGP_COMM_F32 0
+#define NGP_COMM_F16 1
+typedef struct ngp_comm ngp_comm;
+const char* ngp_comm_last_error(void);
+int ngp_comm_unique_id(void* id_bytes);
+int ngp_comm_create(const void* id_bytes, int world, int rank, ngp_comm** out);
+int ngp_comm_destroy(ngp_comm* c);
+int ngp_comm_info(const ngp_comm* c, int32_t* world, int32_t* rank, int32_t* rccl_version, ngp_stream_t* stream);
+int ngp_comm_all_reduce(ngp_comm* c, void* buf, int64_t count, int dtype, ngp_stream_t stream);
+/* recv (recv_count) = this rank's slice of the sum over ranks of send (world x recv_count) */
+int ngp_comm_reduce_scatter(ngp_comm* c, const void* send, void* recv, int64_t recv_count, int dtype, ngp_stream_t stream);
+/* recv (world x send_count) = the ranks' send buffers in rank order; in place when send == recv + rank x send_count */
+int ngp_comm_all_gather(ngp_comm* c, const void* send, void* recv, int64_t send_count, int dtype, ngp_stream_t stream);
+int ngp_comm_broadcast(ngp_comm* c, void* buf, int64_t n_bytes, int root, ngp_stream_t stream);
+
+/* The tail of a data-parallel step, enqueued natively: with an exchange installed, ngp_stepper_tail replaces
+ * ngp_stepper_table_backward + ngp_stepper_update.  Per step, EVERY rank issues the same sequence (a rank whose batch had no
+ * samples contributes zeros):
+ *   main stream:  MLP partial rows -> sums (`small`)  |  table backward in n_groups launch groups
+ *   comm stream:  all-reduce(small)  |  per chunk c, behind the launch group that completes it: reduce-scatter (mode 1) or
+ *                 all-reduce (mode 0) of chunk c of the gradient  |  non-finite checks on the REDUCED buffers  |  Adam (mode 1: this
+ *                 rank's pieces + the MLP blocks; mode 0: the whole table)  |  mode 1: all-gather of the updated f16 table chunks
+ * The main stream only RECORDS events for the communicator's stream and waits once, at the end of the tail (the next step's
+ * forward and the occupancy update read the updated table).  The gradients were produced at loss scale 128 / world, so their SUM
+ * sits at the single-GPU scale: f16 headroom and underflow floor do not depend on the world size.
+ *   mode 1 ("sharded", default): the optimizer pass is divided by the world size and what is gathered is the table the next
+ *     forward reads; a rank's f32 master / moments are current inside its own pieces only.
+ *   mode 0 ("allreduce"): the reference's semantics literally -- gradient all-reduce only, every rank updates everything.
+ * Buffers are the caller's: grad_padded / table_padded must be the stepper's grid_grad16 / enc_half + n_density, allocated with
+ * n_chunks x world x piece values (padding zero). */
+typedef struct ngp_exchange_config {
+    int32_t mode, n_chunks, n_groups, reserved;
+    int64_t piece;                 /* f16 values per rank and chunk, a multiple of 8 */
+    ngp_half* grad_padded; ngp_half* table_padded;
+    ngp_half* shard16;             /* (n_chunks x piece) reduce-scatter output (mode 1) */
+    float* small;                  /* (n_density + n_rgb) f32 */
+    int32_t* flags;                /* 16 x i32, zeroed once by the caller */
+    int32_t* step_state;           /* 4 x i32 (ngp_adam_step_field), zeroed / set to the steps taken once by the caller */
+} ngp_exchange_config;
+/* comm NULL (config ignored): back to the single-process tail.  The communicator must outlive the stepper or be detached first. */
+int ngp_stepper_set_exchange(ngp_stepper* s, ngp_comm* comm, const ngp_exchange_config* config);
+/* lr, step (1-based call count), grad_scale = the total factor the REDUCED gradients carry (loss_scale x world x grad_scale). */
+int ngp_stepper_tail(ngp_stepper* s, float lr, int32_t step, float grad_scale, ngp_stream_t main_stream);
+/* With stage timing on (ngp_stepper_timing): device time of the last tail's grid exchange, first grid collective -> table gathered
+ * (exchange_ms), and the part of it that ran after the table backward had finished, i.e. that nothing on the main stream hid
+ * (exposed_ms).  Synchronises.  Negative = not recorded. */
+int ngp_stepper_exchange_times(ngp_stepper* s, float* exchange_ms, float* exposed_ms);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,12 @@ class StepBuffersC(C.Structure):
          ("fw_ws", P), ("fw_bytes", C.c_size_t), ("bin_ws", P), ("bin_bytes", C.c_size_t), ("bin_max", C.c_int32)]
 
 
+class ExchangeConfig(C.Structure):
+    """ngp_exchange_config (include/ngp_hip.h)."""
+    _fields_ = [("mode", C.c_int32), ("n_chunks", C.c_int32), ("n_groups", C.c_int32), ("reserved", C.c_int32), ("piece", C.c_int64),
+                ("grad_padded", P), ("table_padded", P), ("shard16", P), ("small", P), ("flags", P), ("step_state", P)]
+
+
 # name -> argtypes (every function returns int, except the two queries noted below)
 _PROTOS = {
     "ngp_ray_aabb_intersect": [P, P, P, P, I, I, I, P, P, P, P],
@@ -104,6 +110,18 @@ _PROTOS = {
     "ngp_adam_step_partials": [P, P, P, I, P, P, I, F, F, F, F, F, I, F, P, P],
     "ngp_adam_step_field": [P, P, P, P, P, L, P, P, P, P, P, I, P, P, P, P, P, I, I, F, F, F, F, F, I, F, I, P, P, P],
     "ngp_adam_step_field_shard": [P, P, P, P, P, L, P, P, P, P, P, I, P, P, P, P, P, I, I, F, F, F, F, F, I, F, P, P, P, P],
+    "ngp_adam_step_field_pieces": [P, P, P, P, P, L, L, I, I, I, P, P, P, P, P, I, P, P, P, P, P, I, I, F, F, F, F, F, I, F, P, P, P, P],
+    "ngp_comm_unique_id": [P],
+    "ngp_comm_create": [P, I, I, C.POINTER(P)],
+    "ngp_comm_destroy": [P],
+    "ngp_comm_info": [P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(P)],
+    "ngp_comm_all_reduce": [P, P, L, I, P],
+    "ngp_comm_reduce_scatter": [P, P, P, L, I, P],
+    "ngp_comm_all_gather": [P, P, P, L, I, P],
+    "ngp_comm_broadcast": [P, P, L, I, P],
+    "ngp_stepper_set_exchange": [P, P, C.POINTER(ExchangeConfig)],
+    "ngp_stepper_tail": [P, F, I, F, P],
+    "ngp_stepper_exchange_times": [P, C.POINTER(C.c_float), C.POINTER(C.c_float)],
     "ngp_reduce_partials": [P, I, I, P, P],
     "ngp_found_inf": [P, I, L, P, I, P],
     "ngp_found_inf2": [P, I, L, P, I, L, P, P, P],
@@ -170,6 +188,8 @@ def lib():
             f.restype = I
         h.ngp_build_arch.argtypes = []
         h.ngp_build_arch.restype = C.c_char_p
+        h.ngp_comm_last_error.argtypes = []
+        h.ngp_comm_last_error.restype = C.c_char_p
         h.ngp_render_test_workspace_bytes.argtypes = [I, I, F]
         h.ngp_render_test_workspace_bytes.restype = C.c_size_t
         h.ngp_hashgrid_bwd_binned_workspace_bytes.argtypes = [C.POINTER(GridMeta), I]
@@ -187,7 +207,7 @@ def lib():
 
 
 def exported_symbols():
-    return list(_PROTOS) + ["ngp_build_arch", "ngp_render_test_workspace_bytes", "ngp_occupancy_update_workspace_bytes",
+    return list(_PROTOS) + ["ngp_build_arch", "ngp_comm_last_error", "ngp_render_test_workspace_bytes", "ngp_occupancy_update_workspace_bytes",
                                   "ngp_hashgrid_bwd_binned_workspace_bytes", "ngp_composite_train_fw_loss_workspace_bytes"]
 
 
@@ -203,6 +223,8 @@ def call(name, *args):
     if rc != 0:
         kind = {-1: "NGP_EINVAL (bad argument)", -2: "NGP_EUNSUP (unsupported configuration)",
                 -3: "NGP_ETIMEOUT (a device result did not arrive within NGP_SPIN_TIMEOUT_S)"}.get(rc, "hipError_t %d" % rc)
+        if rc == -4:
+            kind = "NGP_ECOMM (%s)" % (lib().ngp_comm_last_error() or b"?").decode(errors="replace")
         raise NgpError("%s failed: %s" % (name, kind))
     return 0
 

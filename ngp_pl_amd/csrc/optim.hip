@@ -181,6 +181,54 @@ adam_field_kernel(float* __restrict__ param, h1* __restrict__ param_h, void* __r
     else adam_dense<false>(param, param_h, grad16, m, v, n4, n, hp, blk - a.blocks - b.blocks, (int)gridDim.x - a.blocks - b.blocks);
 }
 
+// The same launch for a data-parallel rank that owns one PIECE of every chunk of the table (csrc/comm.hip, stepper tail): the
+// table is exchanged in n_chunks chunks of world x piece values; this rank updates values [c * chunk + rank * piece, + piece) of
+// every chunk c from the reduce-scatter's output, which holds the rank's pieces back to back.  piece is a multiple of 8 and
+// n_grid of 16, so neither a piece boundary nor the end of the table falls inside a group of 4.
+struct AdamPieces { long long piece, chunk, rank_off, n_grid; int n_chunks; };
+__device__ __forceinline__ void adam_dense_pieces(float* __restrict__ param, h1* __restrict__ param_h, const h1* __restrict__ grad,
+                                                  float* __restrict__ m, float* __restrict__ v, const AdamPieces pc,
+                                                  const AdamHyper& hp, int block, int n_blocks) {
+    const float lr = hp.lr, beta1 = hp.beta1, beta2 = hp.beta2, eps = hp.eps, wd = hp.wd, bc1 = hp.bc1, bc2 = hp.bc2, inv_scale = hp.inv_scale;
+    if (hp.found_inf_dense != nullptr && *hp.found_inf_dense != 0) return;
+    const long long n4 = (long long)pc.n_chunks * pc.piece / 4, stride = (long long)n_blocks * blockDim.x;
+    for (long long q = (long long)block * blockDim.x + threadIdx.x; q < n4; q += stride) {
+        const long long i = q * 4, c = i / pc.piece, base = c * pc.chunk + pc.rank_off + (i - c * pc.piece);
+        if (base >= pc.n_grid) continue;                                   // padding behind the table
+        const half4_t t = *reinterpret_cast<const half4_t*>(grad + i);
+        float4 p = *reinterpret_cast<float4*>(param + base);
+        float4 mm = *reinterpret_cast<float4*>(m + base);
+        float4 vv = *reinterpret_cast<float4*>(v + base);
+        float* pp = &p.x; float* mp = &mm.x; float* vp = &vv.x;
+        half4_t ph;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = (float)t[k] * inv_scale;
+            mp[k] = beta1 * mp[k] + (1.f - beta1) * gk;
+            vp[k] = beta2 * vp[k] + (1.f - beta2) * gk * gk;
+            const float denom = sqrtf(vp[k] / bc2) + eps;
+            pp[k] = pp[k] - lr * ((mp[k] / bc1) / denom + wd * pp[k]);
+            ph[k] = (h1)pp[k];
+        }
+        *reinterpret_cast<float4*>(param + base) = p;
+        *reinterpret_cast<float4*>(m + base) = mm;
+        *reinterpret_cast<float4*>(v + base) = vv;
+        *reinterpret_cast<half4_t*>(param_h + base) = ph;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+adam_field_pieces_kernel(float* __restrict__ param, h1* __restrict__ param_h, const h1* __restrict__ shard16, float* __restrict__ m,
+                         float* __restrict__ v, AdamPieces pc, AdamMlp a, AdamMlp b, int n_partials, AdamHyper hp) {
+    __shared__ float s_acc[8][32];
+    const int blk = blockIdx.x;
+    const bool dense = blk >= a.blocks + b.blocks;
+    adam_bias_from_state(hp, dense, blk == 0 || blk == a.blocks + b.blocks);
+    if (blk < a.blocks) adam_from_partials(a.param, a.param_h, a.partials, n_partials, a.m, a.v, a.n, hp, blk, s_acc);
+    else if (!dense) adam_from_partials(b.param, b.param_h, b.partials, n_partials, b.m, b.v, b.n, hp, blk - a.blocks, s_acc);
+    else adam_dense_pieces(param, param_h, shard16, m, v, pc, hp, blk - a.blocks - b.blocks, (int)gridDim.x - a.blocks - b.blocks);
+}
+
 __global__ void __launch_bounds__(256)
 cast_f32_f16_kernel(const float* __restrict__ in, long long n, h1* __restrict__ out) {
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -493,6 +541,33 @@ int ngp_adam_step_field_shard(float* grid_param, ngp_half* grid_param_h, ngp_hal
                                 beta1, beta2, eps, weight_decay, step, grad_scale, 0, found_inf_mlp, found_inf_shard, step_state, stream);
 }
 
+int ngp_adam_step_field_pieces(float* grid_param, ngp_half* grid_param_h, const ngp_half* shard_grad, float* grid_m, float* grid_v,
+                               int64_t n_grid, int64_t piece, int32_t n_chunks, int32_t world, int32_t rank,
+                               float* density_param, ngp_half* density_param_h, const float* density_partials, float* density_m,
+                               float* density_v, int n_density, float* rgb_param, ngp_half* rgb_param_h, const float* rgb_partials,
+                               float* rgb_m, float* rgb_v, int n_rgb, int n_partials, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, int step, float grad_scale, const int32_t* found_inf_mlp,
+                               const int32_t* found_inf_shard, int32_t* step_state, ngp_stream_t stream) {
+    if (n_grid <= 0 || (n_grid & 15) || piece < 8 || (piece & 7) || n_chunks < 1 || n_chunks > 8 || world < 1 || rank < 0 || rank >= world) return NGP_EINVAL;
+    if ((long long)n_chunks * world * piece < n_grid) return NGP_EINVAL;                   // the chunks must cover the table
+    if (n_density <= 0 || n_rgb <= 0 || n_partials < 0 || step < 1 || grad_scale == 0.f) return NGP_EINVAL;
+    NGP_CHECK_PTR(grid_param); NGP_CHECK_PTR(grid_param_h); NGP_CHECK_PTR(shard_grad); NGP_CHECK_PTR(grid_m); NGP_CHECK_PTR(grid_v);
+    NGP_CHECK_PTR(density_param); NGP_CHECK_PTR(density_m); NGP_CHECK_PTR(density_v);
+    NGP_CHECK_PTR(rgb_param); NGP_CHECK_PTR(rgb_m); NGP_CHECK_PTR(rgb_v);
+    if (n_partials > 0) { NGP_CHECK_PTR(density_partials); NGP_CHECK_PTR(rgb_partials); }
+    AdamHyper hp = adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale, found_inf_mlp);
+    hp.found_inf_dense = found_inf_shard;
+    hp.zero_grad = 0;
+    hp.step_state = step_state; hp.slot = (step - 1) & 1;
+    const AdamPieces pc = {(long long)piece, (long long)world * piece, (long long)rank * piece, (long long)n_grid, n_chunks};
+    const long long n4 = (long long)n_chunks * piece / 4;
+    const int dense_blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    const AdamMlp a = {density_param, (h1*)density_param_h, density_partials, density_m, density_v, n_density, ngp_div_up(n_density, 32)};
+    const AdamMlp b = {rgb_param, (h1*)rgb_param_h, rgb_partials, rgb_m, rgb_v, n_rgb, ngp_div_up(n_rgb, 32)};
+    hipLaunchKernelGGL(adam_field_pieces_kernel, dim3(a.blocks + b.blocks + dense_blocks), dim3(256), 0, ngp_stream(stream), grid_param,
+                       (h1*)grid_param_h, (const h1*)shard_grad, grid_m, grid_v, pc, a, b, n_partials, hp);
+    return NGP_LAUNCH_RESULT();
+}
 
 int ngp_found_inf(const void* grad, int grad_is_f32, int64_t n, int32_t* flag, int reset, ngp_stream_t stream) {
     if (n < 0) return NGP_EINVAL;

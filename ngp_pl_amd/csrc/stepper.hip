@@ -7,6 +7,7 @@
 // sample count of the batch's march, written by the scan kernel into pinned host memory -- polled with a deadline.
 // No device memory is allocated here; all buffers are the caller's (ngp_step_buffers).
 #include "ngp_common.h"
+#include "comm.h"
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
@@ -54,7 +55,18 @@ struct ngp_stepper {
     int set_k[2] = {0, 0};                 // first K the scan of each march record set prepared a compact list for (0: none)
     long long two_round_steps = 0;
     int32_t prev_S = 0;
+    // data-parallel exchange (ngp_stepper_set_exchange): the communicator, the plan, and the events the main stream records for
+    // the communicator's stream (one per hand-over point of a tail; reused every step)
+    ngp_comm* comm = nullptr;
+    ngp_exchange_config x = {};
+    hipEvent_t ev_small = nullptr, ev_chunk[8] = {}, ev_done = nullptr;
+    hipEvent_t ev_x0 = nullptr, ev_x1 = nullptr, ev_m = nullptr;      // timing: first grid collective / table gathered (comm stream), backward done (main)
+    bool x_times_set = false;
+    long long tails = 0;
+    int64_t group_end[16] = {};           // values (2 x entries) the first g + 1 launch groups of the binned backward complete
 };
+
+void destroy_exchange_events(ngp_stepper* s);
 
 namespace {
 
@@ -160,6 +172,12 @@ int do_march(ngp_stepper* s, const float* rays_o, const float* rays_d, hipStream
 
 }  // namespace
 
+void destroy_exchange_events(ngp_stepper* s) {
+    hipEvent_t* all[] = {&s->ev_small, &s->ev_done, &s->ev_x0, &s->ev_x1, &s->ev_m};
+    for (hipEvent_t* e : all) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+    for (int i = 0; i < 8; ++i) if (s->ev_chunk[i]) { (void)hipEventDestroy(s->ev_chunk[i]); s->ev_chunk[i] = nullptr; }
+}
+
 extern "C" {
 #pragma GCC visibility push(default)
 
@@ -203,6 +221,7 @@ int ngp_stepper_destroy(ngp_stepper* s) {
         for (int j = 0; j < 2; ++j) if (s->march_t[k][j]) (void)hipEventDestroy(s->march_t[k][j]);
     }
     for (int i = 0; i < N_MARKS; ++i) if (s->mark[i]) (void)hipEventDestroy(s->mark[i]);
+    destroy_exchange_events(s);
     delete s;
     return 0;
 }
@@ -485,6 +504,153 @@ int ngp_stepper_update(ngp_stepper* s, float lr, int32_t step, float grad_scale,
                                  n_partials, lr, c.beta1, c.beta2, c.eps, c.weight_decay, step, grad_scale, 0, found_inf, step_state, main_stream));
     mark(s, 8, ngp_stream(main_stream));
     STEP_TRY(march_next_if_at(s, AT_ADAM));
+    return 0;
+}
+
+int ngp_stepper_set_exchange(ngp_stepper* s, ngp_comm* comm, const ngp_exchange_config* config) {
+    if (!s) return NGP_EINVAL;
+    if (comm == nullptr) {
+        if (s->comm) (void)hipStreamSynchronize(s->comm->stream);
+        s->comm = nullptr;
+        destroy_exchange_events(s);
+        return 0;
+    }
+    if (!config) return NGP_EINVAL;
+    const ngp_exchange_config& x = *config;
+    const ngp_stepper_config& c = s->c;
+    if ((x.mode != 0 && x.mode != 1) || x.n_chunks < 1 || x.n_chunks > 8 || x.n_groups < 1 || x.n_groups > 16 || x.piece < 8 || (x.piece & 7)) return NGP_EINVAL;
+    if ((int64_t)x.n_chunks * comm->world * x.piece < c.n_grid || (c.n_grid & 15)) return NGP_EINVAL;
+    if (x.grad_padded != c.grid_grad16 || x.table_padded != c.enc_half + c.n_density) return NGP_EINVAL;      // the padded storages must be the stepper's own
+    if (!x.small || !x.flags || !x.step_state || (x.mode == 1 && !x.shard16)) return NGP_EINVAL;
+    if (!c.enc_param || !c.enc_m || !c.enc_v || !c.rgb_param || !c.rgb_m || !c.rgb_v) return NGP_EINVAL;
+    // which chunk may leave behind which launch group: the groups complete contiguous entry ranges in table order
+    for (int g = 0; g < x.n_groups; ++g) {
+        int64_t a = 0, b = 0;
+        STEP_TRY(ngp_hashgrid_bwd_binned_group_entries(&c.meta, 1, x.n_groups, g, &a, &b));
+        s->group_end[g] = 2 * b;
+    }
+    if (s->group_end[x.n_groups - 1] != c.n_grid) return NGP_EINVAL;
+    destroy_exchange_events(s);
+    hipError_t e = hipEventCreateWithFlags(&s->ev_small, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming);
+    for (int i = 0; i < x.n_chunks && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&s->ev_chunk[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreate(&s->ev_x0);
+    if (e == hipSuccess) e = hipEventCreate(&s->ev_x1);
+    if (e == hipSuccess) e = hipEventCreate(&s->ev_m);
+    if (e != hipSuccess) { destroy_exchange_events(s); return (int)e; }
+    s->comm = comm; s->x = x; s->tails = 0; s->x_times_set = false;
+    return 0;
+}
+
+// One chunk of the grid gradient to the communicator's stream: behind `ev` (recorded on the main stream by the caller).
+static int exchange_chunk(ngp_stepper* s, int chunk, hipStream_t cs) {
+    const ngp_exchange_config& x = s->x;
+    const int64_t C = (int64_t)s->comm->world * x.piece;
+    ngp_half* g = x.grad_padded + (size_t)chunk * C;
+    if (x.mode == 1) return ngp_comm_reduce_scatter(s->comm, g, x.shard16 + (size_t)chunk * x.piece, x.piece, NGP_COMM_F16, (ngp_stream_t)cs);
+    return ngp_comm_all_reduce(s->comm, g, C, NGP_COMM_F16, (ngp_stream_t)cs);
+}
+
+int ngp_stepper_tail(ngp_stepper* s, float lr, int32_t step, float grad_scale, ngp_stream_t main_stream) {
+    if (!s || step < 1 || grad_scale == 0.f) return NGP_EINVAL;
+    if (!s->comm) return NGP_EINVAL;                                  // no exchange installed: table_backward() + update()
+    HostTimer host_timer(&s->t_enqueue);
+    const ngp_stepper_config& c = s->c;
+    const ngp_step_buffers& b = s->b;
+    const ngp_exchange_config& x = s->x;
+    ngp_comm* comm = s->comm;
+    hipStream_t main = ngp_stream(main_stream), cs = comm->stream;
+    const int64_t C = (int64_t)comm->world * x.piece, padded = (int64_t)x.n_chunks * C;
+    const int32_t S = s->S;
+    const bool timing = s->timing != 0;
+    s->x_times_set = false;
+    // (1) the MLP blocks: per-workgroup partial rows -> sums, all-reduced underneath the table backward
+    if (S > 0 && s->n_part > 0) {
+        STEP_TRY(ngp_reduce_partials2(b.partials, c.n_density, b.partials + (size_t)s->n_part * c.n_density, c.n_rgb, s->n_part, x.small, main_stream));
+    } else {
+        // this rank's batch had no samples: it joins every collective with zeros (DDP semantics: every rank joins every all-reduce)
+        STEP_HIP(hipMemsetAsync(x.small, 0, sizeof(float) * (size_t)(c.n_density + c.n_rgb), main));
+        STEP_HIP(hipMemsetAsync(x.grad_padded, 0, sizeof(ngp_half) * (size_t)padded, main));
+    }
+    STEP_HIP(hipEventRecord(s->ev_small, main));
+    STEP_HIP(hipStreamWaitEvent(cs, s->ev_small, 0));
+    STEP_TRY(ngp_comm_all_reduce(comm, x.small, c.n_density + c.n_rgb, NGP_COMM_F32, (ngp_stream_t)cs));
+    // (2) table backward in launch groups; a chunk of the gradient leaves behind the group that completes it
+    int next_chunk = 0;
+    auto hand_over = [&](int64_t values_done) -> int {
+        while (next_chunk < x.n_chunks && std::min<int64_t>((int64_t)(next_chunk + 1) * C, c.n_grid) <= values_done) {
+            STEP_HIP(hipEventRecord(s->ev_chunk[next_chunk], main));
+            STEP_HIP(hipStreamWaitEvent(cs, s->ev_chunk[next_chunk], 0));
+            if (next_chunk == 0 && timing) STEP_HIP(hipEventRecord(s->ev_x0, cs));
+            STEP_TRY(exchange_chunk(s, next_chunk, cs));
+            ++next_chunk;
+        }
+        return 0;
+    };
+    if (S > 0) {
+        if (s->binned) {
+            for (int g = 0; g < x.n_groups; ++g) {
+                STEP_TRY(ngp_hashgrid_bwd_binned_group(b.x_act, c.xyz_min, c.xyz_max, b.dfeats, &c.meta, S, nullptr, b.n_active, b.bin_ws, b.bin_bytes,
+                                                       c.grid_grad16, x.n_groups, g, main_stream));
+                if (g + 1 < x.n_groups) STEP_TRY(hand_over(s->group_end[g]));
+            }
+        } else {
+            STEP_TRY(ngp_hashgrid_bwd_sliced(b.xyzs, c.xyz_min, c.xyz_max, b.dfeats, &c.meta, S, b.active, b.n_active, c.grid_grad16, main_stream));
+        }
+    }
+    mark(s, 7, main);
+    if (timing) STEP_HIP(hipEventRecord(s->ev_m, main));
+    STEP_TRY(hand_over(c.n_grid));
+    STEP_TRY(march_next_if_at(s, AT_HASHGRID_BWD));
+    // (3) non-finite checks on the REDUCED buffers (alternating flag sets: each launch clears the other set's flag), then Adam
+    const int k = (int)(s->tails & 1);
+    ++s->tails;
+    int32_t* mlp_cur = x.flags + 8 * k; int32_t* mlp_nxt = x.flags + 8 * (1 - k);
+    int32_t* grid_cur = x.flags + 8 * k + 4; int32_t* grid_nxt = x.flags + 8 * (1 - k) + 4;
+    const int n_small = c.n_density + c.n_rgb;
+    ngp_stream_t cst = (ngp_stream_t)cs;
+    if (x.mode == 1) {
+        STEP_TRY(ngp_found_inf2(x.small, 1, n_small, nullptr, 0, 0, mlp_cur, mlp_nxt, cst));
+        STEP_TRY(ngp_found_inf2(x.shard16, 0, (int64_t)x.n_chunks * x.piece, nullptr, 0, 0, grid_cur, grid_nxt, cst));
+        STEP_TRY(ngp_adam_step_field_pieces(c.enc_param + c.n_density, c.enc_half + c.n_density, x.shard16, c.enc_m + c.n_density, c.enc_v + c.n_density,
+                                            c.n_grid, x.piece, x.n_chunks, comm->world, comm->rank,
+                                            c.enc_param, c.enc_half, x.small, c.enc_m, c.enc_v, c.n_density,
+                                            c.rgb_param, c.rgb_half, x.small + c.n_density, c.rgb_m, c.rgb_v, c.n_rgb,
+                                            1, lr, c.beta1, c.beta2, c.eps, c.weight_decay, step, grad_scale, mlp_cur, grid_cur, x.step_state, cst));
+        // the updated f16 table: every rank's pieces to every rank, in place (one RCCL group: one launch for all chunks)
+        if (x.n_chunks > 1) STEP_TRY(ngp_comm_group_begin());
+        int rc = 0;
+        for (int ch = 0; ch < x.n_chunks && rc == 0; ++ch) {
+            ngp_half* t = x.table_padded + (size_t)ch * C;
+            rc = ngp_comm_all_gather(comm, t + (size_t)comm->rank * x.piece, t, x.piece, NGP_COMM_F16, cst);
+        }
+        if (x.n_chunks > 1) { const int rc2 = ngp_comm_group_end(); if (rc == 0) rc = rc2; }
+        STEP_TRY(rc);
+    } else {
+        // one flag for everything (all ranks hold the same sums): GradScaler's whole-step decision
+        STEP_TRY(ngp_found_inf2(x.grad_padded, 0, padded, x.small, 1, n_small, mlp_cur, mlp_nxt, cst));
+        STEP_TRY(ngp_adam_step_field(c.enc_param + c.n_density, c.enc_half + c.n_density, c.grid_grad16, c.enc_m + c.n_density, c.enc_v + c.n_density, c.n_grid,
+                                     c.enc_param, c.enc_half, x.small, c.enc_m, c.enc_v, c.n_density,
+                                     c.rgb_param, c.rgb_half, x.small + c.n_density, c.rgb_m, c.rgb_v, c.n_rgb,
+                                     1, lr, c.beta1, c.beta2, c.eps, c.weight_decay, step, grad_scale, 0, mlp_cur, x.step_state, cst));
+    }
+    if (timing) { STEP_HIP(hipEventRecord(s->ev_x1, cs)); s->x_times_set = true; }
+    // (4) the one wait of the main stream: the next forward, the occupancy update and the next tail's memsets read / write what
+    //     the communicator's stream has just produced / consumed
+    STEP_HIP(hipEventRecord(s->ev_done, cs));
+    STEP_HIP(hipStreamWaitEvent(main, s->ev_done, 0));
+    mark(s, 8, main);
+    STEP_TRY(march_next_if_at(s, AT_ADAM));
+    return 0;
+}
+
+int ngp_stepper_exchange_times(ngp_stepper* s, float* exchange_ms, float* exposed_ms) {
+    if (!s || !exchange_ms || !exposed_ms) return NGP_EINVAL;
+    *exchange_ms = *exposed_ms = -1.0f;
+    if (!s->comm || !s->x_times_set) return 0;
+    STEP_HIP(hipEventSynchronize(s->ev_x1));
+    STEP_HIP(hipEventElapsedTime(exchange_ms, s->ev_x0, s->ev_x1));
+    STEP_HIP(hipEventElapsedTime(exposed_ms, s->ev_m, s->ev_x1));
     return 0;
 }
 

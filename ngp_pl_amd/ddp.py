@@ -186,7 +186,7 @@ class GradientExchange:
 
 
 class ShardedExchange(GradientExchange):
-    """The exchange that scales: reduce-scatter of the packed-f16 grid gradient -> Adam on THIS rank's 1/world shard of (f32 master,
+    """The exchange that scales: reduce-scatter of the packed-f16 grid gradient -> Adam on THIS rank's 1/world share of (f32 master,
     m, v) -> all-gather of the updated f16 working table.  The same bytes cross each link as with the all-reduce (a ring all-reduce
     IS a reduce-scatter + all-gather: 2 (world - 1) / world x 22.9 MB per rank and step), but the optimizer pass -- 52 us of an
     HBM-bound stream over 11.4 M parameters on one GPU -- is divided by the world size, and what is gathered is the table the next
@@ -194,33 +194,46 @@ class ShardedExchange(GradientExchange):
 
     Semantics preserved from DDP (train.py:268-272): mean gradient over ranks, identical parameters on every rank after every
     step (tests/test_ddp_gloo.py: bit-identical f16 tables on all ranks, equal to the single-process update).  Two deliberate
-    differences: (1) a rank's f32 master / m / v are only current inside its own shard -- `gather_master()` makes the f32 master
-    whole again (checkpoints; `state_dict()` callers); (2) the non-finite check decides per shard (owner's reduced shard) and per MLP
+    differences: (1) a rank's f32 master / m / v are only current inside its own pieces -- `gather_master()` makes the f32 master
+    whole again (checkpoints; `state_dict()` callers); (2) the non-finite check decides per share (owner's reduced pieces) and per MLP
     block (the all-reduced sums every rank holds): every parameter is decided by one flag all its updaters agree on, so the ranks
     stay in lock step without a flag collective; GradScaler would skip the whole step.
 
-    Shards: `shard_len` = ceil(n_grid / world / 8) * 8 f16 values (16-byte multiples); the gradient buffer and the f16 working
-    copy are re-seated on storages padded to world x shard_len (the padding stays zero).  Expected link traffic per step at
-    world = 8: 2 x 7/8 x 22.9 MB = 40 MB per rank over the 7 xGMI links (~5.7 MB per link and direction each way)."""
+    Layout (shared with the native tail, csrc/stepper.hip): the table is exchanged in `n_chunks` CHUNKS of world x `piece` f16 values,
+    `piece` = ceil(n_grid / (n_chunks x world x 8)) x 8 (16-byte multiples); rank r owns values [c x chunk + r x piece, + piece) of
+    every chunk c.  Gradient buffer and f16 working copy are re-seated on storages padded to n_chunks x chunk (the padding stays
+    zero).  With n_chunks > 1 a chunk can be handed to the collective as soon as the table backward has completed it, while the
+    backward of the following levels still runs; n_chunks = 1 is one reduce-scatter over the whole table.  Expected link traffic per
+    step at world = 8: 2 x 7/8 x 22.9 MB = 40 MB per rank over the 7 xGMI links (~5.7 MB per link and direction each way)."""
 
-    def __init__(self, model, dist, world, rank, group=None, adam=None):
+    def __init__(self, model, dist, world, rank, group=None, adam=None, n_chunks=1):
         super().__init__(model, dist, world, group=group, n_groups=1)
         self.rank = rank
         enc = model.xyz_encoder
         self.n_grid = enc.n_grid
-        self.shard_len = -(-self.n_grid // (world * 8)) * 8
-        self.lo = min(rank * self.shard_len, self.n_grid)
-        self.hi = min(self.lo + self.shard_len, self.n_grid)
+        if not 1 <= n_chunks <= 8:
+            raise ValueError("n_chunks must be in 1..8")
+        self.n_chunks = n_chunks
+        self.piece = -(-self.n_grid // (n_chunks * world * 8)) * 8
+        self.chunk = world * self.piece
+        self.padded = n_chunks * self.chunk
+        # this rank's pieces as [lo, hi) ranges of table values, clipped to the table
+        self.pieces = []
+        for c in range(n_chunks):
+            lo = min(c * self.chunk + rank * self.piece, self.n_grid)
+            self.pieces.append((lo, min(lo + self.piece, self.n_grid)))
+        self.shard_len = self.piece                                  # (n_chunks = 1: the rank's shard, as before)
+        self.lo, self.hi = self.pieces[0]
         self._shard16 = None
         self._flag_shard = None
         self._adam = adam if adam is not None else self._adam_kernel        # tests on CPU tensors inject a restatement
 
     # -- storage ---------------------------------------------------------------------------------
     def _seat(self, dev):
-        """Gradient buffer and f16 working copy on storages padded to world x shard_len (once)."""
+        """Gradient buffer and f16 working copy on storages padded to n_chunks x world x piece (once)."""
         m = self.model
         enc = m.xyz_encoder
-        padded = self.world * self.shard_len
+        padded = self.padded
         if getattr(self, "_g_big", None) is None or self._g_big.device != dev:
             self._g_big = torch.zeros(padded, dtype=torch.float16, device=dev)
             m._g16 = self._g_big[:self.n_grid]
@@ -231,7 +244,7 @@ class ShardedExchange(GradientExchange):
                 enc._half.t = self._h_big[:enc.n_mlp + self.n_grid]
                 enc._half.mark_fresh(enc.params)
         if self._shard16 is None or self._shard16.device != dev:
-            self._shard16 = torch.zeros(self.shard_len, dtype=torch.float16, device=dev)
+            self._shard16 = torch.zeros(self.n_chunks * self.piece, dtype=torch.float16, device=dev)
 
     def install(self, trainer):
         super().install(trainer)
@@ -246,7 +259,7 @@ class ShardedExchange(GradientExchange):
 
     def uninstall(self, trainer):
         """Back to whole-table updates: every rank gets the whole f32 master AND the whole Adam moments (a rank's m / v are only
-        current inside its own shard; whole-table Adam afterwards would otherwise resume with stale moments everywhere else)."""
+        current inside its own pieces; whole-table Adam afterwards would otherwise resume with stale moments everywhere else)."""
         super().uninstall(trainer)
         trainer.update_hook = None
         self.gather_master()
@@ -256,7 +269,7 @@ class ShardedExchange(GradientExchange):
                 self._gather_shards(t)
 
     def broadcast_parameters(self):
-        """DDP's constructor broadcast.  In sharded mode a rank's f32 master is only current inside its own shard, and the f16
+        """DDP's constructor broadcast.  In sharded mode a rank's f32 master is only current inside its own pieces, and the f16
         working copies are re-cast from the master afterwards: make the master whole first."""
         if getattr(self, "_stepped", False):
             self.gather_master()
@@ -276,7 +289,9 @@ class ShardedExchange(GradientExchange):
         self._t_begin(g16)
         if g16.data_ptr() != self._g_big.data_ptr():
             self._g_big[:self.n_grid].copy_(g16)          # a producer that did not write into the seated buffer (zero_native)
-        self.dist.reduce_scatter_tensor(self._shard16, self._g_big, group=self.group)
+        P, C = self.piece, self.chunk
+        for c in range(self.n_chunks):
+            self.dist.reduce_scatter_tensor(self._shard16[c * P:(c + 1) * P], self._g_big[c * C:(c + 1) * C], group=self.group)
         self._work.wait(); self._work = None
         small = self._small
         nat["density_partials"], nat["rgb_partials"], nat["n_partials"] = small[:enc.n_mlp], small[enc.n_mlp:], 1
@@ -299,7 +314,7 @@ class ShardedExchange(GradientExchange):
         return (one if bad_mlp else None), (one if bad_sh else None)
 
     def update(self, lr, step, grad_scale, found_inf, stream_handle=None):
-        """Adam on this rank's shard + the MLP blocks, then the all-gather of the f16 table (Trainer calls this instead of the
+        """Adam on this rank's pieces + the MLP blocks, then the all-gather of the f16 table (Trainer calls this instead of the
         whole-table update).  grad_scale: the factor the reduced gradients carry."""
         nat = self.model._native
         flag_mlp, flag_shard = found_inf if found_inf is not None else (None, None)
@@ -307,7 +322,10 @@ class ShardedExchange(GradientExchange):
         self._stepped = True
         enc = self.model.xyz_encoder
         table = self._h_big[enc.n_mlp:]
-        self.dist.all_gather_into_tensor(table, table[self.rank * self.shard_len:(self.rank + 1) * self.shard_len], group=self.group)
+        P, C = self.piece, self.chunk
+        for c in range(self.n_chunks):
+            t = table[c * C:(c + 1) * C]
+            self.dist.all_gather_into_tensor(t, t[self.rank * P:(self.rank + 1) * P], group=self.group)
         self._t_end(table)
         self.model._native = None
 
@@ -318,26 +336,169 @@ class ShardedExchange(GradientExchange):
         enc, net = m.xyz_encoder, m.rgb_net
         (em, ev), (rm, rv) = tr.opt.moments("enc"), tr.opt.moments("rgb")
         b1, b2 = tr.opt.betas
-        ne, lo, n = enc.n_mlp, self.lo, self.hi - self.lo
+        ne = enc.n_mlp
         p_enc, p_half, p_m, p_v = enc.params.data_ptr(), self._h_big.data_ptr(), em.data_ptr(), ev.data_ptr()
         sq = stream_handle if stream_handle is not None else stream()
-        # (a rank whose shard is empty -- rank * shard_len >= n_grid: small tables, large worlds -- passes n = 0: the MLP blocks only)
-        call("ngp_adam_step_field_shard", p_enc + 4 * (ne + lo), p_half + 2 * (ne + lo), ptr(self._shard16), p_m + 4 * (ne + lo), p_v + 4 * (ne + lo), n,
-             p_enc, p_half, ptr(nat["density_partials"]), p_m, p_v, ne,
-             net.params.data_ptr(), net._half.t.data_ptr(), ptr(nat["rgb_partials"]), rm.data_ptr(), rv.data_ptr(), net.params.numel(),
-             nat["n_partials"], lr, b1, b2, tr.opt.eps, tr.opt.weight_decay, step, grad_scale, ptr(flag_mlp), ptr(flag_shard),
-             tr.opt.step_state(flag_mlp), sq)
+        mlp = (p_enc, p_half, ptr(nat["density_partials"]), p_m, p_v, ne,
+               net.params.data_ptr(), net._half.t.data_ptr(), ptr(nat["rgb_partials"]), rm.data_ptr(), rv.data_ptr(), net.params.numel(),
+               nat["n_partials"], lr, b1, b2, tr.opt.eps, tr.opt.weight_decay, step, grad_scale, ptr(flag_mlp), ptr(flag_shard),
+               tr.opt.step_state(flag_mlp), sq)
+        if self.n_chunks == 1:
+            lo, n = self.lo, self.hi - self.lo
+            # (a rank whose shard is empty -- rank * shard_len >= n_grid: small tables, large worlds -- passes n = 0: the MLP blocks only)
+            call("ngp_adam_step_field_shard", p_enc + 4 * (ne + lo), p_half + 2 * (ne + lo), ptr(self._shard16), p_m + 4 * (ne + lo), p_v + 4 * (ne + lo), n, *mlp)
+        else:
+            call("ngp_adam_step_field_pieces", p_enc + 4 * ne, p_half + 2 * ne, ptr(self._shard16), p_m + 4 * ne, p_v + 4 * ne, self.n_grid,
+                 self.piece, self.n_chunks, self.world, self.rank, *mlp)
         enc._half.mark_fresh(enc.params); net._half.mark_fresh(net.params)
 
     def gather_master(self):
-        """All ranks' f32 master shards -> every rank's `xyz_encoder.params` (checkpointing / leaving the sharded mode)."""
+        """All ranks' f32 master pieces -> every rank's `xyz_encoder.params` (checkpointing / leaving the sharded mode)."""
         self._gather_shards(self.model.xyz_encoder.params.data)
 
     def _gather_shards(self, p):
-        """p = [density MLP (n_mlp) | grid (n_grid)] f32 whose grid part is current per shard: all-gather the shards in place."""
+        """p = [density MLP (n_mlp) | grid (n_grid)] f32 whose grid part is current per piece: all-gather the pieces in place."""
         enc = self.model.xyz_encoder
-        padded = self.world * self.shard_len
-        buf = torch.zeros(padded, dtype=p.dtype, device=p.device)
-        buf[self.lo:self.hi] = p[enc.n_mlp + self.lo:enc.n_mlp + self.hi]
-        self.dist.all_gather_into_tensor(buf, buf[self.rank * self.shard_len:(self.rank + 1) * self.shard_len].clone(), group=self.group)
+        buf = torch.zeros(self.padded, dtype=p.dtype, device=p.device)
+        buf[:self.n_grid] = p[enc.n_mlp:]
+        P, C = self.piece, self.chunk
+        for c in range(self.n_chunks):
+            t = buf[c * C:(c + 1) * C]
+            self.dist.all_gather_into_tensor(t, t[self.rank * P:(self.rank + 1) * P].clone(), group=self.group)
         p[enc.n_mlp:] = buf[:self.n_grid]
+
+
+class NativeExchange(ShardedExchange):
+    """The same exchange ENQUEUED BY THE LIBRARY (csrc/comm.hip + `ngp_stepper_tail` in csrc/stepper.hip): its own RCCL communicator
+    and stream, no Python and no torch.distributed between the field backward and the gathered table.  Per step the trainer makes
+    ONE call (`ngp_stepper_tail`) behind `ngp_stepper_front`; the main stream records events for the communicator's stream and
+    waits once.  `mode`: "sharded" (reduce-scatter -> Adam on the rank's pieces -> all-gather of the f16 table) or "allreduce" (the
+    reference's semantics literally: gradient all-reduce only, whole-table Adam on every rank).  `n_chunks` pieces of the grid
+    exchange, handed over behind the `n_groups` launch groups of the table backward that complete them.
+
+    torch.distributed (`dist`) is used for what happens once: carrying the communicator id to the ranks, DDP's constructor broadcast
+    of the parameters, and making master / moments whole again when the exchange is taken off."""
+
+    def __init__(self, model, dist, world, rank, mode="sharded", n_chunks=1, n_groups=None, group=None):
+        super().__init__(model, dist, world, rank, group=group, n_chunks=n_chunks)
+        if mode not in ("sharded", "allreduce"):
+            raise ValueError("mode must be 'sharded' or 'allreduce'")
+        self.mode = mode
+        self.n_groups = n_chunks if n_groups is None else n_groups
+        self.comm = None
+        self._cfg = None
+        self._handle = None
+        self._samples = []
+
+    def _make_comm(self, dev):
+        import ctypes as C
+        from ._lib import call
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            buf = (C.c_ubyte * 128)()
+            call("ngp_comm_unique_id", C.cast(buf, C.c_void_p))
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        if self.world > 1:
+            carrier = ident.to(dev) if self.dist.get_backend(self.group) == "nccl" else ident
+            self.dist.broadcast(carrier, 0, group=self.group)
+            ident = carrier.cpu()
+        raw = (C.c_ubyte * 128)(*ident.tolist())
+        h = C.c_void_p()
+        with torch.cuda.device(dev):
+            call("ngp_comm_create", C.cast(raw, C.c_void_p), self.world, self.rank, C.byref(h))
+        self.comm = h
+
+    def install(self, trainer):
+        from . import _lib
+        dev = self.model.xyz_encoder.params.device
+        if dev.type != "cuda":
+            raise RuntimeError("NativeExchange needs the model on a GPU (the gloo tests drive ShardedExchange, its host-side mirror)")
+        trainer.loss_scale = self.loss_scale
+        trainer.mlp_grad_hook = trainer.grad_hook = trainer.group_hook = trainer.update_hook = None
+        trainer.bwd_groups = 1
+        trainer.native_exchange = self
+        self._trainer = trainer
+        self._seat(dev)
+        enc, net = self.model.xyz_encoder, self.model.rgb_net
+        self._small = torch.zeros(enc.n_mlp + net.params.numel(), dtype=torch.float32, device=dev)
+        self._flag = torch.zeros(16, dtype=torch.int32, device=dev)
+        state = trainer.opt.ensure_step_state()
+        if self.comm is None:
+            self._make_comm(dev)
+        c = _lib.ExchangeConfig()
+        c.mode, c.n_chunks, c.n_groups, c.piece = (1 if self.mode == "sharded" else 0), self.n_chunks, self.n_groups, self.piece
+        c.grad_padded, c.table_padded = self._g_big.data_ptr(), self._h_big.data_ptr() + 2 * enc.n_mlp
+        c.shard16, c.small, c.flags, c.step_state = self._shard16.data_ptr(), self._small.data_ptr(), self._flag.data_ptr(), state.data_ptr()
+        self._cfg = c
+        if getattr(trainer, "_stepper", None) is not None:
+            trainer._destroy_stepper()          # it holds the old gradient / working-copy pointers; the next step rebuilds and attaches
+        return self
+
+    def attach(self, handle):
+        """Called by the trainer right after it (re)built its native stepper."""
+        import ctypes as C
+        from ._lib import call
+        call("ngp_stepper_set_exchange", handle, self.comm, C.byref(self._cfg))
+        self._handle = handle
+
+    def _make_whole(self, trainer):
+        """Sharded mode leaves master / moments current per piece only: gather them (torch.distributed; the device is idle first)."""
+        torch.cuda.synchronize()
+        if self.mode == "sharded" and getattr(self, "_stepped", False):
+            self.gather_master()
+            for t in trainer.opt.moments("enc"):
+                self._gather_shards(t)
+            torch.cuda.synchronize()
+            self._stepped = False
+
+    def switch_mode(self, mode):
+        """sharded <-> allreduce on the same communicator and buffers (bench.py measures both)."""
+        import ctypes as C
+        from ._lib import call
+        if mode == self.mode:
+            return
+        self._make_whole(self._trainer)
+        self.mode = mode
+        self._cfg.mode = 1 if mode == "sharded" else 0
+        if self._handle is not None:
+            call("ngp_stepper_set_exchange", self._handle, self.comm, C.byref(self._cfg))
+
+    def uninstall(self, trainer):
+        from ._lib import call
+        self._make_whole(trainer)
+        if getattr(trainer, "_stepper", None) is not None and self._handle is not None:
+            call("ngp_stepper_set_exchange", trainer._stepper, None, None)
+        self._handle = None
+        trainer.native_exchange = None
+        trainer.loss_scale = tcnn.LOSS_SCALE
+
+    def close(self):
+        from . import _lib
+        if self.comm is not None:
+            _lib.lib().ngp_comm_destroy(self.comm)
+            self.comm = None
+
+    def stepped(self):
+        self._stepped = True
+
+    # -- timing --------------------------------------------------------------------------------
+    def sample_times(self):
+        """(exchange_ms, exposed_ms) of the last step's tail, recorded while the trainer's stage timing is on (syncs)."""
+        import ctypes as C
+        from ._lib import call
+        if self._handle is None:
+            return
+        a, b = C.c_float(), C.c_float()
+        call("ngp_stepper_exchange_times", self._handle, C.byref(a), C.byref(b))
+        if a.value >= 0:
+            self._samples.append((a.value, b.value))
+
+    def exchange_ms(self):
+        if not self._samples:
+            return None
+        s, self._samples = self._samples, []
+        self._last_exposed = sum(x[1] for x in s) / len(s)
+        return sum(x[0] for x in s) / len(s)
+
+    def exposed_ms(self):
+        return getattr(self, "_last_exposed", None)

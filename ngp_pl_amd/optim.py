@@ -109,10 +109,14 @@ class FusedAdam(torch.optim.Optimizer):
         handed to this optimizer: without a flag every call applies, and the host count `t` IS the bias-correction step."""
         if found_inf is None and self._step_state is None:
             return None
+        return self.ensure_step_state(self.t - 1).data_ptr()                   # (called inside a step: t counts this call already)
+
+    def ensure_step_state(self, applied=None):
+        """The device-side applied-step counts (4 x i32), created on first use holding `applied` (default: the calls so far)."""
         if self._step_state is None:
             dev = self._roles["enc"].device
-            self._step_state = torch.full((4,), self.t - 1, dtype=torch.int32, device=dev)      # steps applied before this call
-        return self._step_state.data_ptr()
+            self._step_state = torch.full((4,), self.t if applied is None else applied, dtype=torch.int32, device=dev)
+        return self._step_state
 
     def applied_steps(self):
         """Steps actually applied to (MLP blocks, grid block) -- equal to `t` unless a skip flag was raised (syncs)."""

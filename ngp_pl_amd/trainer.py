@@ -99,6 +99,7 @@ class Trainer:
         self.group_hook = None     # called behind each launch group of the table backward: (group, n_groups, entry_begin, entry_end)
         self.bwd_groups = 1        # launch groups of the table backward when a group_hook is installed
         self.update_hook = None    # replaces the whole-table Adam: (lr, step, grad_scale, found_inf, stream) -- ddp.ShardedExchange
+        self.native_exchange = None  # ddp.NativeExchange: the step's tail (exchange + update) is ONE library call, ngp_stepper_tail
         self._group_cache = {}
         self._main = None        # torch's current stream while a step is being enqueued (cached: the query costs ~8 us)
         self.events = None       # list of (stage, event) when stage timing is on (bench.py roofline)
@@ -220,6 +221,8 @@ class Trainer:
         self._stepper, self._stepper_key = h, key
         self._pending_key = self._pending_keep = None
         self._timing_on = False
+        if self.native_exchange is not None:
+            self.native_exchange.attach(h)
         return h
 
     def _destroy_stepper(self):
@@ -286,7 +289,17 @@ class Trainer:
             # there): the tail runs through Python; otherwise table backward + Adam are two more library calls
             custom_opt = "step" in vars(self.opt) and not getattr(self.opt.step, "_wrapped_by_lr_sched", False)     # (an LR scheduler wraps step(): still ours)
             hooks = self.grad_hook is not None or self.mlp_grad_hook is not None or custom_opt
-            if S > 0:
+            if self.native_exchange is not None:
+                # data parallel, enqueued by the library: MLP all-reduce, table backward in launch groups with the chunks of the
+                # gradient handed to the communicator's stream behind them, non-finite checks, Adam, all-gather -- one call,
+                # whether or not THIS rank's batch had samples (it joins every collective with zeros)
+                epoch = self.global_step // self.steps_per_epoch
+                lr = self.opt.param_groups[0]["lr"] = cosine_lr(self.base_lr, epoch, self.num_epochs)
+                self.opt.t += 1
+                call("ngp_stepper_tail", h, lr, self.opt.t, self.loss_scale * self.native_exchange.world * self.grad_scale, mq)
+                self.native_exchange.stepped()
+                enc._half.mark_fresh(enc.params); net._half.mark_fresh(net.params)
+            elif S > 0:
                 epoch = self.global_step // self.steps_per_epoch
                 lr = self.opt.param_groups[0]["lr"] = cosine_lr(self.base_lr, epoch, self.num_epochs)
                 if not hooks:

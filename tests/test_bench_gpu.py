@@ -74,5 +74,5 @@ def test_bench_under_a_one_rank_rccl_group(exchange):
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert "error" not in d, d.get("error")
-    assert d["n_gpus"] == 1 and d["exchange"] == exchange and d["exchange_ms"] > 0 and d["value"] > 1e6
+    assert d["n_gpus"] == 1 and d["exchange"] == exchange and d["exchange_ms"] > 0 and d["value"] > 1e6 and d["exchange_impl"] == "native"
     assert d["config"]["train_psnr"] > 10 and d["march_guards"] == [0, 0, 0, 0]

@@ -254,7 +254,7 @@ class _Opt:
         self.param_groups, self.t, self.betas, self.eps, self.weight_decay = [{"lr": 0.0}], 0, (0.9, 0.999), 1e-15, 0.0
 
 
-def _sharded_worker(rank, world, port, q):
+def _sharded_worker(rank, world, port, q, n_chunks=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
@@ -282,13 +282,13 @@ def _sharded_worker(rank, world, port, q):
 
     def adam_cpu(lr, step, grad_scale, nat, flag_mlp, flag_shard, stream_handle, ex=None):
         ex = exchange
-        lo, hi = ex.lo, ex.hi
         em, ev = state["enc"]
         p = model.xyz_encoder.params
-        if flag_shard is None and hi > lo:
-            g = ex._shard16[:hi - lo].float() / grad_scale
-            _adam_reference(p[n_d + lo:n_d + hi], em[n_d + lo:n_d + hi], ev[n_d + lo:n_d + hi], g, lr, 0.9, 0.999, 1e-15, step)
-            ex._h_big[n_d + lo:n_d + hi] = p[n_d + lo:n_d + hi].half()
+        for c, (lo, hi) in enumerate(ex.pieces):            # this rank's piece of every chunk; the reduce-scatters' outputs sit back to back
+            if flag_shard is None and hi > lo:
+                g = ex._shard16[c * ex.piece:c * ex.piece + hi - lo].float() / grad_scale
+                _adam_reference(p[n_d + lo:n_d + hi], em[n_d + lo:n_d + hi], ev[n_d + lo:n_d + hi], g, lr, 0.9, 0.999, 1e-15, step)
+                ex._h_big[n_d + lo:n_d + hi] = p[n_d + lo:n_d + hi].half()
         if flag_mlp is None:
             _adam_reference(p[:n_d], em[:n_d], ev[:n_d], nat["density_partials"].view(nat["n_partials"], -1).sum(0) / grad_scale, lr, 0.9, 0.999, 1e-15, step)
             ex._h_big[:n_d] = p[:n_d].half()
@@ -296,9 +296,11 @@ def _sharded_worker(rank, world, port, q):
             _adam_reference(model.rgb_net.params, rm, rv, nat["rgb_partials"].view(nat["n_partials"], -1).sum(0) / grad_scale, lr, 0.9, 0.999, 1e-15, step)
             rgb_half.copy_(model.rgb_net.params.half())
 
-    exchange = ShardedExchange(model, dist, world, rank, adam=adam_cpu).install(tr)
-    ok = tr.loss_scale == 128.0 / world and tr.update_hook is not None and exchange.shard_len % 8 == 0
-    ok &= exchange.shard_len * world >= n_grid > exchange.shard_len * (world - 1)
+    exchange = ShardedExchange(model, dist, world, rank, adam=adam_cpu, n_chunks=n_chunks).install(tr)
+    ok = tr.loss_scale == 128.0 / world and tr.update_hook is not None and exchange.piece % 8 == 0
+    ok &= exchange.padded >= n_grid > exchange.padded - exchange.chunk and len(exchange.pieces) == n_chunks
+    if n_chunks == 1:
+        ok &= exchange.shard_len * world >= n_grid > exchange.shard_len * (world - 1)
     exchange._h_big[:n_d + n_grid] = master0.half()
     # three steps of per-rank gradients; values are multiples of 1/64 below 4 in magnitude, so that f16 sums over <= 8 ranks are exact (below 32 in magnitude: f16 spacing 1/64)
     # whatever the order of the ring's adds, and the expected update can be formed from the f32 sum
@@ -359,12 +361,15 @@ def _sharded_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3, 4, 8])
-def test_sharded_exchange_matches_the_single_process_update(world):
+@pytest.mark.parametrize("world,n_chunks", [(2, 1), (3, 1), (4, 1), (8, 1), (3, 2), (8, 4)])
+def test_sharded_exchange_matches_the_single_process_update(world, n_chunks):
+    """n_chunks > 1 is the layout of the OVERLAPPED schedule (a chunk of the gradient leaves as soon as the table backward has
+    completed it; rank r owns one piece of every chunk): every configuration must reproduce the single-process Adam update bit for
+    bit -- hence the chunked schedule at world 8 is bit-identical to the serial one."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q, n_chunks)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=240) for _ in range(world))

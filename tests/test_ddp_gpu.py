@@ -191,3 +191,126 @@ def test_sharded_exchange_trains_like_the_allreduce_exchange_on_one_gpu():
     for p in procs:
         p.join(120)
     assert [(r, ok) for r, ok, _ in res] == [(0, True), (1, True)], res
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the exchange enqueued by the library (csrc/comm.hip + ngp_stepper_tail) on a real RCCL communicator of ONE rank
+# ---------------------------------------------------------------------------------------------------------------------------
+def _native_worker(port, q):
+    """Four runs of 20 steps from the same initialisation on the same batches (two occupancy updates, one batch that misses the box):
+      A  ddp.ShardedExchange    -- torch.distributed collectives issued from Python (the host-side mirror the gloo tests drive)
+      B  ddp.NativeExchange     sharded, one chunk
+      C  ddp.NativeExchange     sharded, two chunks behind two launch groups of the table backward
+      D  ddp.NativeExchange     allreduce (gradient all-reduce only, whole-table Adam)
+    At world 1 every collective is the identity, so all four must leave the SAME parameters bit for bit: same kernels for the MLP
+    sums, exact fixed-point table sums whatever the launch groups, the same Adam arithmetic whether it walks a shard, pieces or the
+    whole table, the same device-side bias-correction count."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        import numpy as np
+        from ngp_pl_amd import synthetic as syn
+        from ngp_pl_amd.ddp import NativeExchange, ShardedExchange
+        from ngp_pl_amd.networks import NGP
+        from ngp_pl_amd.trainer import Trainer
+
+        def batch(n, seed):
+            g = np.random.RandomState(seed)
+            W = 200
+            dirs = syn.get_ray_directions(W, W, syn.intrinsics(W))
+            poses = syn.hemisphere_poses(16, seed=1)
+            ro, rd = syn.get_rays(dirs[torch.from_numpy(g.randint(0, W * W, n))], poses[torch.from_numpy(g.randint(0, 16, n))])
+            ro, rd = ro.cuda().contiguous(), rd.cuda().contiguous()
+            gt, _ = syn.render_ground_truth(ro, rd, n_steps=96)
+            return ro, rd, gt.contiguous()
+        batches = [batch(2048, seed=3000 + s) for s in range(20)]
+        batches[7] = (batches[7][0] + 10.0, batches[7][1].abs() + 0.1, batches[7][2])          # no samples: joins the collectives with zeros
+
+        def run(kind):
+            torch.manual_seed(9)
+            m = NGP(scale=0.5).cuda()
+            m.register_training_buffers()
+            tr = Trainer(m)
+            if kind == "A":
+                ex = ShardedExchange(m, dist, 1, 0)
+            else:
+                ex = NativeExchange(m, dist, 1, 0, mode="allreduce" if kind == "D" else "sharded", n_chunks=2 if kind == "C" else 1,
+                                    n_groups=2 if kind == "C" else 1)
+            ex.install(tr)
+            ex.broadcast_parameters()
+            log = []
+            for s in range(20):
+                nb = batches[s + 1] if s + 1 < 20 else None
+                out = tr.step(*batches[s], next_batch=None if nb is None else (nb[0], nb[1]))
+                log.append((out["rm_samples"], tr.last["stats"].tolist() if out["rm_samples"] > 0 else None))
+            torch.cuda.synchronize()
+            enc = m.xyz_encoder
+            snap = dict(half=enc._half.get(enc.params).clone().cpu(), master=enc.params.detach().cpu().clone(), rgb=m.rgb_net.params.detach().cpu().clone(),
+                        log=log, applied=tr.opt.applied_steps(), m=[t.cpu().clone() for t in tr.opt.moments("enc")], times=None)
+            if kind == "C":                                  # one more step with the stage timing on: the exchange's device times
+                tr.events = []
+                tr.step(*batches[0]); ex.sample_times()
+                tr.events = None
+                snap["times"] = (ex.exchange_ms(), ex.exposed_ms())
+            ex.uninstall(tr)
+            if hasattr(ex, "close"):
+                ex.close()
+            return snap
+        res = {k: run(k) for k in "ABCD"}
+        ok, notes = True, []
+        a = res["A"]
+        ok &= a["log"][7][0] == 0 and a["log"][8][0] > 0
+        for k in "BCD":
+            r = res[k]
+            same_log = r["log"] == a["log"]
+            same = all(torch.equal(r[key], a[key]) for key in ("half", "master", "rgb")) and all(torch.equal(x, y) for x, y in zip(r["m"], a["m"]))
+            ok &= same_log and same
+            notes.append("%s vs A: losses identical %s, parameters + moments identical %s, applied steps %s" % (k, same_log, same, r["applied"]))
+        t = res["C"]["times"]
+        ok &= t is not None and t[0] is not None and t[0] > 0 and t[1] is not None
+        notes.append("C exchange_ms %.4f exposed %.4f" % (t[0] or -1, t[1] or -1))
+        ok &= res["B"]["applied"] == (20, 20)
+        q.put((bool(ok), notes))
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((False, [traceback.format_exc()[-3000:]]))
+        raise
+
+
+def test_native_exchange_equals_the_torch_distributed_exchange_on_one_rank():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_native_worker, args=(port, q))
+    p.start()
+    ok, notes = q.get(timeout=600)
+    p.join(120)
+    assert ok, notes
+
+
+def test_communicator_collectives_on_one_rank():
+    """ngp_comm_* straight through the C ABI: create from a unique id, the four collectives at world 1 (identity / copy), destroy."""
+    import ctypes as C
+    from ngp_pl_amd._lib import call, ptr
+    torch.cuda.set_device(0)
+    buf = (C.c_ubyte * 128)()
+    call("ngp_comm_unique_id", C.cast(buf, C.c_void_p))
+    h = C.c_void_p()
+    call("ngp_comm_create", C.cast(buf, C.c_void_p), 1, 0, C.byref(h))
+    w, r, v, st = C.c_int32(), C.c_int32(), C.c_int32(), C.c_void_p()
+    call("ngp_comm_info", h, C.byref(w), C.byref(r), C.byref(v), C.byref(st))
+    assert (w.value, r.value) == (1, 0) and v.value >= 20000 and st.value
+    x = torch.randn(4096, device="cuda"); x0 = x.clone()
+    call("ngp_comm_all_reduce", h, ptr(x), x.numel(), 0, None)
+    g = torch.randn(1024, device="cuda").half(); out = torch.zeros_like(g)
+    call("ngp_comm_reduce_scatter", h, ptr(g), ptr(out), out.numel(), 1, None)
+    t = torch.randn(2048, device="cuda").half(); t0 = t.clone()
+    call("ngp_comm_all_gather", h, ptr(t), ptr(t), t.numel(), 1, None)
+    b = torch.arange(100, device="cuda", dtype=torch.uint8); b0 = b.clone()
+    call("ngp_comm_broadcast", h, ptr(b), b.numel(), 0, None)
+    torch.cuda.synchronize()
+    assert torch.equal(x, x0) and torch.equal(out, g) and torch.equal(t, t0) and torch.equal(b, b0)
+    from ngp_pl_amd import _lib
+    _lib.lib().ngp_comm_destroy(h)
