@@ -245,6 +245,25 @@ int ngp_composite_train_bw(const float* dL_dopacity, const float* dL_ddepth, con
                            const float* xyzs, float* x_active /* both optional, with active_idx: also copy the
                            listed samples' positions (S,3) to x_active in list order (= ngp_gather_xyz) */,
                            ngp_stream_t stream);
+/* The same pair WITHOUT the one-workgroup scan kernel between them (the native step's default): the forward leaves the per-row
+ * COUNTS of live samples in ray_counts (R) i32 (16-byte aligned) and the per-row loss terms in the workspace; the backward's
+ * workgroups prefix the counts themselves (integer sums: exactly the offsets ngp_composite_train_fw_loss would have written), its
+ * last workgroup writes n_active (+ n_active_host, pinned host memory, may be NULL), its first adds the loss terms in a fixed
+ * order into loss / sq_err.  n_samples must be > 0 (a batch without samples has no backward: use ngp_composite_train_fw_loss). */
+int ngp_composite_train_fw_loss_counts(const float* sigmas, const float* rgbs, const float* deltas, const float* ts,
+                                       const int64_t* rays_a, float T_threshold, int n_rays, int n_samples,
+                                       int64_t* total_samples, float* opacity, float* depth, float* rgb, float* ws,
+                                       int32_t* ray_counts, const float* gt_rgb, const float* bg,
+                                       float lambda_opacity, float grad_scale, float* dL_drgb,
+                                       float* dL_dopacity, void* workspace, size_t workspace_bytes, ngp_stream_t stream);
+int ngp_composite_train_bw_tail(const float* dL_dopacity, const float* dL_ddepth, const float* dL_drgb,
+                                const float* dL_dws, const float* sigmas, const float* rgbs, const float* ws,
+                                const float* deltas, const float* ts, const int64_t* rays_a,
+                                const float* opacity, const float* depth, const float* rgb, float T_threshold,
+                                int n_rays, int n_samples, float* dL_dsigmas, float* dL_drgbs,
+                                const int32_t* ray_counts, int32_t* active_idx, const float* xyzs, float* x_active,
+                                int32_t* n_active, int32_t* n_active_host, float* loss, float* sq_err,
+                                const void* workspace, size_t workspace_bytes, ngp_stream_t stream);
 
 /* vren.composite_test_fw (binding.cpp:166-194, volumerendering.cu:205-285).
  * sigmas,deltas,ts (N_alive,N_samples); rgbs (N_alive,N_samples,3); alive_indices, opacity,

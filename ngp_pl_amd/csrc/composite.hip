@@ -226,6 +226,20 @@ composite_train_fw_kernel(const float* __restrict__ sigmas, const float* __restr
 
 // volumerendering.cu:106-150 (+ host pre-multiply :175), one wave per ray.  The running prefixes
 // r,g,b,d and the prefix of dL/dw*w are wave scans; T is updated before use as in the reference.
+// FUSED_TAIL (ngp_composite_train_bw_tail): `ray_offsets` holds the per-row COUNTS of live samples as the forward left them, not
+// their exclusive prefix -- the one-workgroup scan kernel that used to sit between the composite forward and backward (13 us on the
+// critical path for 32 KB of counts) is gone.  Every workgroup sums the counts of the rows in front of its own four (at most 32 KB
+// from L2, 16-byte loads, all in flight: the sums are integers, so the offsets are exactly the scan's); the LAST workgroup, which
+// holds the total anyway, writes n_active (+ the pinned host copy); workgroup 0 -- dispatched first, never the kernel's tail --
+// adds the per-row loss terms in a fixed order.
+struct BwTail { const float* row_loss; const float* row_sq; float* loss; float* sq_err; int32_t* n_active; int32_t* n_active_host; };
+__device__ __forceinline__ int wave_sum_int(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <bool FUSED_TAIL>
 __global__ void __launch_bounds__(256)
 composite_train_bw_kernel(const float* __restrict__ dL_dopacity, const float* __restrict__ dL_ddepth,
                           const float* __restrict__ dL_drgb, const float* __restrict__ dL_dws,
@@ -236,15 +250,57 @@ composite_train_bw_kernel(const float* __restrict__ dL_dopacity, const float* __
                           const float* __restrict__ rgb, float T_threshold, int n_rays,
                           float* __restrict__ dL_dsigmas, float* __restrict__ dL_drgbs,
                           const int32_t* __restrict__ ray_offsets, int32_t* __restrict__ active_idx,
-                          const float* __restrict__ xyzs, float* __restrict__ x_active) {
+                          const float* __restrict__ xyzs, float* __restrict__ x_active, BwTail tail) {
     const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
+    int a_off = 0;
+    if (FUSED_TAIL) {
+        __shared__ int s_part[4];
+        __shared__ float s_l[4], s_e[4];
+        const int tid = threadIdx.x, wave = tid >> 6;
+        const int row0 = 4 * (int)blockIdx.x;                              // rows in front of this workgroup: a multiple of 4
+        int acc = 0;
+        for (int i = 4 * tid; i < row0; i += 2048) {                       // two independent 16-byte loads per trip
+            const int4 a = *reinterpret_cast<const int4*>(ray_offsets + i);
+            int4 b = make_int4(0, 0, 0, 0);
+            if (i + 1024 < row0) b = *reinterpret_cast<const int4*>(ray_offsets + i + 1024);
+            acc += ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
+        }
+        acc = wave_sum_int(acc);
+        if (lane == 0) s_part[wave] = acc;
+        __syncthreads();
+        const int wg_prefix = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+        int own[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) own[w] = (row0 + w < n_rays) ? ray_offsets[row0 + w] : 0;
+        a_off = wg_prefix;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) if (w < wave) a_off += own[w];
+        if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+            const int total = wg_prefix + ((own[0] + own[1]) + (own[2] + own[3]));
+            *tail.n_active = total;
+            if (tail.n_active_host) *tail.n_active_host = total;
+        }
+        if (blockIdx.x == 0) {                                             // loss = sum of the per-row terms, fixed order
+            const int per = (n_rays + 255) / 256;
+            float l = 0.f, se = 0.f;
+            for (int i = tid * per; i < min((tid + 1) * per, n_rays); ++i) { l += tail.row_loss[i]; se += tail.row_sq[i]; }
+            l = ngp_wave_sum(l); se = ngp_wave_sum(se);
+            __syncthreads();                                               // (s_part has been read by everyone)
+            if (lane == 0) { s_l[wave] = l; s_e[wave] = se; }
+            __syncthreads();
+            if (tid == 0) {
+                *tail.loss = (s_l[0] + s_l[1]) + (s_l[2] + s_l[3]);
+                if (tail.sq_err) *tail.sq_err = (s_e[0] + s_e[1]) + (s_e[2] + s_e[3]);
+            }
+        }
+    }
     if (n >= n_rays) return;
     const int64_t ray_idx = rays_a[3 * (size_t)n];
     const int64_t start = rays_a[3 * (size_t)n + 1];
     const int N = (int)rays_a[3 * (size_t)n + 2];
     if (N <= 0) return;
-    const int a_off = active_idx ? ray_offsets[n] : 0;
+    if (!FUSED_TAIL) a_off = active_idx ? ray_offsets[n] : 0;
     const float R = rgb[3 * ray_idx], G = rgb[3 * ray_idx + 1], B = rgb[3 * ray_idx + 2];
     const float O = opacity[ray_idx], D = depth[ray_idx];
     const float gR = dL_drgb[3 * ray_idx], gG = dL_drgb[3 * ray_idx + 1], gB = dL_drgb[3 * ray_idx + 2];
@@ -455,9 +511,55 @@ int ngp_composite_train_bw(const float* dL_dopacity, const float* dL_ddepth, con
     NGP_CHECK_PTR(opacity); NGP_CHECK_PTR(depth); NGP_CHECK_PTR(rgb); NGP_CHECK_PTR(dL_dsigmas); NGP_CHECK_PTR(dL_drgbs);
     if ((ray_offsets == nullptr) != (active_idx == nullptr)) return NGP_EINVAL;
     if ((xyzs == nullptr) != (x_active == nullptr) || (x_active != nullptr && active_idx == nullptr)) return NGP_EINVAL;
-    hipLaunchKernelGGL(composite_train_bw_kernel, dim3(ngp_div_up((long long)n_rays * 64, 256)), dim3(256), 0, ngp_stream(stream),
+    hipLaunchKernelGGL(composite_train_bw_kernel<false>, dim3(ngp_div_up((long long)n_rays * 64, 256)), dim3(256), 0, ngp_stream(stream),
                        dL_dopacity, dL_ddepth, dL_drgb, dL_dws, sigmas, rgbs, ws, deltas, ts, rays_a,
-                       opacity, depth, rgb, T_threshold, n_rays, dL_dsigmas, dL_drgbs, ray_offsets, active_idx, xyzs, x_active);
+                       opacity, depth, rgb, T_threshold, n_rays, dL_dsigmas, dL_drgbs, ray_offsets, active_idx, xyzs, x_active, BwTail{});
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_composite_train_fw_loss_counts(const float* sigmas, const float* rgbs, const float* deltas, const float* ts,
+                                       const int64_t* rays_a, float T_threshold, int n_rays, int n_samples,
+                                       int64_t* total_samples, float* opacity, float* depth, float* rgb, float* ws,
+                                       int32_t* ray_counts, const float* gt_rgb, const float* bg,
+                                       float lambda_opacity, float grad_scale, float* dL_drgb,
+                                       float* dL_dopacity, void* workspace, size_t workspace_bytes, ngp_stream_t stream) {
+    if (n_rays <= 0 || n_samples < 0) return NGP_EINVAL;
+    NGP_CHECK_PTR(rays_a); NGP_CHECK_PTR(total_samples); NGP_CHECK_PTR(opacity); NGP_CHECK_PTR(depth); NGP_CHECK_PTR(rgb);
+    NGP_CHECK_PTR(ray_counts); NGP_CHECK_PTR(gt_rgb); NGP_CHECK_PTR(dL_drgb); NGP_CHECK_PTR(dL_dopacity); NGP_CHECK_PTR(workspace);
+    if (n_samples > 0) { NGP_CHECK_PTR(sigmas); NGP_CHECK_PTR(rgbs); NGP_CHECK_PTR(deltas); NGP_CHECK_PTR(ts); NGP_CHECK_PTR(ws); }
+    if (workspace_bytes < ngp_composite_train_fw_loss_workspace_bytes(n_rays) || ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(ray_counts)) & 15) != 0) return NGP_EINVAL;
+    FwTail t{};
+    t.gt = gt_rgb; t.bg = bg; t.lambda_o = lambda_opacity; t.grad_scale = grad_scale;
+    t.dL_drgb = dL_drgb; t.dL_dopacity = dL_dopacity;
+    t.row_loss = static_cast<float*>(workspace);
+    t.row_sq = t.row_loss + ((n_rays + 3) & ~3);
+    hipLaunchKernelGGL(composite_train_fw_kernel<true>, dim3(ngp_div_up((long long)n_rays * 64, 256)), dim3(256), 0, ngp_stream(stream),
+                       sigmas, rgbs, deltas, ts, rays_a, T_threshold, n_rays, total_samples, opacity, depth, rgb, ws, ray_counts, t);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_composite_train_bw_tail(const float* dL_dopacity, const float* dL_ddepth, const float* dL_drgb,
+                                const float* dL_dws, const float* sigmas, const float* rgbs, const float* ws,
+                                const float* deltas, const float* ts, const int64_t* rays_a,
+                                const float* opacity, const float* depth, const float* rgb, float T_threshold,
+                                int n_rays, int n_samples, float* dL_dsigmas, float* dL_drgbs,
+                                const int32_t* ray_counts, int32_t* active_idx, const float* xyzs, float* x_active,
+                                int32_t* n_active, int32_t* n_active_host, float* loss, float* sq_err,
+                                const void* workspace, size_t workspace_bytes, ngp_stream_t stream) {
+    if (n_rays <= 0 || n_samples <= 0) return NGP_EINVAL;               // no samples: ngp_composite_train_fw_loss (its tail kernel writes the loss)
+    NGP_CHECK_PTR(dL_dopacity); NGP_CHECK_PTR(dL_ddepth); NGP_CHECK_PTR(dL_drgb); NGP_CHECK_PTR(sigmas);
+    NGP_CHECK_PTR(rgbs); NGP_CHECK_PTR(ws); NGP_CHECK_PTR(deltas); NGP_CHECK_PTR(ts); NGP_CHECK_PTR(rays_a);
+    NGP_CHECK_PTR(opacity); NGP_CHECK_PTR(depth); NGP_CHECK_PTR(rgb); NGP_CHECK_PTR(dL_dsigmas); NGP_CHECK_PTR(dL_drgbs);
+    NGP_CHECK_PTR(ray_counts); NGP_CHECK_PTR(active_idx); NGP_CHECK_PTR(n_active); NGP_CHECK_PTR(loss); NGP_CHECK_PTR(workspace);
+    if ((xyzs == nullptr) != (x_active == nullptr)) return NGP_EINVAL;
+    if (workspace_bytes < ngp_composite_train_fw_loss_workspace_bytes(n_rays) || (reinterpret_cast<uintptr_t>(ray_counts) & 15) != 0) return NGP_EINVAL;
+    BwTail t;
+    t.row_loss = static_cast<const float*>(workspace);
+    t.row_sq = t.row_loss + ((n_rays + 3) & ~3);
+    t.loss = loss; t.sq_err = sq_err; t.n_active = n_active; t.n_active_host = n_active_host;
+    hipLaunchKernelGGL(composite_train_bw_kernel<true>, dim3(ngp_div_up((long long)n_rays * 64, 256)), dim3(256), 0, ngp_stream(stream),
+                       dL_dopacity, dL_ddepth, dL_drgb, dL_dws, sigmas, rgbs, ws, deltas, ts, rays_a,
+                       opacity, depth, rgb, T_threshold, n_rays, dL_dsigmas, dL_drgbs, ray_counts, active_idx, xyzs, x_active, t);
     return NGP_LAUNCH_RESULT();
 }
 

@@ -50,6 +50,7 @@ struct ngp_stepper {
     hipStream_t next_main = nullptr, next_side = nullptr;
     int march_at = 2;
     // two-round forward (include/ngp_hip.h): mode 0 off / 1 on / 2 auto, first K, the auto switch's state, steps run in two rounds
+    int fused_tail = 1;                    // NGP_FUSED_TAIL (default 1): composite forward / backward without the scan kernel between them
     int two_round_mode = 2, two_round_k = 32;
     bool two_round_active = false, two_rounds = false;
     int set_k[2] = {0, 0};                 // first K the scan of each march record set prepared a compact list for (0: none)
@@ -198,6 +199,7 @@ int ngp_stepper_create(const ngp_stepper_config* config, const ngp_step_buffers*
     s->c = c; s->b = *buffers;
     s->march_at = march_at_from_env();
     if (const char* e = getenv("NGP_TWO_ROUND")) s->two_round_mode = strcmp(e, "on") == 0 ? 1 : (strcmp(e, "off") == 0 ? 0 : 2);
+    if (const char* e = getenv("NGP_FUSED_TAIL")) s->fused_tail = atoi(e) != 0;
     if (const char* e = getenv("NGP_TWO_ROUND_K")) { const int k = atoi(e); if (k >= 1 && k <= 64) s->two_round_k = k; }
     (void)hipGetDevice(&s->device);
     hipError_t e = hipSuccess;
@@ -345,7 +347,7 @@ static int forward_field(ngp_stepper* s, const float* rays_o, const float* rays_
 
 // composite backward (+ distortion) -> field backward on the live samples, from seeds w.r.t. the composited per-ray values
 static int backward_field(ngp_stepper* s, const float* dL_dopacity, const float* dL_ddepth, const float* dL_drgb, const float* dL_dws_in,
-                          float loss_scale, hipStream_t main, ngp_stream_t main_stream, int32_t* n_partials) {
+                          float loss_scale, hipStream_t main, ngp_stream_t main_stream, int32_t* n_partials, bool fused_tail = false) {
     const ngp_stepper_config& c = s->c;
     const ngp_step_buffers& b = s->b;
     const int k = s->last_set, n = b.n_rays;
@@ -363,9 +365,17 @@ static int backward_field(ngp_stepper* s, const float* dL_dopacity, const float*
     // backward only over the samples up to each ray's early stop (the rest have zero gradient); the binned table backward
     // reads the live samples' positions as a stream: composite_bw copies them in list order
     s->binned = S <= b.bin_max;
-    STEP_TRY(ngp_composite_train_bw(dL_dopacity, dL_ddepth, dL_drgb, dL_dws, b.sigmas, b.rgbs, b.ws, b.deltas, b.ts, b.rays_a[k], b.opacity,
-                                    b.depth, b.rgb, c.T_threshold, n, S, b.dL_dsigmas, b.dL_drgbs, b.ray_offs, b.active,
-                                    s->binned ? b.xyzs : nullptr, s->binned ? b.x_act : nullptr, main_stream));
+    if (fused_tail) {
+        // (ray_offs holds the rows' live-sample COUNTS: the backward's workgroups prefix them, write n_active and add the loss terms)
+        STEP_TRY(ngp_composite_train_bw_tail(dL_dopacity, dL_ddepth, dL_drgb, dL_dws, b.sigmas, b.rgbs, b.ws, b.deltas, b.ts, b.rays_a[k], b.opacity,
+                                             b.depth, b.rgb, c.T_threshold, n, S, b.dL_dsigmas, b.dL_drgbs, b.ray_offs, b.active,
+                                             s->binned ? b.xyzs : nullptr, s->binned ? b.x_act : nullptr, b.n_active, b.counter[k] + 2,
+                                             b.stats, b.stats + 1, b.fw_ws, b.fw_bytes, main_stream));
+    } else {
+        STEP_TRY(ngp_composite_train_bw(dL_dopacity, dL_ddepth, dL_drgb, dL_dws, b.sigmas, b.rgbs, b.ws, b.deltas, b.ts, b.rays_a[k], b.opacity,
+                                        b.depth, b.rgb, c.T_threshold, n, S, b.dL_dsigmas, b.dL_drgbs, b.ray_offs, b.active,
+                                        s->binned ? b.xyzs : nullptr, s->binned ? b.x_act : nullptr, main_stream));
+    }
     mark(s, 5, main);
     STEP_TRY(march_next_if_at(s, AT_COMPOSITE_BW));
     const int n_part = ngp_field_bwd_partials(S);
@@ -399,12 +409,19 @@ int ngp_stepper_front(ngp_stepper* s, const float* rays_o, const float* rays_d, 
     const int n = b.n_rays;
     // composite + per-ray loss seeds, then one small kernel: offsets of the live samples and the loss sums
     b.counter[k][2] = -1;
-    STEP_TRY(ngp_composite_train_fw_loss_h(b.sigmas, b.rgbs, b.deltas, b.ts, b.rays_a[k], c.T_threshold, n, S, b.total, b.opacity, b.depth, b.rgb,
-                                           b.ws, b.ray_offs, b.n_active, b.counter[k] + 2, rgb_gt, c.bg, c.lambda_opacity, grad_scale, b.stats,
-                                           b.stats + 1, b.dL_drgb, b.dL_dopacity, b.fw_ws, b.fw_bytes, main_stream));
+    const bool fused_tail = s->fused_tail && S > 0;
+    if (fused_tail) {
+        STEP_TRY(ngp_composite_train_fw_loss_counts(b.sigmas, b.rgbs, b.deltas, b.ts, b.rays_a[k], c.T_threshold, n, S, b.total, b.opacity, b.depth, b.rgb,
+                                                    b.ws, b.ray_offs, rgb_gt, c.bg, c.lambda_opacity, grad_scale, b.dL_drgb, b.dL_dopacity, b.fw_ws,
+                                                    b.fw_bytes, main_stream));
+    } else {
+        STEP_TRY(ngp_composite_train_fw_loss_h(b.sigmas, b.rgbs, b.deltas, b.ts, b.rays_a[k], c.T_threshold, n, S, b.total, b.opacity, b.depth, b.rgb,
+                                               b.ws, b.ray_offs, b.n_active, b.counter[k] + 2, rgb_gt, c.bg, c.lambda_opacity, grad_scale, b.stats,
+                                               b.stats + 1, b.dL_drgb, b.dL_dopacity, b.fw_ws, b.fw_bytes, main_stream));
+    }
     mark(s, 4, main);
     STEP_TRY(march_next_if_at(s, AT_COMPOSITE_FW));
-    STEP_TRY(backward_field(s, b.dL_dopacity, b.zeros, b.dL_drgb, nullptr, loss_scale, main, main_stream, n_partials));
+    STEP_TRY(backward_field(s, b.dL_dopacity, b.zeros, b.dL_drgb, nullptr, loss_scale, main, main_stream, n_partials, fused_tail));
     if (s->next_o != nullptr && (S <= 0 || s->march_at < AT_HASHGRID_BWD)) {      // a batch without samples skips the stages a placement may name
         const float* o = s->next_o; const float* d = s->next_d;
         s->next_o = s->next_d = nullptr;

@@ -467,11 +467,18 @@ class Trainer:
                 call("ngp_field_fwd", P["feats"], P["dirs"], eh_p, rh_p, S, P["sigmas"], P["rgbs"], P["h"], mq)
                 self._mark("mlp_fwd")
                 march_next_if_at("mlp_fwd")
-            # composite + per-ray loss seeds, then one small kernel: offsets of the live samples and the loss sums
-            call("ngp_composite_train_fw_loss", P["sigmas"], P["rgbs"], P["deltas"], P["ts"], rays_a, self.T_threshold, n, S,
-                 P["total"], P["opacity"], P["depth"], P["rgb"], P["ws"], P["ray_offs"], P["n_active"], ptr(rgb_gt), ptr(self.bg),
-                 self.lambda_opacity, self.grad_scale, P["stats"], P["stats"] + 4, P["dL_drgb"], P["dL_dopacity"],
-                 P["fw_ws"], B.fw_bytes, mq)
+            # composite + per-ray loss seeds; the offsets of the live samples, their total and the loss sums are formed by the
+            # composite BACKWARD's workgroups (NGP_FUSED_TAIL=0, or a batch without samples: one small kernel behind the forward)
+            fused_tail = S > 0 and os.environ.get("NGP_FUSED_TAIL", "1") != "0"
+            if fused_tail:
+                call("ngp_composite_train_fw_loss_counts", P["sigmas"], P["rgbs"], P["deltas"], P["ts"], rays_a, self.T_threshold, n, S,
+                     P["total"], P["opacity"], P["depth"], P["rgb"], P["ws"], P["ray_offs"], ptr(rgb_gt), ptr(self.bg),
+                     self.lambda_opacity, self.grad_scale, P["dL_drgb"], P["dL_dopacity"], P["fw_ws"], B.fw_bytes, mq)
+            else:
+                call("ngp_composite_train_fw_loss", P["sigmas"], P["rgbs"], P["deltas"], P["ts"], rays_a, self.T_threshold, n, S,
+                     P["total"], P["opacity"], P["depth"], P["rgb"], P["ws"], P["ray_offs"], P["n_active"], ptr(rgb_gt), ptr(self.bg),
+                     self.lambda_opacity, self.grad_scale, P["stats"], P["stats"] + 4, P["dL_drgb"], P["dL_dopacity"],
+                     P["fw_ws"], B.fw_bytes, mq)
             self._mark("composite_fw+loss")
             if S > 0:
                 march_next_if_at("composite_fw")
@@ -491,9 +498,15 @@ class Trainer:
                          rays_a, n, S, dL_dws, mq)
                 # the binned table backward reads the live samples' positions as a stream: composite_bw copies them in list order
                 binned = 0 < S <= B.bin_max                      # larger: occupancy warm-up, the one-pass sliced kernel takes it
-                call("ngp_composite_train_bw", P["dL_dopacity"], P["zeros"], P["dL_drgb"], dL_dws, P["sigmas"], P["rgbs"], P["ws"],
-                     P["deltas"], P["ts"], rays_a, P["opacity"], P["depth"], P["rgb"], self.T_threshold, n, S,
-                     P["dL_dsigmas"], P["dL_drgbs"], P["ray_offs"], P["active"], P["xyzs"] if binned else None, P["x_act"] if binned else None, mq)
+                if fused_tail:
+                    call("ngp_composite_train_bw_tail", P["dL_dopacity"], P["zeros"], P["dL_drgb"], dL_dws, P["sigmas"], P["rgbs"], P["ws"],
+                         P["deltas"], P["ts"], rays_a, P["opacity"], P["depth"], P["rgb"], self.T_threshold, n, S,
+                         P["dL_dsigmas"], P["dL_drgbs"], P["ray_offs"], P["active"], P["xyzs"] if binned else None, P["x_act"] if binned else None,
+                         P["n_active"], None, P["stats"], P["stats"] + 4, P["fw_ws"], B.fw_bytes, mq)
+                else:
+                    call("ngp_composite_train_bw", P["dL_dopacity"], P["zeros"], P["dL_drgb"], dL_dws, P["sigmas"], P["rgbs"], P["ws"],
+                         P["deltas"], P["ts"], rays_a, P["opacity"], P["depth"], P["rgb"], self.T_threshold, n, S,
+                         P["dL_dsigmas"], P["dL_drgbs"], P["ray_offs"], P["active"], P["xyzs"] if binned else None, P["x_act"] if binned else None, mq)
                 self._mark("composite_bw")
                 march_next_if_at("composite_bw")
                 n_part = call("ngp_field_bwd_partials", S)

@@ -281,3 +281,61 @@ def test_fused_composite_loss_launch_equals_the_three_separate_launches(n_rays):
                 assert torch.allclose(a[k], b[k], rtol=1e-5, atol=0), (a[k], b[k])
             else:
                 assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("n_rays", [1, 3, 777, 8192, 20000])
+def test_composite_pair_without_the_scan_kernel_equals_the_pair_with_it(n_rays):
+    """ngp_composite_train_fw_loss_counts + ngp_composite_train_bw_tail (the backward's workgroups prefix the rows' live counts,
+    the last one writes n_active, the first adds the loss terms) == ngp_composite_train_fw_loss + ngp_composite_train_bw: per-ray
+    outputs, seeds, sample gradients, the ACTIVE LIST and the positions copied in list order, n_active (device + pinned host word)
+    bit for bit; loss and squared-error sums to float rounding (another fixed summation order)."""
+    from ngp_pl_amd._lib import call, lib, ptr, stream
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(100 + n_rays)
+    counts = torch.randint(0, 90, (n_rays,), device=dev, generator=g)
+    counts[::7] = 0
+    if n_rays == 3:
+        counts[:] = torch.tensor([5, 0, 70], device=dev)
+    S = max(int(counts.sum()), 1)
+    if int(counts.sum()) == 0:
+        counts[0] = 1
+    rays_a = torch.stack([torch.arange(n_rays, device=dev), torch.cumsum(counts, 0) - counts, counts], 1).contiguous()
+    sigmas = torch.rand(S, device=dev, generator=g) * 60; rgbs = torch.rand(S, 3, device=dev, generator=g)
+    deltas = torch.full((S,), 1.7e-3, device=dev); ts = torch.rand(S, device=dev, generator=g) + 0.5
+    xyzs = torch.rand(S, 3, device=dev, generator=g)
+    gt = torch.rand(n_rays, 3, device=dev, generator=g); bg = torch.ones(3, device=dev)
+    zeros = torch.zeros(n_rays, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev); i32 = dict(dtype=torch.int32, device=dev)
+    nbytes = lib().ngp_composite_train_fw_loss_workspace_bytes(n_rays)
+
+    def outputs():
+        return dict(total=torch.empty(n_rays, dtype=torch.int64, device=dev), opacity=torch.empty(n_rays, **f32),
+                    depth=torch.empty(n_rays, **f32), rgb=torch.empty(n_rays, 3, **f32), ws=torch.empty(S, **f32),
+                    offs=torch.empty((n_rays + 3) // 4 * 4, **i32), n_active=torch.full((1,), -7, **i32),
+                    stats=torch.empty(2, **f32), d_rgb=torch.empty(n_rays, 3, **f32), d_o=torch.empty(n_rays, **f32),
+                    ds=torch.empty(S, **f32), dc=torch.empty(S, 3, **f32), active=torch.full((S,), -1, **i32), x_act=torch.full((S, 3), -1.0, **f32),
+                    wsp=torch.empty(nbytes, dtype=torch.uint8, device=dev))
+    a, b = outputs(), outputs()
+    host = torch.full((4,), -1, dtype=torch.int32).pin_memory()
+    call("ngp_composite_train_fw_loss", ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(ts), ptr(rays_a), 1e-4, n_rays, S, ptr(a["total"]),
+         ptr(a["opacity"]), ptr(a["depth"]), ptr(a["rgb"]), ptr(a["ws"]), ptr(a["offs"]), ptr(a["n_active"]), ptr(gt), ptr(bg),
+         1e-3, 128.0, ptr(a["stats"]), ptr(a["stats"][1:]), ptr(a["d_rgb"]), ptr(a["d_o"]), ptr(a["wsp"]), nbytes, stream())
+    call("ngp_composite_train_bw", ptr(a["d_o"]), ptr(zeros), ptr(a["d_rgb"]), None, ptr(sigmas), ptr(rgbs), ptr(a["ws"]), ptr(deltas), ptr(ts),
+         ptr(rays_a), ptr(a["opacity"]), ptr(a["depth"]), ptr(a["rgb"]), 1e-4, n_rays, S, ptr(a["ds"]), ptr(a["dc"]), ptr(a["offs"]),
+         ptr(a["active"]), ptr(xyzs), ptr(a["x_act"]), stream())
+    call("ngp_composite_train_fw_loss_counts", ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(ts), ptr(rays_a), 1e-4, n_rays, S, ptr(b["total"]),
+         ptr(b["opacity"]), ptr(b["depth"]), ptr(b["rgb"]), ptr(b["ws"]), ptr(b["offs"]), ptr(gt), ptr(bg), 1e-3, 128.0,
+         ptr(b["d_rgb"]), ptr(b["d_o"]), ptr(b["wsp"]), nbytes, stream())
+    call("ngp_composite_train_bw_tail", ptr(b["d_o"]), ptr(zeros), ptr(b["d_rgb"]), None, ptr(sigmas), ptr(rgbs), ptr(b["ws"]), ptr(deltas), ptr(ts),
+         ptr(rays_a), ptr(b["opacity"]), ptr(b["depth"]), ptr(b["rgb"]), 1e-4, n_rays, S, ptr(b["ds"]), ptr(b["dc"]), ptr(b["offs"]),
+         ptr(b["active"]), ptr(xyzs), ptr(b["x_act"]), ptr(b["n_active"]), host.data_ptr(), ptr(b["stats"]), ptr(b["stats"][1:]), ptr(b["wsp"]), nbytes, stream())
+    torch.cuda.synchronize()
+    n_act = int(a["n_active"])
+    assert n_act == int(b["n_active"]) == int(host[0]) and 0 < n_act <= S
+    # the counts the forward left are the differences of the offsets the scan kernel wrote
+    offs = a["offs"][:n_rays].long(); cnt = b["offs"][:n_rays].long()
+    assert torch.equal(torch.cumsum(cnt, 0) - cnt, offs)
+    for k in ("total", "opacity", "depth", "rgb", "ws", "d_rgb", "d_o", "ds", "dc"):
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(a["active"][:n_act], b["active"][:n_act]) and torch.equal(a["x_act"][:n_act], b["x_act"][:n_act])
+    assert torch.allclose(a["stats"], b["stats"], rtol=1e-5, atol=0), (a["stats"], b["stats"])
