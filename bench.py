@@ -163,7 +163,9 @@ class Loop:
             from ngp_pl_amd.ddp import GradientExchange, NativeExchange, ShardedExchange
             self.exchange_kind = os.environ.get("NGP_DDP_EXCHANGE", "sharded")
             self.exchange_impl = "native" if os.environ.get("NGP_DDP_NATIVE", "1") != "0" else "torch.distributed"
-            n_chunks = int(os.environ.get("NGP_DDP_CHUNKS", "2" if world > 1 else "1"))
+            # one chunk, one launch group: measured on a 1-rank RCCL group (profiles/r04_pg1_native_exchange.txt) every further launch
+            # group of the table backward costs more than the reduce-scatter it could hide (2 groups +33 us, 4 groups +170 us per step)
+            n_chunks = int(os.environ.get("NGP_DDP_CHUNKS", "1"))
             if self.exchange_impl == "native":
                 try:
                     self.exchange = NativeExchange(self.model, dist, world, rank, mode=self.exchange_kind, n_chunks=n_chunks,

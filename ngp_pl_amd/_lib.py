@@ -4,6 +4,7 @@ The product path has NO fallback: if the library is missing or a call fails this
 torch is imported first so that the library binds to the HIP runtime torch already loaded
 (same SONAME libamdhip64.so.7) and torch's streams/pointers are valid inside it.
 """
+import contextlib
 import ctypes as C
 import os
 
@@ -283,6 +284,18 @@ def march_guard_first():
     call("ngp_march_guard_first", C.cast(buf, P))
     v = list(buf)
     return dict(t=v[0], t_target=v[1], t_faces=v[2:5], origin=v[5:8], direction=v[8:11], dt_lo=v[11])
+
+
+_NO_GUARD = contextlib.nullcontext()
+
+
+def device_guard(dev):
+    """`with torch.cuda.device(dev)` only when dev is not the current device already (one process per GPU sets its device once; the
+    guard's bookkeeping costs 10-20 us of host time per use, and the reference-shaped step path used six of them)."""
+    idx = dev.index
+    if idx is None or torch.cuda.current_device() == idx:
+        return _NO_GUARD
+    return torch.cuda.device(dev)
 
 
 def ptr(t):

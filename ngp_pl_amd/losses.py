@@ -74,11 +74,11 @@ class _LossTerms(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rgb, opacity, gt, lambda_opacity):
-        from ._lib import call, ptr, stream
+        from ._lib import call, device_guard, ptr, stream
         rgb = rgb.float().contiguous(); opacity = opacity.float().contiguous(); gt = gt.float().contiguous()
         n = rgb.shape[0]
         sq = torch.empty_like(rgb); ent = torch.empty_like(opacity)
-        with torch.cuda.device(rgb.device):
+        with device_guard(rgb.device):
             call("ngp_nerf_loss_terms_fw", ptr(rgb), ptr(opacity), ptr(gt), float(lambda_opacity), n, ptr(sq), ptr(ent), stream())
         ctx.save_for_backward(rgb, opacity, gt)
         ctx.lambda_opacity = float(lambda_opacity)
@@ -86,7 +86,7 @@ class _LossTerms(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_sq, g_ent):
-        from ._lib import call, ptr, stream
+        from ._lib import call, device_guard, ptr, stream
         rgb, opacity, gt = ctx.saved_tensors
         n = rgb.shape[0]
         # `.mean().backward()` hands back expanded (stride-0) views of one scalar: pass the scalar, do not materialise it
@@ -96,7 +96,7 @@ class _LossTerms(torch.autograd.Function):
             return g.float().contiguous(), 0
         (g_sq, sq_scalar), (g_ent, ent_scalar) = seed(g_sq), seed(g_ent)
         g_rgb = torch.empty_like(rgb); g_op = torch.empty_like(opacity)
-        with torch.cuda.device(rgb.device):
+        with device_guard(rgb.device):
             call("ngp_nerf_loss_terms_bw", ptr(g_sq), sq_scalar, ptr(g_ent), ent_scalar, ptr(rgb), ptr(opacity), ptr(gt), ctx.lambda_opacity, n,
                  ptr(g_rgb), ptr(g_op), stream())
         return g_rgb, g_op, None, None

@@ -19,7 +19,7 @@ import weakref
 
 import torch
 
-from ._lib import call, ptr, stream
+from ._lib import call, device_guard, ptr, stream
 
 
 def tag_parameters(model):
@@ -130,8 +130,34 @@ class FusedAdam(torch.optim.Optimizer):
         super().zero_grad(set_to_none=self.set_grad_none if set_to_none is None else set_to_none)
 
     # -- the update ------------------------------------------------------------------------------
-    @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0, found_inf=None, stream_handle=None):
+        """torch.optim.Optimizer.step protocol (closure, registered step pre / post hooks) without torch's per-call profiler
+        wrapper (`Optimizer.profile_hook_step`: a record_function scope, hook-dict chains and a no_grad decorator measured ~60 us of
+        host time per step on the reference-shaped path, which is host-bound): `step.hooked` below tells Optimizer.__init__ this
+        method runs the hooks itself."""
+        if self._optimizer_step_pre_hooks or self._optimizer_step_post_hooks or _global_hooks():
+            return self._step_with_hooks(closure, grad_scale, found_inf, stream_handle)
+        prev = torch.is_grad_enabled()
+        torch.set_grad_enabled(False)
+        try:
+            return self._step(closure, grad_scale, found_inf, stream_handle)
+        finally:
+            torch.set_grad_enabled(prev)
+
+    def _step_with_hooks(self, closure, grad_scale, found_inf, stream_handle):
+        from torch.optim import optimizer as _o
+        args, kwargs = (self,), dict(closure=closure, grad_scale=grad_scale, found_inf=found_inf, stream_handle=stream_handle)
+        for hook in list(_o._global_optimizer_pre_hooks.values()) + list(self._optimizer_step_pre_hooks.values()):
+            result = hook(self, args, kwargs)
+            if result is not None:
+                args, kwargs = result
+        with torch.no_grad():
+            out = self._step(**kwargs)
+        for hook in list(self._optimizer_step_post_hooks.values()) + list(_o._global_optimizer_post_hooks.values()):
+            hook(self, args, kwargs)
+        return out
+
+    def _step(self, closure=None, grad_scale=1.0, found_inf=None, stream_handle=None):
         """grad_scale: extra factor the caller put on the loss (a GradScaler-style scale applied OUTSIDE torch's GradScaler, which
         unscales `.grad` itself); the kernels' own loss scale is taken from the native record.  found_inf: device int32 flag
         (non-zero: skip) -- with it the bias-correction count lives on the device too and does not advance on a skipped step."""
@@ -164,7 +190,7 @@ class FusedAdam(torch.optim.Optimizer):
                 if p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
                     p.grad = p.grad.float().contiguous()
                 half = self._half_of(p)
-                with torch.cuda.device(p.device):
+                with device_guard(p.device):
                     # f32 gradient, CONSUMED: the kernel leaves .grad zero-filled (apex leaves it alone; every training loop clears
                     # it next, Lightning included -- and a copy to preserve it would add 2 x 45.7 MB of traffic per step)
                     call("ngp_adam_step", ptr(p.data), ptr(half), ptr(p.grad), 1, ptr(m), ptr(v), p.numel(), group["lr"], b1, b2,
@@ -202,7 +228,7 @@ class FusedAdam(torch.optim.Optimizer):
         ne = enc.n_mlp
         # raw pointers by arithmetic (a tensor slice costs ~4 us of host time, this call passes 6 of them)
         p_enc, p_half, p_m, p_v = enc.params.data_ptr(), enc._half.t.data_ptr(), m.data_ptr(), v.data_ptr()
-        guard = torch.cuda.device(enc.params.device) if stream_handle is None else contextlib.nullcontext()     # a raw stream handle names its device
+        guard = device_guard(enc.params.device) if stream_handle is None else contextlib.nullcontext()     # a raw stream handle names its device
         with guard:
             call("ngp_adam_step_field", p_enc + 4 * ne, p_half + 2 * ne, ptr(nat["grid16"]), p_m + 4 * ne, p_v + 4 * ne, enc.n_grid,
                  p_enc, p_half, ptr(nat["density_partials"]), p_m, p_v, ne,
@@ -211,6 +237,14 @@ class FusedAdam(torch.optim.Optimizer):
                  self.step_state(found_inf), sq)      # 0: every table backward of this package overwrites the gradient
         enc._half.mark_fresh(enc.params); net._half.mark_fresh(net.params)
         model._native = None
+
+
+FusedAdam.step.hooked = True          # Optimizer._patch_step_function: do not wrap (step() runs registered hooks itself)
+
+
+def _global_hooks():
+    from torch.optim import optimizer as _o
+    return bool(_o._global_optimizer_pre_hooks) or bool(_o._global_optimizer_post_hooks)
 
 
 def cosine_lr(base_lr, epoch, num_epochs, eta_min_ratio=1 / 30):

@@ -317,7 +317,7 @@ class _NativeTrainRender(torch.autograd.Function):
         rs = getattr(model, "_render_stepper", None)
         if rs is None:
             rs = model._render_stepper = RenderStepper(model)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             B, h = rs.prepare(n, esf, T_threshold, bg)
             mq = stream()
             sq = mq
@@ -344,9 +344,9 @@ class _NativeTrainRender(torch.autograd.Function):
         ctx.model, ctx.rs, ctx.generation, ctx.S = model, rs, rs.generation, S
         f32 = torch.float32
         opacity, depth = B.opacity, B.depth
-        rgb_out = B.view("rgb_out", f32, n, 3)
-        ws, deltas, ts = B.view("ws", f32, S), B.view("deltas", f32, S), B.view("ts", f32, S)
-        rays_a = B.view("rays_a%d" % k, torch.int64, n, 3)
+        rgb_out = B.fixed("rgb_out", f32, n, 3)
+        ws, deltas, ts = B.prefix("ws", f32, S), B.prefix("deltas", f32, S), B.prefix("ts", f32, S)
+        rays_a = B.fixed("rays_a%d" % k, torch.int64, n, 3)
         vr_samples = B.total.sum()
         rm_samples = torch.tensor(S, dtype=torch.int32)
         ctx.mark_non_differentiable(rays_a, deltas, ts, vr_samples, rm_samples)
@@ -372,14 +372,13 @@ class _NativeTrainRender(torch.autograd.Function):
         g_depth = None if g_depth is None else g_depth.float().contiguous()
         g_ws = None if g_ws is None else g_ws.float().contiguous()
         np_c = C.c_int32(0)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             mq = stream()
             call("ngp_stepper_render_backward", h, ptr(g_rgb), ptr(g_opacity), ptr(g_depth), ptr(g_ws), tcnn.LOSS_SCALE, mq, C.byref(np_c))
             call("ngp_stepper_table_backward", h, 1, 0, mq)
         n_part = np_c.value
         g16 = model._grid_grad16(dev)
-        p_density = B.view("partials", torch.float32, n_part * enc.n_mlp)
-        p_rgb = B.arena[B.off["partials"] + 4 * n_part * enc.n_mlp:B.off["partials"] + 4 * n_part * B.n_mlp_params].view(torch.float32)
+        p_density, p_rgb = B.partial_rows(n_part, enc.n_mlp)
         model.hand_over_native(dict(grid16=g16, density_partials=p_density, rgb_partials=p_rgb, n_partials=n_part, scale=tcnn.LOSS_SCALE))
         return (None, None) + none7
 

@@ -78,6 +78,8 @@ class StepBuffers:
                 n *= d
             return self.arena[off[name]:off[name] + n * torch.empty(0, dtype=dtype).element_size()].view(dtype).view(*shape)
         self.view = view
+        self._flat = {}              # name -> the whole buffer as a flat tensor (cached: a prefix of it is one slice, ~3 us)
+        self._cached = {}            # (name, dtype, shape) -> fixed-size view
         f32 = torch.float32
         self.total = view("total", torch.int64, n_rays); self.opacity = view("opacity", f32, n_rays)
         self.depth = view("depth", f32, n_rays); self.rgb = view("rgb", f32, n_rays, 3)
@@ -99,6 +101,32 @@ class StepBuffers:
         self.next_set = 0
         self.ready = [torch.cuda.Event() for _ in (0, 1)]
         self.done = [torch.cuda.Event() for _ in (0, 1)]
+
+    def prefix(self, name, dtype, n):
+        """The first n elements of per-sample buffer `name` (what a step with n samples wrote)."""
+        flat = self._flat.get((name, dtype))
+        if flat is None:
+            nbytes = dict(self.PER_SAMPLE + self.DISTORTION)[name] * self.cap
+            flat = self._flat[(name, dtype)] = self.arena[self.off[name]:self.off[name] + nbytes].view(dtype)
+        return flat[:n]
+
+    def fixed(self, name, dtype, *shape):
+        """view() for shapes that do not change from step to step: built once."""
+        key = (name, dtype, shape)
+        v = self._cached.get(key)
+        if v is None:
+            v = self._cached[key] = self.view(name, dtype, *shape)
+        return v
+
+    def partial_rows(self, n_part, n_density):
+        """(density rows, rgb rows) views of the MLP weight-gradient partials the field backward wrote (n_part rows each)."""
+        key = ("partials", n_part)
+        v = self._cached.get(key)
+        if v is None:
+            o = self.off["partials"]
+            v = self._cached[key] = (self.view("partials", torch.float32, n_part * n_density),
+                                     self.arena[o + 4 * n_part * n_density:o + 4 * n_part * self.n_mlp_params].view(torch.float32))
+        return v
 
     def c_struct(self, distortion):
         """The same buffers as an ngp_step_buffers record for the native stepper."""

@@ -1056,7 +1056,9 @@ def test_two_round_forward_ignores_stale_values_behind_a_stop():
         os.environ["NGP_TWO_ROUND_K"] = "32"
         try:
             m = make_model(seed=43)
-            tr = Trainer(m)
+            # (every occupancy update in warm-up style -- each cell once: the sampled updates past step 256 draw cells twice and keep ONE
+            #  of the two densities, whichever store lands last: two runs of the SAME configuration differ from there on)
+            tr = Trainer(m, warmup_steps=1 << 30)
             log, rounds, early = [], 0, 0
             for i in range(N_STEPS):
                 b, nb = batches[i % 8], batches[(i + 1) % 8]
