@@ -641,8 +641,9 @@ int ngp_sample_rays(const float* poses, const float* directions, const float* im
 /* ---- occupancy-grid maintenance -------------------------------------------------------- */
 
 /* density-only forward whose sigma of sample s is stored at sigmas_out[scatter_idx[s]]
- * (`density_grid_tmp[c, indices] = self.density(xyzs_w)`, networks.py:256-258; duplicate indices:
- * one of the values survives, as with index_put). */
+ * (`density_grid_tmp[c, indices] = self.density(xyzs_w)`, networks.py:256-258).  Duplicate indices: the LARGEST value
+ * survives (an integer max on the non-negative floats' bit patterns: deterministic; index_put keeps one of them, unspecified
+ * on CUDA).  sigmas_out must be zero-filled by the caller. */
 int ngp_density_fwd_scatter(const ngp_half* feats, const ngp_half* density_w, int n_samples,
                             const int32_t* scatter_idx, float* sigmas_out, ngp_stream_t stream);
 

@@ -491,7 +491,7 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     long long* lds = reinterpret_cast<long long*>(smem_raw);
     __shared__ int s_task[2];                                          // s_task[k & 1]: id of the workgroup's k-th task
-    __shared__ int s_dir[MAX_CHUNKS];
+    __shared__ int s_dir2[2][MAX_CHUNKS];                              // directory row of the k-th task in s_dir2[k & 1]
     const Box box = load_box(xyz_min, xyz_max);
     const int dir_pitch = plan.n_chunks;                               // the directory / slot layout is planned for n_samples ...
     // ... the loops stop at the last chunk that holds live samples: late in training a few per cent of the marched samples are
@@ -499,17 +499,32 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
     const int n_live = n_active ? min(*n_active, n_samples) : n_samples;
     const int n_chunks = min(plan.n_chunks, (n_live + CHUNK - 1) / CHUNK);
     const int tid = threadIdx.x;
-    // Three barriers per task, none of them behind a global round trip: the id of task k+1 is requested from the queue at the
-    // top of task k and parked in LDS at its end; the accumulators are cleared by the write-out pass that reads them (the
-    // first task finds them cleared by the prologue).
+    // TWO barriers per task, none of them behind a global round trip (round 4; three before, the first behind the load of the
+    // task's directory row): the id of task k+1 is requested from the queue at the top of task k and published at the barrier
+    // behind task k's accumulation; its directory row is then loaded into registers, rides under task k's write-out and is
+    // parked in the other half of s_dir2 at the closing barrier.  The accumulators are cleared by the write-out pass that
+    // reads them (the first task finds them cleared by the prologue).
+    constexpr int PRE = (MAX_CHUNKS + APPLY_THREADS - 1) / APPLY_THREADS;
+    auto dir_row = [&](int task_id) -> const int32_t* {
+        int oi = 0;
+        while (task_id >= plan.first_task[oi + 1]) ++oi;
+        const int lv = plan.order[oi];
+        const int sl = (task_id - plan.first_task[oi]) / plan.k_split[lv];
+        return ws.dir + ((size_t)lv * MAX_SLICES + sl) * dir_pitch;
+    };
     if (tid == 0) s_task[0] = task_begin + atomicAdd(&ws.queue[group], 1);
     for (uint32_t k = tid; k < 2 * SLICE2; k += APPLY_THREADS) lds[k] = 0;
+    __syncthreads();
+    if (s_task[0] < task_end) {
+        const int32_t* __restrict__ d0 = dir_row(s_task[0]);
+        for (int c = tid; c < n_chunks; c += APPLY_THREADS) s_dir2[0][c] = d0[c];
+    }
     __syncthreads();
     for (int it = 0;; ++it) {
         const int task = s_task[it & 1];
         if (task >= task_end) return;
         int next_task = 0;
-        if (tid == 0) next_task = task_begin + atomicAdd(&ws.queue[group], 1);   // consumed at the end of this task
+        if (tid == 0) next_task = task_begin + atomicAdd(&ws.queue[group], 1);   // published behind this task's accumulation
 #ifdef NGP_BIN_TIMING
         if (tid == 0) ws.timing[4 * task + 0] = (long long)wall_clock64();
 #endif
@@ -523,9 +538,7 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
         const uint32_t size = meta.offset[level + 1] - meta.offset[level];
         const uint32_t lo = (uint32_t)slice * SLICE2;
         const uint32_t len = min(SLICE2, size - lo);
-        const int32_t* __restrict__ dir = ws.dir + ((size_t)level * MAX_SLICES + slice) * dir_pitch;
-        for (int c = tid; c < n_chunks; c += APPLY_THREADS) s_dir[c] = dir[c];
-        __syncthreads();
+        const int* s_dir = s_dir2[it & 1];
 #ifdef NGP_BIN_TIMING
         if (tid == 0) ws.timing[4 * task + 1] = (long long)wall_clock64();
 #endif
@@ -537,10 +550,18 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
         }
         else if (NGP_DENSE_RUNS) apply_segments_dense_runs<NGP_DENSE_B>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
         else apply_segments_dense<4>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
-        __syncthreads();
+        if (tid == 0) s_task[(it + 1) & 1] = next_task;
+        __syncthreads();                                               // accumulators complete, next id visible
 #ifdef NGP_BIN_TIMING
         if (tid == 0) ws.timing[4 * task + 2] = (long long)wall_clock64();
 #endif
+        const int nt = s_task[(it + 1) & 1];
+        int pre[PRE];
+        if (nt < task_end) {                                           // (uniform) the next task's directory row, in flight under the write-out
+            const int32_t* __restrict__ dn = dir_row(nt);
+#pragma unroll
+            for (int q = 0; q < PRE; ++q) { const int c = tid + q * APPLY_THREADS; pre[q] = c < n_chunks ? dn[c] : 0; }
+        }
         half2_t* __restrict__ out = grad_table + meta.offset[level] + lo;
         const float inv = 1.0f / FIX_SCALE;
 #if NGP_APPLY_WRITEOUT_BATCHED
@@ -583,8 +604,11 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
             else ws.partial[plan.part_off[level] + (size_t)part * size + lo + k] = make_float2(a0, a1);
         }
 #endif
-        if (tid == 0) s_task[(it + 1) & 1] = next_task;
-        __syncthreads();                                               // accumulators clear, s_dir free, next id visible
+        if (nt < task_end) {
+#pragma unroll
+            for (int q = 0; q < PRE; ++q) { const int c = tid + q * APPLY_THREADS; if (c < n_chunks) s_dir2[(it + 1) & 1][c] = pre[q]; }
+        }
+        __syncthreads();                                               // accumulators clear, the next task's directory row in place
 #ifdef NGP_BIN_TIMING
         if (tid == 0) ws.timing[4 * task + 3] = (long long)wall_clock64();
 #endif

@@ -302,7 +302,15 @@ mlp_fwd_kernel(MlpIO io, const h1* __restrict__ weights, int n_samples) {
                 *reinterpret_cast<half4_t*>(io.out16 + s * 16 + 4 * hh) = lo;
                 *reinterpret_cast<half4_t*>(io.out16 + s * 16 + 8 + 4 * hh) = hi;
             }
-            if (hh == 0) io.sigmas[io.scatter ? (long long)io.scatter[s] : s] = __expf((float)lo[0]);   // TruncExp fwd on the f16 h[0] (networks.py:105)
+            if (hh == 0) {
+                const float sg = __expf((float)lo[0]);                 // TruncExp fwd on the f16 h[0] (networks.py:105)
+                // scatter (occupancy update): a cell drawn twice keeps the LARGER of its densities -- sigma >= 0, so the order of the
+                // bit patterns is the order of the values and an integer max decides, whatever order the stores arrive in.  (torch's
+                // indexed assignment, networks.py:256-258, keeps "one of them", unspecified on CUDA: with a plain store here two runs of
+                // the same training diverged from the first sampled update on, step 256.)  The target is zero-filled by the caller.
+                if (io.scatter) atomicMax(reinterpret_cast<unsigned int*>(io.sigmas + (long long)io.scatter[s]), __float_as_uint(sg));
+                else io.sigmas[s] = sg;
+            }
         } else if (OUT_MODE == OUT_RGB) {
             if (hh == 0) {
 #pragma unroll
