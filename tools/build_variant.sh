@@ -10,7 +10,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -fhip-fp32
 if [ "$src" == "mlp.hip" ]; then FLAGS="$FLAGS -mllvm -amdgpu-mfma-vgpr-form"; fi
 /opt/rocm/bin/hipcc $FLAGS "$@" -c $src -o variants/${src%.hip}_$name.o
 objs=""
-for f in march composite hashgrid mlp optim occupancy hashgrid_bwd_binned stepper; do
+for f in march composite hashgrid mlp optim occupancy hashgrid_bwd_binned stepper comm; do
   if [ "$f.hip" == "$src" ]; then objs="$objs variants/${f}_$name.o"; else objs="$objs $f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o variants/libngp_hip_$name.so
