@@ -638,6 +638,11 @@ int ngp_sample_rays(const float* poses, const float* directions, const float* im
                     float* rays_o, float* rays_d, float* rgb, float* noise,
                     int32_t* img_idx, int32_t* pix_idx, ngp_stream_t stream);
 
+/* datasets/ray_utils.py:50-74 get_rays for one camera: rays_d (n,3) = directions (n,3) @ c2w[:, :3].T (not normalised),
+ * rays_o (n,3) = the camera centre c2w[:, 3] repeated.  c2w (3,4) f32 row-major ON THE DEVICE.  (The reference's FPS figure
+ * times ray generation together with render(): test.ipynb cell 2.) */
+int ngp_get_rays(const float* directions, const float* c2w, int n, float* rays_o, float* rays_d, ngp_stream_t stream);
+
 /* ---- occupancy-grid maintenance -------------------------------------------------------- */
 
 /* density-only forward whose sigma of sample s is stored at sigmas_out[scatter_idx[s]]

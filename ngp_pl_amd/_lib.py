@@ -138,6 +138,7 @@ _PROTOS = {
     "ngp_bg_blend_bw": [P, P, P, I, P, P],
     "ngp_compact_alive": [P, P, I, P, P, P, P],
     "ngp_sample_rays": [P, P, P, I, I, I, C.c_uint64, P, P, P, P, P, P, P],
+    "ngp_get_rays": [P, P, I, P, P, P],
     "ngp_abi_version": [],
     "ngp_march_guard_read": [P, I],
     "ngp_march_guard_first": [P],

@@ -373,6 +373,22 @@ sample_rays_kernel(const float* __restrict__ poses, const float* __restrict__ di
 }
 
 
+// datasets/ray_utils.py:50-74 get_rays for ONE camera: rays_d = directions @ c2w[:, :3].T (not normalised), rays_o = camera centre
+// repeated -- one launch instead of torch's GEMM + expand + two contiguous copies (60 us of a 1.6 ms frame in the FPS protocol,
+// which times ray generation together with render(), test.ipynb cell 2).
+__global__ void __launch_bounds__(256)
+get_rays_kernel(const float* __restrict__ directions, const float* __restrict__ c2w, int n,
+                float* __restrict__ rays_o, float* __restrict__ rays_d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float dx = directions[3 * (size_t)i], dy = directions[3 * (size_t)i + 1], dz = directions[3 * (size_t)i + 2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        rays_d[3 * (size_t)i + k] = (dx * c2w[4 * k] + dy * c2w[4 * k + 1]) + dz * c2w[4 * k + 2];
+        rays_o[3 * (size_t)i + k] = c2w[4 * k + 3];
+    }
+}
+
 // GradScaler's inf check (torch.amp.GradScaler.unscale_ -> _amp_foreach_non_finite_check_and_unscale_) on a native
 // gradient buffer: flag[0] |= 1 if any element is inf/NaN.  16 bytes per lane and trip; f16 exponent all-ones test on the raw bits.
 __global__ void __launch_bounds__(256)
@@ -566,6 +582,14 @@ int ngp_adam_step_field_pieces(float* grid_param, ngp_half* grid_param_h, const 
     const AdamMlp b = {rgb_param, (h1*)rgb_param_h, rgb_partials, rgb_m, rgb_v, n_rgb, ngp_div_up(n_rgb, 32)};
     hipLaunchKernelGGL(adam_field_pieces_kernel, dim3(a.blocks + b.blocks + dense_blocks), dim3(256), 0, ngp_stream(stream), grid_param,
                        (h1*)grid_param_h, (const h1*)shard_grad, grid_m, grid_v, pc, a, b, n_partials, hp);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_get_rays(const float* directions, const float* c2w, int n, float* rays_o, float* rays_d, ngp_stream_t stream) {
+    if (n < 0) return NGP_EINVAL;
+    if (n == 0) return 0;
+    NGP_CHECK_PTR(directions); NGP_CHECK_PTR(c2w); NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d);
+    hipLaunchKernelGGL(get_rays_kernel, dim3(ngp_div_up(n, 256)), dim3(256), 0, ngp_stream(stream), directions, c2w, n, rays_o, rays_d);
     return NGP_LAUNCH_RESULT();
 }
 

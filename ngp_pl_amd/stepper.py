@@ -60,7 +60,7 @@ class StepBuffers:
         # steps of the occupancy warm-up) go to the one-pass sliced kernel, which needs no workspace
         self.bin_max, self.bin_bytes = 0, 0
         if binned:
-            s = min(self.cap, 1 << 20)
+            s = min(self.cap, 2304 * 1024)
             while s > 0 and not lib.ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(enc.meta), s):
                 s -= 1024
             self.bin_max = max(s, 0)

@@ -37,7 +37,17 @@ def get_ray_directions(H, W, K, device="cpu"):
 
 
 def get_rays(directions, c2w):
-    """datasets/ray_utils.py:46-70: rays_d = R @ dir (NOT normalised), rays_o = camera centre."""
+    """datasets/ray_utils.py:46-70: rays_d = R @ dir (NOT normalised), rays_o = camera centre.  One camera, CUDA tensors, no
+    gradient wanted: one native launch (ngp_get_rays); otherwise torch ops (differentiable: pose optimisation, train.py:86-89)."""
+    if c2w.ndim == 2 and directions.is_cuda and c2w.is_cuda and directions.dtype == torch.float32 and c2w.dtype == torch.float32 \
+            and not (torch.is_grad_enabled() and (directions.requires_grad or c2w.requires_grad)):
+        from ._lib import call, device_guard, ptr, stream
+        d = directions if directions.is_contiguous() else directions.contiguous()
+        p = c2w if c2w.is_contiguous() else c2w.contiguous()
+        rays_o = torch.empty_like(d); rays_d = torch.empty_like(d)
+        with device_guard(d.device):
+            call("ngp_get_rays", ptr(d), ptr(p), d.shape[0], ptr(rays_o), ptr(rays_d), stream())
+        return rays_o, rays_d
     if c2w.ndim == 2:
         rays_d = directions @ c2w[:, :3].T
     else:

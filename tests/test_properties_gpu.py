@@ -339,3 +339,19 @@ def test_composite_pair_without_the_scan_kernel_equals_the_pair_with_it(n_rays):
         assert torch.equal(a[k], b[k]), k
     assert torch.equal(a["active"][:n_act], b["active"][:n_act]) and torch.equal(a["x_act"][:n_act], b["x_act"][:n_act])
     assert torch.allclose(a["stats"], b["stats"], rtol=1e-5, atol=0), (a["stats"], b["stats"])
+
+
+def test_native_get_rays_matches_the_torch_statement():
+    """ngp_get_rays (one launch) vs datasets/ray_utils.py:50-74 written with torch ops: origins exact, directions to float rounding
+    of a 3-term dot product; tensors that want a gradient keep the differentiable torch path."""
+    from ngp_pl_amd import synthetic as syn
+    dirs = syn.get_ray_directions(123, 77, syn.intrinsics(123, 77), device="cuda")
+    pose = syn.hemisphere_poses(3, seed=4)[1].cuda()
+    ro, rd = syn.get_rays(dirs, pose)
+    want_d = dirs @ pose[:, :3].T
+    assert ro.shape == rd.shape == dirs.shape and ro.is_contiguous() and rd.is_contiguous()
+    assert torch.equal(ro, pose[:, 3].expand_as(dirs)) and float((rd - want_d).abs().max()) <= 2e-6 * float(want_d.abs().max())
+    p2 = pose.clone().requires_grad_(True)
+    ro2, rd2 = syn.get_rays(dirs, p2)
+    (rd2.sum() + ro2.sum()).backward()
+    assert p2.grad is not None and float(p2.grad.abs().max()) > 0
