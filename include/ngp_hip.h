@@ -389,6 +389,23 @@ int ngp_hashgrid_bwd_binned_group(const float* x, const float* xyz_min, const fl
                                   const int32_t* active_idx, const int32_t* n_active,
                                   void* workspace, size_t workspace_bytes, ngp_half* grad_table,
                                   int n_groups, int group, ngp_stream_t stream);
+/* The same backward (one launch group) WITHOUT its last launch: the coarse dense levels, whose lists are split over K tasks, are
+ * left as K partial f32 tables each in the workspace, described by *partials_out; grad_table holds the gradient of every OTHER
+ * level.  ngp_adam_step_field_merge reads the partials itself (same sums in the same order, the same f16 rounding: the update is
+ * bit-identical to merge + ngp_adam_step_field).  The record is valid until the workspace is written again. */
+typedef struct ngp_grid_partials {
+    int32_t n_levels, reserved;                 /* levels 0 .. n_levels-1 (the table's first entries) come as partials */
+    int64_t value_end;                          /* 2 x offset[n_levels]: gradient VALUES below this index are not in grad_table */
+    uint32_t offset[NGP_MAX_LEVELS + 1];        /* entry offsets of those levels */
+    int32_t k_split[NGP_MAX_LEVELS];            /* partial tables per level */
+    int64_t part_off[NGP_MAX_LEVELS];           /* entry offset of level l's first partial table inside `partial` (then + k x size) */
+    const float* partial;                       /* (entries, 2) f32, device */
+} ngp_grid_partials;
+int ngp_hashgrid_bwd_binned_deferred(const float* x, const float* xyz_min, const float* xyz_max,
+                                     const ngp_half* dfeats, const ngp_grid_meta* meta, int n_samples,
+                                     const int32_t* active_idx, const int32_t* n_active,
+                                     void* workspace, size_t workspace_bytes, ngp_half* grad_table,
+                                     ngp_grid_partials* partials_out, ngp_stream_t stream);
 int ngp_hashgrid_bwd_binned_group_entries(const ngp_grid_meta* meta, int n_samples, int n_groups, int group,
                                           int64_t* entry_begin, int64_t* entry_end);
 
@@ -531,6 +548,18 @@ int ngp_adam_step_field(float* grid_param, ngp_half* grid_param_h, ngp_half* gri
                         int n_partials, float lr, float beta1, float beta2, float eps,
                         float weight_decay, int step, float grad_scale, int zero_grid_grad,
                         const int32_t* found_inf, int32_t* step_state, ngp_stream_t stream);
+/* ... with the gradient of the table's first levels taken from the partial tables ngp_hashgrid_bwd_binned_deferred left behind. */
+int ngp_adam_step_field_merge(float* grid_param, ngp_half* grid_param_h, ngp_half* grid_grad,
+                              float* grid_m, float* grid_v, int64_t n_grid,
+                              float* density_param, ngp_half* density_param_h,
+                              const float* density_partials, float* density_m, float* density_v,
+                              int n_density,
+                              float* rgb_param, ngp_half* rgb_param_h, const float* rgb_partials,
+                              float* rgb_m, float* rgb_v, int n_rgb,
+                              int n_partials, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, int step, float grad_scale,
+                              const int32_t* found_inf, int32_t* step_state, const ngp_grid_partials* partials,
+                              ngp_stream_t stream);
 /* step_state (may be NULL: `step` is the bias-correction step, as everywhere else): 4 x i32 on the device holding the number of
  * APPLIED steps -- {MLP blocks: slot 0, slot 1; grid block: slot 0, slot 1}, zeroed (or set to the steps already taken) by the
  * caller once.  With it `step` is the 1-based number of this CALL: the launch reads slot (step - 1) & 1, corrects the bias for
@@ -810,6 +839,10 @@ int ngp_stepper_front(ngp_stepper* s, const float* rays_o, const float* rays_d, 
                       const float* next_o, const float* next_d, float loss_scale, float grad_scale,
                       ngp_stream_t main_stream, ngp_stream_t march_stream, int32_t* n_samples, int32_t* n_partials);
 int ngp_stepper_table_backward(ngp_stepper* s, int n_groups, int group, ngp_stream_t main_stream);
+/* table_backward(1, 0) + update() of the single-process step in ONE call, with the dense levels' merge folded into the Adam launch
+ * (ngp_hashgrid_bwd_binned_deferred + ngp_adam_step_field_merge: one launch and one pass over 0.5 M entries less on the critical
+ * path; bit-identical parameters).  NGP_MERGE_IN_ADAM=0 keeps the separate merge launch. */
+int ngp_stepper_backward_update(ngp_stepper* s, float lr, int32_t step, float grad_scale, ngp_stream_t main_stream);
 /* The same step split where the reference's API splits it (render() -> NeRFLoss -> autograd, rendering.py:121-163, losses.py:47-60):
  * render_forward = front() up to the composite WITHOUT the loss (plain ngp_composite_train_fw + ngp_active_scan), the
  * background blend into rgb_out (R,3; may be NULL) and the next batch's march; the per-ray / per-sample results stay in the

@@ -51,6 +51,12 @@ class StepBuffersC(C.Structure):
          ("fw_ws", P), ("fw_bytes", C.c_size_t), ("bin_ws", P), ("bin_bytes", C.c_size_t), ("bin_max", C.c_int32)]
 
 
+class GridPartials(C.Structure):
+    """ngp_grid_partials (include/ngp_hip.h)."""
+    _fields_ = [("n_levels", C.c_int32), ("reserved", C.c_int32), ("value_end", C.c_int64), ("offset", C.c_uint32 * (NGP_MAX_LEVELS + 1)),
+                ("k_split", C.c_int32 * NGP_MAX_LEVELS), ("part_off", C.c_int64 * NGP_MAX_LEVELS), ("partial", P)]
+
+
 class ExchangeConfig(C.Structure):
     """ngp_exchange_config (include/ngp_hip.h)."""
     _fields_ = [("mode", C.c_int32), ("n_chunks", C.c_int32), ("n_groups", C.c_int32), ("reserved", C.c_int32), ("piece", C.c_int64),
@@ -113,6 +119,9 @@ _PROTOS = {
     "ngp_adam_step_partials": [P, P, P, I, P, P, I, F, F, F, F, F, I, F, P, P],
     "ngp_adam_step_field": [P, P, P, P, P, L, P, P, P, P, P, I, P, P, P, P, P, I, I, F, F, F, F, F, I, F, I, P, P, P],
     "ngp_adam_step_field_shard": [P, P, P, P, P, L, P, P, P, P, P, I, P, P, P, P, P, I, I, F, F, F, F, F, I, F, P, P, P, P],
+    "ngp_adam_step_field_merge": [P, P, P, P, P, L, P, P, P, P, P, I, P, P, P, P, P, I, I, F, F, F, F, F, I, F, P, P, C.POINTER(GridPartials), P],
+    "ngp_hashgrid_bwd_binned_deferred": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P, C.c_size_t, P, C.POINTER(GridPartials), P],
+    "ngp_stepper_backward_update": [P, F, I, F, P],
     "ngp_adam_step_field_pieces": [P, P, P, P, P, L, L, I, I, I, P, P, P, P, P, I, P, P, P, P, P, I, I, F, F, F, F, F, I, F, P, P, P, P],
     "ngp_comm_unique_id": [P],
     "ngp_comm_create": [P, I, I, C.POINTER(P)],

@@ -734,10 +734,12 @@ int ngp_hashgrid_bwd_binned_group_entries(const ngp_grid_meta* meta, int n_sampl
     return 0;
 }
 
-int ngp_hashgrid_bwd_binned_group(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* dfeats,
-                                  const ngp_grid_meta* meta, int n_samples, const int32_t* active_idx,
-                                  const int32_t* n_active, void* workspace, size_t workspace_bytes,
-                                  ngp_half* grad_table, int n_groups, int group, ngp_stream_t stream) {
+// partials_out != NULL (ngp_hashgrid_bwd_binned_deferred): the merge of the K-split levels' partial tables is left to the consumer
+// of the gradient (the fused Adam reads the K partials itself) and *partials_out says where they are.
+static int binned_group_impl(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* dfeats,
+                             const ngp_grid_meta* meta, int n_samples, const int32_t* active_idx,
+                             const int32_t* n_active, void* workspace, size_t workspace_bytes,
+                             ngp_half* grad_table, int n_groups, int group, ngp_grid_partials* partials_out, ngp_stream_t stream) {
     if (n_samples < 0 || !meta || meta->n_features != 2 || meta->n_levels < 1 || meta->n_levels > NGP_MAX_LEVELS) return NGP_EINVAL;
     if (n_groups < 1 || n_groups > 16 || group < 0 || group >= n_groups) return NGP_EINVAL;
     NGP_CHECK_PTR(grad_table); NGP_CHECK_PTR(workspace);
@@ -783,9 +785,39 @@ int ngp_hashgrid_bwd_binned_group(const float* x, const float* xyz_min, const fl
         apply_kernel<<<dim3(n_wg), dim3(APPLY_THREADS), smem, st>>>(
             x, xyz_min, xyz_max, (const half2_t*)dfeats, dm, P, ws, n_samples, active_idx, n_active, (half2_t*)grad_table, group, task_begin, task_end);
     }
-    if (group == 0 && L.merge_entries > 0)      // the K-split levels all sit in group 0
+    if (partials_out != nullptr) {
+        // the K-split levels must be a prefix of the table (coarse levels first: true for every grid this package builds)
+        ngp_grid_partials& o = *partials_out;
+        int nd = 0;
+        while (nd < meta->n_levels && P.k_split[nd] > 1) ++nd;
+        for (int l = nd; l < meta->n_levels; ++l) if (P.k_split[l] > 1) return NGP_EUNSUP;
+        o.n_levels = nd;
+        for (int l = 0; l < NGP_MAX_LEVELS; ++l) { o.k_split[l] = 1; o.part_off[l] = 0; }
+        for (int l = 0; l <= NGP_MAX_LEVELS; ++l) o.offset[l] = meta->offset[l < nd ? l : nd];
+        for (int l = 0; l < nd; ++l) { o.k_split[l] = P.k_split[l]; o.part_off[l] = P.part_off[l]; }
+        o.value_end = 2 * (int64_t)meta->offset[nd];
+        o.partial = reinterpret_cast<const float*>(ws.partial);
+    } else if (group == 0 && L.merge_entries > 0) {     // the K-split levels all sit in group 0
         merge_kernel<<<dim3(ngp_div_up(L.merge_entries, 256)), dim3(256), 0, st>>>(dm, P, ws, (half2_t*)grad_table);
+    }
     return NGP_LAUNCH_RESULT();
+}
+
+int ngp_hashgrid_bwd_binned_group(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* dfeats,
+                                  const ngp_grid_meta* meta, int n_samples, const int32_t* active_idx,
+                                  const int32_t* n_active, void* workspace, size_t workspace_bytes,
+                                  ngp_half* grad_table, int n_groups, int group, ngp_stream_t stream) {
+    return binned_group_impl(x, xyz_min, xyz_max, dfeats, meta, n_samples, active_idx, n_active, workspace, workspace_bytes, grad_table,
+                             n_groups, group, nullptr, stream);
+}
+
+int ngp_hashgrid_bwd_binned_deferred(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* dfeats,
+                                     const ngp_grid_meta* meta, int n_samples, const int32_t* active_idx,
+                                     const int32_t* n_active, void* workspace, size_t workspace_bytes,
+                                     ngp_half* grad_table, ngp_grid_partials* partials_out, ngp_stream_t stream) {
+    NGP_CHECK_PTR(partials_out);
+    return binned_group_impl(x, xyz_min, xyz_max, dfeats, meta, n_samples, active_idx, n_active, workspace, workspace_bytes, grad_table,
+                             1, 0, partials_out, stream);
 }
 
 int ngp_hashgrid_bwd_binned(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* dfeats,

@@ -37,11 +37,17 @@ __device__ __forceinline__ void adam_bias_from_state(AdamHyper& h, bool dense, b
     if (writer && threadIdx.x == 0) st[h.slot ^ 1] = skip ? applied : applied + 1;
 }
 
+// The coarse dense levels of the grid, whose gradient the binned table backward leaves as K partial f32 tables per level
+// (ngp_grid_partials, include/ngp_hip.h): device-side copy of the record.
+struct GridPartials { long long value_end; uint32_t offset[8]; int k_split[8]; long long part_off[8]; const float2* partial; int n_levels; };
+
 // Dense (streaming) update of n parameters by workgroups `block` of `n_blocks`, 4 parameters per thread and trip.
-template <bool GRAD_F32>
+// MERGE: gradient values below gp.value_end are formed here from the K partial tables -- summed in part order in f32 and rounded to
+// f16 exactly as merge_kernel (hashgrid_bwd_binned.hip) does, so the update is bit-identical to merge + this kernel without MERGE.
+template <bool GRAD_F32, bool MERGE = false>
 __device__ __forceinline__ void adam_dense(float* __restrict__ param, h1* __restrict__ param_h, void* __restrict__ grad,
                                            float* __restrict__ m, float* __restrict__ v, long long n4, long long n,
-                                           const AdamHyper& hp, int block, int n_blocks) {
+                                           const AdamHyper& hp, int block, int n_blocks, const GridPartials* gp = nullptr) {
     const float lr = hp.lr, beta1 = hp.beta1, beta2 = hp.beta2, eps = hp.eps, wd = hp.wd, bc1 = hp.bc1, bc2 = hp.bc2, inv_scale = hp.inv_scale;
     const bool skip = hp.found_inf_dense != nullptr && *hp.found_inf_dense != 0;
     const long long stride = (long long)n_blocks * blockDim.x;
@@ -50,14 +56,27 @@ __device__ __forceinline__ void adam_dense(float* __restrict__ param, h1* __rest
         float g[4];
         const int cnt = (int)((n - base) < 4 ? (n - base) : 4);
         if (cnt == 4) {
-            if (GRAD_F32) {
-                float4* gp = reinterpret_cast<float4*>(reinterpret_cast<float*>(grad) + base);
-                const float4 t = *gp; g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w;
-                if (hp.zero_grad) *gp = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (MERGE && base < gp->value_end) {
+                // two entries of one level (levels are multiples of 8 entries long): sum their K partials
+                const uint32_t e0 = (uint32_t)(base >> 1);
+                int l = 0;
+                while (l + 1 < gp->n_levels && e0 >= gp->offset[l + 1]) ++l;
+                const uint32_t size = gp->offset[l + 1] - gp->offset[l];
+                const float2* __restrict__ p = gp->partial + gp->part_off[l] + (e0 - gp->offset[l]);
+                float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
+                for (int k = 0; k < gp->k_split[l]; ++k) {
+                    const float4 t = *reinterpret_cast<const float4*>(p + (size_t)k * size);
+                    a0 += t.x; b0 += t.y; a1 += t.z; b1 += t.w;
+                }
+                g[0] = (float)(h1)a0; g[1] = (float)(h1)b0; g[2] = (float)(h1)a1; g[3] = (float)(h1)b1;
+            } else if (GRAD_F32) {
+                float4* gp4 = reinterpret_cast<float4*>(reinterpret_cast<float*>(grad) + base);
+                const float4 t = *gp4; g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w;
+                if (hp.zero_grad) *gp4 = make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
-                half4_t* gp = reinterpret_cast<half4_t*>(reinterpret_cast<h1*>(grad) + base);
-                const half4_t t = *gp; g[0] = (float)t[0]; g[1] = (float)t[1]; g[2] = (float)t[2]; g[3] = (float)t[3];
-                if (hp.zero_grad) { const half4_t z = {0, 0, 0, 0}; *gp = z; }
+                half4_t* gp4 = reinterpret_cast<half4_t*>(reinterpret_cast<h1*>(grad) + base);
+                const half4_t t = *gp4; g[0] = (float)t[0]; g[1] = (float)t[1]; g[2] = (float)t[2]; g[3] = (float)t[3];
+                if (hp.zero_grad) { const half4_t z = {0, 0, 0, 0}; *gp4 = z; }
             }
             if (skip) continue;
             float4 p = *reinterpret_cast<float4*>(param + base);
@@ -227,6 +246,18 @@ adam_field_pieces_kernel(float* __restrict__ param, h1* __restrict__ param_h, co
     if (blk < a.blocks) adam_from_partials(a.param, a.param_h, a.partials, n_partials, a.m, a.v, a.n, hp, blk, s_acc);
     else if (!dense) adam_from_partials(b.param, b.param_h, b.partials, n_partials, b.m, b.v, b.n, hp, blk - a.blocks, s_acc);
     else adam_dense_pieces(param, param_h, shard16, m, v, pc, hp, blk - a.blocks - b.blocks, (int)gridDim.x - a.blocks - b.blocks);
+}
+
+__global__ void __launch_bounds__(256)
+adam_field_merge_kernel(float* __restrict__ param, h1* __restrict__ param_h, void* __restrict__ grad16, float* __restrict__ m,
+                        float* __restrict__ v, long long n4, long long n, AdamMlp a, AdamMlp b, int n_partials, AdamHyper hp, GridPartials gp) {
+    __shared__ float s_acc[8][32];
+    const int blk = blockIdx.x;
+    const bool dense = blk >= a.blocks + b.blocks;
+    adam_bias_from_state(hp, dense, blk == 0 || blk == a.blocks + b.blocks);
+    if (blk < a.blocks) adam_from_partials(a.param, a.param_h, a.partials, n_partials, a.m, a.v, a.n, hp, blk, s_acc);
+    else if (!dense) adam_from_partials(b.param, b.param_h, b.partials, n_partials, b.m, b.v, b.n, hp, blk - a.blocks, s_acc);
+    else adam_dense<false, true>(param, param_h, grad16, m, v, n4, n, hp, blk - a.blocks - b.blocks, (int)gridDim.x - a.blocks - b.blocks, &gp);
 }
 
 __global__ void __launch_bounds__(256)
@@ -544,6 +575,47 @@ int ngp_adam_step_field(float* grid_param, ngp_half* grid_param_h, ngp_half* gri
     return adam_step_field_impl(grid_param, grid_param_h, grid_grad, grid_m, grid_v, n_grid, density_param, density_param_h, density_partials,
                                 density_m, density_v, n_density, rgb_param, rgb_param_h, rgb_partials, rgb_m, rgb_v, n_rgb, n_partials, lr,
                                 beta1, beta2, eps, weight_decay, step, grad_scale, zero_grid_grad, found_inf, found_inf, step_state, stream);
+}
+
+int ngp_adam_step_field_merge(float* grid_param, ngp_half* grid_param_h, ngp_half* grid_grad, float* grid_m, float* grid_v, int64_t n_grid,
+                              float* density_param, ngp_half* density_param_h, const float* density_partials, float* density_m,
+                              float* density_v, int n_density, float* rgb_param, ngp_half* rgb_param_h, const float* rgb_partials,
+                              float* rgb_m, float* rgb_v, int n_rgb, int n_partials, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, int step, float grad_scale, const int32_t* found_inf, int32_t* step_state,
+                              const ngp_grid_partials* partials, ngp_stream_t stream) {
+    if (!partials) return NGP_EINVAL;
+    const ngp_grid_partials& q = *partials;
+    if (q.n_levels < 0 || q.n_levels > 8 || q.value_end < 0 || q.value_end > n_grid || (q.value_end & 3)) return NGP_EINVAL;
+    if (q.n_levels == 0)
+        return ngp_adam_step_field(grid_param, grid_param_h, grid_grad, grid_m, grid_v, n_grid, density_param, density_param_h, density_partials, density_m,
+                                   density_v, n_density, rgb_param, rgb_param_h, rgb_partials, rgb_m, rgb_v, n_rgb, n_partials, lr, beta1, beta2, eps,
+                                   weight_decay, step, grad_scale, 0, found_inf, step_state, stream);
+    if (n_grid <= 0 || n_density <= 0 || n_rgb <= 0 || n_partials < 0 || step < 1 || grad_scale == 0.f) return NGP_EINVAL;
+    NGP_CHECK_PTR(grid_param); NGP_CHECK_PTR(grid_grad); NGP_CHECK_PTR(grid_m); NGP_CHECK_PTR(grid_v); NGP_CHECK_PTR(q.partial);
+    NGP_CHECK_PTR(density_param); NGP_CHECK_PTR(density_m); NGP_CHECK_PTR(density_v);
+    NGP_CHECK_PTR(rgb_param); NGP_CHECK_PTR(rgb_m); NGP_CHECK_PTR(rgb_v);
+    if (n_partials > 0) { NGP_CHECK_PTR(density_partials); NGP_CHECK_PTR(rgb_partials); }
+    GridPartials gp;
+    gp.value_end = q.value_end; gp.n_levels = q.n_levels; gp.partial = reinterpret_cast<const float2*>(q.partial);
+    for (int l = 0; l < 8; ++l) {
+        gp.offset[l] = q.offset[l < q.n_levels ? l : q.n_levels];
+        gp.k_split[l] = l < q.n_levels ? q.k_split[l] : 1;
+        gp.part_off[l] = l < q.n_levels ? q.part_off[l] : 0;
+        if (l < q.n_levels && (((q.offset[l + 1] - q.offset[l]) & 1u) || (q.part_off[l] & 1) || q.k_split[l] < 1)) return NGP_EINVAL;   // 16-byte loads of entry pairs
+    }
+    if (q.n_levels == 8) return NGP_EUNSUP;                                   // offset[l + 1] of the last level would not fit the device record
+    gp.offset[q.n_levels] = q.offset[q.n_levels];
+    if (2 * (int64_t)q.offset[q.n_levels] != q.value_end) return NGP_EINVAL;
+    AdamHyper hp = adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale, found_inf);
+    hp.zero_grad = 0;
+    hp.step_state = step_state; hp.slot = (step - 1) & 1;
+    const long long n4 = (n_grid + 3) / 4;
+    const int dense_blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    const AdamMlp a = {density_param, (h1*)density_param_h, density_partials, density_m, density_v, n_density, ngp_div_up(n_density, 32)};
+    const AdamMlp b = {rgb_param, (h1*)rgb_param_h, rgb_partials, rgb_m, rgb_v, n_rgb, ngp_div_up(n_rgb, 32)};
+    hipLaunchKernelGGL(adam_field_merge_kernel, dim3(a.blocks + b.blocks + dense_blocks), dim3(256), 0, ngp_stream(stream), grid_param,
+                       (h1*)grid_param_h, (void*)grid_grad, grid_m, grid_v, n4, (long long)n_grid, a, b, n_partials, hp, gp);
+    return NGP_LAUNCH_RESULT();
 }
 
 int ngp_adam_step_field_shard(float* grid_param, ngp_half* grid_param_h, ngp_half* grid_grad, float* grid_m, float* grid_v, int64_t n_shard,

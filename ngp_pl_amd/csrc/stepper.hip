@@ -50,6 +50,7 @@ struct ngp_stepper {
     hipStream_t next_main = nullptr, next_side = nullptr;
     int march_at = 2;
     // two-round forward (include/ngp_hip.h): mode 0 off / 1 on / 2 auto, first K, the auto switch's state, steps run in two rounds
+    int merge_in_adam = 1;                 // NGP_MERGE_IN_ADAM (default 1): ngp_stepper_backward_update folds the dense levels' merge into the Adam launch
     int fused_tail = 1;                    // NGP_FUSED_TAIL (default 1): composite forward / backward without the scan kernel between them
     int two_round_mode = 2, two_round_k = 32;
     bool two_round_active = false, two_rounds = false;
@@ -200,6 +201,7 @@ int ngp_stepper_create(const ngp_stepper_config* config, const ngp_step_buffers*
     s->march_at = march_at_from_env();
     if (const char* e = getenv("NGP_TWO_ROUND")) s->two_round_mode = strcmp(e, "on") == 0 ? 1 : (strcmp(e, "off") == 0 ? 0 : 2);
     if (const char* e = getenv("NGP_FUSED_TAIL")) s->fused_tail = atoi(e) != 0;
+    if (const char* e = getenv("NGP_MERGE_IN_ADAM")) s->merge_in_adam = atoi(e) != 0;
     if (const char* e = getenv("NGP_TWO_ROUND_K")) { const int k = atoi(e); if (k >= 1 && k <= 64) s->two_round_k = k; }
     (void)hipGetDevice(&s->device);
     hipError_t e = hipSuccess;
@@ -519,6 +521,32 @@ int ngp_stepper_update(ngp_stepper* s, float lr, int32_t step, float grad_scale,
                                  c.enc_param, c.enc_half, density_partials, c.enc_m, c.enc_v, c.n_density,
                                  c.rgb_param, c.rgb_half, rgb_partials, c.rgb_m, c.rgb_v, c.n_rgb,
                                  n_partials, lr, c.beta1, c.beta2, c.eps, c.weight_decay, step, grad_scale, 0, found_inf, step_state, main_stream));
+    mark(s, 8, ngp_stream(main_stream));
+    STEP_TRY(march_next_if_at(s, AT_ADAM));
+    return 0;
+}
+
+int ngp_stepper_backward_update(ngp_stepper* s, float lr, int32_t step, float grad_scale, ngp_stream_t main_stream) {
+    if (!s || step < 1) return NGP_EINVAL;
+    if (s->comm) return NGP_EINVAL;                              // data parallel: ngp_stepper_tail
+    const ngp_stepper_config& c = s->c;
+    const ngp_step_buffers& b = s->b;
+    if (s->S <= 0 || !s->binned || !s->merge_in_adam || s->n_part < 1) {
+        STEP_TRY(ngp_stepper_table_backward(s, 1, 0, main_stream));
+        return s->S > 0 ? ngp_stepper_update(s, lr, step, grad_scale, nullptr, nullptr, 0, nullptr, nullptr, main_stream) : 0;
+    }
+    HostTimer host_timer(&s->t_enqueue);
+    if (!c.enc_param || !c.enc_m || !c.enc_v || !c.rgb_param || !c.rgb_m || !c.rgb_v) return NGP_EINVAL;
+    ngp_grid_partials gp;
+    const int rc = ngp_hashgrid_bwd_binned_deferred(b.x_act, c.xyz_min, c.xyz_max, b.dfeats, &c.meta, s->S, nullptr, b.n_active, b.bin_ws, b.bin_bytes,
+                                                    c.grid_grad16, &gp, main_stream);
+    if (rc) return rc;
+    mark(s, 7, ngp_stream(main_stream));
+    STEP_TRY(march_next_if_at(s, AT_HASHGRID_BWD));
+    STEP_TRY(ngp_adam_step_field_merge(c.enc_param + c.n_density, c.enc_half + c.n_density, c.grid_grad16, c.enc_m + c.n_density, c.enc_v + c.n_density, c.n_grid,
+                                       c.enc_param, c.enc_half, b.partials, c.enc_m, c.enc_v, c.n_density,
+                                       c.rgb_param, c.rgb_half, b.partials + (size_t)s->n_part * c.n_density, c.rgb_m, c.rgb_v, c.n_rgb,
+                                       s->n_part, lr, c.beta1, c.beta2, c.eps, c.weight_decay, step, grad_scale, nullptr, nullptr, &gp, main_stream));
     mark(s, 8, ngp_stream(main_stream));
     STEP_TRY(march_next_if_at(s, AT_ADAM));
     return 0;

@@ -303,9 +303,13 @@ class Trainer:
                 epoch = self.global_step // self.steps_per_epoch
                 lr = self.opt.param_groups[0]["lr"] = cosine_lr(self.base_lr, epoch, self.num_epochs)
                 if not hooks:
-                    call("ngp_stepper_table_backward", h, 1, 0, mq)
                     self.opt.t += 1
-                    call("ngp_stepper_update", h, lr, self.opt.t, self.loss_scale * self.grad_scale, None, None, 0, None, self.opt.step_state(None), mq)
+                    if self.opt._step_state is None:
+                        # table backward + fused Adam in ONE call (the dense levels' merge folded into the Adam launch)
+                        call("ngp_stepper_backward_update", h, lr, self.opt.t, self.loss_scale * self.grad_scale, mq)
+                    else:                                       # a device-side step count is in use (a skip flag was seen earlier)
+                        call("ngp_stepper_table_backward", h, 1, 0, mq)
+                        call("ngp_stepper_update", h, lr, self.opt.t, self.loss_scale * self.grad_scale, None, None, 0, None, self.opt.step_state(None), mq)
                     enc._half.mark_fresh(enc.params); net._half.mark_fresh(net.params)
                 else:
                     g16 = m._grid_grad16(dev)
