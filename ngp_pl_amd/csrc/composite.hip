@@ -259,12 +259,20 @@ composite_train_bw_kernel(const float* __restrict__ dL_dopacity, const float* __
         __shared__ float s_l[4], s_e[4];
         const int tid = threadIdx.x, wave = tid >> 6;
         const int row0 = 4 * (int)blockIdx.x;                              // rows in front of this workgroup: a multiple of 4
+        // all of a thread's loads first (8 x 16 bytes cover 8192 rows: one L2 round trip, not one per trip of a loop -- the first
+        // version's dependent trips added 8 us to a 12 us kernel, profiles/r04_kernel_trace_summary.txt), a loop only beyond that
+        int4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = 4 * tid + 1024 * q;
+            v[q] = i < row0 ? *reinterpret_cast<const int4*>(ray_offsets + i) : make_int4(0, 0, 0, 0);
+        }
         int acc = 0;
-        for (int i = 4 * tid; i < row0; i += 2048) {                       // two independent 16-byte loads per trip
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+        for (int i = 4 * tid + 8192; i < row0; i += 1024) {
             const int4 a = *reinterpret_cast<const int4*>(ray_offsets + i);
-            int4 b = make_int4(0, 0, 0, 0);
-            if (i + 1024 < row0) b = *reinterpret_cast<const int4*>(ray_offsets + i + 1024);
-            acc += ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
+            acc += (a.x + a.y) + (a.z + a.w);
         }
         acc = wave_sum_int(acc);
         if (lane == 0) s_part[wave] = acc;
