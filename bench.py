@@ -302,7 +302,7 @@ class Loop:
         if self.exchange is not None:          # the exchange stage on its own: 20 more steps with device events around it (all ranks alike)
             extra.update({"exchange": self.exchange_kind, "exchange_impl": self.exchange_impl})
             extra.update(self.time_exchange())
-            if hasattr(self.exchange, "switch_mode") and self.world > 1:
+            if hasattr(self.exchange, "switch_mode") and (self.world > 1 or os.environ.get("NGP_BENCH_BOTH_MODES") == "1"):
                 # the other mode on the same communicator and buffers ("sharded": reduce-scatter -> Adam on the rank's pieces ->
                 # all-gather; "allreduce": gradient all-reduce only, the reference's semantics literally): both exchange times in the line
                 other = "allreduce" if self.exchange_kind == "sharded" else "sharded"

@@ -65,7 +65,7 @@ def test_bench_under_a_one_rank_rccl_group(exchange):
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-               NGP_DDP_EXCHANGE=exchange, HSA_ENABLE_IPC_MODE_LEGACY="0")
+               NGP_DDP_EXCHANGE=exchange, HSA_ENABLE_IPC_MODE_LEGACY="0", NGP_BENCH_BOTH_MODES="1")      # (the other mode's leg, which only runs at world > 1 otherwise)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3", "--setup-steps", "48",
                         "--images", "8", "--res", "200", "--no-cpu-baseline", "--no-render", "--no-api"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400, env=env)
@@ -76,3 +76,7 @@ def test_bench_under_a_one_rank_rccl_group(exchange):
     assert "error" not in d, d.get("error")
     assert d["n_gpus"] == 1 and d["exchange"] == exchange and d["exchange_ms"] > 0 and d["value"] > 1e6 and d["exchange_impl"] == "native"
     assert d["config"]["train_psnr"] > 10 and d["march_guards"] == [0, 0, 0, 0]
+    other = "allreduce" if exchange == "sharded" else "sharded"
+    modes = d["exchange_modes"]
+    assert set(modes) == {"sharded", "allreduce"} and "error" not in modes[other], modes
+    assert modes[other]["exchange_ms"] > 0 and modes[other]["ms_per_step"] > 0 and modes[exchange]["exposed_exchange_ms"] is not None
