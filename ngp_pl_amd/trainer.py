@@ -245,8 +245,7 @@ class Trainer:
         dev = rays_o.device
         enc, net = m.xyz_encoder, m.rgb_net
         with self._device_guard(dev):
-            main = self._main = torch.cuda.current_stream()
-            mq = main.cuda_stream
+            mq = stream()                       # raw handle of torch's current stream (0.3 us; torch.cuda.current_stream() costs 12)
             sq = self.side.cuda_stream if self.side is not None else mq
             n = rays_o.shape[0]
             if not (rays_o.is_contiguous() and rays_d.is_contiguous() and rgb_gt.is_contiguous()):

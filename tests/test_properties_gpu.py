@@ -355,3 +355,14 @@ def test_native_get_rays_matches_the_torch_statement():
     ro2, rd2 = syn.get_rays(dirs, p2)
     (rd2.sum() + ro2.sum()).backward()
     assert p2.grad is not None and float(p2.grad.abs().max()) > 0
+
+
+def test_fast_stream_query_follows_torchs_current_stream():
+    """_lib.stream() asks torch's C entry point for the raw handle of the current stream (0.3 us instead of the 12 us of
+    torch.cuda.current_stream().cuda_stream): it must follow `torch.cuda.stream(...)` contexts like the public call."""
+    from ngp_pl_amd import _lib
+    assert _lib.stream() == torch.cuda.current_stream().cuda_stream
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        assert _lib.stream() == s.cuda_stream == torch.cuda.current_stream().cuda_stream
+    assert _lib.stream() == torch.cuda.current_stream().cuda_stream != s.cuda_stream
