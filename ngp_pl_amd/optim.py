@@ -22,6 +22,9 @@ import torch
 from ._lib import call, device_guard, ptr, stream
 
 
+_bump_version = getattr(torch._C, "_increment_version", None)
+
+
 def tag_parameters(model):
     """Called by NGP.__init__: lets an optimizer that is handed bare parameter tensors (train.py:123-131) find the model whose
     native gradient buffers they belong to.  The tags live on the Parameter objects (`.to(device)` keeps the objects)."""
@@ -196,9 +199,13 @@ class FusedAdam(torch.optim.Optimizer):
                     call("ngp_adam_step", ptr(p.data), ptr(half), ptr(p.grad), 1, ptr(m), ptr(v), p.numel(), group["lr"], b1, b2,
                          group["eps"], group["weight_decay"], self.state[p]["step"], float(grad_scale), ptr(found_inf),
                          stream_handle if stream_handle is not None else stream())
+                # the kernel wrote p behind autograd's back: bump the version counter, so that an f16 working copy this optimizer did
+                # NOT refresh (a module that lost its tag, e.g. a deep copy of the model) is re-cast at its next forward ...
+                if _bump_version is not None:
+                    _bump_version([p])
                 mod = self._module_of(p)
                 if mod is not None and half is not None:
-                    mod._half.mark_fresh(p)
+                    mod._half.mark_fresh(p)             # ... and one it did refresh is recorded as current for the new version
         return loss
 
     def _module_of(self, p):

@@ -230,3 +230,25 @@ def test_ngp_under_distributed_data_parallel_two_ranks_stay_identical():
     fire on the f32 gradients of the fused render node, the ranks start from rank 0's parameters and stay bit-identical although
     their batches differ."""
     _spawn(2, "gloo")
+
+
+def test_a_deep_copied_model_still_trains_correctly():
+    """`copy.deepcopy(model)` creates new Parameter objects without the tags FusedAdam uses to find the model and its f16 working
+    copies.  The optimizer then treats the tensors as plain ones (per-tensor kernel, f32 `.grad`) -- and bumps their version counters,
+    so the modules re-cast their working copies at the next forward instead of going on with stale ones."""
+    import copy
+    from ngp_pl_amd.optim import FusedAdam
+    model = copy.deepcopy(_make(seed=14))
+    system = _System(model)
+    opt = FusedAdam(_net_params(system), 1e-2, eps=1e-15)
+    assert opt.model is None
+    enc = model.xyz_encoder
+    for it in range(3):
+        ro, rd, gt = _batch(1024, 700 + it)
+        loss = _loss(system(ro, rd), gt)
+        opt.zero_grad()
+        loss.backward()
+        before = enc.params.detach().clone()
+        opt.step()
+        assert float((enc.params.detach() - before).abs().max()) > 1e-4
+        assert torch.equal(enc._half.get(enc.params), enc.params.detach().half())          # what the next forward will read
