@@ -8,7 +8,7 @@ OUT="$REPO/gpurun_out"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 FRAMES=${FRAMES:-20}
-for cfg in k4_cap64 device_exact; do
+for cfg in k2_cap64 device_exact; do
   rm -rf /tmp/kr_$cfg
   STEPS=${STEPS:-30000} FRAMES=$FRAMES CONFIG=$cfg timeout 400 rocprofv3 --kernel-trace -d /tmp/kr_$cfg -o r -- python $REPO/tools/render_trained.py > "$OUT/${TAG}_render_$cfg.out" 2> "$OUT/${TAG}_render_$cfg.err"
   DB=$(find /tmp/kr_$cfg -name "*.db" | head -1)
@@ -17,7 +17,7 @@ done
 python - "$OUT" "$TAG" <<'PY'
 import json, sys
 out, tag = sys.argv[1], sys.argv[2]
-a = json.load(open("%s/%s_render_trace_k4_cap64.json" % (out, tag)))
+a = json.load(open("%s/%s_render_trace_k2_cap64.json" % (out, tag)))
 b = json.load(open("%s/%s_render_trace_device_exact.json" % (out, tag)))
 a["reference_chunking"] = b
 json.dump(a, open("%s/%s_render_trace.json" % (out, tag), "w"), indent=1)
