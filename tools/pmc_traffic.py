@@ -17,7 +17,7 @@ STAGES = {   # stage of bench.py's roofline block -> kernels of that library cal
     "hashgrid_fwd": ["hashgrid_fwd_kernel"],
     "mlp_fwd": ["field_fwd_kernel"],
     "mlp_bwd": ["mlp_bwd_kernel"],
-    "adam": ["adam_field_kernel"],
+    "adam": ["adam_field"],
     "composite_fw+loss": ["composite_train_fw_kernel", "composite_fw_tail_kernel"],
     "composite_bw": ["composite_train_bw_kernel"],
     "march_write": ["march_train_write_kernel"],

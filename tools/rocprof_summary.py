@@ -22,7 +22,7 @@ def main():
     db = sqlite3.connect(sys.argv[1])
     n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
     rows = list(db.execute("select name, start, end, grid_x, workgroup_x, vgpr_count, accum_vgpr_count, lds_size from kernels order by start"))
-    marks = [i for i, r in enumerate(rows) if "adam_kernelILb0" in r[0] or "adam_field_kernel" in r[0]]
+    marks = [i for i, r in enumerate(rows) if "adam_kernelILb0" in r[0] or "adam_field" in r[0]]          # (adam_field_kernel / adam_field_merge_kernel / adam_field_pieces_kernel: one per step)
     skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     if skip:
         rows = rows[:marks[-skip - 1] + 1]; marks = marks[:-skip]
