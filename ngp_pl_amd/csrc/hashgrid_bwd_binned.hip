@@ -45,9 +45,10 @@ constexpr int BIN_THREADS = 512;             // binning workgroup: 4 of them are
 constexpr int BIN_SPT = NGP_BIN_SPT;         // samples per thread
 constexpr int CHUNK = BIN_THREADS * BIN_SPT; // samples per binning workgroup ("chunk")
 constexpr int CHUNK_SLOTS = CHUNK * 8;       // list entries a chunk can produce for one level (<= 8 slices per sample)
-constexpr int MAX_CHUNKS = 2304;             // 2.36 M samples: the first steps of a run (every cell still "occupied": ~2 M samples for 8192 rays) stay on
-                                             // this exact, deterministic path instead of the one-pass kernel, whose f16 LDS atomics round in arrival order
-                                             // -- round 3's bench runs diverged from step 0 on and landed on operating points 15 % apart
+constexpr int MAX_CHUNKS = 4608;             // 4.7 M samples: the first steps of a run (every cell still "occupied": ~245 samples per ray, 2 M for 8192
+                                             // rays, 4 M for 16 384) stay on this exact, deterministic path instead of the one-pass kernel, whose f16 LDS
+                                             // atomics round in arrival order -- round 3's bench runs diverged from step 0 on and landed on operating
+                                             // points 15 % apart.  (Two directory rows of this length sit in LDS next to the accumulators: 36 KB.)
 // Measured alternative, compiled out by default (NGP_BIN_PAYLOAD=1 builds it; profiles/r03_table_backward_experiments.txt):
 // hashed levels hand the slice owner everything it needs in the list entry itself (12 bytes):
 //   word 0: l0 | l1 << 13      slice-local indices of the pair's two corners (x, .) and (x+1, .); PAY_INVALID = not in this slice

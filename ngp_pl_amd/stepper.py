@@ -60,7 +60,9 @@ class StepBuffers:
         # steps of the occupancy warm-up) go to the one-pass sliced kernel, which needs no workspace
         self.bin_max, self.bin_bytes = 0, 0
         if binned:
-            s = min(self.cap, 2304 * 1024)
+            # workspace for up to 288 samples per ray (the first steps of a run, when every cell still counts as occupied, march ~245),
+            # at most the kernels' 4608 chunks of 1024: larger batches fall to the one-pass kernel
+            s = min(self.cap, -(-288 * n_rays // 1024) * 1024, 4608 * 1024)
             while s > 0 and not lib.ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(enc.meta), s):
                 s -= 1024
             self.bin_max = max(s, 0)

@@ -175,7 +175,7 @@ def test_workspace_queries_and_new_entry_points_validate_on_host():
     # binned backward: chunk slots of 8 entries per sample and level; refuses batches beyond 1024 chunks
     w = lib.ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(meta), 300000)
     assert 16 * 300000 * 8 * 4 <= w < 16 * 300000 * 8 * 4 * 1.2
-    assert lib.ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(meta), 2_000_000) > 0 and lib.ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(meta), 2304 * 1024 + 1) == 0
+    assert lib.ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(meta), 2_000_000) > 0 and lib.ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(meta), 4608 * 1024 + 1) == 0
     with pytest.raises(_lib.NgpError, match="NGP_EINVAL"):
         _lib.call("ngp_render_test_frame", None, None, None, None, 1, 0.5, 0.0, 128, 1024, 1e-4, None, None, None, C.byref(meta), None, None,
                   100, 1, 0, None, None, 0, None, None, None, None, None, None)
