@@ -24,6 +24,12 @@ STAGES = {   # stage of bench.py's roofline block -> kernels of that library cal
 }
 
 
+def matches(name, kernels):
+    """Does the (possibly mangled) kernel name belong to one of `kernels`?  The name must START with it, or follow the length prefix of
+    an Itanium-mangled name (..._112merge_kernelE...): `merge_kernel` must not claim `adam_field_merge_kernel`."""
+    return any(re.search(r"(?:^|\d)%s" % re.escape(k), name) for k in kernels)
+
+
 def table(path):
     out = {}
     with open(path) as f:
@@ -74,19 +80,19 @@ def main():
         fb = wb = 0.0
         found = []
         for name, rec in fetch.items():
-            if any(name.startswith(k) or k in name for k in kernels):
+            if matches(name, kernels):
                 per_step = max(1, round(rec["calls"] / max(fetch[next(n for n in fetch if "adam_field" in n)]["calls"], 1)))
                 fb += rec.get("FETCH_SIZE", 0.0) * 1024 * per_step
                 found.append(name)
         for name, rec in write.items():
-            if any(name.startswith(k) or k in name for k in kernels):
+            if matches(name, kernels):
                 per_step = max(1, round(rec["calls"] / max(write[next(n for n in write if "adam_field" in n)]["calls"], 1)))
                 wb += rec.get("WRITE_SIZE", 0.0) * 1024 * per_step
-        ks = [(name, rec) for name, rec in trace.items() if any(k.split("_kernel")[0] in name for k in kernels)]
+        ks = [(name, rec) for name, rec in trace.items() if matches(name, [k.split("_kernel")[0] for k in kernels])]
         if ks:
             adam_calls = max([c for n, (c, a) in trace.items() if "adam_field" in n] + [1])
             out["kernel_sum_ms"][stage] = round(sum(a * max(1, round(c / adam_calls)) for _n, (c, a) in ks) / 1e3, 4)
-        cand = [(rec["avg_us"], name, rec) for name, rec in sq.items() if any(name.startswith(k) or k in name for k in kernels) and rec.get("SQ_ACTIVE_INST_ANY")]
+        cand = [(rec["avg_us"], name, rec) for name, rec in sq.items() if matches(name, kernels) and rec.get("SQ_ACTIVE_INST_ANY")]
         if cand:
             avg_us, name, rec = max(cand)
             out["issue_bound"][stage] = {"kernel": name, "avg_us_in_pmc_pass": avg_us, "SQ_ACTIVE_INST_ANY": rec["SQ_ACTIVE_INST_ANY"],
