@@ -113,7 +113,7 @@ def test_two_ranks_train_in_lock_step_on_one_gpu(n_groups):
     assert [(r, ok) for r, ok, _ in res] == [(0, True), (1, True)], res
 
 
-def _sharded_worker(rank, world, port, q):
+def _sharded_worker(rank, world, port, q, n_chunks=1):
     """Trains 6 steps twice from the same initialisation on the same per-rank batches: with the all-reduce exchange and with the
     sharded one (reduce-scatter -> shard Adam -> all-gather).  Both must leave every rank with the same f16 working table, and
     the f32 master (after gather_master) must agree between the two exchanges: the grid gradient sums are the same f16 ring sums
@@ -145,7 +145,7 @@ def _sharded_worker(rank, world, port, q):
             m = NGP(scale=0.5).cuda()
             m.register_training_buffers()
             tr = Trainer(m)
-            ex = (GradientExchange(m, dist, world) if kind == "allreduce" else ShardedExchange(m, dist, world, rank)).install(tr)
+            ex = (GradientExchange(m, dist, world) if kind == "allreduce" else ShardedExchange(m, dist, world, rank, n_chunks=n_chunks)).install(tr)
             ex.broadcast_parameters()
             for s in range(6):
                 b = empty if (s == 3 and rank == 1) else batches[s]
@@ -155,7 +155,7 @@ def _sharded_worker(rank, world, port, q):
             enc = m.xyz_encoder
             half = enc._half.get(enc.params).clone()
             if kind == "sharded":
-                assert tr.update_hook is not None and ex.shard_len * world >= enc.n_grid
+                assert tr.update_hook is not None and ex.padded >= enc.n_grid and len(ex.pieces) == n_chunks
                 ex.gather_master()
             results[kind] = (half.cpu(), enc.params.detach().clone().cpu(), m.rgb_net.params.detach().clone().cpu())
             ex.uninstall(tr)
@@ -180,11 +180,14 @@ def _sharded_worker(rank, world, port, q):
         raise
 
 
-def test_sharded_exchange_trains_like_the_allreduce_exchange_on_one_gpu():
+@pytest.mark.parametrize("n_chunks", [1, 2])
+def test_sharded_exchange_trains_like_the_allreduce_exchange_on_one_gpu(n_chunks):
+    """n_chunks = 2: the chunked layout of the native tail (rank r owns one piece of every chunk; `ngp_adam_step_field_pieces` at
+    world 2, both ranks) with real kernels and real gradients."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q, n_chunks)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=600) for _ in range(2))

@@ -366,3 +366,44 @@ def test_fast_stream_query_follows_torchs_current_stream():
     with torch.cuda.stream(s):
         assert _lib.stream() == s.cuda_stream == torch.cuda.current_stream().cuda_stream
     assert _lib.stream() == torch.cuda.current_stream().cuda_stream != s.cuda_stream
+
+
+@pytest.mark.parametrize("world,n_chunks", [(1, 1), (2, 2), (8, 1), (8, 4), (5, 3)])
+def test_piece_adam_of_every_rank_equals_the_whole_table_adam(world, n_chunks):
+    """`ngp_adam_step_field_pieces` for EVERY rank of a world that does not exist on the test box: the gradient is cut into the pieces
+    a reduce-scatter of n_chunks chunks would deliver to each rank, every rank's launch updates its pieces of one shared copy of
+    (master, moments, f16 table), and the result must equal ONE whole-table `ngp_adam_step_field` bit for bit -- piece boundaries,
+    the short last pieces behind the end of the table and the untouched padding included."""
+    from ngp_pl_amd._lib import call, ptr, stream
+    DEV = "cuda"
+    torch.manual_seed(60 + world + n_chunks)
+    n_grid, n_d, n_r, rows = 16 * 6151, 3072, 7168, 3                     # n_grid a multiple of 16, not of world x n_chunks x 8
+    piece = -(-n_grid // (n_chunks * world * 8)) * 8
+    chunk, padded = world * piece, n_chunks * world * piece
+
+    def state(n, pad=0):
+        return [torch.randn(n + pad, device=DEV) * 0.1, torch.zeros(n + pad, dtype=torch.float16, device=DEV),
+                torch.rand(n + pad, device=DEV) * 1e-3, torch.rand(n + pad, device=DEV) * 1e-6]
+    grid = state(n_grid, padded - n_grid)
+    for t in grid:
+        t[n_grid:] = 0                                                   # the padding behind the table
+    dens, rgb = state(n_d), state(n_r)
+    grad = torch.zeros(padded, dtype=torch.float16, device=DEV)
+    grad[:n_grid] = (torch.randn(n_grid, device=DEV) * 0.3).half()
+    pd = torch.randn(rows, n_d, device=DEV); pr = torch.randn(rows, n_r, device=DEV)
+    ref = [[t.clone() for t in s] for s in (grid, dens, rgb)]
+    hyper = (1e-2, 0.9, 0.999, 1e-15, 0.0, 5, 128.0)
+    g, d, r = ref
+    call("ngp_adam_step_field", ptr(g[0]), ptr(g[1]), ptr(grad.clone()), ptr(g[2]), ptr(g[3]), n_grid, ptr(d[0]), ptr(d[1]), ptr(pd), ptr(d[2]), ptr(d[3]), n_d,
+         ptr(r[0]), ptr(r[1]), ptr(pr), ptr(r[2]), ptr(r[3]), n_r, rows, *hyper, 0, None, None, stream())
+    for rank in range(world):
+        shard = torch.cat([grad[c * chunk + rank * piece:c * chunk + (rank + 1) * piece] for c in range(n_chunks)]).contiguous()
+        dd = [[t.clone() for t in s] for s in (dens, rgb)] if rank else [dens, rgb]        # (every rank updates the MLP blocks: keep rank 0's)
+        call("ngp_adam_step_field_pieces", ptr(grid[0]), ptr(grid[1]), ptr(shard), ptr(grid[2]), ptr(grid[3]), n_grid, piece, n_chunks, world, rank,
+             ptr(dd[0][0]), ptr(dd[0][1]), ptr(pd), ptr(dd[0][2]), ptr(dd[0][3]), n_d, ptr(dd[1][0]), ptr(dd[1][1]), ptr(pr), ptr(dd[1][2]), ptr(dd[1][3]), n_r,
+             rows, *hyper, None, None, None, stream())
+    torch.cuda.synchronize()
+    for got, want in zip((grid, dens, rgb), ref):
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+    assert all(not bool(t[n_grid:].any()) for t in grid)
