@@ -35,29 +35,28 @@ def render(model, rays_o, rays_d, **kwargs):
     ts, rays_a, rm_samples, vr_samples; at test time total_samples (rendering.py:11-43)."""
     rays_o = rays_o.contiguous(); rays_d = rays_d.contiguous()
     test_time = kwargs.get("test_time", False)
-    if not test_time and _fused_train(model, rays_o, rays_d, kwargs):
+    native_test = test_time and getattr(model, "fused", False) and model.rgb_act == "Sigmoid" and rays_o.is_cuda and \
+        not any(isinstance(v, torch.Tensor) for v in kwargs.values())
+    if native_test or (not test_time and _fused_train(model, rays_o, rays_d, kwargs)):
         rays_o, rays_d = rays_o.float(), rays_d.float()
         hits_t = None
-        if not _native_train(model, kwargs):       # (the native stepper's march starts with this prologue itself)
-            # rendering.py:27-29 (one box, one hit, near clamp) as ONE launch; (R,1,2) like the operator's output
+        if test_time or not _native_train(model, kwargs):       # (the native stepper's march starts with this prologue itself)
+            # rendering.py:27-29 (one box, one hit, near clamp) as ONE launch; (R,1,2) like the operator's output.  (The operator
+            # chain below costs four launches and -- the boolean-mask assignment goes through nonzero() -- a host synchronisation
+            # per call: 3 % of a 1.5 ms frame on the trained field.)
             hits_t = torch.empty(rays_o.shape[0], 1, 2, dtype=torch.float32, device=rays_o.device)
-            with torch.cuda.device(rays_o.device):
+            with _lib.device_guard(rays_o.device):
                 call("ngp_ray_aabb_near", ptr(rays_o), ptr(rays_d), ptr(model.center), ptr(model.half_size), NEAR_DISTANCE,
                      rays_o.shape[0], ptr(hits_t), stream())
-        fn = _render_train
+        if test_time:
+            fn = _render_test_native if kwargs.get("host_loop", False) else _render_test_device
+        else:
+            fn = _render_train
     else:
         _, hits_t, _ = RayAABBIntersector.apply(rays_o, rays_d, model.center, model.half_size, 1)
         t1 = hits_t[:, 0, 0]
         hits_t[(t1 >= 0) & (t1 < NEAR_DISTANCE), 0, 0] = NEAR_DISTANCE
-        if test_time:
-            native = getattr(model, "fused", False) and model.rgb_act == "Sigmoid" and rays_o.is_cuda and \
-                not any(isinstance(v, torch.Tensor) for v in kwargs.values())
-            if native:
-                fn = _render_test_native if kwargs.get("host_loop", False) else _render_test_device
-            else:
-                fn = _render_test
-        else:
-            fn = _render_train
+        fn = _render_test if test_time else _render_train
     results = fn(model, rays_o, rays_d, hits_t, **kwargs)
     if kwargs.get("to_cpu", False):
         for k, v in results.items():
@@ -181,7 +180,7 @@ def _render_test_device(model, rays_o, rays_d, hits_t, **kwargs):
     hits = hits_t[:, 0].contiguous()
     bg = (C.c_float * 3)(*([1.0, 1.0, 1.0] if esf == 0 else [0.0, 0.0, 0.0]))     # rendering.py:112-116
     n_it = C.c_int32(0)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         call("ngp_render_test_frame", ptr(rays_o), ptr(rays_d), ptr(hits), ptr(model.density_bitfield), model.cascades,
              float(model.scale), esf, model.grid_size, int(kwargs.get("max_samples", MAX_SAMPLES)), float(kwargs.get("T_threshold", 1e-4)),
              ptr(model.xyz_min), ptr(model.xyz_max), ptr(eh[enc.n_mlp:]), C.byref(enc.meta), ptr(eh), ptr(rh),
