@@ -256,6 +256,22 @@ int ngp_composite_train_fw_loss_counts(const float* sigmas, const float* rgbs, c
                                        int32_t* ray_counts, const float* gt_rgb, const float* bg,
                                        float lambda_opacity, float grad_scale, float* dL_drgb,
                                        float* dL_dopacity, void* workspace, size_t workspace_bytes, ngp_stream_t stream);
+/* The same idea for render()'s training branch (rendering.py:121-163), where the caller forms the loss: the forward also writes
+ * the BLENDED colour rgb_out (R,3) = rgb + bg (1 - opacity) (bg 3 floats on the device, NULL = black; rgb_out may be NULL) and
+ * leaves the rows' live counts in ray_counts; the backward takes its seeds w.r.t. that blended colour (g_opacity may be NULL),
+ * folds the blend's backward in, prefixes the counts and writes n_active -- three launches less than ngp_composite_train_fw +
+ * ngp_active_scan + ngp_bg_blend and ngp_bg_blend_bw + ngp_composite_train_bw, the same bits. */
+int ngp_composite_train_fw_blend(const float* sigmas, const float* rgbs, const float* deltas, const float* ts,
+                                 const int64_t* rays_a, float T_threshold, int n_rays, int n_samples,
+                                 int64_t* total_samples, float* opacity, float* depth, float* rgb, float* ws,
+                                 int32_t* ray_counts, const float* bg, float* rgb_out, ngp_stream_t stream);
+int ngp_composite_train_bw_render(const float* g_opacity, const float* g_depth, const float* g_rgb,
+                                  const float* g_ws, const float* sigmas, const float* rgbs, const float* ws,
+                                  const float* deltas, const float* ts, const int64_t* rays_a,
+                                  const float* opacity, const float* depth, const float* rgb, float T_threshold,
+                                  int n_rays, int n_samples, float* dL_dsigmas, float* dL_drgbs,
+                                  const int32_t* ray_counts, int32_t* active_idx, const float* xyzs, float* x_active,
+                                  int32_t* n_active, const float* bg, ngp_stream_t stream);
 int ngp_composite_train_bw_tail(const float* dL_dopacity, const float* dL_ddepth, const float* dL_drgb,
                                 const float* dL_dws, const float* sigmas, const float* rgbs, const float* ws,
                                 const float* deltas, const float* ts, const int64_t* rays_a,

@@ -89,6 +89,8 @@ _PROTOS = {
     "ngp_composite_train_fw_loss": [P, P, P, P, P, F, I, I, P, P, P, P, P, P, P, P, P, F, F, P, P, P, P, P, C.c_size_t, P],
     "ngp_composite_probe": [P, P, P, I, F, I, P, P, P],
     "ngp_composite_train_fw_loss_counts": [P, P, P, P, P, F, I, I, P, P, P, P, P, P, P, P, F, F, P, P, P, C.c_size_t, P],
+    "ngp_composite_train_fw_blend": [P, P, P, P, P, F, I, I, P, P, P, P, P, P, P, P, P],
+    "ngp_composite_train_bw_render": [P] * 13 + [F, I, I, P, P, P, P, P, P, P, P, P],
     "ngp_composite_train_bw_tail": [P] * 13 + [F, I, I, P, P, P, P, P, P, P, P, P, P, P, C.c_size_t, P],
     "ngp_composite_train_fw_loss_h": [P, P, P, P, P, F, I, I, P, P, P, P, P, P, P, P, P, P, F, F, P, P, P, P, P, C.c_size_t, P],
     "ngp_composite_test_fw": [P, P, P, P, P, F, P, I, I, P, P, P, P],

@@ -65,6 +65,7 @@ struct FwTail {
     float* loss; float* sq_err; float* dL_drgb; float* dL_dopacity;
     int32_t* n_active; float* row_loss; float* row_sq;
     int32_t* n_active_host;          // optional: the same count into pinned host memory (the stepper's live-fraction estimate)
+    float* rgb_out;                  // optional (render()'s training branch): rgb + bg (1 - opacity), rendering.py:153-161 (bg NULL: black)
 };
 
 __device__ __forceinline__ void composite_fw_ray(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
@@ -103,7 +104,7 @@ __device__ __forceinline__ void composite_fw_ray(const float* __restrict__ sigma
         depth[ray_idx] = D; opacity[ray_idx] = O;
         total_samples[ray_idx] = samples;
         if (n_active_per_ray) n_active_per_ray[n] = min(N, samples + 1);   // samples that can carry gradient (row order)
-        if (tail) {
+        if (tail && tail->gt) {
             const float c[3] = {R, G, B};
             const float g[3] = {tail->gt[3 * ray_idx], tail->gt[3 * ray_idx + 1], tail->gt[3 * ray_idx + 2]};
             float d_rgb[3], d_o, l = 0.f, se = 0.f;
@@ -112,6 +113,12 @@ __device__ __forceinline__ void composite_fw_ray(const float* __restrict__ sigma
             tail->dL_drgb[3 * ray_idx] = d_rgb[0]; tail->dL_drgb[3 * ray_idx + 1] = d_rgb[1]; tail->dL_drgb[3 * ray_idx + 2] = d_rgb[2];
             tail->dL_dopacity[ray_idx] = d_o;
             tail->row_loss[n] = l; tail->row_sq[n] = se;
+        }
+        if (tail && tail->rgb_out) {                     // bg_blend_kernel's arithmetic (optim.hip), in the composite's own epilogue
+            const float tr = 1.0f - O;
+            const float c[3] = {R, G, B};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) tail->rgb_out[3 * ray_idx + k] = tail->bg ? fmaf(tail->bg[k], tr, c[k]) : c[k];
         }
     }
 }
@@ -232,7 +239,8 @@ composite_train_fw_kernel(const float* __restrict__ sigmas, const float* __restr
 // from L2, 16-byte loads, all in flight: the sums are integers, so the offsets are exactly the scan's); the LAST workgroup, which
 // holds the total anyway, writes n_active (+ the pinned host copy); workgroup 0 -- dispatched first, never the kernel's tail --
 // adds the per-row loss terms in a fixed order.
-struct BwTail { const float* row_loss; const float* row_sq; float* loss; float* sq_err; int32_t* n_active; int32_t* n_active_host; };
+struct BwTail { const float* row_loss; const float* row_sq; float* loss; float* sq_err; int32_t* n_active; int32_t* n_active_host;
+                const float* bg; int blend; };     // blend: the seeds are w.r.t. render()'s BLENDED colour (row_loss may be NULL: no loss terms)
 __device__ __forceinline__ int wave_sum_int(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -289,7 +297,7 @@ composite_train_bw_kernel(const float* __restrict__ dL_dopacity, const float* __
             *tail.n_active = total;
             if (tail.n_active_host) *tail.n_active_host = total;
         }
-        if (blockIdx.x == 0) {                                             // loss = sum of the per-row terms, fixed order
+        if (blockIdx.x == 0 && tail.row_loss != nullptr) {                 // loss = sum of the per-row terms, fixed order
             const int per = (n_rays + 255) / 256;
             float l = 0.f, se = 0.f;
             for (int i = tid * per; i < min((tid + 1) * per, n_rays); ++i) { l += tail.row_loss[i]; se += tail.row_sq[i]; }
@@ -312,7 +320,11 @@ composite_train_bw_kernel(const float* __restrict__ dL_dopacity, const float* __
     const float R = rgb[3 * ray_idx], G = rgb[3 * ray_idx + 1], B = rgb[3 * ray_idx + 2];
     const float O = opacity[ray_idx], D = depth[ray_idx];
     const float gR = dL_drgb[3 * ray_idx], gG = dL_drgb[3 * ray_idx + 1], gB = dL_drgb[3 * ray_idx + 2];
-    const float gO = dL_dopacity[ray_idx], gD = dL_ddepth[ray_idx];
+    float gO = dL_dopacity ? dL_dopacity[ray_idx] : 0.f;
+    if (FUSED_TAIL && tail.blend && tail.bg) {                             // through rgb + bg (1 - opacity): bg_blend_bw_kernel's arithmetic (optim.hip)
+        gO = fmaf(-gR, tail.bg[0], gO); gO = fmaf(-gG, tail.bg[1], gO); gO = fmaf(-gB, tail.bg[2], gO);
+    }
+    const float gD = dL_ddepth[ray_idx];
     float P_total = 0.f;   // sum of dL/dw * w over the whole segment (w = 0 past the stop)
     if (dL_dws != nullptr) {
         for (int k = lane; k < N; k += 64) { const size_t s = (size_t)start + k; P_total += dL_dws[s] * ws[s]; }
@@ -493,7 +505,7 @@ int ngp_composite_train_fw_loss_h(const float* sigmas, const float* rgbs, const 
     NGP_CHECK_PTR(dL_dopacity); NGP_CHECK_PTR(workspace);
     if (n_samples > 0) { NGP_CHECK_PTR(sigmas); NGP_CHECK_PTR(rgbs); NGP_CHECK_PTR(deltas); NGP_CHECK_PTR(ts); NGP_CHECK_PTR(ws); }
     if (workspace_bytes < ngp_composite_train_fw_loss_workspace_bytes(n_rays) || ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(ray_offsets)) & 15) != 0) return NGP_EINVAL;
-    FwTail t;
+    FwTail t{};
     t.gt = gt_rgb; t.bg = bg; t.lambda_o = lambda_opacity; t.grad_scale = grad_scale;
     t.loss = loss; t.sq_err = sq_err; t.dL_drgb = dL_drgb; t.dL_dopacity = dL_dopacity; t.n_active = n_active;
     t.n_active_host = n_active_host;
@@ -546,6 +558,43 @@ int ngp_composite_train_fw_loss_counts(const float* sigmas, const float* rgbs, c
     return NGP_LAUNCH_RESULT();
 }
 
+int ngp_composite_train_fw_blend(const float* sigmas, const float* rgbs, const float* deltas, const float* ts,
+                                 const int64_t* rays_a, float T_threshold, int n_rays, int n_samples,
+                                 int64_t* total_samples, float* opacity, float* depth, float* rgb, float* ws,
+                                 int32_t* ray_counts, const float* bg, float* rgb_out, ngp_stream_t stream) {
+    if (n_rays <= 0 || n_samples < 0) return NGP_EINVAL;
+    NGP_CHECK_PTR(rays_a); NGP_CHECK_PTR(total_samples); NGP_CHECK_PTR(opacity); NGP_CHECK_PTR(depth); NGP_CHECK_PTR(rgb);
+    NGP_CHECK_PTR(ray_counts);
+    if (n_samples > 0) { NGP_CHECK_PTR(sigmas); NGP_CHECK_PTR(rgbs); NGP_CHECK_PTR(deltas); NGP_CHECK_PTR(ts); NGP_CHECK_PTR(ws); }
+    if ((reinterpret_cast<uintptr_t>(ray_counts) & 15) != 0) return NGP_EINVAL;
+    FwTail t{};
+    t.bg = bg; t.rgb_out = rgb_out;
+    hipLaunchKernelGGL(composite_train_fw_kernel<true>, dim3(ngp_div_up((long long)n_rays * 64, 256)), dim3(256), 0, ngp_stream(stream),
+                       sigmas, rgbs, deltas, ts, rays_a, T_threshold, n_rays, total_samples, opacity, depth, rgb, ws, ray_counts, t);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_composite_train_bw_render(const float* g_opacity, const float* g_depth, const float* g_rgb,
+                                  const float* g_ws, const float* sigmas, const float* rgbs, const float* ws,
+                                  const float* deltas, const float* ts, const int64_t* rays_a,
+                                  const float* opacity, const float* depth, const float* rgb, float T_threshold,
+                                  int n_rays, int n_samples, float* dL_dsigmas, float* dL_drgbs,
+                                  const int32_t* ray_counts, int32_t* active_idx, const float* xyzs, float* x_active,
+                                  int32_t* n_active, const float* bg, ngp_stream_t stream) {
+    if (n_rays <= 0 || n_samples <= 0) return NGP_EINVAL;
+    NGP_CHECK_PTR(g_depth); NGP_CHECK_PTR(g_rgb); NGP_CHECK_PTR(sigmas);
+    NGP_CHECK_PTR(rgbs); NGP_CHECK_PTR(ws); NGP_CHECK_PTR(deltas); NGP_CHECK_PTR(ts); NGP_CHECK_PTR(rays_a);
+    NGP_CHECK_PTR(opacity); NGP_CHECK_PTR(depth); NGP_CHECK_PTR(rgb); NGP_CHECK_PTR(dL_dsigmas); NGP_CHECK_PTR(dL_drgbs);
+    NGP_CHECK_PTR(ray_counts); NGP_CHECK_PTR(active_idx); NGP_CHECK_PTR(n_active);
+    if ((xyzs == nullptr) != (x_active == nullptr) || (reinterpret_cast<uintptr_t>(ray_counts) & 15) != 0) return NGP_EINVAL;
+    BwTail t{};
+    t.n_active = n_active; t.bg = bg; t.blend = 1;
+    hipLaunchKernelGGL(composite_train_bw_kernel<true>, dim3(ngp_div_up((long long)n_rays * 64, 256)), dim3(256), 0, ngp_stream(stream),
+                       g_opacity, g_depth, g_rgb, g_ws, sigmas, rgbs, ws, deltas, ts, rays_a,
+                       opacity, depth, rgb, T_threshold, n_rays, dL_dsigmas, dL_drgbs, ray_counts, active_idx, xyzs, x_active, t);
+    return NGP_LAUNCH_RESULT();
+}
+
 int ngp_composite_train_bw_tail(const float* dL_dopacity, const float* dL_ddepth, const float* dL_drgb,
                                 const float* dL_dws, const float* sigmas, const float* rgbs, const float* ws,
                                 const float* deltas, const float* ts, const int64_t* rays_a,
@@ -561,7 +610,7 @@ int ngp_composite_train_bw_tail(const float* dL_dopacity, const float* dL_ddepth
     NGP_CHECK_PTR(ray_counts); NGP_CHECK_PTR(active_idx); NGP_CHECK_PTR(n_active); NGP_CHECK_PTR(loss); NGP_CHECK_PTR(workspace);
     if ((xyzs == nullptr) != (x_active == nullptr)) return NGP_EINVAL;
     if (workspace_bytes < ngp_composite_train_fw_loss_workspace_bytes(n_rays) || (reinterpret_cast<uintptr_t>(ray_counts) & 15) != 0) return NGP_EINVAL;
-    BwTail t;
+    BwTail t{};
     t.row_loss = static_cast<const float*>(workspace);
     t.row_sq = t.row_loss + ((n_rays + 3) & ~3);
     t.loss = loss; t.sq_err = sq_err; t.n_active = n_active; t.n_active_host = n_active_host;

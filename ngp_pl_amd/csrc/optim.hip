@@ -370,7 +370,7 @@ bg_blend_bw_kernel(const float* __restrict__ g_rgb, const float* __restrict__ g_
     if (r >= n_rays) return;
     float g = g_opacity ? g_opacity[r] : 0.f;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) g -= g_rgb[3 * r + k] * bg[k];
+    for (int k = 0; k < 3; ++k) g = fmaf(-g_rgb[3 * r + k], bg[k], g);      // (explicit: composite_train_bw_kernel<true> folds the same line in)
     g_opacity_out[r] = g;
 }
 

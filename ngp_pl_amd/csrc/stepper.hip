@@ -50,6 +50,7 @@ struct ngp_stepper {
     hipStream_t next_main = nullptr, next_side = nullptr;
     int march_at = 2;
     // two-round forward (include/ngp_hip.h): mode 0 off / 1 on / 2 auto, first K, the auto switch's state, steps run in two rounds
+    bool render_tail = false;              // the last render_forward left live COUNTS (not offsets) in ray_offs
     int merge_in_adam = 1;                 // NGP_MERGE_IN_ADAM (default 1): ngp_stepper_backward_update folds the dense levels' merge into the Adam launch
     int fused_tail = 1;                    // NGP_FUSED_TAIL (default 1): composite forward / backward without the scan kernel between them
     int two_round_mode = 2, two_round_k = 32;
@@ -348,8 +349,9 @@ static int forward_field(ngp_stepper* s, const float* rays_o, const float* rays_
 }
 
 // composite backward (+ distortion) -> field backward on the live samples, from seeds w.r.t. the composited per-ray values
+enum { TAIL_NONE = 0, TAIL_LOSS = 1, TAIL_RENDER = 2 };   // who turns the rows' live counts into offsets: ngp_active_scan / the tail kernel (NONE) or the backward itself
 static int backward_field(ngp_stepper* s, const float* dL_dopacity, const float* dL_ddepth, const float* dL_drgb, const float* dL_dws_in,
-                          float loss_scale, hipStream_t main, ngp_stream_t main_stream, int32_t* n_partials, bool fused_tail = false) {
+                          float loss_scale, hipStream_t main, ngp_stream_t main_stream, int32_t* n_partials, int fused_tail = TAIL_NONE) {
     const ngp_stepper_config& c = s->c;
     const ngp_step_buffers& b = s->b;
     const int k = s->last_set, n = b.n_rays;
@@ -367,7 +369,12 @@ static int backward_field(ngp_stepper* s, const float* dL_dopacity, const float*
     // backward only over the samples up to each ray's early stop (the rest have zero gradient); the binned table backward
     // reads the live samples' positions as a stream: composite_bw copies them in list order
     s->binned = S <= b.bin_max;
-    if (fused_tail) {
+    if (fused_tail == TAIL_RENDER) {
+        // (render()'s branch: seeds w.r.t. the BLENDED colour; the blend's backward, the prefix of the live counts and n_active in the same launch)
+        STEP_TRY(ngp_composite_train_bw_render(dL_dopacity, dL_ddepth, dL_drgb, dL_dws, b.sigmas, b.rgbs, b.ws, b.deltas, b.ts, b.rays_a[k], b.opacity,
+                                               b.depth, b.rgb, c.T_threshold, n, S, b.dL_dsigmas, b.dL_drgbs, b.ray_offs, b.active,
+                                               s->binned ? b.xyzs : nullptr, s->binned ? b.x_act : nullptr, b.n_active, c.bg, main_stream));
+    } else if (fused_tail == TAIL_LOSS) {
         // (ray_offs holds the rows' live-sample COUNTS: the backward's workgroups prefix them, write n_active and add the loss terms)
         STEP_TRY(ngp_composite_train_bw_tail(dL_dopacity, dL_ddepth, dL_drgb, dL_dws, b.sigmas, b.rgbs, b.ws, b.deltas, b.ts, b.rays_a[k], b.opacity,
                                              b.depth, b.rgb, c.T_threshold, n, S, b.dL_dsigmas, b.dL_drgbs, b.ray_offs, b.active,
@@ -423,7 +430,7 @@ int ngp_stepper_front(ngp_stepper* s, const float* rays_o, const float* rays_d, 
     }
     mark(s, 4, main);
     STEP_TRY(march_next_if_at(s, AT_COMPOSITE_FW));
-    STEP_TRY(backward_field(s, b.dL_dopacity, b.zeros, b.dL_drgb, nullptr, loss_scale, main, main_stream, n_partials, fused_tail));
+    STEP_TRY(backward_field(s, b.dL_dopacity, b.zeros, b.dL_drgb, nullptr, loss_scale, main, main_stream, n_partials, fused_tail ? TAIL_LOSS : TAIL_NONE));
     if (s->next_o != nullptr && (S <= 0 || s->march_at < AT_HASHGRID_BWD)) {      // a batch without samples skips the stages a placement may name
         const float* o = s->next_o; const float* d = s->next_d;
         s->next_o = s->next_d = nullptr;
@@ -449,12 +456,19 @@ int ngp_stepper_render_forward(ngp_stepper* s, const float* rays_o, const float*
     *n_samples = s->S;
     const int n = b.n_rays;
     b.counter[k][2] = -1;                                    // (no live-sample count from this composite: the auto switch stays where it is)
-    STEP_TRY(ngp_composite_train_fw(b.sigmas, b.rgbs, b.deltas, b.ts, b.rays_a[k], c.T_threshold, n, s->S, b.total, b.opacity, b.depth, b.rgb,
-                                    b.ws, b.ray_offs, main_stream));
-    STEP_TRY(ngp_active_scan(b.ray_offs, n, b.n_active, main_stream));
-    if (rgb_out) {                                           // rendering.py:153-161: rgb + bg (1 - opacity); bg NULL = black: a copy
-        if (c.bg) STEP_TRY(ngp_bg_blend(b.rgb, b.opacity, c.bg, n, rgb_out, main_stream));
-        else STEP_HIP(hipMemcpyAsync(rgb_out, b.rgb, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, main));
+    s->render_tail = s->fused_tail != 0;
+    if (s->render_tail) {
+        // ONE launch: composite + the blended colour (rendering.py:153-161); the rows' live counts stay counts for render_backward
+        STEP_TRY(ngp_composite_train_fw_blend(b.sigmas, b.rgbs, b.deltas, b.ts, b.rays_a[k], c.T_threshold, n, s->S, b.total, b.opacity, b.depth, b.rgb,
+                                              b.ws, b.ray_offs, c.bg, rgb_out, main_stream));
+    } else {
+        STEP_TRY(ngp_composite_train_fw(b.sigmas, b.rgbs, b.deltas, b.ts, b.rays_a[k], c.T_threshold, n, s->S, b.total, b.opacity, b.depth, b.rgb,
+                                        b.ws, b.ray_offs, main_stream));
+        STEP_TRY(ngp_active_scan(b.ray_offs, n, b.n_active, main_stream));
+        if (rgb_out) {                                       // rendering.py:153-161: rgb + bg (1 - opacity); bg NULL = black: a copy
+            if (c.bg) STEP_TRY(ngp_bg_blend(b.rgb, b.opacity, c.bg, n, rgb_out, main_stream));
+            else STEP_HIP(hipMemcpyAsync(rgb_out, b.rgb, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, main));
+        }
     }
     mark(s, 4, main);
     if (next_o) STEP_TRY(do_march(s, next_o, next_d, main, side));      // (the render-shaped halves: always behind the composite forward)
@@ -474,6 +488,8 @@ int ngp_stepper_render_backward(ngp_stepper* s, const float* g_rgb, const float*
     *n_partials = 0;
     if (s->S <= 0) return 0;
     const int n = b.n_rays;
+    if (s->render_tail)                                      // (the forward left counts: the backward folds blend, prefix and n_active in)
+        return backward_field(s, g_opacity, g_depth ? g_depth : b.zeros, g_rgb, g_ws, loss_scale, ngp_stream(main_stream), main_stream, n_partials, TAIL_RENDER);
     const float* g_o = g_opacity;
     if (c.bg) {                                              // through rgb + bg (1 - opacity): dL/do -= sum_c g_rgb[c] bg[c]
         STEP_TRY(ngp_bg_blend_bw(g_rgb, g_opacity, c.bg, n, b.dL_dopacity, main_stream));
