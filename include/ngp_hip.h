@@ -424,6 +424,20 @@ int ngp_hashgrid_bwd_binned_deferred(const float* x, const float* xyz_min, const
                                      ngp_grid_partials* partials_out, ngp_stream_t stream);
 int ngp_hashgrid_bwd_binned_group_entries(const ngp_grid_meta* meta, int n_samples, int n_groups, int group,
                                           int64_t* entry_begin, int64_t* entry_end);
+/* The two passes of the binned backward as separate calls.  Pass 1 (the per-slice sample lists) needs the live samples' positions
+ * only, not their gradients: a caller that has the positions before the gradients (the training step: the composite backward lists
+ * the live samples, THEN the field backward forms dL/dfeats) runs `_lists` on another stream underneath the field backward and
+ * `_owners` (pass 2, [+ merge]; partials_out as in _deferred, may be NULL; n_groups / group as in _group) behind both.  `_lists`
+ * lists EVERY live sample -- the one-call forms skip samples whose gradient is exactly zero on a level; a listed zero adds 0 to
+ * exact integer sums -- so the gradient table is bit-identical to the one-call forms'. */
+int ngp_hashgrid_bwd_binned_lists(const float* x, const float* xyz_min, const float* xyz_max, const ngp_grid_meta* meta,
+                                  int n_samples, const int32_t* active_idx, const int32_t* n_active,
+                                  void* workspace, size_t workspace_bytes, ngp_stream_t stream);
+int ngp_hashgrid_bwd_binned_owners(const float* x, const float* xyz_min, const float* xyz_max,
+                                   const ngp_half* dfeats, const ngp_grid_meta* meta, int n_samples,
+                                   const int32_t* active_idx, const int32_t* n_active,
+                                   void* workspace, size_t workspace_bytes, ngp_half* grad_table,
+                                   int n_groups, int group, ngp_grid_partials* partials_out, ngp_stream_t stream);
 
 /* The samples that can carry gradient after compositing: the first min(N, total_samples+1) of
  * every ray (later ones have w = 0 exactly, volumerendering.cu:41).  Writes their ids in ray
@@ -833,6 +847,14 @@ int ngp_stepper_create(const ngp_stepper_config* config, const ngp_step_buffers*
 int ngp_stepper_destroy(ngp_stepper* s);
 /* New buffers (another batch size).  Any prefetched march is waited for and dropped first. */
 int ngp_stepper_set_buffers(ngp_stepper* s, const ngp_step_buffers* buffers);
+/* A second set of packed-sample buffers (each sized like its namesake in ngp_step_buffers; all four or all NULL = back to one
+ * set).  With two sets a march also EXPANDS its samples (pass 2 of the march, xyzs / dirs / deltas / ts) on the marching stream,
+ * into the set that belongs to its record set, while the running step reads the other one: the expansion leaves the main stream
+ * (9 us of kernel and a launch gap per step; same kernel, same inputs: bit-identical samples).  The set a step read:
+ * ngp_stepper_last_set() (0 = the ngp_step_buffers pointers, 1 = these).  A pending march is waited for and dropped first;
+ * ngp_stepper_set_buffers() forgets the second set.  Marches whose scan prepares the two-round lists expand on the main stream
+ * as before. */
+int ngp_stepper_set_sample_sets(ngp_stepper* s, float* xyzs1, float* dirs1, float* deltas1, float* ts1);
 /* AABB + near clamp + jitter + pass 1 of the march of (rays_o, rays_d) on `march_stream`, behind everything `main_stream`
  * has queued so far.  One march can be pending; NGP_EINVAL if one already is. */
 int ngp_stepper_march(ngp_stepper* s, const float* rays_o, const float* rays_d, ngp_stream_t main_stream, ngp_stream_t march_stream);

@@ -156,6 +156,7 @@ _PROTOS = {
     "ngp_stepper_create": [C.POINTER(StepperConfig), C.POINTER(StepBuffersC), C.POINTER(P)],
     "ngp_stepper_destroy": [P],
     "ngp_stepper_set_buffers": [P, C.POINTER(StepBuffersC)],
+    "ngp_stepper_set_sample_sets": [P, P, P, P, P],
     "ngp_stepper_march": [P, P, P, P, P],
     "ngp_stepper_pending": [P, P, P],
     "ngp_stepper_last_set": [P],
@@ -174,6 +175,8 @@ _PROTOS = {
     "ngp_gather_xyz": [P, P, P, I, P, P],
     "ngp_hashgrid_bwd_binned": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P, C.c_size_t, P, P],
     "ngp_hashgrid_bwd_binned_group": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P, C.c_size_t, P, I, I, P],
+    "ngp_hashgrid_bwd_binned_lists": [P, P, P, C.POINTER(GridMeta), I, P, P, P, C.c_size_t, P],
+    "ngp_hashgrid_bwd_binned_owners": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P, C.c_size_t, P, I, I, C.POINTER(GridPartials), P],
     "ngp_hashgrid_bwd_binned_group_entries": [C.POINTER(GridMeta), I, I, I, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     "ngp_hashgrid_bwd_input": [P, P, P, P, P, C.POINTER(GridMeta), I, F, P, P],
     "ngp_sh4_bwd": [P, P, I, F, P, P],

@@ -138,7 +138,8 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const
     for (int t = 0; t < BIN_SPT; ++t) {               // all loads of the thread's samples before any use
         jj[t] = chunk * CHUNK + t * BIN_THREADS + (int)threadIdx.x;
         const int jc = min(jj[t], n - 1);
-        gg[t] = dfeats[(size_t)level * n_samples + jc];
+        if (dfeats != nullptr) gg[t] = dfeats[(size_t)level * n_samples + jc];
+        else { gg[t][0] = (_Float16)1; gg[t][1] = (_Float16)1; }      // lists built ahead of the gradients: every live sample is listed
         src[t] = active ? active[jc] : jc;
     }
 #pragma unroll
@@ -737,14 +738,18 @@ int ngp_hashgrid_bwd_binned_group_entries(const ngp_grid_meta* meta, int n_sampl
 
 // partials_out != NULL (ngp_hashgrid_bwd_binned_deferred): the merge of the K-split levels' partial tables is left to the consumer
 // of the gradient (the fused Adam reads the K partials itself) and *partials_out says where they are.
+enum { PASS_BOTH = 0, PASS_LISTS = 1, PASS_OWNERS = 2 };
 static int binned_group_impl(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* dfeats,
                              const ngp_grid_meta* meta, int n_samples, const int32_t* active_idx,
                              const int32_t* n_active, void* workspace, size_t workspace_bytes,
-                             ngp_half* grad_table, int n_groups, int group, ngp_grid_partials* partials_out, ngp_stream_t stream) {
+                             ngp_half* grad_table, int n_groups, int group, ngp_grid_partials* partials_out, ngp_stream_t stream,
+                             int pass = PASS_BOTH) {
     if (n_samples < 0 || !meta || meta->n_features != 2 || meta->n_levels < 1 || meta->n_levels > NGP_MAX_LEVELS) return NGP_EINVAL;
     if (n_groups < 1 || n_groups > 16 || group < 0 || group >= n_groups) return NGP_EINVAL;
-    NGP_CHECK_PTR(grad_table); NGP_CHECK_PTR(workspace);
-    if (n_samples > 0) { NGP_CHECK_PTR(x); NGP_CHECK_PTR(xyz_min); NGP_CHECK_PTR(xyz_max); NGP_CHECK_PTR(dfeats); }
+    NGP_CHECK_PTR(workspace);
+    if (pass != PASS_LISTS) NGP_CHECK_PTR(grad_table);
+    if (n_samples > 0) { NGP_CHECK_PTR(x); NGP_CHECK_PTR(xyz_min); NGP_CHECK_PTR(xyz_max); if (pass != PASS_LISTS) NGP_CHECK_PTR(dfeats); }
+    if (NGP_BIN_PAYLOAD && pass != PASS_BOTH) return NGP_EUNSUP;       // payload entries carry the gradient: the lists cannot precede it
     if (active_idx != nullptr && n_active == nullptr) return NGP_EINVAL;      // n_active alone: x and dfeats both in compact order
     BinPlan P; BinLayout L;
     if (!make_plan(meta, n_samples, P, L)) return NGP_EUNSUP;
@@ -764,9 +769,10 @@ static int binned_group_impl(const float* x, const float* xyz_min, const float* 
     ws.partial = reinterpret_cast<float2*>(wsb + L.partial);
     hipError_t e = hipSuccess;
     const GridMeta dm = to_dev_meta(meta);
-    if (group == 0)
+    if (group == 0 && pass != PASS_OWNERS)
         bin_kernel<<<dim3(meta->n_levels * P.n_chunks), dim3(BIN_THREADS), 0, st>>>(
-            x, xyz_min, xyz_max, (const half2_t*)dfeats, dm, P, ws, n_samples, active_idx, n_active);
+            x, xyz_min, xyz_max, pass == PASS_LISTS ? nullptr : (const half2_t*)dfeats, dm, P, ws, n_samples, active_idx, n_active);
+    if (pass == PASS_LISTS) return NGP_LAUNCH_RESULT();
     constexpr int smem = (int)(SLICE2 * 2 * sizeof(long long));
     static bool attr_set[64] = {};              // per device: the attribute belongs to the device's code object
     int dev = 0;
@@ -819,6 +825,21 @@ int ngp_hashgrid_bwd_binned_deferred(const float* x, const float* xyz_min, const
     NGP_CHECK_PTR(partials_out);
     return binned_group_impl(x, xyz_min, xyz_max, dfeats, meta, n_samples, active_idx, n_active, workspace, workspace_bytes, grad_table,
                              1, 0, partials_out, stream);
+}
+
+int ngp_hashgrid_bwd_binned_lists(const float* x, const float* xyz_min, const float* xyz_max, const ngp_grid_meta* meta, int n_samples,
+                                  const int32_t* active_idx, const int32_t* n_active, void* workspace, size_t workspace_bytes,
+                                  ngp_stream_t stream) {
+    return binned_group_impl(x, xyz_min, xyz_max, nullptr, meta, n_samples, active_idx, n_active, workspace, workspace_bytes, nullptr,
+                             1, 0, nullptr, stream, PASS_LISTS);
+}
+
+int ngp_hashgrid_bwd_binned_owners(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* dfeats,
+                                   const ngp_grid_meta* meta, int n_samples, const int32_t* active_idx,
+                                   const int32_t* n_active, void* workspace, size_t workspace_bytes,
+                                   ngp_half* grad_table, int n_groups, int group, ngp_grid_partials* partials_out, ngp_stream_t stream) {
+    return binned_group_impl(x, xyz_min, xyz_max, dfeats, meta, n_samples, active_idx, n_active, workspace, workspace_bytes, grad_table,
+                             n_groups, group, partials_out, stream, PASS_OWNERS);
 }
 
 int ngp_hashgrid_bwd_binned(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* dfeats,

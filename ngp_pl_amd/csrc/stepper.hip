@@ -67,6 +67,21 @@ struct ngp_stepper {
     bool x_times_set = false;
     long long tails = 0;
     int64_t group_end[16] = {};           // values (2 x entries) the first g + 1 launch groups of the binned backward complete
+    // packed samples in two sets (ngp_stepper_set_sample_sets): set k belongs to march record set k, so that the expansion of a
+    // prefetched march (pass 2: march_train_write) can run on the marching stream while the running step still reads its own set
+    // pass 1 of the binned table backward (the per-slice sample lists) needs the live samples' positions, not their gradients: with
+    // NGP_LISTS_AHEAD=1 it runs on the stepper's own stream underneath the field backward.  Measured and NOT the default
+    // (profiles/r04_step_ab.txt): 0.364 -> 0.410 ms per step -- the field backward's workgroups hold 115 / 146 KB of a CU's 160 KB
+    // of LDS, so one binning workgroup (33 KB) fits beside them where four run when the pass has the CU to itself, the pass takes
+    // 3-4x as long, the field backward 59 -> 75 us, and the slice owners wait for both.  Same bits either way.
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_pos = nullptr, ev_lists = nullptr, lists_t[2] = {};
+    int lists_ahead = 0;
+    bool lists_step = false, lists_pending = false, lists_t_set = false;    // this step's lists went ahead / the main stream has not waited for them yet
+    struct SampleSet { float* xyzs; float* dirs; float* deltas; float* ts; };
+    SampleSet samples[2] = {};
+    bool two_sample_sets = false;
+    bool expanded[2] = {false, false};    // record set k: its samples are already written (by the march, on its stream)
 };
 
 void destroy_exchange_events(ngp_stepper* s);
@@ -167,6 +182,16 @@ int do_march(ngp_stepper* s, const float* rays_o, const float* rays_d, hipStream
     STEP_TRY(ngp_raymarching_train_count_k(rays_o, rays_d, b.hits_t[k], c.density_bitfield, c.cascades, c.scale, c.exp_step_factor, b.noise[k],
                                            c.grid_size, c.max_samples, b.n_rays, b.rays_a[k], b.counter[k], b.scratch[k], s->set_k[k],
                                            lists ? b.offs_k[k] : nullptr, (ngp_stream_t)side));
+    // pass 2 on the same stream, into this record set's own sample buffers (the step that is running reads the other set): 9 us of
+    // kernel and a launch gap less on the main stream's critical path.  Not for a march whose scan prepared the two-round lists
+    // (their expansion kernels also build the first-round list and run where the round is decided: forward_field).
+    s->expanded[k] = false;
+    if (s->two_sample_sets && side != main && !lists) {
+        const ngp_stepper::SampleSet& w = s->samples[k];
+        STEP_TRY(ngp_raymarching_train_write(rays_o, rays_d, b.rays_a[k], b.scratch[k], c.scale, c.exp_step_factor, c.grid_size, c.max_samples, b.n_rays,
+                                             w.xyzs, w.dirs, w.deltas, w.ts, (ngp_stream_t)side));
+        s->expanded[k] = true;
+    }
     if (s->timing) { STEP_HIP(hipEventRecord(s->march_t[k][1], side)); s->march_t_set[k] = true; }
     STEP_HIP(hipEventRecord(s->done[k], side));
     s->has_pending = true; s->pend_o = rays_o; s->pend_d = rays_d; s->pend_set = k;
@@ -203,6 +228,7 @@ int ngp_stepper_create(const ngp_stepper_config* config, const ngp_step_buffers*
     if (const char* e = getenv("NGP_TWO_ROUND")) s->two_round_mode = strcmp(e, "on") == 0 ? 1 : (strcmp(e, "off") == 0 ? 0 : 2);
     if (const char* e = getenv("NGP_FUSED_TAIL")) s->fused_tail = atoi(e) != 0;
     if (const char* e = getenv("NGP_MERGE_IN_ADAM")) s->merge_in_adam = atoi(e) != 0;
+    if (const char* e = getenv("NGP_LISTS_AHEAD")) s->lists_ahead = atoi(e) != 0;
     if (const char* e = getenv("NGP_TWO_ROUND_K")) { const int k = atoi(e); if (k >= 1 && k <= 64) s->two_round_k = k; }
     (void)hipGetDevice(&s->device);
     hipError_t e = hipSuccess;
@@ -212,6 +238,14 @@ int ngp_stepper_create(const ngp_stepper_config* config, const ngp_step_buffers*
         for (int j = 0; j < 2 && e == hipSuccess; ++j) e = hipEventCreate(&s->march_t[k][j]);
     }
     for (int i = 0; i < N_MARKS && e == hipSuccess; ++i) e = hipEventCreate(&s->mark[i]);
+    if (s->lists_ahead && e == hipSuccess) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);                  // (hi = numerically smallest = most urgent)
+        e = hipStreamCreateWithPriority(&s->aux, hipStreamNonBlocking, hi);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_pos, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_lists, hipEventDisableTiming);
+        for (int j = 0; j < 2 && e == hipSuccess; ++j) e = hipEventCreate(&s->lists_t[j]);
+    }
     if (e != hipSuccess) { ngp_stepper_destroy(s); return (int)e; }
     *out = s;
     return 0;
@@ -226,6 +260,10 @@ int ngp_stepper_destroy(ngp_stepper* s) {
         for (int j = 0; j < 2; ++j) if (s->march_t[k][j]) (void)hipEventDestroy(s->march_t[k][j]);
     }
     for (int i = 0; i < N_MARKS; ++i) if (s->mark[i]) (void)hipEventDestroy(s->mark[i]);
+    if (s->aux) { (void)hipStreamSynchronize(s->aux); (void)hipStreamDestroy(s->aux); }
+    if (s->ev_pos) (void)hipEventDestroy(s->ev_pos);
+    if (s->ev_lists) (void)hipEventDestroy(s->ev_lists);
+    for (int j = 0; j < 2; ++j) if (s->lists_t[j]) (void)hipEventDestroy(s->lists_t[j]);
     destroy_exchange_events(s);
     delete s;
     return 0;
@@ -246,10 +284,29 @@ int ngp_stepper_set_buffers(ngp_stepper* s, const ngp_step_buffers* buffers) {
     STEP_TRY(ngp_stepper_drop_pending(s));
     STEP_TRY(check_buffers(s->c, *buffers));
     s->b = *buffers;
+    s->two_sample_sets = false; s->expanded[0] = s->expanded[1] = false;     // the second sample set belonged to the old buffers
     s->S = 0; s->n_part = 0;
     s->set_k[0] = s->set_k[1] = 0;                       // (no march of the new record sets has prepared a first-round list)
     s->two_round_active = false; s->two_rounds = false;  // the auto switch starts over: its evidence (live fraction of the previous
     s->prev_S = 0;                                       //  step, counter[.][2] of the OLD pinned words) does not describe these buffers
+    return 0;
+}
+
+int ngp_stepper_set_sample_sets(ngp_stepper* s, float* xyzs1, float* dirs1, float* deltas1, float* ts1) {
+    if (!s) return NGP_EINVAL;
+    STEP_TRY(ngp_stepper_drop_pending(s));               // a pending march may be writing into the set that goes away
+    const bool all = xyzs1 && dirs1 && deltas1 && ts1, none = !xyzs1 && !dirs1 && !deltas1 && !ts1;
+    if (!all && !none) return NGP_EINVAL;
+    if (s->two_sample_sets) {                            // back to the caller's ngp_step_buffers pointers first
+        s->b.xyzs = s->samples[0].xyzs; s->b.dirs = s->samples[0].dirs; s->b.deltas = s->samples[0].deltas; s->b.ts = s->samples[0].ts;
+    }
+    s->expanded[0] = s->expanded[1] = false;
+    s->two_sample_sets = all;
+    if (all) {
+        NGP_CHECK_PTR(xyzs1); NGP_CHECK_PTR(dirs1); NGP_CHECK_PTR(deltas1); NGP_CHECK_PTR(ts1);
+        s->samples[0] = {s->b.xyzs, s->b.dirs, s->b.deltas, s->b.ts};
+        s->samples[1] = {xyzs1, dirs1, deltas1, ts1};
+    }
     return 0;
 }
 
@@ -282,7 +339,11 @@ static int forward_field(ngp_stepper* s, const float* rays_o, const float* rays_
     const int32_t S = b.counter[k][0];
     if (S < 0 || (int64_t)S > b.cap) return NGP_EINVAL;
     s->S = S; s->last_set = k; s->n_part = 0;
+    s->lists_step = s->lists_pending = false; s->lists_t_set = false;
     *k_out = k;
+    if (s->two_sample_sets) {              // every later stage of this step reads the samples through s->b
+        s->b.xyzs = s->samples[k].xyzs; s->b.dirs = s->samples[k].dirs; s->b.deltas = s->samples[k].deltas; s->b.ts = s->samples[k].ts;
+    }
     const int n = b.n_rays;
     for (int i = 0; i < N_MARKS; ++i) s->mark_set[i] = false;
     mark(s, 0, main);
@@ -306,8 +367,9 @@ static int forward_field(ngp_stepper* s, const float* rays_o, const float* rays_
     s->two_rounds = two;
     const ngp_half* table = c.enc_half + c.n_density;
     if (!two) {
-        STEP_TRY(ngp_raymarching_train_write(rays_o, rays_d, b.rays_a[k], b.scratch[k], c.scale, c.exp_step_factor, c.grid_size, c.max_samples, n,
-                                             b.xyzs, b.dirs, b.deltas, b.ts, main_stream));
+        if (!s->expanded[k])
+            STEP_TRY(ngp_raymarching_train_write(rays_o, rays_d, b.rays_a[k], b.scratch[k], c.scale, c.exp_step_factor, c.grid_size, c.max_samples, n,
+                                                 b.xyzs, b.dirs, b.deltas, b.ts, main_stream));
         mark(s, 1, main);
         if (S > 0) {
             STEP_TRY(ngp_hashgrid_fwd(b.xyzs, c.xyz_min, c.xyz_max, table, &c.meta, S, b.feats, main_stream));
@@ -387,6 +449,18 @@ static int backward_field(ngp_stepper* s, const float* dL_dopacity, const float*
     }
     mark(s, 5, main);
     STEP_TRY(march_next_if_at(s, AT_COMPOSITE_BW));
+    s->lists_step = s->lists_pending = false;
+    if (s->binned && s->aux) {
+        // the live samples' positions (x_act, n_active) exist from here on: the table backward's lists are built underneath the
+        // field backward, whose gradients only the slice owners read
+        STEP_HIP(hipEventRecord(s->ev_pos, main));
+        STEP_HIP(hipStreamWaitEvent(s->aux, s->ev_pos, 0));
+        if (s->timing) STEP_HIP(hipEventRecord(s->lists_t[0], s->aux));
+        STEP_TRY(ngp_hashgrid_bwd_binned_lists(b.x_act, c.xyz_min, c.xyz_max, &c.meta, S, nullptr, b.n_active, b.bin_ws, b.bin_bytes, (ngp_stream_t)s->aux));
+        if (s->timing) { STEP_HIP(hipEventRecord(s->lists_t[1], s->aux)); s->lists_t_set = true; }
+        STEP_HIP(hipEventRecord(s->ev_lists, s->aux));
+        s->lists_step = s->lists_pending = true;
+    }
     const int n_part = ngp_field_bwd_partials(S);
     if (n_part < 1 || n_part > b.max_partials) return NGP_EINVAL;
     STEP_TRY(ngp_field_bwd(b.feats, b.dirs, b.h, c.enc_half, c.rgb_half, b.dL_dsigmas, b.dL_drgbs, loss_scale, S, b.active, b.n_active,
@@ -500,6 +574,24 @@ int ngp_stepper_render_backward(ngp_stepper* s, const float* g_rgb, const float*
     return backward_field(s, g_o, g_depth ? g_depth : b.zeros, g_rgb, g_ws, loss_scale, ngp_stream(main_stream), main_stream, n_partials);
 }
 
+// One launch group of the binned table backward on the main stream: behind the lists where backward_field() sent them ahead.
+static int table_backward_group(ngp_stepper* s, int n_groups, int group, ngp_grid_partials* partials_out, ngp_stream_t main_stream) {
+    const ngp_stepper_config& c = s->c;
+    const ngp_step_buffers& b = s->b;
+    if (s->lists_step) {
+        if (s->lists_pending) {
+            STEP_HIP(hipStreamWaitEvent(ngp_stream(main_stream), s->ev_lists, 0));
+            s->lists_pending = false;
+        }
+        return ngp_hashgrid_bwd_binned_owners(b.x_act, c.xyz_min, c.xyz_max, b.dfeats, &c.meta, s->S, nullptr, b.n_active, b.bin_ws, b.bin_bytes,
+                                              c.grid_grad16, n_groups, group, partials_out, main_stream);
+    }
+    if (partials_out) return ngp_hashgrid_bwd_binned_deferred(b.x_act, c.xyz_min, c.xyz_max, b.dfeats, &c.meta, s->S, nullptr, b.n_active, b.bin_ws,
+                                                              b.bin_bytes, c.grid_grad16, partials_out, main_stream);
+    return ngp_hashgrid_bwd_binned_group(b.x_act, c.xyz_min, c.xyz_max, b.dfeats, &c.meta, s->S, nullptr, b.n_active, b.bin_ws, b.bin_bytes,
+                                         c.grid_grad16, n_groups, group, main_stream);
+}
+
 int ngp_stepper_table_backward(ngp_stepper* s, int n_groups, int group, ngp_stream_t main_stream) {
     if (!s || n_groups < 1 || group < 0 || group >= n_groups) return NGP_EINVAL;
     HostTimer host_timer(&s->t_enqueue);
@@ -507,8 +599,7 @@ int ngp_stepper_table_backward(ngp_stepper* s, int n_groups, int group, ngp_stre
     const ngp_stepper_config& c = s->c;
     const ngp_step_buffers& b = s->b;
     if (s->binned) {
-        STEP_TRY(ngp_hashgrid_bwd_binned_group(b.x_act, c.xyz_min, c.xyz_max, b.dfeats, &c.meta, s->S, nullptr, b.n_active, b.bin_ws, b.bin_bytes,
-                                               c.grid_grad16, n_groups, group, main_stream));
+        STEP_TRY(table_backward_group(s, n_groups, group, nullptr, main_stream));
     } else if (group == 0) {
         STEP_TRY(ngp_hashgrid_bwd_sliced(b.xyzs, c.xyz_min, c.xyz_max, b.dfeats, &c.meta, s->S, b.active, b.n_active, c.grid_grad16, main_stream));
     }
@@ -554,8 +645,7 @@ int ngp_stepper_backward_update(ngp_stepper* s, float lr, int32_t step, float gr
     HostTimer host_timer(&s->t_enqueue);
     if (!c.enc_param || !c.enc_m || !c.enc_v || !c.rgb_param || !c.rgb_m || !c.rgb_v) return NGP_EINVAL;
     ngp_grid_partials gp;
-    const int rc = ngp_hashgrid_bwd_binned_deferred(b.x_act, c.xyz_min, c.xyz_max, b.dfeats, &c.meta, s->S, nullptr, b.n_active, b.bin_ws, b.bin_bytes,
-                                                    c.grid_grad16, &gp, main_stream);
+    const int rc = table_backward_group(s, 1, 0, &gp, main_stream);
     if (rc) return rc;
     mark(s, 7, ngp_stream(main_stream));
     STEP_TRY(march_next_if_at(s, AT_HASHGRID_BWD));
@@ -651,8 +741,7 @@ int ngp_stepper_tail(ngp_stepper* s, float lr, int32_t step, float grad_scale, n
     if (S > 0) {
         if (s->binned) {
             for (int g = 0; g < x.n_groups; ++g) {
-                STEP_TRY(ngp_hashgrid_bwd_binned_group(b.x_act, c.xyz_min, c.xyz_max, b.dfeats, &c.meta, S, nullptr, b.n_active, b.bin_ws, b.bin_bytes,
-                                                       c.grid_grad16, x.n_groups, g, main_stream));
+                STEP_TRY(table_backward_group(s, x.n_groups, g, nullptr, main_stream));
                 if (g + 1 < x.n_groups) STEP_TRY(hand_over(s->group_end[g]));
             }
         } else {
@@ -741,6 +830,12 @@ int ngp_stepper_stage_times(ngp_stepper* s, float* ms) {
             ms[i - 1] = t;
         }
         prev = i;
+    }
+    if (s->lists_t_set && ms[6] >= 0) {          // the lists ran on the stepper's stream: their time belongs to the table backward's stage
+        STEP_HIP(hipEventSynchronize(s->lists_t[1]));
+        float t = 0.f;
+        STEP_HIP(hipEventElapsedTime(&t, s->lists_t[0], s->lists_t[1]));
+        ms[6] += t;
     }
     const int k = s->last_set;
     if (s->march_t_set[k]) {

@@ -344,7 +344,7 @@ class _NativeTrainRender(torch.autograd.Function):
         f32 = torch.float32
         opacity, depth = B.opacity, B.depth
         rgb_out = B.fixed("rgb_out", f32, n, 3)
-        ws, deltas, ts = B.prefix("ws", f32, S), B.prefix("deltas", f32, S), B.prefix("ts", f32, S)
+        ws, deltas, ts = B.prefix("ws", f32, S), B.prefix(B.sample_name("deltas", k), f32, S), B.prefix(B.sample_name("ts", k), f32, S)
         rays_a = B.fixed("rays_a%d" % k, torch.int64, n, 3)
         vr_samples = B.total.sum()
         rm_samples = torch.tensor(S, dtype=torch.int32)

@@ -19,13 +19,16 @@ def _align(x, a=256):
 
 class StepBuffers:
     """Every buffer a step touches, allocated ONCE per batch size: the sample-proportional ones at the worst
-    case S = R * MAX_SAMPLES (276 B per sample slot: 2.3 GB for 8192 rays -- under 1 % of the 288 GB of HBM; only
+    case S = R * MAX_SAMPLES (308 B per sample slot: 2.6 GB for 8192 rays -- under 1 % of the 288 GB of HBM; only
     the first S rows of each are ever touched), two sets of march records (the march of batch k+1 runs while
     step k still reads its own), pinned count words, the table-backward workspace.  After construction a step
     performs no hipMalloc / hipHostMalloc / hipFuncSetAttribute: the first timed step costs what the 10 000th does."""
 
     PER_SAMPLE = (("xyzs", 12), ("dirs", 12), ("deltas", 4), ("ts", 4), ("feats", 64), ("h", 32), ("sigmas", 4), ("rgbs", 12),
-                  ("ws", 4), ("dL_dsigmas", 4), ("dL_drgbs", 12), ("active", 4), ("x_act", 12), ("dh", 32), ("dfeats", 64))
+                  ("ws", 4), ("dL_dsigmas", 4), ("dL_drgbs", 12), ("active", 4), ("x_act", 12), ("dh", 32), ("dfeats", 64),
+                  # the packed samples a second time: a prefetched march expands into the set the running step does not read
+                  # (ngp_stepper_set_sample_sets)
+                  ("xyzs1", 12), ("dirs1", 12), ("deltas1", 4), ("ts1", 4))
     DISTORTION = (("ws_incl", 4), ("wts_incl", 4), ("dL_dws", 4))
     PER_RAY = (("total", 8), ("opacity", 4), ("depth", 4), ("rgb", 12), ("dL_drgb", 12), ("dL_dopacity", 4), ("ray_offs", 4),
                ("dist", 4), ("zeros", 4), ("dist_seed", 4), ("rgb_out", 12))
@@ -149,11 +152,26 @@ class StepBuffers:
         c.bin_ws, c.bin_bytes, c.bin_max = (P["bin_ws"] if self.bin_max else None), self.bin_bytes, self.bin_max
         return c
 
-    def sample_views(self, S):
-        """Tensor views of the last step's packed samples (debugging / tests; the step itself uses raw pointers)."""
+    def attach_sample_sets(self, handle):
+        """Hands the second set of packed-sample buffers to a stepper (NGP_TWO_SAMPLE_SETS=0: one set, expansion on the main stream).
+        Which set a step read: `sample_set(handle)`."""
+        self.two_sets = os.environ.get("NGP_TWO_SAMPLE_SETS", "1") != "0"
+        if self.two_sets:
+            P = self.p
+            call("ngp_stepper_set_sample_sets", handle, P["xyzs1"], P["dirs1"], P["deltas1"], P["ts1"])
+        return self.two_sets
+
+    def sample_name(self, name, k):
+        """Buffer name of packed-sample array `name` (xyzs / dirs / deltas / ts) in sample set k (ngp_stepper_last_set)."""
+        return name + "1" if (k == 1 and getattr(self, "two_sets", False)) else name
+
+    def sample_views(self, S, k=0):
+        """Tensor views of the last step's packed samples (debugging / tests; the step itself uses raw pointers).  k: the sample
+        set the step read (ngp_stepper_last_set() of a stepper with two sets, else 0)."""
         f32 = torch.float32
-        return dict(xyzs=self.view("xyzs", f32, S, 3), dirs=self.view("dirs", f32, S, 3), deltas=self.view("deltas", f32, S),
-                    ts=self.view("ts", f32, S), sigmas=self.view("sigmas", f32, S), rgbs=self.view("rgbs", f32, S, 3),
+        nm = lambda a: self.sample_name(a, k)       # noqa: E731
+        return dict(xyzs=self.view(nm("xyzs"), f32, S, 3), dirs=self.view(nm("dirs"), f32, S, 3), deltas=self.view(nm("deltas"), f32, S),
+                    ts=self.view(nm("ts"), f32, S), sigmas=self.view("sigmas", f32, S), rgbs=self.view("rgbs", f32, S, 3),
                     ws=self.view("ws", f32, S))
 
 
@@ -220,4 +238,5 @@ class RenderStepper:
             h = C.c_void_p()
             call("ngp_stepper_create", C.byref(c), C.byref(bc), C.byref(h))
             self.handle, self.key = h, key
+            self.buf.attach_sample_sets(h)
         return self.buf, self.handle

@@ -165,6 +165,7 @@ class Trainer:
             if self._stepper is not None:
                 bc = self._buf.c_struct(self.lambda_distortion > 0)
                 call("ngp_stepper_set_buffers", self._stepper, C.byref(bc))
+                self._buf.attach_sample_sets(self._stepper)
         return self._buf
 
     def host_times(self, reset=True):
@@ -219,6 +220,7 @@ class Trainer:
         h = C.c_void_p()
         call("ngp_stepper_create", C.byref(c), C.byref(bc), C.byref(h))
         self._stepper, self._stepper_key = h, key
+        B.attach_sample_sets(h)
         self._pending_key = self._pending_keep = None
         self._timing_on = False
         if self.native_exchange is not None:

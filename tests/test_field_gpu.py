@@ -551,6 +551,63 @@ def test_binned_backward_in_launch_groups(lib, field):
         assert covered == field.meta.total and torch.equal(out, ref)
 
 
+def test_binned_backward_lists_ahead_of_the_gradients(lib, field):
+    """ngp_hashgrid_bwd_binned_lists (pass 1 from the positions alone, every sample listed) + ngp_hashgrid_bwd_binned_owners
+    == the one-call form, which skips samples whose gradient is exactly zero on a level: a listed zero adds 0 to exact integer
+    sums, so the tables agree bit for bit -- with a third of the gradients zeroed, in launch groups, and with the dense levels
+    left as partial tables for the fused Adam (same record as _deferred)."""
+    meta = native_meta(lib)
+    n = 60000
+    x, _ = sample_points(n, seed=71)
+    g = torch.Generator().manual_seed(72)
+    dfe = (torch.randn(n, 32, generator=g) * 0.3).half()
+    dfe[torch.rand(n, generator=g) < 0.33] = 0                       # whole samples without gradient
+    dfe.view(n, 16, 2)[torch.rand(n, 16, generator=g) < 0.2] = 0     # and single levels
+    dfl = dfe.view(n, 16, 2).permute(1, 0, 2).contiguous().cuda()
+    xs = x.cuda().contiguous()
+    mnt = torch.full((3,), -0.5, device="cuda"); mxt = torch.full((3,), 0.5, device="cuda")
+    nbytes = lib.lib().ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(meta), n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    ref = torch.full((field.meta.total, 2), float("nan"), dtype=torch.float16, device="cuda")
+    lib.call("ngp_hashgrid_bwd_binned", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), n, None, None,
+             lib.ptr(ws), nbytes, lib.ptr(ref), lib.stream())
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for ng in (1, 3):
+        out = torch.full_like(ref, float("nan"))
+        ws.zero_()
+        torch.cuda.synchronize()
+        lib.call("ngp_hashgrid_bwd_binned_lists", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), C.byref(meta), n, None, None,
+                 lib.ptr(ws), nbytes, side.cuda_stream)                # another stream, before the gradients "exist"
+        side.synchronize()
+        for grp in range(ng):
+            lib.call("ngp_hashgrid_bwd_binned_owners", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), n, None, None,
+                     lib.ptr(ws), nbytes, lib.ptr(out), ng, grp, None, lib.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), ng
+    # partial tables for the fused Adam: the record and the tables' contents match the one-call _deferred form
+    gp_a, gp_b = lib.GridPartials(), lib.GridPartials()
+    out_a = torch.full_like(ref, float("nan")); out_b = torch.full_like(ref, float("nan"))
+    lib.call("ngp_hashgrid_bwd_binned_deferred", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), n, None, None,
+             lib.ptr(ws), nbytes, lib.ptr(out_a), C.byref(gp_a), lib.stream())
+    torch.cuda.synchronize()
+    part_a = ws.clone()
+    lib.call("ngp_hashgrid_bwd_binned_lists", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), C.byref(meta), n, None, None, lib.ptr(ws), nbytes, lib.stream())
+    lib.call("ngp_hashgrid_bwd_binned_owners", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), n, None, None,
+             lib.ptr(ws), nbytes, lib.ptr(out_b), 1, 0, C.byref(gp_b), lib.stream())
+    torch.cuda.synchronize()
+    assert gp_a.n_levels == gp_b.n_levels > 0 and gp_a.value_end == gp_b.value_end and gp_a.partial == gp_b.partial
+    lo = gp_a.value_end // 2
+    assert torch.equal(out_a[lo:], out_b[lo:]) and torch.equal(out_a[lo:], ref[lo:])
+    off = gp_a.partial - ws.data_ptr()
+    n_part_bytes = sum(int(gp_a.k_split[l]) * (int(gp_a.offset[l + 1]) - int(gp_a.offset[l])) for l in range(gp_a.n_levels)) * 8
+    assert torch.equal(part_a[off:off + n_part_bytes], ws[off:off + n_part_bytes])
+    # contract: the gradient-free pass takes no gradient pointer, the owners need one
+    with pytest.raises(RuntimeError):
+        lib.call("ngp_hashgrid_bwd_binned_owners", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), None, C.byref(meta), n, None, None,
+                 lib.ptr(ws), nbytes, lib.ptr(out_b), 1, 0, None, lib.stream())
+
+
 def test_exchange_helper_kernels(lib):
     """ngp_reduce_partials2 (both MLP blocks' partial rows in one launch) and ngp_found_inf2 (non-finite check over two
     buffers, alternating flags)."""

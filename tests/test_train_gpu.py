@@ -1169,3 +1169,64 @@ def test_merge_folded_into_adam_is_bit_identical():
             assert all(abs(p - q) <= 1e-5 * abs(p) + 1e-12 for p, q in zip(sa[2], sb[2])), (env, sa, sb)
         for (ka, pa), (kb, pb) in zip(ma.state_dict().items(), mb.state_dict().items()):
             assert ka == kb and torch.equal(pa, pb), (env, ka)
+
+
+def test_work_moved_off_the_main_stream_is_bit_identical():
+    """Two sets of packed-sample buffers (`ngp_stepper_set_sample_sets`, the default): the march of the next batch also EXPANDS its
+    samples on the marching stream, into the set the running step does not read.  Same kernel, same inputs, another stream: every
+    parameter, sample count and loss scalar bit for bit against one set with the expansion on the main stream
+    (NGP_TWO_SAMPLE_SETS=0), occupancy updates (which drop the prefetched march) included; and the steps do alternate sets."""
+    import os
+    from ngp_pl_amd import _lib
+    from ngp_pl_amd.trainer import Trainer
+    batches = [batch(2048, seed=2500 + i) for i in range(8)]
+
+    def run(env):
+        os.environ.update(env)
+        try:
+            m = make_model(seed=59)
+            tr = Trainer(m, warmup_steps=32)
+            log, sets = [], []
+            for i in range(80):
+                b, nb = batches[i % 8], batches[(i + 1) % 8]
+                out = tr.step(*b, next_batch=(nb[0], nb[1]))
+                k = _lib.call("ngp_stepper_last_set", tr._stepper)
+                sets.append(k)
+                sv = tr._buf.sample_views(out["rm_samples"], k)
+                log.append((out["rm_samples"], int(tr.last["n_active"].item()), tr.last["stats"].tolist(),
+                            float(sv["deltas"].double().sum()), float(sv["xyzs"].double().sum())))
+            torch.cuda.synchronize()
+            return m, log, sets, tr._buf.two_sets
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    ma, la, sa, two_a = run({})
+    assert two_a and set(sa) == {0, 1}
+    # ... and the same for the table backward's lists built on the stepper's own stream underneath the field backward
+    # (NGP_LISTS_AHEAD=1; the default builds them in front of the slice owners on the main stream, skipping zero-gradient samples)
+    for env in ({"NGP_TWO_SAMPLE_SETS": "0"}, {"NGP_LISTS_AHEAD": "1"}, {"NGP_TWO_SAMPLE_SETS": "0", "NGP_LISTS_AHEAD": "1"}):
+        mb, lb, sb, two_b = run(env)
+        assert two_b == ("NGP_TWO_SAMPLE_SETS" not in env)
+        assert la == lb, (env, [i for i in range(80) if la[i] != lb[i]][:5])
+        for (ka, pa), (kb, pb) in zip(ma.state_dict().items(), mb.state_dict().items()):
+            assert ka == kb and torch.equal(pa, pb), (env, ka)
+
+
+def test_set_sample_sets_contract():
+    """All four pointers or none; a re-seat of the buffers forgets the second set; with one set the library runs as before."""
+    from ngp_pl_amd import _lib
+    from ngp_pl_amd.trainer import Trainer
+    m = make_model(seed=61)
+    tr = Trainer(m)
+    b = batch(1024, seed=2600)
+    tr.step(*b)
+    h, B = tr._stepper, tr._buf
+    with pytest.raises(RuntimeError):
+        _lib.call("ngp_stepper_set_sample_sets", h, B.p["xyzs1"], None, B.p["deltas1"], B.p["ts1"])
+    _lib.call("ngp_stepper_set_sample_sets", h, None, None, None, None)
+    B.two_sets = False
+    out1 = tr.step(*b)
+    assert _lib.call("ngp_stepper_last_set", h) in (0, 1) and out1["rm_samples"] > 0
+    B.attach_sample_sets(h)
+    out2 = tr.step(*b)
+    assert math.isfinite(tr.metrics()["loss"]) and out2["rm_samples"] > 0
