@@ -99,14 +99,61 @@ __device__ __forceinline__ void cell_of(const float* __restrict__ x, const Box& 
     }
 }
 
+// The 8 corner values of a cell.  On a hashed level the corners (x, y', z') and (x+1, y', z') have the indices (x ^ h) & mask and
+// ((x+1) ^ h) & mask with the same h: for EVEN x they differ in bit 0 only, i.e. they are the two halves of one aligned 8-byte pair
+// of the table, and one 8-byte load per lane fetches both; for odd x the carry sends x+1 somewhere else and the second corner is
+// loaded on its own -- under the lane mask, by the odd lanes only: 4 + 4/2 = 6 lane addresses per cell on average instead of 8.
+// Same table entries, same values: bit-identical (tests/test_field_gpu.py ran green on it).  MEASURED AND NOT KEPT (round 4,
+// tools/r04_call20.sh, same box, alternating runs): the training step's forward 0.0598 / 0.0604 ms -> 0.0715 / 0.0711 ms, the step
+// 0.3651 / 0.3623 -> 0.3763 / 0.3765 ms.  An 8-byte gather costs the vector memory path more than the 4-byte one it replaces plus
+// the half-masked one it saves: what is charged is not the lane address alone.  -DNGP_FWD_PAIR=1 builds it.
+// (Level offsets are multiples of 8 entries and the table is 16-byte aligned: an even index is an 8-byte aligned address.)
+#ifndef NGP_FWD_PAIR
+#define NGP_FWD_PAIR 0
+#endif
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+template <bool HASHED>
+__device__ __forceinline__ void gather_corners(const half2_t* __restrict__ tab, const uint32_t (&p)[3], uint32_t res, uint32_t size,
+                                               half2_t (&v)[8]) {
+    if (HASHED && NGP_FWD_PAIR) {
+        const uint32_t mask = size - 1u;
+        const uint32_t hy0 = p[1] * PRIME_Y, hz0 = p[2] * PRIME_Z;
+        const uint32_t hy[2] = {hy0, hy0 + PRIME_Y}, hz[2] = {hz0, hz0 + PRIME_Z};
+        uint32_t i0[4], i1[4];
+        half4_t pr[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t h = hy[k & 1] ^ hz[k >> 1];
+            i0[k] = (p[0] ^ h) & mask; i1[k] = ((p[0] + 1u) ^ h) & mask;
+            pr[k] = *reinterpret_cast<const half4_t*>(tab + (i0[k] & ~1u));
+        }
+        half2_t far[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { far[k][0] = (_Float16)0; far[k][1] = (_Float16)0; }
+        if (p[0] & 1u) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) far[k] = tab[i1[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            half2_t lo, hi; lo[0] = pr[k][0]; lo[1] = pr[k][1]; hi[0] = pr[k][2]; hi[1] = pr[k][3];
+            const bool up = i0[k] & 1u;
+            v[2 * k] = up ? hi : lo;
+            v[2 * k + 1] = (p[0] & 1u) ? far[k] : (up ? lo : hi);
+        }
+    } else {
+        uint32_t idx[8];
+        corner_indices<HASHED>(p, res, size, idx);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = tab[idx[c]];
+    }
+}
+
 template <bool HASHED>
 __device__ __forceinline__ void encode_one(const half2_t* __restrict__ tab, uint32_t res, uint32_t size,
                                            const uint32_t (&p)[3], const float (&f)[3], float& o0, float& o1) {
-    uint32_t idx[8];
-    corner_indices<HASHED>(p, res, size, idx);
     half2_t v[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) v[c] = tab[idx[c]];
+    gather_corners<HASHED>(tab, p, res, size, v);
     o0 = 0.f; o1 = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -159,11 +206,8 @@ hashgrid_fwd_kernel(const float* __restrict__ x, const float* __restrict__ xyz_m
 #pragma unroll
         for (int c = 0; c < 8; ++c) { v[c][0] = (_Float16)0; v[c][1] = (_Float16)0; }
         if (first) {
-            uint32_t idx[8];
-            if (hashed) corner_indices<true>(p, res, size, idx);
-            else corner_indices<false>(p, res, size, idx);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] = tab[idx[c]];
+            if (hashed) gather_corners<true>(tab, p, res, size, v);
+            else gather_corners<false>(tab, p, res, size, v);
         }
         float o0 = 0.f, o1 = 0.f;
 #pragma unroll
@@ -177,21 +221,17 @@ hashgrid_fwd_kernel(const float* __restrict__ x, const float* __restrict__ xyz_m
         if (ok) __builtin_nontemporal_store(out, feats + (size_t)level * n_samples + i);
         return;
     }
-    uint32_t idx[SPT][8]; float f[SPT][3]; bool ok[SPT];
+    float f[SPT][3]; bool ok[SPT];
+    half2_t v[SPT][8];
 #pragma unroll
     for (int k = 0; k < SPT; ++k) {
         const int i = (chunk * SPT + k) * 256 + threadIdx.x;
         ok[k] = i < n_samples;
         uint32_t p[3];
         cell_of(x, box, (size_t)(ok[k] ? i : 0), scale, p, f[k]);
-        if (hashed) corner_indices<true>(p, res, size, idx[k]);
-        else corner_indices<false>(p, res, size, idx[k]);
+        if (hashed) gather_corners<true>(tab, p, res, size, v[k]);
+        else gather_corners<false>(tab, p, res, size, v[k]);
     }
-    half2_t v[SPT][8];
-#pragma unroll
-    for (int k = 0; k < SPT; ++k)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) v[k][c] = tab[idx[k][c]];
 #pragma unroll
     for (int k = 0; k < SPT; ++k) {
         float o0 = 0.f, o1 = 0.f;
@@ -262,11 +302,8 @@ hashgrid_fwd_persist_kernel(const float* __restrict__ x, const float* __restrict
 #pragma unroll
         for (int c = 0; c < 8; ++c) { v[c][0] = (_Float16)0; v[c][1] = (_Float16)0; }
         if (first) {
-            uint32_t idx[8];
-            if (hashed) corner_indices<true>(p, res, size, idx);
-            else corner_indices<false>(p, res, size, idx);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] = tab[idx[c]];
+            if (hashed) gather_corners<true>(tab, p, res, size, v);
+            else gather_corners<false>(tab, p, res, size, v);
         }
         float o0 = 0.f, o1 = 0.f;
 #pragma unroll
@@ -320,11 +357,8 @@ hashgrid_fwd_list_kernel(const float* __restrict__ x, const float* __restrict__ 
 #pragma unroll
         for (int c = 0; c < 8; ++c) { v[c][0] = (_Float16)0; v[c][1] = (_Float16)0; }
         if (first) {
-            uint32_t idx[8];
-            if (hashed) corner_indices<true>(p, res, size, idx);
-            else corner_indices<false>(p, res, size, idx);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] = tab[idx[c]];
+            if (hashed) gather_corners<true>(tab, p, res, size, v);
+            else gather_corners<false>(tab, p, res, size, v);
         }
         float o0 = 0.f, o1 = 0.f;
 #pragma unroll
