@@ -422,6 +422,23 @@ int ngp_hashgrid_bwd_binned_deferred(const float* x, const float* xyz_min, const
                                      const int32_t* active_idx, const int32_t* n_active,
                                      void* workspace, size_t workspace_bytes, ngp_half* grad_table,
                                      ngp_grid_partials* partials_out, ngp_stream_t stream);
+/* _deferred with the Adam update of every level whose gradient is FINAL inside the launch (all but the K-split coarse levels
+ * described by *partials_out: the hashed levels, 92 % of the reference table) applied by the slice owners' write-out: parameters
+ * (f32 masters grid_param, f16 copies grid_param_h) and moments of those levels are updated in place -- same arithmetic and
+ * hyper-parameter forms as ngp_adam_step_field (apex FusedAdam, train.py:131-137; step >= 1 gives the bias corrections,
+ * grad_scale the factor the gradient carries), bit-identical to _deferred + ngp_adam_step_field_merge over the whole table.
+ * The caller finishes the step with ngp_adam_step_field_merge over the FIRST partials_out->value_end gradient values only
+ * (n_grid = value_end) plus the MLP blocks.  grad_table still receives the f16 gradient.  No skip flag: a caller that may have to
+ * skip the step (GradScaler, data parallel) uses the separate launches.  Measured on MI355X: slower than the separate launches
+ * (a slice owner streams at what one CU sustains and its registers fill the CU); the stepper uses it only under NGP_ADAM_IN_APPLY=1. */
+int ngp_hashgrid_bwd_binned_adam(const float* x, const float* xyz_min, const float* xyz_max,
+                                 const ngp_half* dfeats, const ngp_grid_meta* meta, int n_samples,
+                                 const int32_t* active_idx, const int32_t* n_active,
+                                 void* workspace, size_t workspace_bytes, ngp_half* grad_table,
+                                 ngp_grid_partials* partials_out,
+                                 float* grid_param, ngp_half* grid_param_h, float* grid_m, float* grid_v,
+                                 float lr, float beta1, float beta2, float eps, float weight_decay,
+                                 int step, float grad_scale, ngp_stream_t stream);
 int ngp_hashgrid_bwd_binned_group_entries(const ngp_grid_meta* meta, int n_samples, int n_groups, int group,
                                           int64_t* entry_begin, int64_t* entry_end);
 /* The two passes of the binned backward as separate calls.  Pass 1 (the per-slice sample lists) needs the live samples' positions

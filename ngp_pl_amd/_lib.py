@@ -175,6 +175,8 @@ _PROTOS = {
     "ngp_gather_xyz": [P, P, P, I, P, P],
     "ngp_hashgrid_bwd_binned": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P, C.c_size_t, P, P],
     "ngp_hashgrid_bwd_binned_group": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P, C.c_size_t, P, I, I, P],
+    "ngp_hashgrid_bwd_binned_adam": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P, C.c_size_t, P, C.POINTER(GridPartials), P, P, P, P,
+                                     F, F, F, F, F, I, F, P],
     "ngp_hashgrid_bwd_binned_lists": [P, P, P, C.POINTER(GridMeta), I, P, P, P, C.c_size_t, P],
     "ngp_hashgrid_bwd_binned_owners": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P, C.c_size_t, P, I, I, C.POINTER(GridPartials), P],
     "ngp_hashgrid_bwd_binned_group_entries": [C.POINTER(GridMeta), I, I, I, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libngp_hip.so")
 SOURCES = ["march.hip", "composite.hip", "hashgrid.hip", "mlp.hip", "optim.hip", "occupancy.hip", "hashgrid_bwd_binned.hip", "stepper.hip", "comm.hip"]
-HEADERS = ["ngp_common.h", "hashgrid_common.h", "loss_common.h", "comm.h", os.path.join("..", "..", "include", "ngp_hip.h")]
+HEADERS = ["ngp_common.h", "hashgrid_common.h", "loss_common.h", "comm.h", "adam_common.h", os.path.join("..", "..", "include", "ngp_hip.h")]
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",

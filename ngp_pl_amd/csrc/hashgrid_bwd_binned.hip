@@ -23,6 +23,7 @@
 // Levels with few slices (the coarse dense ones: a z-slab can hold most of the scene) additionally split
 // their lists over K tasks whose partial tables are summed by a small merge kernel (no atomics anywhere).
 #include "hashgrid_common.h"
+#include "adam_common.h"
 #include <hip/hip_fp16.h>
 
 using namespace ngp_grid;
@@ -487,11 +488,20 @@ __device__ __forceinline__ void apply_segments_dense_runs(long long* lds, uint32
     }
 }
 
+// FUSE_ADAM: the write-out of a level whose sums are final in the task (K == 1: the hashed levels, 92 % of the table) applies the
+// Adam update to the slice it has just summed -- 24 B read and 28 B written per entry as coalesced streams, issued by a workgroup
+// that has spent the task waiting on gathers and LDS: the dense Adam kernel (0.055 ms at 5.9 TB/s, nothing else running) shrinks
+// to the K-split levels and the MLP blocks, and the table's optimizer traffic rides under the slice owners' latencies.  The gradient
+// is rounded to f16 first and still written to grad_table: the same value the streaming kernel would have read (adam_common.h:
+// the same update, bit for bit).
+struct ApplyAdam { float2* param; half2_t* param_h; float2* m; float2* v; AdamCoef c; };
+
+template <bool FUSE_ADAM>
 __global__ void __launch_bounds__(APPLY_THREADS, NGP_APPLY_WAVES_PER_EU)
 apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const float* __restrict__ xyz_max,
              const half2_t* __restrict__ dfeats, GridMeta meta, BinPlan plan, BinWs ws, int n_samples,
              const int32_t* __restrict__ active, const int32_t* __restrict__ n_active, half2_t* __restrict__ grad_table,
-             int group, int task_begin, int task_end) {
+             int group, int task_begin, int task_end, ApplyAdam ad) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     long long* lds = reinterpret_cast<long long*>(smem_raw);
     __shared__ int s_task[2];                                          // s_task[k & 1]: id of the workgroup's k-th task
@@ -601,6 +611,34 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
             }
         }
 #else
+        if (FUSE_ADAM && K == 1) {
+            // all of the thread's parameter / moment loads first (the streams of a slice: 6912 x 24 B), then one entry at a time
+            constexpr int WO = (int)((SLICE2 + APPLY_THREADS - 1) / APPLY_THREADS);
+            const size_t e0 = (size_t)meta.offset[level] + lo;
+            float2* __restrict__ P = ad.param + e0; float2* __restrict__ M = ad.m + e0; float2* __restrict__ V = ad.v + e0;
+            half2_t* __restrict__ PH = ad.param_h + e0;
+            float2 pp[WO], mm[WO], vv[WO];
+#pragma unroll
+            for (int q = 0; q < WO; ++q) {
+                const uint32_t k = tid + q * APPLY_THREADS;
+                const uint32_t kc = k < len ? k : 0;
+                pp[q] = P[kc]; mm[q] = M[kc]; vv[q] = V[kc];
+            }
+#pragma unroll
+            for (int q = 0; q < WO; ++q) {
+                const uint32_t k = tid + q * APPLY_THREADS;
+                if (k < len) {
+                    const float a0 = (float)lds[2 * k] * inv, a1 = (float)lds[2 * k + 1] * inv;
+                    lds[2 * k] = 0; lds[2 * k + 1] = 0;
+                    half2_t g; g[0] = (_Float16)a0; g[1] = (_Float16)a1;
+                    out[k] = g;
+                    adam_one(pp[q].x, mm[q].x, vv[q].x, (float)g[0], ad.c);
+                    adam_one(pp[q].y, mm[q].y, vv[q].y, (float)g[1], ad.c);
+                    half2_t ph; ph[0] = (_Float16)pp[q].x; ph[1] = (_Float16)pp[q].y;
+                    P[k] = pp[q]; M[k] = mm[q]; V[k] = vv[q]; PH[k] = ph;
+                }
+            }
+        } else
         for (uint32_t k = tid; k < len; k += APPLY_THREADS) {
             const float a0 = (float)lds[2 * k] * inv, a1 = (float)lds[2 * k + 1] * inv;
             lds[2 * k] = 0; lds[2 * k + 1] = 0;                        // ready for the next task
@@ -743,7 +781,7 @@ static int binned_group_impl(const float* x, const float* xyz_min, const float* 
                              const ngp_grid_meta* meta, int n_samples, const int32_t* active_idx,
                              const int32_t* n_active, void* workspace, size_t workspace_bytes,
                              ngp_half* grad_table, int n_groups, int group, ngp_grid_partials* partials_out, ngp_stream_t stream,
-                             int pass = PASS_BOTH) {
+                             int pass = PASS_BOTH, const ApplyAdam* adam = nullptr) {
     if (n_samples < 0 || !meta || meta->n_features != 2 || meta->n_levels < 1 || meta->n_levels > NGP_MAX_LEVELS) return NGP_EINVAL;
     if (n_groups < 1 || n_groups > 16 || group < 0 || group >= n_groups) return NGP_EINVAL;
     NGP_CHECK_PTR(workspace);
@@ -779,7 +817,8 @@ static int binned_group_impl(const float* x, const float* xyz_min, const float* 
     (void)hipGetDevice(&dev);
     dev &= 63;
     if (!attr_set[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(apply_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(apply_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
         attr_set[dev] = true;
     }
@@ -789,8 +828,12 @@ static int binned_group_impl(const float* x, const float* xyz_min, const float* 
     const int n_tasks = task_end - task_begin;
     if (n_tasks > 0) {
         const int n_wg = n_tasks < NGP_APPLY_WGS ? n_tasks : NGP_APPLY_WGS;
-        apply_kernel<<<dim3(n_wg), dim3(APPLY_THREADS), smem, st>>>(
-            x, xyz_min, xyz_max, (const half2_t*)dfeats, dm, P, ws, n_samples, active_idx, n_active, (half2_t*)grad_table, group, task_begin, task_end);
+        if (adam != nullptr)
+            apply_kernel<true><<<dim3(n_wg), dim3(APPLY_THREADS), smem, st>>>(
+                x, xyz_min, xyz_max, (const half2_t*)dfeats, dm, P, ws, n_samples, active_idx, n_active, (half2_t*)grad_table, group, task_begin, task_end, *adam);
+        else
+            apply_kernel<false><<<dim3(n_wg), dim3(APPLY_THREADS), smem, st>>>(
+                x, xyz_min, xyz_max, (const half2_t*)dfeats, dm, P, ws, n_samples, active_idx, n_active, (half2_t*)grad_table, group, task_begin, task_end, ApplyAdam{});
     }
     if (partials_out != nullptr) {
         // the K-split levels must be a prefix of the table (coarse levels first: true for every grid this package builds)
@@ -840,6 +883,26 @@ int ngp_hashgrid_bwd_binned_owners(const float* x, const float* xyz_min, const f
                                    ngp_half* grad_table, int n_groups, int group, ngp_grid_partials* partials_out, ngp_stream_t stream) {
     return binned_group_impl(x, xyz_min, xyz_max, dfeats, meta, n_samples, active_idx, n_active, workspace, workspace_bytes, grad_table,
                              n_groups, group, partials_out, stream, PASS_OWNERS);
+}
+
+int ngp_hashgrid_bwd_binned_adam(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* dfeats,
+                                 const ngp_grid_meta* meta, int n_samples, const int32_t* active_idx,
+                                 const int32_t* n_active, void* workspace, size_t workspace_bytes,
+                                 ngp_half* grad_table, ngp_grid_partials* partials_out,
+                                 float* grid_param, ngp_half* grid_param_h, float* grid_m, float* grid_v,
+                                 float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                                 ngp_stream_t stream) {
+    NGP_CHECK_PTR(partials_out); NGP_CHECK_PTR(grid_param); NGP_CHECK_PTR(grid_param_h); NGP_CHECK_PTR(grid_m); NGP_CHECK_PTR(grid_v);
+    if (step < 1 || grad_scale == 0.f) return NGP_EINVAL;
+    ApplyAdam ad;
+    ad.param = reinterpret_cast<float2*>(grid_param); ad.param_h = reinterpret_cast<half2_t*>(grid_param_h);
+    ad.m = reinterpret_cast<float2*>(grid_m); ad.v = reinterpret_cast<float2*>(grid_v);
+    // (the streaming kernel's hyper-parameters, formed the same way: optim.hip adam_hyper())
+    ad.c.lr = lr; ad.c.beta1 = beta1; ad.c.beta2 = beta2; ad.c.eps = eps; ad.c.wd = weight_decay;
+    ad.c.bc1 = 1.0f - powf(beta1, (float)step); ad.c.bc2 = 1.0f - powf(beta2, (float)step);
+    ad.c.inv_scale = 1.0f / grad_scale;
+    return binned_group_impl(x, xyz_min, xyz_max, dfeats, meta, n_samples, active_idx, n_active, workspace, workspace_bytes, grad_table,
+                             1, 0, partials_out, stream, PASS_BOTH, &ad);
 }
 
 int ngp_hashgrid_bwd_binned(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* dfeats,

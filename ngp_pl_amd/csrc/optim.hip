@@ -7,6 +7,7 @@
 //  * ngp_nerf_loss    NeRFLoss (losses.py:47-60) + mean reduction (train.py:173) + background
 //                     blend (rendering.py:153-161) with analytic backward seeds.
 #include "ngp_common.h"
+#include "adam_common.h"
 #include "loss_common.h"
 #include <hip/hip_fp16.h>
 
@@ -48,7 +49,7 @@ template <bool GRAD_F32, bool MERGE = false>
 __device__ __forceinline__ void adam_dense(float* __restrict__ param, h1* __restrict__ param_h, void* __restrict__ grad,
                                            float* __restrict__ m, float* __restrict__ v, long long n4, long long n,
                                            const AdamHyper& hp, int block, int n_blocks, const GridPartials* gp = nullptr) {
-    const float lr = hp.lr, beta1 = hp.beta1, beta2 = hp.beta2, eps = hp.eps, wd = hp.wd, bc1 = hp.bc1, bc2 = hp.bc2, inv_scale = hp.inv_scale;
+    const AdamCoef coef = {hp.lr, hp.beta1, hp.beta2, hp.eps, hp.wd, hp.bc1, hp.bc2, hp.inv_scale};
     const bool skip = hp.found_inf_dense != nullptr && *hp.found_inf_dense != 0;
     const long long stride = (long long)n_blocks * blockDim.x;
     for (long long q = (long long)block * blockDim.x + threadIdx.x; q < n4; q += stride) {
@@ -86,11 +87,7 @@ __device__ __forceinline__ void adam_dense(float* __restrict__ param, h1* __rest
             half4_t ph;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float gk = g[k] * inv_scale;
-                mp[k] = beta1 * mp[k] + (1.f - beta1) * gk;
-                vp[k] = beta2 * vp[k] + (1.f - beta2) * gk * gk;
-                const float denom = sqrtf(vp[k] / bc2) + eps;
-                pp[k] = pp[k] - lr * ((mp[k] / bc1) / denom + wd * pp[k]);
+                adam_one(pp[k], mp[k], vp[k], g[k], coef);
                 ph[k] = (h1)pp[k];
             }
             *reinterpret_cast<float4*>(param + base) = p;
@@ -104,11 +101,8 @@ __device__ __forceinline__ void adam_dense(float* __restrict__ param, h1* __rest
                 if (GRAD_F32) { float* gp = reinterpret_cast<float*>(grad) + i; gk = *gp; if (hp.zero_grad) *gp = 0.f; }
                 else { h1* gp = reinterpret_cast<h1*>(grad) + i; gk = (float)*gp; if (hp.zero_grad) *gp = (h1)0; }
                 if (skip) continue;
-                gk *= inv_scale;
-                const float mk = beta1 * m[i] + (1.f - beta1) * gk;
-                const float vk = beta2 * v[i] + (1.f - beta2) * gk * gk;
-                const float denom = sqrtf(vk / bc2) + eps;
-                const float pk = param[i] - lr * ((mk / bc1) / denom + wd * param[i]);
+                float pk = param[i], mk = m[i], vk = v[i];
+                adam_one(pk, mk, vk, gk, coef);
                 m[i] = mk; v[i] = vk; param[i] = pk;
                 if (param_h) param_h[i] = (h1)pk;
             }
@@ -208,7 +202,7 @@ struct AdamPieces { long long piece, chunk, rank_off, n_grid; int n_chunks; };
 __device__ __forceinline__ void adam_dense_pieces(float* __restrict__ param, h1* __restrict__ param_h, const h1* __restrict__ grad,
                                                   float* __restrict__ m, float* __restrict__ v, const AdamPieces pc,
                                                   const AdamHyper& hp, int block, int n_blocks) {
-    const float lr = hp.lr, beta1 = hp.beta1, beta2 = hp.beta2, eps = hp.eps, wd = hp.wd, bc1 = hp.bc1, bc2 = hp.bc2, inv_scale = hp.inv_scale;
+    const AdamCoef coef = {hp.lr, hp.beta1, hp.beta2, hp.eps, hp.wd, hp.bc1, hp.bc2, hp.inv_scale};
     if (hp.found_inf_dense != nullptr && *hp.found_inf_dense != 0) return;
     const long long n4 = (long long)pc.n_chunks * pc.piece / 4, stride = (long long)n_blocks * blockDim.x;
     for (long long q = (long long)block * blockDim.x + threadIdx.x; q < n4; q += stride) {
@@ -222,11 +216,7 @@ __device__ __forceinline__ void adam_dense_pieces(float* __restrict__ param, h1*
         half4_t ph;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float gk = (float)t[k] * inv_scale;
-            mp[k] = beta1 * mp[k] + (1.f - beta1) * gk;
-            vp[k] = beta2 * vp[k] + (1.f - beta2) * gk * gk;
-            const float denom = sqrtf(vp[k] / bc2) + eps;
-            pp[k] = pp[k] - lr * ((mp[k] / bc1) / denom + wd * pp[k]);
+            adam_one(pp[k], mp[k], vp[k], (float)t[k], coef);
             ph[k] = (h1)pp[k];
         }
         *reinterpret_cast<float4*>(param + base) = p;

@@ -52,6 +52,11 @@ struct ngp_stepper {
     // two-round forward (include/ngp_hip.h): mode 0 off / 1 on / 2 auto, first K, the auto switch's state, steps run in two rounds
     bool render_tail = false;              // the last render_forward left live COUNTS (not offsets) in ray_offs
     int merge_in_adam = 1;                 // NGP_MERGE_IN_ADAM (default 1): ngp_stepper_backward_update folds the dense levels' merge into the Adam launch
+    int adam_in_apply = 0;                 // NGP_ADAM_IN_APPLY=1: ... and the hashed levels' Adam into the slice owners' write-out.  Measured and NOT the
+                                           // default (profiles/r04_step_ab.txt): table backward 0.094 -> 0.146 ms, Adam 0.058 -> 0.019 ms: +12 us per step.  A
+                                           // slice owner streams its slice's 387 KB at ~25 GB/s (what ONE CU sustains) while its 1024 threads x 128 registers
+                                           // fill the CU's register file, so nothing else runs there meanwhile: the streaming is not hidden, it is serialised
+                                           // per CU at a sixteenth of the rate the dense kernel gets from the whole chip.
     int fused_tail = 1;                    // NGP_FUSED_TAIL (default 1): composite forward / backward without the scan kernel between them
     int two_round_mode = 2, two_round_k = 32;
     bool two_round_active = false, two_rounds = false;
@@ -229,6 +234,11 @@ int ngp_stepper_create(const ngp_stepper_config* config, const ngp_step_buffers*
     if (const char* e = getenv("NGP_FUSED_TAIL")) s->fused_tail = atoi(e) != 0;
     if (const char* e = getenv("NGP_MERGE_IN_ADAM")) s->merge_in_adam = atoi(e) != 0;
     if (const char* e = getenv("NGP_LISTS_AHEAD")) s->lists_ahead = atoi(e) != 0;
+    if (const char* e = getenv("NGP_ADAM_IN_APPLY")) s->adam_in_apply = atoi(e) != 0;
+    {   // (needs a K-split level in front of the table: the streaming launch that finishes the step is the MERGE form)
+        const uint64_t r0 = c.meta.resolution[0], size0 = c.meta.offset[1] - c.meta.offset[0];
+        if (r0 * r0 * r0 > size0) s->adam_in_apply = 0;
+    }
     if (const char* e = getenv("NGP_TWO_ROUND_K")) { const int k = atoi(e); if (k >= 1 && k <= 64) s->two_round_k = k; }
     (void)hipGetDevice(&s->device);
     hipError_t e = hipSuccess;
@@ -645,11 +655,20 @@ int ngp_stepper_backward_update(ngp_stepper* s, float lr, int32_t step, float gr
     HostTimer host_timer(&s->t_enqueue);
     if (!c.enc_param || !c.enc_m || !c.enc_v || !c.rgb_param || !c.rgb_m || !c.rgb_v) return NGP_EINVAL;
     ngp_grid_partials gp;
-    const int rc = table_backward_group(s, 1, 0, &gp, main_stream);
-    if (rc) return rc;
+    int64_t n_streamed = c.n_grid;                               // gradient values the streaming Adam launch still has to apply
+    if (s->adam_in_apply && !s->lists_step) {
+        STEP_TRY(ngp_hashgrid_bwd_binned_adam(b.x_act, c.xyz_min, c.xyz_max, b.dfeats, &c.meta, s->S, nullptr, b.n_active, b.bin_ws, b.bin_bytes,
+                                              c.grid_grad16, &gp, c.enc_param + c.n_density, c.enc_half + c.n_density, c.enc_m + c.n_density,
+                                              c.enc_v + c.n_density, lr, c.beta1, c.beta2, c.eps, c.weight_decay, step, grad_scale, main_stream));
+        if (gp.n_levels < 1) return NGP_EUNSUP;                  // (excluded at creation)
+        n_streamed = gp.value_end;
+    } else {
+        const int rc = table_backward_group(s, 1, 0, &gp, main_stream);
+        if (rc) return rc;
+    }
     mark(s, 7, ngp_stream(main_stream));
     STEP_TRY(march_next_if_at(s, AT_HASHGRID_BWD));
-    STEP_TRY(ngp_adam_step_field_merge(c.enc_param + c.n_density, c.enc_half + c.n_density, c.grid_grad16, c.enc_m + c.n_density, c.enc_v + c.n_density, c.n_grid,
+    STEP_TRY(ngp_adam_step_field_merge(c.enc_param + c.n_density, c.enc_half + c.n_density, c.grid_grad16, c.enc_m + c.n_density, c.enc_v + c.n_density, n_streamed,
                                        c.enc_param, c.enc_half, b.partials, c.enc_m, c.enc_v, c.n_density,
                                        c.rgb_param, c.rgb_half, b.partials + (size_t)s->n_part * c.n_density, c.rgb_m, c.rgb_v, c.n_rgb,
                                        s->n_part, lr, c.beta1, c.beta2, c.eps, c.weight_decay, step, grad_scale, nullptr, nullptr, &gp, main_stream));

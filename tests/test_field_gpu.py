@@ -608,6 +608,65 @@ def test_binned_backward_lists_ahead_of_the_gradients(lib, field):
                  lib.ptr(ws), nbytes, lib.ptr(out_b), 1, 0, None, lib.stream())
 
 
+def test_adam_in_the_slice_owners_write_out_is_bit_identical(lib, field):
+    """ngp_hashgrid_bwd_binned_adam (the hashed levels' Adam applied by the table backward's write-out) followed by the streaming
+    launch over the K-split levels only == ngp_hashgrid_bwd_binned_deferred followed by the streaming launch over the whole table:
+    f32 masters, f16 copies, both moments and the f16 gradient table bit for bit, over three consecutive steps (moments in use)."""
+    meta = native_meta(lib)
+    n = 50000
+    n_grid = 2 * field.meta.total
+    mnt = torch.full((3,), -0.5, device="cuda"); mxt = torch.full((3,), 0.5, device="cuda")
+    nbytes = lib.lib().ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(meta), n)
+    g = torch.Generator().manual_seed(81)
+    nd, nr = 3072, 7168
+
+    def fresh():
+        gg = torch.Generator().manual_seed(82)
+        st = dict(p=(torch.rand(n_grid, generator=gg) * 2e-4 - 1e-4).cuda(), m=torch.zeros(n_grid, device="cuda"), v=torch.zeros(n_grid, device="cuda"),
+                  dp=torch.randn(nd, generator=gg).cuda(), dm=torch.zeros(nd, device="cuda"), dv=torch.zeros(nd, device="cuda"),
+                  rp=torch.randn(nr, generator=gg).cuda(), rm=torch.zeros(nr, device="cuda"), rv=torch.zeros(nr, device="cuda"))
+        st["p16"] = st["p"].half(); st["dp16"] = st["dp"].half(); st["rp16"] = st["rp"].half()
+        st["g16"] = torch.full((n_grid,), float("nan"), dtype=torch.float16, device="cuda")
+        st["ws"] = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        return st
+    A, B = fresh(), fresh()
+    hyper = (1e-2, 0.9, 0.999, 1e-15, 0.0)
+    for step in (1, 2, 3):
+        x, _ = sample_points(n, seed=90 + step)
+        dfe = (torch.randn(n, 32, generator=g) * 0.3).half()
+        dfl = dfe.view(n, 16, 2).permute(1, 0, 2).contiguous().cuda()
+        xs = x.cuda().contiguous()
+        part = (torch.randn(2, nd + nr, generator=g) * 1e-2).cuda()          # two rows of MLP weight-gradient partials
+        pd = part[:, :nd].contiguous(); pr = part[:, nd:].contiguous()
+        for st, fused in ((A, False), (B, True)):
+            gp = lib.GridPartials()
+            if fused:
+                lib.call("ngp_hashgrid_bwd_binned_adam", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), n, None, None,
+                         lib.ptr(st["ws"]), nbytes, lib.ptr(st["g16"]), C.byref(gp), lib.ptr(st["p"]), lib.ptr(st["p16"]), lib.ptr(st["m"]),
+                         lib.ptr(st["v"]), *hyper, step, 128.0, lib.stream())
+                n_streamed = gp.value_end
+                assert 0 < n_streamed < n_grid
+            else:
+                lib.call("ngp_hashgrid_bwd_binned_deferred", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), n, None, None,
+                         lib.ptr(st["ws"]), nbytes, lib.ptr(st["g16"]), C.byref(gp), lib.stream())
+                n_streamed = n_grid
+            lib.call("ngp_adam_step_field_merge", lib.ptr(st["p"]), lib.ptr(st["p16"]), lib.ptr(st["g16"]), lib.ptr(st["m"]), lib.ptr(st["v"]), n_streamed,
+                     lib.ptr(st["dp"]), lib.ptr(st["dp16"]), lib.ptr(pd), lib.ptr(st["dm"]), lib.ptr(st["dv"]), nd,
+                     lib.ptr(st["rp"]), lib.ptr(st["rp16"]), lib.ptr(pr), lib.ptr(st["rm"]), lib.ptr(st["rv"]), nr,
+                     2, *hyper, step, 128.0, None, None, C.byref(gp), lib.stream())
+        torch.cuda.synchronize()
+        lo = gp.value_end
+        for key in ("p", "p16", "m", "v", "dp", "dp16", "dm", "dv", "rp", "rp16", "rm", "rv"):
+            assert torch.equal(A[key], B[key]), (step, key)
+        assert torch.equal(A["g16"][lo:], B["g16"][lo:]), step                # (below value_end the gradient lives in the partial tables)
+        assert float((A["p"] - fresh()["p"]).abs().max()) > 1e-3             # the steps did move the table
+    # contract: the fused form needs the partials record and an optimizer state
+    with pytest.raises(RuntimeError):
+        lib.call("ngp_hashgrid_bwd_binned_adam", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), n, None, None,
+                 lib.ptr(B["ws"]), nbytes, lib.ptr(B["g16"]), C.byref(gp), lib.ptr(B["p"]), None, lib.ptr(B["m"]), lib.ptr(B["v"]),
+                 *hyper, 1, 128.0, lib.stream())
+
+
 def test_exchange_helper_kernels(lib):
     """ngp_reduce_partials2 (both MLP blocks' partial rows in one launch) and ngp_found_inf2 (non-finite check over two
     buffers, alternating flags)."""

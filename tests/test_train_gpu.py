@@ -1204,7 +1204,10 @@ def test_work_moved_off_the_main_stream_is_bit_identical():
     assert two_a and set(sa) == {0, 1}
     # ... and the same for the table backward's lists built on the stepper's own stream underneath the field backward
     # (NGP_LISTS_AHEAD=1; the default builds them in front of the slice owners on the main stream, skipping zero-gradient samples)
-    for env in ({"NGP_TWO_SAMPLE_SETS": "0"}, {"NGP_LISTS_AHEAD": "1"}, {"NGP_TWO_SAMPLE_SETS": "0", "NGP_LISTS_AHEAD": "1"}):
+    # ... and for the hashed levels' Adam applied by the table backward's write-out (NGP_ADAM_IN_APPLY=1) against the streaming
+    # launch over the whole table (the default)
+    for env in ({"NGP_TWO_SAMPLE_SETS": "0"}, {"NGP_LISTS_AHEAD": "1"}, {"NGP_ADAM_IN_APPLY": "1"},
+                {"NGP_TWO_SAMPLE_SETS": "0", "NGP_ADAM_IN_APPLY": "1"}):
         mb, lb, sb, two_b = run(env)
         assert two_b == ("NGP_TWO_SAMPLE_SETS" not in env)
         assert la == lb, (env, [i for i in range(80) if la[i] != lb[i]][:5])
