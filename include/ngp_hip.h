@@ -749,6 +749,21 @@ int ngp_occupancy_update(float* density_grid, uint8_t* density_bitfield, int cas
                          const float* xyz_min, const float* xyz_max, const ngp_half* table,
                          const ngp_grid_meta* meta, const ngp_half* density_w,
                          void* workspace, size_t workspace_bytes, ngp_stream_t stream);
+/* The same update (not warm-up, one cascade: NGP_EUNSUP otherwise) in two calls.  ngp_occupancy_draw = everything that depends
+ * only on the occupancy grid as the PREVIOUS update left it and on the seed: scratch clear, occupancy words, the 2 x G^3/4 draws,
+ * their regrouping and jittered positions (7 of the update's launches, ~0.09 ms).  It may run any time after the previous update
+ * is complete -- on another stream, underneath the 15 training steps in between (train.py:160-163 updates every 16th) -- as long
+ * as nothing else writes density_grid or the workspace until ngp_occupancy_update_drawn (same grid, threshold, seed, workspace)
+ * has finished the update behind it: field forward at the drawn positions, merge, mean, packing.  Same launches, same inputs:
+ * the two calls leave exactly what ngp_occupancy_update(warmup = 0) leaves. */
+int ngp_occupancy_draw(const float* density_grid, int cascades, int grid_size, float scale, float density_threshold,
+                       uint64_t seed, void* workspace, size_t workspace_bytes, ngp_stream_t stream);
+int ngp_occupancy_update_drawn(float* density_grid, uint8_t* density_bitfield, int cascades, int grid_size,
+                               float scale, float density_threshold, float decay, const float* decay_grid,
+                               uint64_t seed,
+                               const float* xyz_min, const float* xyz_max, const ngp_half* table,
+                               const ngp_grid_meta* meta, const ngp_half* density_w,
+                               void* workspace, size_t workspace_bytes, ngp_stream_t stream);
 
 /* ---- test-time frame loop -------------------------------------------------------------- */
 

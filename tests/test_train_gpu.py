@@ -322,6 +322,7 @@ def test_native_occupancy_update_matches_reference_semantics():
     enc = m.xyz_encoder
     field.density_w = enc.params.detach()[:enc.n_mlp].cpu().clone()
     field.table = enc.params.detach()[enc.n_mlp:].cpu().view(-1, 2).clone()
+    m.occ_draw_ahead = False          # this test reads an update's workspace back: the next update's draws must not be made into it meanwhile
     for warmup in (True, False):
         grid0 = torch.rand(1, cells, device="cuda", generator=g) * 12.0          # ~half the cells above thr
         grid0[0, torch.randint(cells, (5000,), device="cuda", generator=g)] = -1.0     # invisible cells stay -1
@@ -1196,6 +1197,7 @@ def test_work_moved_off_the_main_stream_is_bit_identical():
                 log.append((out["rm_samples"], int(tr.last["n_active"].item()), tr.last["stats"].tolist(),
                             float(sv["deltas"].double().sum()), float(sv["xyzs"].double().sum())))
             torch.cuda.synchronize()
+            assert (getattr(m, "_occ_ahead", None) is not None) == (env.get("NGP_OCC_DRAW_AHEAD", "0") == "1")
             return m, log, sets, tr._buf.two_sets
         finally:
             for k in env:
@@ -1206,8 +1208,10 @@ def test_work_moved_off_the_main_stream_is_bit_identical():
     # (NGP_LISTS_AHEAD=1; the default builds them in front of the slice owners on the main stream, skipping zero-gradient samples)
     # ... and for the hashed levels' Adam applied by the table backward's write-out (NGP_ADAM_IN_APPLY=1) against the streaming
     # launch over the whole table (the default)
-    for env in ({"NGP_TWO_SAMPLE_SETS": "0"}, {"NGP_LISTS_AHEAD": "1"}, {"NGP_ADAM_IN_APPLY": "1"},
-                {"NGP_TWO_SAMPLE_SETS": "0", "NGP_ADAM_IN_APPLY": "1"}):
+    # ... and for the occupancy update's draws made ahead on the model's own stream (NGP_OCC_DRAW_AHEAD=1; updates 48 and 64 of
+    # this run use them) against the update as one call (the default)
+    for env in ({"NGP_TWO_SAMPLE_SETS": "0"}, {"NGP_LISTS_AHEAD": "1"}, {"NGP_ADAM_IN_APPLY": "1"}, {"NGP_OCC_DRAW_AHEAD": "1"},
+                {"NGP_TWO_SAMPLE_SETS": "0", "NGP_ADAM_IN_APPLY": "1", "NGP_OCC_DRAW_AHEAD": "1"}):
         mb, lb, sb, two_b = run(env)
         assert two_b == ("NGP_TWO_SAMPLE_SETS" not in env)
         assert la == lb, (env, [i for i in range(80) if la[i] != lb[i]][:5])
@@ -1233,3 +1237,71 @@ def test_set_sample_sets_contract():
     B.attach_sample_sets(h)
     out2 = tr.step(*b)
     assert math.isfinite(tr.metrics()["loss"]) and out2["rm_samples"] > 0
+
+
+def test_occupancy_draws_made_ahead_equal_the_one_call_update():
+    """`ngp_occupancy_draw` + `ngp_occupancy_update_drawn` == `ngp_occupancy_update(warmup=0)`: grid, bitfield and the workspace's
+    drawn cells / positions / scattered densities bit for bit; draws made for another seed, threshold or grid are not used (the
+    model falls back to the one-call update and gives the same result); a grid somebody wrote through torch invalidates them."""
+    import ctypes as C
+    from ngp_pl_amd import _lib
+    from ngp_pl_amd._lib import call, ptr
+    thr = 0.01 * 1024 / 3 ** 0.5
+    ma, mb = make_model(seed=67), make_model(seed=67)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    cells = ma.grid_size ** 3
+    grid0 = torch.rand(1, cells, device="cuda", generator=g) * 12.0
+    grid0[0, torch.randint(cells, (3000,), device="cuda", generator=g)] = -1.0
+    ma.occ_draw_ahead, mb.occ_draw_ahead = False, True
+    for m in (ma, mb):
+        m.density_grid.copy_(grid0)
+    for rnd in range(3):
+        ma.update_density_grid(thr, warmup=False)                  # one call
+        had = getattr(mb, "_occ_ahead", None) is not None
+        mb.update_density_grid(thr, warmup=False)                  # rounds 1, 2: finishes the draws the previous round made
+        assert had == (rnd > 0)
+        torch.cuda.synchronize()
+        assert torch.equal(ma.density_grid, mb.density_grid) and torch.equal(ma.density_bitfield, mb.density_bitfield), rnd
+    # the draws waiting for round 3 are dropped when somebody writes the grid through torch ...
+    for m in (ma, mb):
+        m.density_grid.mul_(0.5)
+    ma.update_density_grid(thr, warmup=False); mb.update_density_grid(thr, warmup=False)
+    torch.cuda.synchronize()
+    assert torch.equal(ma.density_grid, mb.density_grid) and torch.equal(ma.density_bitfield, mb.density_bitfield)
+    # ... or asks for another threshold
+    ma.update_density_grid(0.5 * thr, warmup=False); mb.update_density_grid(0.5 * thr, warmup=False)
+    torch.cuda.synchronize()
+    assert torch.equal(ma.density_grid, mb.density_grid) and torch.equal(ma.density_bitfield, mb.density_bitfield)
+    # the two library calls by hand against the one call, workspace included
+    mb.occ_draw_ahead = False
+    mb.update_density_grid(thr, warmup=False); ma.update_density_grid(thr, warmup=False)       # (drops mb's pending draws, same state again)
+    torch.cuda.synchronize()
+    enc_a, enc_b = ma.xyz_encoder, mb.xyz_encoder
+    n = ma._occ_ws.numel()
+    seed = 424242
+    before = ma.density_grid.clone()
+    eh = enc_a._half.get(enc_a.params)
+    call("ngp_occupancy_update", ptr(ma.density_grid), ptr(ma.density_bitfield), 1, ma.grid_size, 0.5, thr, 0.95, None, 0, seed,
+         ptr(ma.xyz_min), ptr(ma.xyz_max), ptr(eh[enc_a.n_mlp:]), C.byref(enc_a.meta), ptr(eh), ptr(ma._occ_ws), n, _lib.stream())
+    ehb = enc_b._half.get(enc_b.params)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    call("ngp_occupancy_draw", ptr(mb.density_grid), 1, mb.grid_size, 0.5, thr, seed, ptr(mb._occ_ws), n, side.cuda_stream)
+    side.synchronize()
+    call("ngp_occupancy_update_drawn", ptr(mb.density_grid), ptr(mb.density_bitfield), 1, mb.grid_size, 0.5, thr, 0.95, None, seed,
+         ptr(mb.xyz_min), ptr(mb.xyz_max), ptr(ehb[enc_b.n_mlp:]), C.byref(enc_b.meta), ptr(ehb), ptr(mb._occ_ws), n, _lib.stream())
+    torch.cuda.synchronize()
+    assert not torch.equal(before, ma.density_grid)
+    assert torch.equal(ma.density_grid, mb.density_grid) and torch.equal(ma.density_bitfield, mb.density_bitfield)
+    (ia, xa, ta), (ib, xb, tb) = _occ_workspace_views(ma), _occ_workspace_views(mb)
+    n_drawn = cells // 2
+    # (inside a block of cells the evaluation ORDER is whatever the placement's LDS cursor hands out; the drawn cells, their
+    #  positions and the scattered densities are not)
+    for half in (slice(0, n_drawn // 2), slice(n_drawn // 2, n_drawn)):
+        oa, ob = torch.argsort(ia[half].long() * 4 + 0, stable=True), torch.argsort(ib[half].long() * 4 + 0, stable=True)
+        assert torch.equal(ia[half][oa], ib[half][ob])
+        assert torch.allclose(xa[half].abs().sum(0, dtype=torch.float64), xb[half].abs().sum(0, dtype=torch.float64), rtol=1e-9, atol=0)
+    assert torch.equal(ta, tb)
+    # contract: warm-up and several cascades have no two-call form
+    with pytest.raises(RuntimeError):
+        call("ngp_occupancy_draw", ptr(mb.density_grid), 2, mb.grid_size, 0.5, thr, seed, ptr(mb._occ_ws), n, _lib.stream())
