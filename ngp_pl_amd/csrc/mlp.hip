@@ -226,6 +226,46 @@ __device__ __forceinline__ void stage_fwd_weights(const h1* __restrict__ w, h1* 
     stage_weights(w + L::G_WO, lds + L::OFF_WO, 16, HID, false);
 }
 
+// Backward kernels: the forward-layout copy AND the transposed copy of every matrix from ONE pass over the blob -- all of a thread's
+// 16-byte global loads issued first (compile-time trip count), then the stores: one global round trip in the kernel's prologue instead of the
+// seven dependent ones of stage_fwd_weights() + three stage_weights(transpose) calls (the prologue was 15 % / 29 % of the colour / density
+// kernel at the bench's operating point, tools/bench_mlp.py with -DNGP_MLP_TIMING).  Same LDS images bit for bit.
+#ifndef NGP_MLP_STAGE_ONCE
+#define NGP_MLP_STAGE_ONCE 1
+#endif
+template <int N_IN, int N_HIDDEN, int THREADS>
+__device__ __forceinline__ void stage_bwd_weights(const h1* __restrict__ w, h1* lds, int off_t0, int off_t1, int off_to) {
+    using L = LdsW<N_IN, N_HIDDEN>;
+    constexpr int C0 = HID * N_IN / 8, C1 = (N_HIDDEN == 2 ? HID * HID / 8 : 0), CO = 16 * HID / 8, CT = C0 + C1 + CO;   // 16-byte chunks
+    constexpr int PER = (CT + THREADS - 1) / THREADS;
+    half8_t v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int t = (int)threadIdx.x + k * THREADS;
+        // chunk t of the blob: matrix m (rows x cols), chunk tm inside it; lanes on consecutive ROWS (see stage_weights)
+        int rows, cols, tm, gbase;
+        if (t < C0) { rows = HID; cols = N_IN; tm = t; gbase = 0; }
+        else if (t < C0 + C1) { rows = HID; cols = HID; tm = t - C0; gbase = L::G_W1; }
+        else { rows = 16; cols = HID; tm = t - C0 - C1; gbase = L::G_WO; }
+        const int r = tm % rows, c = 8 * (tm / rows);
+        const int tc = t < CT ? gbase + r * cols + c : 0;
+        v[k] = *reinterpret_cast<const half8_t*>(w + tc);
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int t = (int)threadIdx.x + k * THREADS;
+        if (t >= CT) continue;
+        int rows, cols, tm, off_f, off_t;
+        if (t < C0) { rows = HID; cols = N_IN; tm = t; off_f = L::OFF_W0; off_t = off_t0; }
+        else if (t < C0 + C1) { rows = HID; cols = HID; tm = t - C0; off_f = L::OFF_W1; off_t = off_t1; }
+        else { rows = 16; cols = HID; tm = t - C0 - C1; off_f = L::OFF_WO; off_t = off_to; }
+        const int r = tm % rows, c = 8 * (tm / rows);
+        *reinterpret_cast<half8_t*>(lds + off_f + r * (cols + PAD) + c) = v[k];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) lds[off_t + (c + e) * (rows + PAD) + r] = v[k][e];
+    }
+}
+
 // hidden layer from natural-order input fragments: out tiles m=0,1 (64 neurons)
 template <int N_IN>
 __device__ __forceinline__ void layer_in(const h1* W, const half8_t (&b)[N_IN / 16], int i, int hh, f32x16 (&acc)[2]) {
@@ -772,10 +812,14 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
     const int t0 = blockIdx.x * BWD_WAVES + wave;
     const int raw0 = raw_index(t0);                    // in flight while the weights are staged
     int raw_pre = raw_index(t0 + tile_stride);
-    stage_fwd_weights<N_IN, N_HIDDEN>(weights, lds);
-    stage_weights(weights, lds + OFF_T0, HID, N_IN, true);
-    if (N_HIDDEN == 2) stage_weights(weights + L::G_W1, lds + OFF_T1, HID, HID, true);
-    stage_weights(weights + L::G_WO, lds + OFF_TO, 16, HID, true);
+    if (NGP_MLP_STAGE_ONCE) {
+        stage_bwd_weights<N_IN, N_HIDDEN, 64 * BWD_WAVES>(weights, lds, OFF_T0, OFF_T1, OFF_TO);
+    } else {
+        stage_fwd_weights<N_IN, N_HIDDEN>(weights, lds);
+        stage_weights(weights, lds + OFF_T0, HID, N_IN, true);
+        if (N_HIDDEN == 2) stage_weights(weights + L::G_W1, lds + OFF_T1, HID, HID, true);
+        stage_weights(weights + L::G_WO, lds + OFF_TO, 16, HID, true);
+    }
     fetch(t0, raw0, cur);
     __syncthreads();
     MLP_T(0);                                          // prologue: weights staged, first tile fetched
