@@ -226,6 +226,37 @@ __device__ __forceinline__ void stage_fwd_weights(const h1* __restrict__ w, h1* 
     stage_weights(w + L::G_WO, lds + L::OFF_WO, 16, HID, false);
 }
 
+// The same image from ONE pass over the (tight) blob: all of a thread's 16-byte loads issued first -- compile-time trip count, fully
+// coalesced -- then the stores into the padded rows: one global round trip at the head of the kernel instead of one per matrix and
+// loop trip (three to six dependent ones: 3-4 us of the 26 us field forward).  THREADS = the workgroup's size.
+#ifndef NGP_MLP_FWD_STAGE_ONCE
+#define NGP_MLP_FWD_STAGE_ONCE 1          // 0: matrix by matrix (A/B builds)
+#endif
+template <int N_IN, int N_HIDDEN, int THREADS>
+__device__ __forceinline__ void stage_fwd_weights_once(const h1* __restrict__ w, h1* lds) {
+    using L = LdsW<N_IN, N_HIDDEN>;
+    if (!NGP_MLP_FWD_STAGE_ONCE) { stage_fwd_weights<N_IN, N_HIDDEN>(w, lds); return; }
+    constexpr int C0 = HID * N_IN / 8, C1 = (N_HIDDEN == 2 ? HID * HID / 8 : 0), CO = 16 * HID / 8, CT = C0 + C1 + CO;   // 16-byte chunks
+    constexpr int PER = (CT + THREADS - 1) / THREADS;
+    half8_t v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int t = (int)threadIdx.x + k * THREADS;
+        v[k] = *reinterpret_cast<const half8_t*>(w + 8 * (t < CT ? t : 0));
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int t = (int)threadIdx.x + k * THREADS;
+        if (t >= CT) continue;
+        int cols, tm, off;
+        if (t < C0) { cols = N_IN; tm = t; off = L::OFF_W0; }
+        else if (t < C0 + C1) { cols = HID; tm = t - C0; off = L::OFF_W1; }
+        else { cols = HID; tm = t - C0 - C1; off = L::OFF_WO; }
+        const int chunks = cols / 8, r = tm / chunks, c = 8 * (tm - r * chunks);
+        *reinterpret_cast<half8_t*>(lds + off + r * (cols + PAD) + c) = v[k];
+    }
+}
+
 // Backward kernels: the forward-layout copy AND the transposed copy of every matrix from ONE pass over the blob -- all of a thread's
 // 16-byte global loads issued first (compile-time trip count), then the stores: one global round trip in the kernel's prologue instead of the
 // seven dependent ones of stage_fwd_weights() + three stage_weights(transpose) calls (the prologue was 15 % / 29 % of the colour / density
@@ -311,7 +342,7 @@ mlp_fwd_kernel(MlpIO io, const h1* __restrict__ weights, int n_samples) {
         n_samples = min(*io.n_dev, n_samples);
         if ((long long)blockIdx.x * WAVES * TILE >= n_samples) return;
     }
-    stage_fwd_weights<N_IN, N_HIDDEN>(weights, lds);
+    stage_fwd_weights_once<N_IN, N_HIDDEN, 64 * WAVES>(weights, lds);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, i = lane & 31, hh = lane >> 5;
@@ -398,8 +429,8 @@ field_fwd_kernel(FieldIO io, const h1* __restrict__ density_w, const h1* __restr
         n_samples = min(*io.n_dev, n_samples);
         if ((long long)blockIdx.x * WAVES * TILE >= n_samples) return;
     }
-    stage_fwd_weights<32, 1>(density_w, ldsd);
-    stage_fwd_weights<32, 2>(rgb_w, ldsr);
+    stage_fwd_weights_once<32, 1, 64 * WAVES>(density_w, ldsd);
+    stage_fwd_weights_once<32, 2, 64 * WAVES>(rgb_w, ldsr);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, i = lane & 31, hh = lane >> 5;
