@@ -526,19 +526,21 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
         const int sl = (task_id - plan.first_task[oi]) / plan.k_split[lv];
         return ws.dir + ((size_t)lv * MAX_SLICES + sl) * dir_pitch;
     };
-    if (tid == 0) s_task[0] = task_begin + atomicAdd(&ws.queue[group], 1);
-    for (uint32_t k = tid; k < 2 * SLICE2; k += APPLY_THREADS) lds[k] = 0;
-    __syncthreads();
-    if (s_task[0] < task_end) {
-        const int32_t* __restrict__ d0 = dir_row(s_task[0]);
+    // the first task of every workgroup is its own index (the launch has at most one workgroup per task): no round trip to the
+    // queue and no barrier in front of the first directory row; the queue hands out the tasks behind the first round
+    const int first_task = task_begin + (int)blockIdx.x;
+    if (tid == 0) s_task[0] = first_task;
+    if (first_task < task_end) {
+        const int32_t* __restrict__ d0 = dir_row(first_task);
         for (int c = tid; c < n_chunks; c += APPLY_THREADS) s_dir2[0][c] = d0[c];
     }
+    for (uint32_t k = tid; k < 2 * SLICE2; k += APPLY_THREADS) lds[k] = 0;
     __syncthreads();
     for (int it = 0;; ++it) {
         const int task = s_task[it & 1];
         if (task >= task_end) return;
         int next_task = 0;
-        if (tid == 0) next_task = task_begin + atomicAdd(&ws.queue[group], 1);   // published behind this task's accumulation
+        if (tid == 0) next_task = task_begin + (int)gridDim.x + atomicAdd(&ws.queue[group], 1);   // published behind this task's accumulation
 #ifdef NGP_BIN_TIMING
         if (tid == 0) ws.timing[4 * task + 0] = (long long)wall_clock64();
 #endif
