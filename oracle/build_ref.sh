@@ -12,12 +12,23 @@
 #                                             __expf/thrust path; the hot path is f32 only)
 # The reference's own build system (setup.py / nvcc) is not used.  Skips silently when
 # /root/reference is absent (GPU box): the prebuilt .so files travel with the repo snapshot.
+#
+# It also STAGES the reference's own Python hot path, unmodified, under oracle/_ref/py/ (git-ignored like the
+# rest of oracle/_ref, shipped to the GPU box with the snapshot): models/{__init__,rendering,networks,
+# custom_functions}.py and losses.py.  tests/test_reference_files_gpu.py and bench.py's
+# `api_path_reference_files` leg execute THOSE files on the GPU over this package's `vren` / `tinycudann`
+# bindings (oracle/ref_on_binding.py) -- INTEGRATION.md "Option A" run for real.  Nothing is copied into history.
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
 REF="${NGP_REFERENCE_DIR:-/root/reference}/models/csrc"
 OUT="$HERE/_ref"
 if [ ! -d "$REF" ]; then echo "[build_ref] $REF not present; keeping prebuilt $OUT"; exit 0; fi
 mkdir -p "$OUT"
+PYREF="$(dirname "$(dirname "$REF")")"
+mkdir -p "$OUT/py/models"
+for f in __init__ rendering networks custom_functions; do cp -pf "$PYREF/models/$f.py" "$OUT/py/models/$f.py"; done
+cp -pf "$PYREF/losses.py" "$OUT/py/losses.py"
+echo "[build_ref] staged the reference's models/*.py + losses.py (unmodified) under $OUT/py"
 PY="${PYTHON:-python3}"
 TORCH_INC=$($PY -c "import torch.utils.cpp_extension as c; print(' '.join('-I'+p for p in c.include_paths()))")
 TORCH_LIB=$($PY -c "import torch, os; print(os.path.join(os.path.dirname(torch.__file__), 'lib'))")

@@ -1,0 +1,286 @@
+"""GPU: the reference's OWN Python hot path -- models/rendering.py:11-163, models/custom_functions.py:8-173,
+models/networks.py:12-269, losses.py:6-60, unmodified -- EXECUTED on this package's bindings (INTEGRATION.md "Option A"):
+`vren` = ngp_pl_amd.vren, `tinycudann` = ngp_pl_amd.tcnn, nothing else changed (oracle/ref_on_binding.py loads the files
+from /root/reference where it is mounted, else from the byte-for-byte copies oracle/build_ref.sh staged under
+oracle/_ref/py/, which travel to the GPU box).  What is held to what:
+
+  * `render()` -- both branches, scale 0.5 / 2 (3 cascades, exponential steps) -- against tests/golden/render_golden.npz,
+    i.e. against what the SAME files produced on the CPU over the reference's own kernels compiled for the host: packed
+    sample indices, counts, t and dt bit for bit; composited outputs at the f16-field tolerances of SURVEY.md 8(c);
+  * the same at scale 16 (6 cascades: the mip-NeRF360 recipe) against the CPU oracle;
+  * `NeRFLoss` (with the distortion term: vren.distortion_loss_fw/_bw) against the golden terms;
+  * `NGP.update_density_grid` (both cell-sampling modes) against the oracle field and the oracle's merge / packbits;
+  * a short training run of train.py:159-185's statements around those files + this package's FusedAdam, against the same
+    run through ngp_pl_amd.rendering (the product's mirror of the same API).
+The hash-grid / MLP / SH arithmetic under it stays "parity unpinned" (tiny-cuda-nn is not in /root/reference): tolerances
+on colours are against OUR fp32 restatement."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+GOLDEN = os.path.join(HERE, "golden", "render_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def R():
+    from oracle import ref_on_binding as rb
+    if not rb.available():
+        pytest.skip("the reference's models/*.py are neither mounted nor staged (oracle/build_ref.sh)")
+    rb.load()
+    return rb
+
+
+def _load_field(model, field):
+    """tiny-cuda-nn's parameter layout: [MLP weights, then the table] (tests/golden/ref_harness.py:load_field_params)."""
+    with torch.no_grad():
+        model.xyz_encoder.params.copy_(torch.cat([field.density_w, field.table.reshape(-1)]).to(model.xyz_encoder.params.device))
+        model.rgb_net.params.copy_(field.rgb_w.to(model.rgb_net.params.device))
+
+
+def _fixed_jitter(noise):
+    """RayMarcher.forward draws `torch.rand_like(rays_o[:, 0])` (custom_functions.py:83): hand it a recorded draw instead."""
+    class _Patch:
+        def __enter__(self):
+            self.real = torch.rand_like
+            torch.rand_like = lambda t, *a, **k: noise.to(device=t.device, dtype=t.dtype).reshape(t.shape).clone()
+
+        def __exit__(self, *exc):
+            torch.rand_like = self.real
+    return _Patch()
+
+
+def _close(name, got, want, mean_tol, q99_tol):
+    err = np.abs(np.asarray(got, np.float64) - np.asarray(want, np.float64)).reshape(len(want), -1).max(1)
+    assert err.mean() < mean_tol and np.quantile(err, 0.99) < q99_tol, (name, float(err.mean()), float(np.quantile(err, 0.99)))
+
+
+@pytest.mark.parametrize("tag", ["syn", "real"])
+def test_the_references_render_on_the_binding_reproduces_its_cpu_run(R, tag):
+    from ngp_pl_amd import synthetic as syn
+    from render_cases import CONFIGS, field_checksum, make_field, make_rays
+    gold = np.load(GOLDEN)
+    c = CONFIGS[tag]
+    field = make_field(c["scale"])
+    if not np.allclose(field_checksum(field), gold[tag + "_field_checksum"], rtol=1e-9):
+        pytest.skip("torch's CPU random stream differs from the one the fixture was recorded with")
+    mods = R.load()
+    model = R.make_model(c["scale"], "cuda")
+    assert type(model).__module__ == "models.networks" and mods.rendering.render.__module__ == "models.rendering"
+    _load_field(model, field)
+    bf = syn.random_blob_bitfield(model.cascades, 128, c["fill"], seed=31)
+    assert int(bf.astype(np.int64).sum()) == int(gold[tag + "_bitfield_sum"])
+    model.density_bitfield.copy_(torch.from_numpy(bf).cuda())
+    ro, rd = make_rays(c["n"], c["scale"], seed=7)
+    ro, rd = ro.cuda(), rd.cuda()
+    kw = {} if c["esf"] == 0 else {"exp_step_factor": c["esf"]}
+    # -- test branch (rendering.py:46-118): the reference's host loop over vren.raymarching_test / composite_test_fw -----------
+    res = mods.rendering.render(model, ro, rd, test_time=True, **kw)
+    total = int(gold[tag + "_test_total_samples"])
+    assert abs(int(res["total_samples"]) - total) <= 0.01 * total + 64
+    for k, (mt, qt) in (("opacity", (2e-3, 2e-2)), ("rgb", (2e-3, 2e-2)), ("depth", (4e-3 * max(c["scale"], 1.0), 4e-2 * max(c["scale"], 1.0)))):
+        _close("test " + k, res[k].float().cpu().numpy(), gold["%s_test_%s" % (tag, k)], mt, qt)
+    # -- train branch (rendering.py:121-163) with the jitter of the recorded run ------------------------------------------------
+    with _fixed_jitter(torch.from_numpy(gold[tag + "_noise"])):
+        tr = mods.rendering.render(model, ro, rd, test_time=False, **kw)
+    assert int(tr["rm_samples"]) == int(gold[tag + "_train_rm_samples"])                       # packed sample count: exact
+    assert np.array_equal(tr["rays_a"].cpu().numpy(), gold[tag + "_train_rays_a"])             # (ray, start, count): exact, ray order
+    assert np.array_equal(tr["ts"].cpu().numpy().view(np.uint32), gold[tag + "_train_ts"].view(np.uint32))
+    assert np.array_equal(tr["deltas"].cpu().numpy().view(np.uint32), gold[tag + "_train_deltas"].view(np.uint32))
+    vr = int(gold[tag + "_train_vr_samples"])
+    assert abs(int(tr["vr_samples"]) - vr) <= 0.01 * vr + 64
+    for k, (mt, qt) in (("opacity", (2e-3, 2e-2)), ("rgb", (2e-3, 2e-2)), ("depth", (4e-3 * max(c["scale"], 1.0), 4e-2 * max(c["scale"], 1.0)))):
+        _close("train " + k, tr[k].detach().float().cpu().numpy(), gold["%s_train_%s" % (tag, k)], mt, qt)
+    ws_err = np.abs(tr["ws"].detach().cpu().numpy() - gold[tag + "_train_ws"])
+    assert ws_err.mean() < 1e-3 and np.quantile(ws_err, 0.999) < 5e-2, (ws_err.mean(), ws_err.max())
+    # the whole thing differentiates through the reference's autograd operators down to both parameter tensors
+    gt = torch.from_numpy(gold[tag + "_gt"]).cuda()
+    loss_d = mods.losses.NeRFLoss(lambda_opacity=1e-3, lambda_distortion=1e-3)(tr, {"rgb": gt})
+    sum(v.mean() for v in loss_d.values()).backward()
+    for p in (model.xyz_encoder.params, model.rgb_net.params):
+        assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("tag", ["syn", "real"])
+def test_the_references_nerf_loss_on_the_binding(R, tag):
+    """losses.py:6-60 with its DistortionLoss autograd Function over vren.distortion_loss_fw/_bw, fed the RECORDED train
+    results: the three terms equal the CPU run's; the gradient w.r.t. ws equals a float64 restatement of the O(N^2) definition."""
+    gold = np.load(GOLDEN)
+    mods = R.load()
+    res = {k: torch.from_numpy(gold["%s_train_%s" % (tag, k)]).cuda() for k in ("opacity", "rgb", "ws", "deltas", "ts", "rays_a")}
+    res["ws"].requires_grad_(True)
+    gt = torch.from_numpy(gold[tag + "_gt"]).cuda()
+    d = mods.losses.NeRFLoss(lambda_opacity=1e-3, lambda_distortion=1e-3)(res, {"rgb": gt})
+    for k in ("rgb", "opacity", "distortion"):
+        want = gold["%s_loss_%s" % (tag, k)]
+        got = d[k].detach().cpu().numpy()
+        assert np.allclose(got, want, rtol=2e-4, atol=1e-6 * max(1e-3, float(np.abs(want).max()))), (k, np.abs(got - want).max())     # (scan order differs: wave scans vs serial)
+    d["distortion"].sum().backward()
+    g = res["ws"].grad.cpu().numpy().astype(np.float64)
+    ws, dl, ts, ra = (gold["%s_train_%s" % (tag, k)] for k in ("ws", "deltas", "ts", "rays_a"))
+    checked = 0
+    for r, s, n in ra[ra[:, 2] > 1][:12]:
+        w, t, dd = (a[s:s + n].astype(np.float64) for a in (ws, ts, dl))
+        want = 1e-3 * (2 * (np.abs(t[:, None] - t[None, :]) * w[None, :]).sum(1) + 2.0 / 3.0 * w * dd)
+        assert np.allclose(g[s:s + n], want, rtol=5e-3, atol=1e-4 * np.abs(want).max()), (r, np.abs(g[s:s + n] - want).max())    # (f32 prefix sums cancel)
+        checked += 1
+    assert checked > 0
+
+
+def test_the_references_render_on_the_binding_at_scale_16(R):
+    """The mip-NeRF360 recipe's geometry (scale 16 -> 6 cascades, exp_step_factor 1/256, black background, train.py:95-96) through
+    the reference's render() on the binding, against the CPU oracle of the same function on the same field / bitfield / jitter."""
+    from ngp_pl_amd import synthetic as syn
+    from oracle import render_oracle as RO
+    from oracle.vren_oracle import Oracle
+    from render_cases import make_field
+    mods = R.load()
+    scale, esf, n = 16.0, 1 / 256, 96
+    field = make_field(scale, seed=8)
+    model = R.make_model(scale, "cuda")
+    assert model.cascades == 6
+    _load_field(model, field)
+    bf = syn.random_blob_bitfield(6, 128, 0.12, seed=77)
+    model.density_bitfield.copy_(torch.from_numpy(bf).cuda())
+    g = torch.Generator().manual_seed(21)
+    o = (torch.rand(n, 3, generator=g) - 0.5) * 6.0
+    d = (torch.rand(n, 3, generator=g) - 0.5) * 4.0 - o
+    d = d / d.norm(dim=1, keepdim=True)
+    vr = Oracle(fma=True)
+    noise = torch.rand(n, generator=g)
+    with _fixed_jitter(noise):
+        tr = mods.rendering.render(model, o.cuda(), d.cuda(), test_time=False, exp_step_factor=esf)
+    want = RO.render_rays_train(vr, field, o.numpy(), d.numpy(), bf, noise.numpy(), cascades=6, scale=scale, exp_step_factor=esf)
+    assert int(tr["rm_samples"]) == want["rm_samples"] and want["rm_samples"] > 2000
+    assert np.array_equal(tr["rays_a"].cpu().numpy(), want["rays_a"])
+    assert np.array_equal(tr["ts"].cpu().numpy().view(np.uint32), want["ts"].view(np.uint32))
+    assert np.array_equal(tr["deltas"].cpu().numpy().view(np.uint32), want["deltas"].view(np.uint32))
+    _close("rgb", tr["rgb"].detach().float().cpu().numpy(), want["rgb"], 3e-3, 3e-2)
+    _close("opacity", tr["opacity"].detach().cpu().numpy(), want["opacity"], 3e-3, 3e-2)
+    res = mods.rendering.render(model, o.cuda(), d.cuda(), test_time=True, exp_step_factor=esf)
+    op, depth, rgb, total, iters = RO.render_rays_test(vr, field, o.numpy(), d.numpy(), bf, cascades=6, scale=scale, exp_step_factor=esf)
+    assert abs(int(res["total_samples"]) - total) <= 0.01 * total + 64
+    _close("test rgb", res["rgb"].float().cpu().numpy(), rgb, 3e-3, 3e-2)
+    _close("test opacity", res["opacity"].cpu().numpy(), op, 3e-3, 3e-2)
+
+
+def test_the_references_update_density_grid_on_the_binding(R):
+    """NGP.update_density_grid (networks.py:240-269) of the reference's class, both sampling modes, on the binding (vren.morton3D,
+    morton3D_invert, packbits; xyz_encoder through ngp_pl_amd.tcnn): the densities it evaluates against the fp32 oracle field at
+    the positions it drew; the merged grid against the oracle's merge (cells drawn once or not at all: bit for bit; cells drawn
+    twice: between the merges of their smallest and largest draw -- torch leaves the winner of a duplicate index unspecified);
+    the packed bits against the C oracle's packbits at the same threshold."""
+    from oracle import render_oracle as RO
+    from oracle import tcnn_oracle as T
+    from oracle.vren_oracle import Oracle
+    from render_cases import make_field
+    vo = Oracle(fma=True)
+    field = make_field(0.5, seed=5)
+    model = R.make_model(0.5, "cuda")
+    _load_field(model, field)
+    cells = model.grid_size ** 3
+    thr = 0.01 * 1024 / 3 ** 0.5
+    g = torch.Generator(device="cuda").manual_seed(3)
+    torch.manual_seed(123)
+    for warmup in (True, False):
+        grid0 = torch.rand(1, cells, device="cuda", generator=g) * 12.0
+        grid0[0, torch.randint(cells, (5000,), device="cuda", generator=g)] = -1.0
+        model.density_grid.copy_(grid0)
+        seen, drawn = [], []
+        real_density = model.density
+        real_all, real_sample = model.get_all_cells, model.sample_uniform_and_occupied_cells
+        model.density = lambda x, **k: seen.append((x.clone(), real_density(x, **k))) or seen[-1][1]
+        model.get_all_cells = lambda: drawn.append(real_all()) or drawn[-1]
+        model.sample_uniform_and_occupied_cells = lambda M, t: drawn.append(real_sample(M, t)) or drawn[-1]
+        try:
+            model.update_density_grid(thr, warmup=warmup)
+        finally:
+            model.density, model.get_all_cells, model.sample_uniform_and_occupied_cells = real_density, real_all, real_sample
+        assert len(seen) == 1 and len(drawn) == 1
+        idx = drawn[0][0][0].long()
+        xyz, sig = seen[0][0].float(), seen[0][1].float()
+        assert idx.numel() == (cells if warmup else cells // 2) == sig.numel()
+        if not warmup:
+            assert bool((grid0[0, idx[cells // 4:]] > thr).all())                               # second half: from the occupied set
+        pick = torch.randperm(idx.numel(), device="cuda", generator=g)[:5000]
+        with torch.no_grad():
+            s_or, _, _ = field.density(xyz[pick].cpu(), quantize=True)
+        rel = (sig[pick].cpu() - s_or).abs() / s_or.abs().clamp(min=1e-6)
+        assert float(rel.max()) < 2e-2 and float(rel.median()) < 2e-3, (float(rel.max()), float(rel.median()))
+        # merge
+        got = model.density_grid[0].cpu().numpy()
+        counts = torch.bincount(idx, minlength=cells).cpu().numpy()
+        lo = torch.full((cells,), float("inf"), device="cuda").scatter_reduce(0, idx, sig, "amin").cpu().numpy()
+        hi = torch.zeros(cells, device="cuda").scatter_reduce(0, idx, sig, "amax").cpu().numpy()
+        lo[counts == 0] = 0.0
+        g0 = grid0[0].cpu().numpy()
+        once = counts <= 1
+        grid_or, _, _ = RO.update_density_grid(vo, g0, np.arange(cells), hi, thr)               # (for `once` cells lo == hi == the draw)
+        assert np.array_equal(got[once].view(np.uint32), grid_or[once].view(np.uint32))
+        grid_lo, _, _ = RO.update_density_grid(vo, g0, np.arange(cells), lo, thr)
+        assert (got[~once] >= grid_lo[~once]).all() and (got[~once] <= grid_or[~once]).all()
+        assert (got[g0 < 0] == -1.0).all()
+        # threshold + bits (networks.py:266-268) on the grid the update produced
+        pos = got[got > 0]
+        t_or = min(float(pos.astype(np.float64).mean()), thr)
+        bits_or = np.zeros(cells // 8, np.uint8)
+        vo.packbits(got, np.float32(t_or), bits_or)
+        diff = np.unpackbits(model.density_bitfield.cpu().numpy() ^ bits_or).sum()
+        assert diff <= 4, diff                                                                  # cells within rounding of the f32 mean
+        assert 0.2 * cells < np.unpackbits(bits_or).sum() < 0.8 * cells
+
+
+def _batch(n, seed, dev="cuda"):
+    from ngp_pl_amd import synthetic as syn
+    g = np.random.RandomState(seed)
+    W = 200
+    dirs = syn.get_ray_directions(W, W, syn.intrinsics(W))
+    poses = syn.hemisphere_poses(16, seed=1)
+    ro, rd = syn.get_rays(dirs[torch.from_numpy(g.randint(0, W * W, n))], poses[torch.from_numpy(g.randint(0, 16, n))])
+    ro, rd = ro.to(dev).contiguous(), rd.to(dev).contiguous()
+    gt, _ = syn.render_ground_truth(ro, rd, n_steps=96)
+    return ro, rd, gt.contiguous()
+
+
+def test_train_py_statements_around_the_references_files_train_like_the_product_mirror(R):
+    """train.py:159-185 (occupancy update every 16 steps, render, NeRFLoss, backward) + train.py:131 (FusedAdam(net_params, lr,
+    eps=1e-15)) around the reference's OWN files on the binding, 48 steps of 2048 rays, next to the same statements around
+    ngp_pl_amd.rendering / networks / losses (the product's mirror) from the same initialisation and batches.  The two runs
+    draw different march jitter and occupancy cells (different generators), so they are compared as training runs: both losses
+    fall by > 2x and end within 25 % of each other; the marched sample counts per ray agree within 10 % at the end."""
+    from ngp_pl_amd.losses import NeRFLoss
+    from ngp_pl_amd.networks import NGP
+    from ngp_pl_amd.optim import FusedAdam
+    from ngp_pl_amd.rendering import render
+    torch.manual_seed(11)
+    theirs = R.make_model(0.5, "cuda")
+    step = R.TrainingStep(theirs, FusedAdam)
+    ours = NGP(scale=0.5).cuda()
+    ours.register_training_buffers()
+    assert torch.equal(theirs.xyz_encoder.params.detach(), ours.xyz_encoder.params.detach())    # same seed-1337 initialisation
+    opt = FusedAdam([p for p in ours.parameters()], 1e-2, eps=1e-15)
+    loss_fn = NeRFLoss(lambda_distortion=0.0)
+    batches = [_batch(2048, 900 + i) for i in range(8)]
+    la, lb, rm_a, rm_b = [], [], 0.0, 0.0
+    for it in range(48):
+        ro, rd, gt = batches[it % 8]
+        res_a, loss_a = step(ro, rd, gt)
+        if it % 16 == 0:
+            ours.update_density_grid(0.01 * 1024 / 3 ** 0.5, warmup=True)
+        res_b = render(ours, ro, rd, test_time=False, random_bg=False)
+        loss_b = sum(v.mean() for v in loss_fn(res_b, {"rgb": gt}).values())
+        opt.zero_grad(); loss_b.backward(); opt.step()
+        la.append(float(loss_a)); lb.append(float(loss_b))
+        rm_a, rm_b = float(res_a["rm_samples"]) / 2048, float(res_b["rm_samples"]) / 2048
+    first_a, last_a = np.mean(la[:4]), np.mean(la[-8:])
+    first_b, last_b = np.mean(lb[:4]), np.mean(lb[-8:])
+    assert last_a < 0.5 * first_a and last_b < 0.5 * first_b, (first_a, last_a, first_b, last_b)
+    assert abs(last_a - last_b) < 0.25 * max(last_a, last_b), (last_a, last_b)
+    assert abs(rm_a - rm_b) < 0.1 * max(rm_a, rm_b), (rm_a, rm_b)
+    assert step.global_step == 48 and theirs.density_bitfield.any()
