@@ -64,6 +64,10 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achi
 WORKLOADS = {
     # name: (scene, scale, rays, lr, erode, description)
     "lego": ("lego", 0.5, 8192, 1e-2, False, "configs[1]: Synthetic-NeRF Lego-like, 1xMI355X per rank, 8192 rays/batch, 800x800, scale 0.5"),
+    # the same recipe on a scene that does NOT flatter early termination (ngp_pl_amd/bench_support.py:lego_hard_scene: studs, treads
+    # made of 4 mm bars, a hollow cabin, finite density sigma -> volumetric ground truth); two densities for the sensitivity
+    "lego_hard": ("lego_hard:60", 0.5, 8192, 1e-2, False, "configs[1] recipe on the lego_hard scene (studs, 4 mm tread lattice, hollow cabin), sigma 60"),
+    "lego_hard_soft": ("lego_hard:30", 0.5, 8192, 1e-2, False, "configs[1] recipe on the lego_hard scene (studs, 4 mm tread lattice, hollow cabin), sigma 30"),
     "lego16k": ("lego", 0.5, 16384, 2e-2, False, "configs[2] recipe (benchmark_synthetic_nerf.sh:25-28): 16384 rays/batch, lr 2e-2, on the Lego-like scene"),
     "unbounded": ("unbounded", 16.0, 8192, 1e-2, True, "configs[3] recipe (benchmark_mipnerf360.sh:21-24): scale 16 -> 6 cascades, exp_step_factor 1/256, "
                   "erode, black background, on a procedural unbounded scene"),
@@ -82,12 +86,13 @@ def parse():
     p.add_argument("--setup-steps", type=int, default=SETUP_STEPS)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-render", action="store_true")
-    p.add_argument("--secondary", action="store_true", help="also run the short unbounded / 16k-ray secondary recipes (each rebuilds a "
-                   "100x800x800 dataset and runs 320 setup steps: off by default, they are parity-test configurations, not bench lines)")
-    p.add_argument("--no-secondary", action="store_true", help="(default; kept for older command lines)")
+    p.add_argument("--secondary", action="store_true", help="(default since round 5; kept for older command lines)")
+    p.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / configs[3] recipes and the lego_hard sensitivity (each rebuilds a "
+                   "100x800x800 dataset and runs 320 setup steps)")
     p.add_argument("--deadline", type=float, default=float(os.environ.get("NGP_BENCH_DEADLINE_S", "270")),
                    help="seconds from process start after which the line is printed with whatever is complete")
     p.add_argument("--no-api", action="store_true", help="skip the api_path legs")
+    p.add_argument("--no-dp-eval", action="store_true", help="under a process group: skip the evaluation sharded over the ranks")
     p.add_argument("--no-full-run", action="store_true", help="skip the literal configs[1] run (30 000 steps from scratch + evaluation over 200 held-out poses, ~15 s)")
     p.add_argument("--timed-only", action="store_true", help="stop after the timed windows (for rocprofv3 runs: the trace then ends with the timed steps)")
     p.add_argument("--dry-run", action="store_true", help="launcher + process group only (gloo, no GPU work)")
@@ -149,7 +154,9 @@ class Loop:
         torch.manual_seed(1337)
         self.model = NGP(scale=scale).to(dev)
         self.model.register_training_buffers()
-        self.data = data if data is not None else GpuDataset(args.res, args.images, dev, seed=0, scene=scene)     # ground truth resident in HBM
+        scene, _, sigma = scene.partition(":")
+        self.data = data if data is not None else GpuDataset(args.res, args.images, dev, seed=0, scene=scene,
+                                                             sigma=float(sigma) if sigma else None)               # ground truth resident in HBM
         if erode:      # train.py:73-76,160-163: the colmap recipe marks the cells no camera sees and erodes by visibility
             self.model.mark_invisible_cells(self.data.K.to(dev), self.data.poses, (self.data.W, self.data.H))
         self.trainer = Trainer(self.model, lr=lr, num_epochs=30 if workload != "lego16k" else 20, erode=erode)
@@ -365,11 +372,11 @@ def kernel_roofline(loop, ms_per_step=None, n_steps=ROOFLINE_STEPS):
         whole = {"bytes_per_step": step_bytes, "ms_per_step": ms_per_step, "achieved": round(gbs, 1), "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                  "what": "sum of the stages' algorithmic bytes (SURVEY.md 8(d) per-unit figures x the units this run processed) / ms_per_step of the timed windows"}
     return {"bound": "hbm", "kernel": top["stage"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "builder_traffic_source": source,
             "avg_ms": top["ms"], "samples_marched_per_launch": S, "samples_active_per_launch": A,
             "units_priced": "active samples (the backward runs on the samples up to each ray's early stop)" if top["stage"] in ("hashgrid_bwd", "mlp_bwd") else "marched samples",
             "whole_step": whole, "issue_bound": (prof or {}).get("issue_bound", {}).get(top["stage"]),
-            "profile": profile_roofline(prof, top["stage"]),
+            "builder_profile": profile_roofline(prof, top["stage"]),
             "main_stream_stage_sum_ms": round(sum(d["ms"] for d in main), 4), "stages": stages}
 
 
@@ -512,11 +519,13 @@ def full_run(base_loop, args, dev, budget_s):
            "log": log, "complete": done == steps}
     progress("full_run: %d steps in %.2f s" % (done, train_s))
     poses = syn.hemisphere_poses(FULL_RUN_TEST_POSES, seed=999).to(dev)       # held-out: the training set is seed 0
+    # the reference's protocol AND chunking first (PSNR and FPS of the line are these); then the regrouped loop as an extra
+    ref = render_eval(loop.model, loop.data, poses, psnr=True)
     fast = render_eval(loop.model, loop.data, poses, psnr=True, chunk_scale=2, probe_cap=64)       # (swept on the trained field: profiles/r04_render_sweep_trained.txt)
-    ref = render_eval(loop.model, loop.data, poses, psnr=False)
-    out["psnr"] = fast.pop("psnr")
-    out["psnr_min_max"] = fast.pop("psnr_min_max")
-    out["fps_200"], out["fps_200_reference_chunking"] = fast["fps"], ref["fps"]
+    out["psnr"] = ref.pop("psnr")
+    out["psnr_min_max"] = ref.pop("psnr_min_max")
+    out["psnr_regrouped"] = fast.pop("psnr"); fast.pop("psnr_min_max")
+    out["fps_200"], out["fps_200_regrouped"] = ref["fps"], fast["fps"]
     fast["loop"] = "ngp_render_test_frame chunk_scale=2 probe_cap=64 (the same composited samples per ray, regrouped: <= 1e-5 from the reference chunking)"
     ref["loop"] = "ngp_render_test_frame chunk_scale=1 probe_cap=0 (the reference's chunking, bit-identical to its host loop)"
     out["render"], out["render_reference_chunking"] = fast, ref
@@ -528,8 +537,8 @@ def full_run(base_loop, args, dev, budget_s):
         rr[key] = {"bytes_per_frame": b, "ms_per_frame": rec["ms_per_frame"], "achieved": round(gbs, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
                    "frac": gbs / HBM_PEAK_GBS}
     prof = render_profile()
-    out["roofline_render"] = {"bound": "hbm", "kernel": (prof or {}).get("dominant_kernel"), **rr["regrouped"], "reference_chunking": rr["reference_chunking"],
-                              "samples_per_ray": fast["samples_per_ray"], "profile": prof,
+    out["roofline_render"] = {"bound": "hbm", "kernel": (prof or {}).get("dominant_kernel"), **rr["reference_chunking"], "regrouped": rr["regrouped"],
+                              "samples_per_ray": ref["samples_per_ray"], "builder_profile": prof,
                               "what": "algorithmic bytes of a frame (SURVEY.md 8(d) per-unit figures x the rays and samples of the frame) / mean frame time over the held-out poses"}
     del loop
     torch.cuda.empty_cache()
@@ -661,21 +670,158 @@ def march_guard_record():
         return {"march_guards": None, "march_guards_error": str(e)[:200]}
 
 
-def secondary_line(name, args, dev):
-    """A short run of one of the other recipes (single GPU, rank 0): 320 setup steps, 100 timed."""
+def stage_roofline(loop, ms_per_step):
+    """`kernel_roofline` of a secondary workload reduced to what identifies its dominant stage (no builder profiles: those were
+    recorded on the headline workload)."""
+    r = kernel_roofline(loop, ms_per_step, n_steps=10)
+    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_ms", "samples_marched_per_launch", "samples_active_per_launch",
+            "units_priced", "main_stream_stage_sum_ms")
+    out = {k: r[k] for k in keep}
+    out["traffic"] = None
+    out["stages"] = [{"stage": d["stage"], "ms": d["ms"]} for d in r["stages"][:5]]
+    return out
+
+
+def secondary_line(name, args, dev, late_steps=0, roofline=True):
+    """A short run of one of the other recipes (single GPU, rank 0): 320 setup steps, 100 timed, the dominant stage's roofline;
+    `late_steps` > 0: a second 100-step window after that many steps in total (where the field has sharpened)."""
     progress("secondary %s: building" % name)
+    t_build = time.perf_counter()
     loop = Loop(name, args, dev, 0, 1, None)
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
     progress("secondary %s: running" % name)
     r = loop.run(setup_steps=args.setup_steps, warmup=10, steps=100, min_timed=100)
     progress("secondary %s: done" % name)
     met = r["metrics"]
     out = {"workload": loop.description, "rays_per_s": r["rays_per_s"], "ms_per_step": r["ms_per_step"], "rays_per_batch": loop.rays,
            "samples_per_ray_marched": met["rm_s"], "samples_per_ray_composited": met["vr_s"], "train_psnr": met["psnr"],
-           "cascades": loop.model.cascades, "timed_steps_total": r["timed_steps_total"], "setup_steps": args.setup_steps}
+           "cascades": loop.model.cascades, "timed_steps_total": r["timed_steps_total"], "setup_steps": args.setup_steps,
+           "global_step_at_end": r["global_step_at_end"], "dataset_build_s": round(t_build, 2)}
+    if roofline:
+        try:
+            out["roofline"] = stage_roofline(loop, r["ms_per_step"])
+        except Exception as e:                               # noqa: BLE001
+            out["roofline"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    if late_steps > loop.trainer.global_step + 100:
+        loop.steps(late_steps - loop.trainer.global_step - 100)
+        dt, _ = loop.timed(100)
+        m2 = loop.trainer.metrics()
+        out["late"] = {"global_step_at_end": loop.trainer.global_step, "rays_per_s": loop.rays * 100 / dt, "ms_per_step": dt / 100 * 1e3,
+                       "samples_per_ray_marched": m2["rm_s"], "samples_per_ray_composited": m2["vr_s"], "train_psnr": m2["psnr"]}
     out.update(march_guard_record())
     del loop
     torch.cuda.empty_cache()
     return out
+
+
+def sensitivity(headline, args, dev, late_steps=3000):
+    """rays/s against LIVE (composited) samples per ray: the headline scene (opaque surfaces) and the lego_hard scene at two
+    densities, each at the bench operating point (step ~430) and `late_steps` steps in.  What the procedural Lego-like scene
+    flatters is early termination; these points bracket a scene that does not."""
+    pts = [{"scene": "lego (opaque surfaces; the headline)", "global_step": headline["global_step"], "live_samples_per_ray": headline["vr_s"],
+            "marched_samples_per_ray": headline["rm_s"], "rays_per_s": headline["rays_per_s"], "ms_per_step": headline["ms_per_step"]}]
+    detail = {}
+    for name in ("lego_hard", "lego_hard_soft"):
+        try:
+            r = secondary_line(name, args, dev, late_steps=late_steps, roofline=False)
+        except Exception as e:                               # noqa: BLE001
+            detail[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            continue
+        detail[name] = r
+        pts.append({"scene": r["workload"], "global_step": r["global_step_at_end"], "live_samples_per_ray": r["samples_per_ray_composited"],
+                    "marched_samples_per_ray": r["samples_per_ray_marched"], "rays_per_s": r["rays_per_s"], "ms_per_step": r["ms_per_step"],
+                    "train_psnr": r["train_psnr"]})
+        if "late" in r:
+            lt = r["late"]
+            pts.append({"scene": r["workload"], "global_step": lt["global_step_at_end"], "live_samples_per_ray": lt["samples_per_ray_composited"],
+                        "marched_samples_per_ray": lt["samples_per_ray_marched"], "rays_per_s": lt["rays_per_s"], "ms_per_step": lt["ms_per_step"],
+                        "train_psnr": lt["train_psnr"]})
+    pts.sort(key=lambda d: d["live_samples_per_ray"])
+    return {"points": pts, "what": "train rays/s (Trainer.step, 8192 rays) against composited samples per ray; same recipe, same code, scenes of "
+                                   "increasing translucency / thin structure", "detail": detail}
+
+
+def api_path_reference_files_rate(loop, n_steps=60):
+    """train.py:159-185 + :131 around the reference's OWN files -- models/rendering.py, models/networks.py, models/custom_functions.py,
+    losses.py, unmodified (oracle/ref_on_binding.py: loaded from /root/reference or the staged copies under oracle/_ref/py) -- with
+    `vren` / `tinycudann` aliased to this package's bindings and apex's FusedAdam replaced by this package's: INTEGRATION.md's
+    "Option A", timed.  The reference's NGP is given the state of the bench's model (parameters, occupancy grid) so that it runs at
+    the same operating point as `api_path_plain`.  Every kernel is libngp_hip.so's; the Python around them is the reference's."""
+    from oracle import ref_on_binding as R
+    from ngp_pl_amd.optim import FusedAdam
+    if not R.available():
+        return {"error": "the reference's models/*.py are neither at /root/reference nor staged under oracle/_ref/py"}
+    dev = loop.dev
+    theirs = R.make_model(loop.model.scale, dev)
+    missing = theirs.load_state_dict(loop.model.state_dict(), strict=False)
+    step = R.TrainingStep(theirs, FusedAdam, lr=loop.trainer.opt.param_groups[0]["lr"])
+    step.global_step = loop.trainer.global_step
+    for _ in range(20):
+        cur = loop.draw(on_side=False); _, loss = step(cur[0], cur[1], cur[2])
+    torch.cuda.synchronize()
+    gc.collect(); gc.disable()
+    try:
+        t = time.perf_counter()
+        S = 0
+        for _ in range(n_steps):
+            cur = loop.draw(on_side=False); res, loss = step(cur[0], cur[1], cur[2])
+            S += int(res["rm_samples"])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / n_steps
+    finally:
+        gc.enable()
+    out = {"rays_per_s": loop.rays / dt, "ms_per_step": dt * 1e3, "samples_per_ray_marched": S / n_steps / loop.rays, "loss": float(loss),
+           "source": R.load().source, "state_dict_missing": list(missing.missing_keys), "state_dict_unexpected": list(missing.unexpected_keys),
+           "what": "the reference's own models/{rendering,networks,custom_functions}.py + losses.py, unmodified, on ngp_pl_amd.vren / "
+                   "ngp_pl_amd.tcnn (module aliases only) + ngp_pl_amd.optim.FusedAdam; train.py:159-185 statement for statement incl. the "
+                   "occupancy update every 16 steps through the reference's Python"}
+    del theirs, step
+    torch.cuda.empty_cache()
+    return out
+
+
+DP_EVAL_POSES = 40            # held-out poses of the evaluation sharded over the ranks (world > 1 or a 1-rank process group)
+
+
+def dp_eval(loop, args, dev, rank, world, dist):
+    """Under a process group: the evaluation the reference runs across ranks (train.py:193-237), with the exchange STILL INSTALLED:
+    `NGP_DP_EVAL_STEPS` (default 2000) more data-parallel steps, then DP_EVAL_POSES held-out poses dealt round-robin over the ranks,
+    per-pose PSNR and frame times all_gather'ed; plus what RCCL itself says about the communicator (ngp_comm_info)."""
+    from ngp_pl_amd import synthetic as syn
+    from ngp_pl_amd.bench_support import sharded_eval
+    from ngp_pl_amd.rendering import render
+    more = int(os.environ.get("NGP_DP_EVAL_STEPS", "2000"))
+    t0 = time.perf_counter()
+    loop.steps(more)
+    loop.fence()
+    train_s = time.perf_counter() - t0
+    ex = loop.exchange
+    poses = syn.hemisphere_poses(DP_EVAL_POSES, seed=999).to(dev)
+    ro, rd = syn.get_rays(loop.data.directions, poses[rank % DP_EVAL_POSES])
+    with torch.no_grad():
+        render(loop.model, ro, rd, test_time=True)           # untimed: workspaces
+    torch.cuda.synchronize()
+
+    def render_pose(i):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        ro, rd = syn.get_rays(loop.data.directions, poses[i])
+        with torch.no_grad():
+            out = render(loop.model, ro, rd, test_time=True)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t) * 1e3
+        gt = loop.data.ground_truth(ro, rd)
+        mse = float(((out["rgb"] - gt) ** 2).mean())
+        import math
+        return ms, -10.0 * math.log10(max(mse, 1e-12))
+    rec = sharded_eval(render_pose, DP_EVAL_POSES, rank, world, dist, dev)
+    rec["field_state"] = "after %d data-parallel steps of %d rays per rank (exchange installed)" % (loop.trainer.global_step, loop.rays)
+    rec["extra_train_steps"] = more
+    rec["extra_train_rays_per_s"] = more * loop.rays * world / train_s
+    if hasattr(ex, "info"):
+        rec.update(ex.info())
+    return rec
 
 
 class OnlyTheJsonLineOnStdout:
@@ -835,7 +981,9 @@ def main():
         "value": r["rays_per_s"], "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16/f32", "dtype_detail": "hash tables, features, MLP operands f16 with f32 MFMA/blend accumulation; march, composite, Adam f32",
-        "data": "synthetic (procedural Lego-like scene, random-init weights)",
+        "data": "synthetic (procedural Lego-like scene, 100 x 800x800 ground-truth images resident in HBM; weights: tiny-cuda-nn's random "
+                "initialisation (seed 1337) TRAINED inside this run -- %d untimed setup steps + %d warm-up steps before the timed windows)" % (
+                    args.setup_steps, args.warmup),
         "config": {"workload": loop.description + "; timed after %d untimed setup steps + %d warm-up steps (steady state: SURVEY.md 8(d))" % (args.setup_steps, args.warmup),
                    "rays_per_gpu": loop.rays, "image_res": args.res, "n_images": args.images, "setup_steps_untimed": args.setup_steps,
                    "samples_per_ray_marched": met["rm_s"], "samples_per_ray_composited": met["vr_s"], "train_psnr": met["psnr"],
@@ -852,6 +1000,18 @@ def main():
     out.update(march_guard_record())
     keeper.headline(out)
     exchange = loop.exchange
+    if dist is not None and not args.no_dp_eval and not args.timed_only:
+        # every rank: more data-parallel steps, then the evaluation sharded over the ranks with the exchange still installed
+        # (collectives inside: all ranks enter it together, right behind the timed windows)
+        if rank == 0:
+            keeper.announce(["dp_eval"])
+            keeper.leg("dp_eval", lambda: dp_eval(loop, args, dev, rank, world, dist), 60.0)
+        else:
+            keeper.phase("dp_eval", 60.0)
+            try:
+                dp_eval(loop, args, dev, rank, world, dist)
+            except Exception as e:                          # noqa: BLE001 -- rank 0 reports; this rank must still reach the teardown
+                progress("dp_eval failed on rank %d: %s: %s" % (rank, type(e).__name__, str(e)[:200]))
     if dist is not None:      # what follows runs on rank 0 only: no collectives from here on
         loop.exchange.uninstall(loop.trainer)
     if rank == 0 and not args.timed_only:
@@ -862,12 +1022,12 @@ def main():
         if do_full:
             legs.append("full_run")
         if not args.no_render:
-            legs += ["render_fps_800x800", "render_fps_800x800_reference_chunking"]
+            legs += ["render_fps_800x800", "render_fps_800x800_regrouped"]
         if not args.no_api:
-            legs += ["api_path", "api_path_plain"]
-        secondary = args.secondary and world == 1 and args.workload == "lego"
+            legs += ["api_path", "api_path_plain", "api_path_reference_files"]
+        secondary = not args.no_secondary and world == 1 and args.workload == "lego"
         if secondary:
-            legs.append("secondary")
+            legs += ["secondary", "sensitivity"]
         keeper.announce(legs)
         keeper.leg("roofline", lambda: kernel_roofline(loop, r["ms_per_step"]), 30.0)
         if "cpu_baseline" in legs:
@@ -878,8 +1038,10 @@ def main():
             # legs below are taken from it (200 held-out poses on the trained field) instead of 5 frames on the young one
             keeper.leg("full_run", lambda: full_run(loop, args, dev, 60.0), 60.0)
         fr = keeper.record.get("full_run") if do_full else None
+        # `render_fps_800x800` = the REFERENCE'S protocol and chunking (test.ipynb cell 2: bit-identical to its host loop);
+        # `render_fps_800x800_regrouped` = the same composited samples per ray regrouped into fewer iterations (an extra)
         if isinstance(fr, dict) and fr.get("complete") and "render" in fr and not args.no_render:
-            for name, key in (("render_fps_800x800", "render"), ("render_fps_800x800_reference_chunking", "render_reference_chunking")):
+            for name, key in (("render_fps_800x800", "render_reference_chunking"), ("render_fps_800x800_regrouped", "render")):
                 if name in keeper.pending:
                     keeper.pending.remove(name)
                 keeper.record[name] = dict(fr[key], field_state="trained: after %d steps of %d rays (full_run)" % (fr["steps"], loop.rays))
@@ -899,12 +1061,15 @@ def main():
                 ref["loop"] = "ngp_render_test_frame chunk_scale=1 probe_cap=0 (the reference's chunking, bit-identical to its host loop)"
                 ref["field_state"] = state
                 return ref
-            keeper.leg("render_fps_800x800", fast_frames, 30.0)
-            keeper.leg("render_fps_800x800_reference_chunking", reference_frames, 30.0)
+            keeper.leg("render_fps_800x800", reference_frames, 30.0)
+            keeper.leg("render_fps_800x800_regrouped", fast_frames, 30.0)
         if not args.no_api:
             keeper.leg("api_path", lambda: api_path_rate(loop), 30.0)
             keeper.leg("api_path_plain", lambda: api_path_plain_rate(loop), 30.0)
+            keeper.leg("api_path_reference_files", lambda: api_path_reference_files_rate(loop), 40.0)
         if secondary:
+            head_pt = {"global_step": r.get("global_step_at_end"), "vr_s": met["vr_s"], "rm_s": met["rm_s"], "rays_per_s": r["rays_per_s"],
+                       "ms_per_step": r["ms_per_step"]}
             del loop
             torch.cuda.empty_cache()
 
@@ -916,7 +1081,8 @@ def main():
                     except Exception as e:                   # noqa: BLE001
                         res.append({"workload": name, "error": "%s: %s" % (type(e).__name__, str(e)[:300])})
                 return res
-            keeper.leg("secondary", both, 90.0)
+            keeper.leg("secondary", both, 60.0)
+            keeper.leg("sensitivity", lambda: sensitivity(head_pt, args, dev), 60.0)
     if rank == 0:
         keeper.finish()
     keeper.phase("leaving" if rank == 0 else "waiting for rank 0's legs", 30.0 if rank == 0 else max(keeper.remaining(), 1.0))

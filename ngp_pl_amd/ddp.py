@@ -82,6 +82,10 @@ class GradientExchange:
         trainer.bwd_groups = 1
         self._works, self._issued, self._work = [], 0, None
 
+    def info(self):
+        """Who carries the collectives, as the communicator itself reports it (bench.py puts this in an N-GPU line)."""
+        return {"comm": "torch.distributed (%s)" % self.dist.get_backend(self.group), "comm_ranks": int(self.dist.get_world_size(self.group))}
+
     def broadcast_parameters(self):
         """DDP's constructor broadcast: every rank starts from rank 0's parameters."""
         for p in self.model.parameters():
@@ -408,11 +412,28 @@ class NativeExchange(ShardedExchange):
             call("ngp_comm_create", C.cast(raw, C.c_void_p), self.world, self.rank, C.byref(h))
         self.comm = h
 
+    def info(self):
+        """World size, rank and RCCL version as the library's own communicator reports them (ngp_comm_info -> ncclCommCount /
+        ncclCommUserRank / ncclGetVersion): the proof in an N-GPU line that RCCL saw N ranks."""
+        import ctypes as C
+        from ._lib import call
+        if self.comm is None:
+            return {"comm": "library-owned RCCL communicator (not created)"}
+        w, r, v, st = C.c_int32(), C.c_int32(), C.c_int32(), C.c_void_p()
+        call("ngp_comm_info", self.comm, C.byref(w), C.byref(r), C.byref(v), C.byref(st))
+        return {"comm": "library-owned RCCL communicator (csrc/comm.hip)", "rccl_ranks": int(w.value), "rccl_rank": int(r.value),
+                "rccl_version": int(v.value), "exchange_mode": self.mode}
+
     def install(self, trainer):
         from . import _lib
         dev = self.model.xyz_encoder.params.device
         if dev.type != "cuda":
             raise RuntimeError("NativeExchange needs the model on a GPU (the gloo tests drive ShardedExchange, its host-side mirror)")
+        if not getattr(trainer, "native_step", False):
+            # only the native stepper's tail (ngp_stepper_tail) issues this exchange's collectives: with the Python-enqueued step the
+            # ranks would run whole-table Adam on their local gradients and diverge silently
+            raise RuntimeError("NativeExchange needs Trainer(native_step=True) (the default): ngp_stepper_tail is what enqueues the "
+                               "exchange; use ShardedExchange / GradientExchange with the Python-enqueued step")
         trainer.loss_scale = self.loss_scale
         trainer.mlp_grad_hook = trainer.grad_hook = trainer.group_hook = trainer.update_hook = None
         trainer.bwd_groups = 1

@@ -409,6 +409,9 @@ class Trainer:
         record are views of the step's preallocated buffers: valid until the next step."""
         if self.native_step and rays_o.is_cuda:
             return self._step_native(rays_o, rays_d, rgb_gt, next_batch)
+        if self.native_exchange is not None:
+            raise RuntimeError("a NativeExchange is installed but this step does not go through the native stepper (native_step=False or "
+                               "CPU rays): no collective would be issued and the ranks would diverge")
         m = self.model
         dev = rays_o.device
         enc, net = m.xyz_encoder, m.rgb_net
@@ -581,6 +584,8 @@ class Trainer:
         [grid-gradient collective + non-finite check] -> fused Adam on the native buffers.
         The bracketed hooks are set under multi-GPU (ngp_pl_amd/ddp.py); device agnostic (tests/test_ddp_gloo.py drives
         it with CPU tensors)."""
+        if getattr(self, "native_exchange", None) is not None:
+            raise RuntimeError("a NativeExchange is installed: the step's tail is ngp_stepper_tail, not the hook-driven Python tail")
         self.model._native = native
         if self.mlp_grad_hook is not None:
             self.mlp_grad_hook()
@@ -611,7 +616,7 @@ class Trainer:
     def step_autograd(self, rays_o, rays_d, rgb_gt, noise=None, next_batch=None):
         """render() -> NeRFLoss -> backward -> FusedAdam, as train.py:159-185 (no GradScaler: the
         tcnn modules carry their own loss scale)."""
-        if self.grad_hook is not None or self.mlp_grad_hook is not None or self.update_hook is not None:
+        if self.grad_hook is not None or self.mlp_grad_hook is not None or self.update_hook is not None or self.native_exchange is not None:
             # the autograd surface issues no collectives: under an installed exchange the ranks would train independently and
             # silently diverge (Trainer.step is the data-parallel path; uninstall() the exchange for single-process use)
             raise RuntimeError("step_autograd() with a gradient exchange installed: the reference-shaped path is single-process; "

@@ -57,10 +57,11 @@ def test_the_line_is_printed_whatever_the_side_legs_do(monkeypatch, capfd):
     monkeypatch.setattr(b, "api_path_rate", api)
     monkeypatch.setattr(b, "cpu_baseline", lambda model, data: {"value": None, "unit": "rays/s", "cores": 8, "kind": "port", "sample": "not measured in this run: timeout"})
 
-    def secondary(name, args, dev):
+    def secondary(name, args, dev, late_steps=0, roofline=True):
         if name == "unbounded":
             raise RuntimeError("out of memory")
-        return {"workload": name, "rays_per_s": 2.0e7}
+        return {"workload": name, "rays_per_s": 2.0e7, "ms_per_step": 0.4, "global_step_at_end": 430, "samples_per_ray_composited": 30.0,
+                "samples_per_ray_marched": 50.0, "train_psnr": 20.0}
     monkeypatch.setattr(b, "secondary_line", secondary)
     saved = os.dup(1)
     try:
@@ -72,11 +73,17 @@ def test_the_line_is_printed_whatever_the_side_legs_do(monkeypatch, capfd):
     assert len(lines) == 1, out
     d = json.loads(lines[0])
     assert d["value"] == 1.0e7 and d["steps"] == 20 and d["warmup"] == 5 and d["n_gpus"] == 1 and d["roofline"]["bound"] == "hbm"
-    assert d["render_fps_800x800"]["fps"] == 200.0 and "field_state" in d["render_fps_800x800"] and calls == [4, 1]
-    assert "frame loop failed" in d["render_fps_800x800_reference_chunking"]["error"]
+    # `render_fps_800x800` is the reference's protocol and chunking (it fails here); the regrouped loop is the extra
+    assert d["render_fps_800x800_regrouped"]["fps"] == 200.0 and "field_state" in d["render_fps_800x800_regrouped"] and calls == [1, 4]
+    assert "frame loop failed" in d["render_fps_800x800"]["error"]
+    assert "random-init" not in d["data"] and "TRAINED inside this run" in d["data"]
+    assert "error" in d["api_path_reference_files"]                     # (a fake loop cannot drive it: recorded, not raised)
+    pts = d["sensitivity"]["points"]
+    assert [p_["live_samples_per_ray"] for p_ in pts] == sorted(p_["live_samples_per_ray"] for p_ in pts) and len(pts) == 3
     assert d["api_path"]["error"].startswith("ValueError")
     assert d["cpu_baseline"]["value"] is None and d["cpu_baseline"]["kind"] == "port"
     assert "out of memory" in d["secondary"][0]["error"] and d["secondary"][1]["rays_per_s"] == 2.0e7
+    assert "roofline" in d and "builder_profile" not in d          # (builder-recorded profile data only ever sits under builder_* keys)
 
 
 def _run_bench_with_fakes(tmp_path, body, deadline):
@@ -107,7 +114,7 @@ b.cpu_baseline = lambda model, data: {"value": 100.0, "unit": "rays/s", "cores":
 support.render_fps = lambda model, data, n_frames, **kw: {"fps": 200.0}
 b.api_path_rate = lambda loop: {"rays_per_s": 1.0}
 %s
-sys.argv = ["bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--deadline", "%g"]
+sys.argv = ["bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-secondary", "--deadline", "%g"]
 b.main()
 """ % (ROOT, body, deadline))
     return subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
@@ -131,8 +138,9 @@ support.render_fps = spin
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout, r.stderr)
     d = json.loads(lines[0])
-    assert d["value"] == 1.0e7 and d["roofline"]["frac"] == 0.1 and d["cpu_baseline"]["value"] == 100.0 and d["render_fps_800x800"]["fps"] == 200.0
-    assert "timeout in render_fps_800x800_reference_chunking" in d["render_fps_800x800_reference_chunking"]["error"]
+    assert d["value"] == 1.0e7 and d["roofline"]["frac"] == 0.1 and d["cpu_baseline"]["value"] == 100.0
+    assert "timeout in render_fps_800x800" in d["render_fps_800x800"]["error"]
+    assert d["render_fps_800x800_regrouped"]["error"].startswith("not run: timeout")
     assert d["api_path"]["error"].startswith("not run: timeout") and "timeout" in d["error"]
     assert "stacks of all threads" in r.stderr and "in spin" in r.stderr           # faulthandler names the spinning frame
 

@@ -51,9 +51,20 @@ def test_driver_command_verbatim():
     roof, cpu = d["roofline"], d["cpu_baseline"]
     assert 0 < roof["frac"] < 1 and roof["bound"] == "hbm" and roof["whole_step"]["frac"] > 0
     assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and (cpu["value"] is None or cpu["value"] > 0)
-    for leg in ("render_fps_800x800", "render_fps_800x800_reference_chunking", "api_path"):
+    for leg in ("render_fps_800x800", "render_fps_800x800_regrouped", "api_path", "api_path_plain", "api_path_reference_files", "full_run",
+                "sensitivity"):
         assert "error" not in d[leg], (leg, d[leg])
-    assert wall < 200, wall
+    assert "reference's chunking" in d["render_fps_800x800"]["loop"]             # the headline FPS is the reference-protocol figure
+    ref_files = d["api_path_reference_files"]
+    assert ref_files["rays_per_s"] > 1e5 and ref_files["state_dict_missing"] == [] and ref_files["state_dict_unexpected"] == []
+    sec = d["secondary"]                                                         # configs[3] / configs[2] recipes: on by default
+    assert len(sec) == 2 and all("error" not in x and x["rays_per_s"] > 1e6 and 0 < x["roofline"]["frac"] < 1 for x in sec), sec
+    assert sec[0]["cascades"] == 6 and sec[1]["rays_per_batch"] == 16384
+    pts = d["sensitivity"]["points"]
+    assert len(pts) >= 3 and all(p_["rays_per_s"] > 1e6 for p_ in pts)
+    assert max(p_["live_samples_per_ray"] for p_ in pts) > 1.5 * d["config"]["samples_per_ray_composited"]      # the hard scene IS harder
+    assert "TRAINED inside this run" in d["data"]
+    assert wall < 240, wall
     assert "[bench" in r.stderr and "headline complete" in r.stderr              # leg-by-leg progress is on by default
 
 
@@ -65,7 +76,8 @@ def test_bench_under_a_one_rank_rccl_group(exchange):
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-               NGP_DDP_EXCHANGE=exchange, HSA_ENABLE_IPC_MODE_LEGACY="0", NGP_BENCH_BOTH_MODES="1")      # (the other mode's leg, which only runs at world > 1 otherwise)
+               NGP_DDP_EXCHANGE=exchange, HSA_ENABLE_IPC_MODE_LEGACY="0", NGP_BENCH_BOTH_MODES="1",      # (the other mode's leg, which only runs at world > 1 otherwise)
+               NGP_DP_EVAL_STEPS="100")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3", "--setup-steps", "48",
                         "--images", "8", "--res", "200", "--no-cpu-baseline", "--no-render", "--no-api"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400, env=env)
@@ -80,3 +92,9 @@ def test_bench_under_a_one_rank_rccl_group(exchange):
     modes = d["exchange_modes"]
     assert set(modes) == {"sharded", "allreduce"} and "error" not in modes[other], modes
     assert modes[other]["exchange_ms"] > 0 and modes[other]["ms_per_step"] > 0 and modes[exchange]["exposed_exchange_ms"] is not None
+    # the evaluation sharded over the ranks ran with the exchange installed, and the line says what RCCL itself saw
+    ev = d["dp_eval"]
+    assert "error" not in ev, ev
+    assert ev["rccl_ranks"] == 1 and ev["rccl_rank"] == 0 and ev["rccl_version"] > 20000 and ev["exchange_mode"] == exchange
+    assert ev["n_poses"] == 40 and ev["poses_per_rank"] == [40] and len(ev["render_fps_per_gpu"]) == 1 and ev["render_fps_per_gpu"][0] > 1
+    assert ev["psnr"] > 10 and ev["render_fps_aggregate"] == ev["render_fps_per_gpu"][0]

@@ -218,6 +218,44 @@ def test_two_rank_batches_differ_dataset_agrees():
     assert res == [(0, True), (1, True)]
 
 
+def _eval_worker(rank, world, port, q, n_poses):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ngp_pl_amd.bench_support import sharded_eval
+    rendered = []
+
+    def render_pose(i):                      # stand-in renderer: frame time and PSNR are functions of (pose, rank)
+        rendered.append(i)
+        return 2.0 + rank, 30.0 + 0.1 * i
+    rec = sharded_eval(render_pose, n_poses, rank, world, dist, "cpu")
+    q.put((rank, rendered, rec))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_poses", [(2, 7), (3, 5)])
+def test_evaluation_is_sharded_round_robin_and_gathered(world, n_poses):
+    """train.py:193-237 across ranks: pose i is rendered by rank i % world only, every rank ends with the same gathered record
+    (mean PSNR over ALL poses, one FPS figure per GPU from that rank's own frames), also when the poses do not divide evenly."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_eval_worker, args=(r, world, port, q, n_poses)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    for rank, rendered, rec in res:
+        assert rendered == list(range(rank, n_poses, world))
+        assert rec == res[0][2]                                                   # the same record on every rank
+    rec = res[0][2]
+    assert rec["ranks"] == world and rec["poses_per_rank"] == [len(range(r, n_poses, world)) for r in range(world)]
+    assert abs(rec["psnr"] - (30.0 + 0.1 * (n_poses - 1) / 2)) < 1e-9
+    assert rec["render_fps_per_gpu"] == pytest.approx([1e3 / (2.0 + r) for r in range(world)])
+    assert rec["render_fps_aggregate"] == pytest.approx(sum(1e3 / (2.0 + r) for r in range(world)))
+
+
 def test_bench_launcher_spawns_n_ranks():
     """`python bench.py --gpus 2` with no rank environment starts 2 ranks (torch.distributed.run, 127.0.0.1) and
     reports n_gpus from the process group; without a GPU it stops there (dry run)."""
