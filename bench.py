@@ -66,8 +66,9 @@ WORKLOADS = {
     "lego": ("lego", 0.5, 8192, 1e-2, False, "configs[1]: Synthetic-NeRF Lego-like, 1xMI355X per rank, 8192 rays/batch, 800x800, scale 0.5"),
     # the same recipe on a scene that does NOT flatter early termination (ngp_pl_amd/bench_support.py:lego_hard_scene: studs, treads
     # made of 4 mm bars, a hollow cabin, finite density sigma -> volumetric ground truth); two densities for the sensitivity
-    "lego_hard": ("lego_hard:60", 0.5, 8192, 1e-2, False, "configs[1] recipe on the lego_hard scene (studs, 4 mm tread lattice, hollow cabin), sigma 60"),
-    "lego_hard_soft": ("lego_hard:30", 0.5, 8192, 1e-2, False, "configs[1] recipe on the lego_hard scene (studs, 4 mm tread lattice, hollow cabin), sigma 30"),
+    "lego_hard": ("lego_hard:60:1.0", 0.5, 8192, 1e-2, False, "configs[1] recipe on the lego_hard scene (studs, 4 mm tread lattice, hollow cabin), sigma 60"),
+    "lego_hard_soft": ("lego_hard:30:1.0", 0.5, 8192, 1e-2, False, "configs[1] recipe on the lego_hard scene, sigma 30"),
+    "lego_hard_big": ("lego_hard:30:1.2", 0.5, 8192, 1e-2, False, "configs[1] recipe on the lego_hard scene, sigma 30, object scaled 1.2x (fills the frame)"),
     "lego16k": ("lego", 0.5, 16384, 2e-2, False, "configs[2] recipe (benchmark_synthetic_nerf.sh:25-28): 16384 rays/batch, lr 2e-2, on the Lego-like scene"),
     "unbounded": ("unbounded", 16.0, 8192, 1e-2, True, "configs[3] recipe (benchmark_mipnerf360.sh:21-24): scale 16 -> 6 cascades, exp_step_factor 1/256, "
                   "erode, black background, on a procedural unbounded scene"),
@@ -154,9 +155,9 @@ class Loop:
         torch.manual_seed(1337)
         self.model = NGP(scale=scale).to(dev)
         self.model.register_training_buffers()
-        scene, _, sigma = scene.partition(":")
-        self.data = data if data is not None else GpuDataset(args.res, args.images, dev, seed=0, scene=scene,
-                                                             sigma=float(sigma) if sigma else None)               # ground truth resident in HBM
+        scene, sigma, size = (scene.split(":") + ["", ""])[:3]
+        self.data = data if data is not None else GpuDataset(args.res, args.images, dev, seed=0, scene=scene, sigma=float(sigma) if sigma else None,
+                                                             size=float(size) if size else 1.0)                   # ground truth resident in HBM
         if erode:      # train.py:73-76,160-163: the colmap recipe marks the cells no camera sees and erodes by visibility
             self.model.mark_invisible_cells(self.data.K.to(dev), self.data.poses, (self.data.W, self.data.H))
         self.trainer = Trainer(self.model, lr=lr, num_epochs=30 if workload != "lego16k" else 20, erode=erode)
@@ -722,7 +723,7 @@ def sensitivity(headline, args, dev, late_steps=3000):
     pts = [{"scene": "lego (opaque surfaces; the headline)", "global_step": headline["global_step"], "live_samples_per_ray": headline["vr_s"],
             "marched_samples_per_ray": headline["rm_s"], "rays_per_s": headline["rays_per_s"], "ms_per_step": headline["ms_per_step"]}]
     detail = {}
-    for name in ("lego_hard", "lego_hard_soft"):
+    for name in ("lego_hard", "lego_hard_soft", "lego_hard_big"):
         try:
             r = secondary_line(name, args, dev, late_steps=late_steps, roofline=False)
         except Exception as e:                               # noqa: BLE001

@@ -66,7 +66,17 @@ def surface_ground_truth(rays_o, rays_d, boxes=None, spheres=None, white_bg=True
 # a finite density (sigma 30-60 per unit length instead of an opaque surface): a ray keeps compositing for up to ln(1e4) / sigma =
 # 0.15-0.3 units of solid, i.e. tens of samples, instead of stopping at the first surface.  Ground truth = exact volume rendering
 # of the union of primitives at constant density (`volumetric_ground_truth`).
-def lego_hard_scene():
+def lego_hard_scene(size=1.0):
+    """`size` scales the whole object about the origin (1.2: the blade reaches |x| = 0.49 of the [-0.5, 0.5] box, the object
+    fills the frame the way the real Lego does in its 800x800 renders)."""
+    boxes, spheres = _lego_hard_primitives()
+    if size != 1.0:
+        boxes = [(tuple(size * v for v in c), tuple(size * v for v in h)) for c, h in boxes]
+        spheres = [(tuple(size * v for v in c), size * r) for c, r in spheres]
+    return boxes, spheres
+
+
+def _lego_hard_primitives():
     boxes, spheres = [], []
     boxes.append(((0.0, 0.0, -0.24), (0.34, 0.24, 0.03)))                      # base plate
     boxes.append(((0.17, 0.0, -0.13), (0.10, 0.12, 0.06)))                     # hood (solid)
@@ -171,7 +181,7 @@ class GpuDataset:
     `sample` draws img/pix indices like BaseDataset.__getitem__ ('all_images', base.py:22-35) and
     forms the rays like NeRFSystem.forward (train.py:78-91), all on the GPU."""
 
-    def __init__(self, res, n_images, device, seed=0, scene="lego", sigma=None):
+    def __init__(self, res, n_images, device, seed=0, scene="lego", sigma=None, size=1.0):
         """scene: "lego" (opaque surfaces), "unbounded" (the scale-16 stand-in), "lego_hard" (thin structures, hollow cabin, finite
         density `sigma`: volumetric ground truth)."""
         self.W = self.H = res
@@ -186,7 +196,7 @@ class GpuDataset:
             boxes, spheres = unbounded_scene()
         elif scene == "lego_hard":
             self.poses = syn.hemisphere_poses(n_images, seed=seed).to(device)
-            boxes, spheres = lego_hard_scene()
+            boxes, spheres = lego_hard_scene(size)
             sigma = 45.0 if sigma is None else float(sigma)
         else:
             raise ValueError("unknown scene %r" % scene)

@@ -127,11 +127,15 @@ def make_model(scale, device, rgb_act="Sigmoid", seed=None):
 
 class TrainingStep:
     """NeRFSystem.training_step (train.py:159-185) + configure_optimizers (train.py:123-137) without Lightning, statement for
-    statement, around the reference's own render / NGP / NeRFLoss: occupancy update every 16 steps, render, loss,
-    backward, FusedAdam(net_params, lr, eps=1e-15).  `optimizer_cls` is apex.optimizers.FusedAdam in the reference; the
-    caller passes this package's drop-in."""
+    statement, around the reference's own render / NGP / NeRFLoss: occupancy update every 16 steps, render, loss, backward,
+    FusedAdam(net_params, lr, eps=1e-15).  `optimizer_cls` is apex.optimizers.FusedAdam in the reference; the caller passes this
+    package's drop-in.  `amp=True` (default) reproduces what `Trainer(precision=16)` (train.py:274) wraps around the step: the
+    forward -- occupancy update included, which only works BECAUSE of it: NGP.density() returns float32 through TruncExp's
+    custom_fwd(cast_inputs=float32) under autocast and float16 (tiny-cuda-nn's output dtype) without, and
+    `density_grid_tmp[c, indices] = self.density(xyzs_w)` (networks.py:256) needs float32 -- under torch.autocast, the loss
+    scaled by a GradScaler, unscale + skip-on-inf around the optimizer step."""
 
-    def __init__(self, model, optimizer_cls, lr=1e-2, distortion_loss_w=0.0, erode=False, exp_step_factor=None):
+    def __init__(self, model, optimizer_cls, lr=1e-2, distortion_loss_w=0.0, erode=False, amp=True):
         mods = load()
         self.mods, self.model = mods, model
         self.loss = mods.losses.NeRFLoss(lambda_distortion=distortion_loss_w)
@@ -139,18 +143,26 @@ class TrainingStep:
         self.warmup_steps, self.update_interval, self.global_step = 256, 16, 0
         self.erode = erode
         self.kwargs = {"test_time": False, "random_bg": False}
-        if model.scale > 0.5 if exp_step_factor is None else exp_step_factor:
+        if model.scale > 0.5:                               # train.py:95-96
             self.kwargs["exp_step_factor"] = 1 / 256
+        self.amp = amp
+        self.scaler = torch.amp.GradScaler("cuda") if amp else None
 
     def __call__(self, rays_o, rays_d, rgb):
         MAX_SAMPLES = self.mods.rendering.MAX_SAMPLES
-        if self.global_step % self.update_interval == 0:
-            self.model.update_density_grid(0.01 * MAX_SAMPLES / 3 ** 0.5, warmup=self.global_step < self.warmup_steps, erode=self.erode)
-        results = self.mods.rendering.render(self.model, rays_o, rays_d, **self.kwargs)
-        loss_d = self.loss(results, {"rgb": rgb})
-        loss = sum(lo.mean() for lo in loss_d.values())
+        with torch.autocast("cuda", dtype=torch.float16, enabled=self.amp):
+            if self.global_step % self.update_interval == 0:
+                self.model.update_density_grid(0.01 * MAX_SAMPLES / 3 ** 0.5, warmup=self.global_step < self.warmup_steps, erode=self.erode)
+            results = self.mods.rendering.render(self.model, rays_o, rays_d, **self.kwargs)
+            loss_d = self.loss(results, {"rgb": rgb})
+            loss = sum(lo.mean() for lo in loss_d.values())
         self.net_opt.zero_grad()
-        loss.backward()
-        self.net_opt.step()
+        if self.scaler is not None:
+            self.scaler.scale(loss).backward()
+            self.scaler.step(self.net_opt)
+            self.scaler.update()
+        else:
+            loss.backward()
+            self.net_opt.step()
         self.global_step += 1
         return results, loss

@@ -79,7 +79,7 @@ def test_the_line_is_printed_whatever_the_side_legs_do(monkeypatch, capfd):
     assert "random-init" not in d["data"] and "TRAINED inside this run" in d["data"]
     assert "error" in d["api_path_reference_files"]                     # (a fake loop cannot drive it: recorded, not raised)
     pts = d["sensitivity"]["points"]
-    assert [p_["live_samples_per_ray"] for p_ in pts] == sorted(p_["live_samples_per_ray"] for p_ in pts) and len(pts) == 3
+    assert [p_["live_samples_per_ray"] for p_ in pts] == sorted(p_["live_samples_per_ray"] for p_ in pts) and len(pts) == 4
     assert d["api_path"]["error"].startswith("ValueError")
     assert d["cpu_baseline"]["value"] is None and d["cpu_baseline"]["kind"] == "port"
     assert "out of memory" in d["secondary"][0]["error"] and d["secondary"][1]["rays_per_s"] == 2.0e7

@@ -199,7 +199,10 @@ def test_the_references_update_density_grid_on_the_binding(R):
         model.get_all_cells = lambda: drawn.append(real_all()) or drawn[-1]
         model.sample_uniform_and_occupied_cells = lambda M, t: drawn.append(real_sample(M, t)) or drawn[-1]
         try:
-            model.update_density_grid(thr, warmup=warmup)
+            # under autocast, as Lightning's precision=16 runs training_step (train.py:274): without it NGP.density() hands back
+            # tiny-cuda-nn's float16 and networks.py:256 cannot index-assign it into the float32 grid
+            with torch.autocast("cuda", dtype=torch.float16):
+                model.update_density_grid(thr, warmup=warmup)
         finally:
             model.density, model.get_all_cells, model.sample_uniform_and_occupied_cells = real_density, real_all, real_sample
         assert len(seen) == 1 and len(drawn) == 1
@@ -266,16 +269,18 @@ def test_train_py_statements_around_the_references_files_train_like_the_product_
     assert torch.equal(theirs.xyz_encoder.params.detach(), ours.xyz_encoder.params.detach())    # same seed-1337 initialisation
     opt = FusedAdam([p for p in ours.parameters()], 1e-2, eps=1e-15)
     loss_fn = NeRFLoss(lambda_distortion=0.0)
+    scaler = torch.amp.GradScaler("cuda")                       # (Lightning precision=16, as R.TrainingStep does for the reference's files)
     batches = [_batch(2048, 900 + i) for i in range(8)]
     la, lb, rm_a, rm_b = [], [], 0.0, 0.0
     for it in range(48):
         ro, rd, gt = batches[it % 8]
         res_a, loss_a = step(ro, rd, gt)
-        if it % 16 == 0:
-            ours.update_density_grid(0.01 * 1024 / 3 ** 0.5, warmup=True)
-        res_b = render(ours, ro, rd, test_time=False, random_bg=False)
-        loss_b = sum(v.mean() for v in loss_fn(res_b, {"rgb": gt}).values())
-        opt.zero_grad(); loss_b.backward(); opt.step()
+        with torch.autocast("cuda", dtype=torch.float16):
+            if it % 16 == 0:
+                ours.update_density_grid(0.01 * 1024 / 3 ** 0.5, warmup=True)
+            res_b = render(ours, ro, rd, test_time=False, random_bg=False)
+            loss_b = sum(v.mean() for v in loss_fn(res_b, {"rgb": gt}).values())
+        opt.zero_grad(); scaler.scale(loss_b).backward(); scaler.step(opt); scaler.update()
         la.append(float(loss_a)); lb.append(float(loss_b))
         rm_a, rm_b = float(res_a["rm_samples"]) / 2048, float(res_b["rm_samples"]) / 2048
     first_a, last_a = np.mean(la[:4]), np.mean(la[-8:])
@@ -284,3 +289,4 @@ def test_train_py_statements_around_the_references_files_train_like_the_product_
     assert abs(last_a - last_b) < 0.25 * max(last_a, last_b), (last_a, last_b)
     assert abs(rm_a - rm_b) < 0.1 * max(rm_a, rm_b), (rm_a, rm_b)
     assert step.global_step == 48 and theirs.density_bitfield.any()
+    assert step.scaler.get_scale() >= 1024.0 and scaler.get_scale() >= 1024.0          # neither run collapsed into skipped steps
