@@ -329,7 +329,8 @@ class _NativeTrainRender(torch.autograd.Function):
             no_p = nd_p = None
             if next_rays is not None and next_rays[0].shape[0] == n:       # the caller knows its next batch: march it under this step
                 if rs.side is None:
-                    rs.side = torch.cuda.Stream(device=dev, priority=-1)
+                    from .trainer import marching_stream
+                    rs.side = marching_stream(dev)
                 sq = rs.side.cuda_stream
                 nxt = (next_rays[0].float().contiguous(), next_rays[1].float().contiguous())
                 no_p, nd_p = nxt[0].data_ptr(), nxt[1].data_ptr()

@@ -40,6 +40,22 @@ def _set_current_stream(st):
 from .stepper import StepBuffers, _align        # noqa: E402,F401  (the step's buffers: shared with rendering.py's native render node)
 
 
+_MARCH_STREAMS = {}
+
+
+def marching_stream(dev):
+    """THE marching stream of a device: one per process, shared by every Trainer / render stepper on that device (they run one
+    after another).  torch hands out its 32 pooled high-priority streams round-robin, and which hardware queue a stream lands on
+    depends on how many were handed out before: with one stream per Trainer the SAME workload ran at 0.39 or 0.73 ms per step from
+    one instance to the next inside one process (round 5, tools/loop_variance.py)."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    st = _MARCH_STREAMS.get(key)
+    if st is None or os.environ.get("NGP_SHARED_SIDE", "1") == "0":
+        st = torch.cuda.Stream(device=dev, priority=int(os.environ.get("NGP_MARCH_PRIORITY", "-1")))
+        _MARCH_STREAMS[key] = st
+    return st
+
+
 class Trainer:
     def __init__(self, model, lr=1e-2, num_epochs=30, steps_per_epoch=1000, T_threshold=1e-4,
                  lambda_opacity=1e-3, grad_scale=1.0, warmup_steps=256, update_interval=16, overlap_march=True,
@@ -72,7 +88,7 @@ class Trainer:
         # a few HSA queues (GPU_MAX_HW_QUEUES, default 4) round-robin, and once RCCL has created its streams a
         # default-priority stream was observed to share the main stream's queue (rocprofv3: every kernel on one
         # queue_id, step 0.52 -> 0.89 ms).  High-priority streams are served from a separate queue.
-        self.side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("NGP_MARCH_PRIORITY", "-1"))) if (overlap_march and dev.type == "cuda") else None
+        self.side = marching_stream(dev) if (overlap_march and dev.type == "cuda") else None
         # seed of the march's jitter draws (custom_functions.py:83: every rank's torch.rand_like draws from its own generator): the rank
         # is mixed in so that data-parallel ranks do not jitter ray slot r alike at every step
         rank = 0
