@@ -53,10 +53,10 @@ class FusedAdam(torch.optim.Optimizer):
                 native_grads = True
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.set_grad_none = set_grad_none
-        self.t = 0                       # native step calls so far (1-based inside a step)
+        self._roles = {}
+        self._t = 0                      # optimizer steps so far (1-based inside a step): see the `t` property
         self._step_state = None          # device-side counts of APPLIED steps, once a skip flag has been seen (ngp_adam_step_field)
         # the NGP whose (xyz_encoder.params, rgb_net.params) are both in this optimizer
-        self._roles = {}
         for group in self.param_groups:
             for p in group["params"]:
                 ref = getattr(p, "_ngp_model", None)
@@ -79,6 +79,42 @@ class FusedAdam(torch.optim.Optimizer):
                 self.model.native_grads = bool(native_grads)
 
     # -- state -----------------------------------------------------------------------------------
+    @property
+    def t(self):
+        """Bias-correction step count of the model's two parameter tensors.  ONE count, whichever route the gradients take: the
+        native route (and the trainer's native stepper) advances it here, the `.grad` route through state[p]['step'] -- the two
+        are kept equal, so that switching `model.native_grads` mid-run or reloading a checkpoint continues the same count."""
+        return self._t
+
+    @t.setter
+    def t(self, v):
+        self._t = int(v)
+        for p in self._roles.values():
+            if "exp_avg" in self.state[p]:
+                self.state[p]["step"] = self._t
+
+    def state_dict(self):
+        """torch's optimizer state (per-parameter step / exp_avg / exp_avg_sq, param groups) plus what the native route keeps
+        outside it: the step count and, once a skip flag has been in use, the device-side counts of APPLIED steps."""
+        sd = super().state_dict()
+        sd["ngp_native"] = {"t": self._t, "step_state": None if self._step_state is None else self._step_state.tolist()}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        extra = state_dict.get("ngp_native")
+        super().load_state_dict({k: v for k, v in state_dict.items() if k != "ngp_native"})
+        if extra is None:                # written by another optimizer class / an older version: the per-parameter counts decide
+            steps = [int(self.state[p].get("step", 0)) for p in self._roles.values() if p in self.state]
+            self._t = max(steps, default=0)
+            self._step_state = None
+        else:
+            self.t = extra["t"]
+            ss = extra.get("step_state")
+            if ss is None:
+                self._step_state = None
+            else:
+                self._step_state = torch.tensor(ss, dtype=torch.int32, device=self._roles["enc"].device)
+
     def _moments(self, p):
         st = self.state[p]
         if "exp_avg" not in st:
@@ -190,6 +226,8 @@ class FusedAdam(torch.optim.Optimizer):
                     continue
                 m, v = self._moments(p)
                 self.state[p]["step"] += 1
+                if model is not None and (p is model.xyz_encoder.params or p is model.rgb_net.params):
+                    self._t = max(self._t, self.state[p]["step"])          # (one count for both gradient routes, see `t`)
                 if p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
                     p.grad = p.grad.float().contiguous()
                 half = self._half_of(p)

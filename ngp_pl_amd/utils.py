@@ -14,21 +14,20 @@ import torch
 from . import tcnn
 
 
-def extract_model_state_dict(ckpt_path, model_name="model", prefixes_to_ignore=[]):
-    checkpoint = torch.load(ckpt_path, map_location="cpu") if not isinstance(ckpt_path, dict) else ckpt_path
-    checkpoint_ = {}
-    if "state_dict" in checkpoint:      # a pytorch-lightning checkpoint
-        checkpoint = checkpoint["state_dict"]
-    for k, v in checkpoint.items():
-        if not k.startswith(model_name):
-            continue
-        k = k[len(model_name) + 1:]
-        for prefix in prefixes_to_ignore:
-            if k.startswith(prefix):
-                break
-        else:
-            checkpoint_[k] = v
-    return checkpoint_
+def _open(ckpt):
+    """A checkpoint given as a path or as the loaded dictionary."""
+    return ckpt if isinstance(ckpt, dict) else torch.load(ckpt, map_location="cpu")
+
+
+def extract_model_state_dict(ckpt_path, model_name="model", prefixes_to_ignore=()):
+    """The entries of a checkpoint that belong to `<model_name>.`, with that prefix removed; a Lightning checkpoint keeps its
+    tensors under "state_dict".  Keys that start with one of `prefixes_to_ignore` (after the model prefix) are left out."""
+    tensors = _open(ckpt_path)
+    tensors = tensors.get("state_dict", tensors)
+    head = model_name + "."
+    skip = tuple(prefixes_to_ignore)
+    return {k[len(head):]: v for k, v in tensors.items()
+            if k.startswith(model_name) and not (skip and k[len(head):].startswith(skip))}
 
 
 def grid_param_count(encoding_config, level_table):
@@ -53,7 +52,7 @@ def check_encoder_length(model, n_ckpt):
                        "scale / hash-grid configuration?" % (n_ckpt, model.scale, enc.level_table, n_model))
 
 
-def load_ckpt(model, ckpt_path, model_name="model", prefixes_to_ignore=[]):
+def load_ckpt(model, ckpt_path, model_name="model", prefixes_to_ignore=()):
     if not ckpt_path:
         return
     model_dict = model.state_dict()
@@ -67,14 +66,15 @@ def load_ckpt(model, ckpt_path, model_name="model", prefixes_to_ignore=[]):
             mod._half.invalidate()
 
 
+_NOT_IN_A_SLIM_CKPT = ("directions", "model.density_grid", "model.grid_coords")     # rebuilt from the dataset / by training start
+
+
 def slim_ckpt(ckpt_path, save_poses=False):
-    ckpt = torch.load(ckpt_path, map_location="cpu") if not isinstance(ckpt_path, dict) else ckpt_path
-    keys_to_pop = ["directions", "model.density_grid", "model.grid_coords"]
-    if not save_poses:
-        keys_to_pop += ["poses"]
-    for k in ckpt["state_dict"]:
-        if k.startswith("val_lpips"):
-            keys_to_pop += [k]
-    for k in keys_to_pop:
-        ckpt["state_dict"].pop(k, None)
-    return ckpt["state_dict"]
+    """The state dict of a Lightning checkpoint without what inference does not need: ray directions, the float occupancy grid
+    and its cell coordinates, the LPIPS network, and (unless `save_poses`) the camera poses.  Edits the checkpoint in place, as
+    the reference does."""
+    sd = _open(ckpt_path)["state_dict"]
+    doomed = set(_NOT_IN_A_SLIM_CKPT) | ({"poses"} if not save_poses else set()) | {k for k in sd if k.startswith("val_lpips")}
+    for k in doomed:
+        sd.pop(k, None)
+    return sd

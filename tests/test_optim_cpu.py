@@ -60,6 +60,28 @@ def test_fused_adam_finds_the_model_behind_bare_parameters():
     assert em.shape == m.xyz_encoder.params.shape and float(ev.abs().sum()) == 0.0
 
 
+def test_state_dict_carries_the_step_count_of_the_native_route():
+    """Lightning checkpoints the optimizer (`optimizer.state_dict()`): warm moments reloaded with a step count of 0 would restart
+    the bias correction at step 1.  The native route's count travels in the state dict and in state[p]['step'] alike."""
+    from ngp_pl_amd.networks import NGP
+    from ngp_pl_amd.optim import FusedAdam
+    m = NGP(scale=0.5)
+    opt = FusedAdam(m, lr=1e-2, eps=1e-15)
+    opt.t += 1; opt.t += 1; opt.t += 1                     # what three native steps do
+    assert all(opt.state[p]["step"] == 3 for p in (m.xyz_encoder.params, m.rgb_net.params))
+    opt.moments("rgb")[0].fill_(0.25)
+    sd = opt.state_dict()
+    assert sd["ngp_native"] == {"t": 3, "step_state": None}
+    m2 = NGP(scale=0.5)
+    opt2 = FusedAdam(m2, lr=1e-2, eps=1e-15)
+    opt2.load_state_dict(sd)
+    assert opt2.t == 3 and opt2.state[m2.rgb_net.params]["step"] == 3 and float(opt2.moments("rgb")[0][0]) == 0.25
+    del sd["ngp_native"]                                   # a state dict from a version without the extra record
+    opt3 = FusedAdam(NGP(scale=0.5), lr=1e-2, eps=1e-15)
+    opt3.load_state_dict(sd)
+    assert opt3.t == 3
+
+
 def test_frame_bytes_is_the_survey_accounting():
     import bench
     # SURVEY.md 8(d): per ray AABB 32 + march 24 in + composite 52; per sample march 32 + encode 588 + MLPs 210 + composite 28

@@ -159,6 +159,43 @@ def test_unchanged_training_step_under_torch_gradscaler():
     assert scaler.get_scale() == 1024.0                    # no overflow was seen
 
 
+def test_optimizer_checkpoint_round_trip_continues_bit_for_bit():
+    """`optimizer.state_dict()` -> `load_state_dict()` into a freshly built model + optimizer (what resuming a Lightning checkpoint
+    does): the NEXT update equals the uninterrupted run's bit for bit -- parameters, f16 working copies and moments -- which needs
+    the bias-correction count of the native gradient route to travel with the state (it restarted at 1 before round 5)."""
+    import copy
+    from ngp_pl_amd.optim import FusedAdam
+    from ngp_pl_amd.rendering import render
+
+    def one_step(model, opt, it):
+        ro, rd, gt = _batch(1024, 700 + it)
+        noise = torch.rand(1024, generator=torch.Generator().manual_seed(it)).cuda()       # the march's jitter, the same on both sides
+        res = render(model, ro, rd, test_time=False, noise=noise)
+        opt.zero_grad()
+        _loss(res, gt).backward()
+        assert model._native is not None                    # the native gradient route
+        opt.step()
+
+    a = _make(seed=31)
+    opt_a = FusedAdam(_net_params(_System(a)), 1e-2, eps=1e-15, native_grads=True)
+    for it in range(3):
+        one_step(a, opt_a, it)
+    assert opt_a.t == 3 and opt_a.state[a.rgb_net.params]["step"] == 3
+    sd_model, sd_opt = copy.deepcopy(a.state_dict()), copy.deepcopy(opt_a.state_dict())
+    b = _make(seed=77)
+    b.load_state_dict(sd_model)
+    opt_b = FusedAdam(_net_params(_System(b)), 1e-2, eps=1e-15, native_grads=True)
+    opt_b.load_state_dict(sd_opt)
+    assert opt_b.t == 3
+    one_step(a, opt_a, 3); one_step(b, opt_b, 3)
+    for pa, pb in ((a.xyz_encoder.params, b.xyz_encoder.params), (a.rgb_net.params, b.rgb_net.params)):
+        assert torch.equal(pa.detach(), pb.detach())
+        for k in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(opt_a.state[pa][k], opt_b.state[pb][k]), k
+    assert torch.equal(a.xyz_encoder._half.get(a.xyz_encoder.params), b.xyz_encoder._half.get(b.xyz_encoder.params))
+    assert opt_b.t == 4 == opt_b.state[b.rgb_net.params]["step"]
+
+
 # -------------------------------------------------------------------------------------------------------------------------
 # DistributedDataParallel around the system (train.py:268-272)
 # -------------------------------------------------------------------------------------------------------------------------
