@@ -75,11 +75,6 @@ int ngp_ray_sphere_intersect(const float* rays_o, const float* rays_d,
 int ngp_ray_aabb_near(const float* rays_o, const float* rays_d,
                       const float* center, const float* half_size, float near_distance,
                       int n_rays, float* hits_t, ngp_stream_t stream);
-/* The same launch also draws the marcher's per-ray jitter (custom_functions.py:83: torch.rand_like(rays_o[:, 0])):
- * noise (R) f32 in [0,1) from a counter-based generator keyed by (seed, ray). */
-int ngp_ray_aabb_near_noise(const float* rays_o, const float* rays_d,
-                            const float* center, const float* half_size, float near_distance,
-                            int n_rays, uint64_t seed, float* hits_t, float* noise, ngp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * vren: occupancy grid helpers  (reference: models/csrc/raymarching.cu:35-161)
@@ -105,10 +100,6 @@ int ngp_density_grid_update(float* density_grid, const float* density_grid_tmp,
  * (networks.py:266-268 without the .item() host sync). */
 int ngp_packbits_auto(const float* density_grid, int n_bytes, const float* stats,
                       float density_threshold, uint8_t* density_bitfield, ngp_stream_t stream);
-/* Jittered cell-centre sample points (networks.py:251-255): coords (N,3) i32, noise (N,3) f32
- * in [0,1) -> xyzs_w (N,3) f32 for cascade with half-extent s. */
-int ngp_cells_to_xyz(const int32_t* coords, const float* noise, int n, int grid_size, float s,
-                     float* xyzs_w, ngp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * vren: ray marching            (reference: models/csrc/raymarching.cu:163-454)
@@ -133,37 +124,13 @@ int ngp_raymarching_train_count(const float* rays_o, const float* rays_d, const 
                                 int64_t* rays_a, int32_t* counter, float* t_scratch,
                                 ngp_stream_t stream);
 
-/* ngp_raymarching_train_count that also prepares the compact first-round list of the two-round forward: offs_k (n_rays, i32) =
- * exclusive scan of min(N, first_k) in ray order, counter[3] = its total (counter then holds 4 x i32).  offs_k NULL: exactly
- * ngp_raymarching_train_count. */
-int ngp_raymarching_train_count_k(const float* rays_o, const float* rays_d, const float* hits_t,
-                                  const uint8_t* density_bitfield, int cascades, float scale,
-                                  float exp_step_factor, const float* noise, int grid_size,
-                                  int max_samples, int n_rays, int64_t* rays_a, int32_t* counter,
-                                  float* t_scratch, int first_k, int32_t* offs_k, ngp_stream_t stream);
 int ngp_raymarching_train_write(const float* rays_o, const float* rays_d, const int64_t* rays_a,
                                 const float* t_scratch, float scale, float exp_step_factor,
                                 int grid_size, int max_samples, int n_rays,
                                 float* xyzs, float* dirs, float* deltas, float* ts,
                                 ngp_stream_t stream);
 
-/* ngp_raymarching_train_write that also lists the ids of every ray's first min(N, first_k) samples (first_k in 1..64):
- * list_k[ray * first_k + k] = start + k, or -1 where the ray has fewer (a padded list of n_rays * first_k entries), and clears
- * *n_clear (may be NULL) on the side: the first round of the two-round forward (ngp_stepper, "two-round forward" below). */
-int ngp_raymarching_train_write_k(const float* rays_o, const float* rays_d, const int64_t* rays_a,
-                                  const float* t_scratch, float scale, float exp_step_factor,
-                                  int grid_size, int max_samples, int n_rays,
-                                  float* xyzs, float* dirs, float* deltas, float* ts,
-                                  int first_k, int32_t* list_k, int32_t* n_clear, ngp_stream_t stream);
 
-/* The same with a COMPACT list in ray order: list_k[offs_k[ray] + k] = start + k for k < min(N, first_k), where offs_k is the
- * exclusive scan of min(N, first_k) over the rays that ngp_raymarching_train_count_k wrote (its total is counter[3]: the list's
- * length).  No padding entries: late in training most rays have no samples at all. */
-int ngp_raymarching_train_write_kc(const float* rays_o, const float* rays_d, const int64_t* rays_a,
-                                   const float* t_scratch, float scale, float exp_step_factor,
-                                   int grid_size, int max_samples, int n_rays,
-                                   float* xyzs, float* dirs, float* deltas, float* ts,
-                                   int first_k, const int32_t* offs_k, int32_t* list_k, int32_t* n_clear, ngp_stream_t stream);
 
 /* vren.raymarching_test (binding.cpp:84-106, raymarching.cu:335-454).  hits_t (R_total,2) is
  * advanced in place; alive_indices (N_alive) i64; outputs are dense (N_alive,N_samples,.) and
@@ -197,13 +164,6 @@ int ngp_composite_train_fw(const float* sigmas, const float* rgbs, const float* 
                            float* ws, int32_t* n_active_per_ray /* optional (R) i32: min(N, total+1) per row */,
                            ngp_stream_t stream);
 
-/* Two-round forward: which rays are still transparent behind their first first_k (<= 64) samples?  For every ray with N > first_k
- * whose transmittance after its first first_k samples is above T_threshold (the composite's own arithmetic on sigmas / deltas at
- * those samples), the ids of its remaining samples are appended to list_rest (*n_rest += N - first_k; order unspecified).  The
- * samples NOT listed lie behind their ray's early stop: volumerendering.cu:20-44 never reads them, so neither does the composite
- * that follows -- the field need not be evaluated there. */
-int ngp_composite_probe(const float* sigmas, const float* deltas, const int64_t* rays_a, int first_k, float T_threshold,
-                        int n_rays, int32_t* list_rest, int32_t* n_rest, ngp_stream_t stream);
 
 /* ngp_composite_train_fw + ngp_active_scan + ngp_nerf_loss for the training step in two launches
  * instead of three (train.py:159-176: render -> NeRFLoss -> mean): every wave also forms its
@@ -214,15 +174,6 @@ int ngp_composite_probe(const float* sigmas, const float* deltas, const int64_t*
  * ngp_raymarching_train_count writes it.  bg: 3 floats or NULL.  ray_offsets and workspace
  * (ngp_composite_train_fw_loss_workspace_bytes bytes, scratch) must be 16-byte aligned. */
 size_t ngp_composite_train_fw_loss_workspace_bytes(int n_rays);
-/* (_h: the same with the live-sample count also stored to n_active_host, pinned device-mapped host memory, may be NULL) */
-int ngp_composite_train_fw_loss_h(const float* sigmas, const float* rgbs, const float* deltas,
-                                  const float* ts, const int64_t* rays_a, float T_threshold,
-                                  int n_rays, int n_samples, int64_t* total_samples, float* opacity,
-                                  float* depth, float* rgb, float* ws, int32_t* ray_offsets,
-                                  int32_t* n_active, int32_t* n_active_host, const float* gt_rgb, const float* bg,
-                                  float lambda_opacity, float grad_scale, float* loss, float* sq_err,
-                                  float* dL_drgb, float* dL_dopacity, void* workspace,
-                                  size_t workspace_bytes, ngp_stream_t stream);
 int ngp_composite_train_fw_loss(const float* sigmas, const float* rgbs, const float* deltas,
                                 const float* ts, const int64_t* rays_a, float T_threshold,
                                 int n_rays, int n_samples, int64_t* total_samples, float* opacity,
@@ -245,41 +196,6 @@ int ngp_composite_train_bw(const float* dL_dopacity, const float* dL_ddepth, con
                            const float* xyzs, float* x_active /* both optional, with active_idx: also copy the
                            listed samples' positions (S,3) to x_active in list order (= ngp_gather_xyz) */,
                            ngp_stream_t stream);
-/* The same pair WITHOUT the one-workgroup scan kernel between them (the native step's default): the forward leaves the per-row
- * COUNTS of live samples in ray_counts (R) i32 (16-byte aligned) and the per-row loss terms in the workspace; the backward's
- * workgroups prefix the counts themselves (integer sums: exactly the offsets ngp_composite_train_fw_loss would have written), its
- * last workgroup writes n_active (+ n_active_host, pinned host memory, may be NULL), its first adds the loss terms in a fixed
- * order into loss / sq_err.  n_samples must be > 0 (a batch without samples has no backward: use ngp_composite_train_fw_loss). */
-int ngp_composite_train_fw_loss_counts(const float* sigmas, const float* rgbs, const float* deltas, const float* ts,
-                                       const int64_t* rays_a, float T_threshold, int n_rays, int n_samples,
-                                       int64_t* total_samples, float* opacity, float* depth, float* rgb, float* ws,
-                                       int32_t* ray_counts, const float* gt_rgb, const float* bg,
-                                       float lambda_opacity, float grad_scale, float* dL_drgb,
-                                       float* dL_dopacity, void* workspace, size_t workspace_bytes, ngp_stream_t stream);
-/* The same idea for render()'s training branch (rendering.py:121-163), where the caller forms the loss: the forward also writes
- * the BLENDED colour rgb_out (R,3) = rgb + bg (1 - opacity) (bg 3 floats on the device, NULL = black; rgb_out may be NULL) and
- * leaves the rows' live counts in ray_counts; the backward takes its seeds w.r.t. that blended colour (g_opacity may be NULL),
- * folds the blend's backward in, prefixes the counts and writes n_active -- three launches less than ngp_composite_train_fw +
- * ngp_active_scan + ngp_bg_blend and ngp_bg_blend_bw + ngp_composite_train_bw, the same bits. */
-int ngp_composite_train_fw_blend(const float* sigmas, const float* rgbs, const float* deltas, const float* ts,
-                                 const int64_t* rays_a, float T_threshold, int n_rays, int n_samples,
-                                 int64_t* total_samples, float* opacity, float* depth, float* rgb, float* ws,
-                                 int32_t* ray_counts, const float* bg, float* rgb_out, ngp_stream_t stream);
-int ngp_composite_train_bw_render(const float* g_opacity, const float* g_depth, const float* g_rgb,
-                                  const float* g_ws, const float* sigmas, const float* rgbs, const float* ws,
-                                  const float* deltas, const float* ts, const int64_t* rays_a,
-                                  const float* opacity, const float* depth, const float* rgb, float T_threshold,
-                                  int n_rays, int n_samples, float* dL_dsigmas, float* dL_drgbs,
-                                  const int32_t* ray_counts, int32_t* active_idx, const float* xyzs, float* x_active,
-                                  int32_t* n_active, const float* bg, ngp_stream_t stream);
-int ngp_composite_train_bw_tail(const float* dL_dopacity, const float* dL_ddepth, const float* dL_drgb,
-                                const float* dL_dws, const float* sigmas, const float* rgbs, const float* ws,
-                                const float* deltas, const float* ts, const int64_t* rays_a,
-                                const float* opacity, const float* depth, const float* rgb, float T_threshold,
-                                int n_rays, int n_samples, float* dL_dsigmas, float* dL_drgbs,
-                                const int32_t* ray_counts, int32_t* active_idx, const float* xyzs, float* x_active,
-                                int32_t* n_active, int32_t* n_active_host, float* loss, float* sq_err,
-                                const void* workspace, size_t workspace_bytes, ngp_stream_t stream);
 
 /* vren.composite_test_fw (binding.cpp:166-194, volumerendering.cu:205-285).
  * sigmas,deltas,ts (N_alive,N_samples); rgbs (N_alive,N_samples,3); alive_indices, opacity,
@@ -328,36 +244,12 @@ int ngp_grid_meta_init(ngp_grid_meta* meta, int n_levels, int n_features, int lo
 int ngp_hashgrid_fwd(const float* x, const float* xyz_min, const float* xyz_max,
                      const ngp_half* table, const ngp_grid_meta* meta, int n_samples,
                      ngp_half* feats, ngp_stream_t stream);
-/* Measured alternative for the coarse levels (not used by the default path): the first n_lds_levels levels
- * -- dense, together at most 150 KB of half2: levels 0-2 of the reference configuration -- are gathered from tables RESIDENT IN
- * LDS (one persistent 1024-thread workgroup per CU stages them once).  Writes rows 0 .. n_lds_levels-1 of feats [L][S] half2,
- * bit-identical to ngp_hashgrid_fwd's. */
-int ngp_hashgrid_fwd_lds(const float* x, const float* xyz_min, const float* xyz_max,
-                         const ngp_half* table, const ngp_grid_meta* meta, int n_lds_levels,
-                         int n_samples, ngp_half* feats, ngp_stream_t stream);
 /* Same with a DEVICE-side sample count (sync-free callers): the launch covers n_samples_max,
  * n_dev[0] (i32, <= n_samples_max) is the real count and the level stride of feats. */
 int ngp_hashgrid_fwd_n(const float* x, const float* xyz_min, const float* xyz_max,
                        const ngp_half* table, const ngp_grid_meta* meta, int n_samples_max,
                        const int32_t* n_dev, ngp_half* feats, ngp_stream_t stream);
-/* Diagnostics (host only, no launch): the workgroup map ngp_hashgrid_fwd uses for n_chunks = ceil(n_samples / 256) chunks per
- * level -- every level with a table above 1 MiB whole on one XCD, the small ones in sixteenths (csrc/hashgrid.hip, FwdMap).
- * Writes up to max_blocks triples (xcd, level, chunk), one per workgroup that has work, and returns their number (16 * n_chunks
- * when every (level, chunk) is covered once); 0 when the table uses the pair map. */
-int ngp_debug_hashgrid_fwd_map(const ngp_grid_meta* meta, int n_chunks, int32_t* xcd_level_chunk, int max_blocks);
 
-/* Encode forward over an explicit list of sample ids: work item j < n_list (n_list_max on the host; min(*n_list_dev, n_list_max) if
- * n_list_dev is given) encodes sample list[j] and writes feats[level][list[j]] (level stride n_samples); entries outside
- * [0, n_samples) are padding and skipped.  Per-sample results, independent of the list order. */
-int ngp_hashgrid_fwd_list(const float* x, const float* xyz_min, const float* xyz_max,
-                          const ngp_half* table, const ngp_grid_meta* meta, int n_samples,
-                          const int32_t* list, int n_list_max, const int32_t* n_list_dev,
-                          ngp_half* feats, ngp_stream_t stream);
-/* Encode backward w.r.t. the table: scatter-add of w*dL/dfeat into grad_table (total,2) f16
- * (packed f16 atomics, as tiny-cuda-nn) or f32 when grad_is_f32.  Accumulates (caller zeroes). */
-int ngp_hashgrid_bwd(const float* x, const float* xyz_min, const float* xyz_max,
-                     const ngp_half* dfeats /* [L][S] half2 */, const ngp_grid_meta* meta,
-                     int n_samples, void* grad_table, int grad_is_f32, ngp_stream_t stream);
 
 /* Encode backward w.r.t. the INPUT positions (pose optimisation, train.py:86-89; tiny-cuda-nn computes it
  * when the encoding input requires grad): dL_dx (S,3) f32 = out_scale * sum over levels/features of
@@ -377,10 +269,6 @@ int ngp_hashgrid_bwd_sliced(const float* x, const float* xyz_min, const float* x
                             const ngp_half* dfeats /* [L][S] half2 */, const ngp_grid_meta* meta,
                             int n_samples, const int32_t* active_idx, const int32_t* n_active,
                             ngp_half* grad_table, ngp_stream_t stream);
-/* out[j] = x[idx[j]] for j < n_dev[0] (n_dev NULL: n_max): (S,3) positions of the active samples in compact
- * order, so that the table backward streams them instead of going through the index. */
-int ngp_gather_xyz(const float* x, const int32_t* idx, const int32_t* n_dev, int n_max, float* out,
-                   ngp_stream_t stream);
 
 /* ngp_hashgrid_bwd_sliced with a binning pre-pass: one cheap pass per hashed level writes, per
  * slice, the list of samples whose corners touch it (a sample touches ~4 of a level's 19 slices),
@@ -405,64 +293,8 @@ int ngp_hashgrid_bwd_binned_group(const float* x, const float* xyz_min, const fl
                                   const int32_t* active_idx, const int32_t* n_active,
                                   void* workspace, size_t workspace_bytes, ngp_half* grad_table,
                                   int n_groups, int group, ngp_stream_t stream);
-/* The same backward (one launch group) WITHOUT its last launch: the coarse dense levels, whose lists are split over K tasks, are
- * left as K partial f32 tables each in the workspace, described by *partials_out; grad_table holds the gradient of every OTHER
- * level.  ngp_adam_step_field_merge reads the partials itself (same sums in the same order, the same f16 rounding: the update is
- * bit-identical to merge + ngp_adam_step_field).  The record is valid until the workspace is written again. */
-typedef struct ngp_grid_partials {
-    int32_t n_levels, reserved;                 /* levels 0 .. n_levels-1 (the table's first entries) come as partials */
-    int64_t value_end;                          /* 2 x offset[n_levels]: gradient VALUES below this index are not in grad_table */
-    uint32_t offset[NGP_MAX_LEVELS + 1];        /* entry offsets of those levels */
-    int32_t k_split[NGP_MAX_LEVELS];            /* partial tables per level */
-    int64_t part_off[NGP_MAX_LEVELS];           /* entry offset of level l's first partial table inside `partial` (then + k x size) */
-    const float* partial;                       /* (entries, 2) f32, device */
-} ngp_grid_partials;
-int ngp_hashgrid_bwd_binned_deferred(const float* x, const float* xyz_min, const float* xyz_max,
-                                     const ngp_half* dfeats, const ngp_grid_meta* meta, int n_samples,
-                                     const int32_t* active_idx, const int32_t* n_active,
-                                     void* workspace, size_t workspace_bytes, ngp_half* grad_table,
-                                     ngp_grid_partials* partials_out, ngp_stream_t stream);
-/* _deferred with the Adam update of every level whose gradient is FINAL inside the launch (all but the K-split coarse levels
- * described by *partials_out: the hashed levels, 92 % of the reference table) applied by the slice owners' write-out: parameters
- * (f32 masters grid_param, f16 copies grid_param_h) and moments of those levels are updated in place -- same arithmetic and
- * hyper-parameter forms as ngp_adam_step_field (apex FusedAdam, train.py:131-137; step >= 1 gives the bias corrections,
- * grad_scale the factor the gradient carries), bit-identical to _deferred + ngp_adam_step_field_merge over the whole table.
- * The caller finishes the step with ngp_adam_step_field_merge over the FIRST partials_out->value_end gradient values only
- * (n_grid = value_end) plus the MLP blocks.  grad_table still receives the f16 gradient.  No skip flag: a caller that may have to
- * skip the step (GradScaler, data parallel) uses the separate launches.  Measured on MI355X: slower than the separate launches
- * (a slice owner streams at what one CU sustains and its registers fill the CU); the stepper uses it only under NGP_ADAM_IN_APPLY=1. */
-int ngp_hashgrid_bwd_binned_adam(const float* x, const float* xyz_min, const float* xyz_max,
-                                 const ngp_half* dfeats, const ngp_grid_meta* meta, int n_samples,
-                                 const int32_t* active_idx, const int32_t* n_active,
-                                 void* workspace, size_t workspace_bytes, ngp_half* grad_table,
-                                 ngp_grid_partials* partials_out,
-                                 float* grid_param, ngp_half* grid_param_h, float* grid_m, float* grid_v,
-                                 float lr, float beta1, float beta2, float eps, float weight_decay,
-                                 int step, float grad_scale, ngp_stream_t stream);
 int ngp_hashgrid_bwd_binned_group_entries(const ngp_grid_meta* meta, int n_samples, int n_groups, int group,
                                           int64_t* entry_begin, int64_t* entry_end);
-/* The two passes of the binned backward as separate calls.  Pass 1 (the per-slice sample lists) needs the live samples' positions
- * only, not their gradients: a caller that has the positions before the gradients (the training step: the composite backward lists
- * the live samples, THEN the field backward forms dL/dfeats) runs `_lists` on another stream underneath the field backward and
- * `_owners` (pass 2, [+ merge]; partials_out as in _deferred, may be NULL; n_groups / group as in _group) behind both.  `_lists`
- * lists EVERY live sample -- the one-call forms skip samples whose gradient is exactly zero on a level; a listed zero adds 0 to
- * exact integer sums -- so the gradient table is bit-identical to the one-call forms'. */
-int ngp_hashgrid_bwd_binned_lists(const float* x, const float* xyz_min, const float* xyz_max, const ngp_grid_meta* meta,
-                                  int n_samples, const int32_t* active_idx, const int32_t* n_active,
-                                  void* workspace, size_t workspace_bytes, ngp_stream_t stream);
-int ngp_hashgrid_bwd_binned_owners(const float* x, const float* xyz_min, const float* xyz_max,
-                                   const ngp_half* dfeats, const ngp_grid_meta* meta, int n_samples,
-                                   const int32_t* active_idx, const int32_t* n_active,
-                                   void* workspace, size_t workspace_bytes, ngp_half* grad_table,
-                                   int n_groups, int group, ngp_grid_partials* partials_out, ngp_stream_t stream);
-
-/* The samples that can carry gradient after compositing: the first min(N, total_samples+1) of
- * every ray (later ones have w = 0 exactly, volumerendering.cu:41).  Writes their ids in ray
- * order to active_idx (capacity S) and the count to n_active (device i32); ray_offsets (R) i32
- * receives each ray's offset into the list.  No host sync. */
-int ngp_active_samples(const int64_t* rays_a, const int64_t* total_samples, int n_rays,
-                       int32_t* ray_offsets, int32_t* active_idx, int32_t* n_active,
-                       ngp_stream_t stream);
 /* The fused form used by the trainer: ngp_composite_train_fw emits n_active_per_ray, this call
  * turns it IN PLACE into exclusive offsets (+ the total in n_active), and ngp_composite_train_bw
  * writes the list while it walks the rays anyway. */
@@ -488,25 +320,12 @@ int ngp_active_scan(int32_t* n_active_per_ray, int n_rays, int32_t* n_active, ng
  *      rgbs (S,3) f32 (values rounded through f16 as tiny-cuda-nn emits them). */
 int ngp_density_fwd(const ngp_half* feats, const ngp_half* density_w, int n_samples,
                     float* sigmas, ngp_half* h_out, ngp_stream_t stream);
-int ngp_rgb_fwd(const ngp_half* h, const float* dirs, const ngp_half* rgb_w, int n_samples,
-                float* rgbs, ngp_stream_t stream);
 /* both in ONE kernel: h stays in registers between the two nets and is only stored when h_out
  * is given (training needs it for the backward; inference passes NULL) */
 int ngp_field_fwd(const ngp_half* feats, const float* dirs,
                   const ngp_half* density_w, const ngp_half* rgb_w, int n_samples,
                   float* sigmas, float* rgbs, ngp_half* h_out, ngp_stream_t stream);
-/* same with a device-side sample count (see ngp_hashgrid_fwd_n); n_dev may be NULL */
-int ngp_field_fwd_n(const ngp_half* feats, const float* dirs,
-                    const ngp_half* density_w, const ngp_half* rgb_w, int n_samples_max,
-                    const int32_t* n_dev, float* sigmas, float* rgbs, ngp_half* h_out,
-                    ngp_stream_t stream);
 
-/* ngp_field_fwd over an explicit list of sample ids (see ngp_hashgrid_fwd_list): inputs are read and sigmas / rgbs / h_out written
- * at the listed samples' own places; feats has level stride n_samples. */
-int ngp_field_fwd_list(const ngp_half* feats, const float* dirs,
-                       const ngp_half* density_w, const ngp_half* rgb_w, int n_samples,
-                       const int32_t* list, int n_list_max, const int32_t* n_list_dev,
-                       float* sigmas, float* rgbs, ngp_half* h_out, ngp_stream_t stream);
 
 /* Backward of the two halves.  Each recomputes its forward, runs dgrad in registers and emits
  * per-workgroup partial weight gradients (n_partials, n_params) f32, n_partials =
@@ -522,10 +341,6 @@ int ngp_field_fwd_list(const ngp_half* feats, const float* dirs,
  * ngp_hashgrid_bwd_sliced: inputs and f32 seeds are addressed by sample id, dL_dh / dfeats by
  * compact position.  wgrad_partial must be 16-byte aligned (NGP_EINVAL otherwise; also ngp_mlp_bwd). */
 int ngp_field_bwd_partials(int n_samples);
-int ngp_rgb_bwd(const ngp_half* h, const float* dirs, const ngp_half* rgb_w,
-                const float* dL_drgbs, float loss_scale, int n_samples,
-                const int32_t* active_idx, const int32_t* n_active,
-                ngp_half* dL_dh, float* wgrad_partial, ngp_stream_t stream);
 int ngp_density_bwd(const ngp_half* feats, const ngp_half* density_w, const ngp_half* dL_dh,
                     const float* dL_dsigmas, float loss_scale, int n_samples,
                     const int32_t* active_idx, const int32_t* n_active,
@@ -554,11 +369,6 @@ int ngp_sh4_fwd(const float* dirs01, int n_samples, ngp_half* out, ngp_stream_t 
 int ngp_sh4_bwd(const float* dirs01, const ngp_half* dL_dsh, int n_samples, float out_scale,
                 float* dL_ddirs01, ngp_stream_t stream);
 
-/* Layout converters between the level-major feature layout and tcnn's (S,32) row-major one. */
-int ngp_feats_to_rowmajor(const ngp_half* feats, int n_levels, int n_samples, ngp_half* out,
-                          ngp_stream_t stream);
-int ngp_feats_from_rowmajor(const ngp_half* in, int n_levels, int n_samples, ngp_half* feats,
-                            ngp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * optimizer: apex FusedAdam equivalent (train.py:131, eps 1e-15) fused with AMP plumbing
@@ -572,13 +382,6 @@ int ngp_adam_step(float* param, ngp_half* param_h, void* grad, int grad_is_f32,
                   float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int step, float grad_scale, const int32_t* found_inf,
                   ngp_stream_t stream);
-/* The same update for a parameter block whose gradient is still spread over n_partials rows of
- * per-workgroup partial sums (n_partials, n) f32 (ngp_*_bwd's wgrad_partial): reduces the column
- * and applies Adam in one launch. */
-int ngp_adam_step_partials(float* param, ngp_half* param_h, const float* partials, int n_partials,
-                           float* m, float* v, int n, float lr, float beta1, float beta2, float eps,
-                           float weight_decay, int step, float grad_scale, const int32_t* found_inf,
-                           ngp_stream_t stream);
 /* The optimizer step of the whole field in ONE launch (train.py:131 hands every parameter of the
  * model to one FusedAdam): ngp_adam_step (f16 gradient) on the grid table and
  * ngp_adam_step_partials on the density and rgb MLP blocks, bit-identical to the three separate
@@ -595,18 +398,6 @@ int ngp_adam_step_field(float* grid_param, ngp_half* grid_param_h, ngp_half* gri
                         int n_partials, float lr, float beta1, float beta2, float eps,
                         float weight_decay, int step, float grad_scale, int zero_grid_grad,
                         const int32_t* found_inf, int32_t* step_state, ngp_stream_t stream);
-/* ... with the gradient of the table's first levels taken from the partial tables ngp_hashgrid_bwd_binned_deferred left behind. */
-int ngp_adam_step_field_merge(float* grid_param, ngp_half* grid_param_h, ngp_half* grid_grad,
-                              float* grid_m, float* grid_v, int64_t n_grid,
-                              float* density_param, ngp_half* density_param_h,
-                              const float* density_partials, float* density_m, float* density_v,
-                              int n_density,
-                              float* rgb_param, ngp_half* rgb_param_h, const float* rgb_partials,
-                              float* rgb_m, float* rgb_v, int n_rgb,
-                              int n_partials, float lr, float beta1, float beta2, float eps,
-                              float weight_decay, int step, float grad_scale,
-                              const int32_t* found_inf, int32_t* step_state, const ngp_grid_partials* partials,
-                              ngp_stream_t stream);
 /* step_state (may be NULL: `step` is the bias-correction step, as everywhere else): 4 x i32 on the device holding the number of
  * APPLIED steps -- {MLP blocks: slot 0, slot 1; grid block: slot 0, slot 1}, zeroed (or set to the steps already taken) by the
  * caller once.  With it `step` is the 1-based number of this CALL: the launch reads slot (step - 1) & 1, corrects the bias for
@@ -721,12 +512,6 @@ int ngp_get_rays(const float* directions, const float* c2w, int n, float* rays_o
 
 /* ---- occupancy-grid maintenance -------------------------------------------------------- */
 
-/* density-only forward whose sigma of sample s is stored at sigmas_out[scatter_idx[s]]
- * (`density_grid_tmp[c, indices] = self.density(xyzs_w)`, networks.py:256-258).  Duplicate indices: the LARGEST value
- * survives (an integer max on the non-negative floats' bit patterns: deterministic; index_put keeps one of them, unspecified
- * on CUDA).  sigmas_out must be zero-filled by the caller. */
-int ngp_density_fwd_scatter(const ngp_half* feats, const ngp_half* density_w, int n_samples,
-                            const int32_t* scatter_idx, float* sigmas_out, ngp_stream_t stream);
 
 /* NGP.update_density_grid (networks.py:240-269 with get_all_cells :155-167 and
  * sample_uniform_and_occupied_cells :169-195) in one call, no host sync:
@@ -739,32 +524,12 @@ int ngp_density_fwd_scatter(const ngp_half* feats, const ngp_half* density_w, in
  * decay_grid (C, G^3) f32 per-cell decay or NULL (erode, networks.py:262-264); seed keys the
  * counter-based RNG (pass the step number).  workspace: ngp_occupancy_update_workspace_bytes. */
 size_t ngp_occupancy_update_workspace_bytes(int cascades, int grid_size);
-/* Where an update leaves what it evaluated, as byte offsets into the workspace (diagnostics / tests: which cells were drawn, at
- * which jittered positions, with which density): tmp (C, G^3) f32 = sigma scattered by cell index; cell_idx (n) i32 and
- * xyzs (n,3) f32 of the LAST cascade in evaluation order (n = G^3 in warm-up, G^3 / 2 otherwise). */
-int ngp_occupancy_update_workspace_layout(int cascades, int grid_size, size_t* tmp_off, size_t* cell_idx_off, size_t* xyzs_off);
 int ngp_occupancy_update(float* density_grid, uint8_t* density_bitfield, int cascades, int grid_size,
                          float scale, float density_threshold, float decay, const float* decay_grid,
                          int warmup, uint64_t seed,
                          const float* xyz_min, const float* xyz_max, const ngp_half* table,
                          const ngp_grid_meta* meta, const ngp_half* density_w,
                          void* workspace, size_t workspace_bytes, ngp_stream_t stream);
-/* The same update (not warm-up, one cascade: NGP_EUNSUP otherwise) in two calls.  ngp_occupancy_draw = everything that depends
- * only on the occupancy grid as the PREVIOUS update left it and on the seed: scratch clear, occupancy words, the 2 x G^3/4 draws,
- * their regrouping and jittered positions (7 of the update's launches, ~0.09 ms).  It may run any time after the previous update
- * is complete -- on another stream, underneath the 15 training steps in between (train.py:160-163 updates every 16th) -- as long
- * as nothing else writes density_grid or the workspace until ngp_occupancy_update_drawn (same grid, threshold, seed, workspace)
- * has finished the update behind it: field forward at the drawn positions, merge, mean, packing.  Same launches, same inputs:
- * the two calls leave exactly what ngp_occupancy_update(warmup = 0) leaves. */
-int ngp_occupancy_draw(const float* density_grid, int cascades, int grid_size, float scale, float density_threshold,
-                       uint64_t seed, void* workspace, size_t workspace_bytes, ngp_stream_t stream);
-int ngp_occupancy_update_drawn(float* density_grid, uint8_t* density_bitfield, int cascades, int grid_size,
-                               float scale, float density_threshold, float decay, const float* decay_grid,
-                               uint64_t seed,
-                               const float* xyz_min, const float* xyz_max, const ngp_half* table,
-                               const ngp_grid_meta* meta, const ngp_half* density_w,
-                               void* workspace, size_t workspace_bytes, ngp_stream_t stream);
-
 /* ---- test-time frame loop -------------------------------------------------------------- */
 
 /* The whole test-time loop `__render_rays_test` (rendering.py:46-118) for one batch of rays,
@@ -894,8 +659,6 @@ int ngp_stepper_march(ngp_stepper* s, const float* rays_o, const float* rays_d, 
 int ngp_stepper_pending(const ngp_stepper* s, const float* rays_o, const float* rays_d);
 /* Which of the two march record sets (hits_t / rays_a / noise / scratch / counter) the last front() consumed: 0 or 1. */
 int ngp_stepper_last_set(const ngp_stepper* s);
-/* Did the last front() evaluate the field in two rounds? (1 / 0) */
-int ngp_stepper_two_rounds(const ngp_stepper* s);
 /* sizeof(ngp_stepper_config) (which = 0) / sizeof(ngp_step_buffers) (which = 1) as this library was compiled: a binding that
  * mirrors the records (ctypes, cgo ...) checks its own layout against them before it hands one over. */
 int ngp_stepper_record_bytes(int which);

@@ -9,7 +9,9 @@ import ctypes as C
 import os
 import re
 
-HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "ngp_hip.h")
+HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "ngp_hip.h")        # the drop-in boundary
+# library-internal entry points (cross-translation-unit launchers, white-box test hooks): exported, declared apart, same conventions
+INTERNAL_HEADER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "ngp_internal.h")
 
 _SCALARS = {
     "int": C.c_int, "int32_t": C.c_int32, "uint32_t": C.c_uint32, "int64_t": C.c_int64, "uint64_t": C.c_uint64,
@@ -74,6 +76,7 @@ class Proto:
 def parse(path=HEADER):
     """name -> Proto for every function declared in the header, as a compiler would see them."""
     text = open(path).read()
+    text = re.sub(r'^\s*#include[^\n]*', " ", text, flags=re.M)
     body = _strip_blocks(strip_comments(text))
     # `extern "C"` wrapper braces were removed together with their (unbalanced across #ifdef) partners: what is left between
     # semicolons is typedefs and prototypes
@@ -97,6 +100,15 @@ def parse(path=HEADER):
             raise ValueError("%s declared twice in %s" % (name, path))
         protos[name] = Proto(ret, name, params)
     return protos
+
+
+def parse_all():
+    """Public and internal prototypes together (what libngp_hip.so exports); a name may only be declared in one of the two."""
+    pub, internal = parse(HEADER), parse(INTERNAL_HEADER)
+    both = set(pub) & set(internal)
+    if both:
+        raise ValueError("declared in both headers: %s" % sorted(both))
+    return {**pub, **internal}
 
 
 def ctypes_agrees(argtypes, proto):

@@ -74,7 +74,6 @@ _PROTOS = {
     "ngp_packbits": [P, I, I, F, P, P],
     "ngp_density_grid_update": [P, P, P, F, I, P, P],
     "ngp_packbits_auto": [P, I, P, F, P, P],
-    "ngp_cells_to_xyz": [P, P, I, I, F, P, P],
     "ngp_raymarching_train_count": [P, P, P, P, I, F, F, P, I, I, I, P, P, P, P],
     "ngp_raymarching_train_write": [P, P, P, P, F, F, I, I, I, P, P, P, P, P],
     "ngp_raymarching_train_write_k": [P, P, P, P, F, F, I, I, I, P, P, P, P, I, P, P, P],
@@ -100,14 +99,11 @@ _PROTOS = {
     "ngp_hashgrid_fwd": [P, P, P, P, C.POINTER(GridMeta), I, P, P],
     "ngp_hashgrid_fwd_list": [P, P, P, P, C.POINTER(GridMeta), I, P, I, P, P, P],
     "ngp_field_fwd_list": [P, P, P, P, I, P, I, P, P, P, P, P],
-    "ngp_hashgrid_fwd_lds": [P, P, P, P, C.POINTER(GridMeta), I, I, P, P],
     "ngp_hashgrid_bwd": [P, P, P, P, C.POINTER(GridMeta), I, P, I, P],
     "ngp_hashgrid_bwd_sliced": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P, P],
     "ngp_active_samples": [P, P, I, P, P, P, P],
     "ngp_density_fwd": [P, P, I, P, P, P],
-    "ngp_rgb_fwd": [P, P, P, I, P, P],
     "ngp_field_fwd": [P, P, P, P, I, P, P, P, P],
-    "ngp_rgb_bwd": [P, P, P, P, F, I, P, P, P, P, P],
     "ngp_density_bwd": [P, P, P, P, F, I, P, P, P, P, P],
     "ngp_field_bwd_partials": [I],
     "ngp_field_bwd": [P, P, P, P, P, P, P, F, I, P, P, P, P, P, P],
@@ -172,21 +168,14 @@ _PROTOS = {
     "ngp_stepper_stage_times": [P, C.POINTER(C.c_float)],
     "ngp_hashgrid_fwd_n": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P],
     "ngp_field_fwd_n": [P, P, P, P, I, P, P, P, P, P],
-    "ngp_gather_xyz": [P, P, P, I, P, P],
     "ngp_hashgrid_bwd_binned": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P, C.c_size_t, P, P],
     "ngp_hashgrid_bwd_binned_group": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P, C.c_size_t, P, I, I, P],
-    "ngp_hashgrid_bwd_binned_adam": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P, C.c_size_t, P, C.POINTER(GridPartials), P, P, P, P,
-                                     F, F, F, F, F, I, F, P],
-    "ngp_hashgrid_bwd_binned_lists": [P, P, P, C.POINTER(GridMeta), I, P, P, P, C.c_size_t, P],
-    "ngp_hashgrid_bwd_binned_owners": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P, C.c_size_t, P, I, I, C.POINTER(GridPartials), P],
     "ngp_hashgrid_bwd_binned_group_entries": [C.POINTER(GridMeta), I, I, I, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     "ngp_hashgrid_bwd_input": [P, P, P, P, P, C.POINTER(GridMeta), I, F, P, P],
     "ngp_sh4_bwd": [P, P, I, F, P, P],
     "ngp_density_fwd_scatter": [P, P, I, P, P, P],
     "ngp_occupancy_update_workspace_layout": [I, I, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],
     "ngp_occupancy_update": [P, P, I, I, F, F, F, P, I, C.c_uint64, P, P, P, C.POINTER(GridMeta), P, P, C.c_size_t, P],
-    "ngp_occupancy_draw": [P, I, I, F, F, C.c_uint64, P, C.c_size_t, P],
-    "ngp_occupancy_update_drawn": [P, P, I, I, F, F, F, P, C.c_uint64, P, P, P, C.POINTER(GridMeta), P, P, C.c_size_t, P],
     "ngp_render_test_frame": [P, P, P, P, I, F, F, I, I, F, P, P, P, C.POINTER(GridMeta), P, P, I, I, I,
                               C.POINTER(C.c_float), P, C.c_size_t, P, P, P, P, C.POINTER(C.c_int32), P],
 }

@@ -1,7 +1,7 @@
 // The Adam update of ONE parameter, shared by every kernel that applies it to the hash table (optim.hip: the streaming kernels;
 // hashgrid_bwd_binned.hip: the slice owners' write-out), so that they agree bit for bit: one expression tree, one set of compiler
-// decisions.  Semantics: apex FusedAdam as the reference configures it (/root/reference/train.py:131-137; adam_w_mode = False:
-// L2 regularisation folded into the update), bias corrections bc1 = 1 - beta1^t, bc2 = 1 - beta2^t.
+// decisions.  Semantics: apex FusedAdam as the reference configures it (/root/reference/train.py:131-137; adam_w_mode = True,
+// apex's default: DECOUPLED weight decay, p -= lr * wd * p next to the Adam term; optim.py refuses adam_w_mode=False), bias corrections bc1 = 1 - beta1^t, bc2 = 1 - beta2^t.
 #pragma once
 
 struct AdamCoef { float lr, beta1, beta2, eps, wd, bc1, bc2, inv_scale; };

@@ -99,54 +99,16 @@ __device__ __forceinline__ void cell_of(const float* __restrict__ x, const Box& 
     }
 }
 
-// The 8 corner values of a cell.  On a hashed level the corners (x, y', z') and (x+1, y', z') have the indices (x ^ h) & mask and
-// ((x+1) ^ h) & mask with the same h: for EVEN x they differ in bit 0 only, i.e. they are the two halves of one aligned 8-byte pair
-// of the table, and one 8-byte load per lane fetches both; for odd x the carry sends x+1 somewhere else and the second corner is
-// loaded on its own -- under the lane mask, by the odd lanes only: 4 + 4/2 = 6 lane addresses per cell on average instead of 8.
-// Same table entries, same values: bit-identical (tests/test_field_gpu.py ran green on it).  MEASURED AND NOT KEPT (round 4,
-// tools/r04_call20.sh, same box, alternating runs): the training step's forward 0.0598 / 0.0604 ms -> 0.0715 / 0.0711 ms, the step
-// 0.3651 / 0.3623 -> 0.3763 / 0.3765 ms.  An 8-byte gather costs the vector memory path more than the 4-byte one it replaces plus
-// the half-masked one it saves: what is charged is not the lane address alone.  -DNGP_FWD_PAIR=1 builds it.
-// (Level offsets are multiples of 8 entries and the table is 16-byte aligned: an even index is an 8-byte aligned address.)
-#ifndef NGP_FWD_PAIR
-#define NGP_FWD_PAIR 0
-#endif
-typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+// The 8 corner values of a cell: 8 independent 4-byte gathers.  (Fetching the x-neighbour pairs of a hashed level as one aligned 8-byte
+// gather -- 6 lane addresses per cell instead of 8 -- was built and measured in round 4: forward 0.060 -> 0.071 ms, not kept;
+// profiles/r04_step_ab.txt (c).)
 template <bool HASHED>
 __device__ __forceinline__ void gather_corners(const half2_t* __restrict__ tab, const uint32_t (&p)[3], uint32_t res, uint32_t size,
                                                half2_t (&v)[8]) {
-    if (HASHED && NGP_FWD_PAIR) {
-        const uint32_t mask = size - 1u;
-        const uint32_t hy0 = p[1] * PRIME_Y, hz0 = p[2] * PRIME_Z;
-        const uint32_t hy[2] = {hy0, hy0 + PRIME_Y}, hz[2] = {hz0, hz0 + PRIME_Z};
-        uint32_t i0[4], i1[4];
-        half4_t pr[4];
+    uint32_t idx[8];
+    corner_indices<HASHED>(p, res, size, idx);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t h = hy[k & 1] ^ hz[k >> 1];
-            i0[k] = (p[0] ^ h) & mask; i1[k] = ((p[0] + 1u) ^ h) & mask;
-            pr[k] = *reinterpret_cast<const half4_t*>(tab + (i0[k] & ~1u));
-        }
-        half2_t far[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { far[k][0] = (_Float16)0; far[k][1] = (_Float16)0; }
-        if (p[0] & 1u) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) far[k] = tab[i1[k]];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            half2_t lo, hi; lo[0] = pr[k][0]; lo[1] = pr[k][1]; hi[0] = pr[k][2]; hi[1] = pr[k][3];
-            const bool up = i0[k] & 1u;
-            v[2 * k] = up ? hi : lo;
-            v[2 * k + 1] = (p[0] & 1u) ? far[k] : (up ? lo : hi);
-        }
-    } else {
-        uint32_t idx[8];
-        corner_indices<HASHED>(p, res, size, idx);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = tab[idx[c]];
-    }
+    for (int c = 0; c < 8; ++c) v[c] = tab[idx[c]];
 }
 
 template <bool HASHED>
@@ -177,7 +139,7 @@ template <int SPT>
 __global__ void __launch_bounds__(256)
 hashgrid_fwd_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const float* __restrict__ xyz_max,
                     const half2_t* __restrict__ table, GridMeta meta, int n_samples, int n_chunks,
-                    const int32_t* __restrict__ n_dev, half2_t* __restrict__ feats, uint32_t reuse_max_res, FwdMap fmap) {
+                    const int32_t* __restrict__ n_dev, half2_t* __restrict__ feats, FwdMap fmap) {
     int level, chunk;
     if (fmap.blocks_per_xcd > 0) { if (!map_block_weighted(fmap, n_chunks, level, chunk)) return; }
     else if (!map_block(meta.n_levels, n_chunks, level, chunk)) return;
@@ -193,7 +155,8 @@ hashgrid_fwd_kernel(const float* __restrict__ x, const float* __restrict__ xyz_m
     const Box box = load_box(xyz_min, xyz_max);
     const bool hashed = level_is_hashed(res, size);
     const float scale = meta.scale[level];
-    if (SPT == 1 && res <= reuse_max_res) {                                   // (wave-uniform)
+    static_assert(SPT == 1, "one sample per thread: 2 or 4 measured the same (the kernel is bound by gather transactions)");
+    {
         const int i = chunk * 256 + threadIdx.x, lane = threadIdx.x & 63;
         const bool ok = i < n_samples;
         uint32_t p[3]; float f[3];
@@ -216,102 +179,6 @@ hashgrid_fwd_kernel(const float* __restrict__ x, const float* __restrict__ xyz_m
             const float w = corner_weight(c, f);
             o0 = fmaf(w, (float)u[0], o0);
             o1 = fmaf(w, (float)u[1], o1);
-        }
-        half2_t out; out[0] = (_Float16)o0; out[1] = (_Float16)o1;
-        if (ok) __builtin_nontemporal_store(out, feats + (size_t)level * n_samples + i);
-        return;
-    }
-    float f[SPT][3]; bool ok[SPT];
-    half2_t v[SPT][8];
-#pragma unroll
-    for (int k = 0; k < SPT; ++k) {
-        const int i = (chunk * SPT + k) * 256 + threadIdx.x;
-        ok[k] = i < n_samples;
-        uint32_t p[3];
-        cell_of(x, box, (size_t)(ok[k] ? i : 0), scale, p, f[k]);
-        if (hashed) gather_corners<true>(tab, p, res, size, v[k]);
-        else gather_corners<false>(tab, p, res, size, v[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < SPT; ++k) {
-        float o0 = 0.f, o1 = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float w = corner_weight(c, f[k]);
-            o0 = fmaf(w, (float)v[k][c][0], o0);
-            o1 = fmaf(w, (float)v[k][c][1], o1);
-        }
-        const int i = (chunk * SPT + k) * 256 + threadIdx.x;
-        half2_t out; out[0] = (_Float16)o0; out[1] = (_Float16)o1;
-        if (ok[k]) __builtin_nontemporal_store(out, feats + (size_t)level * n_samples + i);
-    }
-}
-
-
-// Device-sized launches (the test-time frame loop: the sample count is device state, the launch is sized for a bound) as
-// PERSISTENT workgroups under the cost-balanced map: 8 x wgs_per_xcd workgroups, the ones of XCD k stride over that XCD's
-// (level, chunk) tasks, whose number they work out themselves from the real count -- no workgroup is launched just to find its
-// chunk beyond the count (under the per-chunk launch those cost the balanced map more than it gained, see FwdMap), and the map's
-// scalar arithmetic is paid once per workgroup instead of once per chunk.  Cell runs as in hashgrid_fwd_kernel; same bits.
-struct FwdPieces { uint32_t piece[8][16]; };            // level << 16 | phase mask, in the order an XCD takes them; 0 = unused
-
-__global__ void __launch_bounds__(256)
-hashgrid_fwd_persist_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const float* __restrict__ xyz_max,
-                            const half2_t* __restrict__ table, GridMeta meta, int n_bound, const int32_t* __restrict__ n_dev,
-                            half2_t* __restrict__ feats, FwdPieces fp, int wgs_per_xcd) {
-    const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
-    const int n_samples = n_dev != nullptr ? min(*n_dev, n_bound) : n_bound;
-    if (n_samples <= 0) return;
-    const int n_chunks = (n_samples + 255) >> 8, full = n_chunks >> 4;
-    const uint32_t low = (1u << (n_chunks & 15)) - 1u;
-    uint32_t pc[16]; int e[16];
-    int total = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        pc[j] = fp.piece[xcd][j];
-        const uint32_t mk = pc[j] & 0xFFFFu;
-        total += full * __builtin_popcount(mk) + __builtin_popcount(mk & low);
-        e[j] = total;
-    }
-    const Box box = load_box(xyz_min, xyz_max);
-    const int lane = threadIdx.x & 63;
-    for (int q = w; q < total; q += wgs_per_xcd) {
-        int begin = 0; uint32_t mine = pc[0];
-#pragma unroll
-        for (int j = 1; j < 16; ++j) if (q >= e[j - 1]) { begin = e[j - 1]; mine = pc[j]; }
-        const uint32_t mk = mine & 0xFFFFu;
-        const int per = __builtin_popcount(mk), ql = q - begin;
-        const int quot = ql / per, period = quot < full ? quot : full, r = ql - period * per;
-        uint32_t t = mk;
-        for (int k = 0; k < r; ++k) t &= t - 1u;
-        const int level = (int)(mine >> 16), chunk = period * 16 + (int)__builtin_ctz(t);
-        const uint32_t res = meta.resolution[level];
-        const uint32_t size = meta.offset[level + 1] - meta.offset[level];
-        const half2_t* __restrict__ tab = table + meta.offset[level];
-        const bool hashed = level_is_hashed(res, size);
-        const float scale = meta.scale[level];
-        const int i = chunk * 256 + threadIdx.x;
-        const bool ok = i < n_samples;
-        uint32_t p[3]; float f[3];
-        cell_of(x, box, (size_t)(ok ? i : n_samples - 1), scale, p, f);
-        const uint32_t q0 = __shfl_up(p[0], 1, 64), q1 = __shfl_up(p[1], 1, 64), q2 = __shfl_up(p[2], 1, 64);
-        const bool first = lane == 0 || p[0] != q0 || p[1] != q1 || p[2] != q2;
-        const unsigned long long firsts = __ballot(first);
-        const int src = 63 - __builtin_clzll(firsts & ((2ull << lane) - 1ull));
-        half2_t v[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) { v[c][0] = (_Float16)0; v[c][1] = (_Float16)0; }
-        if (first) {
-            if (hashed) gather_corners<true>(tab, p, res, size, v);
-            else gather_corners<false>(tab, p, res, size, v);
-        }
-        float o0 = 0.f, o1 = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const half2_t u = lane_read(v[c], src);
-            const float wgt = corner_weight(c, f);
-            o0 = fmaf(wgt, (float)u[0], o0);
-            o1 = fmaf(wgt, (float)u[1], o1);
         }
         half2_t out; out[0] = (_Float16)o0; out[1] = (_Float16)o1;
         if (ok) __builtin_nontemporal_store(out, feats + (size_t)level * n_samples + i);
@@ -374,50 +241,9 @@ hashgrid_fwd_list_kernel(const float* __restrict__ x, const float* __restrict__ 
 }
 
 
-// ---- coarse levels with their tables RESIDENT IN LDS (north_star: "8-corner trilinear gather staged through LDS") ----------
-// Levels 0 .. n_lds-1 of the reference configuration are dense and small (16^3, 22^3, 28^3 entries: 16 + 43 + 88 = 147 KB of
-// half2, inside one CU's 160 KB): a persistent 1024-thread workgroup per CU copies them into LDS once and serves every gather
-// of those levels from there (ds_read_b32 instead of the texture addresser + L2).  Same arithmetic as hashgrid_fwd_kernel,
-// bit-identical features.  Measured against the L2 path in profiles/r02_hashgrid_fwd_lds_experiment.txt.
-__global__ void __launch_bounds__(1024)
-hashgrid_fwd_lds_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const float* __restrict__ xyz_max,
-                        const half2_t* __restrict__ table, GridMeta meta, int n_lds, int n_samples, int feat_stride,
-                        half2_t* __restrict__ feats) {
-    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    half2_t* tab = reinterpret_cast<half2_t*>(lds_raw);
-    const uint32_t total = meta.offset[n_lds];
-    {   // 16-byte staging loads; the level tables are contiguous and 8-entry aligned
-        const uint4* src = reinterpret_cast<const uint4*>(table);
-        uint4* dst = reinterpret_cast<uint4*>(lds_raw);
-        for (uint32_t k = threadIdx.x; k < total / 4; k += blockDim.x) dst[k] = src[k];
-    }
-    __syncthreads();
-    const Box box = load_box(xyz_min, xyz_max);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_samples; i += gridDim.x * blockDim.x) {
-        const float xin[3] = {__builtin_nontemporal_load(x + 3 * (size_t)i), __builtin_nontemporal_load(x + 3 * (size_t)i + 1),
-                              __builtin_nontemporal_load(x + 3 * (size_t)i + 2)};
-        for (int level = 0; level < n_lds; ++level) {
-            const uint32_t res = meta.resolution[level];
-            const uint32_t size = meta.offset[level + 1] - meta.offset[level];
-            uint32_t p[3], idx[8]; float f[3];
-            cell_of_loaded(xin, box, meta.scale[level], p, f);
-            corner_indices<false>(p, res, size, idx);
-            const half2_t* __restrict__ t = tab + meta.offset[level];
-            half2_t v[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] = t[idx[c]];
-            float o0 = 0.f, o1 = 0.f;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float w = corner_weight(c, f);
-                o0 = fmaf(w, (float)v[c][0], o0);
-                o1 = fmaf(w, (float)v[c][1], o1);
-            }
-            half2_t out; out[0] = (_Float16)o0; out[1] = (_Float16)o1;
-            __builtin_nontemporal_store(out, feats + (size_t)level * feat_stride + i);
-        }
-    }
-}
+// (Coarse levels served from tables RESIDENT IN LDS -- north_star's "gather staged through LDS" -- were built and measured in round 2:
+// 147 KB of half2 for levels 0-2 in one CU's LDS, a persistent 1024-thread workgroup per CU; slower than the L2 path, which already
+// hits 93 % on those tables and keeps 8 workgroups per CU in flight.  profiles/r02_hashgrid_fwd_lds_experiment.txt; removed in round 5.)
 
 // ---- backward w.r.t. the input positions (pose optimisation, train.py:86-89,117-122) -------------
 // tiny-cuda-nn's grid backward-input for linear interpolation: d feat / d pos_k =
@@ -735,18 +561,6 @@ active_write_kernel(const int64_t* __restrict__ rays_a, const int64_t* __restric
     for (int k = lane; k < na; k += 64) active[off + k] = start + k;
 }
 
-// x_out[j] = x[idx[j]], j < *n_dev: positions of the active samples in compact order, so the table backward reads
-// them as a stream instead of through the index (one dependent load less per sample in its scan loops)
-__global__ void __launch_bounds__(256)
-gather_xyz_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx, const int32_t* __restrict__ n_dev, int n_max,
-                  float* __restrict__ out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = n_dev ? min(*n_dev, n_max) : n_max;
-    if (j >= n) return;
-    const size_t s = (size_t)idx[j];
-    out[3 * (size_t)j] = x[3 * s]; out[3 * (size_t)j + 1] = x[3 * s + 1]; out[3 * (size_t)j + 2] = x[3 * s + 2];
-}
-
 __global__ void __launch_bounds__(256)
 feats_to_rowmajor_kernel(const half2_t* __restrict__ feats, int n_levels, int n_samples, half2_t* __restrict__ out) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over (sample, level), level fastest
@@ -768,16 +582,14 @@ feats_from_rowmajor_kernel(const half2_t* __restrict__ in, int n_levels, int n_s
 // across XCDs by weight alone was measured: 54 -> 94..335 us, three 2 MiB tables per L2), so those levels go whole to the least
 // loaded XCD, most expensive first; the small dense levels, whose tables fit any L2 many times over, are dealt out in sixteenths
 // to fill the XCDs up to the same load.
-FwdMap make_fwd_map(const ngp_grid_meta* meta, int n_chunks, bool exact, FwdPieces* pieces = nullptr) {
+FwdMap make_fwd_map(const ngp_grid_meta* meta, int n_chunks, bool exact) {
     FwdMap m;
-    if (pieces) for (int k = 0; k < 8; ++k) for (int j = 0; j < 16; ++j) pieces->piece[k][j] = 0u;
     uint16_t mask[8][NGP_MAX_LEVELS];
     for (int k = 0; k < 8; ++k) for (int l = 0; l < NGP_MAX_LEVELS; ++l) mask[k][l] = 0;
     for (int k = 0; k < 8; ++k) for (int j = 0; j < 16; ++j) { m.end[k][j] = 0; m.piece[k][j] = 1u; m.magic[k][j] = 0xFFFFFFFFu; }
     m.blocks_per_xcd = 0;
-    static const int mode = [] { const char* e = getenv("NGP_FWD_MAP"); return (e && strcmp(e, "pairs") == 0) ? 0 : 1; }();
-    static const float small_cost = [] { const char* e = getenv("NGP_FWD_SMALL_COST"); return e ? (float)atof(e) : 16.0f; }();
-    if (mode == 0 || !exact || meta->n_levels < 8) return m;
+    const float small_cost = 16.0f;
+    if (!exact || meta->n_levels < 8) return m;
     float load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool big[NGP_MAX_LEVELS], done[NGP_MAX_LEVELS];
     float cost[NGP_MAX_LEVELS];
@@ -812,7 +624,6 @@ FwdMap make_fwd_map(const ngp_grid_meta* meta, int n_chunks, bool exact, FwdPiec
             const int per = __builtin_popcount(mask[k][l]);
             cnt += full * per + __builtin_popcount(mask[k][l] & low);
             m.end[k][j] = cnt; m.piece[k][j] = ((uint32_t)l << 16) | mask[k][l];
-            if (pieces) pieces->piece[k][j] = m.piece[k][j];
             m.magic[k][j] = per == 1 ? 0xFFFFFFFFu : (uint32_t)(((1ull << 32) + per - 1) / per);
             ++j;
         }
@@ -859,32 +670,6 @@ int ngp_grid_meta_init(ngp_grid_meta* meta, int n_levels, int n_features, int lo
     return 0;
 }
 
-int ngp_hashgrid_fwd_lds(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* table,
-                         const ngp_grid_meta* meta, int n_lds_levels, int n_samples, ngp_half* feats, ngp_stream_t stream) {
-    if (n_samples < 0 || !meta || meta->n_features != 2 || n_lds_levels < 1 || n_lds_levels > meta->n_levels) return NGP_EINVAL;
-    if (n_samples == 0) return 0;
-    NGP_CHECK_PTR(x); NGP_CHECK_PTR(xyz_min); NGP_CHECK_PTR(xyz_max); NGP_CHECK_PTR(table); NGP_CHECK_PTR(feats);
-    const size_t bytes = (size_t)meta->offset[n_lds_levels] * 4;
-    if (bytes > 150 * 1024 || (meta->offset[n_lds_levels] & 3)) return NGP_EUNSUP;                    // must fit one CU's LDS next to nothing else
-    for (int l = 0; l < n_lds_levels; ++l) {
-        const uint64_t res = meta->resolution[l];
-        if (res * res * res > meta->offset[l + 1] - meta->offset[l]) return NGP_EUNSUP;               // dense levels only
-    }
-    static bool attr_set[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    dev &= 63;
-    if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hashgrid_fwd_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set[dev] = true;
-    }
-    const int blocks = ngp_div_up(n_samples, 1024) < 256 ? ngp_div_up(n_samples, 1024) : 256;
-    hipLaunchKernelGGL(hashgrid_fwd_lds_kernel, dim3(blocks), dim3(1024), bytes, ngp_stream(stream), x, xyz_min, xyz_max, (const half2_t*)table,
-                       to_dev_meta(meta), n_lds_levels, n_samples, n_samples, (half2_t*)feats);
-    return NGP_LAUNCH_RESULT();
-}
-
 int ngp_hashgrid_fwd(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* table,
                      const ngp_grid_meta* meta, int n_samples, ngp_half* feats, ngp_stream_t stream) {
     return ngp_hashgrid_fwd_n(x, xyz_min, xyz_max, table, meta, n_samples, nullptr, feats, stream);
@@ -899,31 +684,17 @@ int ngp_hashgrid_fwd_n(const float* x, const float* xyz_min, const float* xyz_ma
     // SPT = 1: measured on MI355X, 2 or 4 samples per thread change nothing (57 / 55 / 57 us at 303 k coherent samples):
     // the kernel is bound by L2 gather transactions, not by loads in flight per lane.
     const int n_chunks = ngp_div_up(n_samples, 256);
-    // cell runs (see hashgrid_fwd_kernel): levels up to this resolution gather once per run of lanes in one cell
-    static const uint32_t reuse_max_res = [] { const char* e = getenv("NGP_FWD_REUSE_MAX_RES"); return e ? (uint32_t)atoi(e) : 1u << 30; }();
-    // device-sized launches: persistent workgroups under the balanced map (NGP_FWD_PERSIST=0: one workgroup per chunk, pair map)
-    static const int persist = [] { const char* e = getenv("NGP_FWD_PERSIST"); return e ? atoi(e) : 0; }();
-    if (n_dev != nullptr && persist > 0 && reuse_max_res >= (1u << 30)) {
-        FwdPieces fp;
-        const FwdMap pm = make_fwd_map(meta, n_chunks, true, &fp);
-        if (pm.blocks_per_xcd > 0) {
-            const int wgs = persist > 1 ? persist : 256;               // per XCD: 8 per CU
-            hipLaunchKernelGGL(hashgrid_fwd_persist_kernel, dim3(8 * wgs), dim3(256), 0, ngp_stream(stream),
-                               x, xyz_min, xyz_max, (const half2_t*)table, to_dev_meta(meta), n_samples, n_dev, (half2_t*)feats, fp, wgs);
-            return NGP_LAUNCH_RESULT();
-        }
-    }
     const FwdMap fmap = make_fwd_map(meta, n_chunks, n_dev == nullptr);
     const int n_blocks = fmap.blocks_per_xcd > 0 ? 8 * fmap.blocks_per_xcd : n_blocks_for(meta->n_levels, n_chunks);
     hipLaunchKernelGGL(hashgrid_fwd_kernel<1>, dim3(n_blocks), dim3(256), 0, ngp_stream(stream),
-                       x, xyz_min, xyz_max, (const half2_t*)table, to_dev_meta(meta), n_samples, n_chunks, n_dev, (half2_t*)feats, reuse_max_res, fmap);
+                       x, xyz_min, xyz_max, (const half2_t*)table, to_dev_meta(meta), n_samples, n_chunks, n_dev, (half2_t*)feats, fmap);
     return NGP_LAUNCH_RESULT();
 }
 
 int ngp_debug_hashgrid_fwd_map(const ngp_grid_meta* meta, int n_chunks, int32_t* xcd_level_chunk, int max_blocks) {
     if (!meta || n_chunks < 1 || max_blocks < 0 || (max_blocks > 0 && !xcd_level_chunk)) return NGP_EINVAL;
     const FwdMap m = make_fwd_map(meta, n_chunks, true);
-    if (m.blocks_per_xcd <= 0) return 0;                            // the pair map is in use for this table (or NGP_FWD_MAP=pairs)
+    if (m.blocks_per_xcd <= 0) return 0;                            // the pair map is in use for this table
     const int n_blocks = 8 * m.blocks_per_xcd;
     int n = 0;
     for (int b = 0; b < n_blocks; ++b) {
@@ -960,14 +731,6 @@ int ngp_hashgrid_bwd_input(const float* x, const float* xyz_min, const float* xy
     return NGP_LAUNCH_RESULT();
 }
 
-int ngp_gather_xyz(const float* x, const int32_t* idx, const int32_t* n_dev, int n_max, float* out, ngp_stream_t stream) {
-    if (n_max < 0) return NGP_EINVAL;
-    if (n_max == 0) return 0;
-    NGP_CHECK_PTR(x); NGP_CHECK_PTR(idx); NGP_CHECK_PTR(out);
-    hipLaunchKernelGGL(gather_xyz_kernel, dim3(ngp_div_up(n_max, 256)), dim3(256), 0, ngp_stream(stream), x, idx, n_dev, n_max, out);
-    return NGP_LAUNCH_RESULT();
-}
-
 int ngp_hashgrid_bwd(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* dfeats,
                      const ngp_grid_meta* meta, int n_samples, void* grad_table, int grad_is_f32,
                      ngp_stream_t stream) {
@@ -993,9 +756,7 @@ int ngp_hashgrid_bwd_sliced(const float* x, const float* xyz_min, const float* x
     if (n_samples > 0) { NGP_CHECK_PTR(x); NGP_CHECK_PTR(xyz_min); NGP_CHECK_PTR(xyz_max); NGP_CHECK_PTR(dfeats); }
     if ((active_idx == nullptr) != (n_active == nullptr)) return NGP_EINVAL;
     SlicePlan plan;
-    static int run_max_res = -1;
-    if (run_max_res < 0) { const char* e = getenv("NGP_DENSE_RUN_MAX_RES"); run_max_res = e ? atoi(e) : 1 << 20; }   // run accumulation on every dense level (per-sample float atomics measured 4x slower there)
-    plan.run_max_res = run_max_res;
+    plan.run_max_res = 1 << 20;            // run accumulation on every dense level (per-sample float atomics measured 4x slower there)
     int n_blocks = 0;
     uint32_t zero_lo = 0, zero_hi = 0;   // pending [lo, hi) entry range to zero-fill
     hipStream_t st = ngp_stream(stream);

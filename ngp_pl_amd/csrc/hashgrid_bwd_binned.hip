@@ -23,7 +23,6 @@
 // Levels with few slices (the coarse dense ones: a z-slab can hold most of the scene) additionally split
 // their lists over K tasks whose partial tables are summed by a small merge kernel (no atomics anywhere).
 #include "hashgrid_common.h"
-#include "adam_common.h"
 #include <hip/hip_fp16.h>
 
 using namespace ngp_grid;
@@ -50,22 +49,9 @@ constexpr int MAX_CHUNKS = 4608;             // 4.7 M samples: the first steps o
                                              // rays, 4 M for 16 384) stay on this exact, deterministic path instead of the one-pass kernel, whose f16 LDS
                                              // atomics round in arrival order -- round 3's bench runs diverged from step 0 on and landed on operating
                                              // points 15 % apart.  (Two directory rows of this length sit in LDS next to the accumulators: 36 KB.)
-// Measured alternative, compiled out by default (NGP_BIN_PAYLOAD=1 builds it; profiles/r03_table_backward_experiments.txt):
-// hashed levels hand the slice owner everything it needs in the list entry itself (12 bytes):
-//   word 0: l0 | l1 << 13      slice-local indices of the pair's two corners (x, .) and (x+1, .); PAY_INVALID = not in this slice
-//   word 1: the sample's gradient for this level (half2 bits)
-//   word 2: w0 | w1 << 16      the two trilinear weights in 16-bit fixed point (units of 2^-16; tiny-cuda-nn rounds every
-//                              w * g product to f16, i.e. to 11 bits)
-// so that an owner's trip is three coalesced stream loads, four multiplies and four LDS adds per entry: no position /
-// gradient gathers, no cell, hash or weight arithmetic repeated by each of a sample's four pair entries.  On MI355X the
-// slice owners get 14 % faster (apply span 96.5 -> 83.0 us at 155 k samples) and the binning pass, whose 12-byte entries
-// now leave as scattered stores, twice as slow (26 -> 53 us): 132 -> 145 us for the stage.  The owners' time is not in
-// their gathers or arithmetic.
-#ifndef NGP_BIN_PAYLOAD
-#define NGP_BIN_PAYLOAD 0
-#endif
-constexpr uint32_t PAY_INVALID = 0x1fffu;    // >= SLICE2: fails the in-slice test
-static_assert(SLICE2 < PAY_INVALID, "slice-local indices are stored in 13 bits");
+// (Payload list entries -- the slice owner handed corner indices, gradient and fixed-point weights in a 12-byte entry, no gathers on its
+// side -- were built and measured in round 3: owners 14 % faster, binning twice as slow, 132 -> 145 us for the stage; removed in round 5.
+// profiles/r03_table_backward_experiments.txt.)
 #ifndef NGP_APPLY_THREADS
 #define NGP_APPLY_THREADS 1024
 #endif
@@ -133,14 +119,12 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const
     const bool hashed = level_is_hashed(res, size);
     const Box box = load_box(xyz_min, xyz_max);
     int jj[BIN_SPT], sid[BIN_SPT][8], loc[BIN_SPT][8], tag[BIN_SPT][8], n_mine[BIN_SPT];
-    int32_t pay0[BIN_SPT][8], pay2[BIN_SPT][4];       // payload words 0 (per entry) and 2 (per corner pair)
     half2_t gg[BIN_SPT]; int src[BIN_SPT]; float xin[BIN_SPT][3];
 #pragma unroll
     for (int t = 0; t < BIN_SPT; ++t) {               // all loads of the thread's samples before any use
         jj[t] = chunk * CHUNK + t * BIN_THREADS + (int)threadIdx.x;
         const int jc = min(jj[t], n - 1);
-        if (dfeats != nullptr) gg[t] = dfeats[(size_t)level * n_samples + jc];
-        else { gg[t][0] = (_Float16)1; gg[t][1] = (_Float16)1; }      // lists built ahead of the gradients: every live sample is listed
+        gg[t] = dfeats[(size_t)level * n_samples + jc];
         src[t] = active ? active[jc] : jc;
     }
 #pragma unroll
@@ -164,16 +148,6 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const
                     const int s0 = (int)(idx[2 * k] / SLICE2), s1 = (int)(idx[2 * k + 1] / SLICE2);
                     sid[t][2 * k] = s0; tag[t][2 * k] = k;
                     sid[t][2 * k + 1] = (s1 != s0) ? s1 : -1; tag[t][2 * k + 1] = k;
-                    if (NGP_BIN_PAYLOAD) {
-                        const uint32_t l0 = idx[2 * k] - (uint32_t)s0 * SLICE2, l1 = idx[2 * k + 1] - (uint32_t)s1 * SLICE2;
-                        // the pair in one slice: both corners in one entry; straddling two slices: one entry each, the other corner invalid
-                        pay0[t][2 * k] = (int32_t)(l0 | ((s1 == s0 ? l1 : PAY_INVALID) << 13));
-                        pay0[t][2 * k + 1] = (int32_t)(PAY_INVALID | (l1 << 13));
-                        const float wy = (k & 1) ? f[1] : 1.f - f[1], wz = (k >> 1) ? f[2] : 1.f - f[2];
-                        const float w0 = ((1.f - f[0]) * wy) * wz, w1 = (f[0] * wy) * wz;              // corner_weight()'s order
-                        const uint32_t q0 = min((uint32_t)__float2int_rn(w0 * 65536.0f), 65535u), q1 = min((uint32_t)__float2int_rn(w1 * 65536.0f), 65535u);
-                        pay2[t][k] = (int32_t)(q0 | (q1 << 16));
-                    }
                 }
                 n_mine[t] = 8;
             } else {
@@ -213,17 +187,7 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const
     }
     __syncthreads();
     int32_t* __restrict__ slot = ws.pool + plan.pool_off[level] + (size_t)chunk * CHUNK_SLOTS * plan.entry_words[level];
-    if (NGP_BIN_PAYLOAD && hashed) {
-        // payload entries go straight to their place in the chunk's slot (12-byte stores; a slice's segment is written by the
-        // threads that found entries for it and merges in L2)
-#pragma unroll
-        for (int t = 0; t < BIN_SPT; ++t)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) if (q < n_mine[t] && sid[t][q] >= 0) {
-                int32_t* __restrict__ e = slot + 3 * (size_t)(s_pre[sid[t][q]] + loc[t][q]);
-                e[0] = pay0[t][q]; e[1] = __builtin_bit_cast(int32_t, gg[t]); e[2] = pay2[t][q >> 1];
-            }
-    } else {
+    {
 #pragma unroll
         for (int t = 0; t < BIN_SPT; ++t)
 #pragma unroll
@@ -343,44 +307,6 @@ __device__ __forceinline__ void apply_segments_hashed(long long* lds, uint32_t l
     }
 }
 
-// Hashed levels with payload entries (NGP_BIN_PAYLOAD): lane = entry, three coalesced words per entry, no gathers.
-template <int B>
-__device__ __forceinline__ void apply_segments_payload(long long* lds, uint32_t len, const int32_t* __restrict__ pool_level,
-                                                       const int* s_dir, int n_chunks, int part, int K) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int NW = APPLY_THREADS / 64;
-    for (int c0 = part + K * wave; c0 < n_chunks; c0 += K * NW * B) {
-        int cnt[B], maxcnt = 0; size_t start[B];
-#pragma unroll
-        for (int b = 0; b < B; ++b) {
-            const int c = c0 + b * K * NW;
-            const int d = (c < n_chunks) ? s_dir[c] : 0;
-            start[b] = (size_t)c * CHUNK_SLOTS + (d >> 16); cnt[b] = d & 0xffff;
-            maxcnt = max(maxcnt, cnt[b]);
-        }
-        for (int off = 0; off < maxcnt; off += 64) {               // one pass unless a segment has more than 64 entries
-            uint32_t e0[B], e1[B], e2[B];
-#pragma unroll
-            for (int b = 0; b < B; ++b) {
-                const bool ok = off + lane < cnt[b];
-                const int32_t* __restrict__ e = pool_level + 3 * (start[b] + (size_t)(ok ? off + lane : 0));
-                e0[b] = ok ? (uint32_t)__builtin_nontemporal_load(e) : ~0u;             // not ok: both corners invalid
-                e1[b] = (uint32_t)__builtin_nontemporal_load(e + 1); e2[b] = (uint32_t)__builtin_nontemporal_load(e + 2);
-            }
-#pragma unroll
-            for (int b = 0; b < B; ++b) {
-                const uint32_t l0 = e0[b] & 0x1fffu, l1 = (e0[b] >> 13) & 0x1fffu;
-                const half2_t g = __builtin_bit_cast(half2_t, e1[b]);
-                // w * g * 2^24 with w in units of 2^-16: one f32 rounding of a 16 x 11 bit product, then exact
-                const float g0 = (float)g[0] * (FIX_SCALE / 65536.0f), g1 = (float)g[1] * (FIX_SCALE / 65536.0f);
-                const float w0 = (float)(e2[b] & 0xffffu), w1 = (float)(e2[b] >> 16);
-                if (l0 < len) { lds_add_q(lds + 2 * l0, w0 * g0); lds_add_q(lds + 2 * l0 + 1, w0 * g1); }
-                if (l1 < len) { lds_add_q(lds + 2 * l1, w1 * g0); lds_add_q(lds + 2 * l1 + 1, w1 * g1); }
-            }
-        }
-    }
-}
-
 // Dense (coarse) levels: a segment holds up to every sample of its chunk, and dozens of consecutive
 // samples of a ray sit in the same cell, i.e. consecutive entries hit the same 8 accumulators
 // (measured: an LDS add_u64 with 8 lanes per address costs 64 cycles instead of 11.5).  Lane L
@@ -488,20 +414,15 @@ __device__ __forceinline__ void apply_segments_dense_runs(long long* lds, uint32
     }
 }
 
-// FUSE_ADAM: the write-out of a level whose sums are final in the task (K == 1: the hashed levels, 92 % of the table) applies the
-// Adam update to the slice it has just summed -- 24 B read and 28 B written per entry as coalesced streams, issued by a workgroup
-// that has spent the task waiting on gathers and LDS: the dense Adam kernel (0.055 ms at 5.9 TB/s, nothing else running) shrinks
-// to the K-split levels and the MLP blocks, and the table's optimizer traffic rides under the slice owners' latencies.  The gradient
-// is rounded to f16 first and still written to grad_table: the same value the streaming kernel would have read (adam_common.h:
-// the same update, bit for bit).
-struct ApplyAdam { float2* param; half2_t* param_h; float2* m; float2* v; AdamCoef c; };
-
-template <bool FUSE_ADAM>
+// (Applying the hashed levels' Adam update in this kernel's write-out -- three designs, the last with wave specialisation -- was built and
+// measured in round 4: the optimizer's stream is not hidden under the owners' latencies, the owners slow down by as much as the stream takes
+// alone; removed in round 5.  profiles/r04_step_ab.txt (d), (d2).)
+template <bool UNUSED>       // (the template argument only keeps the kernel's name in the round 3-4 traces: apply_kernel<false>)
 __global__ void __launch_bounds__(APPLY_THREADS, NGP_APPLY_WAVES_PER_EU)
 apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, const float* __restrict__ xyz_max,
              const half2_t* __restrict__ dfeats, GridMeta meta, BinPlan plan, BinWs ws, int n_samples,
              const int32_t* __restrict__ active, const int32_t* __restrict__ n_active, half2_t* __restrict__ grad_table,
-             int group, int task_begin, int task_end, ApplyAdam ad) {
+             int group, int task_begin, int task_end) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     long long* lds = reinterpret_cast<long long*>(smem_raw);
     __shared__ int s_task[2];                                          // s_task[k & 1]: id of the workgroup's k-th task
@@ -561,8 +482,7 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
         const half2_t* __restrict__ g_level = dfeats + (size_t)level * n_samples;
         const int32_t* __restrict__ pool_level = ws.pool + plan.pool_off[level];
         if (level_is_hashed(res, size)) {
-            if (NGP_BIN_PAYLOAD) apply_segments_payload<NGP_APPLY_PB>(lds, len, pool_level, s_dir, n_chunks, part, K);
-            else apply_segments_hashed<NGP_APPLY_B>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
+            apply_segments_hashed<NGP_APPLY_B>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
         }
         else if (NGP_DENSE_RUNS) apply_segments_dense_runs<NGP_DENSE_B>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
         else apply_segments_dense<4>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
@@ -613,34 +533,6 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
             }
         }
 #else
-        if (FUSE_ADAM && K == 1) {
-            // all of the thread's parameter / moment loads first (the streams of a slice: 6912 x 24 B), then one entry at a time
-            constexpr int WO = (int)((SLICE2 + APPLY_THREADS - 1) / APPLY_THREADS);
-            const size_t e0 = (size_t)meta.offset[level] + lo;
-            float2* __restrict__ P = ad.param + e0; float2* __restrict__ M = ad.m + e0; float2* __restrict__ V = ad.v + e0;
-            half2_t* __restrict__ PH = ad.param_h + e0;
-            float2 pp[WO], mm[WO], vv[WO];
-#pragma unroll
-            for (int q = 0; q < WO; ++q) {
-                const uint32_t k = tid + q * APPLY_THREADS;
-                const uint32_t kc = k < len ? k : 0;
-                pp[q] = P[kc]; mm[q] = M[kc]; vv[q] = V[kc];
-            }
-#pragma unroll
-            for (int q = 0; q < WO; ++q) {
-                const uint32_t k = tid + q * APPLY_THREADS;
-                if (k < len) {
-                    const float a0 = (float)lds[2 * k] * inv, a1 = (float)lds[2 * k + 1] * inv;
-                    lds[2 * k] = 0; lds[2 * k + 1] = 0;
-                    half2_t g; g[0] = (_Float16)a0; g[1] = (_Float16)a1;
-                    out[k] = g;
-                    adam_one(pp[q].x, mm[q].x, vv[q].x, (float)g[0], ad.c);
-                    adam_one(pp[q].y, mm[q].y, vv[q].y, (float)g[1], ad.c);
-                    half2_t ph; ph[0] = (_Float16)pp[q].x; ph[1] = (_Float16)pp[q].y;
-                    P[k] = pp[q]; M[k] = mm[q]; V[k] = vv[q]; PH[k] = ph;
-                }
-            }
-        } else
         for (uint32_t k = tid; k < len; k += APPLY_THREADS) {
             const float a0 = (float)lds[2 * k] * inv, a1 = (float)lds[2 * k + 1] * inv;
             lds[2 * k] = 0; lds[2 * k + 1] = 0;                        // ready for the next task
@@ -724,7 +616,7 @@ bool make_plan(const ngp_grid_meta* meta, int n_samples, BinPlan& P, BinLayout& 
     for (int l = 0; l < meta->n_levels; ++l) {
         const uint32_t size = meta->offset[l + 1] - meta->offset[l], res = meta->resolution[l];
         const bool hashed = (uint64_t)res * res * res > size;
-        P.entry_words[l] = (NGP_BIN_PAYLOAD && hashed) ? 3 : 1;
+        P.entry_words[l] = 1;
         P.pool_off[l] = pool_words;
         pool_words += (long long)P.n_chunks * CHUNK_SLOTS * P.entry_words[l];
     }
@@ -778,18 +670,15 @@ int ngp_hashgrid_bwd_binned_group_entries(const ngp_grid_meta* meta, int n_sampl
 
 // partials_out != NULL (ngp_hashgrid_bwd_binned_deferred): the merge of the K-split levels' partial tables is left to the consumer
 // of the gradient (the fused Adam reads the K partials itself) and *partials_out says where they are.
-enum { PASS_BOTH = 0, PASS_LISTS = 1, PASS_OWNERS = 2 };
 static int binned_group_impl(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* dfeats,
                              const ngp_grid_meta* meta, int n_samples, const int32_t* active_idx,
                              const int32_t* n_active, void* workspace, size_t workspace_bytes,
-                             ngp_half* grad_table, int n_groups, int group, ngp_grid_partials* partials_out, ngp_stream_t stream,
-                             int pass = PASS_BOTH, const ApplyAdam* adam = nullptr) {
+                             ngp_half* grad_table, int n_groups, int group, ngp_grid_partials* partials_out, ngp_stream_t stream) {
     if (n_samples < 0 || !meta || meta->n_features != 2 || meta->n_levels < 1 || meta->n_levels > NGP_MAX_LEVELS) return NGP_EINVAL;
     if (n_groups < 1 || n_groups > 16 || group < 0 || group >= n_groups) return NGP_EINVAL;
     NGP_CHECK_PTR(workspace);
-    if (pass != PASS_LISTS) NGP_CHECK_PTR(grad_table);
-    if (n_samples > 0) { NGP_CHECK_PTR(x); NGP_CHECK_PTR(xyz_min); NGP_CHECK_PTR(xyz_max); if (pass != PASS_LISTS) NGP_CHECK_PTR(dfeats); }
-    if (NGP_BIN_PAYLOAD && pass != PASS_BOTH) return NGP_EUNSUP;       // payload entries carry the gradient: the lists cannot precede it
+    NGP_CHECK_PTR(grad_table);
+    if (n_samples > 0) { NGP_CHECK_PTR(x); NGP_CHECK_PTR(xyz_min); NGP_CHECK_PTR(xyz_max); NGP_CHECK_PTR(dfeats); }
     if (active_idx != nullptr && n_active == nullptr) return NGP_EINVAL;      // n_active alone: x and dfeats both in compact order
     BinPlan P; BinLayout L;
     if (!make_plan(meta, n_samples, P, L)) return NGP_EUNSUP;
@@ -809,10 +698,9 @@ static int binned_group_impl(const float* x, const float* xyz_min, const float* 
     ws.partial = reinterpret_cast<float2*>(wsb + L.partial);
     hipError_t e = hipSuccess;
     const GridMeta dm = to_dev_meta(meta);
-    if (group == 0 && pass != PASS_OWNERS)
+    if (group == 0)
         bin_kernel<<<dim3(meta->n_levels * P.n_chunks), dim3(BIN_THREADS), 0, st>>>(
-            x, xyz_min, xyz_max, pass == PASS_LISTS ? nullptr : (const half2_t*)dfeats, dm, P, ws, n_samples, active_idx, n_active);
-    if (pass == PASS_LISTS) return NGP_LAUNCH_RESULT();
+            x, xyz_min, xyz_max, (const half2_t*)dfeats, dm, P, ws, n_samples, active_idx, n_active);
     constexpr int smem = (int)(SLICE2 * 2 * sizeof(long long));
     static bool attr_set[64] = {};              // per device: the attribute belongs to the device's code object
     int dev = 0;
@@ -820,7 +708,6 @@ static int binned_group_impl(const float* x, const float* xyz_min, const float* 
     dev &= 63;
     if (!attr_set[dev]) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(apply_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(apply_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
         attr_set[dev] = true;
     }
@@ -830,12 +717,8 @@ static int binned_group_impl(const float* x, const float* xyz_min, const float* 
     const int n_tasks = task_end - task_begin;
     if (n_tasks > 0) {
         const int n_wg = n_tasks < NGP_APPLY_WGS ? n_tasks : NGP_APPLY_WGS;
-        if (adam != nullptr)
-            apply_kernel<true><<<dim3(n_wg), dim3(APPLY_THREADS), smem, st>>>(
-                x, xyz_min, xyz_max, (const half2_t*)dfeats, dm, P, ws, n_samples, active_idx, n_active, (half2_t*)grad_table, group, task_begin, task_end, *adam);
-        else
-            apply_kernel<false><<<dim3(n_wg), dim3(APPLY_THREADS), smem, st>>>(
-                x, xyz_min, xyz_max, (const half2_t*)dfeats, dm, P, ws, n_samples, active_idx, n_active, (half2_t*)grad_table, group, task_begin, task_end, ApplyAdam{});
+        apply_kernel<false><<<dim3(n_wg), dim3(APPLY_THREADS), smem, st>>>(
+                x, xyz_min, xyz_max, (const half2_t*)dfeats, dm, P, ws, n_samples, active_idx, n_active, (half2_t*)grad_table, group, task_begin, task_end);
     }
     if (partials_out != nullptr) {
         // the K-split levels must be a prefix of the table (coarse levels first: true for every grid this package builds)
@@ -870,41 +753,6 @@ int ngp_hashgrid_bwd_binned_deferred(const float* x, const float* xyz_min, const
     NGP_CHECK_PTR(partials_out);
     return binned_group_impl(x, xyz_min, xyz_max, dfeats, meta, n_samples, active_idx, n_active, workspace, workspace_bytes, grad_table,
                              1, 0, partials_out, stream);
-}
-
-int ngp_hashgrid_bwd_binned_lists(const float* x, const float* xyz_min, const float* xyz_max, const ngp_grid_meta* meta, int n_samples,
-                                  const int32_t* active_idx, const int32_t* n_active, void* workspace, size_t workspace_bytes,
-                                  ngp_stream_t stream) {
-    return binned_group_impl(x, xyz_min, xyz_max, nullptr, meta, n_samples, active_idx, n_active, workspace, workspace_bytes, nullptr,
-                             1, 0, nullptr, stream, PASS_LISTS);
-}
-
-int ngp_hashgrid_bwd_binned_owners(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* dfeats,
-                                   const ngp_grid_meta* meta, int n_samples, const int32_t* active_idx,
-                                   const int32_t* n_active, void* workspace, size_t workspace_bytes,
-                                   ngp_half* grad_table, int n_groups, int group, ngp_grid_partials* partials_out, ngp_stream_t stream) {
-    return binned_group_impl(x, xyz_min, xyz_max, dfeats, meta, n_samples, active_idx, n_active, workspace, workspace_bytes, grad_table,
-                             n_groups, group, partials_out, stream, PASS_OWNERS);
-}
-
-int ngp_hashgrid_bwd_binned_adam(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* dfeats,
-                                 const ngp_grid_meta* meta, int n_samples, const int32_t* active_idx,
-                                 const int32_t* n_active, void* workspace, size_t workspace_bytes,
-                                 ngp_half* grad_table, ngp_grid_partials* partials_out,
-                                 float* grid_param, ngp_half* grid_param_h, float* grid_m, float* grid_v,
-                                 float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
-                                 ngp_stream_t stream) {
-    NGP_CHECK_PTR(partials_out); NGP_CHECK_PTR(grid_param); NGP_CHECK_PTR(grid_param_h); NGP_CHECK_PTR(grid_m); NGP_CHECK_PTR(grid_v);
-    if (step < 1 || grad_scale == 0.f) return NGP_EINVAL;
-    ApplyAdam ad;
-    ad.param = reinterpret_cast<float2*>(grid_param); ad.param_h = reinterpret_cast<half2_t*>(grid_param_h);
-    ad.m = reinterpret_cast<float2*>(grid_m); ad.v = reinterpret_cast<float2*>(grid_v);
-    // (the streaming kernel's hyper-parameters, formed the same way: optim.hip adam_hyper())
-    ad.c.lr = lr; ad.c.beta1 = beta1; ad.c.beta2 = beta2; ad.c.eps = eps; ad.c.wd = weight_decay;
-    ad.c.bc1 = 1.0f - powf(beta1, (float)step); ad.c.bc2 = 1.0f - powf(beta2, (float)step);
-    ad.c.inv_scale = 1.0f / grad_scale;
-    return binned_group_impl(x, xyz_min, xyz_max, dfeats, meta, n_samples, active_idx, n_active, workspace, workspace_bytes, grad_table,
-                             1, 0, partials_out, stream, PASS_BOTH, &ad);
 }
 
 int ngp_hashgrid_bwd_binned(const float* x, const float* xyz_min, const float* xyz_max, const ngp_half* dfeats,

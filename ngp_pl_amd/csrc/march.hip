@@ -219,16 +219,6 @@ density_grid_update_kernel(float* __restrict__ grid, const float* __restrict__ t
     }
 }
 
-__global__ void __launch_bounds__(256)
-cells_to_xyz_kernel(const int32_t* __restrict__ coords, const float* __restrict__ noise, int n3,
-                    float gm1, float s_minus_hgs, float hgs, float* __restrict__ xyzs) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n3) return;
-    // (coords/(G-1)*2-1)*(s-hgs) + (rand*2-1)*hgs   (networks.py:253-255), torch op order
-    const float c = ((float)coords[i] / gm1 * 2.0f - 1.0f) * s_minus_hgs;
-    xyzs[i] = c + (noise[i] * 2.0f - 1.0f) * hgs;
-}
-
 // ------------------------------------------------------------------------------------------
 // marching core (raymarching.cu:7-32, 204-234)
 // ------------------------------------------------------------------------------------------
@@ -327,43 +317,10 @@ __device__ __forceinline__ Ray load_ray(const float* __restrict__ rays_o, const 
     return ray;
 }
 
-// Pass 1 of train marching (raymarching.cu:184-234): one march, t of every emitted sample goes
-// to the ray's scratch row.  The loop is a chain of dependent bitfield loads with per-ray trip
-// counts from 0 to ~600, so a wave costs as much as its slowest ray and both branches of every
-// step.  Rays per wave are therefore kept to MARCH_RAYS_PER_WAVE (lanes above stay idle): 8192
-// rays become 512 waves spread over all 256 CUs instead of the reference's 32 blocks of 256.
-constexpr int MARCH_RAYS_PER_WAVE = 16;
-template <bool SIMPLE>
-__global__ void __launch_bounds__(64)
-march_train_count_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                         const float* __restrict__ hits_t, const float* __restrict__ noise,
-                         MarchParams p, int max_samples, int n_rays,
-                         int64_t* __restrict__ rays_a, float* __restrict__ t_scratch) {
-    if (threadIdx.x >= MARCH_RAYS_PER_WAVE) return;
-    const int r = blockIdx.x * MARCH_RAYS_PER_WAVE + threadIdx.x;
-    if (r >= n_rays) return;
-    const Ray ray = load_ray(rays_o, rays_d, r);
-    float t1 = hits_t[2 * r];
-    const float t2 = hits_t[2 * r + 1];
-    if (t1 >= 0) t1 = fmaf(calc_dt(t1, p), noise[r], t1);   // general formula also on the SIMPLE path (== dt_lo there)
-    float* __restrict__ row = t_scratch + (size_t)r * max_samples;
-    float t = t1;
-    int n = 0, iters = 0;
-    while (0 <= t && t < t2 && n < max_samples) {
-        if (++iters > MARCH_ITER_CAP) { atomicAdd(&g_march_guard[2], 1u); break; }
-        float x, y, z, dt, t_next;
-        if (march_probe<SIMPLE>(ray, p, t, x, y, z, dt, t_next)) {
-            row[n] = t;
-            t += dt; ++n;
-        } else {
-            t = t_next;
-        }
-    }
-    rays_a[3 * (size_t)r] = r;
-    rays_a[3 * (size_t)r + 2] = n;
-}
-
-
+// Pass 1 of train marching (raymarching.cu:184-234): one march per ray, t of every emitted sample goes to the ray's scratch row.
+// The reference's loop is a chain of dependent bitfield loads with per-ray trip counts from 0 to ~600 (a serial-chain kernel, 16 rays
+// per wave, took 280-330 us per 8192-ray batch: round 1; removed in round 5, tests/test_march_parallel_proto_cpu.py keeps the numpy
+// prototype of the equivalence).
 // T[j] = fl(T[j-1] + dt), j = 1..64, for a CONSTANT step (the Synthetic-NeRF setting), in closed form instead of a chain of
 // 64 dependent adds: inside one binade [2^e, 2^(e+1)) every element is a multiple of u = 2^(e-23) and dt / u = q + r with a
 // fraction r that is the same for every element, so round-to-nearest adds the SAME integer number of ulps each step:
@@ -403,7 +360,7 @@ __device__ __forceinline__ bool lattice_tile_const_dt(float t_start, float dt, i
     return true;
 }
 
-// The same pass with ONE WAVE PER RAY, bit-identical to the serial loop above.  The loop visits a subsequence of one
+// ONE WAVE PER RAY, bit-identical to the serial loop.  The loop visits a subsequence of one
 // fixed sequence per ray, T[0] = t1, T[j+1] = T[j] + calc_dt(T[j]): an occupied cell advances by one element, an empty
 // cell by k >= 1 elements (the do-while of the skip).  Per tile of 64 elements the wave
 //   1. generates the 64 elements (a chain of adds, no memory) -- lane j keeps T[j];
@@ -1139,17 +1096,6 @@ int ngp_density_grid_update(float* density_grid, const float* density_grid_tmp, 
     return NGP_LAUNCH_RESULT();
 }
 
-int ngp_cells_to_xyz(const int32_t* coords, const float* noise, int n, int grid_size, float s,
-                     float* xyzs_w, ngp_stream_t stream) {
-    if (n < 0 || grid_size < 2) return NGP_EINVAL;
-    if (n == 0) return 0;
-    NGP_CHECK_PTR(coords); NGP_CHECK_PTR(noise); NGP_CHECK_PTR(xyzs_w);
-    const double sd = (double)s, hgs = sd / grid_size;   // python floats are doubles (networks.py:251-253)
-    hipLaunchKernelGGL(cells_to_xyz_kernel, dim3(ngp_div_up(3LL * n, 256)), dim3(256), 0, ngp_stream(stream),
-                       coords, noise, 3 * n, (float)(grid_size - 1), (float)(sd - hgs), (float)hgs, xyzs_w);
-    return NGP_LAUNCH_RESULT();
-}
-
 int ngp_raymarching_train_count(const float* rays_o, const float* rays_d, const float* hits_t,
                                 const uint8_t* density_bitfield, int cascades, float scale,
                                 float exp_step_factor, const float* noise, int grid_size,
@@ -1174,21 +1120,12 @@ int ngp_raymarching_train_count_k(const float* rays_o, const float* rays_d, cons
         // Pass 1 runs one WAVE per ray (march_train_count_wave_kernel: 64 candidates of the ray's fixed t-sequence probed per pass,
         // bit-identical to the serial loop, 101 us instead of 280-330 us per 8192-ray batch: profiles/r01_v20_wave_march_kernel_trace.txt,
         // gpurun sweep of round 2: the step time is the same for every placement, the marching stream is busy a third as long).
-        // NGP_MARCH_WAVE=0 selects the serial-chain kernel (16 rays per wave) for A/B runs.
-        static const bool wave_per_ray = [] { const char* e = getenv("NGP_MARCH_WAVE"); return e ? atoi(e) != 0 : true; }();
-        if (wave_per_ray) {
-            const dim3 grid(ngp_div_up((long long)n_rays * 64, 256));
-            if (p.simple)
-                hipLaunchKernelGGL(march_train_count_wave_kernel<true>, grid, dim3(256), 0, ngp_stream(stream),
-                                   rays_o, rays_d, hits_t, noise, p, max_samples, n_rays, rays_a, t_scratch);
-            else
-                hipLaunchKernelGGL(march_train_count_wave_kernel<false>, grid, dim3(256), 0, ngp_stream(stream),
-                                   rays_o, rays_d, hits_t, noise, p, max_samples, n_rays, rays_a, t_scratch);
-        } else if (p.simple)
-            hipLaunchKernelGGL(march_train_count_kernel<true>, dim3(ngp_div_up(n_rays, MARCH_RAYS_PER_WAVE)), dim3(64), 0, ngp_stream(stream),
+        const dim3 grid(ngp_div_up((long long)n_rays * 64, 256));
+        if (p.simple)
+            hipLaunchKernelGGL(march_train_count_wave_kernel<true>, grid, dim3(256), 0, ngp_stream(stream),
                                rays_o, rays_d, hits_t, noise, p, max_samples, n_rays, rays_a, t_scratch);
         else
-            hipLaunchKernelGGL(march_train_count_kernel<false>, dim3(ngp_div_up(n_rays, MARCH_RAYS_PER_WAVE)), dim3(64), 0, ngp_stream(stream),
+            hipLaunchKernelGGL(march_train_count_wave_kernel<false>, grid, dim3(256), 0, ngp_stream(stream),
                                rays_o, rays_d, hits_t, noise, p, max_samples, n_rays, rays_a, t_scratch);
     }
     hipLaunchKernelGGL(march_train_scan_kernel, dim3(1), dim3(1024), 0, ngp_stream(stream), rays_a, n_rays, counter, first_k, offs_k);
@@ -1340,8 +1277,7 @@ int ngp_render_test_frame(const float* rays_o, const float* rays_d, const float*
         const dim3 mgrid(ngp_div_up(bound, 64));
         // the reference's chunking (chunk_scale 1, no probe cap) takes up to 64 samples per ray and iteration (rendering.py:72); the
         // regrouping modes cap a ray's samples per iteration at 32, which halves the marcher's LDS tile and doubles its waves per CU
-        static const bool nmax64 = [] { const char* e = getenv("NGP_RENDER_NMAX64"); return e && atoi(e) != 0; }();      // A/B switch
-        const bool regroup = (chunk_scale > 1 || probe_cap > 0) && !nmax64;
+        const bool regroup = chunk_scale > 1 || probe_cap > 0;
 #define NGP_RENDER_MARCH(S, NM) hipLaunchKernelGGL((render_march_kernel<S, NM>), mgrid, dim3(64), 0, st, rays_o, rays_d, hits, alive[it & 1], emitted, p, pl, \
                                                    n_rays, chunk_scale, min_samples, max_samples, probe_cap, xyzs, dirs, deltas, ts, n_eff, offsets)
         if (p.simple) { if (regroup) NGP_RENDER_MARCH(true, 32); else NGP_RENDER_MARCH(true, 64); }

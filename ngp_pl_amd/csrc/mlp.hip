@@ -1043,7 +1043,7 @@ int fwd_grid(int n_samples) {
     const int blocks = (n_tiles + WAVES - 1) / WAVES;
     // workgroups per CU: the per-workgroup weight staging (24 KB) wants several tiles per wave, the latency of a tile's loads
     // wants several waves per SIMD (2 workgroups = 2 waves per SIMD measured 75 us per 1.3 M samples in the frame loop)
-    static const int cap = [] { const char* e = getenv("NGP_FWD_GRID_CAP"); return e ? atoi(e) : 512; }();
+    constexpr int cap = 512;
     return blocks < cap ? (blocks < 1 ? 1 : blocks) : cap;
 }
 int bwd_grid(int n_samples) {
@@ -1147,16 +1147,6 @@ int ngp_density_fwd_scatter(const ngp_half* feats, const ngp_half* density_w, in
     return launch_fwd<32, 1, IN_LEVELMAJOR, OUT_DENSITY>(d, (const h1*)density_w, n_samples, ngp_stream(stream));
 }
 
-int ngp_rgb_fwd(const ngp_half* h, const float* dirs, const ngp_half* rgb_w, int n_samples, float* rgbs,
-                ngp_stream_t stream) {
-    if (n_samples < 0) return NGP_EINVAL;
-    if (n_samples == 0) return 0;
-    NGP_CHECK_PTR(h); NGP_CHECK_PTR(dirs); NGP_CHECK_PTR(rgb_w); NGP_CHECK_PTR(rgbs);
-    MlpIO r = {};
-    r.in = (const h1*)h; r.dirs = dirs; r.rgbs = rgbs; r.n_out = 3;
-    return launch_fwd<32, 2, IN_SH_H, OUT_RGB>(r, (const h1*)rgb_w, n_samples, ngp_stream(stream));
-}
-
 int ngp_field_fwd(const ngp_half* feats, const float* dirs, const ngp_half* density_w, const ngp_half* rgb_w,
                   int n_samples, float* sigmas, float* rgbs, ngp_half* h_out, ngp_stream_t stream) {
     return ngp_field_fwd_n(feats, dirs, density_w, rgb_w, n_samples, nullptr, sigmas, rgbs, h_out, stream);
@@ -1203,7 +1193,8 @@ int ngp_debug_mlp_timing(unsigned long long* host_out, int reset) {
 
 int ngp_field_bwd_partials(int n_samples) { return n_samples <= 0 ? 0 : bwd_grid(n_samples); }
 
-int ngp_rgb_bwd(const ngp_half* h, const float* dirs, const ngp_half* rgb_w, const float* dL_drgbs, float loss_scale,
+// (the colour net's half of ngp_field_bwd: internal)
+static int ngp_rgb_bwd(const ngp_half* h, const float* dirs, const ngp_half* rgb_w, const float* dL_drgbs, float loss_scale,
                 int n_samples, const int32_t* active_idx, const int32_t* n_active, ngp_half* dL_dh, float* wgrad_partial,
                 ngp_stream_t stream) {
     if (n_samples < 0) return NGP_EINVAL;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/ngp_hip.h"
+#include "ngp_internal.h"
 
 #define NGP_WAVE 64
 

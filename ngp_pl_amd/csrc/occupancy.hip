@@ -247,21 +247,17 @@ int ngp_occupancy_update_workspace_layout(int cascades, int grid_size, size_t* t
     return 0;
 }
 
-// phase: ALL = the whole update; DRAW = everything that depends on the occupancy grid and the seed only (scratch clear, occupancy
-// words, the draws, their regrouping with the jittered positions): the caller may run it long before the update, on another
-// stream, once the previous update is complete; FINISH = the rest (field forward at the drawn positions, merge, packing).
-enum { OCC_ALL = 0, OCC_DRAW = 1, OCC_FINISH = 2 };
+// (Split into draw / finish with the NEXT update's draws made ahead on a third stream: built and measured in round 4 -- timed windows
+// +0.6 %, the 30 000-step run -8 %: the two cross-stream hand-overs per update cost more than the 0.09 ms they hide; removed in round 5.
+// profiles/r04_step_ab.txt (e).)
 static int occupancy_impl(float* density_grid, uint8_t* density_bitfield, int cascades, int grid_size, float scale,
                           float density_threshold, float decay, const float* decay_grid, int warmup, uint64_t seed,
                           const float* xyz_min, const float* xyz_max, const ngp_half* table, const ngp_grid_meta* meta,
-                          const ngp_half* density_w, void* workspace, size_t workspace_bytes, ngp_stream_t stream, int phase) {
+                          const ngp_half* density_w, void* workspace, size_t workspace_bytes, ngp_stream_t stream) {
     if (cascades < 1 || grid_size < 4 || grid_size > 256 || (grid_size & (grid_size - 1))) return NGP_EINVAL;
     NGP_CHECK_PTR(density_grid); NGP_CHECK_PTR(workspace);
-    if (phase != OCC_DRAW) {
-        if (!meta) return NGP_EINVAL;
-        NGP_CHECK_PTR(density_bitfield); NGP_CHECK_PTR(xyz_min); NGP_CHECK_PTR(xyz_max); NGP_CHECK_PTR(table); NGP_CHECK_PTR(density_w);
-    }
-    if (phase != OCC_ALL && (warmup || cascades != 1)) return NGP_EUNSUP;     // (the draw buffers hold ONE cascade's draws; warm-up draws nothing)
+    if (!meta) return NGP_EINVAL;
+    NGP_CHECK_PTR(density_bitfield); NGP_CHECK_PTR(xyz_min); NGP_CHECK_PTR(xyz_max); NGP_CHECK_PTR(table); NGP_CHECK_PTR(density_w);
     const OccLayout L = occ_layout(cascades, grid_size);
     if (workspace_bytes < L.bytes) return NGP_EINVAL;
     char* ws = static_cast<char*>(workspace);
@@ -277,13 +273,13 @@ static int occupancy_impl(float* density_grid, uint8_t* density_bitfield, int ca
     const int cells = grid_size * grid_size * grid_size, n_words = cells / 64;
     const int M = cells / 4;                                   // networks.py:254
     const int n = warmup ? cells : 2 * M;
-    if (phase != OCC_FINISH) {
+    {
         const hipError_t e = hipMemsetAsync(tmp, 0, (size_t)cascades * cells * 4, st);
         if (e != hipSuccess) return (int)e;
     }
     for (int c = 0; c < cascades; ++c) {
         float* grid_c = density_grid + (size_t)c * cells;
-        if (!warmup && phase != OCC_FINISH) {
+        if (!warmup) {
             hipLaunchKernelGGL(occ_words_kernel, dim3(ngp_div_up((long long)n_words * 64, 256)), dim3(256), 0, st,
                                grid_c, density_threshold, n_words, words, counts);
             hipLaunchKernelGGL(occ_scan_kernel, dim3(1), dim3(1024), 0, st, counts, n_words, prefix);
@@ -297,7 +293,7 @@ static int occupancy_impl(float* density_grid, uint8_t* density_bitfield, int ca
         if (warmup) {
             hipLaunchKernelGGL(occ_sample_kernel, dim3(ngp_div_up(n, 256)), dim3(256), 0, st, 0, n, M, grid_size, n_words,
                                words, prefix, (float)(s - hgs), (float)hgs, sd_lo, sd_hi, idx, xyzs, c == 0 ? stats : (float*)nullptr);
-        } else if (phase != OCC_FINISH) {
+        } else {
             int32_t* drawn = reinterpret_cast<int32_t*>(ws + L.drawn);
             int32_t* hist = reinterpret_cast<int32_t*>(ws + L.hist);
             int bits = 0; while ((1 << bits) < cells) ++bits;
@@ -309,13 +305,11 @@ static int occupancy_impl(float* density_grid, uint8_t* density_bitfield, int ca
             hipLaunchKernelGGL(occ_place_kernel, dim3(2 * OCC_SORT_WGS), dim3(1024), 0, st, drawn, M, shift, hist, grid_size,
                                (float)(s - hgs), (float)hgs, sd_lo, sd_hi, idx, xyzs);
         }
-        if (phase == OCC_DRAW) continue;
         int rc = ngp_hashgrid_fwd(xyzs, xyz_min, xyz_max, table, meta, n, feats, stream);
         if (rc) return rc;
         rc = ngp_density_fwd_scatter(feats, density_w, n, idx, tmp + (size_t)c * cells, stream);
         if (rc) return rc;
     }
-    if (phase == OCC_DRAW) return NGP_LAUNCH_RESULT();
     int rc = ngp_density_grid_update(density_grid, tmp, decay_grid, decay, cascades * cells, stats, stream);
     if (rc) return rc;
     return ngp_packbits_auto(density_grid, cascades * cells / 8, stats, density_threshold, density_bitfield, stream);
@@ -326,21 +320,7 @@ int ngp_occupancy_update(float* density_grid, uint8_t* density_bitfield, int cas
                          const float* xyz_min, const float* xyz_max, const ngp_half* table, const ngp_grid_meta* meta,
                          const ngp_half* density_w, void* workspace, size_t workspace_bytes, ngp_stream_t stream) {
     return occupancy_impl(density_grid, density_bitfield, cascades, grid_size, scale, density_threshold, decay, decay_grid, warmup, seed,
-                          xyz_min, xyz_max, table, meta, density_w, workspace, workspace_bytes, stream, OCC_ALL);
-}
-
-int ngp_occupancy_draw(const float* density_grid, int cascades, int grid_size, float scale, float density_threshold, uint64_t seed,
-                       void* workspace, size_t workspace_bytes, ngp_stream_t stream) {
-    return occupancy_impl(const_cast<float*>(density_grid), nullptr, cascades, grid_size, scale, density_threshold, 0.f, nullptr, 0, seed,
-                          nullptr, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream, OCC_DRAW);
-}
-
-int ngp_occupancy_update_drawn(float* density_grid, uint8_t* density_bitfield, int cascades, int grid_size, float scale,
-                               float density_threshold, float decay, const float* decay_grid, uint64_t seed,
-                               const float* xyz_min, const float* xyz_max, const ngp_half* table, const ngp_grid_meta* meta,
-                               const ngp_half* density_w, void* workspace, size_t workspace_bytes, ngp_stream_t stream) {
-    return occupancy_impl(density_grid, density_bitfield, cascades, grid_size, scale, density_threshold, decay, decay_grid, 0, seed,
-                          xyz_min, xyz_max, table, meta, density_w, workspace, workspace_bytes, stream, OCC_FINISH);
+                          xyz_min, xyz_max, table, meta, density_w, workspace, workspace_bytes, stream);
 }
 
 #pragma GCC visibility pop

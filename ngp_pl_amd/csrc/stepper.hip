@@ -50,14 +50,6 @@ struct ngp_stepper {
     hipStream_t next_main = nullptr, next_side = nullptr;
     int march_at = 2;
     // two-round forward (include/ngp_hip.h): mode 0 off / 1 on / 2 auto, first K, the auto switch's state, steps run in two rounds
-    bool render_tail = false;              // the last render_forward left live COUNTS (not offsets) in ray_offs
-    int merge_in_adam = 1;                 // NGP_MERGE_IN_ADAM (default 1): ngp_stepper_backward_update folds the dense levels' merge into the Adam launch
-    int adam_in_apply = 0;                 // NGP_ADAM_IN_APPLY=1: ... and the hashed levels' Adam into the slice owners' write-out.  Measured and NOT the
-                                           // default (profiles/r04_step_ab.txt): table backward 0.094 -> 0.146 ms, Adam 0.058 -> 0.019 ms: +12 us per step.  A
-                                           // slice owner streams its slice's 387 KB at ~25 GB/s (what ONE CU sustains) while its 1024 threads x 128 registers
-                                           // fill the CU's register file, so nothing else runs there meanwhile: the streaming is not hidden, it is serialised
-                                           // per CU at a sixteenth of the rate the dense kernel gets from the whole chip.
-    int fused_tail = 1;                    // NGP_FUSED_TAIL (default 1): composite forward / backward without the scan kernel between them
     int two_round_mode = 2, two_round_k = 32;
     bool two_round_active = false, two_rounds = false;
     int set_k[2] = {0, 0};                 // first K the scan of each march record set prepared a compact list for (0: none)
@@ -79,10 +71,6 @@ struct ngp_stepper {
     // (profiles/r04_step_ab.txt): 0.364 -> 0.410 ms per step -- the field backward's workgroups hold 115 / 146 KB of a CU's 160 KB
     // of LDS, so one binning workgroup (33 KB) fits beside them where four run when the pass has the CU to itself, the pass takes
     // 3-4x as long, the field backward 59 -> 75 us, and the slice owners wait for both.  Same bits either way.
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_pos = nullptr, ev_lists = nullptr, lists_t[2] = {};
-    int lists_ahead = 0;
-    bool lists_step = false, lists_pending = false, lists_t_set = false;    // this step's lists went ahead / the main stream has not waited for them yet
     struct SampleSet { float* xyzs; float* dirs; float* deltas; float* ts; };
     SampleSet samples[2] = {};
     bool two_sample_sets = false;
@@ -231,14 +219,6 @@ int ngp_stepper_create(const ngp_stepper_config* config, const ngp_step_buffers*
     s->c = c; s->b = *buffers;
     s->march_at = march_at_from_env();
     if (const char* e = getenv("NGP_TWO_ROUND")) s->two_round_mode = strcmp(e, "on") == 0 ? 1 : (strcmp(e, "off") == 0 ? 0 : 2);
-    if (const char* e = getenv("NGP_FUSED_TAIL")) s->fused_tail = atoi(e) != 0;
-    if (const char* e = getenv("NGP_MERGE_IN_ADAM")) s->merge_in_adam = atoi(e) != 0;
-    if (const char* e = getenv("NGP_LISTS_AHEAD")) s->lists_ahead = atoi(e) != 0;
-    if (const char* e = getenv("NGP_ADAM_IN_APPLY")) s->adam_in_apply = atoi(e) != 0;
-    {   // (needs a K-split level in front of the table: the streaming launch that finishes the step is the MERGE form)
-        const uint64_t r0 = c.meta.resolution[0], size0 = c.meta.offset[1] - c.meta.offset[0];
-        if (r0 * r0 * r0 > size0) s->adam_in_apply = 0;
-    }
     if (const char* e = getenv("NGP_TWO_ROUND_K")) { const int k = atoi(e); if (k >= 1 && k <= 64) s->two_round_k = k; }
     (void)hipGetDevice(&s->device);
     hipError_t e = hipSuccess;
@@ -248,14 +228,6 @@ int ngp_stepper_create(const ngp_stepper_config* config, const ngp_step_buffers*
         for (int j = 0; j < 2 && e == hipSuccess; ++j) e = hipEventCreate(&s->march_t[k][j]);
     }
     for (int i = 0; i < N_MARKS && e == hipSuccess; ++i) e = hipEventCreate(&s->mark[i]);
-    if (s->lists_ahead && e == hipSuccess) {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);                  // (hi = numerically smallest = most urgent)
-        e = hipStreamCreateWithPriority(&s->aux, hipStreamNonBlocking, hi);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_pos, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_lists, hipEventDisableTiming);
-        for (int j = 0; j < 2 && e == hipSuccess; ++j) e = hipEventCreate(&s->lists_t[j]);
-    }
     if (e != hipSuccess) { ngp_stepper_destroy(s); return (int)e; }
     *out = s;
     return 0;
@@ -270,10 +242,6 @@ int ngp_stepper_destroy(ngp_stepper* s) {
         for (int j = 0; j < 2; ++j) if (s->march_t[k][j]) (void)hipEventDestroy(s->march_t[k][j]);
     }
     for (int i = 0; i < N_MARKS; ++i) if (s->mark[i]) (void)hipEventDestroy(s->mark[i]);
-    if (s->aux) { (void)hipStreamSynchronize(s->aux); (void)hipStreamDestroy(s->aux); }
-    if (s->ev_pos) (void)hipEventDestroy(s->ev_pos);
-    if (s->ev_lists) (void)hipEventDestroy(s->ev_lists);
-    for (int j = 0; j < 2; ++j) if (s->lists_t[j]) (void)hipEventDestroy(s->lists_t[j]);
     destroy_exchange_events(s);
     delete s;
     return 0;
@@ -349,7 +317,6 @@ static int forward_field(ngp_stepper* s, const float* rays_o, const float* rays_
     const int32_t S = b.counter[k][0];
     if (S < 0 || (int64_t)S > b.cap) return NGP_EINVAL;
     s->S = S; s->last_set = k; s->n_part = 0;
-    s->lists_step = s->lists_pending = false; s->lists_t_set = false;
     *k_out = k;
     if (s->two_sample_sets) {              // every later stage of this step reads the samples through s->b
         s->b.xyzs = s->samples[k].xyzs; s->b.dirs = s->samples[k].dirs; s->b.deltas = s->samples[k].deltas; s->b.ts = s->samples[k].ts;
@@ -459,18 +426,6 @@ static int backward_field(ngp_stepper* s, const float* dL_dopacity, const float*
     }
     mark(s, 5, main);
     STEP_TRY(march_next_if_at(s, AT_COMPOSITE_BW));
-    s->lists_step = s->lists_pending = false;
-    if (s->binned && s->aux) {
-        // the live samples' positions (x_act, n_active) exist from here on: the table backward's lists are built underneath the
-        // field backward, whose gradients only the slice owners read
-        STEP_HIP(hipEventRecord(s->ev_pos, main));
-        STEP_HIP(hipStreamWaitEvent(s->aux, s->ev_pos, 0));
-        if (s->timing) STEP_HIP(hipEventRecord(s->lists_t[0], s->aux));
-        STEP_TRY(ngp_hashgrid_bwd_binned_lists(b.x_act, c.xyz_min, c.xyz_max, &c.meta, S, nullptr, b.n_active, b.bin_ws, b.bin_bytes, (ngp_stream_t)s->aux));
-        if (s->timing) { STEP_HIP(hipEventRecord(s->lists_t[1], s->aux)); s->lists_t_set = true; }
-        STEP_HIP(hipEventRecord(s->ev_lists, s->aux));
-        s->lists_step = s->lists_pending = true;
-    }
     const int n_part = ngp_field_bwd_partials(S);
     if (n_part < 1 || n_part > b.max_partials) return NGP_EINVAL;
     STEP_TRY(ngp_field_bwd(b.feats, b.dirs, b.h, c.enc_half, c.rgb_half, b.dL_dsigmas, b.dL_drgbs, loss_scale, S, b.active, b.n_active,
@@ -502,7 +457,7 @@ int ngp_stepper_front(ngp_stepper* s, const float* rays_o, const float* rays_d, 
     const int n = b.n_rays;
     // composite + per-ray loss seeds, then one small kernel: offsets of the live samples and the loss sums
     b.counter[k][2] = -1;
-    const bool fused_tail = s->fused_tail && S > 0;
+    const bool fused_tail = S > 0;              // composite forward / backward without a scan kernel between them (a batch without samples: the plain pair)
     if (fused_tail) {
         STEP_TRY(ngp_composite_train_fw_loss_counts(b.sigmas, b.rgbs, b.deltas, b.ts, b.rays_a[k], c.T_threshold, n, S, b.total, b.opacity, b.depth, b.rgb,
                                                     b.ws, b.ray_offs, rgb_gt, c.bg, c.lambda_opacity, grad_scale, b.dL_drgb, b.dL_dopacity, b.fw_ws,
@@ -540,20 +495,9 @@ int ngp_stepper_render_forward(ngp_stepper* s, const float* rays_o, const float*
     *n_samples = s->S;
     const int n = b.n_rays;
     b.counter[k][2] = -1;                                    // (no live-sample count from this composite: the auto switch stays where it is)
-    s->render_tail = s->fused_tail != 0;
-    if (s->render_tail) {
-        // ONE launch: composite + the blended colour (rendering.py:153-161); the rows' live counts stay counts for render_backward
-        STEP_TRY(ngp_composite_train_fw_blend(b.sigmas, b.rgbs, b.deltas, b.ts, b.rays_a[k], c.T_threshold, n, s->S, b.total, b.opacity, b.depth, b.rgb,
-                                              b.ws, b.ray_offs, c.bg, rgb_out, main_stream));
-    } else {
-        STEP_TRY(ngp_composite_train_fw(b.sigmas, b.rgbs, b.deltas, b.ts, b.rays_a[k], c.T_threshold, n, s->S, b.total, b.opacity, b.depth, b.rgb,
-                                        b.ws, b.ray_offs, main_stream));
-        STEP_TRY(ngp_active_scan(b.ray_offs, n, b.n_active, main_stream));
-        if (rgb_out) {                                       // rendering.py:153-161: rgb + bg (1 - opacity); bg NULL = black: a copy
-            if (c.bg) STEP_TRY(ngp_bg_blend(b.rgb, b.opacity, c.bg, n, rgb_out, main_stream));
-            else STEP_HIP(hipMemcpyAsync(rgb_out, b.rgb, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, main));
-        }
-    }
+    // ONE launch: composite + the blended colour (rendering.py:153-161); the rows' live counts stay counts for render_backward
+    STEP_TRY(ngp_composite_train_fw_blend(b.sigmas, b.rgbs, b.deltas, b.ts, b.rays_a[k], c.T_threshold, n, s->S, b.total, b.opacity, b.depth, b.rgb,
+                                          b.ws, b.ray_offs, c.bg, rgb_out, main_stream));
     mark(s, 4, main);
     if (next_o) STEP_TRY(do_march(s, next_o, next_d, main, side));      // (the render-shaped halves: always behind the composite forward)
     return 0;
@@ -572,30 +516,14 @@ int ngp_stepper_render_backward(ngp_stepper* s, const float* g_rgb, const float*
     *n_partials = 0;
     if (s->S <= 0) return 0;
     const int n = b.n_rays;
-    if (s->render_tail)                                      // (the forward left counts: the backward folds blend, prefix and n_active in)
-        return backward_field(s, g_opacity, g_depth ? g_depth : b.zeros, g_rgb, g_ws, loss_scale, ngp_stream(main_stream), main_stream, n_partials, TAIL_RENDER);
-    const float* g_o = g_opacity;
-    if (c.bg) {                                              // through rgb + bg (1 - opacity): dL/do -= sum_c g_rgb[c] bg[c]
-        STEP_TRY(ngp_bg_blend_bw(g_rgb, g_opacity, c.bg, n, b.dL_dopacity, main_stream));
-        g_o = b.dL_dopacity;
-    } else if (g_o == nullptr) {
-        g_o = b.zeros;
-    }
-    return backward_field(s, g_o, g_depth ? g_depth : b.zeros, g_rgb, g_ws, loss_scale, ngp_stream(main_stream), main_stream, n_partials);
+    // the forward left live COUNTS in ray_offs: the backward folds the background blend, their prefix and n_active in
+    return backward_field(s, g_opacity, g_depth ? g_depth : b.zeros, g_rgb, g_ws, loss_scale, ngp_stream(main_stream), main_stream, n_partials, TAIL_RENDER);
 }
 
-// One launch group of the binned table backward on the main stream: behind the lists where backward_field() sent them ahead.
+// One launch group of the binned table backward on the main stream.
 static int table_backward_group(ngp_stepper* s, int n_groups, int group, ngp_grid_partials* partials_out, ngp_stream_t main_stream) {
     const ngp_stepper_config& c = s->c;
     const ngp_step_buffers& b = s->b;
-    if (s->lists_step) {
-        if (s->lists_pending) {
-            STEP_HIP(hipStreamWaitEvent(ngp_stream(main_stream), s->ev_lists, 0));
-            s->lists_pending = false;
-        }
-        return ngp_hashgrid_bwd_binned_owners(b.x_act, c.xyz_min, c.xyz_max, b.dfeats, &c.meta, s->S, nullptr, b.n_active, b.bin_ws, b.bin_bytes,
-                                              c.grid_grad16, n_groups, group, partials_out, main_stream);
-    }
     if (partials_out) return ngp_hashgrid_bwd_binned_deferred(b.x_act, c.xyz_min, c.xyz_max, b.dfeats, &c.meta, s->S, nullptr, b.n_active, b.bin_ws,
                                                               b.bin_bytes, c.grid_grad16, partials_out, main_stream);
     return ngp_hashgrid_bwd_binned_group(b.x_act, c.xyz_min, c.xyz_max, b.dfeats, &c.meta, s->S, nullptr, b.n_active, b.bin_ws, b.bin_bytes,
@@ -648,21 +576,15 @@ int ngp_stepper_backward_update(ngp_stepper* s, float lr, int32_t step, float gr
     if (s->comm) return NGP_EINVAL;                              // data parallel: ngp_stepper_tail
     const ngp_stepper_config& c = s->c;
     const ngp_step_buffers& b = s->b;
-    if (s->S <= 0 || !s->binned || !s->merge_in_adam || s->n_part < 1) {
+    if (s->S <= 0 || !s->binned || s->n_part < 1) {
         STEP_TRY(ngp_stepper_table_backward(s, 1, 0, main_stream));
         return s->S > 0 ? ngp_stepper_update(s, lr, step, grad_scale, nullptr, nullptr, 0, nullptr, nullptr, main_stream) : 0;
     }
     HostTimer host_timer(&s->t_enqueue);
     if (!c.enc_param || !c.enc_m || !c.enc_v || !c.rgb_param || !c.rgb_m || !c.rgb_v) return NGP_EINVAL;
     ngp_grid_partials gp;
-    int64_t n_streamed = c.n_grid;                               // gradient values the streaming Adam launch still has to apply
-    if (s->adam_in_apply && !s->lists_step) {
-        STEP_TRY(ngp_hashgrid_bwd_binned_adam(b.x_act, c.xyz_min, c.xyz_max, b.dfeats, &c.meta, s->S, nullptr, b.n_active, b.bin_ws, b.bin_bytes,
-                                              c.grid_grad16, &gp, c.enc_param + c.n_density, c.enc_half + c.n_density, c.enc_m + c.n_density,
-                                              c.enc_v + c.n_density, lr, c.beta1, c.beta2, c.eps, c.weight_decay, step, grad_scale, main_stream));
-        if (gp.n_levels < 1) return NGP_EUNSUP;                  // (excluded at creation)
-        n_streamed = gp.value_end;
-    } else {
+    const int64_t n_streamed = c.n_grid;                         // the whole table's gradient is applied by the streaming launch
+    {
         const int rc = table_backward_group(s, 1, 0, &gp, main_stream);
         if (rc) return rc;
     }
@@ -707,6 +629,10 @@ int ngp_stepper_set_exchange(ngp_stepper* s, ngp_comm* comm, const ngp_exchange_
     if (e == hipSuccess) e = hipEventCreate(&s->ev_x0);
     if (e == hipSuccess) e = hipEventCreate(&s->ev_x1);
     if (e == hipSuccess) e = hipEventCreate(&s->ev_m);
+    if (e != hipSuccess) { destroy_exchange_events(s); return (int)e; }
+    // the caller's flag words outlive a re-attachment (mode switch, stepper rebuild) while the parity count restarts: a flag raised
+    // by the last step before the reset must not be read again as this step's (ngp_found_inf2 only ORs into the current set)
+    e = hipMemsetAsync(x.flags, 0, 16 * sizeof(int32_t), comm->stream);
     if (e != hipSuccess) { destroy_exchange_events(s); return (int)e; }
     s->comm = comm; s->x = x; s->tails = 0; s->x_times_set = false;
     return 0;
@@ -849,12 +775,6 @@ int ngp_stepper_stage_times(ngp_stepper* s, float* ms) {
             ms[i - 1] = t;
         }
         prev = i;
-    }
-    if (s->lists_t_set && ms[6] >= 0) {          // the lists ran on the stepper's stream: their time belongs to the table backward's stage
-        STEP_HIP(hipEventSynchronize(s->lists_t[1]));
-        float t = 0.f;
-        STEP_HIP(hipEventElapsedTime(&t, s->lists_t[0], s->lists_t[1]));
-        ms[6] += t;
     }
     const int k = s->last_set;
     if (s->march_t_set[k]) {

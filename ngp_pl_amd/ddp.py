@@ -395,18 +395,27 @@ class NativeExchange(ShardedExchange):
         self._samples = []
 
     def _make_comm(self, dev):
+        """Every rank leaves through the SAME sequence of collectives whatever happens on rank 0: if the unique id cannot be made
+        there (RCCL not loadable), rank 0 still broadcasts -- an id record whose status byte says so -- and all ranks raise together
+        (a rank that raised BEFORE the broadcast would leave the others waiting in it)."""
         import ctypes as C
         from ._lib import call
-        ident = torch.zeros(128, dtype=torch.uint8)
+        ident = torch.zeros(129, dtype=torch.uint8)             # 128 bytes of id + 1 status byte (1 = valid)
+        failure = None
         if self.rank == 0:
-            buf = (C.c_ubyte * 128)()
-            call("ngp_comm_unique_id", C.cast(buf, C.c_void_p))
-            ident = torch.tensor(list(buf), dtype=torch.uint8)
+            try:
+                buf = (C.c_ubyte * 128)()
+                call("ngp_comm_unique_id", C.cast(buf, C.c_void_p))
+                ident = torch.tensor(list(buf) + [1], dtype=torch.uint8)
+            except Exception as e:          # noqa: BLE001 -- reported after the broadcast, on every rank
+                failure = e
         if self.world > 1:
             carrier = ident.to(dev) if self.dist.get_backend(self.group) == "nccl" else ident
             self.dist.broadcast(carrier, 0, group=self.group)
             ident = carrier.cpu()
-        raw = (C.c_ubyte * 128)(*ident.tolist())
+        if int(ident[128]) != 1:
+            raise RuntimeError("rank 0 could not create the RCCL unique id%s" % (": %s" % failure if failure is not None else ""))
+        raw = (C.c_ubyte * 128)(*ident[:128].tolist())
         h = C.c_void_p()
         with torch.cuda.device(dev):
             call("ngp_comm_create", C.cast(raw, C.c_void_p), self.world, self.rank, C.byref(h))

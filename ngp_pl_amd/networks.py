@@ -279,47 +279,11 @@ class NGP(nn.Module):
             decay_grid = torch.clamp(decay ** (1 / self.count_grid), 0.1, 0.95).contiguous()
         self._occ_updates = getattr(self, "_occ_updates", 0) + 1
         seed = int(getattr(self, "occ_seed", 0)) * 1000003 + self._occ_updates
-        # Draws made ahead (below): valid for exactly this update -- same seed, threshold, workspace, and a grid nobody has touched
-        # through torch since (the library's own writes do not bump the version counter; everything else does).
-        ahead = getattr(self, "_occ_ahead", None)
-        self._occ_ahead = None
-        key = (seed, float(density_threshold), ws.data_ptr(), self.density_grid.data_ptr(), self.density_grid._version)
         with torch.cuda.device(dev):
-            main = torch.cuda.current_stream()
-            if ahead is not None:
-                main.wait_event(ahead[1])                     # (also when the draws are not used: they write the workspace)
-            if ahead is not None and not warmup and ahead[0] == key:
-                call("ngp_occupancy_update_drawn", ptr(self.density_grid), ptr(self.density_bitfield), self.cascades, self.grid_size,
-                     float(self.scale), float(density_threshold), float(decay), ptr(decay_grid), seed,
-                     ptr(self.xyz_min), ptr(self.xyz_max), ptr(eh[enc.n_mlp:]), C.byref(enc.meta), ptr(eh),
-                     ptr(ws), nbytes, stream())
-            else:
-                call("ngp_occupancy_update", ptr(self.density_grid), ptr(self.density_bitfield), self.cascades, self.grid_size,
-                     float(self.scale), float(density_threshold), float(decay), ptr(decay_grid), 1 if warmup else 0, seed,
-                     ptr(self.xyz_min), ptr(self.xyz_max), ptr(eh[enc.n_mlp:]), C.byref(enc.meta), ptr(eh),
-                     ptr(ws), nbytes, stream())
-            # The NEXT update's draws depend on the grid as this update leaves it and on the next seed only: with
-            # model.occ_draw_ahead = True / NGP_OCC_DRAW_AHEAD=1 they are made now, on the model's own stream, underneath the
-            # training steps in between (7 of an update's launches, ~0.09 ms).  Not after a warm-up update (the next one is most
-            # likely warm-up too and draws nothing), not with more than one cascade (the library's draw buffers hold one).
-            # OFF by default, measured (profiles/r04_step_ab.txt): the timed windows gain 0.6 % (0.3635 / 0.3650 -> 0.3611 / 0.3627
-            # ms per step), the 30 000-step run LOSES 8 % (8.02 -> 8.72 s; +0.35 ms per update, the same with 8 hardware queues):
-            # a third stream with its two cross-stream hand-overs per update costs more than the 0.09 ms it hides.  Same bits.
-            if (not warmup and self.cascades == 1
-                    and (getattr(self, "occ_draw_ahead", False) or os.environ.get("NGP_OCC_DRAW_AHEAD", "0") == "1")):
-                side = getattr(self, "_occ_stream", None)
-                if side is None or side.device != dev:
-                    side = self._occ_stream = torch.cuda.Stream(device=dev)
-                    self._occ_events = (torch.cuda.Event(), torch.cuda.Event())
-                done, drawn = self._occ_events
-                done.record(main)
-                side.wait_event(done)
-                next_seed = seed + 1
-                call("ngp_occupancy_draw", ptr(self.density_grid), self.cascades, self.grid_size, float(self.scale), float(density_threshold),
-                     next_seed, ptr(ws), nbytes, side.cuda_stream)
-                drawn.record(side)
-                self._occ_ahead = ((next_seed, float(density_threshold), ws.data_ptr(), self.density_grid.data_ptr(), self.density_grid._version),
-                                   drawn)
+            call("ngp_occupancy_update", ptr(self.density_grid), ptr(self.density_bitfield), self.cascades, self.grid_size,
+                 float(self.scale), float(density_threshold), float(decay), ptr(decay_grid), 1 if warmup else 0, seed,
+                 ptr(self.xyz_min), ptr(self.xyz_max), ptr(eh[enc.n_mlp:]), C.byref(enc.meta), ptr(eh),
+                 ptr(ws), nbytes, stream())
 
     @torch.no_grad()
     def update_density_grid(self, density_threshold, warmup=False, decay=0.95, erode=False):

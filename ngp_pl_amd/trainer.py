@@ -2,22 +2,19 @@
 (/root/reference/train.py:159-185) + configure_optimizers (:112-139) for the default recipe
 (Synthetic-NeRF: scale 0.5, white background, no distortion loss, no pose optimisation).
 
-Two implementations of the same step:
-  * `step()`          -- the hot path: direct calls into libngp_hip.so, no autograd graph, native
-                         gradient buffers consumed by optim.FusedAdam.  12 kernel launches and one
-                         8-byte host read (the packed sample count).  The ray march of step k+1
-                         only needs the occupancy bitfield, so it runs on a SECOND HIP stream
-                         concurrently with step k's encode/MLP/backward kernels (the march is a
-                         latency-bound chain of dependent loads that occupies a fraction of the
-                         CUs) and its count lands in pinned host memory before step k+1 starts.
-  * `step_autograd()` -- the same maths through render() + NeRFLoss + torch autograd, i.e. what
-                         the reference's train.py drives; used to check the hot path (tests).
+  * `step()`          -- the hot path: the native stepper (csrc/stepper.hip), three library calls per step, no autograd
+                         graph, native gradient buffers consumed by the fused Adam.  The ray march of step k+1 only needs
+                         the occupancy bitfield, so it runs on a SECOND HIP stream concurrently with step k's
+                         encode / MLP / backward kernels and its count lands in pinned host memory before step k+1 starts.
+  * `step_autograd()` -- the same maths through render() + NeRFLoss + torch autograd, i.e. what the reference's
+                         train.py drives.
+  * `_exchange_and_update()` -- the host-side restatement of the step's tail for the torch.distributed exchanges
+                         (ddp.GradientExchange / ShardedExchange); device agnostic, driven with CPU tensors by the gloo tests.
 """
 import contextlib
 import ctypes as C
 import math
 import os
-import time
 
 import torch
 
@@ -26,15 +23,6 @@ from ._lib import call, ptr, stream
 from .losses import NeRFLoss
 from .optim import FusedAdam, cosine_lr
 from .rendering import MAX_SAMPLES, NEAR_DISTANCE, render
-
-
-def _set_current_stream(st):
-    """torch.cuda.set_stream without its bookkeeping (the context manager costs ~20 us of host time per use: two
-    current_stream() queries and two switches; this is one switch)."""
-    try:
-        torch._C._cuda_setStream(stream_id=st.stream_id, device_index=st.device_index, device_type=st.device_type)
-    except (AttributeError, TypeError):          # another torch build: the public call does the same with more bookkeeping
-        torch.cuda.set_stream(st)
 
 
 from .stepper import StepBuffers, _align        # noqa: E402,F401  (the step's buffers: shared with rendering.py's native render node)
@@ -81,13 +69,11 @@ class Trainer:
         self._buf = None                 # StepBuffers of the current batch size
         self._grid_step = -1             # global_step the occupancy grid was last brought up to date for
         self.loss_scale = tcnn.LOSS_SCALE   # factor on dL/dsigma, dL/drgb inside the f16 backward; lowered to 128 / world under DDP
-        self._march_count = "ngp_raymarching_train_count"
         # train.py:160-163: erode = (dataset_name == 'colmap'), i.e. the unbounded real scenes; needs NGP.mark_invisible_cells
         self.erode = erode
-        # The marching stream must land on its own hardware queue or nothing overlaps: HIP multiplexes streams onto
-        # a few HSA queues (GPU_MAX_HW_QUEUES, default 4) round-robin, and once RCCL has created its streams a
-        # default-priority stream was observed to share the main stream's queue (rocprofv3: every kernel on one
-        # queue_id, step 0.52 -> 0.89 ms).  High-priority streams are served from a separate queue.
+        # The marching stream must land on a hardware queue that runs NEXT TO the main stream's or nothing overlaps (a
+        # default-priority stream was observed to share the main stream's queue once RCCL had created its own: step 0.52 -> 0.89
+        # ms): a high-priority stream, and ONE per process (marching_stream above).
         self.side = marching_stream(dev) if (overlap_march and dev.type == "cuda") else None
         # seed of the march's jitter draws (custom_functions.py:83: every rank's torch.rand_like draws from its own generator): the rank
         # is mixed in so that data-parallel ranks do not jitter ray slot r alike at every step
@@ -95,20 +81,9 @@ class Trainer:
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             rank = torch.distributed.get_rank()
         self.noise_seed = (int(os.environ.get("NGP_NOISE_SEED", "20240924")) + 0x632BE59BD9B4E019 * rank) & 0xFFFFFFFFFFFFFFFF
-        self._pending = None     # marched-but-not-consumed batch
-        self._marches = 0        # marches enqueued so far (keys the jitter draw)
-        # where in the step the next batch's march is enqueued (it starts behind whatever the main stream has queued by
-        # then): "top" = next to the hash forward, "hashgrid_fwd" / "mlp_fwd" / "composite_fw" (default) / "composite_bw" / "mlp_bwd" /
-        # "hashgrid_bwd" = behind that stage.
-        # Measured in round 2 (profiles/r02_march_sweep.txt): up to "mlp_bwd" the placements were within noise of each other while the
-        # MLP backward took 68 us; with the faster MLP kernels (45 us) the march behind the composite forward -- next to the composite
-        # and MLP backward instead of the hash / field forward it slows -- is 3.5 % ahead of "mlp_fwd" (0.447 vs 0.464 ms, 3 runs each).
-        # Round 3, native stepper (profiles/r03_march_sweep.txt, three runs each on one box): behind the field forward 0.417 ms per step,
-        # behind the hash forward 0.416-0.426, composite forward 0.424, composite backward 0.422-0.427, MLP backward 0.426, top 0.429,
-        # table backward 0.44, Adam 0.47: wherever it lands the march costs the kernels next to it 17-20 us.
-        self.march_at = os.environ.get("NGP_MARCH_AT", "mlp_fwd")
-        if self.march_at not in ("top", "hashgrid_fwd", "mlp_fwd", "composite_fw", "composite_bw", "mlp_bwd", "hashgrid_bwd", "adam"):
-            raise ValueError("NGP_MARCH_AT: unknown stage %r" % self.march_at)
+        # where in the step the next batch's march is enqueued is the native stepper's business (NGP_MARCH_AT, csrc/stepper.hip;
+        # default: behind the field forward.  profiles/r02_march_sweep.txt, r03_march_sweep.txt: wherever it lands the march costs
+        # the kernels next to it 17-20 us)
         self.last = {}
         self.grad_hook = None    # called between backward and optimizer (multi-GPU gradient all-reduce)
         self.mlp_grad_hook = None  # called once the MLP gradients exist, before the hash-grid backward is enqueued
@@ -117,41 +92,28 @@ class Trainer:
         self.update_hook = None    # replaces the whole-table Adam: (lr, step, grad_scale, found_inf, stream) -- ddp.ShardedExchange
         self.native_exchange = None  # ddp.NativeExchange: the step's tail (exchange + update) is ONE library call, ngp_stepper_tail
         self._group_cache = {}
-        self._main = None        # torch's current stream while a step is being enqueued (cached: the query costs ~8 us)
-        self.events = None       # list of (stage, event) when stage timing is on (bench.py roofline)
-        self.march_ms = None
-        # the step is enqueued by the native stepper (csrc/stepper.hip: three C calls per step) unless NGP_NATIVE_STEP=0 /
-        # native_step=False selects the Python enqueue path (the same launches through ctypes, ~0.3 ms of host time per step)
-        self.native_step = bool(int(os.environ.get("NGP_NATIVE_STEP", "1"))) if native_step is None else native_step
+        self.events = None       # not None: stage timing is on (bench.py's roofline leg reads stage_times_ms() after each step)
+        self.native_step = True  # the step is enqueued by the native stepper (the Python-enqueued copy of it was removed in round 5)
+        if native_step is False:
+            raise ValueError("Trainer(native_step=False): the Python-enqueued step was removed; the native stepper is the step")
         self._stepper = None         # ngp_stepper handle
         self._stepper_key = None     # what it was built for (pointers, recipe)
         self._pending_key = None     # (rays_o ptr, rays_d ptr) of the batch whose march the native stepper holds
         self._pending_keep = None    # ... and the tensors themselves (alive until consumed)
         self._timing_on = False
-        self._late_march = self.march_at in ("hashgrid_bwd", "adam")
+        self._late_march = os.environ.get("NGP_MARCH_AT", "mlp_fwd") in ("hashgrid_bwd", "adam")
 
     # -- stage timing ----------------------------------------------------------------------------
-    def _mark(self, name):
-        if self.events is not None:
-            e = torch.cuda.Event(enable_timing=True)
-            e.record()           # torch's current stream == the stream every kernel here is launched on
-            self.events.append((name, e))
-
     STAGES = ("march_write", "hashgrid_fwd", "mlp_fwd", "composite_fw+loss", "composite_bw", "mlp_bwd", "hashgrid_bwd", "adam",
               "march_count(side stream)")
 
     def stage_times_ms(self):
         """Elapsed time between consecutive stage marks of the last profiled step (syncs)."""
-        if self.native_step and self._stepper is not None:
-            ms = (C.c_float * len(self.STAGES))()
-            call("ngp_stepper_stage_times", self._stepper, ms)
-            return [(name, float(t)) for name, t in zip(self.STAGES, ms) if t >= 0]
-        torch.cuda.synchronize()
-        ev = self.events
-        out = [(ev[i + 1][0], ev[i][1].elapsed_time(ev[i + 1][1])) for i in range(len(ev) - 1)]
-        if self.march_ms is not None:
-            out.append(("march_count(side stream)", self.march_ms[0].elapsed_time(self.march_ms[1])))
-        return out
+        if self._stepper is None:
+            return []
+        ms = (C.c_float * len(self.STAGES))()
+        call("ngp_stepper_stage_times", self._stepper, ms)
+        return [(name, float(t)) for name, t in zip(self.STAGES, ms) if t >= 0]
 
     # -- pieces --------------------------------------------------------------------------------
     def _device_guard(self, dev):
@@ -169,9 +131,6 @@ class Trainer:
     def buffers(self, n_rays):
         """The step's preallocated buffers for batches of n_rays (built on first use, rebuilt if the batch size changes)."""
         if self._buf is None or self._buf.n != n_rays:
-            if self._pending is not None:
-                self._pending["done"].synchronize()
-                self._pending = None
             if self._stepper is not None:
                 call("ngp_stepper_drop_pending", self._stepper)
                 self._pending_key = self._pending_keep = None
@@ -196,15 +155,12 @@ class Trainer:
 
     def last_march_noise(self):
         """The jitter values (R) the march of the last stepped batch used (a view of the step buffers; tests hand it to another path)."""
-        B = self._buf
-        if self.native_step and self._stepper is not None:
-            return B.noise[call("ngp_stepper_last_set", self._stepper)]
-        return B.noise[self._last_set]
+        return self._buf.noise[call("ngp_stepper_last_set", self._stepper)]
 
     @property
     def has_pending(self):
         """A march of the next batch has been enqueued ahead of its step."""
-        return self._pending is not None or self._pending_key is not None
+        return self._pending_key is not None
 
     # -- the native stepper ----------------------------------------------------------------------
     def _native_stepper(self, B):
@@ -369,213 +325,15 @@ class Trainer:
                 self._pending_key, self._pending_keep = (no_p, nd_p), next_batch
         return self.last
 
-    def _march(self, rays_o, rays_d):
-        """AABB + near clamp + pass 1 of the march (+ ray-ordered scan).  Enqueued on the side
-        stream behind everything the main stream has queued so far; the packed sample count
-        lands in pinned host memory."""
-        m = self.model
-        n = rays_o.shape[0]
-        B = self.buffers(n)
-        k = B.next_set; B.next_set ^= 1
-        P = B.p
-        main = self._main if self._main is not None else torch.cuda.current_stream()
-        st = self.side if self.side is not None else main
-        ready, done = B.ready[k], B.done[k]                 # reusable events of this record set
-        if st is not main:
-            ready.record(main)          # (event flags make no difference to the ~6 us the marker packet idles the main stream:
-            st.wait_event(ready)        #  hipEventDisableSystemFence / ReleaseToDevice measured the same)
-        sq = st.cuda_stream                      # raw handle once: torch.cuda.current_stream() costs ~8 us per call
-        B.counter_np[k][0] = -1
-        if st is not main:
-            _set_current_stream(st)
-        try:
-            t0 = t1 = None
-            if self.events is not None:
-                t0 = torch.cuda.Event(enable_timing=True); t0.record(st)
-            # AABB + near clamp + the jitter of the first sample (custom_functions.py:83: torch.rand_like) in one launch; the same
-            # counter-based draw as the native stepper's (csrc/stepper.hip), so the two enqueue paths produce the same steps
-            self._marches += 1
-            seed = (self.noise_seed + 0x9E3779B97F4A7C15 * self._marches) & 0xFFFFFFFFFFFFFFFF
-            call("ngp_ray_aabb_near_noise", ptr(rays_o), ptr(rays_d), ptr(m.center), ptr(m.half_size), NEAR_DISTANCE, n, seed,
-                 P["hits_t%d" % k], P["noise%d" % k], sq)
-            call(self._march_count, ptr(rays_o), ptr(rays_d), P["hits_t%d" % k], ptr(m.density_bitfield), m.cascades,
-                 float(m.scale), self.exp_step_factor, P["noise%d" % k], m.grid_size, MAX_SAMPLES, n, P["rays_a%d" % k], B.counter_p[k],
-                 P["scratch%d" % k], sq)
-            if self.events is not None:
-                t1 = torch.cuda.Event(enable_timing=True); t1.record(st)
-            done.record(st)
-        finally:
-            if st is not main:
-                _set_current_stream(main)
-        return dict(rays_o=rays_o, rays_d=rays_d, set=k, done=done, timing=(t0, t1) if t0 is not None else None)
-
-    def _drop_pending(self):
-        """A prefetched march that does not belong to the batch now being stepped: its kernels may still be running on the
-        marching stream and they write the record's buffers, so wait for them before anything reuses that set."""
-        if self._pending is not None:
-            self._pending["done"].synchronize()
-            self._buf.next_set = self._pending["set"]           # hand the set back
-            self._pending = None
-
     # -- the hot path --------------------------------------------------------------------------
     @torch.no_grad()
     def step(self, rays_o, rays_d, rgb_gt, next_batch=None):
         """One optimisation step on a batch of rays.  `next_batch` = (rays_o, rays_d) of the
         following step, if known: its march overlaps this step's kernels.  The tensors in the returned
         record are views of the step's preallocated buffers: valid until the next step."""
-        if self.native_step and rays_o.is_cuda:
-            return self._step_native(rays_o, rays_d, rgb_gt, next_batch)
-        if self.native_exchange is not None:
-            raise RuntimeError("a NativeExchange is installed but this step does not go through the native stepper (native_step=False or "
-                               "CPU rays): no collective would be issued and the ranks would diverge")
-        m = self.model
-        dev = rays_o.device
-        enc, net = m.xyz_encoder, m.rgb_net
-        with self._device_guard(dev):
-            main = self._main = torch.cuda.current_stream()
-            mq = main.cuda_stream
-            n = rays_o.shape[0]
-            if self._pending is not None and self._pending["rays_o"] is rays_o:
-                rec = self._pending
-            else:
-                had_pending = self._pending is not None
-                self._drop_pending()
-                if not had_pending or self._grid_step != self.global_step:
-                    self._maybe_update_grid(); self._grid_step = self.global_step
-                rec = self._march(rays_o.contiguous(), rays_d.contiguous())
-            self._pending = None
-            B = self.buffers(n)
-            P = B.p
-            k = self._last_set = rec["set"]
-            # march of the next batch: concurrent with this step unless the occupancy grid is due
-            # for an update first (that needs this step's optimizer result).  Enqueued BEFORE the
-            # host blocks on this batch's march: the marching stream then runs the marches back to
-            # back instead of idling for a host round trip (wake-up + enqueue) between them.
-            next_needs_update = (self.global_step + 1) % self.update_interval == 0
-            prefetch = next_batch is not None and not next_needs_update and next_batch[0].shape[0] == n
-
-            def march_next_if_at(stage):
-                if prefetch and self.march_at == stage and self._pending is None:
-                    self._pending = self._march(next_batch[0], next_batch[1])
-            march_next_if_at("top")
-            # the step's only host wait: the march of THIS batch.  Polled, not Event.synchronize(): the blocking wait
-            # sleeps on an interrupt and wakes tens of microseconds late, which left the main stream idle at every step.
-            # The long part of the wait polls the count word itself (pinned host memory the scan kernel writes; -1 until
-            # then): no HIP call in that loop, and the core is offered to other threads once the wait gets long.  The event
-            # query that follows is what orders the main stream's kernels behind the march (kernel-end release of its L2)
-            cnt = B.counter_np[k]
-            _lib.poll_event(rec["done"], "ngp_raymarching_train_count (record set %d, %d rays, step %d)" % (k, n, self.global_step), word=cnt)
-            if cnt[0] < 0:
-                raise RuntimeError("ngp_raymarching_train_count finished without writing its sample count")
-            S = int(cnt[0])
-            if S > B.cap:
-                raise RuntimeError("march produced %d samples for %d rays (> R * MAX_SAMPLES)" % (S, n))
-            # no main.wait_event(done): the host has just observed the event, so everything enqueued from here on is
-            # ordered behind the march already; the barrier packet measured ~20 us of idle main stream per step
-            self.march_ms = rec["timing"]
-            if self.events is not None:
-                self.events = []
-            self._mark("start")
-            ro_p, rd_p = ptr(rec["rays_o"]), ptr(rec["rays_d"])
-            rays_a = P["rays_a%d" % k]
-            call("ngp_raymarching_train_write", ro_p, rd_p, rays_a, P["scratch%d" % k],
-                 float(m.scale), self.exp_step_factor, m.grid_size, MAX_SAMPLES, n, P["xyzs"], P["dirs"], P["deltas"], P["ts"], mq)
-            self._mark("march_write")
-            eh, rh = enc._half.get(enc.params), net._half.get(net.params)
-            eh_p, rh_p = eh.data_ptr(), rh.data_ptr()
-            table_p = eh_p + 2 * enc.n_mlp
-            if S > 0:
-                call("ngp_hashgrid_fwd", P["xyzs"], ptr(m.xyz_min), ptr(m.xyz_max), table_p, C.byref(enc.meta), S, P["feats"], mq)
-                self._mark("hashgrid_fwd")
-                march_next_if_at("hashgrid_fwd")
-                call("ngp_field_fwd", P["feats"], P["dirs"], eh_p, rh_p, S, P["sigmas"], P["rgbs"], P["h"], mq)
-                self._mark("mlp_fwd")
-                march_next_if_at("mlp_fwd")
-            # composite + per-ray loss seeds; the offsets of the live samples, their total and the loss sums are formed by the
-            # composite BACKWARD's workgroups (NGP_FUSED_TAIL=0, or a batch without samples: one small kernel behind the forward)
-            fused_tail = S > 0 and os.environ.get("NGP_FUSED_TAIL", "1") != "0"
-            if fused_tail:
-                call("ngp_composite_train_fw_loss_counts", P["sigmas"], P["rgbs"], P["deltas"], P["ts"], rays_a, self.T_threshold, n, S,
-                     P["total"], P["opacity"], P["depth"], P["rgb"], P["ws"], P["ray_offs"], ptr(rgb_gt), ptr(self.bg),
-                     self.lambda_opacity, self.grad_scale, P["dL_drgb"], P["dL_dopacity"], P["fw_ws"], B.fw_bytes, mq)
-            else:
-                call("ngp_composite_train_fw_loss", P["sigmas"], P["rgbs"], P["deltas"], P["ts"], rays_a, self.T_threshold, n, S,
-                     P["total"], P["opacity"], P["depth"], P["rgb"], P["ws"], P["ray_offs"], P["n_active"], ptr(rgb_gt), ptr(self.bg),
-                     self.lambda_opacity, self.grad_scale, P["stats"], P["stats"] + 4, P["dL_drgb"], P["dL_dopacity"],
-                     P["fw_ws"], B.fw_bytes, mq)
-            self._mark("composite_fw+loss")
-            if S > 0:
-                march_next_if_at("composite_fw")
-            use_dist = self.lambda_distortion > 0
-            if S > 0:
-                # backward only over the samples up to each ray's early stop (the rest have zero gradient):
-                # composite_fw counted them per ray, the scan above placed them, composite_bw lists them
-                dL_dws = None
-                if use_dist:
-                    # losses.py:6-37,58-59: lambda * distortion per ray, mean over rays; its gradient enters the composite as dL/dws
-                    call("ngp_distortion_loss_fw", P["ws"], P["deltas"], P["ts"], rays_a, n, S, P["dist"], P["ws_incl"], P["wts_incl"], mq)
-                    seed_val = self.lambda_distortion / n * self.grad_scale
-                    if B.dist_seed_val != seed_val:
-                        B.view("dist_seed", torch.float32, n).fill_(seed_val); B.dist_seed_val = seed_val
-                    dL_dws = P["dL_dws"]
-                    call("ngp_distortion_loss_bw", P["dist_seed"], P["ws_incl"], P["wts_incl"], P["ws"], P["deltas"], P["ts"],
-                         rays_a, n, S, dL_dws, mq)
-                # the binned table backward reads the live samples' positions as a stream: composite_bw copies them in list order
-                binned = 0 < S <= B.bin_max                      # larger: occupancy warm-up, the one-pass sliced kernel takes it
-                if fused_tail:
-                    call("ngp_composite_train_bw_tail", P["dL_dopacity"], P["zeros"], P["dL_drgb"], dL_dws, P["sigmas"], P["rgbs"], P["ws"],
-                         P["deltas"], P["ts"], rays_a, P["opacity"], P["depth"], P["rgb"], self.T_threshold, n, S,
-                         P["dL_dsigmas"], P["dL_drgbs"], P["ray_offs"], P["active"], P["xyzs"] if binned else None, P["x_act"] if binned else None,
-                         P["n_active"], None, P["stats"], P["stats"] + 4, P["fw_ws"], B.fw_bytes, mq)
-                else:
-                    call("ngp_composite_train_bw", P["dL_dopacity"], P["zeros"], P["dL_drgb"], dL_dws, P["sigmas"], P["rgbs"], P["ws"],
-                         P["deltas"], P["ts"], rays_a, P["opacity"], P["depth"], P["rgb"], self.T_threshold, n, S,
-                         P["dL_dsigmas"], P["dL_drgbs"], P["ray_offs"], P["active"], P["xyzs"] if binned else None, P["x_act"] if binned else None, mq)
-                self._mark("composite_bw")
-                march_next_if_at("composite_bw")
-                n_part = call("ngp_field_bwd_partials", S)
-                assert n_part <= B.MAX_PARTIALS
-                call("ngp_field_bwd", P["feats"], P["dirs"], P["h"], eh_p, rh_p, P["dL_dsigmas"], P["dL_drgbs"], self.loss_scale, S,
-                     P["active"], P["n_active"], P["dh"], P["dfeats"], P["partials"], mq)
-                self._mark("mlp_bwd")
-                march_next_if_at("mlp_bwd")
-                g16 = m._grid_grad16(dev)
-                native = dict(grid16=g16, density_partials=B.view("partials", torch.float32, n_part * enc.n_mlp),
-                              rgb_partials=B.arena[B.off["partials"] + 4 * n_part * enc.n_mlp:
-                                                   B.off["partials"] + 4 * n_part * B.n_mlp_params].view(torch.float32),
-                              n_partials=n_part, scale=self.loss_scale)
-
-                def table_backward():
-                    if binned:
-                        # one launch group per piece of the table that is handed on separately (multi-GPU: the exchange of a finished
-                        # piece runs underneath the next group's slice owners); a single group otherwise
-                        ng = self.bwd_groups if (self.group_hook is not None and self.grad_hook is not None) else 1
-                        for g in range(ng):
-                            call("ngp_hashgrid_bwd_binned_group", P["x_act"], ptr(m.xyz_min), ptr(m.xyz_max), P["dfeats"], C.byref(enc.meta), S,
-                                 None, P["n_active"], P["bin_ws"], B.bin_bytes, ptr(g16), ng, g, mq)
-                            if ng > 1:
-                                self.group_hook(g, ng, *self._group_entries(enc.meta, S, ng, g))
-                    else:
-                        call("ngp_hashgrid_bwd_sliced", P["xyzs"], ptr(m.xyz_min), ptr(m.xyz_max), P["dfeats"], C.byref(enc.meta), S,
-                             P["active"], P["n_active"], ptr(g16), mq)
-                    self._mark("hashgrid_bwd")
-                    march_next_if_at("hashgrid_bwd")
-                self._exchange_and_update(native, table_backward, mq)
-                self._mark("adam")
-            elif self.grad_hook is not None or self.mlp_grad_hook is not None:
-                # no samples on THIS rank: the other ranks still expect it in the gradient collectives (DDP semantics:
-                # every rank joins every all-reduce), so it contributes zeros and applies the averaged update like them
-                self._exchange_and_update(self.zero_native(dev), None, mq)
-            if prefetch and self._pending is None:       # a later stage was asked for and this batch had no samples
-                self._pending = self._march(next_batch[0], next_batch[1])
-            self.global_step += 1
-            self.last = dict(stats=B.stats, rm_samples=S, total=B.total, n_rays=n, rgb=B.rgb, opacity=B.opacity,
-                             distortion=B.dist if (S > 0 and use_dist) else None, n_active=B.n_active)
-            if next_batch is not None and next_needs_update:
-                self._maybe_update_grid(); self._grid_step = self.global_step
-                self._mark("grid_update")
-                self._pending = self._march(next_batch[0], next_batch[1])
-        return self.last
+        if not rays_o.is_cuda:
+            raise RuntimeError("Trainer.step: rays on %s -- the product path has no CPU fallback" % rays_o.device)
+        return self._step_native(rays_o, rays_d, rgb_gt, next_batch)
 
     def _group_entries(self, meta, S, n_groups, group):
         """Table-entry range [begin, end) that launch group `group` of `n_groups` completes (host-side plan, cached)."""

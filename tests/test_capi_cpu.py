@@ -1,4 +1,5 @@
-"""CPU: the C-ABI library builds, loads and exports every symbol include/ngp_hip.h declares; host
+"""CPU: the C-ABI library builds, loads and exports every symbol include/ngp_hip.h (the drop-in boundary) and
+ngp_pl_amd/csrc/ngp_internal.h (library-internal launchers and white-box test hooks) declare, and nothing else; host
 side logic (argument validation, level table) works without a GPU.  No compute calls here."""
 import ctypes as C
 import math
@@ -15,15 +16,30 @@ def header_symbols():
     """The entry points a C COMPILER sees in the header (comments stripped first: round 3's header had one declaration inside a
     comment, which a regular expression over the raw text happily matched)."""
     from ngp_pl_amd import _abi
-    return sorted(_abi.parse())
+    return sorted(_abi.parse_all())
+
+
+def test_the_boundary_stays_small():
+    """include/ngp_hip.h is the drop-in boundary: the reference's 12 vren functions, the tiny-cuda-nn module operations, the
+    optimizer, the native stepper, the frame renderer, the communicator -- under 100 entry points (128 in round 4, when every
+    measured alternative was compiled into the ABI).  What the library's own translation units call in each other is declared
+    apart."""
+    from ngp_pl_amd import _abi
+    pub, internal = _abi.parse(_abi.HEADER), _abi.parse(_abi.INTERNAL_HEADER)
+    assert 80 <= len(pub) <= 100 and len(internal) <= 30, (len(pub), len(internal))
+    for name in ("ngp_ray_aabb_intersect", "ngp_ray_sphere_intersect", "ngp_packbits", "ngp_morton3D", "ngp_morton3D_invert",
+                 "ngp_raymarching_train_count", "ngp_raymarching_train_write", "ngp_raymarching_test", "ngp_composite_train_fw",
+                 "ngp_composite_train_bw", "ngp_composite_test_fw", "ngp_distortion_loss_fw", "ngp_distortion_loss_bw"):
+        assert name in pub, name                                    # binding.cpp:234-250, function by function
 
 
 def test_header_compiles_as_c99():
     """The boundary is a C ABI: a C99 translation unit that includes nothing but the header must compile without a warning."""
-    src = '#include "ngp_hip.h"\nint main(void) { return 0; }\n'
-    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-x", "c", "-"],
-                       input=src, text=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-    assert r.returncode == 0, r.stdout
+    for src in ('#include "ngp_hip.h"\nint main(void) { return 0; }\n',
+                '#include "ngp_hip.h"\n#include "../ngp_pl_amd/csrc/ngp_internal.h"\nint main(void) { return 0; }\n'):
+        r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-x", "c", "-"],
+                           input=src, text=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert r.returncode == 0, r.stdout
 
 
 def test_c_program_links_every_declared_symbol(tmp_path):
@@ -31,8 +47,8 @@ def test_c_program_links_every_declared_symbol(tmp_path):
     prototype (a mismatch between declaration and pointer type is a compile error under -Werror), links against libngp_hip.so and
     runs: ngp_abi_version() / ngp_build_arch() through the C ABI, no Python in between."""
     from ngp_pl_amd import _abi, _lib
-    protos = _abi.parse()
-    lines = ['#include "ngp_hip.h"', "#include <stdio.h>", "#include <string.h>", "int main(void) {", "    int n = 0;"]
+    protos = _abi.parse_all()
+    lines = ['#include "ngp_hip.h"', '#include "../ngp_pl_amd/csrc/ngp_internal.h"', "#include <stdio.h>", "#include <string.h>", "int main(void) {", "    int n = 0;"]
     for i, (name, pr) in enumerate(sorted(protos.items())):
         lines.append("    { %s = &%s; n += (p%d != 0); }" % (pr.c_pointer_decl("p%d" % i), name, i))
     lines += ['    printf("%d %d %s\\n", n, ngp_abi_version(), ngp_build_arch());', "    return 0;", "}"]
@@ -53,7 +69,7 @@ def test_ctypes_table_agrees_with_the_header():
     """Every hand-written argtypes list of ngp_pl_amd/_lib.py against the header's prototype: same arity, pointer where the header
     has a pointer, a scalar of the same size and kind (integer / floating) where it has a scalar."""
     from ngp_pl_amd import _abi, _lib
-    protos = _abi.parse()
+    protos = _abi.parse_all()
     problems = [m for m in (_abi.ctypes_agrees(a, protos[n]) for n, a in _lib._PROTOS.items() if n in protos) if m]
     assert not problems, "\n".join(problems)
     lib = _lib.lib()

@@ -551,122 +551,6 @@ def test_binned_backward_in_launch_groups(lib, field):
         assert covered == field.meta.total and torch.equal(out, ref)
 
 
-def test_binned_backward_lists_ahead_of_the_gradients(lib, field):
-    """ngp_hashgrid_bwd_binned_lists (pass 1 from the positions alone, every sample listed) + ngp_hashgrid_bwd_binned_owners
-    == the one-call form, which skips samples whose gradient is exactly zero on a level: a listed zero adds 0 to exact integer
-    sums, so the tables agree bit for bit -- with a third of the gradients zeroed, in launch groups, and with the dense levels
-    left as partial tables for the fused Adam (same record as _deferred)."""
-    meta = native_meta(lib)
-    n = 60000
-    x, _ = sample_points(n, seed=71)
-    g = torch.Generator().manual_seed(72)
-    dfe = (torch.randn(n, 32, generator=g) * 0.3).half()
-    dfe[torch.rand(n, generator=g) < 0.33] = 0                       # whole samples without gradient
-    dfe.view(n, 16, 2)[torch.rand(n, 16, generator=g) < 0.2] = 0     # and single levels
-    dfl = dfe.view(n, 16, 2).permute(1, 0, 2).contiguous().cuda()
-    xs = x.cuda().contiguous()
-    mnt = torch.full((3,), -0.5, device="cuda"); mxt = torch.full((3,), 0.5, device="cuda")
-    nbytes = lib.lib().ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(meta), n)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-    ref = torch.full((field.meta.total, 2), float("nan"), dtype=torch.float16, device="cuda")
-    lib.call("ngp_hashgrid_bwd_binned", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), n, None, None,
-             lib.ptr(ws), nbytes, lib.ptr(ref), lib.stream())
-    torch.cuda.synchronize()
-    side = torch.cuda.Stream()
-    for ng in (1, 3):
-        out = torch.full_like(ref, float("nan"))
-        ws.zero_()
-        torch.cuda.synchronize()
-        lib.call("ngp_hashgrid_bwd_binned_lists", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), C.byref(meta), n, None, None,
-                 lib.ptr(ws), nbytes, side.cuda_stream)                # another stream, before the gradients "exist"
-        side.synchronize()
-        for grp in range(ng):
-            lib.call("ngp_hashgrid_bwd_binned_owners", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), n, None, None,
-                     lib.ptr(ws), nbytes, lib.ptr(out), ng, grp, None, lib.stream())
-        torch.cuda.synchronize()
-        assert torch.equal(out, ref), ng
-    # partial tables for the fused Adam: the record and the tables' contents match the one-call _deferred form
-    gp_a, gp_b = lib.GridPartials(), lib.GridPartials()
-    out_a = torch.full_like(ref, float("nan")); out_b = torch.full_like(ref, float("nan"))
-    lib.call("ngp_hashgrid_bwd_binned_deferred", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), n, None, None,
-             lib.ptr(ws), nbytes, lib.ptr(out_a), C.byref(gp_a), lib.stream())
-    torch.cuda.synchronize()
-    part_a = ws.clone()
-    lib.call("ngp_hashgrid_bwd_binned_lists", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), C.byref(meta), n, None, None, lib.ptr(ws), nbytes, lib.stream())
-    lib.call("ngp_hashgrid_bwd_binned_owners", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), n, None, None,
-             lib.ptr(ws), nbytes, lib.ptr(out_b), 1, 0, C.byref(gp_b), lib.stream())
-    torch.cuda.synchronize()
-    assert gp_a.n_levels == gp_b.n_levels > 0 and gp_a.value_end == gp_b.value_end and gp_a.partial == gp_b.partial
-    lo = gp_a.value_end // 2
-    assert torch.equal(out_a[lo:], out_b[lo:]) and torch.equal(out_a[lo:], ref[lo:])
-    off = gp_a.partial - ws.data_ptr()
-    n_part_bytes = sum(int(gp_a.k_split[l]) * (int(gp_a.offset[l + 1]) - int(gp_a.offset[l])) for l in range(gp_a.n_levels)) * 8
-    assert torch.equal(part_a[off:off + n_part_bytes], ws[off:off + n_part_bytes])
-    # contract: the gradient-free pass takes no gradient pointer, the owners need one
-    with pytest.raises(RuntimeError):
-        lib.call("ngp_hashgrid_bwd_binned_owners", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), None, C.byref(meta), n, None, None,
-                 lib.ptr(ws), nbytes, lib.ptr(out_b), 1, 0, None, lib.stream())
-
-
-def test_adam_in_the_slice_owners_write_out_is_bit_identical(lib, field):
-    """ngp_hashgrid_bwd_binned_adam (the hashed levels' Adam applied by the table backward's write-out) followed by the streaming
-    launch over the K-split levels only == ngp_hashgrid_bwd_binned_deferred followed by the streaming launch over the whole table:
-    f32 masters, f16 copies, both moments and the f16 gradient table bit for bit, over three consecutive steps (moments in use)."""
-    meta = native_meta(lib)
-    n = 50000
-    n_grid = 2 * field.meta.total
-    mnt = torch.full((3,), -0.5, device="cuda"); mxt = torch.full((3,), 0.5, device="cuda")
-    nbytes = lib.lib().ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(meta), n)
-    g = torch.Generator().manual_seed(81)
-    nd, nr = 3072, 7168
-
-    def fresh():
-        gg = torch.Generator().manual_seed(82)
-        st = dict(p=(torch.rand(n_grid, generator=gg) * 2e-4 - 1e-4).cuda(), m=torch.zeros(n_grid, device="cuda"), v=torch.zeros(n_grid, device="cuda"),
-                  dp=torch.randn(nd, generator=gg).cuda(), dm=torch.zeros(nd, device="cuda"), dv=torch.zeros(nd, device="cuda"),
-                  rp=torch.randn(nr, generator=gg).cuda(), rm=torch.zeros(nr, device="cuda"), rv=torch.zeros(nr, device="cuda"))
-        st["p16"] = st["p"].half(); st["dp16"] = st["dp"].half(); st["rp16"] = st["rp"].half()
-        st["g16"] = torch.full((n_grid,), float("nan"), dtype=torch.float16, device="cuda")
-        st["ws"] = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-        return st
-    A, B = fresh(), fresh()
-    hyper = (1e-2, 0.9, 0.999, 1e-15, 0.0)
-    for step in (1, 2, 3):
-        x, _ = sample_points(n, seed=90 + step)
-        dfe = (torch.randn(n, 32, generator=g) * 0.3).half()
-        dfl = dfe.view(n, 16, 2).permute(1, 0, 2).contiguous().cuda()
-        xs = x.cuda().contiguous()
-        part = (torch.randn(2, nd + nr, generator=g) * 1e-2).cuda()          # two rows of MLP weight-gradient partials
-        pd = part[:, :nd].contiguous(); pr = part[:, nd:].contiguous()
-        for st, fused in ((A, False), (B, True)):
-            gp = lib.GridPartials()
-            if fused:
-                lib.call("ngp_hashgrid_bwd_binned_adam", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), n, None, None,
-                         lib.ptr(st["ws"]), nbytes, lib.ptr(st["g16"]), C.byref(gp), lib.ptr(st["p"]), lib.ptr(st["p16"]), lib.ptr(st["m"]),
-                         lib.ptr(st["v"]), *hyper, step, 128.0, lib.stream())
-                n_streamed = gp.value_end
-                assert 0 < n_streamed < n_grid
-            else:
-                lib.call("ngp_hashgrid_bwd_binned_deferred", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), n, None, None,
-                         lib.ptr(st["ws"]), nbytes, lib.ptr(st["g16"]), C.byref(gp), lib.stream())
-                n_streamed = n_grid
-            lib.call("ngp_adam_step_field_merge", lib.ptr(st["p"]), lib.ptr(st["p16"]), lib.ptr(st["g16"]), lib.ptr(st["m"]), lib.ptr(st["v"]), n_streamed,
-                     lib.ptr(st["dp"]), lib.ptr(st["dp16"]), lib.ptr(pd), lib.ptr(st["dm"]), lib.ptr(st["dv"]), nd,
-                     lib.ptr(st["rp"]), lib.ptr(st["rp16"]), lib.ptr(pr), lib.ptr(st["rm"]), lib.ptr(st["rv"]), nr,
-                     2, *hyper, step, 128.0, None, None, C.byref(gp), lib.stream())
-        torch.cuda.synchronize()
-        lo = gp.value_end
-        for key in ("p", "p16", "m", "v", "dp", "dp16", "dm", "dv", "rp", "rp16", "rm", "rv"):
-            assert torch.equal(A[key], B[key]), (step, key)
-        assert torch.equal(A["g16"][lo:], B["g16"][lo:]), step                # (below value_end the gradient lives in the partial tables)
-        assert float((A["p"] - fresh()["p"]).abs().max()) > 1e-3             # the steps did move the table
-    # contract: the fused form needs the partials record and an optimizer state
-    with pytest.raises(RuntimeError):
-        lib.call("ngp_hashgrid_bwd_binned_adam", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), n, None, None,
-                 lib.ptr(B["ws"]), nbytes, lib.ptr(B["g16"]), C.byref(gp), lib.ptr(B["p"]), None, lib.ptr(B["m"]), lib.ptr(B["v"]),
-                 *hyper, 1, 128.0, lib.stream())
-
-
 def test_exchange_helper_kernels(lib):
     """ngp_reduce_partials2 (both MLP blocks' partial rows in one launch) and ngp_found_inf2 (non-finite check over two
     buffers, alternating flags)."""
@@ -699,64 +583,32 @@ def test_exchange_helper_kernels(lib):
     assert int(f1) == 0
 
 
-def test_lds_resident_coarse_levels_forward_is_bit_identical(lib, field):
-    """ngp_hashgrid_fwd_lds (levels 0-2 gathered from tables resident in LDS, the measured alternative of
-    profiles/r02_hashgrid_fwd_lds_experiment.txt) produces exactly ngp_hashgrid_fwd's features for those levels."""
-    meta = native_meta(lib)
-    for n in (1, 777, 200000):
-        x, _ = sample_points(n, seed=71)
-        table_h = field.table.half().cuda()
-        ref = run_hash_fwd(lib, meta, x, table_h)
-        out = torch.zeros_like(ref)
-        xs = x.cuda().contiguous()
-        mnt = torch.full((3,), -0.5, device="cuda"); mxt = torch.full((3,), 0.5, device="cuda")
-        lib.call("ngp_hashgrid_fwd_lds", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(table_h), C.byref(meta), 3, n, lib.ptr(out), lib.stream())
-        assert torch.equal(out[:3], ref[:3]) and (out[3:] == 0).all()
-    with pytest.raises(lib.NgpError):           # level 6 is hashed and the first 7 levels do not fit a CU's LDS
-        lib.call("ngp_hashgrid_fwd_lds", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(table_h), C.byref(meta), 7, n, lib.ptr(out), lib.stream())
-
-
-_FWD_VARIANT_SCRIPT = r"""
-import ctypes as C, hashlib, math, sys, torch
-from ngp_pl_amd._lib import GridMeta, call, ptr, stream
-torch.manual_seed(0)
-meta = GridMeta()
-call("ngp_grid_meta_init", C.byref(meta), 16, 2, 19, 16, float(math.exp(math.log(2048 * 0.5 / 16) / 15)))
-R, K = 700, 41                                   # ray-ordered samples: runs of lanes in one cell on the coarse levels
-o = torch.rand(R, 1, 3, device="cuda") - 0.5
-d = torch.randn(R, 1, 3, device="cuda"); d = d / d.norm(dim=-1, keepdim=True)
-x = (o * 0.7 + d * (torch.arange(K, device="cuda").view(1, K, 1) * 1.7e-3)).clamp(-0.5, 0.5).reshape(-1, 3).contiguous()
-x[1000:1100] = x[1000]                           # a run longer than a wave
-S = x.shape[0]
-table = ((torch.rand(meta.offset[16], 2, device="cuda") - 0.5) * 0.4).half()
-mn = torch.full((3,), -0.5, device="cuda"); mx = torch.full((3,), 0.5, device="cuda")
-f = torch.zeros(16, S, 2, dtype=torch.float16, device="cuda")
-call("ngp_hashgrid_fwd", ptr(x), ptr(mn), ptr(mx), ptr(table), C.byref(meta), S, ptr(f), stream())
-n_dev = torch.tensor([S - 777], dtype=torch.int32, device="cuda")
-g = torch.zeros(16, S, 2, dtype=torch.float16, device="cuda")                       # device-sized launch (level stride = the count)
-call("ngp_hashgrid_fwd_n", ptr(x), ptr(mn), ptr(mx), ptr(table), C.byref(meta), S, ptr(n_dev), ptr(g), stream())
-lst = torch.arange(S, device="cuda", dtype=torch.int32).view(-1, 7)[::2].reshape(-1).contiguous()   # runs of 7 samples, every other one
-h = torch.zeros(16, S, 2, dtype=torch.float16, device="cuda")
-call("ngp_hashgrid_fwd_list", ptr(x), ptr(mn), ptr(mx), ptr(table), C.byref(meta), S, ptr(lst), lst.numel(), None, ptr(h), stream())
-torch.cuda.synchronize()
-assert torch.equal(h[:, lst.long()], f[:, lst.long()])
-print("DIGEST", hashlib.sha256(f.cpu().numpy().tobytes() + g.cpu().numpy().tobytes() + h.cpu().numpy().tobytes()).hexdigest())
-"""
-
-
-def test_forward_variants_agree_bit_for_bit(lib):
-    """The hash forward's cell runs (one gather per run of lanes in a cell, NGP_FWD_REUSE_MAX_RES) and its two workgroup maps
-    (NGP_FWD_MAP = balanced | pairs) are scheduling only: the features of the plain, the device-sized and the list launch are the
-    same bits under every combination (the switches are read once per process, hence child processes)."""
-    import subprocess, sys
-    digests = {}
-    for name, env in (("default", {}), ("no runs, pair map", {"NGP_FWD_REUSE_MAX_RES": "0", "NGP_FWD_MAP": "pairs"}),
-                      ("runs on the dense levels only, pair map", {"NGP_FWD_REUSE_MAX_RES": "64", "NGP_FWD_MAP": "pairs"}),
-                      ("no runs, balanced map", {"NGP_FWD_REUSE_MAX_RES": "0"}),
-                      ("device-sized launch by persistent workgroups", {"NGP_FWD_PERSIST": "1"})):
-        e = dict(os.environ); e.update(env)
-        e["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + e.get("PYTHONPATH", "")
-        r = subprocess.run([sys.executable, "-c", _FWD_VARIANT_SCRIPT], env=e, capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, (name, r.stderr[-2000:])
-        digests[name] = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0]
-    assert len(set(digests.values())) == 1, digests
+def test_forward_launch_forms_agree_bit_for_bit(lib):
+    """The hash forward's three launch forms -- host-sized (cost-balanced XCD map), device-sized (`_n`: the count and the level
+    stride come from device memory, pair map) and over an explicit sample list (`_list`: the two-round forward) -- are scheduling
+    only: the same features, bit for bit, on ray-ordered samples with runs of lanes in one cell (incl. a run longer than a wave)."""
+    import ctypes as C, math
+    from ngp_pl_amd._lib import GridMeta, call, ptr, stream
+    torch.manual_seed(0)
+    meta = GridMeta()
+    call("ngp_grid_meta_init", C.byref(meta), 16, 2, 19, 16, float(math.exp(math.log(2048 * 0.5 / 16) / 15)))
+    R, K = 700, 41
+    o = torch.rand(R, 1, 3, device="cuda") - 0.5
+    d = torch.randn(R, 1, 3, device="cuda"); d = d / d.norm(dim=-1, keepdim=True)
+    x = (o * 0.7 + d * (torch.arange(K, device="cuda").view(1, K, 1) * 1.7e-3)).clamp(-0.5, 0.5).reshape(-1, 3).contiguous()
+    x[1000:1100] = x[1000]                           # a run longer than a wave
+    S = x.shape[0]
+    table = ((torch.rand(meta.offset[16], 2, device="cuda") - 0.5) * 0.4).half()
+    mn = torch.full((3,), -0.5, device="cuda"); mx = torch.full((3,), 0.5, device="cuda")
+    f = torch.zeros(16, S, 2, dtype=torch.float16, device="cuda")
+    call("ngp_hashgrid_fwd", ptr(x), ptr(mn), ptr(mx), ptr(table), C.byref(meta), S, ptr(f), stream())
+    n = S - 777
+    n_dev = torch.tensor([n], dtype=torch.int32, device="cuda")
+    g = torch.zeros(16 * S * 2, dtype=torch.float16, device="cuda")                     # device-sized launch: level stride = the count
+    call("ngp_hashgrid_fwd_n", ptr(x), ptr(mn), ptr(mx), ptr(table), C.byref(meta), S, ptr(n_dev), ptr(g), stream())
+    assert torch.equal(g[:16 * n * 2].view(16, n, 2), f[:, :n]) and not bool(g[16 * n * 2:].any())
+    lst = torch.arange(S, device="cuda", dtype=torch.int32).view(-1, 7)[::2].reshape(-1).contiguous()   # runs of 7 samples, every other one
+    h = torch.zeros(16, S, 2, dtype=torch.float16, device="cuda")
+    call("ngp_hashgrid_fwd_list", ptr(x), ptr(mn), ptr(mx), ptr(table), C.byref(meta), S, ptr(lst), lst.numel(), None, ptr(h), stream())
+    assert torch.equal(h[:, lst.long()], f[:, lst.long()])
+    assert float(f.float().abs().sum()) > 0

@@ -322,7 +322,6 @@ def test_native_occupancy_update_matches_reference_semantics():
     enc = m.xyz_encoder
     field.density_w = enc.params.detach()[:enc.n_mlp].cpu().clone()
     field.table = enc.params.detach()[enc.n_mlp:].cpu().view(-1, 2).clone()
-    m.occ_draw_ahead = False          # this test reads an update's workspace back: the next update's draws must not be made into it meanwhile
     for warmup in (True, False):
         grid0 = torch.rand(1, cells, device="cuda", generator=g) * 12.0          # ~half the cells above thr
         grid0[0, torch.randint(cells, (5000,), device="cuda", generator=g)] = -1.0     # invisible cells stay -1
@@ -806,37 +805,6 @@ def test_gradient_exchange_at_world_size_one_is_the_identity():
         dist.destroy_process_group()
 
 
-def test_native_stepper_equals_the_python_enqueue_path():
-    """Trainer.step through the native stepper (csrc/stepper.hip: three library calls per step) and through the Python enqueue
-    path (NGP_NATIVE_STEP=0: the same launches through ctypes) from the same initialisation on the same batches, with the
-    occupancy update every 16 steps, the prefetched march on the second stream and the distortion loss: sample counts, loss
-    and EVERY parameter bit for bit after 40 steps (the jitter is the same counter-based draw in both, the table backward is
-    the exact fixed-point one, every reduction has a fixed order)."""
-    from ngp_pl_amd.trainer import Trainer
-    batches = [batch(1024, seed=900 + i) for i in range(8)]
-
-    def run(native, lambda_distortion):
-        m = make_model(seed=11)
-        tr = Trainer(m, native_step=native, lambda_distortion=lambda_distortion)
-        log = []
-        for i in range(40):
-            b, nb = batches[i % 8], batches[(i + 1) % 8]
-            out = tr.step(*b, next_batch=(nb[0], nb[1]))
-            log.append((out["rm_samples"], tr.last["stats"].tolist(), int(tr.last["n_active"].item())))
-        torch.cuda.synchronize()
-        return m, tr, log
-
-    for lam in (0.0, 1e-3):
-        ma, ta, la = run(True, lam)
-        mb, tb, lb = run(False, lam)
-        assert ta._stepper is not None and tb._stepper is None
-        assert [x[0] for x in la] == [x[0] for x in lb]
-        assert la == lb, [i for i in range(40) if la[i] != lb[i]][:5]
-        for (ka, pa), (kb, pb) in zip(ma.state_dict().items(), mb.state_dict().items()):
-            assert ka == kb and torch.equal(pa, pb), ka
-        assert la[-1][0] > 0 and la[-1][2] > 0 and la[0][0] > 20 * 1024          # full grid at first, pruned later
-
-
 def test_native_stepper_stage_times_and_timeout_code():
     """Stage timing of the native stepper (what bench.py's roofline reads): every main-stream stage and the march report a
     positive time once timing is on; a stepper asked to step a batch it has not marched refuses (NGP_EINVAL), it does not wait."""
@@ -1138,40 +1106,6 @@ def test_training_is_reproducible_run_to_run():
     assert la[-1][0] < la[0][0]                        # the occupancy grid did prune
 
 
-def test_merge_folded_into_adam_is_bit_identical():
-    """`ngp_stepper_backward_update` (the dense levels' K partial gradient tables summed by the Adam launch itself) against the
-    separate merge launch (NGP_MERGE_IN_ADAM=0), and the composite pair without the scan kernel against the pair with it
-    (NGP_FUSED_TAIL=0): same sums in the same order, the same f16 rounding -- every parameter bit for bit after 80 steps with
-    occupancy updates; the loss scalar agrees to float rounding (the fused tail adds the per-row terms in another fixed order)."""
-    import os
-    from ngp_pl_amd.trainer import Trainer
-    batches = [batch(2048, seed=2300 + i) for i in range(8)]
-
-    def run(env):
-        os.environ.update(env)
-        try:
-            m = make_model(seed=53)
-            tr = Trainer(m, warmup_steps=32)
-            losses = []
-            for i in range(80):
-                b, nb = batches[i % 8], batches[(i + 1) % 8]
-                out = tr.step(*b, next_batch=(nb[0], nb[1]))
-                losses.append((out["rm_samples"], int(tr.last["n_active"].item()), tr.last["stats"].tolist()))
-            torch.cuda.synchronize()
-            return m, losses
-        finally:
-            for k in env:
-                os.environ.pop(k, None)
-    ma, la = run({})
-    for env in ({"NGP_MERGE_IN_ADAM": "0"}, {"NGP_FUSED_TAIL": "0"}, {"NGP_MERGE_IN_ADAM": "0", "NGP_FUSED_TAIL": "0"}):
-        mb, lb = run(env)
-        assert [x[:2] for x in la] == [x[:2] for x in lb], env
-        for (sa, sb) in zip(la, lb):
-            assert all(abs(p - q) <= 1e-5 * abs(p) + 1e-12 for p, q in zip(sa[2], sb[2])), (env, sa, sb)
-        for (ka, pa), (kb, pb) in zip(ma.state_dict().items(), mb.state_dict().items()):
-            assert ka == kb and torch.equal(pa, pb), (env, ka)
-
-
 def test_work_moved_off_the_main_stream_is_bit_identical():
     """Two sets of packed-sample buffers (`ngp_stepper_set_sample_sets`, the default): the march of the next batch also EXPANDS its
     samples on the marching stream, into the set the running step does not read.  Same kernel, same inputs, another stream: every
@@ -1197,21 +1131,13 @@ def test_work_moved_off_the_main_stream_is_bit_identical():
                 log.append((out["rm_samples"], int(tr.last["n_active"].item()), tr.last["stats"].tolist(),
                             float(sv["deltas"].double().sum()), float(sv["xyzs"].double().sum())))
             torch.cuda.synchronize()
-            assert (getattr(m, "_occ_ahead", None) is not None) == (env.get("NGP_OCC_DRAW_AHEAD", "0") == "1")
             return m, log, sets, tr._buf.two_sets
         finally:
             for k in env:
                 os.environ.pop(k, None)
     ma, la, sa, two_a = run({})
     assert two_a and set(sa) == {0, 1}
-    # ... and the same for the table backward's lists built on the stepper's own stream underneath the field backward
-    # (NGP_LISTS_AHEAD=1; the default builds them in front of the slice owners on the main stream, skipping zero-gradient samples)
-    # ... and for the hashed levels' Adam applied by the table backward's write-out (NGP_ADAM_IN_APPLY=1) against the streaming
-    # launch over the whole table (the default)
-    # ... and for the occupancy update's draws made ahead on the model's own stream (NGP_OCC_DRAW_AHEAD=1; updates 48 and 64 of
-    # this run use them) against the update as one call (the default)
-    for env in ({"NGP_TWO_SAMPLE_SETS": "0"}, {"NGP_LISTS_AHEAD": "1"}, {"NGP_ADAM_IN_APPLY": "1"}, {"NGP_OCC_DRAW_AHEAD": "1"},
-                {"NGP_TWO_SAMPLE_SETS": "0", "NGP_ADAM_IN_APPLY": "1", "NGP_OCC_DRAW_AHEAD": "1"}):
+    for env in ({"NGP_TWO_SAMPLE_SETS": "0"},):
         mb, lb, sb, two_b = run(env)
         assert two_b == ("NGP_TWO_SAMPLE_SETS" not in env)
         assert la == lb, (env, [i for i in range(80) if la[i] != lb[i]][:5])
@@ -1239,69 +1165,3 @@ def test_set_sample_sets_contract():
     assert math.isfinite(tr.metrics()["loss"]) and out2["rm_samples"] > 0
 
 
-def test_occupancy_draws_made_ahead_equal_the_one_call_update():
-    """`ngp_occupancy_draw` + `ngp_occupancy_update_drawn` == `ngp_occupancy_update(warmup=0)`: grid, bitfield and the workspace's
-    drawn cells / positions / scattered densities bit for bit; draws made for another seed, threshold or grid are not used (the
-    model falls back to the one-call update and gives the same result); a grid somebody wrote through torch invalidates them."""
-    import ctypes as C
-    from ngp_pl_amd import _lib
-    from ngp_pl_amd._lib import call, ptr
-    thr = 0.01 * 1024 / 3 ** 0.5
-    ma, mb = make_model(seed=67), make_model(seed=67)
-    g = torch.Generator(device="cuda").manual_seed(5)
-    cells = ma.grid_size ** 3
-    grid0 = torch.rand(1, cells, device="cuda", generator=g) * 12.0
-    grid0[0, torch.randint(cells, (3000,), device="cuda", generator=g)] = -1.0
-    ma.occ_draw_ahead, mb.occ_draw_ahead = False, True
-    for m in (ma, mb):
-        m.density_grid.copy_(grid0)
-    for rnd in range(3):
-        ma.update_density_grid(thr, warmup=False)                  # one call
-        had = getattr(mb, "_occ_ahead", None) is not None
-        mb.update_density_grid(thr, warmup=False)                  # rounds 1, 2: finishes the draws the previous round made
-        assert had == (rnd > 0)
-        torch.cuda.synchronize()
-        assert torch.equal(ma.density_grid, mb.density_grid) and torch.equal(ma.density_bitfield, mb.density_bitfield), rnd
-    # the draws waiting for round 3 are dropped when somebody writes the grid through torch ...
-    for m in (ma, mb):
-        m.density_grid.mul_(0.5)
-    ma.update_density_grid(thr, warmup=False); mb.update_density_grid(thr, warmup=False)
-    torch.cuda.synchronize()
-    assert torch.equal(ma.density_grid, mb.density_grid) and torch.equal(ma.density_bitfield, mb.density_bitfield)
-    # ... or asks for another threshold
-    ma.update_density_grid(0.5 * thr, warmup=False); mb.update_density_grid(0.5 * thr, warmup=False)
-    torch.cuda.synchronize()
-    assert torch.equal(ma.density_grid, mb.density_grid) and torch.equal(ma.density_bitfield, mb.density_bitfield)
-    # the two library calls by hand against the one call, workspace included
-    mb.occ_draw_ahead = False
-    mb.update_density_grid(thr, warmup=False); ma.update_density_grid(thr, warmup=False)       # (drops mb's pending draws, same state again)
-    torch.cuda.synchronize()
-    enc_a, enc_b = ma.xyz_encoder, mb.xyz_encoder
-    n = ma._occ_ws.numel()
-    seed = 424242
-    before = ma.density_grid.clone()
-    eh = enc_a._half.get(enc_a.params)
-    call("ngp_occupancy_update", ptr(ma.density_grid), ptr(ma.density_bitfield), 1, ma.grid_size, 0.5, thr, 0.95, None, 0, seed,
-         ptr(ma.xyz_min), ptr(ma.xyz_max), ptr(eh[enc_a.n_mlp:]), C.byref(enc_a.meta), ptr(eh), ptr(ma._occ_ws), n, _lib.stream())
-    ehb = enc_b._half.get(enc_b.params)
-    side = torch.cuda.Stream()
-    torch.cuda.synchronize()
-    call("ngp_occupancy_draw", ptr(mb.density_grid), 1, mb.grid_size, 0.5, thr, seed, ptr(mb._occ_ws), n, side.cuda_stream)
-    side.synchronize()
-    call("ngp_occupancy_update_drawn", ptr(mb.density_grid), ptr(mb.density_bitfield), 1, mb.grid_size, 0.5, thr, 0.95, None, seed,
-         ptr(mb.xyz_min), ptr(mb.xyz_max), ptr(ehb[enc_b.n_mlp:]), C.byref(enc_b.meta), ptr(ehb), ptr(mb._occ_ws), n, _lib.stream())
-    torch.cuda.synchronize()
-    assert not torch.equal(before, ma.density_grid)
-    assert torch.equal(ma.density_grid, mb.density_grid) and torch.equal(ma.density_bitfield, mb.density_bitfield)
-    (ia, xa, ta), (ib, xb, tb) = _occ_workspace_views(ma), _occ_workspace_views(mb)
-    n_drawn = cells // 2
-    # (inside a block of cells the evaluation ORDER is whatever the placement's LDS cursor hands out; the drawn cells, their
-    #  positions and the scattered densities are not)
-    for half in (slice(0, n_drawn // 2), slice(n_drawn // 2, n_drawn)):
-        oa, ob = torch.argsort(ia[half].long() * 4 + 0, stable=True), torch.argsort(ib[half].long() * 4 + 0, stable=True)
-        assert torch.equal(ia[half][oa], ib[half][ob])
-        assert torch.allclose(xa[half].abs().sum(0, dtype=torch.float64), xb[half].abs().sum(0, dtype=torch.float64), rtol=1e-9, atol=0)
-    assert torch.equal(ta, tb)
-    # contract: warm-up and several cascades have no two-call form
-    with pytest.raises(RuntimeError):
-        call("ngp_occupancy_draw", ptr(mb.density_grid), 2, mb.grid_size, 0.5, thr, seed, ptr(mb._occ_ws), n, _lib.stream())

@@ -257,21 +257,6 @@ def test_rejects_cpu_and_noncontiguous(vren):
         vren.morton3D(y)
 
 
-def test_serial_chain_march_is_bit_identical_too():
-    """The default pass-1 kernel is the wave-per-ray one (march_train_count_wave_kernel); NGP_MARCH_WAVE=0 selects the
-    serial-chain kernel (16 rays per wave): the same oracle and golden comparisons must hold bit for bit for it too.  The
-    switch is read once per process, hence the child interpreter."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, NGP_MARCH_WAVE="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_vren_gpu.py::test_raymarching_train", "tests/test_golden.py",
-                        "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"], cwd=root, env=env, stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT, text=True, timeout=600)
-    assert r.returncode == 0 and "9 passed" in r.stdout, r.stdout[-2000:]
-
-
 def test_marching_guards_end_rays_that_would_never_end(vren):
     """Rays whose far hit is infinite (or whose t is so large that a step is absorbed by rounding) make the reference's loops
     (raymarching.cu:225-232) spin for ever.  Here every marching kernel ends such a ray, leaves the other rays of the
