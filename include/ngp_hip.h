@@ -513,6 +513,15 @@ int ngp_get_rays(const float* directions, const float* c2w, int n, float* rays_o
 /* ---- occupancy-grid maintenance -------------------------------------------------------- */
 
 
+/* NGP.mark_invisible_cells (networks.py:197-238; train.py:155-158 runs it once before training): for every cell of every
+ * cascade, count_grid (C, G^3) f32 = the fraction of the n_cams training cameras that have the cell centre inside their image at
+ * depth >= near_distance, density_grid (C, G^3) f32 = 0 where that fraction is > 0 and no camera has the centre inside its image
+ * closer than near_distance, else -1 (such cells are never marched nor updated).  K (3,3) f32 intrinsics, poses (n_cams,3,4) f32
+ * camera-to-world, both on the device; grids in Morton order.  n_cams <= 3000. */
+int ngp_mark_invisible_cells(const float* K, const float* poses, int n_cams, int img_w, int img_h, float near_distance,
+                             int cascades, int grid_size, float scale, float* count_grid, float* density_grid,
+                             ngp_stream_t stream);
+
 /* NGP.update_density_grid (networks.py:240-269 with get_all_cells :155-167 and
  * sample_uniform_and_occupied_cells :169-195) in one call, no host sync:
  *   per cascade: warmup ? every cell : G^3/4 uniform cells + G^3/4 cells uniform over

@@ -375,20 +375,34 @@ __device__ __forceinline__ bool lattice_tile_const_dt(float t_start, float dt, i
 //   4. writes the visited occupied candidates' t to the ray's scratch row (coalesced, ranked by popcount).
 // A skip that leaves the tile carries its landing value into the following tiles.  tools/march_parallel_proto.py is
 // this algorithm in numpy against the oracle.  8192 rays = 8192 waves instead of 512 serial chains of dependent loads.
-template <bool SIMPLE>
+// PROLOGUE (the native stepper's march): the wave also forms its ray's hit interval and jitter -- render()'s prologue
+// (rendering.py:27-29: one box, one hit, near clamp; custom_functions.py:83: the jitter draw), the arithmetic of ray_aabb_near_kernel
+// -- instead of reading them from a launch of their own, and leaves them in hits_out / noise_out for whoever reads them later.
+struct MarchPrologue { const float* center; const float* half_size; float near_distance; uint32_t seed_lo, seed_hi; float* hits_out; float* noise_out; };
+template <bool SIMPLE, bool PROLOGUE>
 __global__ void __launch_bounds__(256)
 march_train_count_wave_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                               const float* __restrict__ hits_t, const float* __restrict__ noise,
                               MarchParams p, int max_samples, int n_rays,
-                              int64_t* __restrict__ rays_a, float* __restrict__ t_scratch) {
+                              int64_t* __restrict__ rays_a, float* __restrict__ t_scratch, int32_t* __restrict__ counts, MarchPrologue pro) {
     // the ray index is wave-uniform; saying so keeps the ray, its hit interval and the whole tile walk on the scalar unit
     const int r = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const int lane = threadIdx.x & 63;
     if (r >= n_rays) return;
     const Ray ray = load_ray(rays_o, rays_d, r);
-    float t1 = hits_t[2 * r];
-    const float t2 = hits_t[2 * r + 1];
-    if (t1 >= 0) t1 = fmaf(calc_dt(t1, p), noise[r], t1);
+    float t1, t2, jitter;
+    if (PROLOGUE) {
+        const float2 t = aabb_hit(ray.ox, ray.oy, ray.oz, ray.ix, ray.iy, ray.iz, pro.center[0], pro.center[1], pro.center[2],
+                                  pro.half_size[0], pro.half_size[1], pro.half_size[2]);
+        t1 = -1.0f; t2 = -1.0f;
+        if (t.y > 0) { t1 = fmaxf(t.x, 0.0f); t2 = t.y; }
+        if (t1 >= 0 && t1 < pro.near_distance) t1 = pro.near_distance;
+        jitter = (float)(ngp_pcg_hash(ngp_rng_key(pro.seed_lo, pro.seed_hi, (uint32_t)r)) >> 8) * (1.0f / 16777216.0f);
+        if (lane == 0) { reinterpret_cast<float2*>(pro.hits_out)[r] = make_float2(t1, t2); pro.noise_out[r] = jitter; }
+    } else {
+        t1 = hits_t[2 * r]; t2 = hits_t[2 * r + 1]; jitter = noise[r];
+    }
+    if (t1 >= 0) t1 = fmaf(calc_dt(t1, p), jitter, t1);
     float* __restrict__ row = t_scratch + (size_t)r * max_samples;
     int n = 0;
     float t_start = t1;
@@ -479,6 +493,7 @@ march_train_count_wave_kernel(const float* __restrict__ rays_o, const float* __r
     if (lane == 0) {
         rays_a[3 * (size_t)r] = r;
         rays_a[3 * (size_t)r + 2] = n;
+        if (counts) counts[r] = n;                      // the same counts as a dense i32 array: what the self-prefixing expansion sums
     }
 }
 
@@ -534,14 +549,49 @@ march_train_write_kernel(const float* __restrict__ rays_o, const float* __restri
                          float* __restrict__ xyzs, float* __restrict__ dirs,
                          float* __restrict__ deltas, float* __restrict__ ts,
                          int first_k, int32_t* __restrict__ list_k, int32_t* __restrict__ n_clear,
-                         const int32_t* __restrict__ offs_k) {
+                         const int32_t* __restrict__ offs_k, const int32_t* __restrict__ counts = nullptr,
+                         int64_t* __restrict__ rays_a_out = nullptr, int32_t* __restrict__ counter = nullptr) {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (first_k > 0 && blockIdx.x == 0 && threadIdx.x == 0 && n_clear) *n_clear = 0;
     const bool in = wave < n_rays;
-    const int64_t r = in ? rays_a[3 * (size_t)wave] : 0;
-    const int64_t start = in ? rays_a[3 * (size_t)wave + 1] : 0;
-    const int n = in ? (int)rays_a[3 * (size_t)wave + 2] : 0;
+    int64_t r, start; int n;
+    if (counts != nullptr) {
+        // SELF-PREFIXING form (the native stepper's march: no scan kernel in between).  Rays are packed in ray order, so ray w's first
+        // sample sits at the sum of the counts of the rays in front of it: the workgroup (4 rays) sums counts[0 .. 4 blockIdx) itself --
+        // 16-byte loads from a dense i32 array the L2 holds (<= 32 KB, 33 MB over the whole launch) -- and publishes the total to the
+        // host (pinned counter, system scope) from the LAST workgroup as soon as it has it, before any expansion work.
+        __shared__ int s_part[4];
+        const int first = (int)blockIdx.x * 4;              // rays [first, first + 4) are this workgroup's
+        int acc = 0;
+        for (int i = (int)threadIdx.x * 4; i < first; i += 1024) {
+            const int4 v = *reinterpret_cast<const int4*>(counts + i);
+            acc += (v.x + v.y) + (v.z + v.w);
+        }
+        acc = ngp_wave_sum_i32(acc);
+        if (lane == 0) s_part[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        int base = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+        const int w_in = (int)(threadIdx.x >> 6);
+        int mine = 0, total = base;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = (first + j < n_rays) ? counts[first + j] : 0;
+            if (j < w_in) base += c;
+            if (j == w_in) mine = c;
+            total += c;
+        }
+        r = wave; start = base; n = in ? mine : 0;
+        if (in && lane == 0) rays_a_out[3 * (size_t)wave + 1] = start;      // (ray id and count were written by the count kernel)
+        if (counter != nullptr && first + 4 >= n_rays && threadIdx.x == 0) {
+            __hip_atomic_store(counter + 1, n_rays, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(counter, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    } else {
+        r = in ? rays_a[3 * (size_t)wave] : 0;
+        start = in ? rays_a[3 * (size_t)wave + 1] : 0;
+        n = in ? (int)rays_a[3 * (size_t)wave + 2] : 0;
+    }
     if (first_k > 0 && in) {
         if (offs_k) { if (lane < min(n, first_k)) list_k[offs_k[wave] + lane] = (int32_t)(start + lane); }       // compact, in ray order
         else if (lane < first_k) list_k[(size_t)wave * first_k + lane] = lane < n ? (int32_t)(start + lane) : -1;
@@ -1122,11 +1172,11 @@ int ngp_raymarching_train_count_k(const float* rays_o, const float* rays_d, cons
         // gpurun sweep of round 2: the step time is the same for every placement, the marching stream is busy a third as long).
         const dim3 grid(ngp_div_up((long long)n_rays * 64, 256));
         if (p.simple)
-            hipLaunchKernelGGL(march_train_count_wave_kernel<true>, grid, dim3(256), 0, ngp_stream(stream),
-                               rays_o, rays_d, hits_t, noise, p, max_samples, n_rays, rays_a, t_scratch);
+            hipLaunchKernelGGL((march_train_count_wave_kernel<true, false>), grid, dim3(256), 0, ngp_stream(stream),
+                               rays_o, rays_d, hits_t, noise, p, max_samples, n_rays, rays_a, t_scratch, (int32_t*)nullptr, MarchPrologue{});
         else
-            hipLaunchKernelGGL(march_train_count_wave_kernel<false>, grid, dim3(256), 0, ngp_stream(stream),
-                               rays_o, rays_d, hits_t, noise, p, max_samples, n_rays, rays_a, t_scratch);
+            hipLaunchKernelGGL((march_train_count_wave_kernel<false, false>), grid, dim3(256), 0, ngp_stream(stream),
+                               rays_o, rays_d, hits_t, noise, p, max_samples, n_rays, rays_a, t_scratch, (int32_t*)nullptr, MarchPrologue{});
     }
     hipLaunchKernelGGL(march_train_scan_kernel, dim3(1), dim3(1024), 0, ngp_stream(stream), rays_a, n_rays, counter, first_k, offs_k);
     return NGP_LAUNCH_RESULT();
@@ -1144,6 +1194,38 @@ int ngp_raymarching_train_write(const float* rays_o, const float* rays_d, const 
     hipLaunchKernelGGL(march_train_write_kernel, dim3(ngp_div_up((long long)n_rays * 64, 256)), dim3(256), 0, ngp_stream(stream),
                        rays_o, rays_d, rays_a, t_scratch, p, max_samples, n_rays, xyzs, dirs, deltas, ts, 0, (int32_t*)nullptr,
                        (int32_t*)nullptr, (const int32_t*)nullptr);
+    return NGP_LAUNCH_RESULT();
+}
+
+// The native stepper's march: prologue + count in one launch, prefix + expansion in the next (two launches where the API-shaped
+// sequence ngp_ray_aabb_near_noise -> ngp_raymarching_train_count [count, scan] -> ngp_raymarching_train_write has four); the same
+// arithmetic, the same packing.  counter (pinned host memory, >= 2 x i32) receives {S, R} from the last workgroup of the second
+// launch BEFORE it expands its samples: a host that polls it can size the forward's launches while the expansion still runs.
+int ngp_march_train_fused(const float* rays_o, const float* rays_d, const float* center, const float* half_size,
+                          float near_distance, uint64_t seed, const uint8_t* density_bitfield, int cascades, float scale,
+                          float exp_step_factor, int grid_size, int max_samples, int n_rays,
+                          float* hits_t, float* noise, int64_t* rays_a, int32_t* counts, int32_t* counter, float* t_scratch,
+                          float* xyzs, float* dirs, float* deltas, float* ts, ngp_stream_t stream) {
+    if (n_rays < 1 || cascades < 1 || grid_size < 1 || grid_size > 1024 || max_samples < 1) return NGP_EINVAL;
+    NGP_CHECK_PTR(rays_o); NGP_CHECK_PTR(rays_d); NGP_CHECK_PTR(center); NGP_CHECK_PTR(half_size); NGP_CHECK_PTR(density_bitfield);
+    NGP_CHECK_PTR(hits_t); NGP_CHECK_PTR(noise); NGP_CHECK_PTR(rays_a); NGP_CHECK_PTR(counts); NGP_CHECK_PTR(counter); NGP_CHECK_PTR(t_scratch);
+    NGP_CHECK_PTR(xyzs); NGP_CHECK_PTR(dirs); NGP_CHECK_PTR(deltas); NGP_CHECK_PTR(ts);
+    if (reinterpret_cast<uintptr_t>(counts) & 15) return NGP_EINVAL;               // (the prefix reads it 16 bytes at a time)
+    const MarchParams p = make_march_params(density_bitfield, cascades, grid_size, scale, scale, exp_step_factor, max_samples);
+    MarchPrologue pro;
+    pro.center = center; pro.half_size = half_size; pro.near_distance = near_distance;
+    pro.seed_lo = (uint32_t)seed; pro.seed_hi = (uint32_t)(seed >> 32); pro.hits_out = hits_t; pro.noise_out = noise;
+    const dim3 grid(ngp_div_up((long long)n_rays * 64, 256));
+    if (p.simple)
+        hipLaunchKernelGGL((march_train_count_wave_kernel<true, true>), grid, dim3(256), 0, ngp_stream(stream),
+                           rays_o, rays_d, (const float*)nullptr, (const float*)nullptr, p, max_samples, n_rays, rays_a, t_scratch, counts, pro);
+    else
+        hipLaunchKernelGGL((march_train_count_wave_kernel<false, true>), grid, dim3(256), 0, ngp_stream(stream),
+                           rays_o, rays_d, (const float*)nullptr, (const float*)nullptr, p, max_samples, n_rays, rays_a, t_scratch, counts, pro);
+    const MarchParams pw = make_march_params(nullptr, 1, grid_size, scale, scale, exp_step_factor, max_samples);
+    hipLaunchKernelGGL(march_train_write_kernel, grid, dim3(256), 0, ngp_stream(stream),
+                       rays_o, rays_d, (const int64_t*)rays_a, (const float*)t_scratch, pw, max_samples, n_rays, xyzs, dirs, deltas, ts, 0, (int32_t*)nullptr,
+                       (int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)counts, rays_a, counter);
     return NGP_LAUNCH_RESULT();
 }
 

@@ -53,6 +53,12 @@ __device__ __forceinline__ float ngp_wave_sum(float v) {
     return v;
 }
 
+__device__ __forceinline__ int ngp_wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 // Exclusive scan across a workgroup (up to 1024 threads) where every thread owns ITEMS consecutive counts (v, already
 // loaded: all of a tile's loads are in flight together, one memory latency per tile of blockDim.x*ITEMS counts).
 // Returns the exclusive prefix of the thread's first item, carry-in included; *s_carry is advanced by the tile

@@ -86,6 +86,19 @@ int ngp_field_fwd_n(const ngp_half* feats, const float* dirs,
                     const int32_t* n_dev, float* sigmas, float* rgbs, ngp_half* h_out,
                     ngp_stream_t stream);
 
+/* The native stepper's march as TWO launches: (1) render()'s prologue (one box, near clamp; the jitter draw keyed by (seed, ray)) +
+ * pass 1 of the march by the same waves (hits_t (R,2), noise (R), rays_a[:,0] and [:,2], counts (R) i32 = the rays' sample counts,
+ * t_scratch); (2) pass 2 whose workgroups prefix `counts` themselves (rays_a[:,1]), write {S, R} to `counter` -- pinned host
+ * memory, system-scope stores from the last workgroup BEFORE it expands, so a polling host can size the forward's launches while
+ * the expansion runs -- and expand the samples into xyzs / dirs / deltas / ts (caller-allocated for the worst case it accepts;
+ * S > capacity is the caller's to check before reading).  The same arithmetic and packing as ngp_ray_aabb_near_noise +
+ * ngp_raymarching_train_count + ngp_raymarching_train_write; counts must be 16-byte aligned. */
+int ngp_march_train_fused(const float* rays_o, const float* rays_d, const float* center, const float* half_size,
+                          float near_distance, uint64_t seed, const uint8_t* density_bitfield, int cascades, float scale,
+                          float exp_step_factor, int grid_size, int max_samples, int n_rays,
+                          float* hits_t, float* noise, int64_t* rays_a, int32_t* counts, int32_t* counter, float* t_scratch,
+                          float* xyzs, float* dirs, float* deltas, float* ts, ngp_stream_t stream);
+
 /* ngp_raymarching_train_count that also prepares the compact first-round list of the two-round forward: offs_k (n_rays, i32) =
  * exclusive scan of min(N, first_k) in ray order, counter[3] = its total (counter then holds 4 x i32).  offs_k NULL: exactly
  * ngp_raymarching_train_count. */

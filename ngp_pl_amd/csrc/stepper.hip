@@ -66,15 +66,13 @@ struct ngp_stepper {
     int64_t group_end[16] = {};           // values (2 x entries) the first g + 1 launch groups of the binned backward complete
     // packed samples in two sets (ngp_stepper_set_sample_sets): set k belongs to march record set k, so that the expansion of a
     // prefetched march (pass 2: march_train_write) can run on the marching stream while the running step still reads its own set
-    // pass 1 of the binned table backward (the per-slice sample lists) needs the live samples' positions, not their gradients: with
-    // NGP_LISTS_AHEAD=1 it runs on the stepper's own stream underneath the field backward.  Measured and NOT the default
-    // (profiles/r04_step_ab.txt): 0.364 -> 0.410 ms per step -- the field backward's workgroups hold 115 / 146 KB of a CU's 160 KB
-    // of LDS, so one binning workgroup (33 KB) fits beside them where four run when the pass has the CU to itself, the pass takes
-    // 3-4x as long, the field backward 59 -> 75 us, and the slice owners wait for both.  Same bits either way.
     struct SampleSet { float* xyzs; float* dirs; float* deltas; float* ts; };
     SampleSet samples[2] = {};
     bool two_sample_sets = false;
     bool expanded[2] = {false, false};    // record set k: its samples are already written (by the march, on its stream)
+    int32_t* counts[2] = {nullptr, nullptr};   // per record set: the rays' sample counts as a dense i32 array (ngp_march_train_fused's prefix input)
+    int counts_rays = 0;
+    bool same_stream[2] = {false, false};  // record set k was marched on the main stream itself (render() without a next batch)
 };
 
 void destroy_exchange_events(ngp_stepper* s);
@@ -110,7 +108,7 @@ inline void mark(ngp_stepper* s, int i, hipStream_t st) {
 
 // Bounded host wait for the march of record set k: first the pinned count word (no HIP call in that loop), then the
 // event, which is what orders the caller's following launches behind the march.
-int wait_march(ngp_stepper* s, int k) {
+int wait_march(ngp_stepper* s, int k, bool count_is_enough = false) {
     volatile int32_t* cnt = s->b.counter[k];
     const auto t_begin = std::chrono::steady_clock::now();
     struct Account { ngp_stepper* s; std::chrono::steady_clock::time_point t0;
@@ -123,6 +121,9 @@ int wait_march(ngp_stepper* s, int k) {
             if (std::chrono::steady_clock::now() > t_end) return NGP_ETIMEOUT;
         }
     }
+    // marched on the main stream itself: what the caller enqueues next is ordered behind the march by the stream, and the count
+    // (published before the expansion) is all the host needs -- it sizes the forward's launches while the expansion still runs
+    if (count_is_enough && s->same_stream[k] && cnt[0] >= 0) return 0;
     hipError_t e;
     while ((e = hipEventQuery(s->done[k])) == hipErrorNotReady) {
         if ((++spins & 255u) == 0 && std::chrono::steady_clock::now() > t_end) return NGP_ETIMEOUT;
@@ -141,6 +142,15 @@ int march_at_from_env() {
         return (int)AT_MLP_FWD;
     }();
     return v;
+}
+
+int ensure_counts(ngp_stepper* s) {
+    const int n = s->b.n_rays;
+    if (s->counts[0] != nullptr && s->counts_rays >= n) return 0;
+    for (int k = 0; k < 2; ++k) { if (s->counts[k]) (void)hipFree(s->counts[k]); s->counts[k] = nullptr; }
+    for (int k = 0; k < 2; ++k) STEP_HIP(hipMalloc(reinterpret_cast<void**>(&s->counts[k]), ((size_t)n + 8) * sizeof(int32_t)));
+    s->counts_rays = n;
+    return 0;
 }
 
 int do_march(ngp_stepper* s, const float* rays_o, const float* rays_d, hipStream_t main, hipStream_t side);
@@ -163,7 +173,26 @@ int do_march(ngp_stepper* s, const float* rays_o, const float* rays_d, hipStream
     }
     b.counter[k][0] = -1;
     s->march_t_set[k] = false;
+    s->same_stream[k] = side == main;
     if (s->timing) STEP_HIP(hipEventRecord(s->march_t[k][0], side));
+    const bool lists_wanted = (s->two_round_mode == 1 || (s->two_round_mode == 2 && s->two_round_active)) && b.list_k && b.list_rest &&
+                              b.two_round_counts && b.offs_k[k];
+    if (s->two_sample_sets && !lists_wanted) {
+        // TWO launches: prologue + count, prefix + expansion into this record set's own sample buffers (the running step reads the
+        // other set).  The count reaches the pinned word from the second launch's last workgroup before it expands.
+        STEP_TRY(ensure_counts(s));
+        const ngp_stepper::SampleSet& w = s->samples[k];
+        s->set_k[k] = 0;
+        STEP_TRY(ngp_march_train_fused(rays_o, rays_d, c.center, c.half_size, c.near_distance, c.noise_seed + 0x9E3779B97F4A7C15ull * (++s->marches),
+                                       c.density_bitfield, c.cascades, c.scale, c.exp_step_factor, c.grid_size, c.max_samples, b.n_rays,
+                                       b.hits_t[k], b.noise[k], b.rays_a[k], s->counts[k], b.counter[k], b.scratch[k],
+                                       w.xyzs, w.dirs, w.deltas, w.ts, (ngp_stream_t)side));
+        s->expanded[k] = true;
+        if (s->timing) { STEP_HIP(hipEventRecord(s->march_t[k][1], side)); s->march_t_set[k] = true; }
+        STEP_HIP(hipEventRecord(s->done[k], side));
+        s->has_pending = true; s->pend_o = rays_o; s->pend_d = rays_d; s->pend_set = k;
+        return 0;
+    }
     STEP_TRY(ngp_ray_aabb_near_noise(rays_o, rays_d, c.center, c.half_size, c.near_distance, b.n_rays, c.noise_seed + 0x9E3779B97F4A7C15ull * (++s->marches),
                                      b.hits_t[k], b.noise[k], (ngp_stream_t)side));
     // (two-round forward: the scan kernel also places every ray's first K samples in the compact first-round list)
@@ -242,6 +271,7 @@ int ngp_stepper_destroy(ngp_stepper* s) {
         for (int j = 0; j < 2; ++j) if (s->march_t[k][j]) (void)hipEventDestroy(s->march_t[k][j]);
     }
     for (int i = 0; i < N_MARKS; ++i) if (s->mark[i]) (void)hipEventDestroy(s->mark[i]);
+    for (int k = 0; k < 2; ++k) if (s->counts[k]) (void)hipFree(s->counts[k]);
     destroy_exchange_events(s);
     delete s;
     return 0;
@@ -312,7 +342,7 @@ static int forward_field(ngp_stepper* s, const float* rays_o, const float* rays_
     // enqueued from here on is ordered behind the march (the barrier packet measured ~20 us of idle main stream per step).
     // On NGP_ETIMEOUT the march stays pending: its kernels may still be writing record set k, so the set must not be handed to
     // another march (do_march refuses while one is pending; a later front() of the same batch waits again).
-    STEP_TRY(wait_march(s, k));
+    STEP_TRY(wait_march(s, k, true));
     s->has_pending = false;
     const int32_t S = b.counter[k][0];
     if (S < 0 || (int64_t)S > b.cap) return NGP_EINVAL;

@@ -235,29 +235,39 @@ class NGP(nn.Module):
 
     @torch.no_grad()
     def mark_invisible_cells(self, K, poses, img_wh, chunk=64 ** 3):
-        """density_grid = -1 for cells no training camera sees or that are closer than the near
-        plane to one; run once before training (networks.py:197-238)."""
+        """density_grid = -1 for cells no training camera sees or that are closer than the near plane to one, count_grid = the
+        fraction of cameras covering a cell; run once before training (networks.py:197-238, train.py:155-158).  On the GPU one
+        launch (`ngp_mark_invisible_cells`: a thread per cell walks the cameras, poses in LDS).  CPU tensors take the statement
+        of the same rule in torch below: host logic the CPU suite pins to the reference's own output
+        (tests/test_reference_python_cpu.py); `chunk` only bounds that path's temporaries."""
         n_cams = poses.shape[0]
         self.count_grid = torch.zeros_like(self.density_grid)
-        w2c_R = poses[:, :3, :3].transpose(1, 2)
-        w2c_T = -w2c_R @ poses[:, :3, 3:]
-        cells = self.get_all_cells()
-        for c in range(self.cascades):
-            indices, coords = cells[c]
+        if self.density_grid.is_cuda:
+            dev = self.density_grid.device
+            Kd = K.to(device=dev, dtype=torch.float32).contiguous()
+            Pd = poses[:, :3, :4].to(device=dev, dtype=torch.float32).contiguous()
+            with torch.cuda.device(dev):
+                call("ngp_mark_invisible_cells", ptr(Kd), ptr(Pd), n_cams, int(img_wh[0]), int(img_wh[1]), NEAR_DISTANCE,
+                     self.cascades, self.grid_size, float(self.scale), ptr(self.count_grid), ptr(self.density_grid), stream())
+            return
+        # camera frame of every cell centre: p_cam = R^T (x - t); image coordinates (u, v) = (K p_cam)_xy / depth
+        world_to_cam = poses[:, :3, :3].transpose(1, 2)
+        cam_origin = -world_to_cam @ poses[:, :3, 3:]
+        W, H = img_wh
+        for c, (cell_idx, cell_xyz) in enumerate(self.get_all_cells()):
             s = min(2 ** (c - 1), self.scale)
-            half_grid_size = s / self.grid_size
-            for i in range(0, len(indices), chunk):
-                xyzs = coords[i:i + chunk] / (self.grid_size - 1) * 2 - 1
-                xyzs_w = (xyzs * (s - half_grid_size)).T
-                uvd = K @ (w2c_R @ xyzs_w + w2c_T)
-                uv = uvd[:, :2] / uvd[:, 2:]
-                in_image = (uvd[:, 2] >= 0) & (uv[:, 0] >= 0) & (uv[:, 0] < img_wh[0]) & (uv[:, 1] >= 0) & (uv[:, 1] < img_wh[1])
-                covered = (uvd[:, 2] >= NEAR_DISTANCE) & in_image
-                count = covered.sum(0) / n_cams
-                self.count_grid[c, indices[i:i + chunk]] = count
-                too_near = ((uvd[:, 2] < NEAR_DISTANCE) & in_image).any(0)
-                valid = (count > 0) & (~too_near)
-                self.density_grid[c, indices[i:i + chunk]] = torch.where(valid, 0., -1.)
+            span = s - s / self.grid_size
+            for lo in range(0, len(cell_idx), chunk):
+                idx = cell_idx[lo:lo + chunk]
+                centres = ((cell_xyz[lo:lo + chunk] / (self.grid_size - 1) * 2 - 1) * span).T
+                proj = K @ (world_to_cam @ centres + cam_origin)                       # (cams, 3, cells): u*d, v*d, d
+                depth = proj[:, 2]
+                u, v = proj[:, 0] / depth, proj[:, 1] / depth
+                inside = (depth >= 0) & (u >= 0) & (u < W) & (v >= 0) & (v < H)
+                seen_by = (inside & (depth >= NEAR_DISTANCE)).sum(0) / n_cams
+                clipped = (inside & (depth < NEAR_DISTANCE)).any(0)
+                self.count_grid[c, idx] = seen_by
+                self.density_grid[c, idx] = torch.where((seen_by > 0) & ~clipped, 0., -1.)
 
     @torch.no_grad()
     def _update_density_grid_native(self, density_threshold, warmup, decay, erode):

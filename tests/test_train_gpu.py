@@ -549,6 +549,47 @@ def test_hdr_branch_and_unbounded_scene_smoke():
     assert int(torch.count_nonzero(big.density_bitfield)) > 0
 
 
+def test_mark_invisible_cells_kernel_matches_the_references_python():
+    """`ngp_mark_invisible_cells` (NGP.mark_invisible_cells on the GPU: one launch) against what the reference's OWN
+    networks.py:197-238 produced for the same intrinsics / poses on a 32^3, three-cascade grid (tests/golden/render_golden.npz,
+    recorded by running the reference's Python on the CPU): density_grid 0 / -1 and the per-cell camera counts, cell for cell.
+    (Both sides evaluate K R^T (x - t) in float32 with different association; a cell whose projection lands within rounding of an
+    image border or of the near plane may flip: at most 4 of the 98 304 cells.)  And against the product's torch statement of
+    the same rule at the training configuration (scale 16, 6 cascades, 128^3, 40 cameras)."""
+    import os
+    from ngp_pl_amd.networks import NGP
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "render_golden.npz"))
+    m = NGP(scale=2.0)
+    m.grid_size = 32
+    m.register_training_buffers()
+    m = m.cuda()
+    m.mark_invisible_cells(torch.from_numpy(G["vis_K"]), torch.from_numpy(G["vis_poses"]), (64, 64))
+    got_d, got_c = m.density_grid.cpu().numpy().astype(np.int8), np.round(m.count_grid.cpu().numpy() * 6).astype(np.uint8)
+    assert got_d.shape == G["vis_density_grid"].shape
+    assert int((got_d != G["vis_density_grid"]).sum()) <= 4 and int((got_c != G["vis_count_grid"]).sum()) <= 4
+    assert 0 < int((got_d < 0).sum()) < got_d.size
+    # the bench's unbounded recipe: kernel vs the torch statement on the same device tensors
+    from ngp_pl_amd import synthetic as syn
+    big = NGP(scale=16.0).cuda()
+    big.register_training_buffers()
+    K = syn.intrinsics(200).cuda()
+    poses = syn.hemisphere_poses(40, radius=4.0, seed=3, min_elev_deg=5.0, max_elev_deg=40.0).cuda()
+    big.mark_invisible_cells(K, poses, (200, 200))
+    d_k, c_k = big.density_grid.clone(), big.count_grid.clone()
+    ref = NGP(scale=16.0)
+    ref.register_training_buffers()
+    import ngp_pl_amd.vren as vren
+    real = vren.morton3D
+    vren.morton3D = lambda coords: torch.from_numpy(syn.morton3D_np(coords.numpy())).int()
+    try:
+        ref.mark_invisible_cells(K.cpu(), poses.cpu(), (200, 200))
+    finally:
+        vren.morton3D = real
+    assert float((d_k.cpu() != ref.density_grid).float().mean()) < 1e-4
+    assert float(((c_k.cpu() - ref.count_grid).abs() > 1e-6).float().mean()) < 1e-4
+    assert 0.05 < float((d_k < 0).float().mean()) < 0.95
+
+
 def test_erode_reaches_the_occupancy_update_through_the_trainer():
     """train.py:160-163: `erode = (dataset_name == 'colmap')` is handed to update_density_grid every 16 steps; with it the
     decay is per cell, clamp(0.95 ** (1 / count_grid), 0.1, 0.95) (networks.py:262-264), count_grid from

@@ -150,6 +150,54 @@ def test_raymarching_test(vren, oracle, cfg):
         same_bits(h_gpu, h_cpu, "hits_t ns=%d" % ns)
 
 
+@pytest.mark.parametrize("scale,cascades,esf,n", [(0.5, 1, 0.0, 8192), (2.0, 3, 1 / 256, 3001), (16.0, 6, 1 / 256, 2050)])
+def test_the_steppers_two_launch_march_equals_the_api_shaped_sequence(vren, oracle, scale, cascades, esf, n):
+    """ngp_march_train_fused (prologue + count in one launch, prefix + expansion in the next: what the native stepper enqueues) against
+    ngp_ray_aabb_near_noise -> ngp_raymarching_train_count -> ngp_raymarching_train_write, the sequence that mirrors the reference's
+    API (and which the tests above hold to the oracle bit for bit): hit intervals, jitter, (ray, start, count) triples, the pinned
+    {S, R} record and every packed sample, bit for bit; ray counts that are not a multiple of the 4 rays a workgroup takes."""
+    import ctypes as C
+    from ngp_pl_amd import _lib
+    from ngp_pl_amd._lib import call, ptr, stream
+    g = np.random.RandomState(5)
+    ro = ((g.rand(n, 3) - 0.5) * 3.0 * scale).astype(np.float32)
+    tgt = ((g.rand(n, 3) - 0.5) * scale).astype(np.float32)
+    rd = tgt - ro; rd /= np.linalg.norm(rd, axis=1, keepdims=True); rd[: n // 9] *= -1          # some rays miss the box
+    bf = syn.random_blob_bitfield(cascades, 128, 0.15, seed=11)
+    ro_d, rd_d, bf_d = dev(ro), dev(rd.astype(np.float32)), dev(bf)
+    centre, half = torch.zeros(1, 3).cuda(), torch.full((1, 3), scale).cuda()
+    seed, near, M = 0x1234567890ABCDEF, 0.01, 1024
+    f32, i32 = dict(dtype=torch.float32, device="cuda"), dict(dtype=torch.int32, device="cuda")
+    # the API-shaped sequence
+    hits_a, noise_a = torch.empty(n, 2, **f32), torch.empty(n, **f32)
+    rays_a_a = torch.empty(n, 3, dtype=torch.int64, device="cuda"); scratch_a = torch.empty(n * M, **f32)
+    counter_a = torch.full((4,), -1, dtype=torch.int32).pin_memory()
+    call("ngp_ray_aabb_near_noise", ptr(ro_d), ptr(rd_d), ptr(centre), ptr(half), near, n, seed, ptr(hits_a), ptr(noise_a), stream())
+    call("ngp_raymarching_train_count", ptr(ro_d), ptr(rd_d), ptr(hits_a), ptr(bf_d), cascades, scale, esf, ptr(noise_a), 128, M, n,
+         ptr(rays_a_a), counter_a.data_ptr(), ptr(scratch_a), stream())
+    torch.cuda.synchronize()
+    S = int(counter_a[0])
+    assert S > 1000 and int(counter_a[1]) == n
+    out_a = [torch.empty(S, 3, **f32), torch.empty(S, 3, **f32), torch.empty(S, **f32), torch.empty(S, **f32)]
+    call("ngp_raymarching_train_write", ptr(ro_d), ptr(rd_d), ptr(rays_a_a), ptr(scratch_a), scale, esf, 128, M, n, *[ptr(t) for t in out_a], stream())
+    # the stepper's two launches
+    hits_b, noise_b = torch.empty(n, 2, **f32), torch.empty(n, **f32)
+    rays_a_b = torch.empty(n, 3, dtype=torch.int64, device="cuda"); scratch_b = torch.empty(n * M, **f32)
+    counts = torch.full((n + 8,), -7, **i32)
+    counter_b = torch.full((4,), -1, dtype=torch.int32).pin_memory()
+    cap = S + 4096
+    out_b = [torch.zeros(cap, 3, **f32), torch.zeros(cap, 3, **f32), torch.zeros(cap, **f32), torch.zeros(cap, **f32)]
+    call("ngp_march_train_fused", ptr(ro_d), ptr(rd_d), ptr(centre), ptr(half), near, seed, ptr(bf_d), cascades, scale, esf, 128, M, n,
+         ptr(hits_b), ptr(noise_b), ptr(rays_a_b), ptr(counts), counter_b.data_ptr(), ptr(scratch_b), *[ptr(t) for t in out_b], stream())
+    torch.cuda.synchronize()
+    assert counter_b[:2].tolist() == [S, n]
+    assert torch.equal(hits_a.view(torch.int32), hits_b.view(torch.int32)) and torch.equal(noise_a, noise_b)
+    assert torch.equal(rays_a_a, rays_a_b) and torch.equal(counts[:n].long(), rays_a_a[:, 2]) and bool((counts[n:] == -7).all())
+    for a, b, name in zip(out_a, out_b, ("xyzs", "dirs", "deltas", "ts")):
+        assert torch.equal(a.view(torch.int32), b[:S].view(torch.int32)), name
+        assert not bool(b[S:].any()), name + ": written past S"
+
+
 def _packed(oracle, n=8192, seed=6):
     ro, rd = make_rays(n, seed=seed)
     bf = syn.random_blob_bitfield(1, 128, 0.1, seed=seed)
