@@ -1,84 +1,70 @@
-"""Scratch: where a training step's wall time goes that no stage accounts for (VERDICT r04 "What's weak" 9).
-From a rocprofv3 --kernel-trace run (rocpd .db) of `bench.py --timed-only`: over the last N steps (step = from the end of one
-grid-Adam launch to the end of the next), per step
-  wall            end-to-end
-  main_busy       sum of kernel durations on the main stream's queue (the queue the Adam launch is on)
-  main_idle       wall - main_busy, split into: idle while an occupancy-update kernel or the march of the NEXT batch is what the main
-                  stream waits for, and launch gaps (< 12 us holes between consecutive main-queue kernels)
-and the same averaged separately over steps with / without an occupancy update.
-Usage: step_gaps.py <results.db> [n_steps=64] > profiles/r05_step_gaps.txt"""
-import re
-import sqlite3
+"""Where a training step's wall time goes that no stage accounts for (VERDICT r04 "What's weak" 9: ms_per_step 0.388 vs a
+main-stream stage sum of 0.341).  Measured IN PROCESS, no tracer attached (under rocprofv3 every launch costs the host ~10x more and
+the loop turns host-bound: the traced walls are 2.4 ms per step, useless for this question):
+  * one HIP event per step on the main stream over 640 steps -> device time of a step by its position in the 16-step occupancy cycle
+    (the update runs at the head of step k = 0 mod 16, the march of that batch can only start behind it);
+  * then 64 steps with the stepper's stage marks -> stage sum of the same steps, and the march's own span on its stream.
+Prints the budget: wall = stage sum + per-step launch gaps + amortised update + amortised exposed march.
+Usage (GPU box): python tools/step_gaps.py > profiles/r05_step_gaps.txt"""
+import os
 import sys
+import time
 
+import torch
 
-def short(name):
-    name = re.sub(r"\(anonymous namespace\)::", "", name)
-    m = re.match(r"_ZN12_GLOBAL__N_1\d+([A-Za-z_0-9]+?)(I[LbEi0-9]+E)?Ev?P", name)
-    if m:
-        return m.group(1)
-    name = re.sub(r"^void ", "", name)
-    return re.sub(r"[(<].*", "", name)[:60]
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench  # noqa: E402
 
-
-db = sqlite3.connect(sys.argv[1])
-n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
-qcol = "queue_id" if "queue_id" in cols else "stream_id"
-rows = [(short(n), s, e, q) for n, s, e, q in db.execute("select name, start, end, %s from kernels order by start" % qcol)]
-marks = [i for i, r in enumerate(rows) if r[0].startswith("adam_field")]
-marks = marks[-(n_steps + 1):]
-mainq = rows[marks[-1]][3]
-OCC = ("occ_", "density_grid_update", "packbits", "fillBuffer")
-steps = []
-for a, b in zip(marks[:-1], marks[1:]):
-    t0, t1 = rows[a][2], rows[b][2]
-    sel = [r for r in rows[a + 1:b + 1]]
-    main = [r for r in sel if r[3] == mainq]
-    side = [r for r in sel if r[3] != mainq]
-    busy = sum(r[2] - r[1] for r in main)
-    has_occ = any(r[0].startswith(OCC) for r in sel)
-    occ_busy = 0
-    if has_occ:          # everything on the main queue from the update's first kernel to its packbits (its hash / density forward included)
-        names = [r[0] for r in main]
-        first = next(k for k, n in enumerate(names) if n.startswith(OCC))
-        last = max(k for k, n in enumerate(names) if n.startswith(OCC))
-        occ_busy = sum(r[2] - r[1] for r in main[first:last + 1])
-    # holes on the main queue
-    holes, prev = [], t0
-    for r in main:
-        if r[1] > prev:
-            holes.append((prev, r[1]))
-        prev = max(prev, r[2])
-    small = sum(h[1] - h[0] for h in holes if h[1] - h[0] < 12e3)
-    big = [(h[0], h[1]) for h in holes if h[1] - h[0] >= 12e3]
-    # what runs on the other queues during the big holes
-    cover = {}
-    for h0, h1 in big:
-        for r in side:
-            ov = min(h1, r[2]) - max(h0, r[1])
-            if ov > 0:
-                cover[r[0]] = cover.get(r[0], 0) + ov
-    steps.append(dict(wall=t1 - t0, busy=busy, small=small, big=sum(h[1] - h[0] for h in big), occ=has_occ, occ_busy=occ_busy, cover=cover,
-                      n_main=len(main), side_busy=sum(r[2] - r[1] for r in side)))
-
-
-def avg(sel, key):
-    return sum(s[key] for s in sel) / max(len(sel), 1) / 1e3
-
-
-print("# %d steps; main queue = %s.  us per step (mean)" % (len(steps), mainq))
-print("%-28s %6s %9s %10s %12s %12s %10s %8s" % ("steps", "count", "wall", "main_busy", "holes<12us", "holes>=12us", "occ_kernels", "launches"))
-for label, sel in (("all", steps), ("without occupancy update", [s for s in steps if not s["occ"]]), ("with occupancy update", [s for s in steps if s["occ"]])):
-    print("%-28s %6d %9.1f %10.1f %12.1f %12.1f %10.1f %8.1f" % (label, len(sel), avg(sel, "wall"), avg(sel, "busy"), avg(sel, "small"), avg(sel, "big"),
-                                                              avg(sel, "occ_busy"), sum(s["n_main"] for s in sel) / max(len(sel), 1)))
-tot = {}
-for s in steps:
-    for k, v in s["cover"].items():
-        tot[k] = tot.get(k, 0) + v
-print("# kernels on the other queues that run during the main queue's holes >= 12 us (us per step, mean over ALL steps):")
-for k, v in sorted(tot.items(), key=lambda kv: -kv[1])[:8]:
-    print("  %-44s %8.1f" % (k, v / len(steps) / 1e3))
-wall_all = avg(steps, "wall")
-print("# amortised: occupancy-update steps add %.1f us per step on average (wall of update steps - wall of plain steps) / %d" % (
-    (avg([s for s in steps if s["occ"]], "wall") - avg([s for s in steps if not s["occ"]], "wall")) * len([s for s in steps if s["occ"]]) / max(len(steps), 1), 1))
+argv, sys.argv = sys.argv, sys.argv[:1]
+try:
+    args = bench.parse()
+finally:
+    sys.argv = argv
+dev = torch.device("cuda:0")
+torch.cuda.set_device(0)
+loop = bench.Loop("lego", args, dev, 0, 1, None)
+loop.steps(528)                                  # the bench's operating point (320 setup + warm-up + the timed windows' first steps)
+n = 640
+torch.cuda.synchronize()
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+t0 = time.perf_counter()
+ev[0].record()
+for i in range(n):
+    loop.steps(1)
+    ev[i + 1].record()
+torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / n * 1e3
+gs0 = loop.trainer.global_step - n
+dt = [ev[i].elapsed_time(ev[i + 1]) for i in range(n)]
+by_pos = {}
+for i in range(n):
+    by_pos.setdefault((gs0 + i) % 16, []).append(dt[i])
+mean = lambda v: sum(v) / max(len(v), 1)         # noqa: E731
+plain = mean([x for p, v in by_pos.items() if p not in (0, 15) for x in v])
+print("# lego, 8192 rays, steps %d..%d, no tracer.  wall %.4f ms per step (host clock around the loop); device time per step by position in the" % (gs0, gs0 + n, wall))
+print("# 16-step occupancy cycle (the update is enqueued at the END of step 15's call, in front of step 0's march):")
+print("position   " + " ".join("%6d" % p for p in range(16)))
+print("device ms  " + " ".join("%6.3f" % mean(by_pos[p]) for p in range(16)))
+cycle = sum(mean(by_pos[p]) for p in range(16))
+print("# mean over the cycle %.4f ms; plain steps (positions 1..14) %.4f ms -> the update cycle costs %.1f us per step amortised" % (
+    cycle / 16, plain, (cycle / 16 - plain) * 1e3))
+# stage marks over 64 more steps
+tr = loop.trainer
+tr.events = []
+acc, cnt = {}, 0
+for i in range(64):
+    loop.steps(1)
+    if (tr.global_step - 1) % 16 in (0, 15):
+        continue                                 # plain steps only
+    cnt += 1
+    for name, ms in tr.stage_times_ms():
+        acc[name] = acc.get(name, 0.0) + ms
+tr.events = None
+stages = {k: v / cnt for k, v in acc.items()}
+main_sum = sum(v for k, v in stages.items() if not k.startswith("march_count"))
+print("# stage marks (plain steps, %d of them): %s" % (cnt, ", ".join("%s %.4f" % (k, v) for k, v in stages.items())))
+print("# main-stream stage sum %.4f ms; plain-step device time %.4f ms -> %.1f us per step between / around the stages (event marks themselves, launch gaps," % (
+    main_sum, plain, (plain - main_sum) * 1e3))
+print("#   the wait for the march's count at the top of the step when the march finishes after the previous step's Adam)")
+print("# budget per step: stage sum %.1f + gaps %.1f + update cycle %.1f = %.1f us; measured wall %.1f us" % (
+    main_sum * 1e3, (plain - main_sum) * 1e3, (cycle / 16 - plain) * 1e3, cycle / 16 * 1e3, wall * 1e3))
