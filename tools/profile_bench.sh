@@ -9,7 +9,7 @@ REPO="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$REPO/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 20 --warmup 5 --no-render --no-cpu-baseline --no-api --no-full-run"
+BENCH="python $REPO/bench.py --steps 20 --warmup 5 --no-render --no-cpu-baseline --no-api --no-full-run --no-secondary"
 rocprofv3 -L 2>/dev/null | grep -E "^\s*(Name|Counter)?\s*:?\s*(SQ_|TCC_|TCP_|GRBM_|FETCH|WRITE)" | head -400 > "$OUT/counters_available.txt" 2>&1
 # 1. kernel trace of the driver's command shape (timed windows last in the trace)
 rm -rf /tmp/kt && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt -o bench -- $BENCH --timed-only > "$OUT/bench_under_trace.json" 2> "$OUT/trace.err"
