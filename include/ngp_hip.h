@@ -738,6 +738,17 @@ int ngp_comm_reduce_scatter(ngp_comm* c, const void* send, void* recv, int64_t r
 /* recv (world x send_count) = the ranks' send buffers in rank order; in place when send == recv + rank x send_count */
 int ngp_comm_all_gather(ngp_comm* c, const void* send, void* recv, int64_t send_count, int dtype, ngp_stream_t stream);
 int ngp_comm_broadcast(ngp_comm* c, void* buf, int64_t n_bytes, int root, ngp_stream_t stream);
+/* Point-to-point forms (xGMI is a full mesh of point-to-point links; a ring collective is bound by one of them).
+ * _exchange_slices: slice q of send (world x count) goes straight to rank q, rank q's contribution lands in recv + q x count; the
+ *   own slice is not copied.  The data movement of a reduce-scatter without its additions: the caller sums the world slices itself
+ *   (ngp_sum_slices_f16: in rank order, in f32 -- deterministic).
+ * _all_gather_direct: in place; this rank's slice buf + rank x count goes to every peer, theirs arrive at buf + q x count.
+ * Both are ONE RCCL group of world - 1 sends and receives; no-ops at world 1. */
+int ngp_comm_exchange_slices(ngp_comm* c, const void* send, void* recv, int64_t count, int dtype, ngp_stream_t stream);
+int ngp_comm_all_gather_direct(ngp_comm* c, void* buf, int64_t count, int dtype, ngp_stream_t stream);
+/* out[i] (f16) = round(sum over q = 0 .. world-1, in that order, in f32, of (q == rank ? own[i] : stage[q x count + i])). */
+int ngp_sum_slices_f16(const ngp_half* own, const ngp_half* stage, int world, int rank, int64_t count, ngp_half* out,
+                       ngp_stream_t stream);
 
 /* The tail of a data-parallel step, enqueued natively: with an exchange installed, ngp_stepper_tail replaces
  * ngp_stepper_table_backward + ngp_stepper_update.  Per step, EVERY rank issues the same sequence (a rank whose batch had no
@@ -752,6 +763,10 @@ int ngp_comm_broadcast(ngp_comm* c, void* buf, int64_t n_bytes, int root, ngp_st
  *   mode 1 ("sharded", default): the optimizer pass is divided by the world size and what is gathered is the table the next
  *     forward reads; a rank's f32 master / moments are current inside its own pieces only.
  *   mode 0 ("allreduce"): the reference's semantics literally -- gradient all-reduce only, every rank updates everything.
+ *   mode 2 ("direct", round 5; n_chunks must be 1): mode 1 with the two ring collectives replaced by point-to-point transfers over
+ *     all xGMI links at once: ngp_comm_exchange_slices moves every peer's slice of this rank's share into `stage`, ngp_sum_slices_f16
+ *     adds the world slices in rank order in f32 (deterministic; the ring adds f16 in ring order), Adam runs on the share, and
+ *     ngp_comm_all_gather_direct sends the updated f16 share to every peer.
  * Buffers are the caller's: grad_padded / table_padded must be the stepper's grid_grad16 / enc_half + n_density, allocated with
  * n_chunks x world x piece values (padding zero). */
 typedef struct ngp_exchange_config {
@@ -762,6 +777,7 @@ typedef struct ngp_exchange_config {
     float* small;                  /* (n_density + n_rgb) f32 */
     int32_t* flags;                /* 16 x i32, zeroed once by the caller */
     int32_t* step_state;           /* 4 x i32 (ngp_adam_step_field), zeroed / set to the steps taken once by the caller */
+    ngp_half* stage;               /* mode 2: (world x piece) f16 landing area of the peers' slices; NULL otherwise */
 } ngp_exchange_config;
 /* comm NULL (config ignored): back to the single-process tail.  The communicator must outlive the stepper or be detached first. */
 int ngp_stepper_set_exchange(ngp_stepper* s, ngp_comm* comm, const ngp_exchange_config* config);

@@ -60,7 +60,7 @@ class GridPartials(C.Structure):
 class ExchangeConfig(C.Structure):
     """ngp_exchange_config (include/ngp_hip.h)."""
     _fields_ = [("mode", C.c_int32), ("n_chunks", C.c_int32), ("n_groups", C.c_int32), ("reserved", C.c_int32), ("piece", C.c_int64),
-                ("grad_padded", P), ("table_padded", P), ("shard16", P), ("small", P), ("flags", P), ("step_state", P)]
+                ("grad_padded", P), ("table_padded", P), ("shard16", P), ("small", P), ("flags", P), ("step_state", P), ("stage", P)]
 
 
 # name -> argtypes (every function returns int, except the two queries noted below)
@@ -129,6 +129,9 @@ _PROTOS = {
     "ngp_comm_reduce_scatter": [P, P, P, L, I, P],
     "ngp_comm_all_gather": [P, P, P, L, I, P],
     "ngp_comm_broadcast": [P, P, L, I, P],
+    "ngp_comm_exchange_slices": [P, P, P, C.c_int64, I, P],
+    "ngp_comm_all_gather_direct": [P, P, C.c_int64, I, P],
+    "ngp_sum_slices_f16": [P, P, I, I, C.c_int64, P, P],
     "ngp_stepper_set_exchange": [P, P, C.POINTER(ExchangeConfig)],
     "ngp_stepper_tail": [P, F, I, F, P],
     "ngp_stepper_exchange_times": [P, C.POINTER(C.c_float), C.POINTER(C.c_float)],

@@ -32,6 +32,8 @@ struct Rccl {
     decltype(&ncclReduceScatter) ReduceScatter = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -61,6 +63,7 @@ Rccl& rccl() {
         NGP_SYM(CommAbort, "ncclCommAbort") NGP_SYM(AllReduce, "ncclAllReduce") NGP_SYM(ReduceScatter, "ncclReduceScatter")
         NGP_SYM(AllGather, "ncclAllGather") NGP_SYM(Broadcast, "ncclBroadcast") NGP_SYM(GroupStart, "ncclGroupStart")
         NGP_SYM(GroupEnd, "ncclGroupEnd") NGP_SYM(GetErrorString, "ncclGetErrorString") NGP_SYM(GetVersion, "ncclGetVersion")
+        NGP_SYM(Send, "ncclSend") NGP_SYM(Recv, "ncclRecv")
 #undef NGP_SYM
         t.ok = true;
         return t;
@@ -167,6 +170,50 @@ int ngp_comm_broadcast(ngp_comm* c, void* buf, int64_t n_bytes, int root, ngp_st
     if (n_bytes == 0) return 0;
     NGP_CHECK_PTR(buf);
     return ngp_comm_check(rccl().Broadcast(buf, buf, (size_t)n_bytes, ncclUint8, root, c->comm, stream ? ngp_stream(stream) : c->stream), "ncclBroadcast");
+}
+
+// ---- the point-to-point forms (round 5): xGMI is a full mesh of point-to-point links, a ring collective is bound by ONE of them ----
+// Slice q of `send` (world x count values) goes straight to rank q; what rank q sends to this rank lands in recv + q x count.  The
+// rank's own slice is not copied (recv + rank x count is left alone).  One RCCL group: world - 1 sends and receives over world - 1
+// different links at once -- the reduce-scatter's data movement without its additions (the caller sums the slices itself, in rank
+// order: deterministic, in f32).
+int ngp_comm_exchange_slices(ngp_comm* c, const void* send, void* recv, int64_t count, int dtype, ngp_stream_t stream) {
+    if (!c || count < 0 || (dtype != NGP_COMM_F16 && dtype != NGP_COMM_F32)) return NGP_EINVAL;
+    if (count == 0 || c->world == 1) return 0;
+    NGP_CHECK_PTR(send); NGP_CHECK_PTR(recv);
+    if (!rccl().ok) return NGP_ECOMM;
+    const size_t bytes = (size_t)count * (dtype == NGP_COMM_F16 ? 2 : 4);
+    hipStream_t st = stream ? ngp_stream(stream) : c->stream;
+    int rc = ngp_comm_check(rccl().GroupStart(), "ncclGroupStart");
+    if (rc) return rc;
+    for (int q = 0; q < c->world && rc == 0; ++q) {
+        if (q == c->rank) continue;
+        rc = ngp_comm_check(rccl().Send(static_cast<const char*>(send) + (size_t)q * bytes, (size_t)count, ngp_comm_dtype(dtype), q, c->comm, st), "ncclSend");
+        if (rc == 0) rc = ngp_comm_check(rccl().Recv(static_cast<char*>(recv) + (size_t)q * bytes, (size_t)count, ngp_comm_dtype(dtype), q, c->comm, st), "ncclRecv");
+    }
+    const int rc2 = ngp_comm_check(rccl().GroupEnd(), "ncclGroupEnd");
+    return rc ? rc : rc2;
+}
+
+// All-gather by direct sends, in place: this rank's slice (buf + rank x count) goes to every peer, rank q's slice arrives at
+// buf + q x count.  Same result as ngp_comm_all_gather(in place); world - 1 links at once instead of a ring.
+int ngp_comm_all_gather_direct(ngp_comm* c, void* buf, int64_t count, int dtype, ngp_stream_t stream) {
+    if (!c || count < 0 || (dtype != NGP_COMM_F16 && dtype != NGP_COMM_F32)) return NGP_EINVAL;
+    if (count == 0 || c->world == 1) return 0;
+    NGP_CHECK_PTR(buf);
+    if (!rccl().ok) return NGP_ECOMM;
+    const size_t bytes = (size_t)count * (dtype == NGP_COMM_F16 ? 2 : 4);
+    hipStream_t st = stream ? ngp_stream(stream) : c->stream;
+    char* b = static_cast<char*>(buf);
+    int rc = ngp_comm_check(rccl().GroupStart(), "ncclGroupStart");
+    if (rc) return rc;
+    for (int q = 0; q < c->world && rc == 0; ++q) {
+        if (q == c->rank) continue;
+        rc = ngp_comm_check(rccl().Send(b + (size_t)c->rank * bytes, (size_t)count, ngp_comm_dtype(dtype), q, c->comm, st), "ncclSend");
+        if (rc == 0) rc = ngp_comm_check(rccl().Recv(b + (size_t)q * bytes, (size_t)count, ngp_comm_dtype(dtype), q, c->comm, st), "ncclRecv");
+    }
+    const int rc2 = ngp_comm_check(rccl().GroupEnd(), "ncclGroupEnd");
+    return rc ? rc : rc2;
 }
 
 #pragma GCC visibility pop

@@ -494,6 +494,26 @@ AdamHyper adam_hyper(float lr, float beta1, float beta2, float eps, float wd, in
     return hp;
 }
 
+
+// out = sum over the world slices, rank order, f32, one rounding to f16 (the direct exchange's "reduce" half).  8 values per thread.
+__global__ void __launch_bounds__(256)
+sum_slices_kernel(const uint4* __restrict__ own, const uint4* __restrict__ stage, int world, int rank, long long n8, uint4* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = 0; q < world; ++q) {
+        const uint4 v = (q == rank) ? own[i] : stage[(long long)q * n8 + i];
+        const _Float16* h = reinterpret_cast<const _Float16*>(&v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += (float)h[k];
+    }
+    uint4 o;
+    _Float16* oh = reinterpret_cast<_Float16*>(&o);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) oh[k] = (_Float16)acc[k];
+    out[i] = o;
+}
+
 }  // namespace
 
 extern "C" {
@@ -790,6 +810,18 @@ int ngp_sample_rays(const float* poses, const float* directions, const float* im
     if ((img_idx == nullptr) != (pix_idx == nullptr)) return NGP_EINVAL;
     hipLaunchKernelGGL(sample_rays_kernel, dim3(ngp_div_up(n, 256)), dim3(256), 0, ngp_stream(stream), poses, directions, images,
                        n_images, n_pixels, n, (uint32_t)seed, (uint32_t)(seed >> 32), rays_o, rays_d, rgb, noise, img_idx, pix_idx);
+    return NGP_LAUNCH_RESULT();
+}
+
+int ngp_sum_slices_f16(const ngp_half* own, const ngp_half* stage, int world, int rank, int64_t count, ngp_half* out, ngp_stream_t stream) {
+    if (world < 1 || rank < 0 || rank >= world || count < 0 || (count & 7)) return NGP_EINVAL;
+    if (count == 0) return 0;
+    NGP_CHECK_PTR(own); NGP_CHECK_PTR(out);
+    if (world > 1) NGP_CHECK_PTR(stage);
+    if ((reinterpret_cast<uintptr_t>(own) | reinterpret_cast<uintptr_t>(stage) | reinterpret_cast<uintptr_t>(out)) & 15) return NGP_EINVAL;
+    const long long n8 = count / 8;
+    hipLaunchKernelGGL(sum_slices_kernel, dim3(ngp_div_up(n8, 256)), dim3(256), 0, ngp_stream(stream),
+                       reinterpret_cast<const uint4*>(own), reinterpret_cast<const uint4*>(stage), world, rank, n8, reinterpret_cast<uint4*>(out));
     return NGP_LAUNCH_RESULT();
 }
 

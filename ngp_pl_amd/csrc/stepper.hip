@@ -640,10 +640,10 @@ int ngp_stepper_set_exchange(ngp_stepper* s, ngp_comm* comm, const ngp_exchange_
     if (!config) return NGP_EINVAL;
     const ngp_exchange_config& x = *config;
     const ngp_stepper_config& c = s->c;
-    if ((x.mode != 0 && x.mode != 1) || x.n_chunks < 1 || x.n_chunks > 8 || x.n_groups < 1 || x.n_groups > 16 || x.piece < 8 || (x.piece & 7)) return NGP_EINVAL;
+    if (x.mode < 0 || x.mode > 2 || (x.mode == 2 && (x.n_chunks != 1 || !x.stage)) || x.n_chunks < 1 || x.n_chunks > 8 || x.n_groups < 1 || x.n_groups > 16 || x.piece < 8 || (x.piece & 7)) return NGP_EINVAL;
     if ((int64_t)x.n_chunks * comm->world * x.piece < c.n_grid || (c.n_grid & 15)) return NGP_EINVAL;
     if (x.grad_padded != c.grid_grad16 || x.table_padded != c.enc_half + c.n_density) return NGP_EINVAL;      // the padded storages must be the stepper's own
-    if (!x.small || !x.flags || !x.step_state || (x.mode == 1 && !x.shard16)) return NGP_EINVAL;
+    if (!x.small || !x.flags || !x.step_state || (x.mode >= 1 && !x.shard16)) return NGP_EINVAL;
     if (!c.enc_param || !c.enc_m || !c.enc_v || !c.rgb_param || !c.rgb_m || !c.rgb_v) return NGP_EINVAL;
     // which chunk may leave behind which launch group: the groups complete contiguous entry ranges in table order
     for (int g = 0; g < x.n_groups; ++g) {
@@ -674,6 +674,10 @@ static int exchange_chunk(ngp_stepper* s, int chunk, hipStream_t cs) {
     const int64_t C = (int64_t)s->comm->world * x.piece;
     ngp_half* g = x.grad_padded + (size_t)chunk * C;
     if (x.mode == 1) return ngp_comm_reduce_scatter(s->comm, g, x.shard16 + (size_t)chunk * x.piece, x.piece, NGP_COMM_F16, (ngp_stream_t)cs);
+    if (x.mode == 2) {          // direct: the peers' slices of this rank's share over all links at once, then the sum in rank order (f32)
+        STEP_TRY(ngp_comm_exchange_slices(s->comm, g, x.stage, x.piece, NGP_COMM_F16, (ngp_stream_t)cs));
+        return ngp_sum_slices_f16(g + (size_t)s->comm->rank * x.piece, x.stage, s->comm->world, s->comm->rank, x.piece, x.shard16, (ngp_stream_t)cs);
+    }
     return ngp_comm_all_reduce(s->comm, g, C, NGP_COMM_F16, (ngp_stream_t)cs);
 }
 
@@ -734,7 +738,7 @@ int ngp_stepper_tail(ngp_stepper* s, float lr, int32_t step, float grad_scale, n
     int32_t* grid_cur = x.flags + 8 * k + 4; int32_t* grid_nxt = x.flags + 8 * (1 - k) + 4;
     const int n_small = c.n_density + c.n_rgb;
     ngp_stream_t cst = (ngp_stream_t)cs;
-    if (x.mode == 1) {
+    if (x.mode >= 1) {
         STEP_TRY(ngp_found_inf2(x.small, 1, n_small, nullptr, 0, 0, mlp_cur, mlp_nxt, cst));
         STEP_TRY(ngp_found_inf2(x.shard16, 0, (int64_t)x.n_chunks * x.piece, nullptr, 0, 0, grid_cur, grid_nxt, cst));
         STEP_TRY(ngp_adam_step_field_pieces(c.enc_param + c.n_density, c.enc_half + c.n_density, x.shard16, c.enc_m + c.n_density, c.enc_v + c.n_density,
@@ -743,6 +747,9 @@ int ngp_stepper_tail(ngp_stepper* s, float lr, int32_t step, float grad_scale, n
                                             c.rgb_param, c.rgb_half, x.small + c.n_density, c.rgb_m, c.rgb_v, c.n_rgb,
                                             1, lr, c.beta1, c.beta2, c.eps, c.weight_decay, step, grad_scale, mlp_cur, grid_cur, x.step_state, cst));
         // the updated f16 table: every rank's pieces to every rank, in place (one RCCL group: one launch for all chunks)
+        if (x.mode == 2) {
+            STEP_TRY(ngp_comm_all_gather_direct(comm, x.table_padded, x.piece, NGP_COMM_F16, cst));
+        } else {
         if (x.n_chunks > 1) STEP_TRY(ngp_comm_group_begin());
         int rc = 0;
         for (int ch = 0; ch < x.n_chunks && rc == 0; ++ch) {
@@ -751,6 +758,7 @@ int ngp_stepper_tail(ngp_stepper* s, float lr, int32_t step, float grad_scale, n
         }
         if (x.n_chunks > 1) { const int rc2 = ngp_comm_group_end(); if (rc == 0) rc = rc2; }
         STEP_TRY(rc);
+        }
     } else {
         // one flag for everything (all ranks hold the same sums): GradScaler's whole-step decision
         STEP_TRY(ngp_found_inf2(x.grad_padded, 0, padded, x.small, 1, n_small, mlp_cur, mlp_nxt, cst));

@@ -372,27 +372,115 @@ class ShardedExchange(GradientExchange):
         p[enc.n_mlp:] = buf[:self.n_grid]
 
 
+class DirectExchange(ShardedExchange):
+    """ShardedExchange with its two ring collectives replaced by point-to-point transfers (round 5): xGMI is a full mesh of
+    point-to-point links, so a ring reduce-scatter / all-gather is bound by ONE link while N - 1 sit idle.  Here every rank sends
+    slice q of its gradient straight to rank q and receives the N - 1 slices of its own share (N - 1 links at once), adds the N
+    slices itself -- in rank order, in f32, one rounding to f16: deterministic, where the ring adds f16 in ring order -- runs Adam on
+    its share and sends the updated f16 share to every peer.  The host-side mirror of ngp_stepper_tail's mode 2 (`NativeExchange(mode=
+    "direct")`: ngp_comm_exchange_slices / ngp_sum_slices_f16 / ngp_comm_all_gather_direct); over torch.distributed it is made of
+    isend / irecv pairs, which gloo has: tests/test_ddp_gloo.py drives it with CPU tensors at world 2-8."""
+
+    def __init__(self, model, dist, world, rank, group=None, adam=None):
+        super().__init__(model, dist, world, rank, group=group, adam=adam, n_chunks=1)
+        self._stage = None
+
+    def _p2p(self, sends, recvs):
+        """All transfers of one phase: (tensor, peer) lists; posted together, waited together (an RCCL group on the device)."""
+        ops = [self.dist.P2POp(self.dist.irecv, t, q, self.group) for t, q in recvs] + \
+              [self.dist.P2POp(self.dist.isend, t, q, self.group) for t, q in sends]
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def reduce_grid(self):
+        nat = self.model._native
+        if nat is None:
+            return None
+        enc = self.model.xyz_encoder
+        if self._work is None:
+            self.reduce_mlp()
+        g16 = nat["grid16"]
+        self._seat(g16.device)
+        self._t_begin(g16)
+        if g16.data_ptr() != self._g_big.data_ptr():
+            self._g_big[:self.n_grid].copy_(g16)
+        P, W, r = self.piece, self.world, self.rank
+        if self._stage is None or self._stage.device != g16.device:
+            self._stage = torch.zeros(W * P, dtype=torch.float16, device=g16.device)
+        # slice q of my gradient -> rank q; rank q's slice of MY share -> stage[q]
+        self._p2p([(self._g_big[q * P:(q + 1) * P], q) for q in range(W) if q != r],
+                  [(self._stage[q * P:(q + 1) * P], q) for q in range(W) if q != r])
+        if g16.is_cuda:
+            from ._lib import call, ptr, stream
+            call("ngp_sum_slices_f16", ptr(self._g_big[r * P:(r + 1) * P]), ptr(self._stage), W, r, P, ptr(self._shard16), stream())
+        else:
+            acc = torch.zeros(P, dtype=torch.float32)
+            for q in range(W):                                  # rank order, f32, one rounding
+                acc += (self._g_big[r * P:(r + 1) * P] if q == r else self._stage[q * P:(q + 1) * P]).float()
+            self._shard16.copy_(acc.half())
+        self._work.wait(); self._work = None
+        small = self._small
+        nat["density_partials"], nat["rgb_partials"], nat["n_partials"] = small[:enc.n_mlp], small[enc.n_mlp:], 1
+        nat["scale"] = nat["scale"] * self.world
+        if g16.is_cuda:
+            from ._lib import call, ptr, stream
+            if self._flag is None or self._flag.device != g16.device:
+                self._flag = torch.zeros(16, dtype=torch.int32, device=g16.device)
+                self._flag_step = 0
+            k = self._flag_step & 1
+            self._flag_step += 1
+            mlp_cur, mlp_nxt = self._flag[8 * k:], self._flag[8 * (1 - k):]
+            sh_cur, sh_nxt = self._flag[8 * k + 4:], self._flag[8 * (1 - k) + 4:]
+            call("ngp_found_inf2", ptr(small), 1, small.numel(), None, 0, 0, ptr(mlp_cur), ptr(mlp_nxt), stream())
+            call("ngp_found_inf2", ptr(self._shard16), 0, self._shard16.numel(), None, 0, 0, ptr(sh_cur), ptr(sh_nxt), stream())
+            return mlp_cur, sh_cur
+        bad_mlp = not bool(torch.isfinite(small).all())
+        bad_sh = not bool(torch.isfinite(self._shard16.float()).all())
+        one = torch.ones(1, dtype=torch.int32)
+        return (one if bad_mlp else None), (one if bad_sh else None)
+
+    def update(self, lr, step, grad_scale, found_inf, stream_handle=None):
+        nat = self.model._native
+        flag_mlp, flag_shard = found_inf if found_inf is not None else (None, None)
+        self._adam(lr, step, grad_scale, nat, flag_mlp, flag_shard, stream_handle)
+        self._stepped = True
+        enc = self.model.xyz_encoder
+        table = self._h_big[enc.n_mlp:]
+        P, W, r = self.piece, self.world, self.rank
+        mine = table[r * P:(r + 1) * P]
+        self._p2p([(mine, q) for q in range(W) if q != r], [(table[q * P:(q + 1) * P], q) for q in range(W) if q != r])
+        self._t_end(table)
+        self.model._native = None
+
+
 class NativeExchange(ShardedExchange):
     """The same exchange ENQUEUED BY THE LIBRARY (csrc/comm.hip + `ngp_stepper_tail` in csrc/stepper.hip): its own RCCL communicator
     and stream, no Python and no torch.distributed between the field backward and the gathered table.  Per step the trainer makes
     ONE call (`ngp_stepper_tail`) behind `ngp_stepper_front`; the main stream records events for the communicator's stream and
     waits once.  `mode`: "sharded" (reduce-scatter -> Adam on the rank's pieces -> all-gather of the f16 table) or "allreduce" (the
     reference's semantics literally: gradient all-reduce only, whole-table Adam on every rank).  `n_chunks` pieces of the grid
-    exchange, handed over behind the `n_groups` launch groups of the table backward that complete them.
+    exchange, handed over behind the `n_groups` launch groups of the table backward that complete them.  "direct" (round 5): the
+    sharded schedule with point-to-point transfers over all xGMI links at once in place of the two ring collectives and the N
+    slices added in rank order in f32 (see DirectExchange); one chunk.
 
     torch.distributed (`dist`) is used for what happens once: carrying the communicator id to the ranks, DDP's constructor broadcast
     of the parameters, and making master / moments whole again when the exchange is taken off."""
 
     def __init__(self, model, dist, world, rank, mode="sharded", n_chunks=1, n_groups=None, group=None):
         super().__init__(model, dist, world, rank, group=group, n_chunks=n_chunks)
-        if mode not in ("sharded", "allreduce"):
-            raise ValueError("mode must be 'sharded' or 'allreduce'")
+        if mode not in ("sharded", "allreduce", "direct"):
+            raise ValueError("mode must be 'sharded', 'allreduce' or 'direct'")
+        if mode == "direct" and n_chunks != 1:
+            raise ValueError("the direct exchange moves each rank's share in one piece: n_chunks must be 1")
         self.mode = mode
         self.n_groups = n_chunks if n_groups is None else n_groups
         self.comm = None
         self._cfg = None
         self._handle = None
         self._samples = []
+
+    _MODES = {"allreduce": 0, "sharded": 1, "direct": 2}
 
     def _make_comm(self, dev):
         """Every rank leaves through the SAME sequence of collectives whatever happens on rank 0: if the unique id cannot be made
@@ -456,7 +544,9 @@ class NativeExchange(ShardedExchange):
         if self.comm is None:
             self._make_comm(dev)
         c = _lib.ExchangeConfig()
-        c.mode, c.n_chunks, c.n_groups, c.piece = (1 if self.mode == "sharded" else 0), self.n_chunks, self.n_groups, self.piece
+        self._stage = torch.zeros(self.world * self.piece, dtype=torch.float16, device=dev) if self.n_chunks == 1 else None
+        c.mode, c.n_chunks, c.n_groups, c.piece = self._MODES[self.mode], self.n_chunks, self.n_groups, self.piece
+        c.stage = self._stage.data_ptr() if self._stage is not None else None
         c.grad_padded, c.table_padded = self._g_big.data_ptr(), self._h_big.data_ptr() + 2 * enc.n_mlp
         c.shard16, c.small, c.flags, c.step_state = self._shard16.data_ptr(), self._small.data_ptr(), self._flag.data_ptr(), state.data_ptr()
         self._cfg = c
@@ -474,7 +564,7 @@ class NativeExchange(ShardedExchange):
     def _make_whole(self, trainer):
         """Sharded mode leaves master / moments current per piece only: gather them (torch.distributed; the device is idle first)."""
         torch.cuda.synchronize()
-        if self.mode == "sharded" and getattr(self, "_stepped", False):
+        if self.mode in ("sharded", "direct") and getattr(self, "_stepped", False):
             self.gather_master()
             for t in trainer.opt.moments("enc"):
                 self._gather_shards(t)
@@ -487,9 +577,11 @@ class NativeExchange(ShardedExchange):
         from ._lib import call
         if mode == self.mode:
             return
+        if mode not in self._MODES or (mode == "direct" and self._stage is None):
+            raise ValueError("cannot switch to mode %r (the direct exchange needs n_chunks == 1)" % (mode,))
         self._make_whole(self._trainer)
         self.mode = mode
-        self._cfg.mode = 1 if mode == "sharded" else 0
+        self._cfg.mode = self._MODES[mode]
         if self._handle is not None:
             call("ngp_stepper_set_exchange", self._handle, self.comm, C.byref(self._cfg))
 

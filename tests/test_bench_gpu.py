@@ -68,7 +68,7 @@ def test_driver_command_verbatim():
     assert "[bench" in r.stderr and "headline complete" in r.stderr              # leg-by-leg progress is on by default
 
 
-@pytest.mark.parametrize("exchange", ["sharded", "allreduce"])
+@pytest.mark.parametrize("exchange", ["sharded", "allreduce", "direct"])
 def test_bench_under_a_one_rank_rccl_group(exchange):
     """The multi-GPU path of bench.py on a real RCCL process group of ONE rank (what `torchrun --nproc-per-node 1 bench.py` runs):
     process group, parameter broadcast, the gradient exchange installed on the trainer (sharded: reduce-scatter -> shard Adam ->
@@ -88,10 +88,13 @@ def test_bench_under_a_one_rank_rccl_group(exchange):
     assert "error" not in d, d.get("error")
     assert d["n_gpus"] == 1 and d["exchange"] == exchange and d["exchange_ms"] > 0 and d["value"] > 1e6 and d["exchange_impl"] == "native"
     assert d["config"]["train_psnr"] > 10 and d["march_guards"] == [0, 0, 0, 0]
-    other = "allreduce" if exchange == "sharded" else "sharded"
     modes = d["exchange_modes"]
-    assert set(modes) == {"sharded", "allreduce"} and "error" not in modes[other], modes
-    assert modes[other]["exchange_ms"] > 0 and modes[other]["ms_per_step"] > 0 and modes[exchange]["exposed_exchange_ms"] is not None
+    assert set(modes) == {"sharded", "allreduce", "direct"}, modes
+    for other in modes:
+        if other != exchange:
+            assert "error" not in modes[other], modes
+            assert modes[other]["exchange_ms"] > 0 and modes[other]["ms_per_step"] > 0
+    assert modes[exchange]["exposed_exchange_ms"] is not None
     # the evaluation sharded over the ranks ran with the exchange installed, and the line says what RCCL itself saw
     ev = d["dp_eval"]
     assert "error" not in ev, ev

@@ -292,11 +292,11 @@ class _Opt:
         self.param_groups, self.t, self.betas, self.eps, self.weight_decay = [{"lr": 0.0}], 0, (0.9, 0.999), 1e-15, 0.0
 
 
-def _sharded_worker(rank, world, port, q, n_chunks=1):
+def _sharded_worker(rank, world, port, q, n_chunks=1, kind="sharded"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
-    from ngp_pl_amd.ddp import ShardedExchange
+    from ngp_pl_amd.ddp import DirectExchange, ShardedExchange
     from ngp_pl_amd.trainer import Trainer
     n_grid, n_d, n_r = 2 * N_ENTRIES_SH, 3072, 7168
     g0 = torch.Generator().manual_seed(1)
@@ -334,7 +334,10 @@ def _sharded_worker(rank, world, port, q, n_chunks=1):
             _adam_reference(model.rgb_net.params, rm, rv, nat["rgb_partials"].view(nat["n_partials"], -1).sum(0) / grad_scale, lr, 0.9, 0.999, 1e-15, step)
             rgb_half.copy_(model.rgb_net.params.half())
 
-    exchange = ShardedExchange(model, dist, world, rank, adam=adam_cpu, n_chunks=n_chunks).install(tr)
+    if kind == "direct":             # point-to-point transfers + the N slices added in rank order in f32 (the mirror of ngp_stepper_tail's mode 2)
+        exchange = DirectExchange(model, dist, world, rank, adam=adam_cpu).install(tr)
+    else:
+        exchange = ShardedExchange(model, dist, world, rank, adam=adam_cpu, n_chunks=n_chunks).install(tr)
     ok = tr.loss_scale == 128.0 / world and tr.update_hook is not None and exchange.piece % 8 == 0
     ok &= exchange.padded >= n_grid > exchange.padded - exchange.chunk and len(exchange.pieces) == n_chunks
     if n_chunks == 1:
@@ -408,6 +411,24 @@ def test_sharded_exchange_matches_the_single_process_update(world, n_chunks):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q, n_chunks)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+    assert res == [(r, True) for r in range(world)], res
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_direct_exchange_matches_the_single_process_update(world):
+    """`ddp.DirectExchange` -- every rank's slices sent straight to their owners (isend / irecv pairs: an RCCL group of sends and
+    receives over all xGMI links on the device), the N slices added in rank order in f32, the updated share sent to every peer --
+    under the same harness as the ring-shaped ShardedExchange: every rank ends with the same f16 table, equal to the single-process
+    Adam update bit for bit, f32 master whole after gather_master(), a non-finite share skipped on every rank alike."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q, 1, "direct")) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=240) for _ in range(world))

@@ -205,7 +205,9 @@ def _native_worker(port, q):
       B  ddp.NativeExchange     sharded, one chunk
       C  ddp.NativeExchange     sharded, two chunks behind two launch groups of the table backward
       D  ddp.NativeExchange     allreduce (gradient all-reduce only, whole-table Adam)
-    At world 1 every collective is the identity, so all four must leave the SAME parameters bit for bit: same kernels for the MLP
+      E  ddp.NativeExchange     direct (point-to-point transfers, the N slices added in rank order in f32: round 5)
+      F  ddp.DirectExchange     -- its torch.distributed mirror
+    At world 1 every collective is the identity, so all six must leave the SAME parameters bit for bit: same kernels for the MLP
     sums, exact fixed-point table sums whatever the launch groups, the same Adam arithmetic whether it walks a shard, pieces or the
     whole table, the same device-side bias-correction count."""
     try:
@@ -214,7 +216,7 @@ def _native_worker(port, q):
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         import numpy as np
         from ngp_pl_amd import synthetic as syn
-        from ngp_pl_amd.ddp import NativeExchange, ShardedExchange
+        from ngp_pl_amd.ddp import DirectExchange, NativeExchange, ShardedExchange
         from ngp_pl_amd.networks import NGP
         from ngp_pl_amd.trainer import Trainer
 
@@ -237,8 +239,10 @@ def _native_worker(port, q):
             tr = Trainer(m)
             if kind == "A":
                 ex = ShardedExchange(m, dist, 1, 0)
+            elif kind == "F":
+                ex = DirectExchange(m, dist, 1, 0)
             else:
-                ex = NativeExchange(m, dist, 1, 0, mode="allreduce" if kind == "D" else "sharded", n_chunks=2 if kind == "C" else 1,
+                ex = NativeExchange(m, dist, 1, 0, mode={"D": "allreduce", "E": "direct"}.get(kind, "sharded"), n_chunks=2 if kind == "C" else 1,
                                     n_groups=2 if kind == "C" else 1)
             ex.install(tr)
             ex.broadcast_parameters()
@@ -260,11 +264,11 @@ def _native_worker(port, q):
             if hasattr(ex, "close"):
                 ex.close()
             return snap
-        res = {k: run(k) for k in "ABCD"}
+        res = {k: run(k) for k in "ABCDEF"}
         ok, notes = True, []
         a = res["A"]
         ok &= a["log"][7][0] == 0 and a["log"][8][0] > 0
-        for k in "BCD":
+        for k in "BCDEF":
             r = res[k]
             same_log = r["log"] == a["log"]
             same = all(torch.equal(r[key], a[key]) for key in ("half", "master", "rgb")) and all(torch.equal(x, y) for x, y in zip(r["m"], a["m"]))
@@ -311,9 +315,20 @@ def test_communicator_collectives_on_one_rank():
     call("ngp_comm_reduce_scatter", h, ptr(g), ptr(out), out.numel(), 1, None)
     t = torch.randn(2048, device="cuda").half(); t0 = t.clone()
     call("ngp_comm_all_gather", h, ptr(t), ptr(t), t.numel(), 1, None)
+    # the point-to-point forms: no peers at world 1 (no-ops that must not touch the buffers) ...
+    stage = torch.full((2048,), 7.0, device="cuda").half()
+    call("ngp_comm_exchange_slices", h, ptr(t), ptr(stage), t.numel(), 1, None)
+    call("ngp_comm_all_gather_direct", h, ptr(t), t.numel(), 1, None)
+    # ... and the slice sum for three "ranks" laid out as the landing area has them: own slice at rank 1, the others from the stage
+    own = (torch.randint(-64, 65, (4096,), device="cuda").float() / 16).half()
+    st3 = (torch.randint(-64, 65, (3, 4096), device="cuda").float() / 16).half()
+    summed = torch.zeros(4096, device="cuda").half()
+    call("ngp_sum_slices_f16", ptr(own), ptr(st3), 3, 1, 4096, ptr(summed), None)
     b = torch.arange(100, device="cuda", dtype=torch.uint8); b0 = b.clone()
     call("ngp_comm_broadcast", h, ptr(b), b.numel(), 0, None)
     torch.cuda.synchronize()
     assert torch.equal(x, x0) and torch.equal(out, g) and torch.equal(t, t0) and torch.equal(b, b0)
+    assert bool((stage == 7.0).all())
+    assert torch.equal(summed, (st3[0].float() + own.float() + st3[2].float()).half())
     from ngp_pl_amd import _lib
     _lib.lib().ngp_comm_destroy(h)
