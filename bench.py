@@ -1001,6 +1001,9 @@ def main():
                    "samples_per_ray_marched": met["rm_s"], "samples_per_ray_composited": met["vr_s"], "train_psnr": met["psnr"],
                    "parallelism": "dp%d (per-ray data parallel, one native-gradient exchange per step)" % world},
         "value_is": "Trainer.step (native step: direct C-ABI calls, no autograd graph); api_path = the same step through render()+autograd",
+        "parity_note": "every PSNR in this line is on a procedural scene (no dataset exists on the box) and every one rests on the hash-grid / MLP / SH "
+                       "arithmetic, which is held to OUR fp32 restatement of tiny-cuda-nn only (parity unpinned: tiny-cuda-nn is not in the reference tree); "
+                       "marching and compositing are pinned to the reference's own kernels",
         "timed_windows": r["timed_windows"], "timed_steps_total": r["timed_steps_total"], "window_ms_per_step_min_max": r["window_ms_per_step_min_max"],
         "ms_per_step_hip_events": r["ms_per_step_hip_events"], "cold_start": r["cold_start"],
     }
