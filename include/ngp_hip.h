@@ -194,7 +194,7 @@ int ngp_composite_train_bw(const float* dL_dopacity, const float* dL_ddepth, con
                            const int32_t* ray_offsets, int32_t* active_idx /* both optional: also list the
                            live samples of row n at active_idx[ray_offsets[n] ...] (see ngp_active_scan) */,
                            const float* xyzs, float* x_active /* both optional, with active_idx: also copy the
-                           listed samples' positions (S,3) to x_active in list order (= ngp_gather_xyz) */,
+                           listed samples' positions (S,3) to x_active in list order */,
                            ngp_stream_t stream);
 
 /* vren.composite_test_fw (binding.cpp:166-194, volumerendering.cu:205-285).
@@ -276,7 +276,7 @@ int ngp_hashgrid_bwd_sliced(const float* x, const float* xyz_min, const float* x
  * accumulation order aside), same arguments plus a scratch of
  * ngp_hashgrid_bwd_binned_workspace_bytes(meta, n_samples) bytes. */
 size_t ngp_hashgrid_bwd_binned_workspace_bytes(const ngp_grid_meta* meta, int n_samples);
-/* active_idx NULL with n_active given: x is already in compact order too (see ngp_gather_xyz). */
+/* active_idx NULL with n_active given: x is already in compact order too (the composite backward's x_active). */
 int ngp_hashgrid_bwd_binned(const float* x, const float* xyz_min, const float* xyz_max,
                             const ngp_half* dfeats, const ngp_grid_meta* meta, int n_samples,
                             const int32_t* active_idx, const int32_t* n_active,
@@ -331,7 +331,7 @@ int ngp_field_fwd(const ngp_half* feats, const float* dirs,
  * per-workgroup partial weight gradients (n_partials, n_params) f32, n_partials =
  * ngp_field_bwd_partials(n_samples); sum them with ngp_reduce_partials.  All gradients carry
  * the factor loss_scale (tiny-cuda-nn uses 128 for f16).
- *   ngp_rgb_bwd:     dL_drgbs (S,3) f32 unscaled -> dL_dh (S,16) f16, partials (.,7168)
+ *   (colour net, inside ngp_field_bwd): dL_drgbs (S,3) f32 unscaled -> dL_dh (S,16) f16, partials (.,7168)
  *   ngp_density_bwd: dL_dh (S,16) f16 already scaled (may be NULL) and dL_dsigmas (S) f32
  *                    unscaled (may be NULL; TruncExp backward custom_functions.py:168-173 is
  *                    applied here) -> dfeats [L][S] half2, partials (.,3072)
