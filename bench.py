@@ -302,7 +302,7 @@ class Loop:
                 self.exchange.switch_mode(other)
                 self.steps(5)
                 t = self.timed(20)[0]
-                modes[other] = dict(self.time_exchange(), ms_per_step=t / 20 * 1e3)
+                modes[other] = dict(self.time_exchange(), ms_per_step=t / 20 * 1e3, rays_per_s=self.rays * self.world * 20 / t)
             except Exception as e:             # noqa: BLE001
                 modes[other] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         try:
