@@ -123,9 +123,10 @@ def _lego_hard_primitives():
 def volumetric_ground_truth(rays_o, rays_d, boxes, spheres, sigma, white_bg=True, chunk=1 << 17):
     """EXACT volume rendering of {density = sigma inside the union of the primitives, 0 outside; colour = syn.colour(x, view)}:
     per ray the entry / exit parameters of every primitive are sorted, the inside-count is swept along the ray, and each
-    constant-density segment [a, b] contributes T(a) (1 - exp(-sigma (b - a))) times the colour at its own transmittance-weighted
-    centroid a + 1/sigma - L e^{-sigma L} / (1 - e^{-sigma L}) (exact for a colour that is linear across the segment; segments are a
-    few millimetres to centimetres, the colour stripes have a period of 0.2-0.3).  Rays that miss every primitive are skipped."""
+    constant-density segment [a, b] contributes T(a) (1 - exp(-sigma (b - a))) times its weight-averaged colour, formed by a two-node
+    rule at mean +- standard deviation of the segment's own transmittance weight (exact for a colour that is quadratic along the
+    segment; the colour stripes have a period of 0.2-0.3, the weight of a segment sits within ~1/sigma = 0.02-0.07 of its entry).
+    Transmittance and opacity are exact.  Rays that miss every primitive are skipped."""
     n, dev = rays_o.shape[0], rays_o.device
     out = torch.ones(n, 3, device=dev) if white_bg else torch.zeros(n, 3, device=dev)
     bc = torch.tensor([b[0] for b in boxes], device=dev); bh = torch.tensor([b[1] for b in boxes], device=dev)
@@ -164,13 +165,21 @@ def volumetric_ground_truth(rays_o, rays_d, boxes, spheres, sigma, white_bg=True
         T = torch.exp(-(tau.cumsum(1) - tau))
         e = torch.exp(-tau)
         w = T * (1 - e)
-        cen = torch.where(tau > 1e-4, 1.0 / sigma - L * e / (1 - e).clamp(min=1e-12), 0.5 * L)
-        tm = torch.where(L > 0, a_ + cen, torch.zeros_like(a_))
+        # colour of a segment = the weight-averaged colour over it, by a two-node rule that is exact for a colour QUADRATIC along the
+        # segment: nodes at mean +- standard deviation of the truncated exponential weight sigma e^(-sigma t) on [0, L]
+        # (mean 1/sigma - L e / (1 - e), variance 1/sigma^2 - L^2 e / (1 - e)^2 with e = exp(-sigma L); L/2 and L^2/12 as sigma L -> 0)
+        one_m_e = (1 - e).clamp(min=1e-12)
+        mean = torch.where(tau > 1e-3, 1.0 / sigma - L * e / one_m_e, 0.5 * L)
+        var = torch.where(tau > 1e-3, 1.0 / sigma ** 2 - L * L * e / (one_m_e * one_m_e), L * L / 12.0).clamp(min=0)
+        sd = var.sqrt()
         dn = d / d.norm(dim=-1, keepdim=True)
         acc = torch.zeros(o.shape[0], 3, device=dev)
-        for j0 in range(0, tm.shape[1], 32):                                       # (colour over 32 segment slots at a time: bounded temporaries)
-            x = o[:, None] + tm[:, j0:j0 + 32, None] * d[:, None]
-            acc += (w[:, j0:j0 + 32, None] * syn.colour(x, dn[:, None].expand_as(x))).sum(1)
+        for j0 in range(0, a_.shape[1], 32):                                       # (colour over 32 segment slots at a time: bounded temporaries)
+            wj = 0.5 * w[:, j0:j0 + 32, None]
+            for sign in (-1.0, 1.0):
+                tm = torch.where(L[:, j0:j0 + 32] > 0, a_[:, j0:j0 + 32] + (mean[:, j0:j0 + 32] + sign * sd[:, j0:j0 + 32]).clamp(min=0), torch.zeros_like(a_[:, j0:j0 + 32]))
+                x = o[:, None] + tm[..., None] * d[:, None]
+                acc += (wj * syn.colour(x, dn[:, None].expand_as(x))).sum(1)
         opac = w.sum(1)
         out[lo + rows] = (acc + ((1 - opac)[:, None] if white_bg else 0.0)).clamp(0, 1)
     return out
