@@ -261,9 +261,21 @@ struct Ray {
 // dt = max(dt_lo, min(t*0, dt_hi)) = dt_lo for every t >= 0, so the two frexp, the scalbn, the
 // division and the clamp leave the dependent chain; every value that remains is computed by
 // the same operations as in the general case.
+// block_any (optional, LDS; SIMPLE only): bit b = "some cell of the 8^3 block b = idx >> 9 (512 Morton-consecutive cells) is
+// occupied".  In a block without one the serial walk hops cell by cell (up to 22 hops of ~110 instructions) and emits nothing; where it
+// comes out does not depend on those hops: every hop lands on L(tau) = the first lattice point at or behind tau, tau = the float
+// evaluation of the time the ray leaves the current cell, and the LAST hop inside the block evaluates the time the ray leaves the
+// block -- the same plane whichever cell it is taken from.  Two evaluations of that time, from different points of the ray, differ
+// by rounding only: each is within d = |t| 2^-23 + (tau - t) 2^-22 + 2^-23 max|1/d_axis| of the real crossing (x = fma(t, d, o)
+// is within half an ulp of a value below 1, the plane is exact, one subtraction, one product with the rounded reciprocal, one sum).
+// So when no lattice point lies within `hop_slack` >= 2 d (x4 for safety) of the block's tau evaluated HERE, L(tau) is the point the
+// cell-by-cell walk reaches, and the hop goes there at once; lattice points that close to the boundary (about 1% of the hops) take
+// the cells one by one as before.  Points between here and there are inside the block by more than the rounding of their own
+// position, so none of them can have been attributed to a neighbouring (occupied) block.  A set bit reads the cell as before.
 template <bool SIMPLE>
 __device__ __forceinline__ bool march_probe(const Ray& ray, const MarchParams& p, float t,
-                                            float& x, float& y, float& z, float& dt, float& t_next, int* steps = nullptr) {
+                                            float& x, float& y, float& z, float& dt, float& t_next, int* steps = nullptr,
+                                            const uint32_t* block_any = nullptr, float hop_slack = 0.0f) {
     x = fmaf(t, ray.dx, ray.ox); y = fmaf(t, ray.dy, ray.oy); z = fmaf(t, ray.dz, ray.oz);
     const float G = (float)p.grid_size;
     int mip = 0;
@@ -285,7 +297,43 @@ __device__ __forceinline__ bool march_probe(const Ray& ray, const MarchParams& p
     const int nz = (int)fmaxf(0.0f, fminf(0.5f * (z * mip_bound_inv + 1) * G, gm1));
     const uint32_t g3 = (uint32_t)(p.grid_size * p.grid_size * p.grid_size);
     const uint32_t idx = (uint32_t)mip * g3 + ngp_morton3D((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
-    const bool occ = (p.bitfield[idx >> 3] >> (idx & 7)) & 1;
+    bool occ = true;
+    if (SIMPLE && block_any != nullptr) {
+        occ = (block_any[idx >> 14] >> ((idx >> 9) & 31)) & 1;
+        if (!occ) {
+            const float g8 = 8.0f / G;
+            const float ux = ((((nx >> 3) + 0.5f + 0.5f * copysignf(1.0f, ray.dx)) * g8 * 2 - 1) * mip_bound - x) * ray.ix;
+            const float uy = ((((ny >> 3) + 0.5f + 0.5f * copysignf(1.0f, ray.dy)) * g8 * 2 - 1) * mip_bound - y) * ray.iy;
+            const float uz = ((((nz >> 3) + 0.5f + 0.5f * copysignf(1.0f, ray.dz)) * g8 * 2 - 1) * mip_bound - z) * ray.iz;
+            const float tau = t + fmaxf(0.0f, fminf(ux, fminf(uy, uz)));
+            // L(tau) and its predecessor without the chain of adds (a wave pays every lane's longest loop): t and tau in one binade,
+            // where the constant step adds the same number of ulps every time (lattice_tile_const_dt has the argument); a hop that
+            // would leave the binade, a step that ties, a t below 2 dt take the cells one by one
+            const uint32_t tb = __float_as_uint(t), ub = __float_as_uint(tau), db = __float_as_uint(p.dt_lo);
+            const int sh = (int)(tb >> 23) - (int)(db >> 23);                  // (signs are 0: t > 0, dt > 0)
+            if (tau - t < 0.25f && (ub >> 23) == (tb >> 23) && sh >= 1 && sh <= 23 && (db >> 23) != 0u && (tb >> 23) != 0u) {
+                const uint32_t md = (db & 0x7fffffu) | 0x800000u;
+                const uint32_t rem = md & ((1u << sh) - 1u), half = 1u << (sh - 1);
+                const uint32_t delta = (md >> sh) + (rem > half ? 1u : 0u);
+                const uint32_t diff = (ub & 0x7fffffu) - (tb & 0x7fffffu);           // tau >= t, same binade
+                uint32_t k = (uint32_t)((float)diff * __builtin_amdgcn_rcpf((float)delta));
+                if (k * delta < diff) ++k;                                            // k = the smallest count with k delta >= diff, at least 1:
+                if (k * delta < diff) ++k;                                            // the quotient above is within one of it
+                if (k > 1u && (k - 1u) * delta >= diff) --k;
+                if (k == 0u) k = 1u;
+                const uint32_t mk = (tb & 0x7fffffu) + k * delta;
+                if (rem != half && delta != 0u && mk < 0x800000u) {
+                    const float tt = __uint_as_float((tb & 0xff800000u) | mk), prev = __uint_as_float((tb & 0xff800000u) | (mk - delta));
+                    if (tt - tau > hop_slack && tau - prev > hop_slack) {
+                        t_next = tt;
+                        if (steps) *steps = (int)k;
+                        return false;
+                    }
+                }
+            }
+        }
+    }
+    if (occ) occ = (p.bitfield[idx >> 3] >> (idx & 7)) & 1;
     if (!occ) {
         const float ginv = 1.0f / G;
         const float tx = (((nx + 0.5f + 0.5f * copysignf(1.0f, ray.dx)) * ginv * 2 - 1) * mip_bound - x) * ray.ix;
@@ -707,18 +755,32 @@ constexpr int RENDER_RETIRE = 1 << 16;      // n_eff flag: drop the ray after co
 constexpr int RENDER_MAX_ITERS = 2048;
 constexpr int RENDER_RING = 4;
 
+// block_any (RENDER_MASK_WORDS words, or NULL): the "any cell of the 8^3 block occupied" bits the marcher keeps in LDS (march_probe);
+// built here from the bitfield the frame was called with, by the first 16 workgroups (one thread per block: 64 bytes of bitfield).
+constexpr int RENDER_MASK_WORDS = 128;           // (128 / 8)^3 blocks
 __global__ void __launch_bounds__(256)
 render_begin_kernel(const float* __restrict__ hits_in, int n_rays, float* __restrict__ hits,
                     int32_t* __restrict__ alive, int32_t* __restrict__ emitted, float* __restrict__ opacity, float* __restrict__ depth,
-                    float* __restrict__ rgb, RenderPlan* __restrict__ plan, unsigned long long* __restrict__ total) {
+                    float* __restrict__ rgb, RenderPlan* __restrict__ plan, unsigned long long* __restrict__ total,
+                    const uint8_t* __restrict__ bitfield, uint32_t* __restrict__ block_any, int hits_pairs_aligned) {
     const int stride = gridDim.x * blockDim.x;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    for (int i = tid; i < n_rays; i += stride) {
-        hits[2 * i] = hits_in[2 * i]; hits[2 * i + 1] = hits_in[2 * i + 1];
-        alive[i] = i; emitted[i] = 0;
-        opacity[i] = 0.f; depth[i] = 0.f;
-        rgb[3 * i] = 0.f; rgb[3 * i + 1] = 0.f; rgb[3 * i + 2] = 0.f;
+    if (block_any != nullptr && tid < RENDER_MASK_WORDS * 32) {
+        const uint4* cells = reinterpret_cast<const uint4*>(bitfield) + 4 * (size_t)tid;
+        const uint4 a = cells[0], b = cells[1], c = cells[2], d = cells[3];
+        const bool any = (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w | c.x | c.y | c.z | c.w | d.x | d.y | d.z | d.w) != 0u;
+        const unsigned long long m = __ballot(any);
+        if ((threadIdx.x & 63) == 0) { block_any[tid >> 5] = (uint32_t)m; block_any[(tid >> 5) + 1] = (uint32_t)(m >> 32); }
     }
+    if (hits_pairs_aligned) {
+        const float2* in2 = reinterpret_cast<const float2*>(hits_in);
+        float2* out2 = reinterpret_cast<float2*>(hits);
+        for (int i = tid; i < n_rays; i += stride) out2[i] = in2[i];
+    } else {
+        for (int i = tid; i < 2 * n_rays; i += stride) hits[i] = hits_in[i];
+    }
+    for (int i = tid; i < n_rays; i += stride) { alive[i] = i; emitted[i] = 0; opacity[i] = 0.f; depth[i] = 0.f; }
+    for (int i = tid; i < 3 * n_rays; i += stride) rgb[i] = 0.f;
     int32_t* pl = reinterpret_cast<int32_t*>(plan);
     for (int i = tid; i < (RENDER_MAX_ITERS + 1) * (int)(sizeof(RenderPlan) / 4); i += stride) pl[i] = (i == 0) ? n_rays : 0;
     if (tid == 0) *total = 0ull;
@@ -750,7 +812,9 @@ render_march_kernel(const float* __restrict__ rays_o, const float* __restrict__ 
                     MarchParams p, RenderPlan* __restrict__ plan, int n_rays, int chunk_scale, int min_samples,
                     int max_samples_total, int probe_cap,
                     float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas,
-                    float* __restrict__ ts, int32_t* __restrict__ n_eff, int32_t* __restrict__ offsets) {
+                    float* __restrict__ ts, int32_t* __restrict__ n_eff, int32_t* __restrict__ offsets,
+                    const uint32_t* __restrict__ block_any) {
+    __shared__ uint32_t s_any[RENDER_MASK_WORDS];
     __shared__ float s_t[NMAX * 64];        // [sample][lane]; 16 KiB at NMAX = 64 allows two of these waves per SIMD, 8 KiB four
     __shared__ float s_ray[6 * 64];
     __shared__ int s_incl[64];
@@ -769,6 +833,14 @@ render_march_kernel(const float* __restrict__ rays_o, const float* __restrict__ 
     const int lane = threadIdx.x;
     const int n = blockIdx.x * 64 + lane;
     const bool active = n < n_alive;
+    // rays leaving the object walk the rest of the box cell by cell and emit nothing: a chain of dependent bitfield loads per lane,
+    // as long as the longest walk in the wave.  With the 8^3-block bits in LDS the walk through empty blocks needs no global load.
+    const uint32_t* any = nullptr;
+    if (SIMPLE && block_any != nullptr) {
+        s_any[lane] = block_any[lane]; s_any[64 + lane] = block_any[64 + lane];
+        wave_lds_fence();
+        any = s_any;
+    }
     int s = 0, flags = 0;
     Ray ray = {};
     size_t r = 0;
@@ -777,13 +849,16 @@ render_march_kernel(const float* __restrict__ rays_o, const float* __restrict__ 
         ray = load_ray(rays_o, rays_d, r);
         float t = hits[2 * r];
         const float t2 = hits[2 * r + 1];
+        // march_probe's `hop_slack`: 4 x 2 x the rounding of a crossing time anywhere on this ray (t <= t2, tau - t < 0.25); a ray with a
+        // zero direction component has an infinite one and walks cell by cell
+        const float hop_slack = 8.0f * (fabsf(t2) * 1.2e-7f + 1.2e-7f + 1.2e-7f * fmaxf(fabsf(ray.ix), fmaxf(fabsf(ray.iy), fabsf(ray.iz))));
         if (probe_cap <= 0) {
             float t_resume = t;
             int iters = 0;
             while (t < t2 && s < N) {
                 if (++iters > MARCH_ITER_CAP) { atomicAdd(&g_march_guard[2], 1u); t_resume = t2; break; }
                 float x, y, z, dt, t_next;
-                if (march_probe<SIMPLE>(ray, p, t, x, y, z, dt, t_next)) {
+                if (march_probe<SIMPLE>(ray, p, t, x, y, z, dt, t_next, nullptr, any, hop_slack)) {
                     s_t[s * 64 + lane] = t;
                     t += dt; ++s;
                     t_resume = t;
@@ -800,7 +875,7 @@ render_march_kernel(const float* __restrict__ rays_o, const float* __restrict__ 
                 if (s >= N || probes >= probe_cap) break;
                 ++probes;
                 float x, y, z, dt, t_next;
-                if (march_probe<SIMPLE>(ray, p, t, x, y, z, dt, t_next)) {
+                if (march_probe<SIMPLE>(ray, p, t, x, y, z, dt, t_next, nullptr, any, hop_slack)) {
                     s_t[s * 64 + lane] = t;
                     t += dt; ++s;
                 } else {
@@ -968,7 +1043,7 @@ render_finish_kernel(const float* __restrict__ opacity, float* __restrict__ rgb,
 }
 
 struct RenderLayout {
-    size_t hits, alive0, alive1, n_eff, offsets, emitted, plan, total, xyzs, dirs, deltas, ts, feats, sigmas, rgbs, bytes;
+    size_t hits, alive0, alive1, n_eff, offsets, emitted, plan, total, block_any, xyzs, dirs, deltas, ts, feats, sigmas, rgbs, bytes;
     long long m_cap;
 };
 RenderLayout render_layout(int n_rays, int chunk_scale, float esf) {
@@ -979,7 +1054,7 @@ RenderLayout render_layout(int n_rays, int chunk_scale, float esf) {
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     L.hits = take(R * 8); L.alive0 = take(R * 4); L.alive1 = take(R * 4); L.n_eff = take(R * 4); L.offsets = take(R * 4); L.emitted = take(R * 4);
-    L.plan = take((RENDER_MAX_ITERS + 1) * sizeof(RenderPlan)); L.total = take(8);
+    L.plan = take((RENDER_MAX_ITERS + 1) * sizeof(RenderPlan)); L.total = take(8); L.block_any = take(RENDER_MASK_WORDS * 4);
     const long long slack = 64;            // the composite reads whole 8-sample batches
     L.xyzs = take(L.m_cap * 12); L.dirs = take(L.m_cap * 12); L.deltas = take((L.m_cap + slack) * 4); L.ts = take((L.m_cap + slack) * 4);
     L.feats = take(L.m_cap * 64); L.sigmas = take((L.m_cap + slack) * 4); L.rgbs = take((L.m_cap + slack) * 12);
@@ -1013,6 +1088,8 @@ struct RenderHost {
     }
 };
 thread_local RenderHost g_render_host;
+static int g_render_block_hops = 1;                 // ngp_debug_render_block_hops
+
 
 double render_wait_limit_s() {
     static const double v = [] { const char* e = getenv("NGP_SPIN_TIMEOUT_S"); const double x = e ? atof(e) : 30.0; return x > 0 ? x : 30.0; }();
@@ -1297,6 +1374,11 @@ size_t ngp_render_test_workspace_bytes(int n_rays, int chunk_scale, float exp_st
     return render_layout(n_rays, chunk_scale, exp_step_factor).bytes;
 }
 
+int ngp_debug_render_block_hops(int enabled) {
+    g_render_block_hops = enabled ? 1 : 0;
+    return 0;
+}
+
 int ngp_render_test_frame(const float* rays_o, const float* rays_d, const float* hits_t,
                           const uint8_t* density_bitfield, int cascades, float scale,
                           float exp_step_factor, int grid_size, int max_samples, float T_threshold,
@@ -1334,7 +1416,12 @@ int ngp_render_test_frame(const float* rays_o, const float* rays_d, const float*
     // the reference passes `cascades` where calc_dt expects `scale` (raymarching.cu:370,399)
     const MarchParams p = make_march_params(density_bitfield, cascades, grid_size, scale, (float)cascades, exp_step_factor, max_samples);
 
-    hipLaunchKernelGGL(render_begin_kernel, dim3(1024), dim3(256), 0, st, hits_t, n_rays, hits, alive[0], emitted, opacity, depth, rgb, plan, total);
+    // Synthetic-NeRF setting on the 128^3 grid: the marcher crosses 8^3 blocks without an occupied cell in one hop (march_probe), from
+    // 512 bytes of block bits in LDS
+    uint32_t* block_any = nullptr;
+    if (g_render_block_hops && p.simple && grid_size == 128 && (reinterpret_cast<uintptr_t>(density_bitfield) & 15) == 0) block_any = reinterpret_cast<uint32_t*>(ws + L.block_any);
+    hipLaunchKernelGGL(render_begin_kernel, dim3(1024), dim3(256), 0, st, hits_t, n_rays, hits, alive[0], emitted, opacity, depth, rgb, plan, total,
+                       density_bitfield, block_any, (reinterpret_cast<uintptr_t>(hits_t) & 7) == 0 ? 1 : 0);
     constexpr int LAG = 2;
     long long bound = n_rays;
     int it = 0;
@@ -1361,9 +1448,12 @@ int ngp_render_test_frame(const float* rays_o, const float* rays_d, const float*
         // regrouping modes cap a ray's samples per iteration at 32, which halves the marcher's LDS tile and doubles its waves per CU
         const bool regroup = chunk_scale > 1 || probe_cap > 0;
 #define NGP_RENDER_MARCH(S, NM) hipLaunchKernelGGL((render_march_kernel<S, NM>), mgrid, dim3(64), 0, st, rays_o, rays_d, hits, alive[it & 1], emitted, p, pl, \
-                                                   n_rays, chunk_scale, min_samples, max_samples, probe_cap, xyzs, dirs, deltas, ts, n_eff, offsets)
-        if (p.simple) { if (regroup) NGP_RENDER_MARCH(true, 32); else NGP_RENDER_MARCH(true, 64); }
-        else { if (regroup) NGP_RENDER_MARCH(false, 32); else NGP_RENDER_MARCH(false, 64); }
+                                                   n_rays, chunk_scale, min_samples, max_samples, probe_cap, xyzs, dirs, deltas, ts, n_eff, offsets, block_any)
+        // iteration 0 marches EVERY ray for N = max(chunk_scale, min_samples) samples (n_alive = n_rays): with a tile of 8 samples per
+        // ray instead of 32 / 64 the longest walks of the frame run at the SIMDs' full wave count
+        const bool first = it == 0 && chunk_scale <= 8;
+        if (p.simple) { if (first) NGP_RENDER_MARCH(true, 8); else if (regroup) NGP_RENDER_MARCH(true, 32); else NGP_RENDER_MARCH(true, 64); }
+        else { if (first) NGP_RENDER_MARCH(false, 8); else if (regroup) NGP_RENDER_MARCH(false, 32); else NGP_RENDER_MARCH(false, 64); }
 #undef NGP_RENDER_MARCH
         const int n_max = regroup ? 32 : 64;
         long long m_bound = (long long)chunk_scale * n_rays;

@@ -183,6 +183,11 @@ int ngp_density_fwd_scatter(const ngp_half* feats, const ngp_half* density_w, in
  * when every (level, chunk) is covered once); 0 when the table uses the pair map. */
 int ngp_debug_hashgrid_fwd_map(const ngp_grid_meta* meta, int n_chunks, int32_t* xcd_level_chunk, int max_blocks);
 
+/* Diagnostics: ngp_render_test_frame's marcher crosses 8^3-cell blocks without an occupied cell in one hop (csrc/march.hip, march_probe:
+ * same samples as the cell-by-cell walk).  enabled == 0 makes the calling process walk cell by cell again, != 0 restores the default;
+ * tests render the same frames both ways and compare bits, tools time both. */
+int ngp_debug_render_block_hops(int enabled);
+
 /* Did the last front() evaluate the field in two rounds? (1 / 0) */
 int ngp_stepper_two_rounds(const ngp_stepper* s);
 

@@ -259,6 +259,80 @@ def test_device_frame_loop_matches_host_loop():
     assert torch.equal(far["rgb"], torch.ones_like(far["rgb"]))      # white background (rendering.py:112)
 
 
+@pytest.mark.parametrize("n_cells", [1, 3000, 200000])
+def test_frame_loop_block_hops_on_scattered_cells(n_cells):
+    """The frame loop's marcher crosses 8^3-cell blocks without an occupied cell in one hop (csrc/march.hip: render_begin_kernel builds
+    the block bits from the bitfield of the call, march_probe hops where no lattice point lies within the rounding slack of the
+    block's exit time; tests/test_block_hop_proto_cpu.py has the algorithm against the reference's walk) and runs iteration 0 on a
+    smaller sample tile.  On bitfields of isolated cells -- one cell, a few thousand, a fifth of the grid -- where nearly every
+    block boundary is a transition, the frame must stay the host loop's (vren.raymarching_test per iteration: the cell-by-cell
+    walk) bit for bit, and a second frame with a DIFFERENT bitfield must not see the first one's bits."""
+    from ngp_pl_amd.rendering import render
+    m = make_model(seed=9)
+    rng = np.random.default_rng(n_cells)
+    ro, rd, _ = batch(30000, seed=81)
+    for trial in range(2):
+        bits = np.zeros(128 ** 3, np.uint8)
+        bits[rng.integers(0, 128 ** 3, n_cells)] = 1
+        m.density_bitfield.copy_(torch.from_numpy(np.packbits(bits, bitorder="little")).cuda())
+        host = render(m, ro, rd, test_time=True, host_loop=True)
+        dev = render(m, ro, rd, test_time=True)
+        assert int(dev["total_samples"]) == int(host["total_samples"])
+        if n_cells > 1:
+            assert int(host["total_samples"]) > 0
+        for k in ("rgb", "depth", "opacity"):
+            assert torch.equal(dev[k], host[k]), (k, trial)
+        fast = render(m, ro, rd, test_time=True, chunk_scale=4, probe_cap=64)
+        for k in ("rgb", "depth", "opacity"):
+            np.testing.assert_allclose(fast[k].cpu().numpy(), host[k].cpu().numpy(), rtol=0, atol=1e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("field", ["trained", "hollow_box_on_block_faces", "blobs"])
+def test_frame_loop_block_hops_change_no_bit_of_a_frame(field):
+    """Whole 400 x 400 frames from six poses (camera rays: small lateral direction components, the case with the widest slack), rendered
+    with the block hops and -- ngp_debug_render_block_hops(0) -- cell by cell: image, depth, opacity and the sample count are the same
+    bits, in the reference's chunking and regrouped (the probe cap counts probes, so there the hops regroup the iterations: same
+    samples per ray, float rounding of T between chunks as for any regrouping)."""
+    from ngp_pl_amd import _lib
+    from ngp_pl_amd.rendering import render
+    m = make_model(seed=4)
+    if field == "trained":
+        from ngp_pl_amd.trainer import Trainer
+        tr = Trainer(m)
+        bs = [batch(4096, seed=320 + i) for i in range(4)]
+        for it in range(200):
+            tr.step(*bs[it % 4])
+    elif field == "blobs":
+        m.density_bitfield.copy_(torch.from_numpy(syn.random_blob_bitfield(1, 128, 0.05, seed=12)).cuda())
+    else:
+        g = torch.zeros(128, 128, 128, dtype=torch.bool); g[40:88, 40:88, 40:88] = True; g[44:84, 44:84, 44:84] = False      # faces ON block boundaries
+        z, y, x = torch.nonzero(g, as_tuple=True)
+        from ngp_pl_amd import vren
+        bits = np.zeros(128 ** 3, np.uint8)
+        bits[vren.morton3D(torch.stack([x, y, z], 1).int().cuda()).cpu().numpy()] = 1
+        m.density_bitfield.copy_(torch.from_numpy(np.packbits(bits, bitorder="little")).cuda())
+    W = 400
+    dirs = syn.get_ray_directions(W, W, syn.intrinsics(W)).cuda()
+    poses = syn.hemisphere_poses(6, seed=77).cuda()
+    n_samples = 0
+    try:
+        for i in range(6):
+            ro, rd = syn.get_rays(dirs, poses[i])
+            _lib.call("ngp_debug_render_block_hops", 1)
+            on = render(m, ro, rd, test_time=True)
+            on_fast = render(m, ro, rd, test_time=True, chunk_scale=4, probe_cap=64)
+            _lib.call("ngp_debug_render_block_hops", 0)
+            off = render(m, ro, rd, test_time=True)
+            assert int(on["total_samples"]) == int(off["total_samples"]), i
+            n_samples += int(on["total_samples"])
+            for k in ("rgb", "depth", "opacity"):
+                assert torch.equal(on[k], off[k]), (k, i)
+                np.testing.assert_allclose(on_fast[k].cpu().numpy(), off[k].cpu().numpy(), rtol=0, atol=1e-5, err_msg=k)
+    finally:
+        _lib.call("ngp_debug_render_block_hops", 1)
+    assert n_samples > 100000
+
+
 def test_device_frame_loop_unbounded_scene():
     """cascades > 1, exponential stepping (min_samples = 4, black background): device loop == host loop."""
     from ngp_pl_amd.rendering import render
