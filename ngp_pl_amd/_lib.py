@@ -182,6 +182,7 @@ _PROTOS = {
     "ngp_mark_invisible_cells": [P, P, I, I, I, F, I, I, F, P, P, P],
     "ngp_occupancy_update": [P, P, I, I, F, F, F, P, I, C.c_uint64, P, P, P, C.POINTER(GridMeta), P, P, C.c_size_t, P],
     "ngp_debug_render_block_hops": [I],
+    "ngp_debug_render_wave_rays": [I],
     "ngp_render_test_frame": [P, P, P, P, I, F, F, I, I, F, P, P, P, C.POINTER(GridMeta), P, P, I, I, I,
                               C.POINTER(C.c_float), P, C.c_size_t, P, P, P, P, C.POINTER(C.c_int32), P],
 }

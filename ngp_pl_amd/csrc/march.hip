@@ -1042,6 +1042,153 @@ render_finish_kernel(const float* __restrict__ opacity, float* __restrict__ rgb,
     rgb[3 * (size_t)i + 2] = rgb[3 * (size_t)i + 2] + bg_b * rest;
 }
 
+// The same iteration with ONE WAVE PER RAY, for the late iterations of a frame: a few thousand rays x up to 64 samples each, where a
+// thread per ray is one long chain of dependent probes per lane (a launch over 64 rays took 20 us, one over 1 856 rays 51 us).  The
+// wave walks the ray's lattice a tile of 64 candidates at a time exactly as march_train_count_wave_kernel does (all candidates probed
+// at once with march_probe's arithmetic, skip chains closed by pointer doubling, the orbit of the entry lane on the scalar unit) and
+// stops after the ray's N-th sample like the serial loop: same samples, same resume point (t of the last sample + its step), same
+// N_eff / retire flags.  16 rays per workgroup: their counts are summed in LDS and the packed range is reserved with one atomic.
+// Reference chunking only (probe_cap == 0: the capped mode counts probes, which a tile does not have).
+constexpr int RENDER_WAVE_RAYS_PER_WG = 16;
+template <bool SIMPLE>
+__global__ void __launch_bounds__(64 * RENDER_WAVE_RAYS_PER_WG)
+render_march_wave_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                         float* __restrict__ hits, const int32_t* __restrict__ alive,
+                         MarchParams p, RenderPlan* __restrict__ plan, int n_rays, int chunk_scale, int min_samples, int max_samples_total,
+                         float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas,
+                         float* __restrict__ ts, int32_t* __restrict__ n_eff, int32_t* __restrict__ offsets) {
+    __shared__ float s_t[RENDER_WAVE_RAYS_PER_WG][64];
+    __shared__ int s_cnt[RENDER_WAVE_RAYS_PER_WG];
+    __shared__ int s_base;
+    const int done = plan->samples_done;
+    const int n_alive = (done < max_samples_total) ? plan->n_alive_raw : 0;
+    int N = 0;
+    if (n_alive > 0) N = max(min((int)(((long long)chunk_scale * n_rays) / n_alive), 64), min_samples);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        plan->n_alive = n_alive; plan->n_step = N;
+        plan[1].samples_done = done + N;
+    }
+    if ((int)blockIdx.x * RENDER_WAVE_RAYS_PER_WG >= n_alive) return;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int n = (int)blockIdx.x * RENDER_WAVE_RAYS_PER_WG + w;
+    const bool active = n < n_alive;
+    int s = 0, flags = 0;
+    Ray ray = {};
+    size_t r = 0;
+    if (active) {
+        r = (size_t)alive[n];
+        ray = load_ray(rays_o, rays_d, r);
+        const float t2 = hits[2 * r + 1];
+        float t_start = hits[2 * r];
+        float pending = -1.0f;                              // landing value of a skip that left the previous tile (< 0: none)
+        int tiles = 0;
+        for (;;) {
+            if (++tiles > MARCH_TILE_CAP) { if (lane == 0) atomicAdd(&g_march_guard[1], 1u); break; }
+            // 1. the tile's elements
+            float mine = t_start, t_end = t_start;
+            if (!(SIMPLE && lattice_tile_const_dt(t_start, p.dt_lo, lane, mine, t_end))) {
+                float tt = t_start;
+                mine = t_start;
+#pragma unroll 8
+                for (int j = 0; j < 64; ++j) {
+                    mine = (lane == j) ? tt : mine;
+                    tt += SIMPLE ? p.dt_lo : calc_dt(tt, p);
+                }
+                t_end = tt;
+            }
+            const int nvalid = __popcll(__ballot(mine < t2));                  // the sequence increases: valid lanes are a prefix
+            const int entry = pending >= 0 ? __popcll(__ballot(mine < pending)) : 0;
+            if (entry >= 64) {
+                if (nvalid < 64) break;
+                t_start = t_end;
+                continue;
+            }
+            // 2. all candidates at once
+            float x, y, z, dt, t_next = 0.f;
+            int k = 1;
+            const bool occ = march_probe<SIMPLE>(ray, p, mine, x, y, z, dt, t_next, &k);
+            const unsigned long long empty_mask = ~__ballot(occ);
+            // 3a. where does the chain of skips that starts at an empty lane end (pointer doubling, see march_train_count_wave_kernel)
+            int chain = occ ? ((lane << 8) | 64) : ((lane << 8) | (lane + k > 64 ? 64 : lane + k));
+#pragma unroll 1
+            for (int round = 0; round < 6; ++round) {
+                const int h = chain & 0xff;
+                const bool go = h < 64 && ((empty_mask >> h) & 1ull);
+                const int via = __builtin_amdgcn_ds_bpermute((h & 63) << 2, chain);
+                if (go) chain = via;
+                if (!__ballot(go)) break;
+            }
+            // 3b. the orbit of `entry`
+            unsigned long long emit = 0ull;
+            float next_pending = -1.0f;
+            bool finished = false;
+            int v = entry;
+            while (v < 64) {
+                if (v >= nvalid) { finished = true; break; }
+                if ((empty_mask >> v) & 1ull) {
+                    const int pk = __builtin_amdgcn_readlane(chain, v);
+                    const int h = pk & 0xff;
+                    if (h >= 64) {
+                        next_pending = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t_next), pk >> 8));
+                        v = 64;
+                        break;
+                    }
+                    v = h;
+                    continue;
+                }
+                const unsigned long long un = empty_mask >> v;
+                const int u = un ? v + (int)__builtin_ctzll(un) : 64;
+                const int hi = u < nvalid ? u : nvalid;
+                if (hi > v) {
+                    const int len = hi - v;
+                    emit |= (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << v;
+                }
+                if (nvalid < 64 && u >= nvalid) { finished = true; break; }
+                v = u;
+            }
+            // 4. the ray's next samples, N in all
+            const int room = N - s;
+            const bool my = (emit >> lane) & 1ull;
+            const int rank = __popcll(emit & ((1ull << lane) - 1ull));
+            if (my && rank < room) s_t[w][s + rank] = mine;
+            const int cnt = __popcll(emit);
+            s += cnt < room ? cnt : room;
+            if (finished || s >= N) break;
+            pending = next_pending;
+            if (pending >= 0 && !(pending < t2)) break;
+            t_start = t_end;
+        }
+        wave_lds_fence();
+        if (s > 0) {
+            const float t_last = s_t[w][s - 1];
+            if (lane == 0) hits[2 * r] = t_last + (SIMPLE ? p.dt_lo : calc_dt(t_last, p));      // the serial loop's `t += dt` behind its last sample
+        } else {
+            flags = RENDER_RETIRE;                           // N_eff == 0 (volumerendering.cu:222)
+        }
+    }
+    if (lane == 0) s_cnt[w] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+#pragma unroll
+        for (int j = 0; j < RENDER_WAVE_RAYS_PER_WG; ++j) total += s_cnt[j];
+        s_base = total > 0 ? atomicAdd(&plan->m, total) : 0;
+    }
+    __syncthreads();
+    if (!active) return;
+    int base = s_base;
+    for (int j = 0; j < w; ++j) base += s_cnt[j];
+    if (lane == 0) { offsets[n] = base; n_eff[n] = s | flags; }
+    for (int j = lane; j < s; j += 64) {
+        const float t = s_t[w][j];
+        const size_t o = (size_t)base + j;
+        xyzs[3 * o] = fmaf(t, ray.dx, ray.ox); xyzs[3 * o + 1] = fmaf(t, ray.dy, ray.oy); xyzs[3 * o + 2] = fmaf(t, ray.dz, ray.oz);
+        dirs[3 * o] = ray.dx; dirs[3 * o + 1] = ray.dy; dirs[3 * o + 2] = ray.dz;
+        ts[o] = t; deltas[o] = SIMPLE ? p.dt_lo : calc_dt(t, p);
+    }
+}
+
 struct RenderLayout {
     size_t hits, alive0, alive1, n_eff, offsets, emitted, plan, total, block_any, xyzs, dirs, deltas, ts, feats, sigmas, rgbs, bytes;
     long long m_cap;
@@ -1089,6 +1236,7 @@ struct RenderHost {
 };
 thread_local RenderHost g_render_host;
 static int g_render_block_hops = 1;                 // ngp_debug_render_block_hops
+static int g_render_wave_rays = 80000;              // ngp_debug_render_wave_rays: iterations with at most this many rays run one wave per ray
 
 
 double render_wait_limit_s() {
@@ -1374,6 +1522,11 @@ size_t ngp_render_test_workspace_bytes(int n_rays, int chunk_scale, float exp_st
     return render_layout(n_rays, chunk_scale, exp_step_factor).bytes;
 }
 
+int ngp_debug_render_wave_rays(int max_rays) {
+    g_render_wave_rays = max_rays < 0 ? 80000 : max_rays;
+    return 0;
+}
+
 int ngp_debug_render_block_hops(int enabled) {
     g_render_block_hops = enabled ? 1 : 0;
     return 0;
@@ -1452,8 +1605,21 @@ int ngp_render_test_frame(const float* rays_o, const float* rays_d, const float*
         // iteration 0 marches EVERY ray for N = max(chunk_scale, min_samples) samples (n_alive = n_rays): with a tile of 8 samples per
         // ray instead of 32 / 64 the longest walks of the frame run at the SIMDs' full wave count
         const bool first = it == 0 && chunk_scale <= 8;
-        if (p.simple) { if (first) NGP_RENDER_MARCH(true, 8); else if (regroup) NGP_RENDER_MARCH(true, 32); else NGP_RENDER_MARCH(true, 64); }
-        else { if (first) NGP_RENDER_MARCH(false, 8); else if (regroup) NGP_RENDER_MARCH(false, 32); else NGP_RENDER_MARCH(false, 64); }
+        // late iterations (few rays, many samples each): one wave per ray (render_march_wave_kernel); `bound` is the survivor count of
+        // two iterations ago, an upper bound of the rays alive now.  Crossover measured on the trained fields (tools/frame_wave_ab.py:
+        // 0 / 16 384 / 80 000 / 200 000 rays -> 727 / 780 / 824 / 799 FPS on `lego`, 255 / 258 / 263 / 223 on `lego_hard`)
+        const bool per_wave = !regroup && it >= LAG && bound <= (long long)g_render_wave_rays;
+        if (per_wave) {
+            const dim3 wgrid(ngp_div_up(bound, RENDER_WAVE_RAYS_PER_WG)), wblock(64 * RENDER_WAVE_RAYS_PER_WG);
+            if (p.simple) hipLaunchKernelGGL((render_march_wave_kernel<true>), wgrid, wblock, 0, st, rays_o, rays_d, hits, alive[it & 1], p, pl, n_rays, chunk_scale,
+                                             min_samples, max_samples, xyzs, dirs, deltas, ts, n_eff, offsets);
+            else hipLaunchKernelGGL((render_march_wave_kernel<false>), wgrid, wblock, 0, st, rays_o, rays_d, hits, alive[it & 1], p, pl, n_rays, chunk_scale,
+                                    min_samples, max_samples, xyzs, dirs, deltas, ts, n_eff, offsets);
+        } else if (p.simple) {
+            if (first) NGP_RENDER_MARCH(true, 8); else if (regroup) NGP_RENDER_MARCH(true, 32); else NGP_RENDER_MARCH(true, 64);
+        } else {
+            if (first) NGP_RENDER_MARCH(false, 8); else if (regroup) NGP_RENDER_MARCH(false, 32); else NGP_RENDER_MARCH(false, 64);
+        }
 #undef NGP_RENDER_MARCH
         const int n_max = regroup ? 32 : 64;
         long long m_bound = (long long)chunk_scale * n_rays;

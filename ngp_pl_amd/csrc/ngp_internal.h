@@ -188,6 +188,11 @@ int ngp_debug_hashgrid_fwd_map(const ngp_grid_meta* meta, int n_chunks, int32_t*
  * tests render the same frames both ways and compare bits, tools time both. */
 int ngp_debug_render_block_hops(int enabled);
 
+/* Diagnostics: iterations of ngp_render_test_frame (reference chunking) that have at most max_rays rays alive march one WAVE per ray
+ * (render_march_wave_kernel) instead of one thread per ray.  0 = never, a negative value restores the default.  Same samples either way:
+ * tests render both ways and compare bits, tools time the crossover. */
+int ngp_debug_render_wave_rays(int max_rays);
+
 /* Did the last front() evaluate the field in two rounds? (1 / 0) */
 int ngp_stepper_two_rounds(const ngp_stepper* s);
 

@@ -333,6 +333,50 @@ def test_frame_loop_block_hops_change_no_bit_of_a_frame(field):
     assert n_samples > 100000
 
 
+@pytest.mark.parametrize("scene", ["trained", "blobs", "unbounded"])
+def test_frame_loop_wave_per_ray_iterations_change_no_bit(scene):
+    """Late iterations of a frame (few rays, up to 64 samples each) march one WAVE per ray (csrc/march.hip, render_march_wave_kernel:
+    the tile walk of the training marcher, stopped at the ray's N-th sample).  The crossover is a ray count
+    (ngp_debug_render_wave_rays); with it at 0 (never), at the default and at 'always' the frames are the same bits -- and the host
+    loop's -- in the Synthetic-NeRF setting and with cascades and exponential steps."""
+    from ngp_pl_amd import _lib
+    from ngp_pl_amd.rendering import render
+    kw = dict(test_time=True)
+    if scene == "unbounded":
+        from ngp_pl_amd.networks import NGP
+        torch.manual_seed(0)
+        m = NGP(4.0).cuda()
+        m.density_bitfield.copy_(torch.from_numpy(syn.random_blob_bitfield(m.cascades, 128, 0.3, seed=5).reshape(-1)).cuda())
+        g = torch.Generator(device="cuda").manual_seed(6)
+        ro = (torch.rand(20000, 3, device="cuda", generator=g) - 0.5) * 2
+        rd = torch.nn.functional.normalize(torch.randn(20000, 3, device="cuda", generator=g), dim=-1)
+        kw["exp_step_factor"] = 1 / 256.
+    else:
+        m = make_model(seed=8)
+        if scene == "trained":
+            from ngp_pl_amd.trainer import Trainer
+            tr = Trainer(m)
+            bs = [batch(4096, seed=330 + i) for i in range(4)]
+            for it in range(200):
+                tr.step(*bs[it % 4])
+        else:
+            m.density_bitfield.copy_(torch.from_numpy(syn.random_blob_bitfield(1, 128, 0.08, seed=13)).cuda())
+        ro, rd, _ = batch(60000, seed=83)
+    try:
+        _lib.call("ngp_debug_render_wave_rays", 0)
+        never = render(m, ro, rd, **kw)
+        host = render(m, ro, rd, host_loop=True, **kw)
+        assert int(never["total_samples"]) == int(host["total_samples"]) > 10000 and never["n_iterations"] > 4
+        for limit in (-1, 1 << 30, 700):
+            _lib.call("ngp_debug_render_wave_rays", limit)
+            got = render(m, ro, rd, **kw)
+            assert int(got["total_samples"]) == int(never["total_samples"]) and got["n_iterations"] == never["n_iterations"], limit
+            for k in ("rgb", "depth", "opacity"):
+                assert torch.equal(got[k], never[k]) and torch.equal(got[k], host[k]), (k, limit)
+    finally:
+        _lib.call("ngp_debug_render_wave_rays", -1)
+
+
 def test_device_frame_loop_unbounded_scene():
     """cascades > 1, exponential stepping (min_samples = 4, black background): device loop == host loop."""
     from ngp_pl_amd.rendering import render
