@@ -247,6 +247,14 @@ __device__ __forceinline__ float calc_dt(float t, const MarchParams& p) {
 // that ran into [1] (diagnostics).
 __device__ unsigned int g_march_guard[4];
 __device__ float g_march_guard_first[12];       // the first probe that ran into [0]: t, t_target, tx, ty, tz, o (3), d (3), dt_lo
+#ifdef NGP_RENDER_TIMING
+// diagnostics build (tools/build_variant.sh ... -DNGP_RENDER_TIMING; tools/render_wave_times.py): one row per wave of the frame loop's
+// thread-per-ray marcher -- wall clock at entry and exit (100 MHz), the wave's longest and summed probe counts, N and the alive count,
+// and the longest lane's own mix: hops of at most 8 lattice steps (a cell's diagonal), longer hops (blocks), samples
+constexpr unsigned int RENDER_TIMING_ROWS = 1u << 18;
+__device__ unsigned long long g_render_timing[6 * RENDER_TIMING_ROWS];
+__device__ unsigned int g_render_timing_n;
+#endif
 constexpr int MARCH_TILE_CAP = 1 << 14;          // 2^20 lattice points per ray; the longest legitimate ray (scale 64) has 2^17
 constexpr int MARCH_ITER_CAP = 1 << 20;
 
@@ -833,6 +841,10 @@ render_march_kernel(const float* __restrict__ rays_o, const float* __restrict__ 
     const int lane = threadIdx.x;
     const int n = blockIdx.x * 64 + lane;
     const bool active = n < n_alive;
+#ifdef NGP_RENDER_TIMING
+    const unsigned long long clk0 = wall_clock64();
+    int n_probes = 0, n_short = 0, n_long = 0;           // hops of at most / more than 8 lattice steps (a cell's diagonal is 8 steps long)
+#endif
     // rays leaving the object walk the rest of the box cell by cell and emit nothing: a chain of dependent bitfield loads per lane,
     // as long as the longest walk in the wave.  With the 8^3-block bits in LDS the walk through empty blocks needs no global load.
     const uint32_t* any = nullptr;
@@ -857,12 +869,18 @@ render_march_kernel(const float* __restrict__ rays_o, const float* __restrict__ 
             int iters = 0;
             while (t < t2 && s < N) {
                 if (++iters > MARCH_ITER_CAP) { atomicAdd(&g_march_guard[2], 1u); t_resume = t2; break; }
+#ifdef NGP_RENDER_TIMING
+                ++n_probes;
+#endif
                 float x, y, z, dt, t_next;
                 if (march_probe<SIMPLE>(ray, p, t, x, y, z, dt, t_next, nullptr, any, hop_slack)) {
                     s_t[s * 64 + lane] = t;
                     t += dt; ++s;
                     t_resume = t;
                 } else {
+#ifdef NGP_RENDER_TIMING
+                    if (t_next - t > 8.5f * p.dt_lo) ++n_long; else ++n_short;
+#endif
                     t = t_next;
                 }
             }
@@ -921,6 +939,26 @@ render_march_kernel(const float* __restrict__ rays_o, const float* __restrict__ 
         dirs[3 * o] = dx; dirs[3 * o + 1] = dy; dirs[3 * o + 2] = dz;
         ts[o] = t; deltas[o] = SIMPLE ? p.dt_lo : calc_dt(t, p);
     }
+#ifdef NGP_RENDER_TIMING
+    {
+        int mx = n_probes, sm = n_probes;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { mx = max(mx, __shfl_xor(mx, o, 64)); sm += __shfl_xor(sm, o, 64); }
+        const int first = (int)__builtin_ctzll(__ballot(n_probes == mx));          // the wave's longest lane and its own mix of hops
+        const int l_short = __shfl(n_short, first, 64), l_long = __shfl(n_long, first, 64), l_s = __shfl(s, first, 64);
+        if (lane == 0) {
+            const unsigned int row = atomicAdd(&g_render_timing_n, 1u);
+            if (row < RENDER_TIMING_ROWS) {
+                unsigned long long* q = g_render_timing + 6 * (size_t)row;
+                q[0] = clk0; q[1] = wall_clock64();
+                q[2] = (unsigned long long)(unsigned)mx | ((unsigned long long)(unsigned)sm << 32);
+                q[3] = (unsigned long long)(unsigned)N | ((unsigned long long)(unsigned)n_alive << 32);
+                q[4] = (unsigned long long)(unsigned)l_short | ((unsigned long long)(unsigned)l_long << 16) | ((unsigned long long)(unsigned)l_s << 32);
+                q[5] = blockIdx.x;
+            }
+        }
+    }
+#endif
 }
 
 // composite_test_fw (volumerendering.cu:219-248) for one iteration, fused with the alive-ray
@@ -1521,6 +1559,20 @@ size_t ngp_render_test_workspace_bytes(int n_rays, int chunk_scale, float exp_st
     if (n_rays <= 0 || chunk_scale < 1) return 0;
     return render_layout(n_rays, chunk_scale, exp_step_factor).bytes;
 }
+
+#ifdef NGP_RENDER_TIMING
+int ngp_debug_render_timing_read(unsigned long long* rows, int max_rows, int reset) {
+    unsigned int n = 0;
+    hipError_t e = hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_render_timing_n), sizeof(n), 0, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return -(int)e;
+    if (n > RENDER_TIMING_ROWS) n = RENDER_TIMING_ROWS;
+    if ((int)n > max_rows) n = (unsigned)max_rows;
+    if (n) e = hipMemcpyFromSymbol(rows, HIP_SYMBOL(g_render_timing), (size_t)n * 48, 0, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return -(int)e;
+    if (reset) { const unsigned int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_render_timing_n), &z, sizeof(z), 0, hipMemcpyHostToDevice); }
+    return (int)n;
+}
+#endif
 
 int ngp_debug_render_wave_rays(int max_rays) {
     g_render_wave_rays = max_rays < 0 ? 80000 : max_rays;
