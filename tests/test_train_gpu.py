@@ -377,6 +377,25 @@ def test_frame_loop_wave_per_ray_iterations_change_no_bit(scene):
         _lib.call("ngp_debug_render_wave_rays", -1)
 
 
+@pytest.mark.parametrize("n_rays", [1, 17, 63, 65, 1000])
+def test_frame_loop_on_a_handful_of_rays(n_rays):
+    """Ray counts below a wave, a workgroup's 16 rays, a wave plus one: the frame loop (thread per ray for two iterations, then a wave
+    per ray -- every count here is below the crossover) is the host loop bit for bit."""
+    from ngp_pl_amd.rendering import render
+    m = make_model(seed=2)
+    m.density_bitfield.copy_(torch.from_numpy(syn.random_blob_bitfield(1, 128, 0.1, seed=3)).cuda())
+    ro, rd, _ = batch(4096, seed=90)
+    sel = torch.randperm(4096, generator=torch.Generator().manual_seed(n_rays))[:n_rays].cuda()
+    ro, rd = ro[sel].contiguous(), rd[sel].contiguous()
+    host = render(m, ro, rd, test_time=True, host_loop=True)
+    dev = render(m, ro, rd, test_time=True)
+    assert int(dev["total_samples"]) == int(host["total_samples"])
+    if n_rays >= 17:
+        assert int(host["total_samples"]) > 0 and dev["n_iterations"] > 2
+    for k in ("rgb", "depth", "opacity"):
+        assert torch.equal(dev[k], host[k]), k
+
+
 def test_device_frame_loop_unbounded_scene():
     """cascades > 1, exponential stepping (min_samples = 4, black background): device loop == host loop."""
     from ngp_pl_amd.rendering import render
