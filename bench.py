@@ -34,7 +34,8 @@ exercised (gloo): the product path has no CPU fallback.
 
 Legs behind the headline (each with its own budget; the line is printed with whatever is complete): under a process group, on every
 rank, `dp_eval` (more data-parallel steps, then the evaluation sharded over the ranks, train.py:193-237) and `exchange_modes` (the other
-exchange modes on the same communicator); then on rank 0 `roofline`, `cpu_baseline`, `full_run`, the FPS legs, `api_path`,
+exchange modes on the same communicator); then on rank 0 `roofline`, `cpu_baseline`, `full_run`, the FPS legs (incl.
+`render_fps_800x800_reference_files`: test.ipynb cell 2 around the reference's own rendering.py on the bindings), `api_path`,
 `api_path_plain`, `api_path_reference_files` (train.py:159-185 around the reference's OWN models/*.py + losses.py, staged unmodified by
 oracle/build_ref.sh and loaded by oracle/ref_on_binding.py over this package's bindings: every kernel that runs is the product's; no
 oracle restatement is executed), `secondary` (configs[3] / configs[2] recipes) and `sensitivity` (rays/s against live samples per ray).
@@ -550,6 +551,10 @@ def full_run(base_loop, args, dev, budget_s):
     fast["loop"] = "ngp_render_test_frame chunk_scale=2 probe_cap=64 (the same composited samples per ray, regrouped: <= 1e-5 from the reference chunking)"
     ref["loop"] = "ngp_render_test_frame chunk_scale=1 probe_cap=0 (the reference's chunking, bit-identical to its host loop)"
     out["render"], out["render_reference_chunking"] = fast, ref
+    try:
+        out["render_reference_files"] = render_fps_reference_files(loop, poses[:REFERENCE_FILES_POSES])
+    except Exception as e:                                        # noqa: BLE001 -- an extra leg: say so, keep the run
+        out["render_reference_files"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     n_rays = loop.data.W * loop.data.H
     rr = {}
     for key, rec in (("regrouped", fast), ("reference_chunking", ref)):
@@ -562,6 +567,46 @@ def full_run(base_loop, args, dev, budget_s):
                               "samples_per_ray": ref["samples_per_ray"], "builder_profile": prof,
                               "what": "algorithmic bytes of a frame (SURVEY.md 8(d) per-unit figures x the rays and samples of the frame) / mean frame time over the held-out poses"}
     del loop
+    torch.cuda.empty_cache()
+    return out
+
+
+REFERENCE_FILES_POSES = 10
+
+
+@torch.no_grad()
+def render_fps_reference_files(loop, poses):
+    """test.ipynb cell 2 around the reference's OWN models/rendering.py + networks.py + custom_functions.py (unmodified; oracle/ref_on_binding)
+    on this package's `vren` / `tinycudann` bindings: `get_rays` + `render(model, rays_o, rays_d, test_time=True)` per held-out pose of the
+    trained field, one untimed frame first.  What a user of the unchanged files gets at test time: the host loop of rendering.py:46-118
+    (a `.item()`-style sync and a handful of torch kernels per iteration) over this library's kernels -- next to `render_fps_800x800`, the
+    same frames through `ngp_render_test_frame`.  The last frame is compared with that renderer's."""
+    from oracle import ref_on_binding as R
+    from ngp_pl_amd import synthetic as syn
+    from ngp_pl_amd.rendering import render
+    if not R.available():
+        return {"error": "the reference's models/*.py are neither at /root/reference nor staged under oracle/_ref/py"}
+    mods = R.load()
+    theirs = R.make_model(loop.model.scale, loop.dev)
+    theirs.load_state_dict(loop.model.state_dict(), strict=False)
+    theirs.eval()
+    ro, rd = syn.get_rays(loop.data.directions, poses[0])
+    mods.rendering.render(theirs, ro, rd, test_time=True)
+    times = []
+    for i in range(poses.shape[0]):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        ro, rd = syn.get_rays(loop.data.directions, poses[i])
+        res = mods.rendering.render(theirs, ro, rd, test_time=True)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t)
+    ours = render(loop.model, ro, rd, test_time=True)
+    mean = sum(times) / len(times)
+    out = {"fps": 1.0 / mean, "ms_per_frame": mean * 1e3, "n_frames": len(times), "source": mods.source,
+           "max_abs_rgb_difference_to_ngp_render_test_frame": float((res["rgb"].float() - ours["rgb"]).abs().max()),
+           "total_samples": int(res["total_samples"]), "total_samples_ngp_render_test_frame": int(ours["total_samples"]),
+           "what": "get_rays + the reference's own render(test_time=True) (models/rendering.py:46-118, unmodified) on ngp_pl_amd.vren / ngp_pl_amd.tcnn"}
+    del theirs
     torch.cuda.empty_cache()
     return out
 
@@ -1076,6 +1121,8 @@ def main():
                 if name in keeper.pending:
                     keeper.pending.remove(name)
                 keeper.record[name] = dict(fr[key], field_state="trained: after %d steps of %d rays (full_run)" % (fr["steps"], loop.rays))
+            if "render_reference_files" in fr:
+                keeper.record["render_fps_800x800_reference_files"] = fr["render_reference_files"]
         elif not args.no_render:
             # device-driven frame loop; chunk_scale/probe_cap only regroup the SAME per-ray samples into fewer
             # iterations (tests/test_train_gpu.py::test_device_frame_loop_matches_host_loop)

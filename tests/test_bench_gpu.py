@@ -57,6 +57,9 @@ def test_driver_command_verbatim():
     assert "reference's chunking" in d["render_fps_800x800"]["loop"]             # the headline FPS is the reference-protocol figure
     ref_files = d["api_path_reference_files"]
     assert ref_files["rays_per_s"] > 1e5 and ref_files["state_dict_missing"] == [] and ref_files["state_dict_unexpected"] == []
+    rf = d["render_fps_800x800_reference_files"]                                 # test.ipynb cell 2 around the reference's own rendering.py
+    assert "error" not in rf and rf["fps"] > 1 and rf["total_samples"] == rf["total_samples_ngp_render_test_frame"], rf
+    assert rf["max_abs_rgb_difference_to_ngp_render_test_frame"] < 2e-3, rf       # (their module path rounds h / SH once more than the fused field)
     sec = d["secondary"]                                                         # configs[3] / configs[2] recipes: on by default
     assert len(sec) == 2 and all("error" not in x and x["rays_per_s"] > 1e6 and 0 < x["roofline"]["frac"] < 1 for x in sec), sec
     assert sec[0]["cascades"] == 6 and sec[1]["rays_per_batch"] == 16384
