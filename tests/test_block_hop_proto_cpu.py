@@ -106,3 +106,18 @@ def test_block_hops_emit_the_cell_walks_samples(lib, kind):
             assert stats[4] == 0                   # the closed-form landing (one binade, constant ulps per step) is the chain of adds'
     if kind == "dense_blobs":
         assert bad_without_rule > 0           # without the slack rule the hop is NOT the walk (a handful of rays per million)
+
+
+def test_the_restatement_and_the_kernel_use_the_same_rule():
+    """The slack of a ray and the hop's acceptance test are written once in csrc/march.hip and once in tools/block_hop_proto.c: the two
+    texts must stay the same expressions (a changed constant in one of them would leave this file testing something else)."""
+    def squeeze(x):
+        return "".join(x.split())
+    kernel = squeeze(open(os.path.join(ROOT, "ngp_pl_amd", "csrc", "march.hip")).read())
+    proto = squeeze(open(os.path.join(ROOT, "tools", "block_hop_proto.c")).read())
+    slack = "8.0f*(fabsf(t2)*1.2e-7f+1.2e-7f+1.2e-7f*fmaxf(fabsf("
+    assert slack in kernel and slack in proto
+    for text in ("if(tt-tau>hop_slack&&tau-prev>hop_slack)", "if(k*delta<diff)++k;if(k*delta<diff)++k;if(k>1u&&(k-1u)*delta>=diff)--k;if(k==0u)k=1u;",
+                 "tau-t<0.25f&&(ub>>23)==(tb>>23)&&sh>=1&&sh<=23"):
+        assert text in kernel.replace("//k=thesmallestcountwithkdelta>=diff,atleast1:", "").replace("//thequotientaboveiswithinoneofit", ""), text
+        assert text in proto, text
