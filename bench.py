@@ -71,7 +71,7 @@ ROOFLINE_STEPS = 20
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
 WORKLOADS = {
     # name: (scene, scale, rays, lr, erode, description)
-    "lego": ("lego", 0.5, 8192, 1e-2, False, "configs[1]: Synthetic-NeRF Lego-like, 1xMI355X per rank, 8192 rays/batch, 800x800, scale 0.5"),
+    "lego": ("lego", 0.5, 8192, 1e-2, False, "configs[1]: Lego-like 800x800, 8192 rays/batch per MI355X, scale 0.5"),
     # the same recipe on a scene that does NOT flatter early termination (ngp_pl_amd/bench_support.py:lego_hard_scene: studs, treads
     # made of 4 mm bars, a hollow cabin, finite density sigma -> volumetric ground truth); two densities for the sensitivity
     "lego_hard": ("lego_hard:60:1.0", 0.5, 8192, 1e-2, False, "configs[1] recipe on the lego_hard scene (studs, 4 mm tread lattice, hollow cabin), sigma 60"),
@@ -142,7 +142,7 @@ def dry_run(args, rank, world, out_stream):
     else:
         world_seen = 1
     if rank == 0:
-        out_stream.emit(json.dumps({"metric": "train rays/sec", "value": None, "unit": "rays/s", "n_gpus": world_seen, "steps": args.steps,
+        out_stream.emit(compact_line({"metric": "train rays/sec", "value": None, "unit": "rays/s", "n_gpus": world_seen, "steps": args.steps,
                           "warmup": args.warmup, "dry_run": True, "note": "no GPU visible: launcher and process group only (gloo); "
                           "the product path has no CPU fallback"}))
 
@@ -484,6 +484,7 @@ def api_path_plain_rate(loop, n_steps=120):
 
 FULL_RUN_STEPS = 30000          # BASELINE.json configs[1]: 30 epochs x 1000 steps (opt.py:40, datasets/base.py:17-19)
 FULL_RUN_TEST_POSES = 200       # the Synthetic-NeRF test split (README.md:118-121 reports mean PSNR / FPS over it)
+HARD_TEST_POSES = 50            # held-out poses of the lego_hard leg (its exact volumetric ground truth costs ~0.1 s a frame, outside the timed bracket)
 
 
 def frame_bytes(n_rays, samples_per_ray):
@@ -505,15 +506,17 @@ def render_profile():
     return rec
 
 
-def full_run(base_loop, args, dev, budget_s):
+def full_run(base_loop, args, dev, budget_s, workload="lego", n_poses=FULL_RUN_TEST_POSES, extras=True):
     """BASELINE.json configs[1] run literally: FULL_RUN_STEPS optimisation steps of 8192 rays from the random initialisation
     (cosine schedule over 30 epochs, occupancy warm-up, every step timed: one wall-clock bracket around the whole run), then the
     reference's evaluation protocol on the TRAINED field (train.py:193-237, test.ipynb cell 2): PSNR and render time of
-    `render(test_time=True)` incl. ray generation over FULL_RUN_TEST_POSES held-out poses, with both chunkings of the frame loop."""
+    `render(test_time=True)` incl. ray generation over FULL_RUN_TEST_POSES held-out poses, with both chunkings of the frame loop.
+    `workload` = "lego_hard_big" (extras off): the same run and protocol on the scene that does not flatter early termination
+    (finite density, thin structures, object filling the frame) -- the `render_fps_800x800_hard` leg."""
     from ngp_pl_amd import synthetic as syn
     from ngp_pl_amd.bench_support import render_eval
     t_leg = time.perf_counter()
-    loop = Loop("lego", args, dev, 0, 1, None, data=base_loop.data)       # fresh model (seed 1337), the same HBM-resident dataset
+    loop = Loop(workload, args, dev, 0, 1, None, data=base_loop.data if workload == "lego" else None)       # fresh model (seed 1337); lego: the same HBM-resident dataset
     tr = loop.trainer
     steps = int(os.environ.get("NGP_FULL_RUN_STEPS", FULL_RUN_STEPS))
     tr.steps_per_epoch = max(steps // tr.num_epochs, 1)
@@ -536,13 +539,23 @@ def full_run(base_loop, args, dev, budget_s):
         train_s = time.perf_counter() - t0
     finally:
         gc.enable()
-    out = {"workload": "BASELINE configs[1] literal: %d steps x %d rays from the random initialisation, 800x800 Lego-like, scale 0.5" % (done, loop.rays),
+    out = {"workload": ("BASELINE configs[1] literal: %d steps x %d rays from the random initialisation, 800x800 Lego-like, scale 0.5" % (done, loop.rays))
+           if workload == "lego" else "%d steps x %d rays from the random initialisation; %s" % (done, loop.rays, loop.description),
            "steps": done, "train_s": train_s, "rays_per_s": done * loop.rays / train_s, "ms_per_step_mean": train_s / done * 1e3,
            "log": log, "complete": done == steps}
     progress("full_run: %d steps in %.2f s" % (done, train_s))
-    poses = syn.hemisphere_poses(FULL_RUN_TEST_POSES, seed=999).to(dev)       # held-out: the training set is seed 0
+    poses = syn.hemisphere_poses(n_poses, seed=999).to(dev)       # held-out: the training set is seed 0
     # the reference's protocol AND chunking first (PSNR and FPS of the line are these); then the regrouped loop as an extra
     ref = render_eval(loop.model, loop.data, poses, psnr=True)
+    if not extras:
+        out["psnr"], out["psnr_min_max"] = ref.pop("psnr"), ref.pop("psnr_min_max")
+        b = frame_bytes(loop.data.W * loop.data.H, ref["samples_per_ray"])
+        ref["roofline_frac"] = b / (ref["ms_per_frame"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        ref["loop"] = "ngp_render_test_frame chunk_scale=1 probe_cap=0 (the reference's chunking, bit-identical to its host loop)"
+        out.update(ref)
+        del loop
+        torch.cuda.empty_cache()
+        return out
     fast = render_eval(loop.model, loop.data, poses, psnr=True, chunk_scale=2, probe_cap=64)       # (swept on the trained field: profiles/r04_render_sweep_trained.txt)
     out["psnr"] = ref.pop("psnr")
     out["psnr_min_max"] = ref.pop("psnr_min_max")
@@ -718,10 +731,9 @@ def cpu_baseline_worker(path):
             S_tot += ts.shape[0]
     dt = time.perf_counter() - t0
     print(json.dumps({"value": R * n_done / dt, "unit": "rays/s", "cores": cores, "kind": "port",
-                      "sample": "%d full training steps of 256 rays (BASELINE configs[0] batch) on the same scene/occupancy grid, %.1f samples/ray, %.1f s; "
-                                "vren kernels = %s, tiny-cuda-nn parts = fp32 torch-CPU restatement with autograd + torch Adam" % (
+                      "sample": "%d full steps of 256 rays (configs[0]), %.1f samples/ray, %.1f s; vren = %s; tcnn parts = fp32 torch-CPU" % (
                                     n_done, S_tot / max(n_done, 1) / R, dt,
-                                    "reference .cu compiled for CPU (oracle/_ref)" if isinstance(vr, Reference) else "oracle/ngp_oracle.c")}), flush=True)
+                                    "reference .cu built for CPU (oracle/_ref)" if isinstance(vr, Reference) else "oracle/ngp_oracle.c")}), flush=True)
 
 
 def march_guard_record():
@@ -890,6 +902,110 @@ def dp_eval(loop, args, dev, rank, world, dist):
     return rec
 
 
+LINE_LIMIT = 3072             # bytes: the driver keeps only a tail of stdout (BENCH_r05: a 22 KB line came back unparsed)
+DETAIL_PATH = os.environ.get("NGP_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json"))
+
+
+def _num(x, digits=5):
+    """Numbers of the line at `digits` significant figures (a float's repr is 17-18 characters)."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    return float("%.*g" % (digits, x)) if x == x and abs(x) != float("inf") else None
+
+
+def _get(rec, *path):
+    for k in path:
+        if isinstance(rec, dict) and k in rec:
+            rec = rec[k]
+        elif isinstance(rec, list) and isinstance(k, int) and k < len(rec):
+            rec = rec[k]
+        else:
+            return None
+    return rec
+
+
+def compact_line(rec):
+    """The ONE line of stdout: the driver's contract fields, `roofline` and `cpu_baseline` as objects, one scalar per leg, the legs
+    that failed by name -- at most LINE_LIMIT bytes.  Everything else (per-stage times, logs, every leg's full record) is the detail
+    record: DETAIL_PATH next to this script, and stderr."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "dry_run", "note", "error", "exchange", "exchange_impl", "exchange_ms", "exposed_exchange_ms", "timed_windows", "timed_steps_total",
+            "march_guards")
+    out = {k: _num(rec[k]) if not isinstance(rec[k], str) else rec[k][:200] for k in keep if k in rec}
+    cfg = rec.get("config")
+    if isinstance(cfg, dict):
+        out["config"] = {k: (_num(v) if not isinstance(v, str) else v[:160]) for k, v in cfg.items()}
+    roof = rec.get("roofline")
+    if isinstance(roof, dict):
+        r = {k: _num(roof[k]) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_ms", "avg_ms_is", "error") if k in roof}
+        prof = roof.get("builder_profile") or {}
+        if prof.get("frac") is not None:          # the same entry from the committed rocprofv3 kernel trace (its own operating point)
+            r["profile_avg_ms"], r["profile_frac"] = _num(prof.get("kernel_sum_ms")), _num(prof["frac"])
+        for k in ("samples_marched_per_launch", "samples_active_per_launch"):
+            if k in roof:
+                r[k] = _num(roof[k], 7)
+        if _get(roof, "whole_step", "frac") is not None:
+            r["whole_step_frac"] = _num(roof["whole_step"]["frac"])
+        out["roofline"] = r
+    cpu = rec.get("cpu_baseline")
+    if isinstance(cpu, dict):
+        out["cpu_baseline"] = {k: (_num(v) if not isinstance(v, str) else v[:150]) for k, v in cpu.items() if k in ("value", "unit", "cores", "kind", "sample", "error")}
+    scalars = {
+        "render_fps_800x800": ("render_fps_800x800", "fps"), "render_fps_800x800_regrouped": ("render_fps_800x800_regrouped", "fps"),
+        "render_fps_800x800_hard": ("render_fps_800x800_hard", "fps"), "render_fps_800x800_reference_files": ("render_fps_800x800_reference_files", "fps"),
+        "render_samples_per_ray": ("render_fps_800x800", "samples_per_ray"), "render_hard_samples_per_ray": ("render_fps_800x800_hard", "samples_per_ray"),
+        "render_roofline_frac": ("full_run", "roofline_render", "frac"),
+        "psnr": ("full_run", "psnr"), "psnr_hard": ("render_fps_800x800_hard", "psnr"), "full_run_steps": ("full_run", "steps"), "full_run_train_s": ("full_run", "train_s"),
+        "api_path_rays_per_s": ("api_path", "rays_per_s"), "api_path_plain_rays_per_s": ("api_path_plain", "rays_per_s"),
+        "api_path_reference_files_rays_per_s": ("api_path_reference_files", "rays_per_s"),
+        "configs3_unbounded_rays_per_s": ("secondary", 0, "rays_per_s"), "configs2_16k_rays_per_s": ("secondary", 1, "rays_per_s"),
+        "cold_start_rays_per_s": ("cold_start", "rays_per_s"),
+        "dp_eval_psnr": ("dp_eval", "psnr"), "dp_eval_fps_aggregate": ("dp_eval", "render_fps_aggregate"), "rccl_ranks": ("dp_eval", "rccl_ranks"),
+        "exchange_mode": ("dp_eval", "exchange_mode"),
+    }
+    for name, path in scalars.items():
+        v = _get(rec, *path)
+        if v is not None:
+            out[name] = _num(v)
+    pts = _get(rec, "sensitivity", "points")
+    if pts:
+        lo, hi = min(pts, key=lambda d: d["live_samples_per_ray"]), max(pts, key=lambda d: d["live_samples_per_ray"])
+        out["sensitivity_rays_per_s"] = {"at_live_samples_per_ray": [_num(lo["live_samples_per_ray"]), _num(hi["live_samples_per_ray"])],
+                                         "rays_per_s": [_num(lo["rays_per_s"]), _num(hi["rays_per_s"])]}
+    modes = rec.get("exchange_modes")
+    if isinstance(modes, dict):
+        out["exchange_modes_ms_per_step"] = {k: _num(v.get("ms_per_step")) if isinstance(v, dict) and "error" not in v else "error" for k, v in modes.items()
+                                             if isinstance(v, dict)}
+    failed = sorted(k for k, v in rec.items() if isinstance(v, dict) and "error" in v)
+    if failed:
+        out["legs_failed"] = failed
+    out["detail"] = os.path.basename(DETAIL_PATH) + " (next to bench.py) and stderr: every leg's full record"
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) > LINE_LIMIT:                 # never expected; the contract fields win
+        for k in list(out):
+            if k not in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                         "data", "config", "roofline", "cpu_baseline", "error"):
+                out.pop(k)
+        line = json.dumps(out, separators=(",", ":"))
+    return line
+
+
+def write_detail(rec):
+    """The full record: DETAIL_PATH (best effort: a read-only tree must not cost the line) and stderr."""
+    text = json.dumps(rec)
+    try:
+        with open(DETAIL_PATH, "w") as f:
+            f.write(text + "\n")
+    except OSError as e:
+        progress("could not write %s: %s" % (DETAIL_PATH, e))
+    print("[bench detail] " + text, file=sys.stderr, flush=True)
+    # (the driver keeps the tail of stderr: what it should end with is the headline, not the middle of the detail record)
+    progress("line: value %s %s, %s ms/step; roofline %s; cpu_baseline %s" % (
+        rec.get("value"), rec.get("unit"), rec.get("ms_per_step"),
+        {k: _num(v) for k, v in (rec.get("roofline") or {}).items() if k in ("kernel", "achieved", "frac", "avg_ms", "traffic")},
+        {k: _num(v) for k, v in (rec.get("cpu_baseline") or {}).items() if k in ("value", "cores", "kind")}))
+
+
 class OnlyTheJsonLineOnStdout:
     """Everything a library prints to file descriptor 1 while the bench runs (RCCL writes a five-line version banner there when the
     first communicator is created) goes to stderr; `emit` writes the one JSON line to the real stdout."""
@@ -982,7 +1098,8 @@ class LineKeeper:
             self.emitted = True
             rec = self.record if self.record is not None else dict(self.partial)
             if self.rank == 0:
-                self.out_stream.emit(json.dumps(rec))
+                write_detail(rec)
+                self.out_stream.emit(compact_line(rec))
 
     def _watch(self):
         while not self._stop.wait(0.25):
@@ -1047,10 +1164,9 @@ def main():
         "value": r["rays_per_s"], "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16/f32", "dtype_detail": "hash tables, features, MLP operands f16 with f32 MFMA/blend accumulation; march, composite, Adam f32",
-        "data": "synthetic (procedural Lego-like scene, 100 x 800x800 ground-truth images resident in HBM; weights: tiny-cuda-nn's random "
-                "initialisation (seed 1337) TRAINED inside this run -- %d untimed setup steps + %d warm-up steps before the timed windows)" % (
-                    args.setup_steps, args.warmup),
-        "config": {"workload": loop.description + "; timed after %d untimed setup steps + %d warm-up steps (steady state: SURVEY.md 8(d))" % (args.setup_steps, args.warmup),
+        "data": "synthetic: procedural Lego-like scene, %d x %dx%d images in HBM; tcnn random init (seed 1337) TRAINED inside this run "
+                "(%d setup + %d warm-up steps, untimed)" % (args.images, args.res, args.res, args.setup_steps, args.warmup),
+        "config": {"workload": loop.description + "; steady state",
                    "rays_per_gpu": loop.rays, "image_res": args.res, "n_images": args.images, "setup_steps_untimed": args.setup_steps,
                    "samples_per_ray_marched": met["rm_s"], "samples_per_ray_composited": met["vr_s"], "train_psnr": met["psnr"],
                    "parallelism": "dp%d (per-ray data parallel, one native-gradient exchange per step)" % world},
@@ -1099,6 +1215,9 @@ def main():
             legs.append("full_run")
         if not args.no_render:
             legs += ["render_fps_800x800", "render_fps_800x800_regrouped"]
+        do_hard = do_full and not args.no_render and not args.no_secondary
+        if do_hard:
+            legs.append("render_fps_800x800_hard")
         if not args.no_api:
             legs += ["api_path", "api_path_plain", "api_path_reference_files"]
         secondary = not args.no_secondary and world == 1 and args.workload == "lego"
@@ -1141,6 +1260,9 @@ def main():
                 return ref
             keeper.leg("render_fps_800x800", reference_frames, 30.0)
             keeper.leg("render_fps_800x800_regrouped", fast_frames, 30.0)
+        if do_hard:
+            # the FPS figure on the scene that does not flatter early termination, beside the opaque one
+            keeper.leg("render_fps_800x800_hard", lambda: full_run(loop, args, dev, 45.0, workload="lego_hard_big", n_poses=HARD_TEST_POSES, extras=False), 45.0)
         if not args.no_api:
             keeper.leg("api_path", lambda: api_path_rate(loop), 30.0)
             keeper.leg("api_path_plain", lambda: api_path_plain_rate(loop), 30.0)

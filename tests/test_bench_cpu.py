@@ -32,7 +32,8 @@ class _FakeLoop:
                     metrics=dict(rm_s=40.0, vr_s=20.0, psnr=25.0, loss=0.01))
 
 
-def test_the_line_is_printed_whatever_the_side_legs_do(monkeypatch, capfd):
+def test_the_line_is_printed_whatever_the_side_legs_do(monkeypatch, capfd, tmp_path):
+    monkeypatch.setenv("NGP_BENCH_DETAIL", str(tmp_path / "bench_detail.json"))
     b = _load_bench()
     import ngp_pl_amd.bench_support as support
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--secondary"])
@@ -71,7 +72,13 @@ def test_the_line_is_printed_whatever_the_side_legs_do(monkeypatch, capfd):
     out, _ = capfd.readouterr()
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out
-    d = json.loads(lines[0])
+    assert len(lines[0]) < 4096                     # the driver keeps a tail of stdout: the line must fit (BENCH_r05's 22 KB did not)
+    line = json.loads(lines[0])
+    assert line["value"] == 1.0e7 and line["steps"] == 20 and line["warmup"] == 5 and line["n_gpus"] == 1 and line["roofline"]["bound"] == "hbm"
+    assert line["cpu_baseline"]["kind"] == "port" and line["render_fps_800x800_regrouped"] == 200.0
+    assert {"render_fps_800x800", "api_path", "api_path_reference_files"} <= set(line["legs_failed"])       # failed legs are named in the line
+    with open(tmp_path / "bench_detail.json") as f:
+        d = json.load(f)                            # every leg's full record: next to the script
     assert d["value"] == 1.0e7 and d["steps"] == 20 and d["warmup"] == 5 and d["n_gpus"] == 1 and d["roofline"]["bound"] == "hbm"
     # `render_fps_800x800` is the reference's protocol and chunking (it fails here); the regrouped loop is the extra
     assert d["render_fps_800x800_regrouped"]["fps"] == 200.0 and "field_state" in d["render_fps_800x800_regrouped"] and calls == [1, 4]
@@ -117,7 +124,13 @@ b.api_path_rate = lambda loop: {"rays_per_s": 1.0}
 sys.argv = ["bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-secondary", "--deadline", "%g"]
 b.main()
 """ % (ROOT, body, deadline))
-    return subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    return subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120,
+                          env=dict(os.environ, NGP_BENCH_DETAIL=str(tmp_path / "bench_detail.json")))
+
+
+def _detail(tmp_path):
+    with open(tmp_path / "bench_detail.json") as f:
+        return json.load(f)
 
 
 def test_a_leg_that_never_returns_costs_its_budget_not_the_line(tmp_path):
@@ -137,7 +150,11 @@ support.render_fps = spin
     assert time.perf_counter() - t < 60
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout, r.stderr)
-    d = json.loads(lines[0])
+    line = json.loads(lines[0])
+    assert len(lines[0]) < 4096
+    assert line["value"] == 1.0e7 and line["roofline"]["frac"] == 0.1 and line["cpu_baseline"]["value"] == 100.0 and "timeout" in line["error"]
+    assert {"render_fps_800x800", "render_fps_800x800_regrouped", "api_path"} <= set(line["legs_failed"])
+    d = _detail(tmp_path)
     assert d["value"] == 1.0e7 and d["roofline"]["frac"] == 0.1 and d["cpu_baseline"]["value"] == 100.0
     assert "timeout in render_fps_800x800" in d["render_fps_800x800"]["error"]
     assert d["render_fps_800x800_regrouped"]["error"].startswith("not run: timeout")
@@ -173,7 +190,7 @@ def test_cpu_baseline_runs_in_a_child_process_and_is_bounded():
     assert r["kind"] == "port" and r["unit"] == "rays/s" and r["value"] > 0 and r["cores"] == min(b.usable_cpus(), 32)
     m.density_bitfield.fill_(255)
     r = b.cpu_baseline(m, data, budget_s=1.0, timeout_s=240)          # full grid: real steps through the oracle
-    assert r["value"] > 0 and "full training steps of 256 rays" in r["sample"]
+    assert r["value"] > 0 and "full steps of 256 rays" in r["sample"]
     r = b.cpu_baseline(m, data, budget_s=30.0, timeout_s=2.0)
     assert r["value"] is None and "did not finish" in r["sample"] and r["kind"] == "port"
 

@@ -8,19 +8,34 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LINE_LIMIT = 4096          # the driver keeps a tail of stdout: BENCH_r05's 22 KB line came back unparsed
 
 
-def test_bench_prints_one_json_line_with_roofline_and_cold_start():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3", "--setup-steps", "48",
-                        "--images", "8", "--res", "200", "--no-cpu-baseline", "--no-render"],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+def _run_bench(argv, tmp_path, timeout, env=None):
+    """bench.py as the driver runs it; returns (completed process, the ONE line parsed, the detail record it left beside it)."""
+    detail = str(tmp_path / "bench_detail.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=timeout, env=dict(env or os.environ, NGP_BENCH_DETAIL=detail))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    assert len(lines[0]) < LINE_LIMIT, len(lines[0])
+    with open(detail) as f:
+        return r, json.loads(lines[0]), json.load(f)
+
+
+def test_bench_prints_one_json_line_with_roofline_and_cold_start(tmp_path):
+    _, line, d = _run_bench(["--gpus", "1", "--steps", "10", "--warmup", "3", "--setup-steps", "48", "--images", "8", "--res", "200",
+                             "--no-cpu-baseline", "--no-render"], tmp_path, 600)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cold_start", "timed_windows", "timed_steps_total", "api_path"):
         assert k in d, k
+    # the line carries the contract fields and the roofline as an object; everything else is one scalar per leg
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "api_path_rays_per_s", "cold_start_rays_per_s"):
+        assert k in line, k
+    assert abs(line["value"] - d["value"]) < 1e-4 * d["value"] and abs(line["roofline"]["frac"] - d["roofline"]["frac"]) < 1e-4
+    assert set(line["roofline"]) >= {"bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_ms"}
     assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 3 and d["unit"] == "rays/s" and d["scaling"] == "weak"
     assert d["timed_windows"] * d["steps"] == d["timed_steps_total"] >= 200
     assert d["value"] > 1e6 and abs(d["value"] - 8192 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
@@ -34,19 +49,23 @@ def test_bench_prints_one_json_line_with_roofline_and_cold_start():
     assert cold["ms_per_step"] > 0 and cold["window"].startswith("steps [3, 13)")
 
 
-def test_driver_command_verbatim():
+def test_driver_command_verbatim(tmp_path):
     """The driver's literal command, no skip flags: ONE line on stdout within the time the driver allows, carrying `roofline`
     and `cpu_baseline`, exit status 0.  (Round 2's driver run of this command was killed at 1800 s with an empty stdout.)"""
     import time
     t = time.perf_counter()
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    r, line, d = _run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5"], tmp_path, 300)
     wall = time.perf_counter() - t
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
-    d = json.loads(lines[0])
     assert "error" not in d, (d["error"], r.stderr[-3000:])
+    # what the driver parses: value + roofline + cpu_baseline as objects, the three train numbers and both FPS figures as scalars
+    assert "error" not in line and "legs_failed" not in line, line
+    assert line["value"] > 3e6 and line["steps"] == 20 and line["warmup"] == 5 and line["n_gpus"] == 1 and line["dtype"] == "f16/f32"
+    assert 0 < line["roofline"]["frac"] < 1 and line["roofline"]["bound"] == "hbm" and line["roofline"]["avg_ms"] > 0
+    assert line["cpu_baseline"]["kind"] in ("port", "reference") and line["cpu_baseline"]["cores"] >= 1
+    for k in ("render_fps_800x800", "render_fps_800x800_hard", "psnr", "api_path_rays_per_s", "api_path_plain_rays_per_s",
+              "api_path_reference_files_rays_per_s", "configs3_unbounded_rays_per_s", "configs2_16k_rays_per_s", "sensitivity_rays_per_s"):
+        assert k in line, (k, line)
+    assert "workload" in line["config"] and "model" not in line["config"]
     assert d["value"] > 3e6 and d["steps"] == 20 and d["warmup"] == 5 and d["n_gpus"] == 1
     roof, cpu = d["roofline"], d["cpu_baseline"]
     assert 0 < roof["frac"] < 1 and roof["bound"] == "hbm" and roof["whole_step"]["frac"] > 0
@@ -72,7 +91,7 @@ def test_driver_command_verbatim():
 
 
 @pytest.mark.parametrize("exchange", ["sharded", "allreduce", "direct"])
-def test_bench_under_a_one_rank_rccl_group(exchange):
+def test_bench_under_a_one_rank_rccl_group(exchange, tmp_path):
     """The multi-GPU path of bench.py on a real RCCL process group of ONE rank (what `torchrun --nproc-per-node 1 bench.py` runs):
     process group, parameter broadcast, the gradient exchange installed on the trainer (sharded: reduce-scatter -> shard Adam ->
     all-gather; or the all-reduce), the timed windows, the exchange stage timed on its own, teardown."""
@@ -81,14 +100,12 @@ def test_bench_under_a_one_rank_rccl_group(exchange):
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                NGP_DDP_EXCHANGE=exchange, HSA_ENABLE_IPC_MODE_LEGACY="0", NGP_BENCH_BOTH_MODES="1",      # (the other mode's leg, which only runs at world > 1 otherwise)
                NGP_DP_EVAL_STEPS="100")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3", "--setup-steps", "48",
-                        "--images", "8", "--res", "200", "--no-cpu-baseline", "--no-render", "--no-api"],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400, env=env)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
+    _, line, d = _run_bench(["--gpus", "1", "--steps", "10", "--warmup", "3", "--setup-steps", "48", "--images", "8", "--res", "200",
+                             "--no-cpu-baseline", "--no-render", "--no-api"], tmp_path, 400, env=env)
     assert "error" not in d, d.get("error")
+    # the N-GPU line is the same compact line + what identifies the exchange
+    assert line["exchange"] == exchange and line["exchange_impl"] == "native" and line["exchange_ms"] > 0 and line["exposed_exchange_ms"] is not None
+    assert line["rccl_ranks"] == 1 and line["exchange_mode"] == exchange and set(line["exchange_modes_ms_per_step"]) == {"sharded", "allreduce", "direct"}
     assert d["n_gpus"] == 1 and d["exchange"] == exchange and d["exchange_ms"] > 0 and d["value"] > 1e6 and d["exchange_impl"] == "native"
     assert d["config"]["train_psnr"] > 10 and d["march_guards"] == [0, 0, 0, 0]
     modes = d["exchange_modes"]

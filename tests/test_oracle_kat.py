@@ -165,3 +165,43 @@ def test_mlp_layout():
     np.testing.assert_allclose(T.mlp(x, p, 32, 2, 3, "Sigmoid").numpy(), want.numpy(), rtol=1e-6)
     f = T.Field()
     assert f.density_w.numel() == 3072 and f.rgb_w.numel() == 7168
+
+
+# ---- known answers from sources independent of the restatement (tests/kat_independent.py) ---------------------
+def test_sh4_against_scipy():
+    """oracle/tcnn_oracle.py:sh4 (the polynomial forms recalled from spherical_harmonics.h) against scipy.special's spherical harmonics
+    on 10 000 directions incl. the poles and axes: a8's constants and signs are pinned to an independent implementation."""
+    import kat_independent as K
+    d = K.unit_directions(10000, seed=3)
+    want = K.sh4_scipy(d)
+    got = T.sh4(torch.from_numpy(d)).numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+    assert np.abs(want).max() > 0.7 and (np.abs(want).max(0) > 0.28).all()      # every basis function is exercised
+
+
+def test_level_tables_are_the_literal_known_answers():
+    """Resolutions / offsets / parameter counts of the hash grid for scale 0.5 and 16 in both table modes, as literal numbers: the oracle's
+    GridMeta and the product's make_grid_meta (library ngp_grid_meta_init for float32, Python for exact) against them."""
+    import kat_independent as K
+    from ngp_pl_amd import tcnn
+    for (scale, mode), want in K.LEVELS.items():
+        b = K.per_level_scale(scale)
+        m = T.GridMeta(16, 2, 19, 16, b, exact=(mode == "exact"))
+        assert m.resolution == want["resolution"] and m.offset == want["offset"] and 2 * m.total == want["n_params"], (scale, mode)
+        pm = tcnn.make_grid_meta({"otype": "Grid", "type": "Hash", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 19,
+                                  "base_resolution": 16, "per_level_scale": b, "interpolation": "Linear"}, level_table=mode)
+        assert [pm.resolution[i] for i in range(16)] == want["resolution"] and [pm.offset[i] for i in range(17)] == want["offset"], (scale, mode)
+        assert all(abs(pm.scale[i] - m.scale[i]) <= 1e-6 * m.scale[i] for i in range(16))
+    # the parameter vector of `xyz_encoder` = 3072 MLP weights + the table (SURVEY.md 8a: 11 423 136 is the exact table's)
+    assert 3072 + K.LEVELS[(0.5, "exact")]["n_params"] == 11423136 and 3072 + K.LEVELS[(0.5, "float32")]["n_params"] == 11448112
+
+
+def test_hash_indices_are_the_hand_computed_known_answers():
+    import kat_independent as K
+    meta = T.GridMeta(16, 2, 19, 16, K.per_level_scale(0.5))
+    for (x, y, z), want in K.HASH_KAT:
+        got = int(T._corner_indices(meta, 15, torch.tensor([[x, y, z]]))[0][0])
+        assert got == want, ((x, y, z), got, want)
+    # all 8 corners of one cell: corner c adds (c & 1, (c >> 1) & 1, c >> 2)
+    idx = [int(t[0]) for t in T._corner_indices(meta, 15, torch.tensor([[0, 0, 0]]))]
+    assert idx == [0, 1, 489905, 489905 ^ 1, 153493, 153493 ^ 1, 489905 ^ 153493, 489905 ^ 153493 ^ 1]
