@@ -180,7 +180,7 @@ class Loop:
             from ngp_pl_amd.ddp import GradientExchange, NativeExchange, ShardedExchange
             self.exchange_kind = os.environ.get("NGP_DDP_EXCHANGE", "sharded")
             self.exchange_impl = "native" if os.environ.get("NGP_DDP_NATIVE", "1") != "0" else "torch.distributed"
-            # one chunk, one launch group: measured on a 1-rank RCCL group (profiles/r04_pg1_native_exchange.txt) every further launch
+            # one chunk, one launch group: measured on a 1-rank RCCL group (profiles/archive_r01_r04/r04_pg1_native_exchange.txt) every further launch
             # group of the table backward costs more than the reduce-scatter it could hide (2 groups +33 us, 4 groups +170 us per step)
             n_chunks = int(os.environ.get("NGP_DDP_CHUNKS", "1"))
             if self.exchange_impl == "native":
@@ -215,7 +215,7 @@ class Loop:
         # MARCHING stream: the allocator may hand out a block that a main-stream kernel still queued (a zero-fill of a temporary of
         # the dataset / occupancy set-up above, already freed on the host) is going to write.  Without this hand-over the first batch
         # of a loop built behind bench.py's api leg came back (partly) zeroed -- rays with origin = direction = 0, whose march never
-        # ended in round 2's kernels (t_target = inf): the 1800 s stall of BENCH_r02 (profiles/r03_round2_stall_root_cause.txt).
+        # ended in round 2's kernels (t_target = inf): the 1800 s stall of BENCH_r02 (profiles/archive_r01_r04/r03_round2_stall_root_cause.txt).
         if self.trainer.side is not None:
             self.trainer.side.wait_stream(torch.cuda.current_stream())
         self.cur = self.draw()
@@ -543,6 +543,8 @@ def full_run(base_loop, args, dev, budget_s, workload="lego", n_poses=FULL_RUN_T
            if workload == "lego" else "%d steps x %d rays from the random initialisation; %s" % (done, loop.rays, loop.description),
            "steps": done, "train_s": train_s, "rays_per_s": done * loop.rays / train_s, "ms_per_step_mean": train_s / done * 1e3,
            "log": log, "complete": done == steps}
+    if hasattr(tr, "skipped_steps"):        # steps the overflow guard did not apply (non-finite weight gradient: GradScaler's skip)
+        out["skipped_steps"] = tr.skipped_steps()[0]
     progress("full_run: %d steps in %.2f s" % (done, train_s))
     poses = syn.hemisphere_poses(n_poses, seed=999).to(dev)       # held-out: the training set is seed 0
     # the reference's protocol AND chunking first (PSNR and FPS of the line are these); then the regrouped loop as an extra
@@ -556,7 +558,7 @@ def full_run(base_loop, args, dev, budget_s, workload="lego", n_poses=FULL_RUN_T
         del loop
         torch.cuda.empty_cache()
         return out
-    fast = render_eval(loop.model, loop.data, poses, psnr=True, chunk_scale=2, probe_cap=64)       # (swept on the trained field: profiles/r04_render_sweep_trained.txt)
+    fast = render_eval(loop.model, loop.data, poses, psnr=True, chunk_scale=2, probe_cap=64)       # (swept on the trained field: profiles/archive_r01_r04/r04_render_sweep_trained.txt)
     out["psnr"] = ref.pop("psnr")
     out["psnr_min_max"] = ref.pop("psnr_min_max")
     out["psnr_regrouped"] = fast.pop("psnr"); fast.pop("psnr_min_max")

@@ -34,7 +34,8 @@ typedef uint16_t ngp_half;    /* IEEE binary16 bits */
 
 #define NGP_MAX_LEVELS 16
 
-/* ABI version; bumped when a signature changes. */
+/* ABI version; bumped when a signature, a record layout or the set of entry points changes (5: round 5's removals + `stage` in
+ * ngp_exchange_config).  A binding asserts the number it was written against (ngp_pl_amd/_lib.py: ABI_VERSION). */
 int ngp_abi_version(void);
 /* Name of the GPU arch the library was built for ("gfx950"). */
 const char* ngp_build_arch(void);
@@ -517,7 +518,7 @@ int ngp_get_rays(const float* directions, const float* c2w, int n, float* rays_o
  * cascade, count_grid (C, G^3) f32 = the fraction of the n_cams training cameras that have the cell centre inside their image at
  * depth >= near_distance, density_grid (C, G^3) f32 = 0 where that fraction is > 0 and no camera has the centre inside its image
  * closer than near_distance, else -1 (such cells are never marched nor updated).  K (3,3) f32 intrinsics, poses (n_cams,3,4) f32
- * camera-to-world, both on the device; grids in Morton order.  n_cams <= 3000. */
+ * camera-to-world, both on the device; grids in Morton order.  Any n_cams >= 1 (the cameras pass through LDS 1024 at a time). */
 int ngp_mark_invisible_cells(const float* K, const float* poses, int n_cams, int img_w, int img_h, float near_distance,
                              int cascades, int grid_size, float scale, float* count_grid, float* density_grid,
                              ngp_stream_t stream);
@@ -646,7 +647,7 @@ typedef struct ngp_step_buffers {
  * equivalent: the composite never reads a sample behind a ray's stop (volumerendering.cu:20-44), and every sample in front of it
  * has been evaluated by the same per-sample kernels (tests/test_train_gpu.py::test_two_round_forward_is_bit_identical).  What it
  * buys is modest because rays stop deep, not early (the occupied shell in front of a surface is ~20 samples thick): 0.304 -> 0.288
- * ms per step after 8 000 steps, 0.302 -> 0.283 after 25 000 (profiles/r03_two_round_forward.txt); K = 8 loses.  Not used with
+ * ms per step after 8 000 steps, 0.302 -> 0.283 after 25 000 (profiles/archive_r01_r04/r03_two_round_forward.txt); K = 8 loses.  Not used with
  * the distortion loss (its kernels walk every sample's ws) and never at the bench's operating point (half of the samples live). */
 typedef struct ngp_stepper ngp_stepper;
 int ngp_stepper_create(const ngp_stepper_config* config, const ngp_step_buffers* buffers, ngp_stepper** out);
@@ -668,7 +669,8 @@ int ngp_stepper_march(ngp_stepper* s, const float* rays_o, const float* rays_d, 
 int ngp_stepper_pending(const ngp_stepper* s, const float* rays_o, const float* rays_d);
 /* Which of the two march record sets (hits_t / rays_a / noise / scratch / counter) the last front() consumed: 0 or 1. */
 int ngp_stepper_last_set(const ngp_stepper* s);
-/* sizeof(ngp_stepper_config) (which = 0) / sizeof(ngp_step_buffers) (which = 1) as this library was compiled: a binding that
+/* sizeof(ngp_stepper_config) (which = 0) / sizeof(ngp_step_buffers) (which = 1) / sizeof(ngp_exchange_config) (which = 2) as this
+ * library was compiled: a binding that
  * mirrors the records (ctypes, cgo ...) checks its own layout against them before it hands one over. */
 int ngp_stepper_record_bytes(int which);
 /* Waits for a pending march and forgets it (the batch it was made for is not going to be stepped). */
@@ -683,8 +685,13 @@ int ngp_stepper_front(ngp_stepper* s, const float* rays_o, const float* rays_d, 
 int ngp_stepper_table_backward(ngp_stepper* s, int n_groups, int group, ngp_stream_t main_stream);
 /* table_backward(1, 0) + update() of the single-process step in ONE call, with the dense levels' merge folded into the Adam launch
  * (ngp_hashgrid_bwd_binned_deferred + ngp_adam_step_field_merge: one launch and one pass over 0.5 M entries less on the critical
- * path; bit-identical parameters).  NGP_MERGE_IN_ADAM=0 keeps the separate merge launch. */
-int ngp_stepper_backward_update(ngp_stepper* s, float lr, int32_t step, float grad_scale, ngp_stream_t main_stream);
+ * path; bit-identical parameters).
+ * OVERFLOW GUARD (what torch.cuda.amp.GradScaler does for the reference under Lightning's precision=16, train.py:274): the field
+ * backward of front() raises a device flag when a weight-gradient sum is inf / NaN -- an f16 overflow anywhere in the recomputed
+ * forward or the backward chain ends there --, and this call (like ngp_stepper_update without a found_inf of the caller's) hands the
+ * flag to the optimizer launch: such a step changes no parameter and no moment.  step_state (may be NULL): the device-side counts of
+ * APPLIED steps of ngp_adam_step_field, so that the bias correction does not advance on a skipped step. */
+int ngp_stepper_backward_update(ngp_stepper* s, float lr, int32_t step, float grad_scale, int32_t* step_state, ngp_stream_t main_stream);
 /* The same step split where the reference's API splits it (render() -> NeRFLoss -> autograd, rendering.py:121-163, losses.py:47-60):
  * render_forward = front() up to the composite WITHOUT the loss (plain ngp_composite_train_fw + ngp_active_scan), the
  * background blend into rgb_out (R,3; may be NULL) and the next batch's march; the per-ray / per-sample results stay in the

@@ -57,6 +57,9 @@ class GridPartials(C.Structure):
                 ("k_split", C.c_int32 * NGP_MAX_LEVELS), ("part_off", C.c_int64 * NGP_MAX_LEVELS), ("partial", P)]
 
 
+ABI_VERSION = 5              # include/ngp_hip.h: ngp_abi_version()
+
+
 class ExchangeConfig(C.Structure):
     """ngp_exchange_config (include/ngp_hip.h)."""
     _fields_ = [("mode", C.c_int32), ("n_chunks", C.c_int32), ("n_groups", C.c_int32), ("reserved", C.c_int32), ("piece", C.c_int64),
@@ -107,6 +110,7 @@ _PROTOS = {
     "ngp_density_bwd": [P, P, P, P, F, I, P, P, P, P, P],
     "ngp_field_bwd_partials": [I],
     "ngp_field_bwd": [P, P, P, P, P, P, P, F, I, P, P, P, P, P, P],
+    "ngp_field_bwd_guarded": [P, P, P, P, P, P, P, F, I, P, P, P, P, P, P, I, P],
     "ngp_mlp_fwd": [P, P, I, I, I, I, I, P, P],
     "ngp_mlp_bwd_partials": [I],
     "ngp_mlp_bwd": [P, P, P, I, I, I, I, I, P, P, P],
@@ -119,7 +123,7 @@ _PROTOS = {
     "ngp_adam_step_field_shard": [P, P, P, P, P, L, P, P, P, P, P, I, P, P, P, P, P, I, I, F, F, F, F, F, I, F, P, P, P, P],
     "ngp_adam_step_field_merge": [P, P, P, P, P, L, P, P, P, P, P, I, P, P, P, P, P, I, I, F, F, F, F, F, I, F, P, P, C.POINTER(GridPartials), P],
     "ngp_hashgrid_bwd_binned_deferred": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P, C.c_size_t, P, C.POINTER(GridPartials), P],
-    "ngp_stepper_backward_update": [P, F, I, F, P],
+    "ngp_stepper_backward_update": [P, F, I, F, P, P],
     "ngp_adam_step_field_pieces": [P, P, P, P, P, L, L, I, I, I, P, P, P, P, P, I, P, P, P, P, P, I, I, F, F, F, F, F, I, F, P, P, P, P],
     "ngp_comm_unique_id": [P],
     "ngp_comm_create": [P, I, I, C.POINTER(P)],
@@ -216,7 +220,10 @@ def lib():
         h.ngp_composite_train_fw_loss_workspace_bytes.restype = C.c_size_t
         h.ngp_occupancy_update_workspace_bytes.argtypes = [I, I]
         h.ngp_occupancy_update_workspace_bytes.restype = C.c_size_t
-        for which, rec in ((0, StepperConfig), (1, StepBuffersC)):      # the mirrored records must be the library's own layout
+        if h.ngp_abi_version() != ABI_VERSION:                         # a stale .so next to newer Python (or the reverse)
+            raise RuntimeError("%s has ABI version %d, this package binds version %d: rebuild the library (python -m ngp_pl_amd.build)" % (
+                LIB_PATH, h.ngp_abi_version(), ABI_VERSION))
+        for which, rec in ((0, StepperConfig), (1, StepBuffersC), (2, ExchangeConfig)):      # the mirrored records must be the library's own layout
             if h.ngp_stepper_record_bytes(which) != C.sizeof(rec):
                 raise RuntimeError("%s is %d bytes here, %d in %s: rebuild the library (python -m ngp_pl_amd.build)" % (
                     rec.__name__, C.sizeof(rec), h.ngp_stepper_record_bytes(which), LIB_PATH))

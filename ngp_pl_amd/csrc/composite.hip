@@ -268,7 +268,7 @@ composite_train_bw_kernel(const float* __restrict__ dL_dopacity, const float* __
         const int tid = threadIdx.x, wave = tid >> 6;
         const int row0 = 4 * (int)blockIdx.x;                              // rows in front of this workgroup: a multiple of 4
         // all of a thread's loads first (8 x 16 bytes cover 8192 rows: one L2 round trip, not one per trip of a loop -- the first
-        // version's dependent trips added 8 us to a 12 us kernel, profiles/r04_kernel_trace_summary.txt), a loop only beyond that
+        // version's dependent trips added 8 us to a 12 us kernel, profiles/archive_r01_r04/r04_kernel_trace_summary.txt), a loop only beyond that
         int4 v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {

@@ -101,7 +101,7 @@ __device__ __forceinline__ void cell_of(const float* __restrict__ x, const Box& 
 
 // The 8 corner values of a cell: 8 independent 4-byte gathers.  (Fetching the x-neighbour pairs of a hashed level as one aligned 8-byte
 // gather -- 6 lane addresses per cell instead of 8 -- was built and measured in round 4: forward 0.060 -> 0.071 ms, not kept;
-// profiles/r04_step_ab.txt (c).)
+// profiles/archive_r01_r04/r04_step_ab.txt (c).)
 template <bool HASHED>
 __device__ __forceinline__ void gather_corners(const half2_t* __restrict__ tab, const uint32_t (&p)[3], uint32_t res, uint32_t size,
                                                half2_t (&v)[8]) {
@@ -243,7 +243,7 @@ hashgrid_fwd_list_kernel(const float* __restrict__ x, const float* __restrict__ 
 
 // (Coarse levels served from tables RESIDENT IN LDS -- north_star's "gather staged through LDS" -- were built and measured in round 2:
 // 147 KB of half2 for levels 0-2 in one CU's LDS, a persistent 1024-thread workgroup per CU; slower than the L2 path, which already
-// hits 93 % on those tables and keeps 8 workgroups per CU in flight.  profiles/r02_hashgrid_fwd_lds_experiment.txt; removed in round 5.)
+// hits 93 % on those tables and keeps 8 workgroups per CU in flight.  profiles/archive_r01_r04/r02_hashgrid_fwd_lds_experiment.txt; removed in round 5.)
 
 // ---- backward w.r.t. the input positions (pose optimisation, train.py:86-89,117-122) -------------
 // tiny-cuda-nn's grid backward-input for linear interpolation: d feat / d pos_k =

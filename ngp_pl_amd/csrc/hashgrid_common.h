@@ -16,15 +16,20 @@ struct GridMeta {
     float scale[NGP_MAX_LEVELS];
 };
 
-// x01 = (x - min) * (1/(max - min))  [networks.py:103 divides; the reciprocal is exact for the
-// power-of-two extents the reference uses], pos = x01*scale + 0.5, cell = floor(pos).
+// x01 = (x - min) * (1/(max - min))  [networks.py:103 divides: identical bits for the power-of-two extents 2 x scale of every recipe
+// of the reference (scale 0.5 ... 16); for any other extent the product with the correctly rounded reciprocal is within 1 ulp of the
+// quotient -- INTEGRATION.md "Box extents"], pos = x01*scale + 0.5, cell = floor(pos).
 struct Box { float mn[3], inv[3]; };
 __device__ __forceinline__ Box load_box(const float* __restrict__ xyz_min, const float* __restrict__ xyz_max) {
     Box b;
+    // v_rcp_f32 is exact for a power of two (the common case: one instruction); any other extent takes the correctly rounded division
+    // of this build's flags (~10 vector instructions per axis, behind a branch that is uniform over the launch)
 #pragma unroll
-    // v_rcp_f32 (exact for the power-of-two extents 2 x scale of every recipe, 1 ulp otherwise): the correctly rounded division this
-    // build's flags give `1.0f / x` costs ~10 vector instructions per axis (28 of the forward kernel's 201; measured: -1 us, round 5)
-    for (int k = 0; k < 3; ++k) { b.mn[k] = xyz_min[k]; b.inv[k] = __builtin_amdgcn_rcpf(xyz_max[k] - xyz_min[k]); }
+    for (int k = 0; k < 3; ++k) {
+        const float e = xyz_max[k] - xyz_min[k];
+        b.mn[k] = xyz_min[k];
+        b.inv[k] = (__float_as_uint(e) & 0x007fffffu) == 0u ? __builtin_amdgcn_rcpf(e) : 1.0f / e;
+    }
     return b;
 }
 // tiny-cuda-nn grid_index(): the dense stride walk uses the hash iff res^3 overflows the level

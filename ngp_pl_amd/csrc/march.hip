@@ -1290,7 +1290,7 @@ double render_wait_limit_s() {
 extern "C" {
 #pragma GCC visibility push(default)
 
-int ngp_abi_version(void) { return 4; }
+int ngp_abi_version(void) { return 5; }
 
 int ngp_march_guard_first(float* probe12) {
     NGP_CHECK_PTR(probe12);
@@ -1431,7 +1431,7 @@ int ngp_raymarching_train_count_k(const float* rays_o, const float* rays_d, cons
         NGP_CHECK_PTR(noise); NGP_CHECK_PTR(rays_a); NGP_CHECK_PTR(t_scratch);
         const MarchParams p = make_march_params(density_bitfield, cascades, grid_size, scale, scale, exp_step_factor, max_samples);
         // Pass 1 runs one WAVE per ray (march_train_count_wave_kernel: 64 candidates of the ray's fixed t-sequence probed per pass,
-        // bit-identical to the serial loop, 101 us instead of 280-330 us per 8192-ray batch: profiles/r01_v20_wave_march_kernel_trace.txt,
+        // bit-identical to the serial loop, 101 us instead of 280-330 us per 8192-ray batch: profiles/archive_r01_r04/r01_v20_wave_march_kernel_trace.txt,
         // gpurun sweep of round 2: the step time is the same for every placement, the marching stream is busy a third as long).
         const dim3 grid(ngp_div_up((long long)n_rays * 64, 256));
         if (p.simple)

@@ -538,6 +538,11 @@ struct MlpBwdIO {
     // dL_din out) by the compact position, so rgb-net -> density-net -> grid scatter stay dense.
     const int32_t* active;
     const int32_t* n_active;
+    // Optional overflow guard (the native stepper's GradScaler: a step whose weight gradient is not finite is skipped by the
+    // optimizer launch): a workgroup whose reduced dW holds an inf / NaN sets *nonfinite; workgroup 0 clears *nonfinite_clear (the
+    // flag of the NEXT step: two flags alternate, so that no launch resets a word a later launch of the same step reads).
+    int32_t* nonfinite;
+    int32_t* nonfinite_clear;
 };
 
 // Lanes of one wave exchange data through LDS: DS operations of a wave execute in program
@@ -636,7 +641,7 @@ __device__ __forceinline__ void wgrad_tile(const char* dy, const char* x, const 
 // LDS copy, 4 serial rounds with barriers -- 11 000 cycles of a 70 000-cycle kernel.)
 template <int MT, int NT, int BWD_WAVES, bool SPLIT>
 __device__ __forceinline__ void wgrad_reduce_layer(float* slabs, int n_rows, int n_cols, int wave, int j, int hh,
-                                                   const f32x16 (&acc)[MT][NT], float* __restrict__ out) {
+                                                   const f32x16 (&acc)[MT][NT], float* __restrict__ out, float& nonfinite) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     // SPLIT: one pass per 32-row block of the layer (slabs of 32 x n_cols floats), else the whole layer at once
     constexpr int PASSES = SPLIT ? MT : 1, MP = SPLIT ? 1 : MT;
@@ -661,6 +666,8 @@ __device__ __forceinline__ void wgrad_reduce_layer(float* slabs, int n_rows, int
 #pragma unroll
             for (int w = 1; w < BWD_WAVES; ++w) v += *reinterpret_cast<const f32x4*>(slabs + w * n + t);
             *reinterpret_cast<f32x4*>(o + t) = v;
+            const f32x4 d = v - v;                        // 0 for a finite sum, NaN for inf / NaN
+            nonfinite += (d[0] + d[1]) + (d[2] + d[3]);
         }
         __syncthreads();                                  // the next pass / layer reuses the slabs
     }
@@ -1026,9 +1033,12 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
     __syncthreads();                                      // the slabs reuse the operand images: every wave is done with them
     constexpr int NT0 = (N_IN / 32 > 0 ? N_IN / 32 : 1);
     float* out = io.wgrad_partial + (size_t)blockIdx.x * L::G_SIZE;
-    wgrad_reduce_layer<2, NT0, BWD_WAVES, B::STAGED>(part, HID, N_IN, wave, i, hh, gW0, out);
-    if (N_HIDDEN == 2) wgrad_reduce_layer<2, 2, BWD_WAVES, B::STAGED>(part, HID, HID, wave, i, hh, gW1, out + L::G_W1);
-    wgrad_reduce_layer<1, 2, BWD_WAVES, B::STAGED>(part, 16, HID, wave, i, hh, gWo, out + L::G_WO);
+    float nonfinite = 0.f;
+    wgrad_reduce_layer<2, NT0, BWD_WAVES, B::STAGED>(part, HID, N_IN, wave, i, hh, gW0, out, nonfinite);
+    if (N_HIDDEN == 2) wgrad_reduce_layer<2, 2, BWD_WAVES, B::STAGED>(part, HID, HID, wave, i, hh, gW1, out + L::G_W1, nonfinite);
+    wgrad_reduce_layer<1, 2, BWD_WAVES, B::STAGED>(part, 16, HID, wave, i, hh, gWo, out + L::G_WO, nonfinite);
+    if (io.nonfinite != nullptr && nonfinite != 0.f) atomicOr(io.nonfinite, 1);          // (NaN != 0: taken exactly when a sum was inf / NaN)
+    if (io.nonfinite_clear != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *io.nonfinite_clear = 0;
     MLP_T(5);                                          // epilogue
     MLP_TEND();
 }
@@ -1196,7 +1206,7 @@ int ngp_field_bwd_partials(int n_samples) { return n_samples <= 0 ? 0 : bwd_grid
 // (the colour net's half of ngp_field_bwd: internal)
 static int ngp_rgb_bwd(const ngp_half* h, const float* dirs, const ngp_half* rgb_w, const float* dL_drgbs, float loss_scale,
                 int n_samples, const int32_t* active_idx, const int32_t* n_active, ngp_half* dL_dh, float* wgrad_partial,
-                ngp_stream_t stream) {
+                int32_t* nonfinite, int32_t* nonfinite_clear, ngp_stream_t stream) {
     if (n_samples < 0) return NGP_EINVAL;
     if (n_samples == 0) return 0;
     NGP_CHECK_PTR(h); NGP_CHECK_PTR(dirs); NGP_CHECK_PTR(rgb_w); NGP_CHECK_PTR(dL_drgbs); NGP_CHECK_PTR(dL_dh); NGP_CHECK_PTR(wgrad_partial);
@@ -1205,12 +1215,13 @@ static int ngp_rgb_bwd(const ngp_half* h, const float* dirs, const ngp_half* rgb
     r.dL_drgbs = dL_drgbs; r.loss_scale = loss_scale; r.dL_din = (h1*)dL_dh; r.wgrad_partial = wgrad_partial;
     if ((active_idx == nullptr) != (n_active == nullptr)) return NGP_EINVAL;
     r.active = active_idx; r.n_active = n_active;
+    r.nonfinite = nonfinite; r.nonfinite_clear = nonfinite_clear;
     return launch_bwd<32, 2, IN_SH_H, OUT_RGB>(r, (const h1*)rgb_w, n_samples, ngp_stream(stream));
 }
 
-int ngp_density_bwd(const ngp_half* feats, const ngp_half* density_w, const ngp_half* dL_dh, const float* dL_dsigmas,
-                    float loss_scale, int n_samples, const int32_t* active_idx, const int32_t* n_active,
-                    ngp_half* dfeats, float* wgrad_partial, ngp_stream_t stream) {
+static int density_bwd_guarded(const ngp_half* feats, const ngp_half* density_w, const ngp_half* dL_dh, const float* dL_dsigmas,
+                               float loss_scale, int n_samples, const int32_t* active_idx, const int32_t* n_active,
+                               ngp_half* dfeats, float* wgrad_partial, int32_t* nonfinite, ngp_stream_t stream) {
     if (n_samples < 0) return NGP_EINVAL;
     if (n_samples == 0) return 0;
     NGP_CHECK_PTR(feats); NGP_CHECK_PTR(density_w); NGP_CHECK_PTR(dfeats); NGP_CHECK_PTR(wgrad_partial);
@@ -1220,22 +1231,40 @@ int ngp_density_bwd(const ngp_half* feats, const ngp_half* density_w, const ngp_
     d.dL_dsigmas = dL_dsigmas; d.loss_scale = loss_scale; d.dL_din = (h1*)dfeats; d.wgrad_partial = wgrad_partial;
     if ((active_idx == nullptr) != (n_active == nullptr)) return NGP_EINVAL;
     d.active = active_idx; d.n_active = n_active;
+    d.nonfinite = nonfinite;
     return launch_bwd<32, 1, IN_LEVELMAJOR, OUT_DENSITY>(d, (const h1*)density_w, n_samples, ngp_stream(stream));
+}
+
+int ngp_density_bwd(const ngp_half* feats, const ngp_half* density_w, const ngp_half* dL_dh, const float* dL_dsigmas,
+                    float loss_scale, int n_samples, const int32_t* active_idx, const int32_t* n_active,
+                    ngp_half* dfeats, float* wgrad_partial, ngp_stream_t stream) {
+    return density_bwd_guarded(feats, density_w, dL_dh, dL_dsigmas, loss_scale, n_samples, active_idx, n_active, dfeats, wgrad_partial, nullptr, stream);
 }
 
 int ngp_field_bwd(const ngp_half* feats, const float* dirs, const ngp_half* h, const ngp_half* density_w,
                   const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale,
                   int n_samples, const int32_t* active_idx, const int32_t* n_active,
                   ngp_half* dh_scratch, ngp_half* dfeats, float* wgrad_partial, ngp_stream_t stream) {
+    return ngp_field_bwd_guarded(feats, dirs, h, density_w, rgb_w, dL_dsigmas, dL_drgbs, loss_scale, n_samples, active_idx, n_active, dh_scratch, dfeats,
+                                 wgrad_partial, nullptr, 0, stream);
+}
+
+// (csrc/ngp_internal.h) the same with the native stepper's overflow guard: nonfinite2 = two device flags; this call ORs 1 into
+// nonfinite2[parity] when a weight-gradient sum of either network is inf / NaN and clears nonfinite2[parity ^ 1] (the next step's).
+int ngp_field_bwd_guarded(const ngp_half* feats, const float* dirs, const ngp_half* h, const ngp_half* density_w,
+                          const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale,
+                          int n_samples, const int32_t* active_idx, const int32_t* n_active,
+                          ngp_half* dh_scratch, ngp_half* dfeats, float* wgrad_partial, int32_t* nonfinite2, int parity, ngp_stream_t stream) {
     if (n_samples < 0) return NGP_EINVAL;
     if (n_samples == 0) return 0;
     NGP_CHECK_PTR(wgrad_partial);
     const int n_part = bwd_grid(n_samples);
+    int32_t* flag = nonfinite2 ? nonfinite2 + (parity & 1) : nullptr;
     const int rc = ngp_rgb_bwd(h, dirs, rgb_w, dL_drgbs, loss_scale, n_samples, active_idx, n_active, dh_scratch,
-                               wgrad_partial + (size_t)n_part * NGP_DENSITY_NET_PARAMS, stream);
+                               wgrad_partial + (size_t)n_part * NGP_DENSITY_NET_PARAMS, flag, nonfinite2 ? nonfinite2 + ((parity & 1) ^ 1) : nullptr, stream);
     if (rc) return rc;
-    return ngp_density_bwd(feats, density_w, dh_scratch, dL_dsigmas, loss_scale, n_samples, active_idx, n_active, dfeats,
-                           wgrad_partial, stream);
+    return density_bwd_guarded(feats, density_w, dh_scratch, dL_dsigmas, loss_scale, n_samples, active_idx, n_active, dfeats,
+                               wgrad_partial, flag, stream);
 }
 
 int ngp_mlp_fwd(const ngp_half* in, const ngp_half* weights, int n_in, int n_hidden, int n_out, int out_act,

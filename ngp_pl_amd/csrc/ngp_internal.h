@@ -27,6 +27,17 @@ typedef struct ngp_grid_partials {
     const float* partial;                       /* (entries, 2) f32, device */
 } ngp_grid_partials;
 
+/* ngp_field_bwd with the native stepper's overflow guard (what torch.cuda.amp.GradScaler does for the reference under Lightning's
+ * precision=16, train.py:274: a step whose gradients hold an inf / NaN is skipped).  nonfinite2 = two i32 flags on the device (NULL:
+ * no guard); this call ORs 1 into nonfinite2[parity & 1] when a weight-gradient sum of either network is not finite -- an f16
+ * overflow anywhere in the forward recompute or the backward chain ends there -- and clears nonfinite2[(parity & 1) ^ 1], the flag of
+ * the next step: the optimizer launch of THIS step reads nonfinite2[parity & 1] as its found_inf. */
+int ngp_field_bwd_guarded(const ngp_half* feats, const float* dirs, const ngp_half* h, const ngp_half* density_w,
+                          const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale,
+                          int n_samples, const int32_t* active_idx, const int32_t* n_active,
+                          ngp_half* dh_scratch, ngp_half* dfeats, float* wgrad_partial, int32_t* nonfinite2, int parity,
+                          ngp_stream_t stream);
+
 /* The same launch also draws the marcher's per-ray jitter (custom_functions.py:83: torch.rand_like(rays_o[:, 0])):
  * noise (R) f32 in [0,1) from a counter-based generator keyed by (seed, ray). */
 int ngp_ray_aabb_near_noise(const float* rays_o, const float* rays_d,

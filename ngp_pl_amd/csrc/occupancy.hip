@@ -234,28 +234,19 @@ OccLayout occ_layout(int cascades, int grid_size) {
 // One thread per cell of every cascade (Morton index = position in the grid): the cell centre is taken to every training camera
 // -- p_cam = R^T (x - t) from the camera-to-world pose [R | t], (u, v, d) = K p_cam -- and the cell is VALID when at least one camera
 // has it inside its image at depth >= near and NO camera has it inside its image closer than near.  count_grid = fraction of the
-// cameras that cover the cell (the erode decay's exponent, networks.py:262-264), density_grid = 0 / -1.  The poses sit in LDS
-// (48 B per camera), every thread walks them in the same order: no divergence but the two flags.
+// cameras that cover the cell (the erode decay's exponent, networks.py:262-264), density_grid = 0 / -1.  The poses pass through LDS
+// MARK_CAMS at a time (48 B per camera), every thread walks them in the same order: no divergence but the two flags, and no
+// bound on the number of training cameras (the reference's loop has none either).
+constexpr int MARK_CAMS = 1024;
 __global__ void __launch_bounds__(256)
 mark_invisible_kernel(const float* __restrict__ K, const float* __restrict__ poses, int n_cams, float img_w, float img_h,
                       float near_distance, int grid_size, float scale, int cells, int n_total,
                       float* __restrict__ count_grid, float* __restrict__ density_grid) {
-    extern __shared__ float s_cam[];                       // per camera: the 9 entries of R^T, then -R^T t
-    for (int i = threadIdx.x; i < n_cams; i += blockDim.x) {
-        const float* P = poses + 12 * (size_t)i;           // row-major 3 x 4: [R | t]
-        float* o = s_cam + 12 * i;
-        const float t0 = P[3], t1 = P[7], t2 = P[11];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {                      // row r of R^T = column r of R
-            const float a = P[r], b = P[4 + r], c = P[8 + r];
-            o[3 * r] = a; o[3 * r + 1] = b; o[3 * r + 2] = c;
-            o[9 + r] = -(a * t0 + b * t1 + c * t2);
-        }
-    }
-    __syncthreads();
+    __shared__ float s_cam[12 * MARK_CAMS];                // per camera: the 9 entries of R^T, then -R^T t
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_total) return;
-    const int c = g / cells, m = g - c * cells;
+    const bool live = g < n_total;
+    const int gc = live ? g : n_total - 1;
+    const int c = gc / cells, m = gc - c * cells;
     // s = min(2^(c-1), scale); cell centres at (coord / (G - 1) * 2 - 1) * (s - s / G)   (networks.py:216-221)
     float s = c == 0 ? 0.5f : (float)(1 << (c - 1));
     s = fminf(s, scale);
@@ -265,17 +256,34 @@ mark_invisible_kernel(const float* __restrict__ K, const float* __restrict__ pos
     const float z = ((float)ngp_compact_bits((uint32_t)m >> 2) / gm1 * 2.0f - 1.0f) * span;
     const float k00 = K[0], k01 = K[1], k02 = K[2], k10 = K[3], k11 = K[4], k12 = K[5], k20 = K[6], k21 = K[7], k22 = K[8];
     int covered = 0; bool too_near = false;
-    for (int i = 0; i < n_cams; ++i) {
-        const float* o = s_cam + 12 * i;
-        const float px = o[0] * x + o[1] * y + o[2] * z + o[9];
-        const float py = o[3] * x + o[4] * y + o[5] * z + o[10];
-        const float pz = o[6] * x + o[7] * y + o[8] * z + o[11];
-        const float ud = k00 * px + k01 * py + k02 * pz, vd = k10 * px + k11 * py + k12 * pz, d = k20 * px + k21 * py + k22 * pz;
-        const float u = ud / d, v = vd / d;                // (d == 0: inf / nan, every comparison below is false like torch's)
-        const bool in_image = d >= 0.f && u >= 0.f && u < img_w && v >= 0.f && v < img_h;
-        covered += (in_image && d >= near_distance) ? 1 : 0;
-        too_near = too_near || (in_image && d < near_distance);
+    for (int c0 = 0; c0 < n_cams; c0 += MARK_CAMS) {
+        const int nc = min(MARK_CAMS, n_cams - c0);
+        if (c0 > 0) __syncthreads();                       // the previous tile has been read by every thread
+        for (int i = threadIdx.x; i < nc; i += blockDim.x) {
+            const float* P = poses + 12 * (size_t)(c0 + i);    // row-major 3 x 4: [R | t]
+            float* o = s_cam + 12 * i;
+            const float t0 = P[3], t1 = P[7], t2 = P[11];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {                  // row r of R^T = column r of R
+                const float a = P[r], b = P[4 + r], cc = P[8 + r];
+                o[3 * r] = a; o[3 * r + 1] = b; o[3 * r + 2] = cc;
+                o[9 + r] = -(a * t0 + b * t1 + cc * t2);
+            }
+        }
+        __syncthreads();
+        for (int i = 0; i < nc; ++i) {
+            const float* o = s_cam + 12 * i;
+            const float px = o[0] * x + o[1] * y + o[2] * z + o[9];
+            const float py = o[3] * x + o[4] * y + o[5] * z + o[10];
+            const float pz = o[6] * x + o[7] * y + o[8] * z + o[11];
+            const float ud = k00 * px + k01 * py + k02 * pz, vd = k10 * px + k11 * py + k12 * pz, d = k20 * px + k21 * py + k22 * pz;
+            const float u = ud / d, v = vd / d;            // (d == 0: inf / nan, every comparison below is false like torch's)
+            const bool in_image = d >= 0.f && u >= 0.f && u < img_w && v >= 0.f && v < img_h;
+            covered += (in_image && d >= near_distance) ? 1 : 0;
+            too_near = too_near || (in_image && d < near_distance);
+        }
     }
+    if (!live) return;
     const float count = (float)covered / (float)n_cams;
     count_grid[g] = count;
     density_grid[g] = (count > 0.f && !too_near) ? 0.f : -1.f;
@@ -301,7 +309,7 @@ int ngp_occupancy_update_workspace_layout(int cascades, int grid_size, size_t* t
 
 // (Split into draw / finish with the NEXT update's draws made ahead on a third stream: built and measured in round 4 -- timed windows
 // +0.6 %, the 30 000-step run -8 %: the two cross-stream hand-overs per update cost more than the 0.09 ms they hide; removed in round 5.
-// profiles/r04_step_ab.txt (e).)
+// profiles/archive_r01_r04/r04_step_ab.txt (e).)
 static int occupancy_impl(float* density_grid, uint8_t* density_bitfield, int cascades, int grid_size, float scale,
                           float density_threshold, float decay, const float* decay_grid, int warmup, uint64_t seed,
                           const float* xyz_min, const float* xyz_max, const ngp_half* table, const ngp_grid_meta* meta,
@@ -378,23 +386,12 @@ int ngp_occupancy_update(float* density_grid, uint8_t* density_bitfield, int cas
 
 int ngp_mark_invisible_cells(const float* K, const float* poses, int n_cams, int img_w, int img_h, float near_distance,
                              int cascades, int grid_size, float scale, float* count_grid, float* density_grid, ngp_stream_t stream) {
-    if (n_cams < 1 || n_cams > 3000 || cascades < 1 || grid_size < 2 || grid_size > 1024 || (grid_size & (grid_size - 1)) || img_w < 1 || img_h < 1)
-        return NGP_EINVAL;                                  // (3000 cameras x 48 B: the poses must fit one CU's LDS)
+    if (n_cams < 1 || cascades < 1 || grid_size < 2 || grid_size > 1024 || (grid_size & (grid_size - 1)) || img_w < 1 || img_h < 1)
+        return NGP_EINVAL;
     NGP_CHECK_PTR(K); NGP_CHECK_PTR(poses); NGP_CHECK_PTR(count_grid); NGP_CHECK_PTR(density_grid);
     const long long cells = (long long)grid_size * grid_size * grid_size, total = cells * cascades;
     if (total > 0x7fffffffLL) return NGP_EINVAL;
-    const size_t smem = (size_t)n_cams * 12 * sizeof(float);
-    if (smem > 48 * 1024) {
-        static bool attr_set[64] = {};
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        dev &= 63;
-        if (!attr_set[dev]) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mark_invisible_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-            if (e != hipSuccess) return (int)e;
-            attr_set[dev] = true;
-        }
-    }
+    const size_t smem = 0;
     hipLaunchKernelGGL(mark_invisible_kernel, dim3(ngp_div_up(total, 256)), dim3(256), smem, ngp_stream(stream),
                        K, poses, n_cams, (float)img_w, (float)img_h, near_distance, grid_size, scale, (int)cells, (int)total, count_grid, density_grid);
     return NGP_LAUNCH_RESULT();

@@ -73,6 +73,12 @@ struct ngp_stepper {
     int32_t* counts[2] = {nullptr, nullptr};   // per record set: the rays' sample counts as a dense i32 array (ngp_march_train_fused's prefix input)
     int counts_rays = 0;
     bool same_stream[2] = {false, false};  // record set k was marched on the main stream itself (render() without a next batch)
+    // overflow guard of the native step (GradScaler's skip, train.py:274): two device flags used alternately; the field backward of
+    // a step raises guard[guard_parity] when a weight-gradient sum is not finite, the optimizer launch of that step reads it
+    int32_t* guard = nullptr;
+    int guard_parity = 0;
+    bool guard_armed = false;              // this step's field backward ran with the guard (consumed by the update)
+    bool fused[2] = {false, false};        // record set k was marched by ngp_march_train_fused (count word published by its expansion launch's last workgroup)
 };
 
 void destroy_exchange_events(ngp_stepper* s);
@@ -121,9 +127,11 @@ int wait_march(ngp_stepper* s, int k, bool count_is_enough = false) {
             if (std::chrono::steady_clock::now() > t_end) return NGP_ETIMEOUT;
         }
     }
-    // marched on the main stream itself: what the caller enqueues next is ordered behind the march by the stream, and the count
-    // (published before the expansion) is all the host needs -- it sizes the forward's launches while the expansion still runs
-    if (count_is_enough && s->same_stream[k] && cnt[0] >= 0) return 0;
+    // marched on the main stream itself by ngp_march_train_fused: what the caller enqueues next is ordered behind the march by the
+    // stream, and the count (published before the expansion) is all the host needs -- it sizes the forward's launches while the
+    // expansion still runs.  NOT for the scan path: its kernel publishes counter[0] before counter[3] (the launch size of the compact
+    // two-round list, which forward_field reads on the host) with plain stores; only the event orders those two reads.
+    if (count_is_enough && s->same_stream[k] && s->fused[k] && cnt[0] >= 0) return 0;
     hipError_t e;
     while ((e = hipEventQuery(s->done[k])) == hipErrorNotReady) {
         if ((++spins & 255u) == 0 && std::chrono::steady_clock::now() > t_end) return NGP_ETIMEOUT;
@@ -136,7 +144,7 @@ enum { AT_TOP = 0, AT_HASHGRID_FWD, AT_MLP_FWD, AT_COMPOSITE_FW, AT_COMPOSITE_BW
 int march_at_from_env() {
     static const int v = [] {
         const char* e = getenv("NGP_MARCH_AT");
-        if (!e) return (int)AT_MLP_FWD;            // profiles/r03_march_sweep.txt: 0.417 ms per step against 0.424 behind the composite forward
+        if (!e) return (int)AT_MLP_FWD;            // profiles/archive_r01_r04/r03_march_sweep.txt: 0.417 ms per step against 0.424 behind the composite forward
         const char* names[] = {"top", "hashgrid_fwd", "mlp_fwd", "composite_fw", "composite_bw", "mlp_bwd", "hashgrid_bwd", "adam"};
         for (int i = 0; i < 8; ++i) if (strcmp(e, names[i]) == 0) return i;
         return (int)AT_MLP_FWD;
@@ -172,12 +180,17 @@ int do_march(ngp_stepper* s, const float* rays_o, const float* rays_d, hipStream
         STEP_HIP(hipStreamWaitEvent(side, s->ready[k], 0));
     }
     b.counter[k][0] = -1;
+    b.counter[k][3] = -1;                  // (a stale two-round launch size of this set's previous march must not pass a range check)
     s->march_t_set[k] = false;
     s->same_stream[k] = side == main;
+    s->fused[k] = false;
     if (s->timing) STEP_HIP(hipEventRecord(s->march_t[k][0], side));
     const bool lists_wanted = (s->two_round_mode == 1 || (s->two_round_mode == 2 && s->two_round_active)) && b.list_k && b.list_rest &&
                               b.two_round_counts && b.offs_k[k];
-    if (s->two_sample_sets && !lists_wanted) {
+    // (the fused march's expansion sums the counts in front of every 4-ray workgroup itself: R^2 / 4 reads from L2 -- 33 MB at 8192 rays,
+    //  2 GB at 65 536, where the scan launch of the other path is cheaper)
+    constexpr int FUSED_MARCH_MAX_RAYS = 32768;
+    if (s->two_sample_sets && !lists_wanted && b.n_rays <= FUSED_MARCH_MAX_RAYS) {
         // TWO launches: prologue + count, prefix + expansion into this record set's own sample buffers (the running step reads the
         // other set).  The count reaches the pinned word from the second launch's last workgroup before it expands.
         STEP_TRY(ensure_counts(s));
@@ -188,6 +201,7 @@ int do_march(ngp_stepper* s, const float* rays_o, const float* rays_d, hipStream
                                        b.hits_t[k], b.noise[k], b.rays_a[k], s->counts[k], b.counter[k], b.scratch[k],
                                        w.xyzs, w.dirs, w.deltas, w.ts, (ngp_stream_t)side));
         s->expanded[k] = true;
+        s->fused[k] = true;
         if (s->timing) { STEP_HIP(hipEventRecord(s->march_t[k][1], side)); s->march_t_set[k] = true; }
         STEP_HIP(hipEventRecord(s->done[k], side));
         s->has_pending = true; s->pend_o = rays_o; s->pend_d = rays_d; s->pend_set = k;
@@ -257,6 +271,8 @@ int ngp_stepper_create(const ngp_stepper_config* config, const ngp_step_buffers*
         for (int j = 0; j < 2 && e == hipSuccess; ++j) e = hipEventCreate(&s->march_t[k][j]);
     }
     for (int i = 0; i < N_MARKS && e == hipSuccess; ++i) e = hipEventCreate(&s->mark[i]);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->guard), 2 * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemset(s->guard, 0, 2 * sizeof(int32_t));
     if (e != hipSuccess) { ngp_stepper_destroy(s); return (int)e; }
     *out = s;
     return 0;
@@ -272,6 +288,7 @@ int ngp_stepper_destroy(ngp_stepper* s) {
     }
     for (int i = 0; i < N_MARKS; ++i) if (s->mark[i]) (void)hipEventDestroy(s->mark[i]);
     for (int k = 0; k < 2; ++k) if (s->counts[k]) (void)hipFree(s->counts[k]);
+    if (s->guard) (void)hipFree(s->guard);
     destroy_exchange_events(s);
     delete s;
     return 0;
@@ -324,7 +341,9 @@ int ngp_stepper_pending(const ngp_stepper* s, const float* rays_o, const float* 
 
 int ngp_stepper_last_set(const ngp_stepper* s) { return s ? s->last_set : 0; }
 int ngp_stepper_two_rounds(const ngp_stepper* s) { return (s && s->two_rounds) ? 1 : 0; }
-int ngp_stepper_record_bytes(int which) { return which == 0 ? (int)sizeof(ngp_stepper_config) : (which == 1 ? (int)sizeof(ngp_step_buffers) : NGP_EINVAL); }
+int ngp_stepper_record_bytes(int which) {
+    return which == 0 ? (int)sizeof(ngp_stepper_config) : which == 1 ? (int)sizeof(ngp_step_buffers) : which == 2 ? (int)sizeof(ngp_exchange_config) : NGP_EINVAL;
+}
 
 int ngp_stepper_march(ngp_stepper* s, const float* rays_o, const float* rays_d, ngp_stream_t main_stream, ngp_stream_t march_stream) {
     if (!s) return NGP_EINVAL;
@@ -458,8 +477,10 @@ static int backward_field(ngp_stepper* s, const float* dL_dopacity, const float*
     STEP_TRY(march_next_if_at(s, AT_COMPOSITE_BW));
     const int n_part = ngp_field_bwd_partials(S);
     if (n_part < 1 || n_part > b.max_partials) return NGP_EINVAL;
-    STEP_TRY(ngp_field_bwd(b.feats, b.dirs, b.h, c.enc_half, c.rgb_half, b.dL_dsigmas, b.dL_drgbs, loss_scale, S, b.active, b.n_active,
-                           b.dh, b.dfeats, b.partials, main_stream));
+    s->guard_parity ^= 1;
+    STEP_TRY(ngp_field_bwd_guarded(b.feats, b.dirs, b.h, c.enc_half, c.rgb_half, b.dL_dsigmas, b.dL_drgbs, loss_scale, S, b.active, b.n_active,
+                                   b.dh, b.dfeats, b.partials, s->guard, s->guard_parity, main_stream));
+    s->guard_armed = true;
     mark(s, 6, main);
     STEP_TRY(march_next_if_at(s, AT_MLP_BWD));
     s->n_part = n_part;
@@ -592,6 +613,8 @@ int ngp_stepper_update(ngp_stepper* s, float lr, int32_t step, float grad_scale,
         n_partials = s->n_part;
     }
     if (n_partials < 1) return NGP_EINVAL;
+    if (found_inf == nullptr && s->guard_armed && density_partials == b.partials) found_inf = s->guard + s->guard_parity;    // this step's own field backward
+    s->guard_armed = false;
     STEP_TRY(ngp_adam_step_field(c.enc_param + c.n_density, c.enc_half + c.n_density, c.grid_grad16, c.enc_m + c.n_density, c.enc_v + c.n_density, c.n_grid,
                                  c.enc_param, c.enc_half, density_partials, c.enc_m, c.enc_v, c.n_density,
                                  c.rgb_param, c.rgb_half, rgb_partials, c.rgb_m, c.rgb_v, c.n_rgb,
@@ -601,14 +624,14 @@ int ngp_stepper_update(ngp_stepper* s, float lr, int32_t step, float grad_scale,
     return 0;
 }
 
-int ngp_stepper_backward_update(ngp_stepper* s, float lr, int32_t step, float grad_scale, ngp_stream_t main_stream) {
+int ngp_stepper_backward_update(ngp_stepper* s, float lr, int32_t step, float grad_scale, int32_t* step_state, ngp_stream_t main_stream) {
     if (!s || step < 1) return NGP_EINVAL;
     if (s->comm) return NGP_EINVAL;                              // data parallel: ngp_stepper_tail
     const ngp_stepper_config& c = s->c;
     const ngp_step_buffers& b = s->b;
     if (s->S <= 0 || !s->binned || s->n_part < 1) {
         STEP_TRY(ngp_stepper_table_backward(s, 1, 0, main_stream));
-        return s->S > 0 ? ngp_stepper_update(s, lr, step, grad_scale, nullptr, nullptr, 0, nullptr, nullptr, main_stream) : 0;
+        return s->S > 0 ? ngp_stepper_update(s, lr, step, grad_scale, nullptr, nullptr, 0, nullptr, step_state, main_stream) : 0;
     }
     HostTimer host_timer(&s->t_enqueue);
     if (!c.enc_param || !c.enc_m || !c.enc_v || !c.rgb_param || !c.rgb_m || !c.rgb_v) return NGP_EINVAL;
@@ -623,7 +646,9 @@ int ngp_stepper_backward_update(ngp_stepper* s, float lr, int32_t step, float gr
     STEP_TRY(ngp_adam_step_field_merge(c.enc_param + c.n_density, c.enc_half + c.n_density, c.grid_grad16, c.enc_m + c.n_density, c.enc_v + c.n_density, n_streamed,
                                        c.enc_param, c.enc_half, b.partials, c.enc_m, c.enc_v, c.n_density,
                                        c.rgb_param, c.rgb_half, b.partials + (size_t)s->n_part * c.n_density, c.rgb_m, c.rgb_v, c.n_rgb,
-                                       s->n_part, lr, c.beta1, c.beta2, c.eps, c.weight_decay, step, grad_scale, nullptr, nullptr, &gp, main_stream));
+                                       s->n_part, lr, c.beta1, c.beta2, c.eps, c.weight_decay, step, grad_scale,
+                                       s->guard_armed ? s->guard + s->guard_parity : nullptr, step_state, &gp, main_stream));
+    s->guard_armed = false;
     mark(s, 8, ngp_stream(main_stream));
     STEP_TRY(march_next_if_at(s, AT_ADAM));
     return 0;

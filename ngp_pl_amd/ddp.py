@@ -32,7 +32,7 @@ from . import tcnn
 class GradientExchange:
     def __init__(self, model, dist, world, group=None, n_groups=1, ranges=None):
         """`n_groups`: launch groups of the table backward = pieces of the grid-gradient exchange (1, the default: one
-        all-reduce behind the whole backward.  Measured on MI355X with a 1-rank process group (profiles/r02_pg1_timeline.txt):
+        all-reduce behind the whole backward.  Measured on MI355X with a 1-rank process group (profiles/archive_r01_r04/r02_pg1_timeline.txt):
         every cross-stream hand-over -- the event the collective's stream waits on, the event the main stream waits on --
         idles the main stream for ~20 us, so a piece only pays where the transfer it hides is much longer than that).  `ranges`: their table-entry ranges [(begin, end), ...]; taken from the library's plan for the
         model's grid when not given.  EVERY rank issues the same sequence of collectives every step -- MLP block, then the

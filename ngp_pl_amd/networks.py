@@ -236,38 +236,19 @@ class NGP(nn.Module):
     @torch.no_grad()
     def mark_invisible_cells(self, K, poses, img_wh, chunk=64 ** 3):
         """density_grid = -1 for cells no training camera sees or that are closer than the near plane to one, count_grid = the
-        fraction of cameras covering a cell; run once before training (networks.py:197-238, train.py:155-158).  On the GPU one
-        launch (`ngp_mark_invisible_cells`: a thread per cell walks the cameras, poses in LDS).  CPU tensors take the statement
-        of the same rule in torch below: host logic the CPU suite pins to the reference's own output
-        (tests/test_reference_python_cpu.py); `chunk` only bounds that path's temporaries."""
+        fraction of cameras covering a cell; run once before training (networks.py:197-238, train.py:155-158).  One launch
+        (`ngp_mark_invisible_cells`: a thread per cell walks the cameras, which pass through LDS 1024 at a time -- any number of
+        training cameras).  GPU only, like every other operator of this package; `chunk` is accepted for the reference's
+        signature and unused (the kernel has no temporaries to bound)."""
         n_cams = poses.shape[0]
+        _lib.require_cuda(self.density_grid)
         self.count_grid = torch.zeros_like(self.density_grid)
-        if self.density_grid.is_cuda:
-            dev = self.density_grid.device
-            Kd = K.to(device=dev, dtype=torch.float32).contiguous()
-            Pd = poses[:, :3, :4].to(device=dev, dtype=torch.float32).contiguous()
-            with torch.cuda.device(dev):
-                call("ngp_mark_invisible_cells", ptr(Kd), ptr(Pd), n_cams, int(img_wh[0]), int(img_wh[1]), NEAR_DISTANCE,
-                     self.cascades, self.grid_size, float(self.scale), ptr(self.count_grid), ptr(self.density_grid), stream())
-            return
-        # camera frame of every cell centre: p_cam = R^T (x - t); image coordinates (u, v) = (K p_cam)_xy / depth
-        world_to_cam = poses[:, :3, :3].transpose(1, 2)
-        cam_origin = -world_to_cam @ poses[:, :3, 3:]
-        W, H = img_wh
-        for c, (cell_idx, cell_xyz) in enumerate(self.get_all_cells()):
-            s = min(2 ** (c - 1), self.scale)
-            span = s - s / self.grid_size
-            for lo in range(0, len(cell_idx), chunk):
-                idx = cell_idx[lo:lo + chunk]
-                centres = ((cell_xyz[lo:lo + chunk] / (self.grid_size - 1) * 2 - 1) * span).T
-                proj = K @ (world_to_cam @ centres + cam_origin)                       # (cams, 3, cells): u*d, v*d, d
-                depth = proj[:, 2]
-                u, v = proj[:, 0] / depth, proj[:, 1] / depth
-                inside = (depth >= 0) & (u >= 0) & (u < W) & (v >= 0) & (v < H)
-                seen_by = (inside & (depth >= NEAR_DISTANCE)).sum(0) / n_cams
-                clipped = (inside & (depth < NEAR_DISTANCE)).any(0)
-                self.count_grid[c, idx] = seen_by
-                self.density_grid[c, idx] = torch.where((seen_by > 0) & ~clipped, 0., -1.)
+        dev = self.density_grid.device
+        Kd = K.to(device=dev, dtype=torch.float32).contiguous()
+        Pd = poses[:, :3, :4].to(device=dev, dtype=torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            call("ngp_mark_invisible_cells", ptr(Kd), ptr(Pd), n_cams, int(img_wh[0]), int(img_wh[1]), NEAR_DISTANCE,
+                 self.cascades, self.grid_size, float(self.scale), ptr(self.count_grid), ptr(self.density_grid), stream())
 
     @torch.no_grad()
     def _update_density_grid_native(self, density_threshold, warmup, decay, erode):

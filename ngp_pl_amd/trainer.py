@@ -82,7 +82,7 @@ class Trainer:
             rank = torch.distributed.get_rank()
         self.noise_seed = (int(os.environ.get("NGP_NOISE_SEED", "20240924")) + 0x632BE59BD9B4E019 * rank) & 0xFFFFFFFFFFFFFFFF
         # where in the step the next batch's march is enqueued is the native stepper's business (NGP_MARCH_AT, csrc/stepper.hip;
-        # default: behind the field forward.  profiles/r02_march_sweep.txt, r03_march_sweep.txt: wherever it lands the march costs
+        # default: behind the field forward.  profiles/archive_r01_r04/r02_march_sweep.txt, r03_march_sweep.txt: wherever it lands the march costs
         # the kernels next to it 17-20 us)
         self.last = {}
         self.grad_hook = None    # called between backward and optimizer (multi-GPU gradient all-reduce)
@@ -277,12 +277,12 @@ class Trainer:
                 lr = self.opt.param_groups[0]["lr"] = cosine_lr(self.base_lr, epoch, self.num_epochs)
                 if not hooks:
                     self.opt.t += 1
+                    # table backward + fused Adam in ONE call (the dense levels' merge folded into the Adam launch).  The library's
+                    # overflow guard decides on the device whether the step applies (a non-finite weight gradient: skipped, as
+                    # GradScaler does for the reference, train.py:274); the count of APPLIED steps lives next to it (step_state)
                     if self.opt._step_state is None:
-                        # table backward + fused Adam in ONE call (the dense levels' merge folded into the Adam launch)
-                        call("ngp_stepper_backward_update", h, lr, self.opt.t, self.loss_scale * self.grad_scale, mq)
-                    else:                                       # a device-side step count is in use (a skip flag was seen earlier)
-                        call("ngp_stepper_table_backward", h, 1, 0, mq)
-                        call("ngp_stepper_update", h, lr, self.opt.t, self.loss_scale * self.grad_scale, None, None, 0, None, self.opt.step_state(None), mq)
+                        self.opt.ensure_step_state(self.opt.t - 1)
+                    call("ngp_stepper_backward_update", h, lr, self.opt.t, self.loss_scale * self.grad_scale, self.opt._step_state.data_ptr(), mq)
                     enc._half.mark_fresh(enc.params); net._half.mark_fresh(net.params)
                 else:
                     g16 = m._grid_grad16(dev)
@@ -375,6 +375,11 @@ class Trainer:
             self.update_hook(self.opt.param_groups[0]["lr"], self.opt.t, self.model._native["scale"] * self.grad_scale, found_inf, mq)
         else:
             self.opt.step(grad_scale=self.grad_scale, found_inf=found_inf, stream_handle=mq)
+
+    def skipped_steps(self):
+        """Optimizer steps the overflow guard (or a caller's skip flag) did not apply, as (MLP blocks, grid block) -- syncs."""
+        a_mlp, a_grid = self.opt.applied_steps()
+        return self.opt.t - a_mlp, self.opt.t - a_grid
 
     def metrics(self):
         """Host-side readout of the last step (syncs): loss, psnr, rm_s, vr_s as train.py:177-183 logs them."""

@@ -112,3 +112,34 @@ def update_density_grid(vr, density_grid, cells, sigmas, density_threshold, deca
     bitfield = np.zeros(len(grid) // 8, np.uint8)
     vr.packbits(grid, thr, bitfield)
     return grid, bitfield, thr
+
+
+def mark_invisible_cells(vr, K, poses, img_wh, cascades, grid_size, scale, chunk=64 ** 3):
+    """`NGP.mark_invisible_cells` (networks.py:197-238) restated in torch on the CPU: for every cell of every cascade (Morton
+    order, `get_all_cells` :155-167) the centre `(coord / (G - 1) * 2 - 1) * (s - s / G)`, s = min(2^(c-1), scale) (:216-221), is
+    taken to every camera -- p_cam = R^T (x - t), (u d, v d, d) = K p_cam (:222-226) --; count_grid = fraction of the cameras that
+    have the cell inside their image at depth >= NEAR_DISTANCE (:227-231), density_grid = -1 where no camera does or where one
+    has it inside its image closer than the near plane, else 0 (:232-238).  Returns (density_grid, count_grid), each (cascades, G^3)
+    float32 torch tensors.  `chunk` bounds the temporaries.  Pinned to the reference's own output by tests/test_reference_python_cpu.py."""
+    K = torch.as_tensor(K, dtype=torch.float32); poses = torch.as_tensor(poses, dtype=torch.float32)
+    n_cams = poses.shape[0]
+    n_cells = grid_size ** 3
+    coords = torch.from_numpy(vr.morton3D_invert(np.arange(n_cells, dtype=np.int32)).astype(np.float32))      # cell m of the grid sits at Morton index m
+    density = torch.zeros(cascades, n_cells); count = torch.zeros(cascades, n_cells)
+    world_to_cam = poses[:, :3, :3].transpose(1, 2)
+    cam_origin = -world_to_cam @ poses[:, :3, 3:]
+    W, H = img_wh
+    for c in range(cascades):
+        s = min(2 ** (c - 1), scale)
+        span = s - s / grid_size
+        for lo in range(0, n_cells, chunk):
+            centres = ((coords[lo:lo + chunk] / (grid_size - 1) * 2 - 1) * span).T
+            proj = K @ (world_to_cam @ centres + cam_origin)                          # (cams, 3, cells): u*d, v*d, d
+            depth = proj[:, 2]
+            u, v = proj[:, 0] / depth, proj[:, 1] / depth
+            inside = (depth >= 0) & (u >= 0) & (u < W) & (v >= 0) & (v < H)
+            seen_by = (inside & (depth >= NEAR_DISTANCE)).sum(0) / n_cams
+            clipped = (inside & (depth < NEAR_DISTANCE)).any(0)
+            count[c, lo:lo + chunk] = seen_by
+            density[c, lo:lo + chunk] = torch.where((seen_by > 0) & ~clipped, 0., -1.)
+    return density, count

@@ -30,3 +30,22 @@ def aabb_hits(oracle, ro, rd, scale=0.5, near=0.01):
     m = (ht[:, 0] >= 0) & (ht[:, 0] < near)
     ht[m, 0] = near
     return ht
+
+
+def error_distribution(name, got, want, log=None):
+    """Per-row max-abs error between two arrays (rows = rays) as a distribution: mean / median / q90 / q99 / q999 / max.  Printed (pytest -s
+    shows it) and, with NGP_PARITY_LOG set, appended to that file -- profiles/r06_parity_distribution.txt is such a log from an MI355X,
+    and the tolerances of the end-to-end parity tests are 3 x its figures."""
+    import os
+    want = np.asarray(want, np.float64)
+    err = np.abs(np.asarray(got, np.float64) - want).reshape(len(want), -1).max(1)
+    d = {"n": int(len(err)), "mean": float(err.mean()), "median": float(np.median(err)), "q90": float(np.quantile(err, 0.90)),
+         "q99": float(np.quantile(err, 0.99)), "q999": float(np.quantile(err, 0.999)), "max": float(err.max())}
+    line = "%-52s n %6d  mean %.3e  median %.3e  q90 %.3e  q99 %.3e  q999 %.3e  max %.3e" % (
+        name, d["n"], d["mean"], d["median"], d["q90"], d["q99"], d["q999"], d["max"])
+    print(line)
+    path = log or os.environ.get("NGP_PARITY_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(line + "\n")
+    return err, d

@@ -62,7 +62,7 @@ def test_c_program_links_every_declared_symbol(tmp_path):
     assert r.returncode == 0, r.stdout[-3000:]
     r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
     assert r.returncode == 0, r.stdout
-    assert r.stdout.split() == [str(len(protos)), "4", "gfx950"], r.stdout
+    assert r.stdout.split() == [str(len(protos)), "5", "gfx950"], r.stdout
 
 
 def test_ctypes_table_agrees_with_the_header():
@@ -108,7 +108,7 @@ def test_library_exports_every_declared_symbol():
     assert set(names) <= exported, sorted(set(names) - exported)
     assert exported <= set(names), "exported but undeclared: %s" % sorted(exported - set(names))
     assert set(_lib.exported_symbols()) == set(names)          # the ctypes table covers the whole header
-    assert lib.ngp_abi_version() == 4 and lib.ngp_build_arch() == b"gfx950"
+    assert lib.ngp_abi_version() == 5 == _lib.ABI_VERSION and lib.ngp_build_arch() == b"gfx950"
 
 
 def test_code_object_is_gfx950_only():
@@ -240,7 +240,8 @@ def test_mirrored_records_have_the_librarys_layout():
     h = _lib.lib()
     assert h.ngp_stepper_record_bytes(0) == C.sizeof(_lib.StepperConfig)
     assert h.ngp_stepper_record_bytes(1) == C.sizeof(_lib.StepBuffersC)
-    assert h.ngp_stepper_record_bytes(2) < 0
+    assert h.ngp_stepper_record_bytes(2) == C.sizeof(_lib.ExchangeConfig)
+    assert h.ngp_stepper_record_bytes(3) < 0
 
 
 @pytest.mark.parametrize("scale", [0.5, 16.0])

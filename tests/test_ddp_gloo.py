@@ -435,3 +435,46 @@ def test_direct_exchange_matches_the_single_process_update(world):
     for p in procs:
         p.join(60)
     assert res == [(r, True) for r in range(world)], res
+
+
+def test_f16_ring_accumulation_at_world_8_is_bounded_against_the_f32_sum():
+    """The default exchange (`sharded`) reduce-scatters the packed-f16 table gradient through RCCL's ring: a chunk travels rank to
+    rank and every hop adds one rank's addend IN f16 (world - 1 roundings on top of each addend's own), where the reference's DDP
+    all-reduces f32 gradients (train.py:268-272: one rounding).  Simulated here hop by hop for world 8 on gradients with the
+    spread of real table gradients (|g| log-uniform over 2^-20 .. 2^-3 at loss scale 128 / world, random signs, a third of the
+    entries touched by one rank only): the ring result stays within (world - 1) half-ulps of the running sums of the exact (f32)
+    sum rounded once -- the a-priori bound; relative to the sum of the addends' magnitudes that is ~1e-4 on average and below
+    (world - 1) 2^-11 = 3.4e-3 always (where the addends cancel, the error is large against the RESULT, as with any finite
+    accumulator: the f32 sum has the same property 2^13 lower).  `direct` (f32,
+    rank order, one rounding: ddp.DirectExchange / ngp_sum_slices_f16) has no such term; it stays the second mode until it has run
+    on real links."""
+    world, n = 8, 1 << 18
+    g = np.random.RandomState(5)
+    mag = np.exp2(g.uniform(-20, -3, size=(world, n)))
+    x = (mag * g.choice([-1.0, 1.0], size=(world, n))).astype(np.float16)          # every rank's addend: one f16 rounding of its own
+    lonely = g.rand(n) < 0.33
+    owner = g.randint(0, world, n)
+    x[:, lonely] = np.where(np.arange(world)[:, None] == owner[None, lonely], x[:, lonely], np.float16(0))
+    exact = x.astype(np.float64).sum(0)
+    once = exact.astype(np.float32).astype(np.float16).astype(np.float64)          # DDP's f32 sum, cast to the f16 the optimizer reads
+    # ring reduce-scatter: the chunk that ends on rank r starts on rank r + 1 and visits r + 2, ..., r (each adds its slice in f16)
+    ring = np.empty(n, np.float64)
+    bound = np.zeros(n, np.float64)
+    chunk = n // world
+    for r in range(world):
+        sl = slice(r * chunk, (r + 1) * chunk)
+        order = [(r + 1 + k) % world for k in range(world)]
+        acc = x[order[0], sl].copy()
+        for q in order[1:]:
+            acc = (acc.astype(np.float16) + x[q, sl]).astype(np.float16)           # numpy adds f16 + f16 in f16 (one rounding per hop)
+            bound[sl] += np.spacing(np.abs(acc).astype(np.float16)).astype(np.float64) / 2
+        ring[sl] = acc.astype(np.float64)
+    err = np.abs(ring - exact)
+    assert (err <= bound + 1e-30).all()                                             # the a-priori bound: half an ulp of every running sum
+    same_sign = (np.sign(x.astype(np.float64)).min(0) >= 0) | (np.sign(x.astype(np.float64)).max(0) <= 0)
+    ulp = np.maximum(np.spacing(np.abs(once).astype(np.float16)).astype(np.float64), 2.0 ** -24)
+    dev = np.abs(ring - once)[same_sign] / ulp[same_sign]
+    assert dev.max() <= world - 1, float(dev.max())                                 # no cancellation: at most one ulp of the result per hop
+    assert (ring[lonely] == once[lonely]).all()                                     # an entry only one rank touched arrives unchanged (x + 0 is exact)
+    rel = np.abs(ring - once)[~lonely] / np.abs(x.astype(np.float64)).sum(0)[~lonely]
+    assert rel.mean() < 2e-4 and rel.max() < (world - 1) * 2.0 ** -11               # relative to the sum of magnitudes: ~1e-4 on average

@@ -57,8 +57,9 @@ def _fixed_jitter(noise):
 
 
 def _close(name, got, want, mean_tol, q99_tol):
-    err = np.abs(np.asarray(got, np.float64) - np.asarray(want, np.float64)).reshape(len(want), -1).max(1)
-    assert err.mean() < mean_tol and np.quantile(err, 0.99) < q99_tol, (name, float(err.mean()), float(np.quantile(err, 0.99)))
+    from helpers import error_distribution
+    err, d = error_distribution("reference files on the binding vs its cpu run: " + name, got, want)
+    assert d["mean"] < mean_tol and d["q99"] < q99_tol, (name, d)
 
 
 @pytest.mark.parametrize("tag", ["syn", "real"])

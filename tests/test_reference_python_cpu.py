@@ -104,18 +104,13 @@ def test_occupancy_update_matches_the_reference_python(step):
     assert 0 < thr <= float(G["occ_threshold"])
 
 
-def test_mark_invisible_cells_matches_the_reference_python(monkeypatch):
-    """ngp_pl_amd.networks.NGP.mark_invisible_cells (host logic, torch) against the reference's on a 32^3, three-cascade grid.
-    Only the Morton kernel is swapped for the oracle's (the native one needs a GPU); everything else is the product code."""
-    from ngp_pl_amd import networks
-    o = Oracle(True)
-    monkeypatch.setattr(networks.vren, "morton3D", lambda coords: torch.from_numpy(o.morton3D(coords.numpy().astype(np.int32))))
-    m = networks.NGP(scale=2.0)
-    m.grid_size = 32
-    m.register_training_buffers()
-    m.mark_invisible_cells(torch.from_numpy(G["vis_K"]), torch.from_numpy(G["vis_poses"]), (64, 64))
-    assert np.array_equal(m.density_grid.numpy().astype(np.int8), G["vis_density_grid"])
-    assert np.array_equal(np.round(m.count_grid.numpy() * 6).astype(np.uint8), G["vis_count_grid"])
+def test_mark_invisible_cells_matches_the_reference_python():
+    """oracle/render_oracle.mark_invisible_cells (the CPU statement the GPU test holds `ngp_mark_invisible_cells` to at the training
+    configuration) against the reference's own networks.py:197-238 on a 32^3, three-cascade grid: density_grid 0 / -1 and the
+    per-cell camera counts, cell for cell."""
+    density, count = R.mark_invisible_cells(Oracle(True), G["vis_K"], G["vis_poses"], (64, 64), cascades=3, grid_size=32, scale=2.0)
+    assert np.array_equal(density.numpy().astype(np.int8), G["vis_density_grid"])
+    assert np.array_equal(np.round(count.numpy() * 6).astype(np.uint8), G["vis_count_grid"])
     assert 0 < int((G["vis_density_grid"] < 0).sum()) < G["vis_density_grid"].size
 
 
