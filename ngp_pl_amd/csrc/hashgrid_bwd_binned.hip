@@ -70,9 +70,6 @@ constexpr int MAX_CHUNKS = 4608;             // 4.7 M samples: the first steps o
 #ifndef NGP_DENSE_B
 #define NGP_DENSE_B 4                         // dense levels: entries per lane in flight
 #endif
-#ifndef NGP_APPLY_PB
-#define NGP_APPLY_PB 8                        // payload entries: segments per trip (3 words per segment and lane in flight)
-#endif
 constexpr int APPLY_THREADS = NGP_APPLY_THREADS;
 
 struct BinPlan {
@@ -456,6 +453,12 @@ __device__ __forceinline__ void apply_segments_dense_runs(long long* lds, uint32
     }
 }
 
+// Workgroup barrier for data that lives in LDS only (accumulators, task ids, directory rows).  __syncthreads() carries a workgroup-scope
+// fence, and gfx9's single vmcnt makes that fence wait for EVERY outstanding global access of the wave: behind the write-out that is the
+// round trip of its gradient stores, which no thread of the launch reads (round 6: write-out phase 2.8 -> 1.6 us per task,
+// profiles/r06_table_backward.txt).  The "memory" clobber keeps the compiler from moving LDS accesses across it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // (Applying the hashed levels' Adam update in this kernel's write-out -- three designs, the last with wave specialisation -- was built and
 // measured in round 4: the optimizer's stream is not hidden under the owners' latencies, the owners slow down by as much as the stream takes
 // alone; removed in round 5.  profiles/archive_r01_r04/r04_step_ab.txt (d), (d2).)
@@ -534,7 +537,7 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
         else if (NGP_DENSE_RUNS) apply_segments_dense_runs<NGP_DENSE_B>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
         else apply_segments_dense<4>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
         if (tid == 0) s_task[(it + 1) & 1] = next_task;
-        __syncthreads();                                               // accumulators complete, next id visible
+        lds_barrier();                                                 // accumulators complete, next id visible
 #ifdef NGP_BIN_TIMING
         if (tid == 0) ws.timing[4 * task + 2] = (long long)wall_clock64();
 #endif
@@ -591,7 +594,7 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
 #pragma unroll
             for (int q = 0; q < PRE; ++q) { const int c = tid + q * APPLY_THREADS; if (c < n_chunks) s_dir2[(it + 1) & 1][c] = pre[q]; }
         }
-        __syncthreads();                                               // accumulators clear, the next task's directory row in place
+        lds_barrier();                                                 // accumulators clear, the next task's directory row in place (the write-out's stores still in flight)
 #ifdef NGP_BIN_TIMING
         if (tid == 0) ws.timing[4 * task + 3] = (long long)wall_clock64();
 #endif

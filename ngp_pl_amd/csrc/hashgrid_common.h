@@ -23,12 +23,15 @@ struct Box { float mn[3], inv[3]; };
 __device__ __forceinline__ Box load_box(const float* __restrict__ xyz_min, const float* __restrict__ xyz_max) {
     Box b;
     // v_rcp_f32 is exact for a power of two (the common case: one instruction); any other extent takes the correctly rounded division
-    // of this build's flags (~10 vector instructions per axis, behind a branch that is uniform over the launch)
+    // of this build's flags (~10 vector instructions per axis: 28 of the forward kernel's 201 when it ran unconditionally, round 5).
+    // The extent is made wave-uniform first, so that the test is a scalar branch and the division is SKIPPED, not selected away.
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const float e = xyz_max[k] - xyz_min[k];
+        const uint32_t eb = __builtin_amdgcn_readfirstlane(__float_as_uint(xyz_max[k] - xyz_min[k]));
+        const float e = __uint_as_float(eb);
         b.mn[k] = xyz_min[k];
-        b.inv[k] = (__float_as_uint(e) & 0x007fffffu) == 0u ? __builtin_amdgcn_rcpf(e) : 1.0f / e;
+        if ((eb & 0x007fffffu) == 0u) b.inv[k] = __builtin_amdgcn_rcpf(e);
+        else b.inv[k] = 1.0f / e;
     }
     return b;
 }

@@ -56,10 +56,17 @@ def _fixed_jitter(noise):
     return _Patch()
 
 
+# (mean, q99) of the per-ray max-abs error = 3 x what an MI355X measured (profiles/r06_parity_distribution.txt: rgb mean <= 2.6e-6 /
+# q99 <= 3.3e-5 / max 1.3e-4 over the four configurations; the reference's module path rounds h and the SH values to f16 once more
+# than the fused field, hence the 1e-4 tail the product's own render() does not have).  Round 5 asserted 2e-3 / 2e-2.
+REF_TOL = {"opacity": (1.5e-6, 4e-5), "rgb": (1.2e-5, 1.3e-4), "depth": (2.5e-6, 6e-5)}
+REF_MAX = 4e-4
+
+
 def _close(name, got, want, mean_tol, q99_tol):
     from helpers import error_distribution
     err, d = error_distribution("reference files on the binding vs its cpu run: " + name, got, want)
-    assert d["mean"] < mean_tol and d["q99"] < q99_tol, (name, d)
+    assert d["mean"] < mean_tol and d["q99"] < q99_tol and d["max"] < REF_MAX * max(1.0, q99_tol / 1.3e-4), (name, d)
 
 
 @pytest.mark.parametrize("tag", ["syn", "real"])
@@ -85,8 +92,9 @@ def test_the_references_render_on_the_binding_reproduces_its_cpu_run(R, tag):
     res = mods.rendering.render(model, ro, rd, test_time=True, **kw)
     total = int(gold[tag + "_test_total_samples"])
     assert abs(int(res["total_samples"]) - total) <= 0.01 * total + 64
-    for k, (mt, qt) in (("opacity", (2e-3, 2e-2)), ("rgb", (2e-3, 2e-2)), ("depth", (4e-3 * max(c["scale"], 1.0), 4e-2 * max(c["scale"], 1.0)))):
-        _close("test " + k, res[k].float().cpu().numpy(), gold["%s_test_%s" % (tag, k)], mt, qt)
+    for k, (mt, qt) in REF_TOL.items():
+        _close("test " + k, res[k].float().cpu().numpy(), gold["%s_test_%s" % (tag, k)], mt * (max(c["scale"], 1.0) if k == "depth" else 1.0),
+               qt * (max(c["scale"], 1.0) if k == "depth" else 1.0))
     # -- train branch (rendering.py:121-163) with the jitter of the recorded run ------------------------------------------------
     with _fixed_jitter(torch.from_numpy(gold[tag + "_noise"])):
         tr = mods.rendering.render(model, ro, rd, test_time=False, **kw)
@@ -96,8 +104,9 @@ def test_the_references_render_on_the_binding_reproduces_its_cpu_run(R, tag):
     assert np.array_equal(tr["deltas"].cpu().numpy().view(np.uint32), gold[tag + "_train_deltas"].view(np.uint32))
     vr = int(gold[tag + "_train_vr_samples"])
     assert abs(int(tr["vr_samples"]) - vr) <= 0.01 * vr + 64
-    for k, (mt, qt) in (("opacity", (2e-3, 2e-2)), ("rgb", (2e-3, 2e-2)), ("depth", (4e-3 * max(c["scale"], 1.0), 4e-2 * max(c["scale"], 1.0)))):
-        _close("train " + k, tr[k].detach().float().cpu().numpy(), gold["%s_train_%s" % (tag, k)], mt, qt)
+    for k, (mt, qt) in REF_TOL.items():
+        _close("train " + k, tr[k].detach().float().cpu().numpy(), gold["%s_train_%s" % (tag, k)], mt * (max(c["scale"], 1.0) if k == "depth" else 1.0),
+               qt * (max(c["scale"], 1.0) if k == "depth" else 1.0))
     ws_err = np.abs(tr["ws"].detach().cpu().numpy() - gold[tag + "_train_ws"])
     assert ws_err.mean() < 1e-3 and np.quantile(ws_err, 0.999) < 5e-2, (ws_err.mean(), ws_err.max())
     # the whole thing differentiates through the reference's autograd operators down to both parameter tensors
@@ -162,13 +171,13 @@ def test_the_references_render_on_the_binding_at_scale_16(R):
     assert np.array_equal(tr["rays_a"].cpu().numpy(), want["rays_a"])
     assert np.array_equal(tr["ts"].cpu().numpy().view(np.uint32), want["ts"].view(np.uint32))
     assert np.array_equal(tr["deltas"].cpu().numpy().view(np.uint32), want["deltas"].view(np.uint32))
-    _close("rgb", tr["rgb"].detach().float().cpu().numpy(), want["rgb"], 3e-3, 3e-2)
-    _close("opacity", tr["opacity"].detach().cpu().numpy(), want["opacity"], 3e-3, 3e-2)
+    _close("rgb", tr["rgb"].detach().float().cpu().numpy(), want["rgb"], *REF_TOL["rgb"])
+    _close("opacity", tr["opacity"].detach().cpu().numpy(), want["opacity"], *REF_TOL["opacity"])
     res = mods.rendering.render(model, o.cuda(), d.cuda(), test_time=True, exp_step_factor=esf)
     op, depth, rgb, total, iters = RO.render_rays_test(vr, field, o.numpy(), d.numpy(), bf, cascades=6, scale=scale, exp_step_factor=esf)
     assert abs(int(res["total_samples"]) - total) <= 0.01 * total + 64
-    _close("test rgb", res["rgb"].float().cpu().numpy(), rgb, 3e-3, 3e-2)
-    _close("test opacity", res["opacity"].cpu().numpy(), op, 3e-3, 3e-2)
+    _close("test rgb", res["rgb"].float().cpu().numpy(), rgb, *REF_TOL["rgb"])
+    _close("test opacity", res["opacity"].cpu().numpy(), op, *REF_TOL["opacity"])
 
 
 def test_the_references_update_density_grid_on_the_binding(R):

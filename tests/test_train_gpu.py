@@ -585,8 +585,9 @@ def test_step_without_samples_is_a_noop_for_the_parameters():
 
 # End-to-end tolerances (mean, q99 of the per-ray max-abs error) = 3 x the distribution measured on an MI355X
 # (profiles/r06_parity_distribution.txt; VERDICT r05 asked for bounds that say something the measurement does not already beat by 50x).
-E2E_TOL = {"rgb": (2e-3, 2e-2), "opacity": (2e-3, 2e-2), "depth": (2e-3, 2e-2)}
-E2E_CLEAR_FRACTION = 0.0
+#   measured: rgb mean 2.4e-7 / q99 3.1e-6 / max 7.9e-6; opacity 2.6e-7 / 1.1e-6 / 2.6e-6; depth 3.7e-7 / 1.4e-6 / 3.8e-6
+E2E_TOL = {"rgb": (1e-6, 1e-5), "opacity": (1e-6, 4e-6), "depth": (1.5e-6, 5e-6)}
+E2E_MAX = 1e-4            # north_star: "RGB / sigma within 1e-4 abs" -- every ray, both branches (measured max 7.9e-6)
 
 
 def test_render_matches_the_cpu_oracle_end_to_end():
@@ -622,7 +623,7 @@ def test_render_matches_the_cpu_oracle_end_to_end():
     from helpers import error_distribution
     for name, a, b in (("rgb", got["rgb"], rgb), ("opacity", got["opacity"], op), ("depth", got["depth"], depth)):
         err, d = error_distribution("e2e test-time loop vs cpu oracle: " + name, a.cpu().numpy(), b)
-        assert d["mean"] < E2E_TOL[name][0] and d["q99"] < E2E_TOL[name][1], (name, d)
+        assert d["mean"] < E2E_TOL[name][0] and d["q99"] < E2E_TOL[name][1] and d["max"] < E2E_MAX, (name, d)
     # training branch (through the native stepper: the model has a FusedAdam), same jitter on both sides: the oracle marches
     # with the draw the stepper made
     from ngp_pl_amd import _lib
@@ -636,13 +637,9 @@ def test_render_matches_the_cpu_oracle_end_to_end():
     np.testing.assert_array_equal(res["ts"].cpu().numpy(), want["ts"])
     err, d = error_distribution("e2e train branch vs cpu oracle: rgb", res["rgb"].detach().cpu().numpy(), want["rgb"])
     assert d["mean"] < E2E_TOL["rgb"][0] and d["q99"] < E2E_TOL["rgb"][1], d
-    # per ray at SURVEY.md 8(c)'s 1e-3 (the f16-level bound on rgb), for the rays whose early stop does not hang on the threshold: a
-    # ray whose transmittance passes within 2 % of T_threshold at some sample may composite one sample more or less on either side
-    T_end = 1.0 - want["opacity"].astype(np.float64)         # (a stopped ray ends at its deciding sample: this IS the T that was compared)
-    clear = np.abs(T_end / 1e-4 - 1.0) > 0.25                # the f16-level field moves ln T by a few per cent: a wide band
-    frac = float((err[clear] < 1e-3).mean())
-    error_distribution("e2e train branch: rgb, rays clear of the threshold", res["rgb"].detach().cpu().numpy()[clear], want["rgb"][clear])
-    assert frac >= E2E_CLEAR_FRACTION, (frac, int(clear.sum()))
+    # per ray, EVERY ray: north_star's 1e-4 (SURVEY.md 8(c) asks 1e-3 of the f16-level field).  Rays whose early stop hangs on the
+    # threshold need no exemption: the sample a side composites more or less carries a weight below T_threshold = 1e-4 itself.
+    assert d["max"] < E2E_MAX, d
     assert abs(int(res["vr_samples"]) - want["vr_samples"]) <= 0.01 * want["vr_samples"] + 64
 
 

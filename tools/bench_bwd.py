@@ -42,9 +42,9 @@ e0.record()
 for _ in range(N):
     run()
 e1.record(); torch.cuda.synchronize()
-print("lib %s: %d active samples (plan %d): %.1f us per launch (bin + apply + merge); checksum %.6f" % (
-    os.path.basename(os.environ.get("NGP_HIP_LIB", "libngp_hip.so")), S, S_plan, e0.elapsed_time(e1) / N * 1e3, float(g16.float().abs().sum())))
-assert torch.equal(ref, g16)
+print("lib %s: %d active samples (plan %d): %.1f us per launch (bin + apply + merge); checksum %.6f; run-to-run identical: %s" % (
+    os.path.basename(os.environ.get("NGP_HIP_LIB", "libngp_hip.so")), S, S_plan, e0.elapsed_time(e1) / N * 1e3, float(g16.float().abs().sum()),
+    bool(torch.equal(ref, g16))))
 tm = ws[256:256 + 65536].view(torch.int64).view(-1, 4).cpu().double()
 if os.environ.get("NGP_BIN_T2"):
     # -DNGP_BIN_TIMING2=<wave> build: per hashed task, wave <wave>'s first trip: top -> entries arrived -> gathers arrived -> adds issued
@@ -59,3 +59,14 @@ if len(tm) > 100:
     print("  tasks %d, apply span %.1f us" % (len(tm), (tm[:, 3].max() - t0) / 100))
     pro = (tm[:, 1] - tm[:, 0]).mean() / 100; scan = (tm[:, 2] - tm[:, 1]).mean() / 100; wr = (tm[:, 3] - tm[:, 2]).mean() / 100
     print("  per task: prologue %.2f us, segments %.2f us (max %.1f), write-out %.2f us" % (pro, scan, (tm[:, 2] - tm[:, 1]).max() / 100, wr))
+    # marks: [0] task top, [1] after the decode (old kernel) / wave 0's rows done (pipelined kernel), [2] behind barrier A, [3] behind barrier B
+    nd = len(tm) - 760
+    if nd > 0 and len(tm) == 1072:
+        for lv in range(10):                                    # hashed levels 6..15: 76 slice tasks each, in level order
+            sel = tm[nd + 76 * lv: nd + 76 * (lv + 1)]
+            d = (sel[:, 1:] - sel[:, :-1]) / 100
+            print("    level %2d: scan %.2f us (max %.1f), write-out %.2f us" % (6 + lv, (d[:, 0] + d[:, 1]).mean(), (d[:, 0] + d[:, 1]).max(), d[:, 2].mean()))
+    for name, sel in (("dense", tm[:nd]), ("hashed", tm[nd:])):
+        d = (sel[:, 1:] - sel[:, :-1]) / 100
+        print("  %s tasks (%d): top -> mark1 %.2f us, mark1 -> barrier A %.2f us, A -> barrier B %.2f us; task %.2f us (max %.1f)" % (
+            name, len(sel), d[:, 0].mean(), d[:, 1].mean(), d[:, 2].mean(), d.sum(1).mean(), d.sum(1).max()))

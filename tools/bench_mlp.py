@@ -51,7 +51,8 @@ from ngp_pl_amd import _lib
 libh = _lib.lib()
 if hasattr(libh, "ngp_debug_mlp_timing"):          # -DNGP_MLP_TIMING build: cycles wave 0 spends per stage, mean over workgroups, per kernel
     names = ["prologue", "fwd recompute", "dgrad", "image stores", "wgrad", "epilogue"]
-    kernels = (("density net", lambda: call("ngp_density_bwd", ptr(feats), ptr(dw), ptr(dh), ptr(dsig), 128.0, S, ptr(active), ptr(n_act), ptr(dfe), ptr(part), stream())),)
+    kernels = (("density net", lambda: call("ngp_density_bwd", ptr(feats), ptr(dw), ptr(dh), ptr(dsig), 128.0, S, ptr(active), ptr(n_act), ptr(dfe), ptr(part), stream())),
+               ("both nets (colour = this - density)", bwd))
     out = (C.c_ulonglong * 16)()
     for label, fn in kernels:
         torch.cuda.synchronize(); libh.ngp_debug_mlp_timing(None, 1)

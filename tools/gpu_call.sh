@@ -6,6 +6,8 @@
 #         bench3  -- the same three times back to back (run-to-run spread on one box)
 #         profile -- tools/profile_bench.sh <tag> (kernel trace + PMC passes of the driver-shaped command)
 #         py:<script> [args] -- python tools/<script> ..., log -> gpurun_out/<tag>_<script>.log   (quote the whole word)
+#         sh:<script> [args] -- bash tools/<script> ..., log -> gpurun_out/<tag>_<script>.log
+#         parity  -- the end-to-end parity tests with NGP_PARITY_LOG set: their measured error distributions -> <tag>_parity_distribution.txt
 #         test:<expr> -- pytest -m gpu -k <expr>
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 TAG=$1; shift
@@ -30,6 +32,14 @@ for what in "$@"; do
     py:*)
       cmd=${what#py:}; name=$(echo "$cmd" | cut -d' ' -f1 | sed 's/\.py$//')
       timeout 900 python tools/$cmd > gpurun_out/${TAG}_${name}.log 2>&1; echo "$name rc=$?"; tail -40 gpurun_out/${TAG}_${name}.log ;;
+    sh:*)
+      cmd=${what#sh:}; name=$(echo "$cmd" | cut -d' ' -f1 | sed 's/\.sh$//')
+      timeout 1200 bash tools/$cmd > gpurun_out/${TAG}_${name}.log 2>&1; echo "$name rc=$?"; tail -60 gpurun_out/${TAG}_${name}.log ;;
+    parity)
+      rm -f gpurun_out/${TAG}_parity_distribution.txt
+      NGP_PARITY_LOG=$PWD/gpurun_out/${TAG}_parity_distribution.txt timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider \
+        -k "end_to_end or references_render_on_the_binding" 2>&1 | tail -5
+      cat gpurun_out/${TAG}_parity_distribution.txt ;;
     test:*)
       timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider -x -k "${what#test:}" 2>&1 | tail -15 | tee gpurun_out/${TAG}_test_k.log ;;
     *) echo "unknown: $what" ;;
