@@ -17,7 +17,9 @@
 # rest of oracle/_ref, shipped to the GPU box with the snapshot): models/{__init__,rendering,networks,
 # custom_functions}.py and losses.py.  tests/test_reference_files_gpu.py and bench.py's
 # `api_path_reference_files` leg execute THOSE files on the GPU over this package's `vren` / `tinycudann`
-# bindings (oracle/ref_on_binding.py) -- INTEGRATION.md "Option A" run for real.  Nothing is copied into history.
+# bindings (oracle/ref_on_binding.py) -- INTEGRATION.md "Option A" run for real.  Round 6 adds train.py, opt.py, utils.py and
+# datasets/{base,ray_utils}.py: tests/test_reference_train_gpu.py executes the reference's train.py itself
+# (oracle/ref_train_harness.py supplies the packages this image lacks).  Nothing is copied into history.
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
 REF="${NGP_REFERENCE_DIR:-/root/reference}/models/csrc"
@@ -28,7 +30,11 @@ PYREF="$(dirname "$(dirname "$REF")")"
 mkdir -p "$OUT/py/models"
 for f in __init__ rendering networks custom_functions; do cp -pf "$PYREF/models/$f.py" "$OUT/py/models/$f.py"; done
 cp -pf "$PYREF/losses.py" "$OUT/py/losses.py"
-echo "[build_ref] staged the reference's models/*.py + losses.py (unmodified) under $OUT/py"
+# ... and what tests/test_reference_train_gpu.py needs to execute the reference's train.py itself (oracle/ref_train_harness.py)
+mkdir -p "$OUT/py/datasets"
+for f in train opt utils; do cp -pf "$PYREF/$f.py" "$OUT/py/$f.py"; done
+for f in base ray_utils; do cp -pf "$PYREF/datasets/$f.py" "$OUT/py/datasets/$f.py"; done
+echo "[build_ref] staged the reference's models/*.py + losses.py + train.py, opt.py, utils.py, datasets/{base,ray_utils}.py (unmodified) under $OUT/py"
 PY="${PYTHON:-python3}"
 TORCH_INC=$($PY -c "import torch.utils.cpp_extension as c; print(' '.join('-I'+p for p in c.include_paths()))")
 TORCH_LIB=$($PY -c "import torch, os; print(os.path.join(os.path.dirname(torch.__file__), 'lib'))")

@@ -67,3 +67,34 @@ def test_hash_grid_gathers_the_hand_computed_entries(lib):
         # corner-0 weight (1 - f)^3 with f within [0, 0.01] (float32 rounding of x01 * scale at 1023 is ~6e-5 per axis)
         assert 0.96 * v <= got[j, 0] <= v + 1e-3 and -v - 1e-3 <= got[j, 1] <= -0.96 * v, (c, idx, got[j])
         j += 1
+
+
+@pytest.mark.parametrize("n_hidden", [1, 2])
+def test_fully_fused_mlp_with_hand_computable_weights(lib, n_hidden):
+    """tcnn.Network (FullyFusedMLP, 64 neurons, ReLU, no bias, weights (out, in) row-major layer after layer, output rows padded to 16
+    -- models/networks.py:49-55,67-77) with weights whose result is known without any restatement:
+        layer 0:  h[i] = relu(x[i]), h[32 + i] = relu(-x[i])                      (W0[i][i] = 1, W0[32 + i][i] = -1)
+        layer 1:  (two hidden layers only) a reversal, h'[j] = h[63 - j]           (W1[j][63 - j] = 1)
+        output :  y[k] = 2 relu(x[k]) - 2 relu(-x[k]) + 0.5 relu(x[k + 16]) = 2 x[k] + 0.5 max(x[k + 16], 0),  k < 16
+    on inputs that are exact in f16.  A transposed layout, a swapped layer order, a bias or a different padding all change y."""
+    from ngp_pl_amd import tcnn
+    net = tcnn.Network(32, 16, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64,
+                                "n_hidden_layers": n_hidden}).cuda()
+    W0 = torch.zeros(64, 32); W1 = torch.zeros(64, 64); Wo = torch.zeros(16, 64)
+    for i in range(32):
+        W0[i, i] = 1.0; W0[32 + i, i] = -1.0
+    pos = (lambda j: 63 - j) if n_hidden == 2 else (lambda j: j)             # where unit j of layer 0 sits in the last hidden layer
+    for j in range(64):
+        W1[j, 63 - j] = 1.0
+    for k in range(16):
+        Wo[k, pos(k)] = 2.0; Wo[k, pos(32 + k)] = -2.0; Wo[k, pos(16 + k)] = 0.5
+    blob = torch.cat([W0.reshape(-1)] + ([W1.reshape(-1)] if n_hidden == 2 else []) + [Wo.reshape(-1)])
+    assert blob.numel() == net.params.numel() == 64 * 32 + (64 * 64 if n_hidden == 2 else 0) + 16 * 64
+    with torch.no_grad():
+        net.params.copy_(blob.cuda())
+    net._half.invalidate()
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randint(-32, 33, (4099, 32), generator=g).float() / 8.0)      # multiples of 1/8 in [-4, 4]: exact in f16, sums exact too
+    want = 2.0 * x[:, :16] + 0.5 * x[:, 16:32].clamp(min=0)
+    got = net(x.cuda().half()).float().cpu()
+    assert got.shape == (4099, 16) and torch.equal(got, want)

@@ -205,3 +205,25 @@ def test_hash_indices_are_the_hand_computed_known_answers():
     # all 8 corners of one cell: corner c adds (c & 1, (c >> 1) & 1, c >> 2)
     idx = [int(t[0]) for t in T._corner_indices(meta, 15, torch.tensor([[0, 0, 0]]))]
     assert idx == [0, 1, 489905, 489905 ^ 1, 153493, 153493 ^ 1, 489905 ^ 153493, 489905 ^ 153493 ^ 1]
+
+
+@pytest.mark.parametrize("n_hidden", [1, 2])
+def test_mlp_with_hand_computable_weights(n_hidden):
+    """The restatement of FullyFusedMLP on the weights of tests/test_kat_gpu.py::test_fully_fused_mlp_with_hand_computable_weights
+    (h[i] = relu(x[i]), h[32 + i] = relu(-x[i]); optional reversal layer; y[k] = 2 x[k] + 0.5 max(x[k + 16], 0)): the answer is known
+    without evaluating any matrix product, so the (out, in) row-major / layer-after-layer layout of oracle and product are pinned to
+    the same independent statement."""
+    W0 = torch.zeros(64, 32); W1 = torch.zeros(64, 64); Wo = torch.zeros(16, 64)
+    for i in range(32):
+        W0[i, i] = 1.0; W0[32 + i, i] = -1.0
+    pos = (lambda j: 63 - j) if n_hidden == 2 else (lambda j: j)
+    for j in range(64):
+        W1[j, 63 - j] = 1.0
+    for k in range(16):
+        Wo[k, pos(k)] = 2.0; Wo[k, pos(32 + k)] = -2.0; Wo[k, pos(16 + k)] = 0.5
+    blob = torch.cat([W0.reshape(-1)] + ([W1.reshape(-1)] if n_hidden == 2 else []) + [Wo.reshape(-1)])
+    g = torch.Generator().manual_seed(1)
+    x = torch.randint(-32, 33, (257, 32), generator=g).float() / 8.0
+    want = 2.0 * x[:, :16] + 0.5 * x[:, 16:32].clamp(min=0)
+    assert torch.equal(T.mlp(x, blob, 32, n_hidden, 16, quantize=True), want)
+    assert torch.equal(T.mlp(x, blob, 32, n_hidden, 16, acc16=True), want)
