@@ -68,7 +68,7 @@ constexpr int MAX_CHUNKS = 4608;             // 4.7 M samples: the first steps o
 #define NGP_APPLY_WRITEOUT_BATCHED 0          // accumulators per thread read together at write-out; 0: one at a time (round 2; A/B builds)
 #endif
 #ifndef NGP_DENSE_B
-#define NGP_DENSE_B 4                         // dense levels: entries per lane in flight
+#define NGP_DENSE_B 2                         // dense levels: entries per lane in flight (round 6, same box: 2 -> 122.8 us alone, 4 -> 125.6, 8 -> 128.7)
 #endif
 constexpr int APPLY_THREADS = NGP_APPLY_THREADS;
 

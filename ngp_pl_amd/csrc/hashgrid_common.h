@@ -17,21 +17,27 @@ struct GridMeta {
 };
 
 // x01 = (x - min) * (1/(max - min))  [networks.py:103 divides: identical bits for the power-of-two extents 2 x scale of every recipe
-// of the reference (scale 0.5 ... 16); for any other extent the product with the correctly rounded reciprocal is within 1 ulp of the
-// quotient -- INTEGRATION.md "Box extents"], pos = x01*scale + 0.5, cell = floor(pos).
+// of the reference (scale 0.5 ... 16); for any other extent v_rcp_f32 is 1 ulp off and the product within 2 ulp of the quotient --
+// INTEGRATION.md "Box extents"], pos = x01*scale + 0.5, cell = floor(pos).
 struct Box { float mn[3], inv[3]; };
+#ifndef NGP_BOX_EXACT_RECIPROCAL
+#define NGP_BOX_EXACT_RECIPROCAL 0
+#endif
 __device__ __forceinline__ Box load_box(const float* __restrict__ xyz_min, const float* __restrict__ xyz_max) {
     Box b;
-    // v_rcp_f32 is exact for a power of two (the common case: one instruction); any other extent takes the correctly rounded division
-    // of this build's flags (~10 vector instructions per axis: 28 of the forward kernel's 201 when it ran unconditionally, round 5).
-    // The extent is made wave-uniform first, so that the test is a scalar branch and the division is SKIPPED, not selected away.
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
+        b.mn[k] = xyz_min[k];
+#if NGP_BOX_EXACT_RECIPROCAL
+        // correctly rounded reciprocal for extents that are not powers of two, behind a scalar branch (A/B builds)
         const uint32_t eb = __builtin_amdgcn_readfirstlane(__float_as_uint(xyz_max[k] - xyz_min[k]));
         const float e = __uint_as_float(eb);
-        b.mn[k] = xyz_min[k];
         if ((eb & 0x007fffffu) == 0u) b.inv[k] = __builtin_amdgcn_rcpf(e);
         else b.inv[k] = 1.0f / e;
+#else
+        // v_rcp_f32: exact for a power of two, 1 ulp otherwise (INTEGRATION.md "Box extents")
+        b.inv[k] = __builtin_amdgcn_rcpf(xyz_max[k] - xyz_min[k]);
+#endif
     }
     return b;
 }
