@@ -46,13 +46,6 @@ print("lib %s: %d active samples (plan %d): %.1f us per launch (bin + apply + me
     os.path.basename(os.environ.get("NGP_HIP_LIB", "libngp_hip.so")), S, S_plan, e0.elapsed_time(e1) / N * 1e3, float(g16.float().abs().sum()),
     bool(torch.equal(ref, g16))))
 tm = ws[256:256 + 65536].view(torch.int64).view(-1, 4).cpu().double()
-if os.environ.get("NGP_BIN_T2"):
-    # -DNGP_BIN_TIMING2=<wave> build: per hashed task, wave <wave>'s first trip: top -> entries arrived -> gathers arrived -> adds issued
-    tm = tm[(tm > 0).all(1)]
-    d = (tm[:, 1:] - tm[:, :-1]) / 100
-    print("  T2 (wave %s, %d hashed tasks): entries %.2f us, gathers %.2f us, compute + LDS adds %.2f us (max %.2f); sum %.2f" % (
-        os.environ["NGP_BIN_T2"], len(tm), d[:, 0].mean(), d[:, 1].mean(), d[:, 2].mean(), d[:, 2].max(), d.sum(1).mean()))
-    sys.exit(0)
 tm = tm[tm[:, 0] > 0]
 if len(tm) > 100:
     t0 = tm[:, 0].min()
