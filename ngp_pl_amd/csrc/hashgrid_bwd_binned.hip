@@ -61,9 +61,6 @@ constexpr int MAX_CHUNKS = 4608;             // 4.7 M samples: the first steps o
 #ifndef NGP_APPLY_B
 #define NGP_APPLY_B 11
 #endif
-#ifndef NGP_APPLY_BRANCHLESS
-#define NGP_APPLY_BRANCHLESS 0
-#endif
 #ifndef NGP_APPLY_WRITEOUT_BATCHED
 #define NGP_APPLY_WRITEOUT_BATCHED 0          // accumulators per thread read together at write-out; 0: one at a time (round 2; A/B builds)
 #endif
@@ -245,11 +242,10 @@ __device__ __forceinline__ void apply_entries(long long* lds, uint32_t lo, uint3
 
 // The same for (sample, corner pair) entries of a hashed level: entry = (j << 2) | (cy + 2 cz); only the pair
 // (x, y+cy, z+cz), (x+1, y+cy, z+cz) is formed -- index arithmetic and weight order of corner_indices()/corner_weight().
-template <int B, bool TIMED = false>
+template <int B>
 __device__ __forceinline__ void apply_pairs(long long* lds, uint32_t lo, uint32_t len, uint32_t size, float scale,
                                             const float* __restrict__ x, const Box& box, const half2_t* __restrict__ g_level,
-                                            const int32_t* __restrict__ active, const int (&ee)[B], const bool (&ok)[B],
-                                            long long* tmark = nullptr, bool wait_all = false) {
+                                            const int32_t* __restrict__ active, const int (&ee)[B], const bool (&ok)[B]) {
     int src[B]; half2_t g[B]; float px[B][3];
 #pragma unroll
     for (int b = 0; b < B; ++b) { const int jj = ee[b] >> 2; g[b] = g_level[jj]; src[b] = active ? active[jj] : jj; }
@@ -258,30 +254,9 @@ __device__ __forceinline__ void apply_pairs(long long* lds, uint32_t lo, uint32_
         const float* __restrict__ xp = x + 3 * (size_t)src[b];
         px[b][0] = xp[0]; px[b][1] = xp[1]; px[b][2] = xp[2];
     }
-    if (TIMED && wait_all) {
-        __builtin_amdgcn_s_waitcnt(0);                     // every gather of the trip is here
-        if (tmark) tmark[0] = (long long)wall_clock64();
-    }
     const uint32_t mask = size - 1u;
 #pragma unroll
     for (int b = 0; b < B; ++b) {
-#if NGP_APPLY_BRANCHLESS
-        // straight-line form: a lane without an entry, or a corner outside the slice, adds 0 to a spare accumulator behind the slice
-        // (index SLICE2) -- no exec-mask region per entry and corner, one basic block per trip
-        // (the 2^24 of the fixed point rides on the gradient: (w g) 2^24 == w (g 2^24) bit for bit, powers of two scale exactly)
-        const float g0 = (float)g[b][0] * FIX_SCALE, g1 = (float)g[b][1] * FIX_SCALE;
-        uint32_t p[3]; float f[3];
-        cell_of_loaded(px[b], box, scale, p, f);
-        const uint32_t cy = (uint32_t)ee[b] & 1u, cz = ((uint32_t)ee[b] >> 1) & 1u;
-        const uint32_t h = ((p[1] + cy) * PRIME_Y) ^ ((p[2] + cz) * PRIME_Z);
-        uint32_t l0 = ((p[0] ^ h) & mask) - lo, l1 = (((p[0] + 1u) ^ h) & mask) - lo;
-        const float wy = cy ? f[1] : 1.f - f[1], wz = cz ? f[2] : 1.f - f[2];
-        const bool in0 = ok[b] && l0 < len, in1 = ok[b] && l1 < len;
-        const float w0 = in0 ? ((1.f - f[0]) * wy) * wz : 0.f, w1 = in1 ? (f[0] * wy) * wz : 0.f;
-        l0 = in0 ? l0 : SLICE2; l1 = in1 ? l1 : SLICE2;
-        lds_add_q(lds + 2 * l0, w0 * g0); lds_add_q(lds + 2 * l0 + 1, w0 * g1);
-        lds_add_q(lds + 2 * l1, w1 * g0); lds_add_q(lds + 2 * l1 + 1, w1 * g1);
-#else
         if (!ok[b]) continue;
         const float g0 = (float)g[b][0], g1 = (float)g[b][1];
         uint32_t p[3]; float f[3];
@@ -293,7 +268,6 @@ __device__ __forceinline__ void apply_pairs(long long* lds, uint32_t lo, uint32_
         const float w0 = ((1.f - f[0]) * wy) * wz, w1 = (f[0] * wy) * wz;
         if (l0 < len) { lds_add_fixed(lds + 2 * l0, w0 * g0); lds_add_fixed(lds + 2 * l0 + 1, w0 * g1); }
         if (l1 < len) { lds_add_fixed(lds + 2 * l1, w1 * g0); lds_add_fixed(lds + 2 * l1 + 1, w1 * g1); }
-#endif
     }
 }
 
@@ -306,16 +280,9 @@ template <int B>
 __device__ __forceinline__ void apply_segments_hashed(long long* lds, uint32_t lo, uint32_t len, uint32_t res, uint32_t size, float scale,
                                                       const float* __restrict__ x, const Box& box, const half2_t* __restrict__ g_level,
                                                       const int32_t* __restrict__ active, const int32_t* __restrict__ pool_level,
-                                                      const int* s_dir, int n_chunks, int part, int K, long long* tmark = nullptr) {
+                                                      const int* s_dir, int n_chunks, int part, int K) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NW = APPLY_THREADS / 64;
-#ifdef NGP_BIN_TIMING2
-    // where a hashed task's scan goes, per wave: [0] top, [1] entries arrived, [2] gathers arrived, [3] all adds issued -- of wave
-    // NGP_BIN_TIMING2 (0 .. 15), first trip only; the waits this inserts are the dependences the code has anyway
-    const bool t2 = tmark != nullptr && wave == NGP_BIN_TIMING2 && lane == 0;
-    if (t2) tmark[0] = (long long)wall_clock64();
-    bool first_trip = true;
-#endif
     for (int c0 = part + K * wave; c0 < n_chunks; c0 += K * NW * B) {
         int start[B], cnt[B], maxcnt = 0;
 #pragma unroll
@@ -332,16 +299,7 @@ __device__ __forceinline__ void apply_segments_hashed(long long* lds, uint32_t l
                 ok[b] = off + lane < cnt[b];
                 ee[b] = ok[b] ? pool_level[(size_t)start[b] + off + lane] : 0;
             }
-#ifdef NGP_BIN_TIMING2
-            if (first_trip) {
-                __builtin_amdgcn_s_waitcnt(0);             // vmcnt(0) lgkmcnt(0): the entries are here
-                if (t2) tmark[1] = (long long)wall_clock64();
-            }
-            apply_pairs<B, true>(lds, lo, len, size, scale, x, box, g_level, active, ee, ok, first_trip && t2 ? tmark + 2 : nullptr, first_trip);
-            if (first_trip) { if (t2) tmark[3] = (long long)wall_clock64(); first_trip = false; }
-#else
             apply_pairs<B>(lds, lo, len, size, scale, x, box, g_level, active, ee, ok);
-#endif
         }
     }
 }
@@ -527,12 +485,7 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
         const half2_t* __restrict__ g_level = dfeats + (size_t)level * n_samples;
         const int32_t* __restrict__ pool_level = ws.pool + plan.pool_off[level];
         if (level_is_hashed(res, size)) {
-#ifdef NGP_BIN_TIMING2
-            apply_segments_hashed<NGP_APPLY_B>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K,
-                                               ws.timing + 4 * task);
-#else
             apply_segments_hashed<NGP_APPLY_B>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
-#endif
         }
         else if (NGP_DENSE_RUNS) apply_segments_dense_runs<NGP_DENSE_B>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
         else apply_segments_dense<4>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
@@ -751,7 +704,7 @@ static int binned_group_impl(const float* x, const float* xyz_min, const float* 
     if (group == 0)
         bin_kernel<<<dim3(meta->n_levels * P.n_chunks), dim3(BIN_THREADS), 0, st>>>(
             x, xyz_min, xyz_max, (const half2_t*)dfeats, dm, P, ws, n_samples, active_idx, n_active);
-    constexpr int smem = (int)((SLICE2 + 1) * 2 * sizeof(long long));         // (+ one spare accumulator: NGP_APPLY_BRANCHLESS builds add their zeros there)
+    constexpr int smem = (int)(SLICE2 * 2 * sizeof(long long));
     static bool attr_set[64] = {};              // per device: the attribute belongs to the device's code object
     int dev = 0;
     (void)hipGetDevice(&dev);
