@@ -336,8 +336,12 @@ int ngp_field_fwd(const ngp_half* feats, const float* dirs,
  *   ngp_density_bwd: dL_dh (S,16) f16 already scaled (may be NULL) and dL_dsigmas (S) f32
  *                    unscaled (may be NULL; TruncExp backward custom_functions.py:168-173 is
  *                    applied here) -> dfeats [L][S] half2, partials (.,3072)
- *   ngp_field_bwd:   both; wgrad_partial = [n_partials x 3072 | n_partials x 7168],
- *                    h = forward's h_out, dh_scratch (S,16) f16 workspace.
+ *   ngp_field_bwd:   both, in ONE launch since round 6: the density net's forward is recomputed from feats and dL_dh
+ *                    passes from the colour net to the density net in registers, rounded to f16 as the (S,16)
+ *                    hand-over rounded it (dfeats bit-identical to the two-launch form).
+ *                    wgrad_partial = [n_partials x 3072 | n_partials x 7168].  h (the forward's h_out) and
+ *                    dh_scratch ((S,16) f16 workspace) are no longer read or written and may be NULL; a caller
+ *                    that only kept h_out for this call can pass NULL to ngp_field_fwd as well.
  * active_idx / n_active (both NULL or both set) compact the backward as in
  * ngp_hashgrid_bwd_sliced: inputs and f32 seeds are addressed by sample id, dL_dh / dfeats by
  * compact position.  wgrad_partial must be 16-byte aligned (NGP_EINVAL otherwise; also ngp_mlp_bwd). */

@@ -111,6 +111,8 @@ _PROTOS = {
     "ngp_field_bwd_partials": [I],
     "ngp_field_bwd": [P, P, P, P, P, P, P, F, I, P, P, P, P, P, P],
     "ngp_field_bwd_guarded": [P, P, P, P, P, P, P, F, I, P, P, P, P, P, P, I, P],
+    "ngp_field_bwd_two_launches": [P, P, P, P, P, P, P, F, I, P, P, P, P, P, P],
+    "ngp_field_bwd_uses_h": [],
     "ngp_mlp_fwd": [P, P, I, I, I, I, I, P, P],
     "ngp_mlp_bwd_partials": [I],
     "ngp_mlp_bwd": [P, P, P, I, I, I, I, I, P, P, P],
@@ -190,7 +192,7 @@ _PROTOS = {
     "ngp_render_test_frame": [P, P, P, P, I, F, F, I, I, F, P, P, P, C.POINTER(GridMeta), P, P, I, I, I,
                               C.POINTER(C.c_float), P, C.c_size_t, P, P, P, P, C.POINTER(C.c_int32), P],
 }
-_COUNT_QUERIES = ("ngp_field_bwd_partials", "ngp_mlp_bwd_partials", "ngp_abi_version", "ngp_stepper_pending", "ngp_stepper_last_set", "ngp_stepper_two_rounds",
+_COUNT_QUERIES = ("ngp_field_bwd_partials", "ngp_field_bwd_uses_h", "ngp_mlp_bwd_partials", "ngp_abi_version", "ngp_stepper_pending", "ngp_stepper_last_set", "ngp_stepper_two_rounds",
                   "ngp_stepper_record_bytes", "ngp_debug_hashgrid_fwd_map")
 
 _lib = None
@@ -252,6 +254,18 @@ def call(name, *args):
             kind = "NGP_ECOMM (%s)" % (lib().ngp_comm_last_error() or b"?").decode(errors="replace")
         raise NgpError("%s failed: %s" % (name, kind))
     return 0
+
+
+_FIELD_BWD_USES_H = None
+
+
+def field_bwd_uses_h():
+    """False when ngp_field_bwd neither reads the forward's h_out nor writes dh_scratch (the one-launch kernel: both may be NULL,
+    the forward then skips the (S,16) store); True in the two-launch A/B build."""
+    global _FIELD_BWD_USES_H
+    if _FIELD_BWD_USES_H is None:
+        _FIELD_BWD_USES_H = bool(call("ngp_field_bwd_uses_h"))
+    return _FIELD_BWD_USES_H
 
 
 SPIN_TIMEOUT_S = float(os.environ.get("NGP_SPIN_TIMEOUT_S", "30"))

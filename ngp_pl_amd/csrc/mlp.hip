@@ -135,7 +135,12 @@ __device__ __forceinline__ void stage_weights(const h1* __restrict__ g, h1* lds,
 }
 
 // ---- SH degree 4 (tiny-cuda-nn spherical_harmonics.h, constants as SURVEY.md section 8a) ----
-__device__ __forceinline__ void sh4(float x, float y, float z, float* o) {
+template <class O>
+__device__ __forceinline__ void sh4(float x, float y, float z, O& o) {
+    // no mul+add contraction: every kernel that evaluates the basis (forward, both backwards, ngp_sh4_fwd) gets the SAME sixteen
+    // f32 values -- the plain products and sums the fp32 restatement computes -- instead of whatever mix of FMAs each inlined copy
+    // was given (round 6: the one-launch backward differed from the two-launch one by an f16 ulp of one coefficient in 2 % of tiles)
+#pragma clang fp contract(off)
     const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
     o[0] = 0.28209479177387814f;
     o[1] = -0.48860251190291987f * y;
@@ -153,6 +158,22 @@ __device__ __forceinline__ void sh4(float x, float y, float z, float* o) {
     o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
     o[14] = 1.4453057213202769f * z * (x2 - y2);
     o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+}
+
+// SH(d/|d|) as the B fragment of input chunk 0 (natural K order: lane-half hh holds coefficients 8hh .. 8hh+7).  The coefficients
+// live in a VECTOR value: as a float[16] indexed by 8*hh + e they went through scratch memory (80 bytes, a store + load round trip per tile).
+__device__ __forceinline__ half8_t sh4_fragment(float dx, float dy, float dz, int hh) {
+#pragma clang fp contract(off)
+    const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    f32x16 sh;
+    sh4(dx * inv, dy * inv, dz * inv, sh);
+    half8_t b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float lo = sh[e], hi = sh[8 + e];
+        b[e] = (h1)(hh ? hi : lo);
+    }
+    return b;
 }
 
 enum InMode { IN_ROWMAJOR = 0, IN_LEVELMAJOR = 1, IN_SH_H = 2 };
@@ -193,12 +214,7 @@ __device__ __forceinline__ void load_input(const MlpIO& io, long long s, bool va
                 b[c][2 * q] = v[0]; b[c][2 * q + 1] = v[1];
             }
     } else {  // IN_SH_H: chunk 0 = SH(d/|d|), chunk 1 = h
-        const float dx = io.dirs[3 * s], dy = io.dirs[3 * s + 1], dz = io.dirs[3 * s + 2];
-        const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-        float sh[16];
-        sh4(dx * inv, dy * inv, dz * inv, sh);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) b[0][e] = (h1)(hh ? sh[8 + e] : sh[e]);
+        b[0] = sh4_fragment(io.dirs[3 * s], io.dirs[3 * s + 1], io.dirs[3 * s + 2], hh);
         b[1] = *reinterpret_cast<const half8_t*>(io.in + s * 16 + 8 * hh);
     }
 }
@@ -486,14 +502,7 @@ field_fwd_kernel(FieldIO io, const h1* __restrict__ density_w, const h1* __restr
 #pragma unroll
         for (int e = 0; e < 8; ++e) hfrag[e] = (h1)o[0][e];
         // colour net input chunk 0: SH(d/|d|), natural K order
-        half8_t shfrag;
-        {
-            const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-            float sh[16];
-            sh4(dx * inv, dy * inv, dz * inv, sh);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) shfrag[e] = (h1)(hh ? sh[8 + e] : sh[e]);
-        }
+        const half8_t shfrag = sh4_fragment(dx, dy, dz, hh);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             acc[m] = mfma(ldsA_nat(ldsr + LR::OFF_W0, LR::LD0, 32 * m + i, true, 0, hh), shfrag, zero16());
@@ -745,14 +754,7 @@ __device__ __forceinline__ void bwd_input(const BwdRaw<N_IN>& r, int hh, half8_t
     if (IN_MODE == IN_SH_H) {
         const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
         b[0] = z;
-        {
-            const float dx = r.dir[0], dy = r.dir[1], dz = r.dir[2];
-            const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-            float sh[16];
-            sh4(dx * inv, dy * inv, dz * inv, sh);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) b[0][e] = (h1)(hh ? sh[8 + e] : sh[e]);
-        }
+        b[0] = sh4_fragment(r.dir[0], r.dir[1], r.dir[2], hh);
     }
 }
 
@@ -1043,6 +1045,311 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
     MLP_TEND();
 }
 
+// ------------------------------------------------------------------------------------------
+// fused field backward (NGP_FIELD_BWD_FUSED): the colour net's and the density net's backward chained in ONE launch.  What the two
+// mlp_bwd_kernel launches hand over through memory -- dL/dh (S,16) f16 out and in, h (S,16) in -- stays in registers: the
+// density net's forward is recomputed from the features (bit for bit the h the forward stored), the colour net's input gradient
+// is rounded to f16 exactly as the (S,16) store rounded it and becomes the density net's output gradient in the D order it is
+// produced in.  One prologue (both nets' weights + transposes staged once), one epilogue, one pass over the active list.
+// The twelve dW accumulator tiles of the two nets (192 registers) are pinned in AGPRs: the wgrad MFMAs are issued as inline
+// assembly with "+a" operands, which leaves the 256 VGPRs to forward / dgrad (-amdgpu-mfma-vgpr-form keeps THEIR results in VGPRs).
+// Results: dfeats bit-identical to the two-kernel path; dW partial rows differ in summation order (4 waves of tiles instead of 8
+// for the density net).
+// ------------------------------------------------------------------------------------------
+#ifndef NGP_FIELD_BWD_FUSED
+#define NGP_FIELD_BWD_FUSED 1          // 0: ngp_field_bwd = the two mlp_bwd_kernel launches (A/B builds; tests reach them through ngp_field_bwd_two_launches)
+#endif
+struct FieldBwdIO {
+    const h1* feats;          // [16][S] half2
+    const float* dirs;        // (S,3)
+    const float* dL_dsigmas;  // (S) f32 unscaled
+    const float* dL_drgbs;    // (S,3) f32 unscaled
+    float loss_scale;
+    h1* dfeats;               // [16][S] half2, by compact position
+    float* wgrad_density;     // (gridDim.x, 3072)
+    float* wgrad_rgb;         // (gridDim.x, 7168)
+    const int32_t* active;    // optional compaction, as MlpBwdIO
+    const int32_t* n_active;
+    int32_t* nonfinite;
+    int32_t* nonfinite_clear;
+};
+struct FieldBwdRaw {
+    bool valid;
+    half8_t in[2];
+    float dir[3];
+    float seed_rgb[3];
+    float seed_sig;
+};
+struct FieldBwdLds {
+    using LD = LdsW<32, 1>;
+    using LR = LdsW<32, 2>;
+    static constexpr int LDT = HID + PAD, LDTO = 16 + PAD;
+    // density: forward image | W0^T (32, 64) | Wo^T (64, 16);  colour: forward image | W0^T (32, 64) | W1^T (64, 64) | Wo^T (64, 16)
+    static constexpr int D_T0 = LD::SIZE, D_TO = D_T0 + 32 * LDT, D_SIZE = D_TO + HID * LDTO;
+    static constexpr int R_T0 = LR::SIZE, R_T1 = R_T0 + 32 * LDT, R_TO = R_T1 + HID * LDT, R_SIZE = R_TO + HID * LDTO;
+    static constexpr int OFF_R = (D_SIZE + 7) / 8 * 8;
+    static constexpr int OFF_TR = (OFF_R + R_SIZE + 127) / 128 * 128;
+    static constexpr int FWAVES = 4, NB = 10;
+    static constexpr int IMG_BYTES = FWAVES * NB * BLK_BYTES;                  // 80 KB; the dW reduction slabs (4 x 16 KB) reuse it
+    static constexpr int BYTES = OFF_TR * 2 + IMG_BYTES;
+};
+
+// dW tile accumulate with the accumulator in AGPRs
+__device__ __forceinline__ void mfma_agpr(f32x16& acc, half8_t a, half8_t b) {
+    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+template <int MT, int NT>
+__device__ __forceinline__ void wgrad_tile_agpr(const char* dy, const char* x, const TrAddr& ta, f32x16 (&acc)[MT][NT]) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        half8_t a[MT], b[NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = tr_get(dy + m * BLK_BYTES, c, ta);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) b[n] = tr_get(x + n * BLK_BYTES, c, ta);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) mfma_agpr(acc[m][n], a[m], b[n]);
+    }
+}
+// D-order 16-unit fragment (register e of lane-half hh = unit 4hh + (e&3) + 8(e>>2)) -> natural order (unit 8hh + e): the lane
+// halves exchange two registers each (v_permlane32_swap: upper half of the first operand <-> lower half of the second)
+__device__ __forceinline__ half8_t d_order_to_natural(half8_t v) {
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t w = __builtin_bit_cast(u32x4_t, v);
+    const auto p02 = __builtin_amdgcn_permlane32_swap(w[0], w[2], false, false);
+    const auto p13 = __builtin_amdgcn_permlane32_swap(w[1], w[3], false, false);
+    w[0] = p02[0]; w[2] = p02[1]; w[1] = p13[0]; w[3] = p13[1];
+    return __builtin_bit_cast(half8_t, w);
+}
+
+__global__ void __launch_bounds__(64 * FieldBwdLds::FWAVES)
+field_bwd_kernel(FieldBwdIO io, const h1* __restrict__ density_w, const h1* __restrict__ rgb_w, int n_samples) {
+    using F = FieldBwdLds;
+    using LD = F::LD;
+    using LR = F::LR;
+    constexpr int FW = F::FWAVES;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    h1* ldsd = reinterpret_cast<h1*>(smem_raw);
+    h1* ldsr = ldsd + F::OFF_R;
+    float* part = reinterpret_cast<float*>(ldsd + F::OFF_TR);
+
+    MLP_T0();
+    const int lane = threadIdx.x & 63, i = lane & 31, hh = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    char* img = reinterpret_cast<char*>(ldsd + F::OFF_TR) + wave * F::NB * BLK_BYTES;
+    // colour net: x (1 block) dh0 (2) h0 (2) dh1 (2) h1 (2) dy (1); the density net's operands then reuse the first six
+    char* img_x = img;
+    char* img_dh0 = img + 1 * BLK_BYTES;
+    char* img_h0 = img + 3 * BLK_BYTES;
+    char* img_dh1 = img + 5 * BLK_BYTES;
+    char* img_h1 = img + 7 * BLK_BYTES;
+    char* img_dy = img + 9 * BLK_BYTES;
+    char* imd_x = img;
+    char* imd_dh0 = img + 1 * BLK_BYTES;
+    char* imd_h0 = img + 3 * BLK_BYTES;
+    char* imd_dy = img + 5 * BLK_BYTES;
+    const TrAddr ta = tr_addr(lane);
+    const int n_eff = io.active ? min(*io.n_active, n_samples) : n_samples;
+    const int n_tiles = (n_eff + TILE - 1) / TILE;
+
+    f32x16 gR0[2][1], gR1[2][2], gRo[1][2], gD0[2][1], gDo[1][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        gR0[m][0] = zero16(); gD0[m][0] = zero16();
+        gR1[m][0] = zero16(); gR1[m][1] = zero16();
+    }
+    gRo[0][0] = zero16(); gRo[0][1] = zero16(); gDo[0][0] = zero16(); gDo[0][1] = zero16();
+
+    const int tile_stride = gridDim.x * FW;
+    const bool has_list = io.active != nullptr;
+    const long long j_last = n_eff > 0 ? n_eff - 1 : 0;
+    const int32_t* idx_src = has_list ? io.active : reinterpret_cast<const int32_t*>(density_w);
+    auto raw_index = [&](int t) -> int {
+        const long long jj = (long long)t * TILE + i;
+        return idx_src[has_list ? (jj < j_last ? jj : j_last) : 0];
+    };
+    const half2_t* fp = reinterpret_cast<const half2_t*>(io.feats);
+    auto fetch = [&](int t, int raw, FieldBwdRaw& r) {
+        const long long jj = (long long)t * TILE + i;
+        r.valid = t < n_tiles && jj < n_eff;
+        const long long jc = jj < j_last ? jj : j_last;
+        long long sc = has_list ? (long long)raw : jc;
+        sc = sc < 0 ? 0 : (sc < n_samples ? sc : (long long)n_samples - 1);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const half2_t v = __builtin_nontemporal_load(fp + (size_t)(8 * c + 4 * hh + q) * n_samples + sc);
+                r.in[c][2 * q] = v[0]; r.in[c][2 * q + 1] = v[1];
+            }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { r.dir[c] = io.dirs[3 * sc + c]; r.seed_rgb[c] = io.dL_drgbs[3 * sc + c]; }
+        r.seed_sig = io.dL_dsigmas[sc];
+    };
+    FieldBwdRaw cur, nxt;
+    const int t0 = blockIdx.x * FW + wave;
+    const int raw0 = raw_index(t0);
+    int raw_pre = raw_index(t0 + tile_stride);
+    stage_bwd_weights<32, 1, 64 * FW>(density_w, ldsd, F::D_T0, 0, F::D_TO);
+    stage_bwd_weights<32, 2, 64 * FW>(rgb_w, ldsr, F::R_T0, F::R_T1, F::R_TO);
+    fetch(t0, raw0, cur);
+    __syncthreads();
+    MLP_T(0);
+    for (int tile = t0; tile < n_tiles; tile += tile_stride) {
+        fetch(tile + tile_stride, raw_pre, nxt);
+        raw_pre = raw_index(tile + 2 * tile_stride);
+        const long long j = min((long long)tile * TILE + i, j_last);
+        const bool valid = cur.valid;
+        // ---- density net forward: h (f16, D order) ----
+        half8_t xd[2] = {cur.in[0], cur.in[1]};
+        f32x16 acc[2];
+        half8_t h0d[4];
+        layer_in<32>(ldsd + LD::OFF_W0, xd, i, hh, acc);
+        acc_to_frag<true>(acc, h0d);
+        f32x16 od[1];
+        layer_hid<1>(ldsd + LD::OFF_WO, LD::LDH, 16, h0d, i, hh, od);
+        half8_t hfrag;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hfrag[e] = (h1)od[0][e];
+        // ---- colour net forward, operands as the stand-alone kernel forms them (h from its (S,16) row: natural order) ----
+        half8_t xr[2];
+        xr[0] = sh4_fragment(cur.dir[0], cur.dir[1], cur.dir[2], hh);
+        xr[1] = d_order_to_natural(hfrag);
+        half8_t h0r[4], h1r[4];
+        layer_in<32>(ldsr + LR::OFF_W0, xr, i, hh, acc);
+        acc_to_frag<true>(acc, h0r);
+        layer_hid<2>(ldsr + LR::OFF_W1, LR::LDH, 64, h0r, i, hh, acc);
+        acc_to_frag<true>(acc, h1r);
+        f32x16 oc[1];
+        layer_hid<1>(ldsr + LR::OFF_WO, LR::LDH, 16, h1r, i, hh, oc);
+        half8_t dyr[1];
+        {
+            const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+            dyr[0] = z;
+            if (valid && hh == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float sg = sigmoidf(oc[0][c]);
+                    dyr[0][c] = (h1)(cur.seed_rgb[c] * io.loss_scale * sg * (1.0f - sg));
+                }
+            }
+        }
+        MLP_T(1);
+        // ---- colour net dgrad ----
+        half8_t dh1r[4], dh0r[4];
+        {
+            f32x16 d[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                d[m] = mfma(ldsA_dl(ldsr + F::R_TO, F::LDTO, 32 * m + i, true, 0, hh), dyr[0], zero16());
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) dh1r[2 * m + c2] = relu_bwd(d_to_b<false>(d[m], c2), h1r[2 * m + c2]);
+            d[0] = zero16(); d[1] = zero16();
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    d[m] = mfma(ldsA_dl(ldsr + F::R_T1, F::LDT, 32 * m + i, true, c, hh), dh1r[c], d[m]);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) dh0r[2 * m + c2] = relu_bwd(d_to_b<false>(d[m], c2), h0r[2 * m + c2]);
+        }
+        // input rows 16..31 of the colour net = h: dL/dh, rounded to f16 as the (S,16) hand-over rounded it (D order)
+        f32x16 dhf = zero16();
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            dhf = mfma(ldsA_dl(ldsr + F::R_T0, F::LDT, 16 + i, i < 16, c, hh), dh0r[c], dhf);
+        MLP_T(2);
+        // ---- colour net wgrad ----
+        wave_lds_sync();
+        tr_put_nat<2>(img_x, xr, ta);
+        tr_put_dl<4>(img_dh0, dh0r, ta);
+        tr_put_dl<4>(img_h0, h0r, ta);
+        tr_put_dl<4>(img_dh1, dh1r, ta);
+        tr_put_dl<4>(img_h1, h1r, ta);
+        tr_put_dl<1>(img_dy, dyr, ta);
+        wave_lds_sync();
+        MLP_T(3);
+        wgrad_tile_agpr<2, 1>(img_dh0, img_x, ta, gR0);
+        wgrad_tile_agpr<2, 2>(img_dh1, img_h0, ta, gR1);
+        wgrad_tile_agpr<1, 2>(img_dy, img_h1, ta, gRo);
+        MLP_T(4);
+        // ---- density net: output gradient = dL/dh + TruncExp backward of the sigma seed (custom_functions.py:168-173) ----
+        half8_t dyd[1];
+        {
+            const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+            dyd[0] = z;
+            if (valid) {
+                float g[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) g[r] = (float)(h1)dhf[r];
+                if (hh == 0) g[0] += cur.seed_sig * io.loss_scale * __expf(fminf(fmaxf((float)hfrag[0], -15.f), 15.f));
+#pragma unroll
+                for (int r = 0; r < 8; ++r) dyd[0][r] = (h1)g[r];
+            }
+        }
+        half8_t dh0d[4];
+        {
+            f32x16 d[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                d[m] = mfma(ldsA_dl(ldsd + F::D_TO, F::LDTO, 32 * m + i, true, 0, hh), dyd[0], zero16());
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) dh0d[2 * m + c2] = relu_bwd(d_to_b<false>(d[m], c2), h0d[2 * m + c2]);
+        }
+        {
+            f32x16 d = zero16();
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                d = mfma(ldsA_dl(ldsd + F::D_T0, F::LDT, i, true, c, hh), dh0d[c], d);
+            if (valid) {
+                half2_t* df = reinterpret_cast<half2_t*>(io.dfeats);
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int f = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    half2_t v; v[0] = (h1)d[r]; v[1] = (h1)d[r + 1];
+                    __builtin_nontemporal_store(v, df + (size_t)(f >> 1) * n_samples + j);
+                }
+            }
+        }
+        MLP_T(2);
+        // ---- density net wgrad through the blocks the colour net's operands have been read from ----
+        wave_lds_sync();
+        tr_put_nat<2>(imd_x, xd, ta);
+        tr_put_dl<4>(imd_dh0, dh0d, ta);
+        tr_put_dl<4>(imd_h0, h0d, ta);
+        tr_put_dl<1>(imd_dy, dyd, ta);
+        wave_lds_sync();
+        MLP_T(3);
+        wgrad_tile_agpr<2, 1>(imd_dh0, imd_x, ta, gD0);
+        wgrad_tile_agpr<1, 2>(imd_dy, imd_h0, ta, gDo);
+        MLP_T(4);
+        cur = nxt;
+    }
+    // ---- reduce the waves' dW layer by layer into the workgroup's partial rows ----
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last inline-assembly MFMAs retire before their AGPRs are read
+    __syncthreads();
+    float* outd = io.wgrad_density + (size_t)blockIdx.x * LD::G_SIZE;
+    float* outr = io.wgrad_rgb + (size_t)blockIdx.x * LR::G_SIZE;
+    float nonfinite = 0.f;
+    wgrad_reduce_layer<2, 1, FW, false>(part, HID, 32, wave, i, hh, gR0, outr, nonfinite);
+    wgrad_reduce_layer<2, 2, FW, false>(part, HID, HID, wave, i, hh, gR1, outr + LR::G_W1, nonfinite);
+    wgrad_reduce_layer<1, 2, FW, false>(part, 16, HID, wave, i, hh, gRo, outr + LR::G_WO, nonfinite);
+    wgrad_reduce_layer<2, 1, FW, false>(part, HID, 32, wave, i, hh, gD0, outd, nonfinite);
+    wgrad_reduce_layer<1, 2, FW, false>(part, 16, HID, wave, i, hh, gDo, outd + LD::G_WO, nonfinite);
+    if (io.nonfinite != nullptr && nonfinite != 0.f) atomicOr(io.nonfinite, 1);
+    if (io.nonfinite_clear != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *io.nonfinite_clear = 0;
+    MLP_T(5);
+    MLP_TEND();
+}
+
 template <int N_IN, int N_HIDDEN>
 constexpr int fwd_smem_bytes() { return LdsW<N_IN, N_HIDDEN>::SIZE * 2; }
 template <int N_IN, int N_HIDDEN>
@@ -1249,6 +1556,44 @@ int ngp_field_bwd(const ngp_half* feats, const float* dirs, const ngp_half* h, c
                                  wgrad_partial, nullptr, 0, stream);
 }
 
+// The two-launch form: colour net (writes dL/dh to dh_scratch) then density net (reads it).  nonfinite2 / parity as below.
+static int field_bwd_two_launches(const ngp_half* feats, const float* dirs, const ngp_half* h, const ngp_half* density_w,
+                                  const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale,
+                                  int n_samples, const int32_t* active_idx, const int32_t* n_active,
+                                  ngp_half* dh_scratch, ngp_half* dfeats, float* wgrad_partial, int32_t* nonfinite2, int parity, ngp_stream_t stream) {
+    const int n_part = bwd_grid(n_samples);
+    int32_t* flag = nonfinite2 ? nonfinite2 + (parity & 1) : nullptr;
+    const int rc = ngp_rgb_bwd(h, dirs, rgb_w, dL_drgbs, loss_scale, n_samples, active_idx, n_active, dh_scratch,
+                               wgrad_partial + (size_t)n_part * NGP_DENSITY_NET_PARAMS, flag, nonfinite2 ? nonfinite2 + ((parity & 1) ^ 1) : nullptr, stream);
+    if (rc) return rc;
+    return density_bwd_guarded(feats, density_w, dh_scratch, dL_dsigmas, loss_scale, n_samples, active_idx, n_active, dfeats,
+                               wgrad_partial, flag, stream);
+}
+
+// The one-launch form (field_bwd_kernel): h and dL/dh never touch memory.
+static int field_bwd_one_launch(const ngp_half* feats, const float* dirs, const ngp_half* density_w,
+                                const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale,
+                                int n_samples, const int32_t* active_idx, const int32_t* n_active,
+                                ngp_half* dfeats, float* wgrad_partial, int32_t* nonfinite2, int parity, ngp_stream_t stream) {
+    NGP_CHECK_PTR(feats); NGP_CHECK_PTR(dirs); NGP_CHECK_PTR(density_w); NGP_CHECK_PTR(rgb_w); NGP_CHECK_PTR(dL_dsigmas);
+    NGP_CHECK_PTR(dL_drgbs); NGP_CHECK_PTR(dfeats);
+    if ((active_idx == nullptr) != (n_active == nullptr)) return NGP_EINVAL;
+    if (reinterpret_cast<uintptr_t>(wgrad_partial) & 15) return NGP_EINVAL;     // partial rows are stored 16 bytes at a time
+    const int n_part = bwd_grid(n_samples);
+    FieldBwdIO io = {};
+    io.feats = (const h1*)feats; io.dirs = dirs; io.dL_dsigmas = dL_dsigmas; io.dL_drgbs = dL_drgbs; io.loss_scale = loss_scale;
+    io.dfeats = (h1*)dfeats; io.wgrad_density = wgrad_partial; io.wgrad_rgb = wgrad_partial + (size_t)n_part * NGP_DENSITY_NET_PARAMS;
+    io.active = active_idx; io.n_active = n_active;
+    io.nonfinite = nonfinite2 ? nonfinite2 + (parity & 1) : nullptr;
+    io.nonfinite_clear = nonfinite2 ? nonfinite2 + ((parity & 1) ^ 1) : nullptr;
+    constexpr int smem = FieldBwdLds::BYTES;
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(field_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
+    field_bwd_kernel<<<dim3(n_part), dim3(64 * FieldBwdLds::FWAVES), smem, ngp_stream(stream)>>>(io, (const h1*)density_w, (const h1*)rgb_w, n_samples);
+    return NGP_LAUNCH_RESULT();
+}
+
 // (csrc/ngp_internal.h) the same with the native stepper's overflow guard: nonfinite2 = two device flags; this call ORs 1 into
 // nonfinite2[parity] when a weight-gradient sum of either network is inf / NaN and clears nonfinite2[parity ^ 1] (the next step's).
 int ngp_field_bwd_guarded(const ngp_half* feats, const float* dirs, const ngp_half* h, const ngp_half* density_w,
@@ -1258,13 +1603,28 @@ int ngp_field_bwd_guarded(const ngp_half* feats, const float* dirs, const ngp_ha
     if (n_samples < 0) return NGP_EINVAL;
     if (n_samples == 0) return 0;
     NGP_CHECK_PTR(wgrad_partial);
-    const int n_part = bwd_grid(n_samples);
-    int32_t* flag = nonfinite2 ? nonfinite2 + (parity & 1) : nullptr;
-    const int rc = ngp_rgb_bwd(h, dirs, rgb_w, dL_drgbs, loss_scale, n_samples, active_idx, n_active, dh_scratch,
-                               wgrad_partial + (size_t)n_part * NGP_DENSITY_NET_PARAMS, flag, nonfinite2 ? nonfinite2 + ((parity & 1) ^ 1) : nullptr, stream);
-    if (rc) return rc;
-    return density_bwd_guarded(feats, density_w, dh_scratch, dL_dsigmas, loss_scale, n_samples, active_idx, n_active, dfeats,
-                               wgrad_partial, flag, stream);
+    if (NGP_FIELD_BWD_FUSED)
+        return field_bwd_one_launch(feats, dirs, density_w, rgb_w, dL_dsigmas, dL_drgbs, loss_scale, n_samples, active_idx, n_active, dfeats,
+                                    wgrad_partial, nonfinite2, parity, stream);
+    return field_bwd_two_launches(feats, dirs, h, density_w, rgb_w, dL_dsigmas, dL_drgbs, loss_scale, n_samples, active_idx, n_active, dh_scratch,
+                                  dfeats, wgrad_partial, nonfinite2, parity, stream);
+}
+
+// (csrc/ngp_internal.h) 1 when ngp_field_bwd reads the forward's h_out and writes dh_scratch (the two-launch A/B build), 0 when both
+// may be NULL: callers that own the buffers (the native stepper) skip the forward's h store.
+int ngp_field_bwd_uses_h(void) { return NGP_FIELD_BWD_FUSED ? 0 : 1; }
+
+// (csrc/ngp_internal.h, test hook) ngp_field_bwd as two launches whatever the build's default: the cross-check of the one-launch kernel
+// (dfeats must agree bit for bit; the density net's dW partial rows differ in summation order).
+int ngp_field_bwd_two_launches(const ngp_half* feats, const float* dirs, const ngp_half* h, const ngp_half* density_w,
+                               const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale,
+                               int n_samples, const int32_t* active_idx, const int32_t* n_active,
+                               ngp_half* dh_scratch, ngp_half* dfeats, float* wgrad_partial, ngp_stream_t stream) {
+    if (n_samples < 0) return NGP_EINVAL;
+    if (n_samples == 0) return 0;
+    NGP_CHECK_PTR(wgrad_partial); NGP_CHECK_PTR(h); NGP_CHECK_PTR(dh_scratch);
+    return field_bwd_two_launches(feats, dirs, h, density_w, rgb_w, dL_dsigmas, dL_drgbs, loss_scale, n_samples, active_idx, n_active, dh_scratch,
+                                  dfeats, wgrad_partial, nullptr, 0, stream);
 }
 
 int ngp_mlp_fwd(const ngp_half* in, const ngp_half* weights, int n_in, int n_hidden, int n_out, int out_act,

@@ -37,6 +37,14 @@ int ngp_field_bwd_guarded(const ngp_half* feats, const float* dirs, const ngp_ha
                           int n_samples, const int32_t* active_idx, const int32_t* n_active,
                           ngp_half* dh_scratch, ngp_half* dfeats, float* wgrad_partial, int32_t* nonfinite2, int parity,
                           ngp_stream_t stream);
+/* 1 when ngp_field_bwd reads h / writes dh_scratch (the two-launch A/B build), 0 when both may be NULL (the one-launch kernel, round 6:
+ * h is recomputed from the features and dL/dh handed from the colour net to the density net in registers). */
+int ngp_field_bwd_uses_h(void);
+/* test hook: ngp_field_bwd as the two launches (colour net -> dh_scratch -> density net) whatever the build's default. */
+int ngp_field_bwd_two_launches(const ngp_half* feats, const float* dirs, const ngp_half* h, const ngp_half* density_w,
+                               const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale,
+                               int n_samples, const int32_t* active_idx, const int32_t* n_active,
+                               ngp_half* dh_scratch, ngp_half* dfeats, float* wgrad_partial, ngp_stream_t stream);
 
 /* The same launch also draws the marcher's per-ray jitter (custom_functions.py:83: torch.rand_like(rays_o[:, 0])):
  * noise (R) f32 in [0,1) from a counter-based generator keyed by (seed, ray). */

@@ -392,6 +392,7 @@ static int forward_field(ngp_stepper* s, const float* rays_o, const float* rays_
     s->prev_S = S;
     s->two_rounds = two;
     const ngp_half* table = c.enc_half + c.n_density;
+    ngp_half* h_store = ngp_field_bwd_uses_h() ? b.h : nullptr;      // the one-launch field backward recomputes h: the forward need not store it
     if (!two) {
         if (!s->expanded[k])
             STEP_TRY(ngp_raymarching_train_write(rays_o, rays_d, b.rays_a[k], b.scratch[k], c.scale, c.exp_step_factor, c.grid_size, c.max_samples, n,
@@ -401,7 +402,7 @@ static int forward_field(ngp_stepper* s, const float* rays_o, const float* rays_
             STEP_TRY(ngp_hashgrid_fwd(b.xyzs, c.xyz_min, c.xyz_max, table, &c.meta, S, b.feats, main_stream));
             mark(s, 2, main);
             STEP_TRY(march_next_if_at(s, AT_HASHGRID_FWD));
-            STEP_TRY(ngp_field_fwd(b.feats, b.dirs, c.enc_half, c.rgb_half, S, b.sigmas, b.rgbs, b.h, main_stream));
+            STEP_TRY(ngp_field_fwd(b.feats, b.dirs, c.enc_half, c.rgb_half, S, b.sigmas, b.rgbs, h_store, main_stream));
             mark(s, 3, main);
             STEP_TRY(march_next_if_at(s, AT_MLP_FWD));
         }
@@ -427,10 +428,10 @@ static int forward_field(ngp_stepper* s, const float* rays_o, const float* rays_
     STEP_TRY(ngp_hashgrid_fwd_list(b.xyzs, c.xyz_min, c.xyz_max, table, &c.meta, S, b.list_k, n1, nullptr, b.feats, main_stream));
     mark(s, 2, main);
     STEP_TRY(march_next_if_at(s, AT_HASHGRID_FWD));
-    STEP_TRY(ngp_field_fwd_list(b.feats, b.dirs, c.enc_half, c.rgb_half, S, b.list_k, n1, nullptr, b.sigmas, b.rgbs, b.h, main_stream));
+    STEP_TRY(ngp_field_fwd_list(b.feats, b.dirs, c.enc_half, c.rgb_half, S, b.list_k, n1, nullptr, b.sigmas, b.rgbs, h_store, main_stream));
     STEP_TRY(ngp_composite_probe(b.sigmas, b.deltas, b.rays_a[k], K, c.T_threshold, n, b.list_rest, n2, main_stream));
     STEP_TRY(ngp_hashgrid_fwd_list(b.xyzs, c.xyz_min, c.xyz_max, table, &c.meta, S, b.list_rest, S, n2, b.feats, main_stream));
-    STEP_TRY(ngp_field_fwd_list(b.feats, b.dirs, c.enc_half, c.rgb_half, S, b.list_rest, S, n2, b.sigmas, b.rgbs, b.h, main_stream));
+    STEP_TRY(ngp_field_fwd_list(b.feats, b.dirs, c.enc_half, c.rgb_half, S, b.list_rest, S, n2, b.sigmas, b.rgbs, h_store, main_stream));
     mark(s, 3, main);
     STEP_TRY(march_next_if_at(s, AT_MLP_FWD));
     return 0;

@@ -34,14 +34,14 @@ class _FusedField(torch.autograd.Function):
         enc, net = model.xyz_encoder, model.rgb_net
         eh, rh = enc._half.get(enc_params), net._half.get(rgb_params)
         feats = torch.empty(16, n, 2, dtype=torch.float16, device=dev)
-        h = torch.empty(n, 16, dtype=torch.float16, device=dev)
+        h = torch.empty(n if _lib.field_bwd_uses_h() else 0, 16, dtype=torch.float16, device=dev)    # (the one-launch backward recomputes it)
         sigmas = torch.empty(n, dtype=torch.float32, device=dev)
         rgbs = torch.empty(n, 3, dtype=torch.float32, device=dev)
         if n > 0:
             with torch.cuda.device(dev):
                 call("ngp_hashgrid_fwd", ptr(x), ptr(model.xyz_min), ptr(model.xyz_max), ptr(eh[enc.n_mlp:]),
                      C.byref(enc.meta), n, ptr(feats), stream())
-                call("ngp_field_fwd", ptr(feats), ptr(d), ptr(eh), ptr(rh), n, ptr(sigmas), ptr(rgbs), ptr(h), stream())
+                call("ngp_field_fwd", ptr(feats), ptr(d), ptr(eh), ptr(rh), n, ptr(sigmas), ptr(rgbs), ptr(h) if h.numel() else None, stream())
         ctx.model = model
         ctx.save_for_backward(x, d, feats, h)
         return sigmas, rgbs
@@ -60,9 +60,9 @@ class _FusedField(torch.autograd.Function):
         with torch.cuda.device(dev):
             n_part = call("ngp_field_bwd_partials", n)
             partials = torch.empty(n_part * (enc.n_mlp + net.params.numel()), dtype=torch.float32, device=dev)
-            dh = torch.empty(n, 16, dtype=torch.float16, device=dev)
+            dh = torch.empty(n, 16, dtype=torch.float16, device=dev) if h.numel() else None
             dfeats = torch.empty(16, n, 2, dtype=torch.float16, device=dev)
-            call("ngp_field_bwd", ptr(feats), ptr(d), ptr(h), ptr(eh), ptr(rh), ptr(dL_dsigmas), ptr(dL_drgbs), scale, n,
+            call("ngp_field_bwd", ptr(feats), ptr(d), ptr(h) if h.numel() else None, ptr(eh), ptr(rh), ptr(dL_dsigmas), ptr(dL_drgbs), scale, n,
                  None, None, ptr(dh), ptr(dfeats), ptr(partials), stream())
             g16 = model._grid_grad16(dev)
             tcnn.grid_backward(x, model.xyz_min, model.xyz_max, dfeats, enc.meta, n, g16)

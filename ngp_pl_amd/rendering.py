@@ -139,10 +139,10 @@ def _render_test_native(model, rays_o, rays_d, hits_t, **kwargs):
             call("ngp_raymarching_test", ptr(rays_o), ptr(rays_d), ptr(hits), ptr(alive), ptr(model.density_bitfield), model.cascades,
                  float(model.scale), float(esf), model.grid_size, MAX_SAMPLES, N, n_alive, ptr(xyzs), ptr(dirs), ptr(deltas), ptr(ts),
                  ptr(n_eff), stream())
-            feats = torch.empty(16, M, 2, dtype=torch.float16, device=dev); h = torch.empty(M, 16, dtype=torch.float16, device=dev)
+            feats = torch.empty(16, M, 2, dtype=torch.float16, device=dev)
             sigmas = torch.empty(M, **f32); rgbs = torch.empty(M, 3, **f32)
             call("ngp_hashgrid_fwd", ptr(xyzs), ptr(model.xyz_min), ptr(model.xyz_max), ptr(eh[enc.n_mlp:]), C.byref(enc.meta), M, ptr(feats), stream())
-            call("ngp_field_fwd", ptr(feats), ptr(dirs), ptr(eh), ptr(rh), M, ptr(sigmas), ptr(rgbs), ptr(h), stream())
+            call("ngp_field_fwd", ptr(feats), ptr(dirs), ptr(eh), ptr(rh), M, ptr(sigmas), ptr(rgbs), None, stream())       # inference: h stays in registers
             call("ngp_composite_test_fw", ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(ts), ptr(alive), float(T_threshold), ptr(n_eff), n_alive, N,
                  ptr(opacity), ptr(depth), ptr(rgb), stream())
             alive_new = torch.empty(n_alive, dtype=torch.int64, device=dev)
@@ -225,7 +225,8 @@ class _FusedTrainRender(torch.autograd.Function):
             xyzs = torch.empty(S, 3, **f32); dirs = torch.empty(S, 3, **f32); deltas = torch.empty(S, **f32); ts = torch.empty(S, **f32)
             call("ngp_raymarching_train_write", ptr(rays_o), ptr(rays_d), ptr(rays_a), ptr(scratch), float(model.scale), float(esf),
                  model.grid_size, MAX_SAMPLES, n, ptr(xyzs), ptr(dirs), ptr(deltas), ptr(ts), sq)
-            feats = torch.empty(16, S, 2, **f16); h = torch.empty(S, 16, **f16)
+            feats = torch.empty(16, S, 2, **f16)
+            h = torch.empty(S, 16, **f16) if _lib.field_bwd_uses_h() else None      # (the one-launch backward recomputes it)
             sigmas = torch.empty(S, **f32); rgbs = torch.empty(S, 3, **f32)
             if S > 0:
                 call("ngp_hashgrid_fwd", ptr(xyzs), ptr(model.xyz_min), ptr(model.xyz_max), ptr(eh[enc.n_mlp:]), C.byref(enc.meta), S, ptr(feats), sq)
@@ -279,7 +280,8 @@ class _FusedTrainRender(torch.autograd.Function):
                  ptr(ray_offs), ptr(active), ptr(xyzs) if nbytes else None, ptr(x_act), sq)
             n_part = call("ngp_field_bwd_partials", S)
             partials = torch.empty(n_part * (enc.n_mlp + net.params.numel()), **f32)
-            dh = torch.empty(S, 16, **f16); dfeats = torch.empty(16, S, 2, **f16)
+            dh = torch.empty(S, 16, **f16) if h is not None else None
+            dfeats = torch.empty(16, S, 2, **f16)
             call("ngp_field_bwd", ptr(feats), ptr(dirs), ptr(h), ptr(eh), ptr(rh), ptr(dL_dsigmas), ptr(dL_drgbs), scale, S,
                  ptr(active), ptr(n_active), ptr(dh), ptr(dfeats), ptr(partials), sq)
             g16 = model._grid_grad16(dev)

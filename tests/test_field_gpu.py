@@ -612,3 +612,42 @@ def test_forward_launch_forms_agree_bit_for_bit(lib):
     call("ngp_hashgrid_fwd_list", ptr(x), ptr(mn), ptr(mx), ptr(table), C.byref(meta), S, ptr(lst), lst.numel(), None, ptr(h), stream())
     assert torch.equal(h[:, lst.long()], f[:, lst.long()])
     assert float(f.float().abs().sum()) > 0
+
+
+@pytest.mark.parametrize("n,n_act", [(20011, None), (40000, 17003), (40000, 31), (300, 0)])
+def test_one_launch_field_backward_equals_the_two_launch_chain(lib, field, n, n_act):
+    """ngp_field_bwd (round 6: colour net + density net in ONE launch, h recomputed, dL/dh handed over in registers, h / dh_scratch
+    NULL) against the two mlp_bwd_kernel launches it replaces (test hook ngp_field_bwd_two_launches: colour net -> dh (S,16) in
+    memory -> density net).  dfeats: bit for bit.  Colour-net dW partial rows: bit for bit (same tile -> wave mapping, same
+    accumulation order).  Density-net dW: the tiles are summed by 4 waves per workgroup instead of 8 -> f32 summation order only."""
+    x, d = sample_points(n, seed=41)
+    feats, sig, rgb, h, dw, rw, ds = field_native(lib, field, x, d)
+    g = torch.Generator().manual_seed(42)
+    dsig_d = (torch.randn(n, generator=g) * 1e-3).cuda(); drgb_d = (torch.randn(n, 3, generator=g) * 1e-2).cuda().contiguous()
+    active = n_active = None
+    rows = n
+    if n_act is not None:
+        active = torch.randperm(n, generator=g)[:max(n_act, 1)].sort().values.int().cuda().contiguous()
+        n_active = torch.tensor([n_act], dtype=torch.int32, device="cuda")
+        rows = n_act
+    n_part = lib.call("ngp_field_bwd_partials", n)
+    out = {}
+    for name in ("ngp_field_bwd", "ngp_field_bwd_two_launches"):
+        partials = torch.full((n_part * 10240,), float("nan"), device="cuda")
+        dfeats = torch.zeros(16, n, 2, dtype=torch.float16, device="cuda")
+        two = name.endswith("two_launches")
+        dh = torch.empty(n, 16, dtype=torch.float16, device="cuda") if two else None
+        lib.call(name, lib.ptr(feats), lib.ptr(ds), lib.ptr(h) if two else None, lib.ptr(dw), lib.ptr(rw), lib.ptr(dsig_d), lib.ptr(drgb_d),
+                 128.0, n, lib.ptr(active), lib.ptr(n_active), lib.ptr(dh), lib.ptr(dfeats), lib.ptr(partials), lib.stream())
+        torch.cuda.synchronize()
+        out[name] = (dfeats[:, :rows].cpu(), partials[:n_part * 3072].view(n_part, 3072).cpu(), partials[n_part * 3072:].view(n_part, 7168).cpu())
+    (df1, pd1, pr1), (df2, pd2, pr2) = out["ngp_field_bwd"], out["ngp_field_bwd_two_launches"]
+    assert torch.equal(df1, df2), "dfeats: %d elements differ" % int((df1 != df2).sum())
+    assert torch.isfinite(pd1).all() and torch.isfinite(pr1).all()          # every partial row written, also by workgroups without tiles
+    assert torch.equal(pr1, pr2), "colour-net dW partial rows: %d elements differ" % int((pr1 != pr2).sum())
+    gd1, gd2 = pd1.double().sum(0), pd2.double().sum(0)
+    if rows:
+        assert float((gd1 - gd2).abs().max()) <= 2e-6 * float(gd2.abs().max()) + 1e-30
+        assert float(df1.float().abs().sum()) > 0
+    else:
+        assert not pd1.any() and not pr1.any() and not df1.any()
