@@ -439,6 +439,15 @@ def pmc_traffic(stage, S, A):
     return rec["hbm_bytes_per_launch"], "%s, recorded at %.0f marched / %.0f active samples per step (%s)" % (rel, pS, pA, rec.get("how", "FETCH_SIZE x2 + WRITE_SIZE")), prof
 
 
+def _loss_scale_note(tr):
+    """The dynamic loss scale the native step trains under (GradScaler's rule on the device on top of tiny-cuda-nn's 128, round 6), read
+    after the timed windows: 'x<scale> dynamic, <skipped> steps skipped so far'; 'fixed 128' when the scaler is off."""
+    if getattr(tr, "loss_scaler", None) is None:
+        return "fixed 128"
+    sc, clean = tr.loss_scale_state()
+    return "128 x %g dynamic (GradScaler rule on the device; %d clean steps, %d skipped so far)" % (sc, clean, tr.skipped_steps()[0])
+
+
 def api_path_rate(loop, n_steps=120):
     """The same step driven through the reference-shaped surface: render() -> NeRFLoss -> torch autograd -> FusedAdam
     (Trainer.step_autograd), i.e. what train.py would exercise; the loop hands render() its next batch (`next_rays`), as a
@@ -545,6 +554,7 @@ def full_run(base_loop, args, dev, budget_s, workload="lego", n_poses=FULL_RUN_T
            "log": log, "complete": done == steps}
     if hasattr(tr, "skipped_steps"):        # steps the overflow guard did not apply (non-finite weight gradient: GradScaler's skip)
         out["skipped_steps"] = tr.skipped_steps()[0]
+        out["loss_scale"] = _loss_scale_note(tr)
     progress("full_run: %d steps in %.2f s" % (done, train_s))
     poses = syn.hemisphere_poses(n_poses, seed=999).to(dev)       # held-out: the training set is seed 0
     # the reference's protocol AND chunking first (PSNR and FPS of the line are these); then the regrouped loop as an extra
@@ -1171,7 +1181,8 @@ def main():
         "config": {"workload": loop.description + "; steady state",
                    "rays_per_gpu": loop.rays, "image_res": args.res, "n_images": args.images, "setup_steps_untimed": args.setup_steps,
                    "samples_per_ray_marched": met["rm_s"], "samples_per_ray_composited": met["vr_s"], "train_psnr": met["psnr"],
-                   "parallelism": "dp%d (per-ray data parallel, one native-gradient exchange per step)" % world},
+                   "parallelism": "dp%d (per-ray data parallel, one native-gradient exchange per step)" % world,
+                   "loss_scale": _loss_scale_note(loop.trainer)},
         "value_is": "Trainer.step (native step: direct C-ABI calls, no autograd graph); api_path = the same step through render()+autograd",
         "parity_note": "every PSNR in this line is on a procedural scene (no dataset exists on the box) and every one rests on the hash-grid / MLP / SH "
                        "arithmetic, which is held to OUR fp32 restatement of tiny-cuda-nn only (parity unpinned: tiny-cuda-nn is not in the reference tree); "

@@ -35,7 +35,7 @@ typedef uint16_t ngp_half;    /* IEEE binary16 bits */
 #define NGP_MAX_LEVELS 16
 
 /* ABI version; bumped when a signature, a record layout or the set of entry points changes (5: round 5's removals + `stage` in
- * ngp_exchange_config).  A binding asserts the number it was written against (ngp_pl_amd/_lib.py: ABI_VERSION). */
+ * ngp_exchange_config; 6: round 6, ngp_stepper_backward_update's step_state, the loss scaler's two entry points).  A binding asserts the number it was written against (ngp_pl_amd/_lib.py: ABI_VERSION). */
 int ngp_abi_version(void);
 /* Name of the GPU arch the library was built for ("gfx950"). */
 const char* ngp_build_arch(void);
@@ -714,6 +714,17 @@ int ngp_stepper_render_backward(ngp_stepper* s, const float* g_rgb, const float*
 int ngp_stepper_update(ngp_stepper* s, float lr, int32_t step, float grad_scale, const float* density_partials,
                        const float* rgb_partials, int32_t n_partials, const int32_t* found_inf, int32_t* step_state,
                        ngp_stream_t main_stream);
+/* Dynamic loss scale of the native step = torch.cuda.amp.GradScaler on the device (the reference trains under Lightning's precision=16,
+ * train.py:274: GradScaler's scale on top of tiny-cuda-nn's fixed 128; without it half of the feature gradients of a step flush to
+ * zero in f16 and nearly all others are subnormal -- round 6, profiles/r06_loss_scale.txt).  The field backward multiplies its f32 seeds by
+ * loss_scale x scale, the optimizer launch divides by it (powers of two: exact) and applies GradScaler's rule next to the overflow
+ * guard's flag: scale x backoff_factor after a skipped step, x growth_factor after growth_interval clean ones (defaults of
+ * torch: 65536, 2, 0.5, 2000).  No host sync anywhere.  init_scale <= 0: off (the fixed loss_scale alone, as before).  Synchronises
+ * main_stream once (at configuration). */
+int ngp_stepper_set_loss_scaler(ngp_stepper* s, float init_scale, float growth_factor, float backoff_factor, int32_t growth_interval,
+                                ngp_stream_t main_stream);
+/* The scale the NEXT step will use and its count of clean steps (synchronises main_stream; 0 when the scaler is off). */
+int ngp_stepper_loss_scale(ngp_stepper* s, float* scale, int32_t* growth_tracker, ngp_stream_t main_stream);
 /* Host-side accounting since the last reset: seconds the entry points spent polling for a march's sample count (device-bound
  * wait) and in everything else (argument checks, launches, event records), and the number of front() calls. */
 int ngp_stepper_host_times(ngp_stepper* s, double* wait_s, double* enqueue_s, long long* n_steps, int reset);

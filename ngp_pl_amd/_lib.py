@@ -57,7 +57,7 @@ class GridPartials(C.Structure):
                 ("k_split", C.c_int32 * NGP_MAX_LEVELS), ("part_off", C.c_int64 * NGP_MAX_LEVELS), ("partial", P)]
 
 
-ABI_VERSION = 5              # include/ngp_hip.h: ngp_abi_version()
+ABI_VERSION = 6              # include/ngp_hip.h: ngp_abi_version()
 
 
 class ExchangeConfig(C.Structure):
@@ -110,7 +110,8 @@ _PROTOS = {
     "ngp_density_bwd": [P, P, P, P, F, I, P, P, P, P, P],
     "ngp_field_bwd_partials": [I],
     "ngp_field_bwd": [P, P, P, P, P, P, P, F, I, P, P, P, P, P, P],
-    "ngp_field_bwd_guarded": [P, P, P, P, P, P, P, F, I, P, P, P, P, P, P, I, P],
+    "ngp_field_bwd_guarded": [P, P, P, P, P, P, P, F, P, I, P, P, P, P, P, P, I, P],
+    "ngp_adam_use_loss_scaler": [P, I, F, F, I, F, F],
     "ngp_field_bwd_two_launches": [P, P, P, P, P, P, P, F, I, P, P, P, P, P, P],
     "ngp_field_bwd_uses_h": [],
     "ngp_mlp_fwd": [P, P, I, I, I, I, I, P, P],
@@ -173,6 +174,9 @@ _PROTOS = {
     "ngp_stepper_render_backward": [P, P, P, P, P, F, P, C.POINTER(C.c_int32)],
     "ngp_stepper_update": [P, F, I, F, P, P, I, P, P, P],
     "ngp_stepper_host_times": [P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong), I],
+    "ngp_stepper_before_update": [P, C.POINTER(C.c_void_p)],
+    "ngp_stepper_set_loss_scaler": [P, F, F, F, I, P],
+    "ngp_stepper_loss_scale": [P, C.POINTER(C.c_float), C.POINTER(C.c_int32), P],
     "ngp_stepper_timing": [P, I],
     "ngp_stepper_stage_times": [P, C.POINTER(C.c_float)],
     "ngp_hashgrid_fwd_n": [P, P, P, P, C.POINTER(GridMeta), I, P, P, P],

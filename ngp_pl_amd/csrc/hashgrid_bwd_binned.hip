@@ -415,6 +415,10 @@ __device__ __forceinline__ void apply_segments_dense_runs(long long* lds, uint32
 // fence, and gfx9's single vmcnt makes that fence wait for EVERY outstanding global access of the wave: behind the write-out that is the
 // round trip of its gradient stores, which no thread of the launch reads (round 6: write-out phase 2.8 -> 1.6 us per task,
 // profiles/r06_table_backward.txt).  The "memory" clobber keeps the compiler from moving LDS accesses across it.
+// An entry's sum -> the f16 the gradient table holds, SATURATED: thousands of samples can sum past the f16 range when no single one
+// leaves it (those the field backward's overflow guard watches); +-65504 instead of inf keeps the optimizer's moments finite.
+__device__ __forceinline__ _Float16 sat_f16(float v) { return (_Float16)fminf(fmaxf(v, -65504.0f), 65504.0f); }
+
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // (Applying the hashed levels' Adam update in this kernel's write-out -- three designs, the last with wave specialisation -- was built and
@@ -529,7 +533,7 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
                     const uint32_t k = tid + (q0 + q) * APPLY_THREADS;
                     if (k < len) {
                         const float a0 = (float)acc2[q][0] * inv, a1 = (float)acc2[q][1] * inv;
-                        if (K == 1) { half2_t v; v[0] = (_Float16)a0; v[1] = (_Float16)a1; out[k] = v; }
+                        if (K == 1) { half2_t v; v[0] = sat_f16(a0); v[1] = sat_f16(a1); out[k] = v; }
                         else pout[k] = make_float2(a0, a1);
                     }
                 }
@@ -539,7 +543,7 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
         for (uint32_t k = tid; k < len; k += APPLY_THREADS) {
             const float a0 = (float)lds[2 * k] * inv, a1 = (float)lds[2 * k + 1] * inv;
             lds[2 * k] = 0; lds[2 * k + 1] = 0;                        // ready for the next task
-            if (K == 1) { half2_t v; v[0] = (_Float16)a0; v[1] = (_Float16)a1; out[k] = v; }
+            if (K == 1) { half2_t v; v[0] = sat_f16(a0); v[1] = sat_f16(a1); out[k] = v; }
             else ws.partial[plan.part_off[level] + (size_t)part * size + lo + k] = make_float2(a0, a1);
         }
 #endif
@@ -569,7 +573,7 @@ merge_kernel(GridMeta meta, BinPlan plan, BinWs ws, half2_t* __restrict__ grad_t
                 const float2 v = ws.partial[plan.part_off[l] + (size_t)p * size + e];
                 a += v.x; b += v.y;
             }
-            half2_t o; o[0] = (_Float16)a; o[1] = (_Float16)b;
+            half2_t o; o[0] = sat_f16(a); o[1] = sat_f16(b);
             grad_table[meta.offset[l] + e] = o;
             return;
         }

@@ -1290,7 +1290,7 @@ double render_wait_limit_s() {
 extern "C" {
 #pragma GCC visibility push(default)
 
-int ngp_abi_version(void) { return 5; }
+int ngp_abi_version(void) { return 6; }
 
 int ngp_march_guard_first(float* probe12) {
     NGP_CHECK_PTR(probe12);

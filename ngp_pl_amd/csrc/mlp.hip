@@ -540,6 +540,7 @@ struct MlpBwdIO {
     const float* dL_dsigmas; // OUT_DENSITY: (S) f32 unscaled, may be null
     const float* dL_drgbs;   // OUT_RGB: (S,3) f32 unscaled
     float loss_scale;
+    const float* loss_scale_dev;   // optional device-side factor on loss_scale (the native stepper's dynamic loss scale), read once per launch
     h1* dL_din;              // IN_ROWMAJOR: (S,N_IN); IN_LEVELMAJOR: [16][S] half2; IN_SH_H: dh (S,16); may be null
     float* wgrad_partial;    // (gridDim.x, G_SIZE) f32
     // Optional compaction: only the samples active[0 .. *n_active) are processed.  Network inputs
@@ -816,6 +817,8 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
     const TrAddr ta = tr_addr(lane);
     const int n_eff = io.active ? min(*io.n_active, n_samples) : n_samples;
     const int n_tiles = (n_eff + TILE - 1) / TILE;
+    const float loss_scale = io.loss_scale * (io.loss_scale_dev != nullptr ? *io.loss_scale_dev : 1.0f);
+    float din_max = 0.f;                                      // largest |input gradient| this lane converts to f16 (overflow guard)
 
     f32x16 gW0[2][N_IN / 32 > 0 ? N_IN / 32 : 1];
     f32x16 gW1[2][2];
@@ -898,7 +901,7 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
                             const float sg = sigmoidf(o[0][c]);
-                            dyb[0][c] = (h1)(cur.seed[c] * io.loss_scale * sg * (1.0f - sg));
+                            dyb[0][c] = (h1)(cur.seed[c] * loss_scale * sg * (1.0f - sg));
                         }
                     }
                 } else {
@@ -909,7 +912,7 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
                         if (hh == 0 && io.dL_dsigmas) {
                             // TruncExp backward (custom_functions.py:168-173) on the f16 h[0]
                             const float h0 = (float)(h1)o[0][0];
-                            g[0] += cur.seed[0] * io.loss_scale * __expf(fminf(fmaxf(h0, -15.f), 15.f));
+                            g[0] += cur.seed[0] * loss_scale * __expf(fminf(fmaxf(h0, -15.f), 15.f));
                         }
                     } else if (io.fwd.out_act == 1) {
 #pragma unroll
@@ -974,6 +977,7 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
                     for (int r = 0; r < 16; r += 2) {
                         const int f = (r & 3) + 8 * (r >> 2) + 4 * hh;
                         half2_t v; v[0] = (h1)d[0][r]; v[1] = (h1)d[0][r + 1];
+                        din_max = fmaxf(din_max, fmaxf(fabsf(d[0][r]), fabsf(d[0][r + 1])));
                         __builtin_nontemporal_store(v, df + (size_t)(f >> 1) * n_samples + j);
                     }
                 } else if (IN_MODE == IN_SH_H) {
@@ -1039,7 +1043,9 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
     wgrad_reduce_layer<2, NT0, BWD_WAVES, B::STAGED>(part, HID, N_IN, wave, i, hh, gW0, out, nonfinite);
     if (N_HIDDEN == 2) wgrad_reduce_layer<2, 2, BWD_WAVES, B::STAGED>(part, HID, HID, wave, i, hh, gW1, out + L::G_W1, nonfinite);
     wgrad_reduce_layer<1, 2, BWD_WAVES, B::STAGED>(part, 16, HID, wave, i, hh, gWo, out + L::G_WO, nonfinite);
-    if (io.nonfinite != nullptr && nonfinite != 0.f) atomicOr(io.nonfinite, 1);          // (NaN != 0: taken exactly when a sum was inf / NaN)
+    // (NaN != 0: taken exactly when a sum was inf / NaN) ... or a feature gradient left the f16 range on its way to the table backward
+    // (finite in the f32 accumulator, inf as the half the scatter reads: the dW sums, f32, do not see that one)
+    if (io.nonfinite != nullptr && (nonfinite != 0.f || din_max > 65504.f)) atomicOr(io.nonfinite, 1);
     if (io.nonfinite_clear != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *io.nonfinite_clear = 0;
     MLP_T(5);                                          // epilogue
     MLP_TEND();
@@ -1065,6 +1071,7 @@ struct FieldBwdIO {
     const float* dL_dsigmas;  // (S) f32 unscaled
     const float* dL_drgbs;    // (S,3) f32 unscaled
     float loss_scale;
+    const float* loss_scale_dev;   // optional device-side factor on loss_scale (the dynamic loss scale), read once per launch
     h1* dfeats;               // [16][S] half2, by compact position
     float* wgrad_density;     // (gridDim.x, 3072)
     float* wgrad_rgb;         // (gridDim.x, 7168)
@@ -1153,6 +1160,8 @@ field_bwd_kernel(FieldBwdIO io, const h1* __restrict__ density_w, const h1* __re
     const TrAddr ta = tr_addr(lane);
     const int n_eff = io.active ? min(*io.n_active, n_samples) : n_samples;
     const int n_tiles = (n_eff + TILE - 1) / TILE;
+    const float loss_scale = io.loss_scale * (io.loss_scale_dev != nullptr ? *io.loss_scale_dev : 1.0f);
+    float din_max = 0.f;                                      // largest |feature gradient| this lane converts to f16 (overflow guard)
 
     f32x16 gR0[2][1], gR1[2][2], gRo[1][2], gD0[2][1], gDo[1][2];
 #pragma unroll
@@ -1232,7 +1241,7 @@ field_bwd_kernel(FieldBwdIO io, const h1* __restrict__ density_w, const h1* __re
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float sg = sigmoidf(oc[0][c]);
-                    dyr[0][c] = (h1)(cur.seed_rgb[c] * io.loss_scale * sg * (1.0f - sg));
+                    dyr[0][c] = (h1)(cur.seed_rgb[c] * loss_scale * sg * (1.0f - sg));
                 }
             }
         }
@@ -1288,7 +1297,7 @@ field_bwd_kernel(FieldBwdIO io, const h1* __restrict__ density_w, const h1* __re
                 float g[8];
 #pragma unroll
                 for (int r = 0; r < 8; ++r) g[r] = (float)(h1)dhf[r];
-                if (hh == 0) g[0] += cur.seed_sig * io.loss_scale * __expf(fminf(fmaxf((float)hfrag[0], -15.f), 15.f));
+                if (hh == 0) g[0] += cur.seed_sig * loss_scale * __expf(fminf(fmaxf((float)hfrag[0], -15.f), 15.f));
 #pragma unroll
                 for (int r = 0; r < 8; ++r) dyd[0][r] = (h1)g[r];
             }
@@ -1315,6 +1324,7 @@ field_bwd_kernel(FieldBwdIO io, const h1* __restrict__ density_w, const h1* __re
                 for (int r = 0; r < 16; r += 2) {
                     const int f = (r & 3) + 8 * (r >> 2) + 4 * hh;
                     half2_t v; v[0] = (h1)d[r]; v[1] = (h1)d[r + 1];
+                    din_max = fmaxf(din_max, fmaxf(fabsf(d[r]), fabsf(d[r + 1])));
                     __builtin_nontemporal_store(v, df + (size_t)(f >> 1) * n_samples + j);
                 }
             }
@@ -1344,7 +1354,7 @@ field_bwd_kernel(FieldBwdIO io, const h1* __restrict__ density_w, const h1* __re
     wgrad_reduce_layer<1, 2, FW, false>(part, 16, HID, wave, i, hh, gRo, outr + LR::G_WO, nonfinite);
     wgrad_reduce_layer<2, 1, FW, false>(part, HID, 32, wave, i, hh, gD0, outd, nonfinite);
     wgrad_reduce_layer<1, 2, FW, false>(part, 16, HID, wave, i, hh, gDo, outd + LD::G_WO, nonfinite);
-    if (io.nonfinite != nullptr && nonfinite != 0.f) atomicOr(io.nonfinite, 1);
+    if (io.nonfinite != nullptr && (nonfinite != 0.f || din_max > 65504.f)) atomicOr(io.nonfinite, 1);      // (as mlp_bwd_kernel)
     if (io.nonfinite_clear != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *io.nonfinite_clear = 0;
     MLP_T(5);
     MLP_TEND();
@@ -1511,7 +1521,7 @@ int ngp_debug_mlp_timing(unsigned long long* host_out, int reset) {
 int ngp_field_bwd_partials(int n_samples) { return n_samples <= 0 ? 0 : bwd_grid(n_samples); }
 
 // (the colour net's half of ngp_field_bwd: internal)
-static int ngp_rgb_bwd(const ngp_half* h, const float* dirs, const ngp_half* rgb_w, const float* dL_drgbs, float loss_scale,
+static int ngp_rgb_bwd(const ngp_half* h, const float* dirs, const ngp_half* rgb_w, const float* dL_drgbs, float loss_scale, const float* loss_scale_dev,
                 int n_samples, const int32_t* active_idx, const int32_t* n_active, ngp_half* dL_dh, float* wgrad_partial,
                 int32_t* nonfinite, int32_t* nonfinite_clear, ngp_stream_t stream) {
     if (n_samples < 0) return NGP_EINVAL;
@@ -1519,7 +1529,7 @@ static int ngp_rgb_bwd(const ngp_half* h, const float* dirs, const ngp_half* rgb
     NGP_CHECK_PTR(h); NGP_CHECK_PTR(dirs); NGP_CHECK_PTR(rgb_w); NGP_CHECK_PTR(dL_drgbs); NGP_CHECK_PTR(dL_dh); NGP_CHECK_PTR(wgrad_partial);
     MlpBwdIO r = {};
     r.fwd.in = (const h1*)h; r.fwd.dirs = dirs; r.fwd.n_out = 3;
-    r.dL_drgbs = dL_drgbs; r.loss_scale = loss_scale; r.dL_din = (h1*)dL_dh; r.wgrad_partial = wgrad_partial;
+    r.dL_drgbs = dL_drgbs; r.loss_scale = loss_scale; r.loss_scale_dev = loss_scale_dev; r.dL_din = (h1*)dL_dh; r.wgrad_partial = wgrad_partial;
     if ((active_idx == nullptr) != (n_active == nullptr)) return NGP_EINVAL;
     r.active = active_idx; r.n_active = n_active;
     r.nonfinite = nonfinite; r.nonfinite_clear = nonfinite_clear;
@@ -1527,7 +1537,7 @@ static int ngp_rgb_bwd(const ngp_half* h, const float* dirs, const ngp_half* rgb
 }
 
 static int density_bwd_guarded(const ngp_half* feats, const ngp_half* density_w, const ngp_half* dL_dh, const float* dL_dsigmas,
-                               float loss_scale, int n_samples, const int32_t* active_idx, const int32_t* n_active,
+                               float loss_scale, const float* loss_scale_dev, int n_samples, const int32_t* active_idx, const int32_t* n_active,
                                ngp_half* dfeats, float* wgrad_partial, int32_t* nonfinite, ngp_stream_t stream) {
     if (n_samples < 0) return NGP_EINVAL;
     if (n_samples == 0) return 0;
@@ -1535,7 +1545,7 @@ static int density_bwd_guarded(const ngp_half* feats, const ngp_half* density_w,
     MlpBwdIO d = {};
     d.fwd.in = (const h1*)feats; d.fwd.n_out = 16; d.fwd.out_ld = 16;
     d.dL_dout16 = (const h1*)dL_dh; d.dout_ld = 16;
-    d.dL_dsigmas = dL_dsigmas; d.loss_scale = loss_scale; d.dL_din = (h1*)dfeats; d.wgrad_partial = wgrad_partial;
+    d.dL_dsigmas = dL_dsigmas; d.loss_scale = loss_scale; d.loss_scale_dev = loss_scale_dev; d.dL_din = (h1*)dfeats; d.wgrad_partial = wgrad_partial;
     if ((active_idx == nullptr) != (n_active == nullptr)) return NGP_EINVAL;
     d.active = active_idx; d.n_active = n_active;
     d.nonfinite = nonfinite;
@@ -1545,34 +1555,34 @@ static int density_bwd_guarded(const ngp_half* feats, const ngp_half* density_w,
 int ngp_density_bwd(const ngp_half* feats, const ngp_half* density_w, const ngp_half* dL_dh, const float* dL_dsigmas,
                     float loss_scale, int n_samples, const int32_t* active_idx, const int32_t* n_active,
                     ngp_half* dfeats, float* wgrad_partial, ngp_stream_t stream) {
-    return density_bwd_guarded(feats, density_w, dL_dh, dL_dsigmas, loss_scale, n_samples, active_idx, n_active, dfeats, wgrad_partial, nullptr, stream);
+    return density_bwd_guarded(feats, density_w, dL_dh, dL_dsigmas, loss_scale, nullptr, n_samples, active_idx, n_active, dfeats, wgrad_partial, nullptr, stream);
 }
 
 int ngp_field_bwd(const ngp_half* feats, const float* dirs, const ngp_half* h, const ngp_half* density_w,
                   const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale,
                   int n_samples, const int32_t* active_idx, const int32_t* n_active,
                   ngp_half* dh_scratch, ngp_half* dfeats, float* wgrad_partial, ngp_stream_t stream) {
-    return ngp_field_bwd_guarded(feats, dirs, h, density_w, rgb_w, dL_dsigmas, dL_drgbs, loss_scale, n_samples, active_idx, n_active, dh_scratch, dfeats,
+    return ngp_field_bwd_guarded(feats, dirs, h, density_w, rgb_w, dL_dsigmas, dL_drgbs, loss_scale, nullptr, n_samples, active_idx, n_active, dh_scratch, dfeats,
                                  wgrad_partial, nullptr, 0, stream);
 }
 
 // The two-launch form: colour net (writes dL/dh to dh_scratch) then density net (reads it).  nonfinite2 / parity as below.
 static int field_bwd_two_launches(const ngp_half* feats, const float* dirs, const ngp_half* h, const ngp_half* density_w,
-                                  const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale,
+                                  const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale, const float* loss_scale_dev,
                                   int n_samples, const int32_t* active_idx, const int32_t* n_active,
                                   ngp_half* dh_scratch, ngp_half* dfeats, float* wgrad_partial, int32_t* nonfinite2, int parity, ngp_stream_t stream) {
     const int n_part = bwd_grid(n_samples);
     int32_t* flag = nonfinite2 ? nonfinite2 + (parity & 1) : nullptr;
-    const int rc = ngp_rgb_bwd(h, dirs, rgb_w, dL_drgbs, loss_scale, n_samples, active_idx, n_active, dh_scratch,
+    const int rc = ngp_rgb_bwd(h, dirs, rgb_w, dL_drgbs, loss_scale, loss_scale_dev, n_samples, active_idx, n_active, dh_scratch,
                                wgrad_partial + (size_t)n_part * NGP_DENSITY_NET_PARAMS, flag, nonfinite2 ? nonfinite2 + ((parity & 1) ^ 1) : nullptr, stream);
     if (rc) return rc;
-    return density_bwd_guarded(feats, density_w, dh_scratch, dL_dsigmas, loss_scale, n_samples, active_idx, n_active, dfeats,
+    return density_bwd_guarded(feats, density_w, dh_scratch, dL_dsigmas, loss_scale, loss_scale_dev, n_samples, active_idx, n_active, dfeats,
                                wgrad_partial, flag, stream);
 }
 
 // The one-launch form (field_bwd_kernel): h and dL/dh never touch memory.
 static int field_bwd_one_launch(const ngp_half* feats, const float* dirs, const ngp_half* density_w,
-                                const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale,
+                                const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale, const float* loss_scale_dev,
                                 int n_samples, const int32_t* active_idx, const int32_t* n_active,
                                 ngp_half* dfeats, float* wgrad_partial, int32_t* nonfinite2, int parity, ngp_stream_t stream) {
     NGP_CHECK_PTR(feats); NGP_CHECK_PTR(dirs); NGP_CHECK_PTR(density_w); NGP_CHECK_PTR(rgb_w); NGP_CHECK_PTR(dL_dsigmas);
@@ -1581,7 +1591,7 @@ static int field_bwd_one_launch(const ngp_half* feats, const float* dirs, const 
     if (reinterpret_cast<uintptr_t>(wgrad_partial) & 15) return NGP_EINVAL;     // partial rows are stored 16 bytes at a time
     const int n_part = bwd_grid(n_samples);
     FieldBwdIO io = {};
-    io.feats = (const h1*)feats; io.dirs = dirs; io.dL_dsigmas = dL_dsigmas; io.dL_drgbs = dL_drgbs; io.loss_scale = loss_scale;
+    io.feats = (const h1*)feats; io.dirs = dirs; io.dL_dsigmas = dL_dsigmas; io.dL_drgbs = dL_drgbs; io.loss_scale = loss_scale; io.loss_scale_dev = loss_scale_dev;
     io.dfeats = (h1*)dfeats; io.wgrad_density = wgrad_partial; io.wgrad_rgb = wgrad_partial + (size_t)n_part * NGP_DENSITY_NET_PARAMS;
     io.active = active_idx; io.n_active = n_active;
     io.nonfinite = nonfinite2 ? nonfinite2 + (parity & 1) : nullptr;
@@ -1595,18 +1605,20 @@ static int field_bwd_one_launch(const ngp_half* feats, const float* dirs, const 
 }
 
 // (csrc/ngp_internal.h) the same with the native stepper's overflow guard: nonfinite2 = two device flags; this call ORs 1 into
-// nonfinite2[parity] when a weight-gradient sum of either network is inf / NaN and clears nonfinite2[parity ^ 1] (the next step's).
+// nonfinite2[parity] when a weight-gradient sum of either network is inf / NaN -- or a feature gradient leaves the f16 range -- and
+// clears nonfinite2[parity ^ 1] (the next step's).  loss_scale_dev (may be NULL): a device-side factor on loss_scale, read by the
+// launch (the stepper's dynamic loss scale: GradScaler's scale on top of tiny-cuda-nn's 128).
 int ngp_field_bwd_guarded(const ngp_half* feats, const float* dirs, const ngp_half* h, const ngp_half* density_w,
-                          const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale,
+                          const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale, const float* loss_scale_dev,
                           int n_samples, const int32_t* active_idx, const int32_t* n_active,
                           ngp_half* dh_scratch, ngp_half* dfeats, float* wgrad_partial, int32_t* nonfinite2, int parity, ngp_stream_t stream) {
     if (n_samples < 0) return NGP_EINVAL;
     if (n_samples == 0) return 0;
     NGP_CHECK_PTR(wgrad_partial);
     if (NGP_FIELD_BWD_FUSED)
-        return field_bwd_one_launch(feats, dirs, density_w, rgb_w, dL_dsigmas, dL_drgbs, loss_scale, n_samples, active_idx, n_active, dfeats,
+        return field_bwd_one_launch(feats, dirs, density_w, rgb_w, dL_dsigmas, dL_drgbs, loss_scale, loss_scale_dev, n_samples, active_idx, n_active, dfeats,
                                     wgrad_partial, nonfinite2, parity, stream);
-    return field_bwd_two_launches(feats, dirs, h, density_w, rgb_w, dL_dsigmas, dL_drgbs, loss_scale, n_samples, active_idx, n_active, dh_scratch,
+    return field_bwd_two_launches(feats, dirs, h, density_w, rgb_w, dL_dsigmas, dL_drgbs, loss_scale, loss_scale_dev, n_samples, active_idx, n_active, dh_scratch,
                                   dfeats, wgrad_partial, nonfinite2, parity, stream);
 }
 
@@ -1623,7 +1635,7 @@ int ngp_field_bwd_two_launches(const ngp_half* feats, const float* dirs, const n
     if (n_samples < 0) return NGP_EINVAL;
     if (n_samples == 0) return 0;
     NGP_CHECK_PTR(wgrad_partial); NGP_CHECK_PTR(h); NGP_CHECK_PTR(dh_scratch);
-    return field_bwd_two_launches(feats, dirs, h, density_w, rgb_w, dL_dsigmas, dL_drgbs, loss_scale, n_samples, active_idx, n_active, dh_scratch,
+    return field_bwd_two_launches(feats, dirs, h, density_w, rgb_w, dL_dsigmas, dL_drgbs, loss_scale, nullptr, n_samples, active_idx, n_active, dh_scratch,
                                   dfeats, wgrad_partial, nullptr, 0, stream);
 }
 

@@ -31,12 +31,25 @@ typedef struct ngp_grid_partials {
  * precision=16, train.py:274: a step whose gradients hold an inf / NaN is skipped).  nonfinite2 = two i32 flags on the device (NULL:
  * no guard); this call ORs 1 into nonfinite2[parity & 1] when a weight-gradient sum of either network is not finite -- an f16
  * overflow anywhere in the forward recompute or the backward chain ends there -- and clears nonfinite2[(parity & 1) ^ 1], the flag of
- * the next step: the optimizer launch of THIS step reads nonfinite2[parity & 1] as its found_inf. */
+ * the next step: the optimizer launch of THIS step reads nonfinite2[parity & 1] as its found_inf.  A feature gradient that leaves the
+ * f16 range raises the flag as well (finite in the f32 accumulator, inf in the half the table backward reads).  loss_scale_dev (may be
+ * NULL): a factor on loss_scale read from device memory by the launch -- the stepper's dynamic loss scale. */
 int ngp_field_bwd_guarded(const ngp_half* feats, const float* dirs, const ngp_half* h, const ngp_half* density_w,
                           const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale,
-                          int n_samples, const int32_t* active_idx, const int32_t* n_active,
+                          const float* loss_scale_dev, int n_samples, const int32_t* active_idx, const int32_t* n_active,
                           ngp_half* dh_scratch, ngp_half* dfeats, float* wgrad_partial, int32_t* nonfinite2, int parity,
                           ngp_stream_t stream);
+/* Dynamic loss scale of the native step (round 6; GradScaler's rule on the device, see ngp_stepper_set_loss_scaler): hands the NEXT
+ * optimizer launch this thread enqueues through an ngp_adam_step_field* entry point the scaler's device state = {f32 scale[2], i32
+ * growth_tracker[2]} and the half (slot 0 / 1) this step's launches read; the launch divides the gradients by scale[slot] on top
+ * of grad_scale and writes the next step's scale and tracker into slot ^ 1.  state == NULL: withdraws a pending hand-over. */
+int ngp_adam_use_loss_scaler(float* state, int slot, float growth_factor, float backoff_factor, int growth_interval,
+                             float min_scale, float max_scale);
+/* Before an optimizer launch the caller enqueues itself on gradients a stepper's backward left behind (FusedAdam behind render()):
+ * hands the stepper's dynamic loss scale to that launch (ngp_adam_use_loss_scaler) and returns this step's overflow flag in
+ * *found_inf (device i32; NULL when no guarded field backward ran since the last update). */
+struct ngp_stepper;
+int ngp_stepper_before_update(struct ngp_stepper* s, int32_t** found_inf);
 /* 1 when ngp_field_bwd reads h / writes dh_scratch (the two-launch A/B build), 0 when both may be NULL (the one-launch kernel, round 6:
  * h is recomputed from the features and dL/dh handed from the colour net to the density net in registers). */
 int ngp_field_bwd_uses_h(void);

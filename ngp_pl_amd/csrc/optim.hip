@@ -17,9 +17,17 @@ typedef _Float16 h1;
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// Dynamic loss scale on the device (torch.cuda.amp.GradScaler's rule, which Lightning's precision=16 puts on top of tiny-cuda-nn's
+// fixed 128 in the reference, train.py:274): state = {f32 scale[2], i32 growth_tracker[2]}.  The launches of a step read slot
+// `slot` (the field backward multiplies its seeds by scale[slot], this kernel divides the gradients by it -- powers of two: exact);
+// the first MLP workgroup writes slot ^ 1: scale * backoff and tracker 0 when the step's flag is raised, else tracker + 1, and
+// scale * growth every `interval` clean steps.  Readers and the writer never share a word inside a launch.
+struct LossScaler { float* state; int slot; float growth, backoff; int interval; float lo, hi; };
+
 struct AdamHyper { float lr, beta1, beta2, eps, wd, bc1, bc2, inv_scale; const int32_t* found_inf; int zero_grad;
                    const int32_t* found_inf_dense;        // skip flag of the dense (grid) block: found_inf unless a caller gives it its own
-                   int32_t* step_state; int slot; };      // device-side counts of APPLIED steps (below), or NULL: bc1 / bc2 as given
+                   int32_t* step_state; int slot;         // device-side counts of APPLIED steps (below), or NULL: bc1 / bc2 as given
+                   LossScaler scaler; };                  // state == NULL: none
 
 // Bias correction under a skip flag.  apex / GradScaler leave the optimizer's step count unchanged when a step is skipped; the host
 // cannot know whether the device-side flag was raised without a sync, so the count of APPLIED steps lives next to the flag:
@@ -28,6 +36,20 @@ struct AdamHyper { float lr, beta1, beta2, eps, wd, bc1, bc2, inv_scale; const i
 // first workgroup of each kind writes slot c & 1 = applied + (skipped ? 0 : 1): readers and the writer never share an address
 // inside a launch, launches are ordered by the stream.
 __device__ __forceinline__ void adam_bias_from_state(AdamHyper& h, bool dense, bool writer) {
+    if (h.scaler.state != nullptr) {
+        const LossScaler& q = h.scaler;
+        const float sc = q.state[q.slot];
+        h.inv_scale = h.inv_scale / sc;
+        if (writer && !dense && threadIdx.x == 0) {       // decided by the MLP blocks' flag (under a data-parallel exchange: the one every rank agrees on)
+            int32_t* tr = reinterpret_cast<int32_t*>(q.state + 2);
+            const bool skip = h.found_inf != nullptr && *h.found_inf != 0;
+            float next = sc;
+            int32_t t = tr[q.slot];
+            if (skip) { next = fmaxf(sc * q.backoff, q.lo); t = 0; }
+            else if (++t >= q.interval) { next = fminf(sc * q.growth, q.hi); t = 0; }
+            q.state[q.slot ^ 1] = next; tr[q.slot ^ 1] = t;
+        }
+    }
     if (h.step_state == nullptr) return;
     int32_t* st = h.step_state + (dense ? 2 : 0);
     const int32_t applied = st[h.slot];
@@ -37,6 +59,10 @@ __device__ __forceinline__ void adam_bias_from_state(AdamHyper& h, bool dense, b
     h.bc1 = 1.0f - powf(h.beta1, t); h.bc2 = 1.0f - powf(h.beta2, t);
     if (writer && threadIdx.x == 0) st[h.slot ^ 1] = skip ? applied : applied + 1;
 }
+
+// f32 sum -> the f16 the gradient table holds, SATURATED: a sum over thousands of samples can leave the f16 range when no single
+// sample does (the overflow guard watches the samples); +-65504 instead of inf keeps Adam's moments finite.
+__device__ __forceinline__ h1 sat_f16(float v) { return (h1)fminf(fmaxf(v, -65504.0f), 65504.0f); }
 
 // The coarse dense levels of the grid, whose gradient the binned table backward leaves as K partial f32 tables per level
 // (ngp_grid_partials, include/ngp_hip.h): device-side copy of the record.
@@ -69,7 +95,7 @@ __device__ __forceinline__ void adam_dense(float* __restrict__ param, h1* __rest
                     const float4 t = *reinterpret_cast<const float4*>(p + (size_t)k * size);
                     a0 += t.x; b0 += t.y; a1 += t.z; b1 += t.w;
                 }
-                g[0] = (float)(h1)a0; g[1] = (float)(h1)b0; g[2] = (float)(h1)a1; g[3] = (float)(h1)b1;
+                g[0] = (float)sat_f16(a0); g[1] = (float)sat_f16(b0); g[2] = (float)sat_f16(a1); g[3] = (float)sat_f16(b1);     // (as merge_kernel)
             } else if (GRAD_F32) {
                 float4* gp4 = reinterpret_cast<float4*>(reinterpret_cast<float*>(grad) + base);
                 const float4 t = *gp4; g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w;
@@ -485,8 +511,13 @@ reduce_partials2_kernel(const float* __restrict__ pa, int n_a, const float* __re
     }
 }
 
+// (csrc/ngp_internal.h: ngp_adam_use_loss_scaler) the scaler of the NEXT optimizer launch this thread enqueues; consumed by it
+thread_local LossScaler t_next_scaler = {nullptr, 0, 2.0f, 0.5f, 2000, 1.0f, 1.0f};
+
 AdamHyper adam_hyper(float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale, const int32_t* found_inf) {
     AdamHyper hp;
+    hp.scaler = t_next_scaler;
+    t_next_scaler.state = nullptr;
     hp.lr = lr; hp.beta1 = beta1; hp.beta2 = beta2; hp.eps = eps; hp.wd = wd;
     hp.bc1 = 1.0f - powf(beta1, (float)step); hp.bc2 = 1.0f - powf(beta2, (float)step);
     hp.inv_scale = 1.0f / grad_scale; hp.found_inf = found_inf; hp.found_inf_dense = found_inf; hp.zero_grad = 1;
@@ -518,6 +549,16 @@ sum_slices_kernel(const uint4* __restrict__ own, const uint4* __restrict__ stage
 
 extern "C" {
 #pragma GCC visibility push(default)
+
+// (csrc/ngp_internal.h) Hands the NEXT optimizer launch enqueued by this thread (any ngp_adam_step_field* entry point) a device-side
+// dynamic loss scale: state = {f32 scale[2], i32 growth_tracker[2]} on the device, slot = the half this step's launches read.
+int ngp_adam_use_loss_scaler(float* state, int slot, float growth_factor, float backoff_factor, int growth_interval, float min_scale, float max_scale) {
+    if (state == nullptr) { t_next_scaler.state = nullptr; return 0; }
+    if ((slot & ~1) || !(growth_factor >= 1.0f) || !(backoff_factor > 0.0f && backoff_factor <= 1.0f) || growth_interval < 1 || !(min_scale > 0.f) || !(max_scale >= min_scale))
+        return NGP_EINVAL;
+    t_next_scaler = {state, slot, growth_factor, backoff_factor, growth_interval, min_scale, max_scale};
+    return 0;
+}
 
 int ngp_adam_step(float* param, ngp_half* param_h, void* grad, int grad_is_f32, float* m, float* v, int64_t n,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,

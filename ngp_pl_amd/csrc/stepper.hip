@@ -79,6 +79,13 @@ struct ngp_stepper {
     int guard_parity = 0;
     bool guard_armed = false;              // this step's field backward ran with the guard (consumed by the update)
     bool fused[2] = {false, false};        // record set k was marched by ngp_march_train_fused (count word published by its expansion launch's last workgroup)
+    // dynamic loss scale (ngp_stepper_set_loss_scaler): device state {f32 scale[2], i32 growth_tracker[2]}; the step's launches read
+    // half scaler_slot, its optimizer launch writes the other half and the host flips scaler_slot behind it
+    float* scaler_state = nullptr;
+    bool scaler_on = false;
+    int scaler_slot = 0;
+    float scaler_growth = 2.0f, scaler_backoff = 0.5f, scaler_lo = 9.5367431640625e-07f /* 2^-20 */, scaler_hi = 1.152921504606847e18f /* 2^60: GradScaler has no cap; f32 seeds x 128 x 2^60 stay finite */;
+    int scaler_interval = 2000;
 };
 
 void destroy_exchange_events(ngp_stepper* s);
@@ -273,6 +280,7 @@ int ngp_stepper_create(const ngp_stepper_config* config, const ngp_step_buffers*
     for (int i = 0; i < N_MARKS && e == hipSuccess; ++i) e = hipEventCreate(&s->mark[i]);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->guard), 2 * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemset(s->guard, 0, 2 * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->scaler_state), 4 * sizeof(float));
     if (e != hipSuccess) { ngp_stepper_destroy(s); return (int)e; }
     *out = s;
     return 0;
@@ -289,6 +297,7 @@ int ngp_stepper_destroy(ngp_stepper* s) {
     for (int i = 0; i < N_MARKS; ++i) if (s->mark[i]) (void)hipEventDestroy(s->mark[i]);
     for (int k = 0; k < 2; ++k) if (s->counts[k]) (void)hipFree(s->counts[k]);
     if (s->guard) (void)hipFree(s->guard);
+    if (s->scaler_state) (void)hipFree(s->scaler_state);
     destroy_exchange_events(s);
     delete s;
     return 0;
@@ -479,7 +488,8 @@ static int backward_field(ngp_stepper* s, const float* dL_dopacity, const float*
     const int n_part = ngp_field_bwd_partials(S);
     if (n_part < 1 || n_part > b.max_partials) return NGP_EINVAL;
     s->guard_parity ^= 1;
-    STEP_TRY(ngp_field_bwd_guarded(b.feats, b.dirs, b.h, c.enc_half, c.rgb_half, b.dL_dsigmas, b.dL_drgbs, loss_scale, S, b.active, b.n_active,
+    STEP_TRY(ngp_field_bwd_guarded(b.feats, b.dirs, b.h, c.enc_half, c.rgb_half, b.dL_dsigmas, b.dL_drgbs, loss_scale,
+                                   s->scaler_on ? s->scaler_state + s->scaler_slot : nullptr, S, b.active, b.n_active,
                                    b.dh, b.dfeats, b.partials, s->guard, s->guard_parity, main_stream));
     s->guard_armed = true;
     mark(s, 6, main);
@@ -600,6 +610,24 @@ int ngp_stepper_table_backward(ngp_stepper* s, int n_groups, int group, ngp_stre
     return 0;
 }
 
+// The optimizer launch enqueued next divides by this step's dynamic loss scale and writes the next step's (optim.hip: LossScaler).
+static int hand_over_scaler(ngp_stepper* s) {
+    if (!s->scaler_on) return 0;
+    STEP_TRY(ngp_adam_use_loss_scaler(s->scaler_state, s->scaler_slot, s->scaler_growth, s->scaler_backoff, s->scaler_interval, s->scaler_lo, s->scaler_hi));
+    s->scaler_slot ^= 1;                 // the next step's field backward reads what this launch writes
+    return 0;
+}
+
+// (csrc/ngp_internal.h) For an optimizer launch the CALLER enqueues (ngp_pl_amd.optim.FusedAdam behind render()'s native backward:
+// ngp_adam_step_field on the gradients this stepper left in its buffers): hands that launch the dynamic loss scale, and returns
+// the overflow flag this step's field backward may have raised (NULL: no guarded backward since the last update).
+int ngp_stepper_before_update(ngp_stepper* s, int32_t** found_inf) {
+    if (!s || !found_inf) return NGP_EINVAL;
+    *found_inf = s->guard_armed ? s->guard + s->guard_parity : nullptr;
+    s->guard_armed = false;
+    return hand_over_scaler(s);
+}
+
 int ngp_stepper_update(ngp_stepper* s, float lr, int32_t step, float grad_scale, const float* density_partials,
                        const float* rgb_partials, int32_t n_partials, const int32_t* found_inf, int32_t* step_state, ngp_stream_t main_stream) {
     if (!s || step < 1 || (density_partials == nullptr) != (rgb_partials == nullptr)) return NGP_EINVAL;
@@ -616,6 +644,7 @@ int ngp_stepper_update(ngp_stepper* s, float lr, int32_t step, float grad_scale,
     if (n_partials < 1) return NGP_EINVAL;
     if (found_inf == nullptr && s->guard_armed && density_partials == b.partials) found_inf = s->guard + s->guard_parity;    // this step's own field backward
     s->guard_armed = false;
+    STEP_TRY(hand_over_scaler(s));
     STEP_TRY(ngp_adam_step_field(c.enc_param + c.n_density, c.enc_half + c.n_density, c.grid_grad16, c.enc_m + c.n_density, c.enc_v + c.n_density, c.n_grid,
                                  c.enc_param, c.enc_half, density_partials, c.enc_m, c.enc_v, c.n_density,
                                  c.rgb_param, c.rgb_half, rgb_partials, c.rgb_m, c.rgb_v, c.n_rgb,
@@ -644,6 +673,7 @@ int ngp_stepper_backward_update(ngp_stepper* s, float lr, int32_t step, float gr
     }
     mark(s, 7, ngp_stream(main_stream));
     STEP_TRY(march_next_if_at(s, AT_HASHGRID_BWD));
+    STEP_TRY(hand_over_scaler(s));
     STEP_TRY(ngp_adam_step_field_merge(c.enc_param + c.n_density, c.enc_half + c.n_density, c.grid_grad16, c.enc_m + c.n_density, c.enc_v + c.n_density, n_streamed,
                                        c.enc_param, c.enc_half, b.partials, c.enc_m, c.enc_v, c.n_density,
                                        c.rgb_param, c.rgb_half, b.partials + (size_t)s->n_part * c.n_density, c.rgb_m, c.rgb_v, c.n_rgb,
@@ -767,6 +797,7 @@ int ngp_stepper_tail(ngp_stepper* s, float lr, int32_t step, float grad_scale, n
     if (x.mode >= 1) {
         STEP_TRY(ngp_found_inf2(x.small, 1, n_small, nullptr, 0, 0, mlp_cur, mlp_nxt, cst));
         STEP_TRY(ngp_found_inf2(x.shard16, 0, (int64_t)x.n_chunks * x.piece, nullptr, 0, 0, grid_cur, grid_nxt, cst));
+        STEP_TRY(hand_over_scaler(s));
         STEP_TRY(ngp_adam_step_field_pieces(c.enc_param + c.n_density, c.enc_half + c.n_density, x.shard16, c.enc_m + c.n_density, c.enc_v + c.n_density,
                                             c.n_grid, x.piece, x.n_chunks, comm->world, comm->rank,
                                             c.enc_param, c.enc_half, x.small, c.enc_m, c.enc_v, c.n_density,
@@ -788,6 +819,7 @@ int ngp_stepper_tail(ngp_stepper* s, float lr, int32_t step, float grad_scale, n
     } else {
         // one flag for everything (all ranks hold the same sums): GradScaler's whole-step decision
         STEP_TRY(ngp_found_inf2(x.grad_padded, 0, padded, x.small, 1, n_small, mlp_cur, mlp_nxt, cst));
+        STEP_TRY(hand_over_scaler(s));
         STEP_TRY(ngp_adam_step_field(c.enc_param + c.n_density, c.enc_half + c.n_density, c.grid_grad16, c.enc_m + c.n_density, c.enc_v + c.n_density, c.n_grid,
                                      c.enc_param, c.enc_half, x.small, c.enc_m, c.enc_v, c.n_density,
                                      c.rgb_param, c.rgb_half, x.small + c.n_density, c.rgb_m, c.rgb_v, c.n_rgb,
@@ -817,6 +849,36 @@ int ngp_stepper_host_times(ngp_stepper* s, double* wait_s, double* enqueue_s, lo
     if (!s || !wait_s || !enqueue_s || !n_steps) return NGP_EINVAL;
     *wait_s = s->t_wait; *enqueue_s = s->t_enqueue; *n_steps = s->n_fronts;
     if (reset) { s->t_wait = s->t_enqueue = 0.0; s->n_fronts = 0; }
+    return 0;
+}
+
+int ngp_stepper_set_loss_scaler(ngp_stepper* s, float init_scale, float growth_factor, float backoff_factor, int32_t growth_interval,
+                                ngp_stream_t main_stream) {
+    if (!s) return NGP_EINVAL;
+    if (!(init_scale > 0.f)) { s->scaler_on = false; return 0; }
+    if (!(growth_factor >= 1.0f) || !(backoff_factor > 0.f && backoff_factor <= 1.0f) || growth_interval < 1) return NGP_EINVAL;
+    const struct { float scale[2]; int32_t tracker[2]; } init = {{init_scale, init_scale}, {0, 0}};
+    hipStream_t st = ngp_stream(main_stream);
+    STEP_HIP(hipMemcpyAsync(s->scaler_state, &init, sizeof(init), hipMemcpyHostToDevice, st));
+    STEP_HIP(hipStreamSynchronize(st));                  // (`init` lives on this frame)
+    s->scaler_growth = growth_factor; s->scaler_backoff = backoff_factor; s->scaler_interval = growth_interval;
+    s->scaler_slot = 0;
+    s->scaler_on = true;
+    return 0;
+}
+
+int ngp_stepper_loss_scale(ngp_stepper* s, float* scale, int32_t* growth_tracker, ngp_stream_t main_stream) {
+    if (!s || !scale) return NGP_EINVAL;
+    *scale = 0.f;
+    if (growth_tracker) *growth_tracker = 0;
+    if (!s->scaler_on) return 0;
+    struct { float scale[2]; int32_t tracker[2]; } st;
+    hipStream_t q = ngp_stream(main_stream);
+    STEP_HIP(hipStreamSynchronize(q));
+    if (s->comm) STEP_HIP(hipStreamSynchronize(s->comm->stream));          // (the exchange's optimizer launch runs on the communicator's stream)
+    STEP_HIP(hipMemcpy(&st, s->scaler_state, sizeof(st), hipMemcpyDeviceToHost));
+    *scale = st.scale[s->scaler_slot];
+    if (growth_tracker) *growth_tracker = st.tracker[s->scaler_slot];
     return 0;
 }
 

@@ -119,6 +119,9 @@ class NGP(nn.Module):
         # fused-path switches
         self.fused = True            # one autograd node for the whole field (False: module by module, as the reference)
         self.native_grads = False    # leave gradients in native f16/partial buffers for optim.FusedAdam
+        # render()'s native training node (native_grads) runs its f16 backward under a dynamic loss scale = GradScaler's rule on the
+        # device, on top of tiny-cuda-nn's 128 (what Lightning's precision=16 gives the reference, train.py:274; None: the fixed 128 alone)
+        self.native_loss_scaler = dict(init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000)
         self.sync_free_sampling = True   # occupancy-cell sampling without the reference's nonzero() host sync
         self._native = None
         self._g16 = None

@@ -268,6 +268,15 @@ class FusedAdam(torch.optim.Optimizer):
         b1, b2 = group["betas"]
         total_scale = nat["scale"] * grad_scale
         sq = stream_handle if stream_handle is not None else stream()
+        h = nat.get("stepper")
+        if h is not None:
+            # gradients left by render()'s native node: its stepper hands this launch the dynamic loss scale its field backward ran
+            # under and names the overflow flag that backward may have raised (the skip decision, GradScaler's, on the device)
+            import ctypes as C
+            fi = C.c_void_p()
+            call("ngp_stepper_before_update", h, C.byref(fi))
+            if found_inf is None and fi.value:
+                found_inf = _FlagRef(fi.value)
         m, v = self.moments("enc")
         rm, rv = self.moments("rgb")
         ne = enc.n_mlp
@@ -282,6 +291,15 @@ class FusedAdam(torch.optim.Optimizer):
                  self.step_state(found_inf), sq)      # 0: every table backward of this package overwrites the gradient
         enc._half.mark_fresh(enc.params); net._half.mark_fresh(net.params)
         model._native = None
+
+
+class _FlagRef:
+    """A device int32 flag owned by the library (the stepper's overflow guard), passed where a found_inf tensor is expected."""
+    def __init__(self, address):
+        self.address = address
+
+    def data_ptr(self):
+        return self.address
 
 
 FusedAdam.step.hooked = True          # Optimizer._patch_step_function: do not wrap (step() runs registered hooks itself)

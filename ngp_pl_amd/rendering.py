@@ -381,7 +381,8 @@ class _NativeTrainRender(torch.autograd.Function):
         n_part = np_c.value
         g16 = model._grid_grad16(dev)
         p_density, p_rgb = B.partial_rows(n_part, enc.n_mlp)
-        model.hand_over_native(dict(grid16=g16, density_partials=p_density, rgb_partials=p_rgb, n_partials=n_part, scale=tcnn.LOSS_SCALE))
+        model.hand_over_native(dict(grid16=g16, density_partials=p_density, rgb_partials=p_rgb, n_partials=n_part, scale=tcnn.LOSS_SCALE,
+                                    stepper=h))          # (FusedAdam asks it for the step's overflow flag and the dynamic loss scale)
         return (None, None) + none7
 
 

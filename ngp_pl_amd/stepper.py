@@ -8,7 +8,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import call, ptr
+from ._lib import call, ptr, stream
 
 MAX_SAMPLES = 1024          # rendering.py:7 (ngp_pl_amd.rendering re-exports it)
 
@@ -190,12 +190,15 @@ class RenderStepper:
         self.generation = 0
         self.side = None
         self.pending = None          # (ptr_o, ptr_d, tensors) of a prefetched march
+        self.scaler_on, self.scale_saved = False, None
         dev = model.center.device
         self.bg_buf = torch.zeros(3, device=dev)
         self.bg_src = None
 
     def _destroy(self):
         if self.handle is not None:
+            if getattr(self, "scaler_on", False):
+                self.scale_saved = self.loss_scale_state()[0]          # carried over the rebuild
             _lib.lib().ngp_stepper_destroy(self.handle)
             self.handle = self.key = self.pending = None
 
@@ -239,4 +242,19 @@ class RenderStepper:
             call("ngp_stepper_create", C.byref(c), C.byref(bc), C.byref(h))
             self.handle, self.key = h, key
             self.buf.attach_sample_sets(h)
+            # the dynamic loss scale (GradScaler's rule on the device, include/ngp_hip.h): this node only runs with native gradients,
+            # i.e. with this package's FusedAdam behind it, which hands the scale to its launch (optim.FusedAdam._step_native)
+            cfg = getattr(m, "native_loss_scaler", None)
+            if cfg:
+                call("ngp_stepper_set_loss_scaler", h, float(self.scale_saved or cfg["init_scale"]), float(cfg["growth_factor"]), float(cfg["backoff_factor"]),
+                     int(cfg["growth_interval"]), stream())
+            self.scaler_on = bool(cfg)
         return self.buf, self.handle
+
+    def loss_scale_state(self):
+        """(scale, clean steps) of the node's dynamic loss scale; (1.0, 0) when off.  Syncs."""
+        if self.handle is None or not self.scaler_on:
+            return 1.0, 0
+        sc, tr = C.c_float(0.0), C.c_int32(0)
+        call("ngp_stepper_loss_scale", self.handle, C.byref(sc), C.byref(tr), stream())
+        return float(sc.value), int(tr.value)

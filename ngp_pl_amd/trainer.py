@@ -47,7 +47,7 @@ def marching_stream(dev):
 class Trainer:
     def __init__(self, model, lr=1e-2, num_epochs=30, steps_per_epoch=1000, T_threshold=1e-4,
                  lambda_opacity=1e-3, grad_scale=1.0, warmup_steps=256, update_interval=16, overlap_march=True,
-                 lambda_distortion=0.0, binned_backward=None, erode=False, native_step=None):
+                 lambda_distortion=0.0, binned_backward=None, erode=False, native_step=None, loss_scaler=True):
         self.model = model
         if not hasattr(model, "density_grid"):
             model.register_training_buffers()
@@ -56,6 +56,19 @@ class Trainer:
         self.T_threshold, self.lambda_opacity = T_threshold, lambda_opacity
         self.warmup_steps, self.update_interval = warmup_steps, update_interval
         self.grad_scale = grad_scale
+        # Dynamic loss scale of the native step: torch.cuda.amp.GradScaler's rule on the device, on top of tiny-cuda-nn's fixed 128 --
+        # what Lightning's precision=16 gives the reference (train.py:274).  True: GradScaler's defaults (init 65536, growth 2 every
+        # 2000 clean steps, backoff 0.5); a dict(init_scale=, growth_factor=, backoff_factor=, growth_interval=) overrides them; False /
+        # None: the fixed scale alone (rounds 1-5: half of a step's feature gradients flush to zero in f16, profiles/r06_loss_scale.txt).
+        # Steps whose update runs through Python hooks (grad_hook / mlp_grad_hook / a replaced optimizer step) keep the fixed scale.
+        self.loss_scaler = None
+        if loss_scaler:
+            self.loss_scaler = dict(init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000)
+            if isinstance(loss_scaler, dict):
+                self.loss_scaler.update(loss_scaler)
+        model.native_loss_scaler = dict(self.loss_scaler) if self.loss_scaler else None       # render()'s native node (step_autograd): the same rule
+        self._scaler_active = False          # what the current stepper is configured with
+        self._scaler_saved = None            # scale carried over a rebuild of the stepper
         self.global_step = 0
         self.exp_step_factor = 1 / 256 if model.scale > 0.5 else 0.0      # train.py:95-96
         dev = model.center.device
@@ -199,8 +212,32 @@ class Trainer:
             self.native_exchange.attach(h)
         return h
 
+    def loss_scale_state(self):
+        """(scale the next step multiplies tiny-cuda-nn's 128 by, clean steps since it last changed); (1.0, 0) while the scaler is off.  Syncs."""
+        if self._stepper is None or not self._scaler_active:
+            return (self._scaler_saved or 1.0), 0
+        sc, tr = C.c_float(0.0), C.c_int32(0)
+        call("ngp_stepper_loss_scale", self._stepper, C.byref(sc), C.byref(tr), stream())
+        return float(sc.value), int(tr.value)
+
+    def _configure_scaler(self, h, want):
+        if want:
+            cfg = dict(self.loss_scaler)
+            if self._scaler_saved:
+                cfg["init_scale"] = self._scaler_saved
+            call("ngp_stepper_set_loss_scaler", h, float(cfg["init_scale"]), float(cfg["growth_factor"]), float(cfg["backoff_factor"]),
+                 int(cfg["growth_interval"]), stream())
+        else:
+            if self._scaler_active:
+                self._scaler_saved = self.loss_scale_state()[0]
+            call("ngp_stepper_set_loss_scaler", h, 0.0, 2.0, 0.5, 2000, stream())
+        self._scaler_active = want
+
     def _destroy_stepper(self):
         if self._stepper is not None:
+            if self._scaler_active:
+                self._scaler_saved = self.loss_scale_state()[0]
+                self._scaler_active = False
             _lib.lib().ngp_stepper_destroy(self._stepper)
             self._stepper = self._stepper_key = None
             self._pending_key = self._pending_keep = None
@@ -252,16 +289,20 @@ class Trainer:
                 seed_val = self.lambda_distortion / n * self.grad_scale
                 if B.dist_seed_val != seed_val:
                     B.view("dist_seed", torch.float32, n).fill_(seed_val); B.dist_seed_val = seed_val
+            # hooks (multi-GPU exchange through Python), an update hook, or an optimizer whose step() was replaced (tests capture the
+            # gradients there): the tail runs through Python, at the fixed loss scale
+            custom_opt = "step" in vars(self.opt) and not getattr(self.opt.step, "_wrapped_by_lr_sched", False)     # (an LR scheduler wraps step(): still ours)
+            hooks = self.grad_hook is not None or self.mlp_grad_hook is not None or custom_opt
+            want_scaler = self.loss_scaler is not None and (self.native_exchange is not None or not hooks)
+            if want_scaler != self._scaler_active:
+                self._configure_scaler(h, want_scaler)
             S_c, np_c = C.c_int32(0), C.c_int32(0)
             call("ngp_stepper_front", h, ro_p, rd_p, rgb_gt.data_ptr(), no_p if prefetch else None, nd_p if prefetch else None,
                  self.loss_scale, self.grad_scale, mq, sq, C.byref(S_c), C.byref(np_c))
             if prefetch:
                 self._pending_key, self._pending_keep = (no_p, nd_p), next_batch
             S, n_part = S_c.value, np_c.value
-            # hooks (multi-GPU exchange), an update hook, or an optimizer whose step() was replaced (tests capture the gradients
-            # there): the tail runs through Python; otherwise table backward + Adam are two more library calls
-            custom_opt = "step" in vars(self.opt) and not getattr(self.opt.step, "_wrapped_by_lr_sched", False)     # (an LR scheduler wraps step(): still ours)
-            hooks = self.grad_hook is not None or self.mlp_grad_hook is not None or custom_opt
+            # (hooks: the tail runs through Python; otherwise table backward + Adam are two more library calls)
             if self.native_exchange is not None:
                 # data parallel, enqueued by the library: MLP all-reduce, table backward in launch groups with the chunks of the
                 # gradient handed to the communicator's stream behind them, non-finite checks, Adam, all-gather -- one call,
@@ -393,8 +434,9 @@ class Trainer:
 
     # -- the reference-shaped path ---------------------------------------------------------------
     def step_autograd(self, rays_o, rays_d, rgb_gt, noise=None, next_batch=None):
-        """render() -> NeRFLoss -> backward -> FusedAdam, as train.py:159-185 (no GradScaler: the
-        tcnn modules carry their own loss scale)."""
+        """render() -> NeRFLoss -> backward -> FusedAdam, as train.py:159-185.  The GradScaler Lightning's precision=16 wraps around
+        that step (train.py:274) lives on the device here: render()'s native node runs its f16 backward under the dynamic loss scale
+        (`model.native_loss_scaler`), FusedAdam unscales, skips and updates the scale in its launch -- no host sync."""
         if self.grad_hook is not None or self.mlp_grad_hook is not None or self.update_hook is not None or self.native_exchange is not None:
             # the autograd surface issues no collectives: under an installed exchange the ranks would train independently and
             # silently diverge (Trainer.step is the data-parallel path; uninstall() the exchange for single-process use)

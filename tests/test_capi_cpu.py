@@ -26,7 +26,7 @@ def test_the_boundary_stays_small():
     apart."""
     from ngp_pl_amd import _abi
     pub, internal = _abi.parse(_abi.HEADER), _abi.parse(_abi.INTERNAL_HEADER)
-    assert 80 <= len(pub) <= 100 and len(internal) <= 30, (len(pub), len(internal))
+    assert 80 <= len(pub) <= 100 and len(internal) <= 32, (len(pub), len(internal))
     for name in ("ngp_ray_aabb_intersect", "ngp_ray_sphere_intersect", "ngp_packbits", "ngp_morton3D", "ngp_morton3D_invert",
                  "ngp_raymarching_train_count", "ngp_raymarching_train_write", "ngp_raymarching_test", "ngp_composite_train_fw",
                  "ngp_composite_train_bw", "ngp_composite_test_fw", "ngp_distortion_loss_fw", "ngp_distortion_loss_bw"):
@@ -62,7 +62,7 @@ def test_c_program_links_every_declared_symbol(tmp_path):
     assert r.returncode == 0, r.stdout[-3000:]
     r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
     assert r.returncode == 0, r.stdout
-    assert r.stdout.split() == [str(len(protos)), "5", "gfx950"], r.stdout
+    assert r.stdout.split() == [str(len(protos)), "6", "gfx950"], r.stdout
 
 
 def test_ctypes_table_agrees_with_the_header():
@@ -108,7 +108,7 @@ def test_library_exports_every_declared_symbol():
     assert set(names) <= exported, sorted(set(names) - exported)
     assert exported <= set(names), "exported but undeclared: %s" % sorted(exported - set(names))
     assert set(_lib.exported_symbols()) == set(names)          # the ctypes table covers the whole header
-    assert lib.ngp_abi_version() == 5 == _lib.ABI_VERSION and lib.ngp_build_arch() == b"gfx950"
+    assert lib.ngp_abi_version() == 6 == _lib.ABI_VERSION and lib.ngp_build_arch() == b"gfx950"
 
 
 def test_code_object_is_gfx950_only():

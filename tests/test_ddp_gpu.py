@@ -48,9 +48,28 @@ def _worker(rank, world, port, n_groups, q):
 
         def spy():                                         # local gradient right before the grid collective
             nat = m._native
-            pre["grid"] = nat["grid16"].clone(); pre["scale"] = nat["scale"]
+            parts = pre.pop("parts", None)
+            if parts:                                      # n_groups > 1: the ranges were cloned group by group, before their piece went out
+                g = nat["grid16"].clone()
+                for (a, b), t in parts:
+                    g[2 * a:2 * b] = t
+                pre["grid"] = g
+            else:
+                pre["grid"] = nat["grid16"].clone()
+            pre["scale"] = nat["scale"]
             return reduce_grid()
         tr.grad_hook = spy
+        reduce_piece = tr.group_hook
+        if reduce_piece is not None:
+            # (an asynchronous piece may have been reduced IN PLACE by the time the grad hook runs: a clone taken there raced with it --
+            # round 6, when the step's timing moved)
+            def spy_piece(group, n_groups_, a, b):
+                nat = m._native
+                if nat is not None:
+                    torch.cuda.synchronize()
+                    pre.setdefault("parts", []).append(((a, b), nat["grid16"][2 * a:2 * b].clone()))
+                return reduce_piece(group, n_groups_, a, b)
+            tr.group_hook = spy_piece
         adam = tr.opt.step
 
         def spy_adam(grad_scale=1.0, found_inf=None, stream_handle=None):
@@ -236,7 +255,9 @@ def _native_worker(port, q):
             torch.manual_seed(9)
             m = NGP(scale=0.5).cuda()
             m.register_training_buffers()
-            tr = Trainer(m)
+            # A-F at the fixed loss scale (the torch.distributed mirrors have no scaler); G: the device-side loss scaler under the library's
+            # exchange, S: the same factor applied statically through grad_scale
+            tr = Trainer(m, loss_scaler=kind == "G", grad_scale=65536.0 if kind == "S" else 1.0)
             if kind == "A":
                 ex = ShardedExchange(m, dist, 1, 0)
             elif kind == "F":
@@ -260,11 +281,12 @@ def _native_worker(port, q):
                 tr.step(*batches[0]); ex.sample_times()
                 tr.events = None
                 snap["times"] = (ex.exchange_ms(), ex.exposed_ms())
+            snap["scale"] = tr.loss_scale_state()
             ex.uninstall(tr)
             if hasattr(ex, "close"):
                 ex.close()
             return snap
-        res = {k: run(k) for k in "ABCDEF"}
+        res = {k: run(k) for k in "ABCDEFGS"}
         ok, notes = True, []
         a = res["A"]
         ok &= a["log"][7][0] == 0 and a["log"][8][0] > 0
@@ -274,6 +296,13 @@ def _native_worker(port, q):
             same = all(torch.equal(r[key], a[key]) for key in ("half", "master", "rgb")) and all(torch.equal(x, y) for x, y in zip(r["m"], a["m"]))
             ok &= same_log and same
             notes.append("%s vs A: losses identical %s, parameters + moments identical %s, applied steps %s" % (k, same_log, same, r["applied"]))
+        # the dynamic loss scale under the library's exchange (G: sharded, 1 rank; GradScaler's defaults: 65536, no growth within 20
+        # steps, no overflow on these batches) is the same arithmetic as the factor applied statically (S) -- and not the fixed scale's
+        g, st = res["G"], res["S"]
+        same_gs = g["log"] == st["log"] and all(torch.equal(g[key], st[key]) for key in ("half", "master", "rgb")) and all(torch.equal(x, y) for x, y in zip(g["m"], st["m"]))
+        ok &= same_gs and g["scale"] == (65536.0, 20) and st["scale"] == (1.0, 0) and g["applied"] == (20, 20) and not torch.equal(g["master"], a["master"])
+        notes.append("G vs S (loss scaler under the exchange vs the same static factor): identical %s, scale %s / %s, applied %s / %s" % (
+            same_gs, g["scale"], st["scale"], g["applied"], st["applied"]))
         t = res["C"]["times"]
         ok &= t is not None and t[0] is not None and t[0] > 0 and t[1] is not None
         notes.append("C exchange_ms %.4f exposed %.4f" % (t[0] or -1, t[1] or -1))

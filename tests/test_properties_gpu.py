@@ -436,7 +436,7 @@ def test_overflow_guard_skips_a_step_with_a_non_finite_weight_gradient():
         return [p.clone() for p in parts]
 
     m = NGP(scale=0.5).to(dev)
-    tr = Trainer(m)
+    tr = Trainer(m, loss_scaler=False)                    # (the fixed scale: the dynamic one is the next test's)
     tr.step(ro, rd, gt)                                   # an ordinary step: applied
     assert tr.skipped_steps() == (0, 0)
     before = state(tr, m)
@@ -454,8 +454,81 @@ def test_overflow_guard_skips_a_step_with_a_non_finite_weight_gradient():
     # the same two applied steps without the skipped one in between: identical parameters (the skipped step left no trace)
     torch.manual_seed(3)
     m2 = NGP(scale=0.5).to(dev)
-    tr2 = Trainer(m2)
+    tr2 = Trainer(m2, loss_scaler=False)
     tr2.step(ro, rd, gt); tr2.step(ro, rd, gt)
     # (the march's jitter is drawn per march: the third march of `tr` differs from the second of `tr2`, so compare moments' finiteness
     # and the bias-correction count only)
     assert tr2.opt.applied_steps() == (2, 2)
+
+
+def _scaler_batch(dev, n=2048):
+    from ngp_pl_amd import synthetic as syn
+    K = syn.intrinsics(64)
+    dirs = syn.get_ray_directions(64, 64, K)
+    poses = syn.hemisphere_poses(4, seed=1)
+    g = torch.Generator().manual_seed(5)
+    ro, rd = syn.get_rays(dirs[torch.randint(4096, (n,), generator=g)], poses[torch.randint(4, (n,), generator=g)])
+    ro, rd = ro.to(dev).contiguous(), rd.to(dev).contiguous()
+    gt, _ = syn.render_ground_truth(ro, rd, n_steps=64)
+    return ro, rd, gt.contiguous()
+
+
+def test_dynamic_loss_scale_equals_the_same_static_scale_bit_for_bit():
+    """The device-side loss scaler (GradScaler's rule on top of tiny-cuda-nn's 128, train.py:274 under precision=16) at a scale that
+    neither grows nor overflows is the SAME arithmetic as that factor applied statically through `grad_scale`: the field backward
+    multiplies its f32 seeds by a power of two, the optimizer divides by it -- parameters, f16 copies and moments after 12 steps are
+    bit-identical.  And both differ from the fixed 128 alone (gradients that flushed to zero there survive)."""
+    from ngp_pl_amd.networks import NGP
+    from ngp_pl_amd.trainer import Trainer
+    dev = torch.device("cuda")
+    ro, rd, gt = _scaler_batch(dev)
+
+    def run(**kw):
+        torch.manual_seed(3)
+        m = NGP(scale=0.5).to(dev)
+        tr = Trainer(m, **kw)
+        for _ in range(12):
+            tr.step(ro, rd, gt)
+        enc, net = m.xyz_encoder, m.rgb_net
+        return tr, [p.clone() for p in (enc.params.detach(), net.params.detach(), enc._half.get(enc.params), net._half.get(net.params),
+                                         *tr.opt.moments("enc"), *tr.opt.moments("rgb"))]
+    tr_d, dyn = run(loss_scaler=dict(init_scale=256.0, growth_interval=10 ** 9))
+    tr_s, sta = run(loss_scaler=False, grad_scale=256.0)
+    tr_f, fix = run(loss_scaler=False)
+    assert tr_d.skipped_steps() == (0, 0) and tr_s.skipped_steps() == (0, 0)
+    assert tr_d.loss_scale_state() == (256.0, 12) and tr_s.loss_scale_state() == (1.0, 0)
+    for a, b in zip(dyn, sta):
+        assert torch.equal(a, b)
+    assert not torch.equal(dyn[0], fix[0])
+
+
+def test_loss_scaler_backs_off_on_overflow_and_grows_after_clean_steps():
+    """GradScaler's rule, decided on the device: from a scale that must overflow (2^40 on top of 128) every step is skipped and halves
+    the scale until the f16 chain fits; then `growth_interval` clean steps double it, the doubled scale overflows again or not, and so
+    on.  Checked against the rule replayed on the host from the skip counts; no parameter ever goes non-finite."""
+    from ngp_pl_amd.networks import NGP
+    from ngp_pl_amd.trainer import Trainer
+    dev = torch.device("cuda")
+    ro, rd, gt = _scaler_batch(dev)
+    torch.manual_seed(3)
+    m = NGP(scale=0.5).to(dev)
+    tr = Trainer(m, loss_scaler=dict(init_scale=2.0 ** 40, growth_interval=3))
+    scale, tracker, skipped = 2.0 ** 40, 0, 0
+    seen = []
+    for i in range(60):
+        tr.step(ro, rd, gt)
+        now = tr.skipped_steps()[0]
+        if now > skipped:                       # this step was skipped: backoff
+            scale, tracker = scale * 0.5, 0
+        else:
+            tracker += 1
+            if tracker >= 3:
+                scale, tracker = scale * 2.0, 0
+        skipped = now
+        assert tr.loss_scale_state() == (scale, tracker), (i, tr.loss_scale_state(), scale, tracker)
+        seen.append(scale)
+    assert skipped >= 10 and tr.opt.applied_steps()[0] == 60 - skipped          # it took many halvings to come down from 2^40 ...
+    assert min(seen) < 2.0 ** 30 and seen[-1] >= min(seen)                       # ... and it came back up afterwards
+    assert any(b > a for a, b in zip(seen, seen[1:]))                            # (growth happened)
+    enc, net = m.xyz_encoder, m.rgb_net
+    assert bool(torch.isfinite(enc.params).all()) and bool(torch.isfinite(net.params).all())

@@ -106,6 +106,7 @@ def test_native_gradients_and_grad_tensors_drive_the_same_update():
     from ngp_pl_amd._lib import call, ptr, stream
     from ngp_pl_amd.optim import FusedAdam
     model_a, model_b = _make(seed=12), _make(seed=12)
+    model_a.native_loss_scaler = None                      # the fixed loss scale: the native buffers are re-scaled by hand below
     sys_a, sys_b = _System(model_a), _System(model_b)
     opt_a = FusedAdam(_net_params(sys_a), 1e-2, eps=1e-15, native_grads=True)
     opt_b = FusedAdam(_net_params(sys_b), 1e-2, eps=1e-15)
@@ -289,3 +290,32 @@ def test_a_deep_copied_model_still_trains_correctly():
         opt.step()
         assert float((enc.params.detach() - before).abs().max()) > 1e-4
         assert torch.equal(enc._half.get(enc.params), enc.params.detach().half())          # what the next forward will read
+
+
+def test_native_render_node_trains_under_the_dynamic_loss_scale():
+    """render() + NeRFLoss + backward + FusedAdam(native_grads=True) exactly as train.py:159-185 strings them together, with the
+    GradScaler of Lightning's precision=16 (train.py:274) living on the device: the native node's field backward multiplies its seeds
+    by the dynamic scale, FusedAdam's one launch divides by it, skips on overflow and updates it.  From GradScaler's default 65536 on
+    a fresh model: no parameter goes non-finite, the scale stays a power of two, skipped steps leave the applied count behind, and
+    the loss falls."""
+    from ngp_pl_amd.optim import FusedAdam
+    model = _make(seed=14)
+    system = _System(model)
+    opt = FusedAdam(_net_params(system), 1e-2, eps=1e-15, native_grads=True)
+    assert model.native_loss_scaler["init_scale"] == 65536.0
+    losses = []
+    for it in range(40):
+        ro, rd, gt = _batch(2048, 700 + it % 4)
+        loss = _loss(system(ro, rd), gt)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    rs = model._render_stepper
+    scale, clean = rs.loss_scale_state()
+    applied = opt.applied_steps()[0]
+    assert scale > 1.0 and math.log2(scale) == int(math.log2(scale)) and 0 <= clean <= 40
+    assert applied + int(round(math.log2(65536.0 / scale))) == 40 or applied == 40          # every skip halved the scale (no growth within 40 steps)
+    for p in _net_params(system):
+        assert bool(torch.isfinite(p).all())
+    assert sum(losses[-5:]) < 0.5 * sum(losses[:5])

@@ -1112,8 +1112,8 @@ def test_native_render_node_matches_the_launch_by_launch_node():
     from ngp_pl_amd.rendering import render
     from ngp_pl_amd.trainer import Trainer
     m = make_model(seed=31)
-    tr = Trainer(m)                                               # FusedAdam: model.native_grads = True
-    bs = [batch(4096, seed=1200 + i) for i in range(3)]
+    tr = Trainer(m, loss_scaler=False)                            # FusedAdam: model.native_grads = True; the fixed loss scale: the two nodes' native
+    bs = [batch(4096, seed=1200 + i) for i in range(3)]           # buffers are compared raw (the dynamic scale is the native node's alone)
     for it in range(120):
         tr.step(*bs[it % 3])
     ro, rd, gt = batch(4096, seed=1290)

@@ -41,7 +41,7 @@ for what in "$@"; do
         -k "end_to_end or references_render_on_the_binding or references_train_py" 2>&1 | tail -5
       cat gpurun_out/${TAG}_parity_distribution.txt ;;
     test:*)
-      timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider -x -k "${what#test:}" 2>&1 | tail -15 | tee gpurun_out/${TAG}_test_k.log ;;
+      timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider -x -k "${what#test:}" 2>&1 | tail -45 | tee gpurun_out/${TAG}_test_k.log ;;
     *) echo "unknown: $what" ;;
   esac
 done
