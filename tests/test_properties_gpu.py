@@ -515,10 +515,16 @@ def test_loss_scaler_backs_off_on_overflow_and_grows_after_clean_steps():
     tr = Trainer(m, loss_scaler=dict(init_scale=2.0 ** 40, growth_interval=3))
     scale, tracker, skipped = 2.0 ** 40, 0, 0
     seen = []
+    # ... and against torch's own GradScaler fed the same skip decisions (a one-element parameter whose gradient is inf on the steps
+    # the device skipped): the scale the reference's Lightning run would be at
+    theirs = torch.amp.GradScaler("cuda", init_scale=2.0 ** 40, growth_interval=3)
+    dummy = torch.nn.Parameter(torch.zeros(1, device=dev))
+    dummy_opt = torch.optim.SGD([dummy], lr=0.0)
     for i in range(60):
         tr.step(ro, rd, gt)
         now = tr.skipped_steps()[0]
-        if now > skipped:                       # this step was skipped: backoff
+        was_skipped = now > skipped
+        if was_skipped:                         # this step was skipped: backoff
             scale, tracker = scale * 0.5, 0
         else:
             tracker += 1
@@ -526,6 +532,11 @@ def test_loss_scaler_backs_off_on_overflow_and_grows_after_clean_steps():
                 scale, tracker = scale * 2.0, 0
         skipped = now
         assert tr.loss_scale_state() == (scale, tracker), (i, tr.loss_scale_state(), scale, tracker)
+        dummy.grad = torch.full((1,), float("inf") if was_skipped else 1.0, device=dev)
+        theirs.scale(torch.zeros((), device=dev))           # (initialises the scaler's device state on first use)
+        theirs.step(dummy_opt)
+        theirs.update()
+        assert theirs.get_scale() == scale, (i, theirs.get_scale(), scale)
         seen.append(scale)
     assert skipped >= 10 and tr.opt.applied_steps()[0] == 60 - skipped          # it took many halvings to come down from 2^40 ...
     assert min(seen) < 2.0 ** 30 and seen[-1] >= min(seen)                       # ... and it came back up afterwards
