@@ -33,3 +33,9 @@ bounds = [("L0", 0, 16), ("L1", 16, 32), ("L2", 32, 48), ("L3", 48, 80), ("L4", 
 for name, a, b in bounds:
     sel = scan[a:b]
     print("%s: %d tasks, scan mean %.1f max %.1f us, start of first %.1f us" % (name, b - a, sel.mean(), sel.max(), (tm[a, 0] - t0) / 100))
+# how much of the launch is tail: the sum of the tasks' durations over 256 workgroups against the span
+dur = (tm[:, 3] - tm[:, 0]) / 100
+end = (tm[:, 3] - t0) / 100
+print("sum of task durations %.1f us x WG -> %.1f us on 256 workgroups; span %.1f us; tasks ending in the last 10 us: %d, last 20 us: %d; hashed task %.1f us, dense task %.1f us (max %.1f)" % (
+    float(dur.sum()), float(dur.sum()) / 256, float(end.max()), int((end > end.max() - 10).sum()), int((end > end.max() - 20).sum()),
+    float(dur[nd:].mean()), float(dur[:nd].mean()), float(dur[:nd].max())))
