@@ -611,6 +611,8 @@ int ngp_stepper_table_backward(ngp_stepper* s, int n_groups, int group, ngp_stre
 }
 
 // The optimizer launch enqueued next divides by this step's dynamic loss scale and writes the next step's (optim.hip: LossScaler).
+static void withdraw_scaler() { (void)ngp_adam_use_loss_scaler(nullptr, 0, 2.0f, 0.5f, 1, 1.0f, 1.0f); }
+
 static int hand_over_scaler(ngp_stepper* s) {
     if (!s->scaler_on) return 0;
     STEP_TRY(ngp_adam_use_loss_scaler(s->scaler_state, s->scaler_slot, s->scaler_growth, s->scaler_backoff, s->scaler_interval, s->scaler_lo, s->scaler_hi));
@@ -645,10 +647,14 @@ int ngp_stepper_update(ngp_stepper* s, float lr, int32_t step, float grad_scale,
     if (found_inf == nullptr && s->guard_armed && density_partials == b.partials) found_inf = s->guard + s->guard_parity;    // this step's own field backward
     s->guard_armed = false;
     STEP_TRY(hand_over_scaler(s));
-    STEP_TRY(ngp_adam_step_field(c.enc_param + c.n_density, c.enc_half + c.n_density, c.grid_grad16, c.enc_m + c.n_density, c.enc_v + c.n_density, c.n_grid,
+    {
+        const int rc_adam = ngp_adam_step_field(c.enc_param + c.n_density, c.enc_half + c.n_density, c.grid_grad16, c.enc_m + c.n_density, c.enc_v + c.n_density, c.n_grid,
                                  c.enc_param, c.enc_half, density_partials, c.enc_m, c.enc_v, c.n_density,
                                  c.rgb_param, c.rgb_half, rgb_partials, c.rgb_m, c.rgb_v, c.n_rgb,
-                                 n_partials, lr, c.beta1, c.beta2, c.eps, c.weight_decay, step, grad_scale, 0, found_inf, step_state, main_stream));
+                                 n_partials, lr, c.beta1, c.beta2, c.eps, c.weight_decay, step, grad_scale, 0, found_inf, step_state, main_stream);
+        withdraw_scaler();                       // (consumed by a launch that went out; withdrawn if validation refused it)
+        if (rc_adam) return rc_adam;
+    }
     mark(s, 8, ngp_stream(main_stream));
     STEP_TRY(march_next_if_at(s, AT_ADAM));
     return 0;
@@ -674,11 +680,15 @@ int ngp_stepper_backward_update(ngp_stepper* s, float lr, int32_t step, float gr
     mark(s, 7, ngp_stream(main_stream));
     STEP_TRY(march_next_if_at(s, AT_HASHGRID_BWD));
     STEP_TRY(hand_over_scaler(s));
-    STEP_TRY(ngp_adam_step_field_merge(c.enc_param + c.n_density, c.enc_half + c.n_density, c.grid_grad16, c.enc_m + c.n_density, c.enc_v + c.n_density, n_streamed,
+    {
+        const int rc_adam = ngp_adam_step_field_merge(c.enc_param + c.n_density, c.enc_half + c.n_density, c.grid_grad16, c.enc_m + c.n_density, c.enc_v + c.n_density, n_streamed,
                                        c.enc_param, c.enc_half, b.partials, c.enc_m, c.enc_v, c.n_density,
                                        c.rgb_param, c.rgb_half, b.partials + (size_t)s->n_part * c.n_density, c.rgb_m, c.rgb_v, c.n_rgb,
                                        s->n_part, lr, c.beta1, c.beta2, c.eps, c.weight_decay, step, grad_scale,
-                                       s->guard_armed ? s->guard + s->guard_parity : nullptr, step_state, &gp, main_stream));
+                                       s->guard_armed ? s->guard + s->guard_parity : nullptr, step_state, &gp, main_stream);
+        withdraw_scaler();                       // (consumed by a launch that went out; withdrawn if validation refused it)
+        if (rc_adam) return rc_adam;
+    }
     s->guard_armed = false;
     mark(s, 8, ngp_stream(main_stream));
     STEP_TRY(march_next_if_at(s, AT_ADAM));
@@ -798,11 +808,15 @@ int ngp_stepper_tail(ngp_stepper* s, float lr, int32_t step, float grad_scale, n
         STEP_TRY(ngp_found_inf2(x.small, 1, n_small, nullptr, 0, 0, mlp_cur, mlp_nxt, cst));
         STEP_TRY(ngp_found_inf2(x.shard16, 0, (int64_t)x.n_chunks * x.piece, nullptr, 0, 0, grid_cur, grid_nxt, cst));
         STEP_TRY(hand_over_scaler(s));
-        STEP_TRY(ngp_adam_step_field_pieces(c.enc_param + c.n_density, c.enc_half + c.n_density, x.shard16, c.enc_m + c.n_density, c.enc_v + c.n_density,
+        {
+            const int rc_adam = ngp_adam_step_field_pieces(c.enc_param + c.n_density, c.enc_half + c.n_density, x.shard16, c.enc_m + c.n_density, c.enc_v + c.n_density,
                                             c.n_grid, x.piece, x.n_chunks, comm->world, comm->rank,
                                             c.enc_param, c.enc_half, x.small, c.enc_m, c.enc_v, c.n_density,
                                             c.rgb_param, c.rgb_half, x.small + c.n_density, c.rgb_m, c.rgb_v, c.n_rgb,
-                                            1, lr, c.beta1, c.beta2, c.eps, c.weight_decay, step, grad_scale, mlp_cur, grid_cur, x.step_state, cst));
+                                            1, lr, c.beta1, c.beta2, c.eps, c.weight_decay, step, grad_scale, mlp_cur, grid_cur, x.step_state, cst);
+            withdraw_scaler();                       // (consumed by a launch that went out; withdrawn if validation refused it)
+            if (rc_adam) return rc_adam;
+        }
         // the updated f16 table: every rank's pieces to every rank, in place (one RCCL group: one launch for all chunks)
         if (x.mode == 2) {
             STEP_TRY(ngp_comm_all_gather_direct(comm, x.table_padded, x.piece, NGP_COMM_F16, cst));
@@ -820,10 +834,14 @@ int ngp_stepper_tail(ngp_stepper* s, float lr, int32_t step, float grad_scale, n
         // one flag for everything (all ranks hold the same sums): GradScaler's whole-step decision
         STEP_TRY(ngp_found_inf2(x.grad_padded, 0, padded, x.small, 1, n_small, mlp_cur, mlp_nxt, cst));
         STEP_TRY(hand_over_scaler(s));
-        STEP_TRY(ngp_adam_step_field(c.enc_param + c.n_density, c.enc_half + c.n_density, c.grid_grad16, c.enc_m + c.n_density, c.enc_v + c.n_density, c.n_grid,
+        {
+            const int rc_adam = ngp_adam_step_field(c.enc_param + c.n_density, c.enc_half + c.n_density, c.grid_grad16, c.enc_m + c.n_density, c.enc_v + c.n_density, c.n_grid,
                                      c.enc_param, c.enc_half, x.small, c.enc_m, c.enc_v, c.n_density,
                                      c.rgb_param, c.rgb_half, x.small + c.n_density, c.rgb_m, c.rgb_v, c.n_rgb,
-                                     1, lr, c.beta1, c.beta2, c.eps, c.weight_decay, step, grad_scale, 0, mlp_cur, x.step_state, cst));
+                                     1, lr, c.beta1, c.beta2, c.eps, c.weight_decay, step, grad_scale, 0, mlp_cur, x.step_state, cst);
+            withdraw_scaler();                       // (consumed by a launch that went out; withdrawn if validation refused it)
+            if (rc_adam) return rc_adam;
+        }
     }
     if (timing) { STEP_HIP(hipEventRecord(s->ev_x1, cs)); s->x_times_set = true; }
     // (4) the one wait of the main stream: the next forward, the occupancy update and the next tail's memsets read / write what

@@ -283,12 +283,16 @@ class FusedAdam(torch.optim.Optimizer):
         # raw pointers by arithmetic (a tensor slice costs ~4 us of host time, this call passes 6 of them)
         p_enc, p_half, p_m, p_v = enc.params.data_ptr(), enc._half.t.data_ptr(), m.data_ptr(), v.data_ptr()
         guard = device_guard(enc.params.device) if stream_handle is None else contextlib.nullcontext()     # a raw stream handle names its device
-        with guard:
-            call("ngp_adam_step_field", p_enc + 4 * ne, p_half + 2 * ne, ptr(nat["grid16"]), p_m + 4 * ne, p_v + 4 * ne, enc.n_grid,
-                 p_enc, p_half, ptr(nat["density_partials"]), p_m, p_v, ne,
-                 net.params.data_ptr(), net._half.t.data_ptr(), ptr(nat["rgb_partials"]), rm.data_ptr(), rv.data_ptr(), net.params.numel(),
-                 nat["n_partials"], lr, b1, b2, group["eps"], group["weight_decay"], self.t, total_scale, 0, ptr(found_inf),
-                 self.step_state(found_inf), sq)      # 0: every table backward of this package overwrites the gradient
+        try:
+            with guard:
+                call("ngp_adam_step_field", p_enc + 4 * ne, p_half + 2 * ne, ptr(nat["grid16"]), p_m + 4 * ne, p_v + 4 * ne, enc.n_grid,
+                     p_enc, p_half, ptr(nat["density_partials"]), p_m, p_v, ne,
+                     net.params.data_ptr(), net._half.t.data_ptr(), ptr(nat["rgb_partials"]), rm.data_ptr(), rv.data_ptr(), net.params.numel(),
+                     nat["n_partials"], lr, b1, b2, group["eps"], group["weight_decay"], self.t, total_scale, 0, ptr(found_inf),
+                     self.step_state(found_inf), sq)      # 0: every table backward of this package overwrites the gradient
+        finally:
+            if h is not None:                         # (a launch that went out has consumed the hand-over; one that raised must not leave it behind)
+                call("ngp_adam_use_loss_scaler", None, 0, 2.0, 0.5, 1, 1.0, 1.0)
         enc._half.mark_fresh(enc.params); net._half.mark_fresh(net.params)
         model._native = None
 
