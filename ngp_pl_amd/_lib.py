@@ -110,7 +110,7 @@ _PROTOS = {
     "ngp_density_bwd": [P, P, P, P, F, I, P, P, P, P, P],
     "ngp_field_bwd_partials": [I],
     "ngp_field_bwd": [P, P, P, P, P, P, P, F, I, P, P, P, P, P, P],
-    "ngp_field_bwd_guarded": [P, P, P, P, P, P, P, F, P, I, P, P, P, P, P, P, I, P],
+    "ngp_field_bwd_guarded": [P, P, P, P, P, P, P, F, P, F, I, P, P, P, P, P, P, I, P],
     "ngp_adam_use_loss_scaler": [P, I, F, F, I, F, F],
     "ngp_field_bwd_two_launches": [P, P, P, P, P, P, P, F, I, P, P, P, P, P, P],
     "ngp_field_bwd_uses_h": [],

@@ -541,6 +541,7 @@ struct MlpBwdIO {
     const float* dL_drgbs;   // OUT_RGB: (S,3) f32 unscaled
     float loss_scale;
     const float* loss_scale_dev;   // optional device-side factor on loss_scale (the native stepper's dynamic loss scale), read once per launch
+    float din_limit;               // an input gradient beyond this magnitude raises `nonfinite` (0: 65504, the f16 range)
     h1* dL_din;              // IN_ROWMAJOR: (S,N_IN); IN_LEVELMAJOR: [16][S] half2; IN_SH_H: dh (S,16); may be null
     float* wgrad_partial;    // (gridDim.x, G_SIZE) f32
     // Optional compaction: only the samples active[0 .. *n_active) are processed.  Network inputs
@@ -1045,7 +1046,7 @@ mlp_bwd_kernel(MlpBwdIO io, const h1* __restrict__ weights, int n_samples) {
     wgrad_reduce_layer<1, 2, BWD_WAVES, B::STAGED>(part, 16, HID, wave, i, hh, gWo, out + L::G_WO, nonfinite);
     // (NaN != 0: taken exactly when a sum was inf / NaN) ... or a feature gradient left the f16 range on its way to the table backward
     // (finite in the f32 accumulator, inf as the half the scatter reads: the dW sums, f32, do not see that one)
-    if (io.nonfinite != nullptr && (nonfinite != 0.f || din_max > 65504.f)) atomicOr(io.nonfinite, 1);
+    if (io.nonfinite != nullptr && (nonfinite != 0.f || din_max > (io.din_limit > 0.f ? io.din_limit : 65504.f))) atomicOr(io.nonfinite, 1);
     if (io.nonfinite_clear != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *io.nonfinite_clear = 0;
     MLP_T(5);                                          // epilogue
     MLP_TEND();
@@ -1072,6 +1073,7 @@ struct FieldBwdIO {
     const float* dL_drgbs;    // (S,3) f32 unscaled
     float loss_scale;
     const float* loss_scale_dev;   // optional device-side factor on loss_scale (the dynamic loss scale), read once per launch
+    float din_limit;               // a feature gradient beyond this magnitude raises `nonfinite` (0: 65504, the f16 range; a data-parallel rank: 65504 / world)
     h1* dfeats;               // [16][S] half2, by compact position
     float* wgrad_density;     // (gridDim.x, 3072)
     float* wgrad_rgb;         // (gridDim.x, 7168)
@@ -1354,7 +1356,7 @@ field_bwd_kernel(FieldBwdIO io, const h1* __restrict__ density_w, const h1* __re
     wgrad_reduce_layer<1, 2, FW, false>(part, 16, HID, wave, i, hh, gRo, outr + LR::G_WO, nonfinite);
     wgrad_reduce_layer<2, 1, FW, false>(part, HID, 32, wave, i, hh, gD0, outd, nonfinite);
     wgrad_reduce_layer<1, 2, FW, false>(part, 16, HID, wave, i, hh, gDo, outd + LD::G_WO, nonfinite);
-    if (io.nonfinite != nullptr && (nonfinite != 0.f || din_max > 65504.f)) atomicOr(io.nonfinite, 1);      // (as mlp_bwd_kernel)
+    if (io.nonfinite != nullptr && (nonfinite != 0.f || din_max > (io.din_limit > 0.f ? io.din_limit : 65504.f))) atomicOr(io.nonfinite, 1);      // (as mlp_bwd_kernel)
     if (io.nonfinite_clear != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *io.nonfinite_clear = 0;
     MLP_T(5);
     MLP_TEND();
@@ -1537,7 +1539,7 @@ static int ngp_rgb_bwd(const ngp_half* h, const float* dirs, const ngp_half* rgb
 }
 
 static int density_bwd_guarded(const ngp_half* feats, const ngp_half* density_w, const ngp_half* dL_dh, const float* dL_dsigmas,
-                               float loss_scale, const float* loss_scale_dev, int n_samples, const int32_t* active_idx, const int32_t* n_active,
+                               float loss_scale, const float* loss_scale_dev, float din_limit, int n_samples, const int32_t* active_idx, const int32_t* n_active,
                                ngp_half* dfeats, float* wgrad_partial, int32_t* nonfinite, ngp_stream_t stream) {
     if (n_samples < 0) return NGP_EINVAL;
     if (n_samples == 0) return 0;
@@ -1545,7 +1547,7 @@ static int density_bwd_guarded(const ngp_half* feats, const ngp_half* density_w,
     MlpBwdIO d = {};
     d.fwd.in = (const h1*)feats; d.fwd.n_out = 16; d.fwd.out_ld = 16;
     d.dL_dout16 = (const h1*)dL_dh; d.dout_ld = 16;
-    d.dL_dsigmas = dL_dsigmas; d.loss_scale = loss_scale; d.loss_scale_dev = loss_scale_dev; d.dL_din = (h1*)dfeats; d.wgrad_partial = wgrad_partial;
+    d.dL_dsigmas = dL_dsigmas; d.loss_scale = loss_scale; d.loss_scale_dev = loss_scale_dev; d.din_limit = din_limit; d.dL_din = (h1*)dfeats; d.wgrad_partial = wgrad_partial;
     if ((active_idx == nullptr) != (n_active == nullptr)) return NGP_EINVAL;
     d.active = active_idx; d.n_active = n_active;
     d.nonfinite = nonfinite;
@@ -1555,20 +1557,20 @@ static int density_bwd_guarded(const ngp_half* feats, const ngp_half* density_w,
 int ngp_density_bwd(const ngp_half* feats, const ngp_half* density_w, const ngp_half* dL_dh, const float* dL_dsigmas,
                     float loss_scale, int n_samples, const int32_t* active_idx, const int32_t* n_active,
                     ngp_half* dfeats, float* wgrad_partial, ngp_stream_t stream) {
-    return density_bwd_guarded(feats, density_w, dL_dh, dL_dsigmas, loss_scale, nullptr, n_samples, active_idx, n_active, dfeats, wgrad_partial, nullptr, stream);
+    return density_bwd_guarded(feats, density_w, dL_dh, dL_dsigmas, loss_scale, nullptr, 0.f, n_samples, active_idx, n_active, dfeats, wgrad_partial, nullptr, stream);
 }
 
 int ngp_field_bwd(const ngp_half* feats, const float* dirs, const ngp_half* h, const ngp_half* density_w,
                   const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale,
                   int n_samples, const int32_t* active_idx, const int32_t* n_active,
                   ngp_half* dh_scratch, ngp_half* dfeats, float* wgrad_partial, ngp_stream_t stream) {
-    return ngp_field_bwd_guarded(feats, dirs, h, density_w, rgb_w, dL_dsigmas, dL_drgbs, loss_scale, nullptr, n_samples, active_idx, n_active, dh_scratch, dfeats,
+    return ngp_field_bwd_guarded(feats, dirs, h, density_w, rgb_w, dL_dsigmas, dL_drgbs, loss_scale, nullptr, 0.f, n_samples, active_idx, n_active, dh_scratch, dfeats,
                                  wgrad_partial, nullptr, 0, stream);
 }
 
 // The two-launch form: colour net (writes dL/dh to dh_scratch) then density net (reads it).  nonfinite2 / parity as below.
 static int field_bwd_two_launches(const ngp_half* feats, const float* dirs, const ngp_half* h, const ngp_half* density_w,
-                                  const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale, const float* loss_scale_dev,
+                                  const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale, const float* loss_scale_dev, float din_limit,
                                   int n_samples, const int32_t* active_idx, const int32_t* n_active,
                                   ngp_half* dh_scratch, ngp_half* dfeats, float* wgrad_partial, int32_t* nonfinite2, int parity, ngp_stream_t stream) {
     const int n_part = bwd_grid(n_samples);
@@ -1576,13 +1578,13 @@ static int field_bwd_two_launches(const ngp_half* feats, const float* dirs, cons
     const int rc = ngp_rgb_bwd(h, dirs, rgb_w, dL_drgbs, loss_scale, loss_scale_dev, n_samples, active_idx, n_active, dh_scratch,
                                wgrad_partial + (size_t)n_part * NGP_DENSITY_NET_PARAMS, flag, nonfinite2 ? nonfinite2 + ((parity & 1) ^ 1) : nullptr, stream);
     if (rc) return rc;
-    return density_bwd_guarded(feats, density_w, dh_scratch, dL_dsigmas, loss_scale, loss_scale_dev, n_samples, active_idx, n_active, dfeats,
+    return density_bwd_guarded(feats, density_w, dh_scratch, dL_dsigmas, loss_scale, loss_scale_dev, din_limit, n_samples, active_idx, n_active, dfeats,
                                wgrad_partial, flag, stream);
 }
 
 // The one-launch form (field_bwd_kernel): h and dL/dh never touch memory.
 static int field_bwd_one_launch(const ngp_half* feats, const float* dirs, const ngp_half* density_w,
-                                const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale, const float* loss_scale_dev,
+                                const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale, const float* loss_scale_dev, float din_limit,
                                 int n_samples, const int32_t* active_idx, const int32_t* n_active,
                                 ngp_half* dfeats, float* wgrad_partial, int32_t* nonfinite2, int parity, ngp_stream_t stream) {
     NGP_CHECK_PTR(feats); NGP_CHECK_PTR(dirs); NGP_CHECK_PTR(density_w); NGP_CHECK_PTR(rgb_w); NGP_CHECK_PTR(dL_dsigmas);
@@ -1591,7 +1593,7 @@ static int field_bwd_one_launch(const ngp_half* feats, const float* dirs, const 
     if (reinterpret_cast<uintptr_t>(wgrad_partial) & 15) return NGP_EINVAL;     // partial rows are stored 16 bytes at a time
     const int n_part = bwd_grid(n_samples);
     FieldBwdIO io = {};
-    io.feats = (const h1*)feats; io.dirs = dirs; io.dL_dsigmas = dL_dsigmas; io.dL_drgbs = dL_drgbs; io.loss_scale = loss_scale; io.loss_scale_dev = loss_scale_dev;
+    io.feats = (const h1*)feats; io.dirs = dirs; io.dL_dsigmas = dL_dsigmas; io.dL_drgbs = dL_drgbs; io.loss_scale = loss_scale; io.loss_scale_dev = loss_scale_dev; io.din_limit = din_limit;
     io.dfeats = (h1*)dfeats; io.wgrad_density = wgrad_partial; io.wgrad_rgb = wgrad_partial + (size_t)n_part * NGP_DENSITY_NET_PARAMS;
     io.active = active_idx; io.n_active = n_active;
     io.nonfinite = nonfinite2 ? nonfinite2 + (parity & 1) : nullptr;
@@ -1607,18 +1609,19 @@ static int field_bwd_one_launch(const ngp_half* feats, const float* dirs, const 
 // (csrc/ngp_internal.h) the same with the native stepper's overflow guard: nonfinite2 = two device flags; this call ORs 1 into
 // nonfinite2[parity] when a weight-gradient sum of either network is inf / NaN -- or a feature gradient leaves the f16 range -- and
 // clears nonfinite2[parity ^ 1] (the next step's).  loss_scale_dev (may be NULL): a device-side factor on loss_scale, read by the
-// launch (the stepper's dynamic loss scale: GradScaler's scale on top of tiny-cuda-nn's 128).
+// launch (the stepper's dynamic loss scale: GradScaler's scale on top of tiny-cuda-nn's 128).  din_limit: the magnitude beyond which a
+// feature gradient raises the flag (0 = 65504; a data-parallel rank passes 65504 / world: the ranks' gradients are summed in f16).
 int ngp_field_bwd_guarded(const ngp_half* feats, const float* dirs, const ngp_half* h, const ngp_half* density_w,
-                          const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale, const float* loss_scale_dev,
+                          const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale, const float* loss_scale_dev, float din_limit,
                           int n_samples, const int32_t* active_idx, const int32_t* n_active,
                           ngp_half* dh_scratch, ngp_half* dfeats, float* wgrad_partial, int32_t* nonfinite2, int parity, ngp_stream_t stream) {
     if (n_samples < 0) return NGP_EINVAL;
     if (n_samples == 0) return 0;
     NGP_CHECK_PTR(wgrad_partial);
     if (NGP_FIELD_BWD_FUSED)
-        return field_bwd_one_launch(feats, dirs, density_w, rgb_w, dL_dsigmas, dL_drgbs, loss_scale, loss_scale_dev, n_samples, active_idx, n_active, dfeats,
+        return field_bwd_one_launch(feats, dirs, density_w, rgb_w, dL_dsigmas, dL_drgbs, loss_scale, loss_scale_dev, din_limit, n_samples, active_idx, n_active, dfeats,
                                     wgrad_partial, nonfinite2, parity, stream);
-    return field_bwd_two_launches(feats, dirs, h, density_w, rgb_w, dL_dsigmas, dL_drgbs, loss_scale, loss_scale_dev, n_samples, active_idx, n_active, dh_scratch,
+    return field_bwd_two_launches(feats, dirs, h, density_w, rgb_w, dL_dsigmas, dL_drgbs, loss_scale, loss_scale_dev, din_limit, n_samples, active_idx, n_active, dh_scratch,
                                   dfeats, wgrad_partial, nonfinite2, parity, stream);
 }
 
@@ -1635,7 +1638,7 @@ int ngp_field_bwd_two_launches(const ngp_half* feats, const float* dirs, const n
     if (n_samples < 0) return NGP_EINVAL;
     if (n_samples == 0) return 0;
     NGP_CHECK_PTR(wgrad_partial); NGP_CHECK_PTR(h); NGP_CHECK_PTR(dh_scratch);
-    return field_bwd_two_launches(feats, dirs, h, density_w, rgb_w, dL_dsigmas, dL_drgbs, loss_scale, nullptr, n_samples, active_idx, n_active, dh_scratch,
+    return field_bwd_two_launches(feats, dirs, h, density_w, rgb_w, dL_dsigmas, dL_drgbs, loss_scale, nullptr, 0.f, n_samples, active_idx, n_active, dh_scratch,
                                   dfeats, wgrad_partial, nullptr, 0, stream);
 }
 

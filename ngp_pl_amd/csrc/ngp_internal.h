@@ -33,10 +33,11 @@ typedef struct ngp_grid_partials {
  * overflow anywhere in the forward recompute or the backward chain ends there -- and clears nonfinite2[(parity & 1) ^ 1], the flag of
  * the next step: the optimizer launch of THIS step reads nonfinite2[parity & 1] as its found_inf.  A feature gradient that leaves the
  * f16 range raises the flag as well (finite in the f32 accumulator, inf in the half the table backward reads).  loss_scale_dev (may be
- * NULL): a factor on loss_scale read from device memory by the launch -- the stepper's dynamic loss scale. */
+ * NULL): a factor on loss_scale read from device memory by the launch -- the stepper's dynamic loss scale.  din_limit: the
+ * magnitude beyond which a feature gradient raises the flag (0: 65504; 65504 / world under a data-parallel exchange). */
 int ngp_field_bwd_guarded(const ngp_half* feats, const float* dirs, const ngp_half* h, const ngp_half* density_w,
                           const ngp_half* rgb_w, const float* dL_dsigmas, const float* dL_drgbs, float loss_scale,
-                          const float* loss_scale_dev, int n_samples, const int32_t* active_idx, const int32_t* n_active,
+                          const float* loss_scale_dev, float din_limit, int n_samples, const int32_t* active_idx, const int32_t* n_active,
                           ngp_half* dh_scratch, ngp_half* dfeats, float* wgrad_partial, int32_t* nonfinite2, int parity,
                           ngp_stream_t stream);
 /* Dynamic loss scale of the native step (round 6; GradScaler's rule on the device, see ngp_stepper_set_loss_scaler): hands the NEXT

@@ -489,7 +489,9 @@ static int backward_field(ngp_stepper* s, const float* dL_dopacity, const float*
     if (n_part < 1 || n_part > b.max_partials) return NGP_EINVAL;
     s->guard_parity ^= 1;
     STEP_TRY(ngp_field_bwd_guarded(b.feats, b.dirs, b.h, c.enc_half, c.rgb_half, b.dL_dsigmas, b.dL_drgbs, loss_scale,
-                                   s->scaler_on ? s->scaler_state + s->scaler_slot : nullptr, S, b.active, b.n_active,
+                                   s->scaler_on ? s->scaler_state + s->scaler_slot : nullptr,
+                                   s->comm ? 65504.0f / (float)s->comm->world : 0.f,      // (data parallel: the ranks' f16 gradients are summed)
+                                   S, b.active, b.n_active,
                                    b.dh, b.dfeats, b.partials, s->guard, s->guard_parity, main_stream));
     s->guard_armed = true;
     mark(s, 6, main);
@@ -747,6 +749,13 @@ static int exchange_chunk(ngp_stepper* s, int chunk, hipStream_t cs) {
     return ngp_comm_all_reduce(s->comm, g, C, NGP_COMM_F16, (ngp_stream_t)cs);
 }
 
+// Data parallel + dynamic loss scale: a rank whose own field backward raised the overflow flag makes every rank see it -- one inf into
+// the MLP sums it is about to all-reduce.  The reduced sums are what the skip decision and the scale's backoff are keyed on, so all
+// ranks skip and halve together (a flag each rank kept to itself would let their scales part).
+__global__ void poison_small_kernel(float* __restrict__ small, const int32_t* __restrict__ flag) {
+    if (*flag != 0) small[0] = __builtin_inff();
+}
+
 int ngp_stepper_tail(ngp_stepper* s, float lr, int32_t step, float grad_scale, ngp_stream_t main_stream) {
     if (!s || step < 1 || grad_scale == 0.f) return NGP_EINVAL;
     if (!s->comm) return NGP_EINVAL;                                  // no exchange installed: table_backward() + update()
@@ -763,6 +772,11 @@ int ngp_stepper_tail(ngp_stepper* s, float lr, int32_t step, float grad_scale, n
     // (1) the MLP blocks: per-workgroup partial rows -> sums, all-reduced underneath the table backward
     if (S > 0 && s->n_part > 0) {
         STEP_TRY(ngp_reduce_partials2(b.partials, c.n_density, b.partials + (size_t)s->n_part * c.n_density, c.n_rgb, s->n_part, x.small, main_stream));
+        if (s->scaler_on && s->guard_armed) {
+            hipLaunchKernelGGL(poison_small_kernel, dim3(1), dim3(1), 0, main, x.small, s->guard + s->guard_parity);
+            STEP_TRY(NGP_LAUNCH_RESULT());
+        }
+        s->guard_armed = false;
     } else {
         // this rank's batch had no samples: it joins every collective with zeros (DDP semantics: every rank joins every all-reduce)
         STEP_HIP(hipMemsetAsync(x.small, 0, sizeof(float) * (size_t)(c.n_density + c.n_rgb), main));

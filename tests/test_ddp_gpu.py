@@ -315,6 +315,74 @@ def _native_worker(port, q):
         raise
 
 
+def _scaler_worker(port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        import numpy as np
+        from ngp_pl_amd import synthetic as syn
+        from ngp_pl_amd.ddp import NativeExchange
+        from ngp_pl_amd.networks import NGP
+        from ngp_pl_amd.trainer import Trainer
+
+        def batch(n, seed):
+            g = np.random.RandomState(seed)
+            W = 200
+            dirs = syn.get_ray_directions(W, W, syn.intrinsics(W))
+            poses = syn.hemisphere_poses(16, seed=1)
+            ro, rd = syn.get_rays(dirs[torch.from_numpy(g.randint(0, W * W, n))], poses[torch.from_numpy(g.randint(0, 16, n))])
+            ro, rd = ro.cuda().contiguous(), rd.cuda().contiguous()
+            gt, _ = syn.render_ground_truth(ro, rd, n_steps=96)
+            return ro, rd, gt.contiguous()
+        batches = [batch(2048, seed=4000 + s) for s in range(24)]
+
+        def run(exchange):
+            torch.manual_seed(9)
+            m = NGP(scale=0.5).cuda()
+            m.register_training_buffers()
+            tr = Trainer(m, loss_scaler=dict(init_scale=2.0 ** 40, growth_interval=3))
+            ex = None
+            if exchange:
+                ex = NativeExchange(m, dist, 1, 0, mode=exchange)
+                ex.install(tr); ex.broadcast_parameters()
+            seq = []
+            for s in range(24):
+                tr.step(*batches[s])
+                seq.append((tr.loss_scale_state(), tr.opt.applied_steps()[0]))
+            finite = bool(torch.isfinite(m.xyz_encoder.params).all()) and bool(torch.isfinite(m.rgb_net.params).all())
+            if ex is not None:
+                ex.uninstall(tr); ex.close()
+            return seq, finite
+        plain = run(None)
+        notes, ok = [], plain[1] and plain[0][0][0][0] < 2.0 ** 40
+        for mode in ("sharded", "allreduce", "direct"):
+            seq, finite = run(mode)
+            same = seq == plain[0]
+            ok &= same and finite
+            notes.append("%s: scale / skip sequence equal to the plain native step %s, finite %s, final %s" % (mode, same, finite, seq[-1]))
+        q.put((bool(ok), notes))
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((False, [traceback.format_exc()[-3000:]]))
+        raise
+
+
+def test_loss_scaler_under_the_native_exchange_follows_the_same_skip_sequence():
+    """From a scale that must overflow (2^40), the library's exchange (every mode, 1 rank) and the plain native step walk the SAME
+    sequence of skips, halvings and doublings: under the exchange the decision is keyed on the reduced MLP sums, into which a rank whose
+    own field backward raised the overflow flag writes one inf -- so every rank would see it."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_scaler_worker, args=(port, q))
+    p.start()
+    ok, notes = q.get(timeout=600)
+    p.join(120)
+    assert ok, notes
+
+
 def test_native_exchange_equals_the_torch_distributed_exchange_on_one_rank():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
