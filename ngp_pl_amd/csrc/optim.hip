@@ -102,7 +102,11 @@ __device__ __forceinline__ void adam_dense(float* __restrict__ param, h1* __rest
                 if (hp.zero_grad) *gp4 = make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
                 half4_t* gp4 = reinterpret_cast<half4_t*>(reinterpret_cast<h1*>(grad) + base);
-                const half4_t t = *gp4; g[0] = (float)t[0]; g[1] = (float)t[1]; g[2] = (float)t[2]; g[3] = (float)t[3];
+                const half4_t t = *gp4;
+                // (an f16 gradient is finite unless a path that sums in f16 overflowed -- the one-pass fallback of oversized batches, a
+                // reduce-scatter of the ranks' tables: +-65504 instead of inf / NaN keeps the moments finite; free on this stream)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[k] = fminf(fmaxf((float)t[k], -65504.0f), 65504.0f);
                 if (hp.zero_grad) { const half4_t z = {0, 0, 0, 0}; *gp4 = z; }
             }
             if (skip) continue;
@@ -125,7 +129,7 @@ __device__ __forceinline__ void adam_dense(float* __restrict__ param, h1* __rest
                 const long long i = base + k;
                 float gk;
                 if (GRAD_F32) { float* gp = reinterpret_cast<float*>(grad) + i; gk = *gp; if (hp.zero_grad) *gp = 0.f; }
-                else { h1* gp = reinterpret_cast<h1*>(grad) + i; gk = (float)*gp; if (hp.zero_grad) *gp = (h1)0; }
+                else { h1* gp = reinterpret_cast<h1*>(grad) + i; gk = fminf(fmaxf((float)*gp, -65504.0f), 65504.0f); if (hp.zero_grad) *gp = (h1)0; }
                 if (skip) continue;
                 float pk = param[i], mk = m[i], vk = v[i];
                 adam_one(pk, mk, vk, gk, coef);
