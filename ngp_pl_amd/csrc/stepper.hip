@@ -752,8 +752,11 @@ static int exchange_chunk(ngp_stepper* s, int chunk, hipStream_t cs) {
 // Data parallel + dynamic loss scale: a rank whose own field backward raised the overflow flag makes every rank see it -- one inf into
 // the MLP sums it is about to all-reduce.  The reduced sums are what the skip decision and the scale's backoff are keyed on, so all
 // ranks skip and halve together (a flag each rank kept to itself would let their scales part).
-__global__ void poison_small_kernel(float* __restrict__ small, const int32_t* __restrict__ flag) {
-    if (*flag != 0) small[0] = __builtin_inff();
+// The second flag is LAST step's verdict on this rank's share of the reduced table gradient (sharded / direct modes: the f16 sum of the
+// ranks' tables can overflow although no rank's own entries did; only the share's owner sees it, one step late for everybody else):
+// its owner skipped that block then, everyone skips and backs off now.
+__global__ void poison_small_kernel(float* __restrict__ small, const int32_t* __restrict__ flag, const int32_t* __restrict__ last_shard_flag) {
+    if ((flag != nullptr && *flag != 0) || (last_shard_flag != nullptr && *last_shard_flag != 0)) small[0] = __builtin_inff();
 }
 
 int ngp_stepper_tail(ngp_stepper* s, float lr, int32_t step, float grad_scale, ngp_stream_t main_stream) {
@@ -772,8 +775,10 @@ int ngp_stepper_tail(ngp_stepper* s, float lr, int32_t step, float grad_scale, n
     // (1) the MLP blocks: per-workgroup partial rows -> sums, all-reduced underneath the table backward
     if (S > 0 && s->n_part > 0) {
         STEP_TRY(ngp_reduce_partials2(b.partials, c.n_density, b.partials + (size_t)s->n_part * c.n_density, c.n_rgb, s->n_part, x.small, main_stream));
-        if (s->scaler_on && s->guard_armed) {
-            hipLaunchKernelGGL(poison_small_kernel, dim3(1), dim3(1), 0, main, x.small, s->guard + s->guard_parity);
+        if (s->scaler_on) {
+            // (flag sets alternate per tail: set (tails & 1) is this step's, the other still holds the previous step's until this step's check clears it)
+            const int32_t* last_shard = (x.mode >= 1 && s->tails > 0) ? x.flags + 8 * (1 - (int)(s->tails & 1)) + 4 : nullptr;
+            hipLaunchKernelGGL(poison_small_kernel, dim3(1), dim3(1), 0, main, x.small, s->guard_armed ? s->guard + s->guard_parity : nullptr, last_shard);
             STEP_TRY(NGP_LAUNCH_RESULT());
         }
         s->guard_armed = false;
