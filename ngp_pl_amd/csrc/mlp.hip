@@ -1600,8 +1600,15 @@ static int field_bwd_one_launch(const ngp_half* feats, const float* dirs, const 
     io.nonfinite_clear = nonfinite2 ? nonfinite2 + ((parity & 1) ^ 1) : nullptr;
     constexpr int smem = FieldBwdLds::BYTES;
     static_assert(smem <= 160 * 1024, "LDS budget");
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(field_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return (int)e;
+    static bool attr_set[64] = {};              // per device: the attribute belongs to the device's code object
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(field_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set[dev] = true;
+    }
     field_bwd_kernel<<<dim3(n_part), dim3(64 * FieldBwdLds::FWAVES), smem, ngp_stream(stream)>>>(io, (const h1*)density_w, (const h1*)rgb_w, n_samples);
     return NGP_LAUNCH_RESULT();
 }
