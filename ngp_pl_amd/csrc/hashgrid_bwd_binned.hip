@@ -64,6 +64,9 @@ constexpr int MAX_CHUNKS = 4608;             // 4.7 M samples: the first steps o
 #ifndef NGP_APPLY_WRITEOUT_BATCHED
 #define NGP_APPLY_WRITEOUT_BATCHED 0          // accumulators per thread read together at write-out; 0: one at a time (round 2; A/B builds)
 #endif
+#ifndef NGP_DIR_BY_WAVE0
+#define NGP_DIR_BY_WAVE0 1                    // 0: every thread fetches its part of the next directory row under the write-out (rounds 4-6; A/B builds)
+#endif
 #ifndef NGP_DENSE_B
 #define NGP_DENSE_B 2                         // dense levels: entries per lane in flight (round 6, same box: 2 -> 122.8 us alone, 4 -> 125.6, 8 -> 128.7)
 #endif
@@ -497,11 +500,33 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
         }
         else if (NGP_DENSE_RUNS) apply_segments_dense_runs<NGP_DENSE_B>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
         else apply_segments_dense<4>(lds, lo, len, res, size, meta.scale[level], x, box, g_level, active, pool_level, s_dir, n_chunks, part, K);
+#if NGP_DIR_BY_WAVE0
+        // The next task's directory row is fetched by WAVE 0 alone, as soon as its own rows are done and before the barrier: the global
+        // round trip hides in the other waves' remaining rows (the waves of a task finish microseconds apart) instead of sitting in the
+        // write-out, where all sixteen waited for it (round 6: 3 us of a 20 us task).  The row goes straight into the idle half of s_dir2.
+        if (tid < 64) {
+            const int nt0 = __shfl(next_task, 0, 64);                  // (thread 0 holds the id the queue returned)
+            if (tid == 0) s_task[(it + 1) & 1] = nt0;
+            if (nt0 < task_end) {
+                const int32_t* __restrict__ dn = dir_row(nt0);
+                int* __restrict__ dst = s_dir2[(it + 1) & 1];
+                for (int c0 = 0; c0 < n_chunks; c0 += 64 * 8) {         // eight loads in flight per lane
+                    int v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { const int c = c0 + q * 64 + tid; v[q] = c < n_chunks ? dn[c] : 0; }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { const int c = c0 + q * 64 + tid; if (c < n_chunks) dst[c] = v[q]; }
+                }
+            }
+        }
+#else
         if (tid == 0) s_task[(it + 1) & 1] = next_task;
+#endif
         lds_barrier();                                                 // accumulators complete, next id visible
 #ifdef NGP_BIN_TIMING
         if (tid == 0) ws.timing[4 * task + 2] = (long long)wall_clock64();
 #endif
+#if !NGP_DIR_BY_WAVE0
         const int nt = s_task[(it + 1) & 1];
         int pre[PRE];
         if (nt < task_end) {                                           // (uniform) the next task's directory row, in flight under the write-out
@@ -509,6 +534,7 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
 #pragma unroll
             for (int q = 0; q < PRE; ++q) { const int c = tid + q * APPLY_THREADS; pre[q] = c < n_chunks ? dn[c] : 0; }
         }
+#endif
         half2_t* __restrict__ out = grad_table + meta.offset[level] + lo;
         const float inv = 1.0f / FIX_SCALE;
 #if NGP_APPLY_WRITEOUT_BATCHED
@@ -551,10 +577,12 @@ apply_kernel(const float* __restrict__ x, const float* __restrict__ xyz_min, con
             else ws.partial[plan.part_off[level] + (size_t)part * size + lo + k] = make_float2(a0, a1);
         }
 #endif
+#if !NGP_DIR_BY_WAVE0
         if (nt < task_end) {
 #pragma unroll
             for (int q = 0; q < PRE; ++q) { const int c = tid + q * APPLY_THREADS; if (c < n_chunks) s_dir2[(it + 1) & 1][c] = pre[q]; }
         }
+#endif
         lds_barrier();                                                 // accumulators clear, the next task's directory row in place (the write-out's stores still in flight)
 #ifdef NGP_BIN_TIMING
         if (tid == 0) ws.timing[4 * task + 3] = (long long)wall_clock64();
