@@ -651,3 +651,45 @@ def test_one_launch_field_backward_equals_the_two_launch_chain(lib, field, n, n_
         assert float(df1.float().abs().sum()) > 0
     else:
         assert not pd1.any() and not pr1.any() and not df1.any()
+
+
+def test_binned_backward_keeps_gradients_near_the_top_of_the_f16_range(lib, field):
+    """Under the dynamic loss scale the feature gradients sit near the top of the f16 range, not at ~1e-5 as under the fixed 128.  The
+    slice owners' fixed-point conversion went through v_cvt_i32_f32 until round 6, which saturates at |w x g| = 128: every larger
+    contribution was silently clipped.  Gradients of magnitude 200 .. 30 000 against the fp32 autograd of the oracle: exact sums,
+    one f16 rounding at the end (saturated at +-65504 where a sum leaves the range, never inf)."""
+    meta = native_meta(lib)
+    n = 6000
+    x, _ = sample_points(n, seed=71)
+    g = torch.Generator().manual_seed(72)
+    mag = torch.exp(torch.rand(n, 32, generator=g) * (math.log(30000.0) - math.log(200.0)) + math.log(200.0))
+    dfe = (mag * torch.where(torch.rand(n, 32, generator=g) < 0.5, -1.0, 1.0)).half()
+    table = field.table.clone().requires_grad_(True)
+    T.hash_encode(x + 0.5, table, field.meta).backward(dfe.float())
+    want = table.grad
+    table_abs = field.table.clone().requires_grad_(True)
+    T.hash_encode(x + 0.5, table_abs, field.meta).backward(dfe.float().abs())
+    mass = table_abs.grad                              # sum of |contribution| per entry: what the ORACLE's f32 summation error scales with
+    xs = x.cuda().contiguous()
+    dfl = dfe.view(n, 16, 2).permute(1, 0, 2).contiguous().cuda()
+    mnt = torch.full((3,), -0.5, device="cuda"); mxt = torch.full((3,), 0.5, device="cuda")
+    grad = torch.full((field.meta.total, 2), float("nan"), dtype=torch.float16, device="cuda")
+    nbytes = lib.lib().ngp_hashgrid_bwd_binned_workspace_bytes(C.byref(meta), n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    lib.call("ngp_hashgrid_bwd_binned", lib.ptr(xs), lib.ptr(mnt), lib.ptr(mxt), lib.ptr(dfl), C.byref(meta), n, None, None,
+             lib.ptr(ws), nbytes, lib.ptr(grad), lib.stream())
+    got = grad.float().cpu()
+    assert torch.isfinite(got).all()
+    want_sat = want.clamp(-65504.0, 65504.0)
+    err = (got - want_sat).abs()
+    assert float(want.abs().max()) > 20000.0 and float((want.abs() > 128.0).float().mean()) > 0.001      # the case is in the data
+    # exact sums + ONE f16 rounding (2^-11 of the value) on this side; f32 summation noise (1e-6 of the entry's mass) on the oracle's
+    # ... and 3.6 absolute: a sample's fractional cell position differs by up to ~1.2e-4 between the two fp32 evaluations at the fine
+    # levels ((x - min) * (1 / extent) * scale with scale ~2000: a few ulps of 2000), so do its corner weights, times gradients of up
+    # to 30 000.  (What rounds 1-5 would have produced is 70 .. 30 000 away: asserted below.)
+    bound = 6e-4 * want_sat.abs() + 2e-6 * mass + 3.6
+    worst = int((err / bound).flatten().argmax())
+    assert bool((err <= bound).all()), (float((err / bound).max()), float(err.max()), worst // 2, float(got.flatten()[worst]), float(want.flatten()[worst]),
+                                        float(mass.flatten()[worst]), [int(o) for o in field.meta.offset[:17]])
+    clipped = want.clamp(-128.0, 128.0)                # what rounds 1-5 would have produced for single large contributions: far outside the bound
+    assert float(((clipped - want_sat).abs() > bound).float().mean()) > 0.001
